@@ -1,0 +1,196 @@
+/*
+ * semtools_hip.h -- C ABI of libsemtools_hip.so, the MI355X (gfx950) core for
+ * the `semtools search` / `semtools workspace` hot path:
+ *
+ *     embed (token-id gather + mean-pool + L2-normalise)
+ *       -> cosine scan of query vector(s) over the row-major f32 corpus
+ *       -> top-k / max-distance selection
+ *
+ * The reference (run-llama/semtools v3.0.0, /root/reference) has NO FFI seam
+ * for this path: the arithmetic sits behind three Rust crates (model2vec-rs,
+ * simsimd, qdrant-edge) called from ordinary Rust functions.  Each entry point
+ * below names the reference interface (file:line, relative to /root/reference)
+ * it replaces; INTEGRATION.md shows the Rust `extern "C"` stub a maintainer
+ * would add at those call sites.
+ *
+ * Conventions
+ *   - Plain C: opaque handles, raw pointers, sizes.  No torch/C++ types.
+ *   - Every function returning `int` returns SMT_OK (0) or a negative SMT_E_*;
+ *     smt_last_error() returns a thread-local message for the last failure.
+ *     Nothing unwinds or aborts across the ABI.
+ *   - Host buffers are owned by the caller; device memory lives behind handles.
+ *   - Handles are not thread-safe: serialise calls per handle (the reference
+ *     calls this path synchronously from one task, src/bin/semtools.rs:134).
+ *   - One smt_ctx == one GPU + one HIP stream == one process rank.  Multi-GPU is
+ *     one process per GPU; ranks exchange per-shard top-k lists with an RCCL
+ *     all-gather (smt_search_topk_device -> all_gather -> smt_merge_topk*).
+ *   - "_device" entry points take/return DEVICE pointers and enqueue on the
+ *     context's stream without synchronising (bench / multi-GPU pipelines).
+ *   - There is no CPU fallback: every compute entry point fails with
+ *     SMT_E_HIP when no gfx950 device is usable.
+ */
+#ifndef SEMTOOLS_HIP_H
+#define SEMTOOLS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMT_OK 0
+#define SMT_E_INVALID (-1)     /* bad argument                                   */
+#define SMT_E_HIP (-2)         /* HIP runtime / device error, or no GPU          */
+#define SMT_E_NOMEM (-3)       /* host or device allocation failed / capacity    */
+#define SMT_E_TRUNCATED (-4)   /* more hits than out_cap; counts hold true sizes */
+#define SMT_E_IO (-5)          /* file error in save/load                        */
+#define SMT_E_UNSUPPORTED (-6) /* e.g. embedding dim other than 256              */
+
+#define SMT_DIM 256u /* LINE_EMBEDDING_SIZE, src/workspace/store.rs:37 */
+
+/* selection semantics of smt_search */
+#define SMT_MODE_DOCUMENTS 0 /* search_documents, src/search/mod.rs:77-120            */
+#define SMT_MODE_WORKSPACE 1 /* Store::search_line_embeddings, store.rs:481-546        */
+
+typedef struct smt_ctx smt_ctx;
+typedef struct smt_model smt_model;
+typedef struct smt_corpus smt_corpus;
+
+/* half-open range of corpus rows [begin, end) */
+typedef struct smt_range {
+    uint64_t begin;
+    uint64_t end;
+} smt_range;
+
+/* ------------------------------------------------------------------ context */
+
+/* Bind to GPU `device`.  `stream` is an existing hipStream_t to enqueue on
+ * (e.g. the host framework's current stream) or NULL to create a private one. */
+int smt_ctx_create(int device, void *stream, smt_ctx **out);
+void smt_ctx_destroy(smt_ctx *ctx);
+int smt_ctx_synchronize(smt_ctx *ctx);
+const char *smt_last_error(void);
+const char *smt_version(void);
+/* number of visible HIP devices, or SMT_E_HIP */
+int smt_device_count(void);
+
+/* Per-kernel timing with HIP events recorded on the context's stream around
+ * each launch of the named kernel family ("scan", "gemm", "embed", "select").
+ * Reading synchronises the stream. */
+int smt_prof_enable(smt_ctx *ctx, int on);
+int smt_prof_reset(smt_ctx *ctx);
+int smt_prof_read(smt_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
+
+/* -------------------------------------------------------------------- model
+ * Replaces the device half of StaticModel::from_pretrained (call sites
+ * src/cmds/search.rs:123-128, src/cmds/ask.rs:128-133): the f32 `embeddings`
+ * table [V x D] is uploaded once and stays resident.  `normalize` is the
+ * model's config flag (true for potion-multilingual-128M). */
+int smt_model_create(smt_ctx *ctx, const float *table_host, uint64_t V, uint32_t D,
+                     int normalize, smt_model **out);
+/* adopt a table already in device memory (not copied, not freed) */
+int smt_model_create_from_device(smt_ctx *ctx, const float *table_dev, uint64_t V, uint32_t D,
+                                 int normalize, smt_model **out);
+void smt_model_destroy(smt_model *model);
+
+/* Replaces the pool step of StaticModel::encode_with_args / encode_single
+ * (call sites src/search/mod.rs:69,138,153; src/cmds/search.rs:136,154).
+ * Tokenisation stays on the host: `ids` are the unk-filtered token ids of all
+ * lines back to back, `offsets[n_lines+1]` the CSR boundaries.  Each line is
+ * truncated to `max_tokens` ids (2048 for lines, 512 for queries; 0 = no cap),
+ * rows are summed in token order in f32, divided by the count, and (if the
+ * model normalises) divided by max(||v||, 1e-12).  An empty line gives the
+ * zero vector.  Output goes to `out_host` [n_lines x D] and/or is appended to
+ * `append_to` (first new row index in *first_row). Either may be NULL. */
+int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines,
+              uint32_t max_tokens, float *out_host, smt_corpus *append_to, uint64_t *first_row);
+/* everything resident: ids/offsets/out are device pointers; async on the stream */
+int smt_embed_device(smt_model *model, const uint32_t *ids_dev, const uint64_t *offsets_dev,
+                     uint64_t n_lines, uint32_t max_tokens, float *out_dev);
+
+/* ------------------------------------------------------------------- corpus
+ * Replaces `Document::embeddings: Vec<Vec<f32>>` (src/search/mod.rs:18-22)
+ * and the vector half of the workspace store (line_embeddings.qdrant,
+ * src/workspace/store.rs:152-166, upsert :402-434): one row-major f32 matrix
+ * [rows x D] resident in HBM; row index == insertion order. */
+int smt_corpus_create(smt_ctx *ctx, uint32_t D, uint64_t capacity_rows, smt_corpus **out);
+/* adopt rows already in device memory (not copied, not freed, not growable) */
+int smt_corpus_from_device(smt_ctx *ctx, const float *rows_dev, uint64_t n_rows, uint32_t D,
+                           smt_corpus **out);
+void smt_corpus_destroy(smt_corpus *corpus);
+int smt_corpus_append_host(smt_corpus *corpus, const float *rows, uint64_t n_rows,
+                           uint64_t *first_row);
+/* overwrite existing rows [first_row, first_row+n_rows) (upsert of a changed doc) */
+int smt_corpus_write_rows(smt_corpus *corpus, uint64_t first_row, const float *rows,
+                          uint64_t n_rows);
+int smt_corpus_read_rows(smt_corpus *corpus, uint64_t first_row, uint64_t n_rows, float *out_host);
+int smt_corpus_truncate(smt_corpus *corpus, uint64_t n_rows);
+uint64_t smt_corpus_rows(const smt_corpus *corpus);
+uint32_t smt_corpus_dim(const smt_corpus *corpus);
+/* flat little-endian file: 32-byte header + rows*D f32 */
+int smt_corpus_save(smt_corpus *corpus, const char *path);
+int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out);
+
+/* ------------------------------------------------------------------- search
+ * Replaces f32::cosine + the selection in search_documents
+ * (src/search/mod.rs:84-119) and Store::search_line_embeddings
+ * (src/workspace/store.rs:481-546).
+ *
+ *   queries     host, [nq x D] f32
+ *   max_distance NaN = "None".
+ *   mode SMT_MODE_DOCUMENTS: max_distance None -> the top_k rows by
+ *        (distance asc, row asc) [= the reference's stable sort + take(top_k)];
+ *        max_distance given -> ALL rows with distance < max_distance (strict),
+ *        same order, top_k ignored.
+ *   mode SMT_MODE_WORKSPACE: rows with score > 1 - max_distance (f32, if given),
+ *        then ALWAYS the top_k of them; top_k == 0 -> nothing.
+ *   ranges      optional filter: only rows inside these sorted, disjoint
+ *        ranges are scanned (workspace path subset; a document's lines are
+ *        contiguous rows).  NULL/0 = whole corpus.
+ *   row_base    added to every returned row (global index of this shard's row 0).
+ *   out_rows/out_dist  [nq x out_cap]; out_counts[nq] = hits for each query
+ *        (the TRUE count even when > out_cap, in which case the call returns
+ *        SMT_E_TRUNCATED after filling the first out_cap of each).
+ *
+ * Distances are f64: the f32 scan only nominates candidates; every returned
+ * distance is recomputed on the GPU with f64 accumulation in index order --
+ * simsimd's "accurate" formula -- so results do not depend on reduction order.
+ */
+int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k,
+               double max_distance, int mode, const smt_range *ranges, uint32_t n_ranges,
+               uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts,
+               uint64_t out_cap);
+
+/* Resident top-k (mode DOCUMENTS, no threshold, no ranges): queries_dev
+ * [nq x D] and outputs [nq x top_k] are device pointers; unused slots are
+ * (row = UINT64_MAX, dist = +inf).  Enqueues on the stream, no sync. */
+int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq,
+                           uint32_t top_k, uint64_t row_base, uint64_t *out_rows_dev,
+                           double *out_dist_dev);
+
+/* Merge `n_lists` sorted (dist asc, row asc) lists of length k_in each (padded
+ * with UINT64_MAX/+inf) per query into the best k_out.  Inputs are laid out
+ * [n_lists][nq][k_in] -- exactly what an all-gather of per-rank
+ * smt_search_topk_device outputs produces.  Host version: */
+int smt_merge_topk(const uint64_t *rows, const double *dist, uint32_t n_lists, uint32_t nq,
+                   uint32_t k_in, uint32_t k_out, uint64_t *out_rows, double *out_dist,
+                   uint64_t *out_counts);
+/* device version (all pointers device, async on the stream) */
+int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *dist_dev,
+                          uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
+                          uint64_t *out_rows_dev, double *out_dist_dev);
+
+/* Tuning knobs (0 = library default); for benchmarking sweeps. */
+int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value);
+
+/* ------------------------------------------------------------------ host ids
+ * FNV-1a 64 and the point ids of the workspace store
+ * (src/workspace/store.rs:651-661, :82-89, :75-80) -- pure host helpers. */
+uint64_t smt_fnv1a_hash(const uint8_t *bytes, uint64_t n);
+uint64_t smt_line_embedding_id(const char *path, int32_t line_number);
+uint64_t smt_doc_meta_id(const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMTOOLS_HIP_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libsemtools_hip.so (the C ABI in include/semtools_hip.h).
+
+The library is the product; this module only marshals numpy arrays / raw device
+pointers across the ABI.  There is NO CPU fallback: if the shared object is
+missing or no gfx950 GPU is usable, calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsemtools_hip.so")
+
+SMT_OK, SMT_E_INVALID, SMT_E_HIP, SMT_E_NOMEM, SMT_E_TRUNCATED, SMT_E_IO, SMT_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+MODE_DOCUMENTS, MODE_WORKSPACE = 0, 1
+DIM = 256
+
+EXPORTS = [
+    "smt_ctx_create", "smt_ctx_destroy", "smt_ctx_synchronize", "smt_last_error", "smt_version",
+    "smt_device_count", "smt_prof_enable", "smt_prof_reset", "smt_prof_read",
+    "smt_model_create", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
+    "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
+    "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
+    "smt_corpus_save", "smt_corpus_load", "smt_search", "smt_search_topk_device", "smt_merge_topk",
+    "smt_merge_topk_device", "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
+]
+
+
+class SmtRange(C.Structure):
+    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64)]
+
+
+class SmtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsemtools_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    if force:
+        for f in os.listdir(os.path.join(_HERE, "lib")) if os.path.isdir(os.path.join(_HERE, "lib")) else []:
+            if f.endswith(".o") or f.endswith(".so"):
+                os.remove(os.path.join(_HERE, "lib", f))
+    subprocess.check_call(["bash", script])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libsemtools_hip.so.  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmtError(SMT_E_HIP, f"{LIB_PATH} not built; run semtools_amd/csrc/build.sh (no CPU fallback exists)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    P = C.POINTER
+    L.smt_last_error.restype = C.c_char_p
+    L.smt_version.restype = C.c_char_p
+    L.smt_device_count.restype = i32
+    L.smt_ctx_create.argtypes = [i32, vp, P(vp)]
+    L.smt_ctx_destroy.argtypes = [vp]
+    L.smt_ctx_destroy.restype = None
+    L.smt_ctx_synchronize.argtypes = [vp]
+    L.smt_prof_enable.argtypes = [vp, i32]
+    L.smt_prof_reset.argtypes = [vp]
+    L.smt_prof_read.argtypes = [vp, C.c_char_p, P(u64), P(f64)]
+    L.smt_model_create.argtypes = [vp, vp, u64, u32, i32, P(vp)]
+    L.smt_model_create_from_device.argtypes = [vp, vp, u64, u32, i32, P(vp)]
+    L.smt_model_destroy.argtypes = [vp]
+    L.smt_model_destroy.restype = None
+    L.smt_embed.argtypes = [vp, vp, vp, u64, u32, vp, vp, P(u64)]
+    L.smt_embed_device.argtypes = [vp, vp, vp, u64, u32, vp]
+    L.smt_corpus_create.argtypes = [vp, u32, u64, P(vp)]
+    L.smt_corpus_from_device.argtypes = [vp, vp, u64, u32, P(vp)]
+    L.smt_corpus_destroy.argtypes = [vp]
+    L.smt_corpus_destroy.restype = None
+    L.smt_corpus_append_host.argtypes = [vp, vp, u64, P(u64)]
+    L.smt_corpus_write_rows.argtypes = [vp, u64, vp, u64]
+    L.smt_corpus_read_rows.argtypes = [vp, u64, u64, vp]
+    L.smt_corpus_truncate.argtypes = [vp, u64]
+    L.smt_corpus_rows.argtypes = [vp]
+    L.smt_corpus_rows.restype = u64
+    L.smt_corpus_dim.argtypes = [vp]
+    L.smt_corpus_dim.restype = u32
+    L.smt_corpus_save.argtypes = [vp, C.c_char_p]
+    L.smt_corpus_load.argtypes = [vp, C.c_char_p, P(vp)]
+    L.smt_search.argtypes = [vp, vp, u32, u32, f64, i32, vp, u32, u64, vp, vp, vp, u64]
+    L.smt_search_topk_device.argtypes = [vp, vp, u32, u32, u64, vp, vp]
+    L.smt_merge_topk.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.smt_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp]
+    L.smt_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.smt_fnv1a_hash.argtypes = [C.c_char_p, u64]
+    L.smt_fnv1a_hash.restype = u64
+    L.smt_line_embedding_id.argtypes = [C.c_char_p, C.c_int32]
+    L.smt_line_embedding_id.restype = u64
+    L.smt_doc_meta_id.argtypes = [C.c_char_p]
+    L.smt_doc_meta_id.restype = u64
+    _lib = L
+    return L
+
+
+def check(rc, allow=()):
+    if rc != SMT_OK and rc not in allow:
+        raise SmtError(rc, lib().smt_last_error().decode(errors="replace"))
+    return rc
+
+
+def np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None

@@ -1,0 +1,207 @@
+"""Object wrappers over the C ABI handles (context / model / corpus)."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """One GPU + one HIP stream (smt_ctx).  `stream` = raw hipStream_t int or None."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        L.check(L.lib().smt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        L.check(L.lib().smt_ctx_synchronize(self._h))
+
+    def set_tuning(self, key, value):
+        L.check(L.lib().smt_set_tuning(self._h, key.encode(), int(value)))
+
+    def prof_enable(self, on=True):
+        L.check(L.lib().smt_prof_enable(self._h, int(bool(on))))
+
+    def prof_reset(self):
+        L.check(L.lib().smt_prof_reset(self._h))
+
+    def prof_read(self, kernel):
+        n, ms = C.c_uint64(), C.c_double()
+        L.check(L.lib().smt_prof_read(self._h, kernel.encode(), C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def merge_topk_device(self, rows_ptr, dist_ptr, n_lists, nq, k_in, k_out, out_rows_ptr, out_dist_ptr):
+        L.check(L.lib().smt_merge_topk_device(self._h, C.c_void_p(rows_ptr), C.c_void_p(dist_ptr), n_lists, nq,
+                                              k_in, k_out, C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
+
+
+class Model:
+    """Device-resident model2vec table (smt_model)."""
+
+    def __init__(self, ctx, table=None, normalize=True, device_ptr=None, V=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if device_ptr is not None:
+            L.check(L.lib().smt_model_create_from_device(ctx._h, C.c_void_p(device_ptr), int(V), L.DIM,
+                                                         int(normalize), C.byref(self._h)))
+            self.V = int(V)
+        else:
+            table = _f32c(table)
+            assert table.ndim == 2
+            L.check(L.lib().smt_model_create(ctx._h, L.np_ptr(table), table.shape[0], table.shape[1],
+                                             int(normalize), C.byref(self._h)))
+            self.V = table.shape[0]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def embed(self, ids, offsets, max_tokens=2048, append_to=None, want_host=True):
+        """encode_with_args' pool step for a CSR batch of token ids.  Returns
+        ([n_lines x 256] f32 or None, first_row or None)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = max(offsets.size - 1, 0)
+        out = np.empty((n, L.DIM), dtype=np.float32) if want_host else None
+        first = C.c_uint64(0)
+        L.check(L.lib().smt_embed(self._h, L.np_ptr(ids), L.np_ptr(offsets), n, int(max_tokens),
+                                  L.np_ptr(out) if want_host else None,
+                                  append_to._h if append_to is not None else None, C.byref(first)))
+        return out, (int(first.value) if append_to is not None else None)
+
+    def embed_device(self, ids_ptr, offsets_ptr, n_lines, max_tokens, out_ptr):
+        L.check(L.lib().smt_embed_device(self._h, C.c_void_p(ids_ptr), C.c_void_p(offsets_ptr), int(n_lines),
+                                         int(max_tokens), C.c_void_p(out_ptr)))
+
+
+class Corpus:
+    """Row-major f32 [rows x 256] matrix resident in HBM (smt_corpus)."""
+
+    def __init__(self, ctx, capacity_rows=0, device_ptr=None, rows=None, _handle=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        elif device_ptr is not None:
+            L.check(L.lib().smt_corpus_from_device(ctx._h, C.c_void_p(device_ptr), int(rows), L.DIM, C.byref(self._h)))
+        else:
+            L.check(L.lib().smt_corpus_create(ctx._h, L.DIM, int(capacity_rows), C.byref(self._h)))
+
+    @classmethod
+    def load(cls, ctx, path):
+        h = C.c_void_p()
+        L.check(L.lib().smt_corpus_load(ctx._h, str(path).encode(), C.byref(h)))
+        return cls(ctx, _handle=h)
+
+    def save(self, path):
+        L.check(L.lib().smt_corpus_save(self._h, str(path).encode()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_corpus_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def rows(self):
+        return int(L.lib().smt_corpus_rows(self._h))
+
+    def __len__(self):
+        return self.rows
+
+    def append(self, rows):
+        rows = _f32c(rows).reshape(-1, L.DIM)
+        first = C.c_uint64(0)
+        L.check(L.lib().smt_corpus_append_host(self._h, L.np_ptr(rows), rows.shape[0], C.byref(first)))
+        return int(first.value)
+
+    def write_rows(self, first_row, rows):
+        rows = _f32c(rows).reshape(-1, L.DIM)
+        L.check(L.lib().smt_corpus_write_rows(self._h, int(first_row), L.np_ptr(rows), rows.shape[0]))
+
+    def read_rows(self, first_row, n_rows):
+        out = np.empty((int(n_rows), L.DIM), dtype=np.float32)
+        L.check(L.lib().smt_corpus_read_rows(self._h, int(first_row), int(n_rows), L.np_ptr(out)))
+        return out
+
+    def truncate(self, n_rows):
+        L.check(L.lib().smt_corpus_truncate(self._h, int(n_rows)))
+
+    def search(self, queries, top_k=3, max_distance=None, mode=L.MODE_DOCUMENTS, ranges=None, row_base=0,
+               out_cap=None):
+        """Returns a list (one per query) of (rows uint64[n], dist float64[n]).
+
+        mode/threshold semantics: see include/semtools_hip.h (smt_search)."""
+        q = _f32c(queries).reshape(-1, L.DIM)
+        nq = q.shape[0]
+        if out_cap is None:
+            out_cap = max(int(top_k), 1)
+            if max_distance is not None and mode == L.MODE_DOCUMENTS:
+                out_cap = max(self.rows, 1)
+        rng = None
+        n_rng = 0
+        if ranges is not None:
+            n_rng = len(ranges)
+            rng = (L.SmtRange * max(n_rng, 1))()
+            for i, (b, e) in enumerate(ranges):
+                rng[i].begin, rng[i].end = int(b), int(e)
+        while True:
+            out_rows = np.empty((nq, out_cap), dtype=np.uint64)
+            out_dist = np.empty((nq, out_cap), dtype=np.float64)
+            counts = np.zeros(nq, dtype=np.uint64)
+            rc = L.lib().smt_search(self._h, L.np_ptr(q), nq, int(top_k),
+                                    float("nan") if max_distance is None else float(max_distance), int(mode),
+                                    C.cast(rng, C.c_void_p) if rng is not None else None, n_rng, int(row_base),
+                                    L.np_ptr(out_rows), L.np_ptr(out_dist), L.np_ptr(counts), int(out_cap))
+            if rc == L.SMT_E_TRUNCATED:
+                out_cap = int(counts.max())
+                continue
+            L.check(rc)
+            break
+        return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
+
+    def search_topk_device(self, queries_ptr, nq, top_k, row_base, out_rows_ptr, out_dist_ptr):
+        L.check(L.lib().smt_search_topk_device(self._h, C.c_void_p(queries_ptr), int(nq), int(top_k), int(row_base),
+                                               C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
+
+
+def merge_topk(rows, dist, k_out):
+    """Host merge of per-shard sorted top-k lists laid out [n_lists][nq][k_in]."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    dist = np.ascontiguousarray(dist, dtype=np.float64)
+    n_lists, nq, k_in = rows.shape
+    out_rows = np.empty((nq, k_out), dtype=np.uint64)
+    out_dist = np.empty((nq, k_out), dtype=np.float64)
+    counts = np.zeros(nq, dtype=np.uint64)
+    L.check(L.lib().smt_merge_topk(L.np_ptr(rows), L.np_ptr(dist), n_lists, nq, k_in, int(k_out),
+                                   L.np_ptr(out_rows), L.np_ptr(out_dist), L.np_ptr(counts)))
+    return out_rows, out_dist, counts

@@ -1,0 +1,804 @@
+// api.cpp -- host side of libsemtools_hip.so: handles, memory, orchestration of
+// the kernels, and the extern "C" entry points declared in
+// include/semtools_hip.h.  There is no CPU fallback anywhere in this file:
+// every compute entry point needs a live gfx950 context.
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <limits>
+
+#include "common.h"
+
+namespace smt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_scratch(smt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return SMT_OK;
+    // stream-ordered safety: earlier kernels may still read the old buffer
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_scratch) SMT_HIP_CHECK(hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    SMT_HIP_CHECK(hipMalloc(&ctx->d_scratch, want));
+    ctx->scratch_bytes = want;
+    return SMT_OK;
+}
+
+int ensure_pinned(smt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_bytes) return SMT_OK;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned) SMT_HIP_CHECK(hipHostFree(ctx->h_pinned));
+    ctx->h_pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 16);
+    SMT_HIP_CHECK(hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+    return SMT_OK;
+}
+
+void prof_begin(smt_ctx *ctx, const char *name)
+{
+    if (!ctx->prof_on) return;
+    ProfEntry &e = ctx->prof[name];
+    if (e.used + 2 > e.ev.size()) {
+        const size_t old = e.ev.size();
+        e.ev.resize(old + 256);
+        for (size_t i = old; i < e.ev.size(); ++i) (void)hipEventCreate(&e.ev[i]);
+    }
+    (void)hipEventRecord(e.ev[e.used], ctx->stream);
+}
+
+void prof_end(smt_ctx *ctx, const char *name)
+{
+    if (!ctx->prof_on) return;
+    ProfEntry &e = ctx->prof[name];
+    (void)hipEventRecord(e.ev[e.used + 1], ctx->stream);
+    e.used += 2;
+}
+
+static int check_ctx(const smt_ctx *ctx)
+{
+    if (!ctx) { set_error("null context"); return SMT_E_INVALID; }
+    return SMT_OK;
+}
+
+static int bind_device(const smt_ctx *ctx)
+{
+    SMT_HIP_CHECK(hipSetDevice(ctx->device));
+    return SMT_OK;
+}
+
+// Device buffers carved out of one temporary allocation, freed on scope exit.
+struct DeviceTemp {
+    void *p = nullptr;
+    ~DeviceTemp() { if (p) (void)hipFree(p); }
+};
+
+static uint64_t fnv1a(const uint8_t *b, uint64_t n)
+{
+    // reference src/workspace/store.rs:651-661
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint64_t i = 0; i < n; ++i) { h ^= (uint64_t)b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+}  // namespace smt
+
+using namespace smt;
+
+extern "C" {
+
+const char *smt_last_error(void) { return g_err; }
+const char *smt_version(void) { return "semtools-hip 0.1.0 (gfx950)"; }
+
+int smt_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+    return n;
+}
+
+int smt_ctx_create(int device, void *stream, smt_ctx **out)
+{
+    SMT_REQUIRE(out != nullptr, "out");
+    *out = nullptr;
+    int n = 0;
+    SMT_HIP_CHECK(hipGetDeviceCount(&n));
+    if (n <= 0) { set_error("no HIP device visible: libsemtools_hip has no CPU fallback"); return SMT_E_HIP; }
+    SMT_REQUIRE(device >= 0 && device < n, "device index out of range");
+    SMT_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SMT_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return SMT_E_HIP;
+    }
+    smt_ctx *ctx = new (std::nothrow) smt_ctx();
+    if (!ctx) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+        ctx->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return SMT_OK;
+}
+
+void smt_ctx_destroy(smt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof)
+        for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int smt_ctx_synchronize(smt_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMT_OK;
+}
+
+int smt_prof_enable(smt_ctx *ctx, int on)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->prof_on = on != 0;
+    return SMT_OK;
+}
+
+int smt_prof_reset(smt_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->prof) kv.second.used = 0;
+    return SMT_OK;
+}
+
+int smt_prof_read(smt_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(kernel && launches && total_ms, "null argument");
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *launches = 0;
+    *total_ms = 0.0;
+    auto it = ctx->prof.find(kernel);
+    if (it == ctx->prof.end()) return SMT_OK;
+    ProfEntry &e = it->second;
+    for (size_t i = 0; i + 1 < e.used; i += 2) {
+        float ms = 0.f;
+        SMT_HIP_CHECK(hipEventElapsedTime(&ms, e.ev[i], e.ev[i + 1]));
+        *total_ms += (double)ms;
+        *launches += 1;
+    }
+    return SMT_OK;
+}
+
+int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(key != nullptr, "key");
+    std::string k(key);
+    if (k == "scan_blocks") ctx->tune.scan_blocks = (int)value;
+    else if (k == "scan_threads") {
+        SMT_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "scan_threads must be a multiple of 64 in [64,1024]");
+        ctx->tune.scan_threads = (int)value;
+    } else if (k == "scan_unroll") {
+        SMT_REQUIRE(value == 4 || value == 8 || value == 16, "scan_unroll must be 4, 8 or 16");
+        ctx->tune.scan_unroll = (int)value;
+    } else if (k == "scan_nontemporal") ctx->tune.scan_nontemporal = (int)value;
+    else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
+    else { set_error("unknown tuning key '%s'", key); return SMT_E_INVALID; }
+    return SMT_OK;
+}
+
+/* ---------------------------------------------------------------- model ---- */
+
+int smt_model_create(smt_ctx *ctx, const float *table_host, uint64_t V, uint32_t D, int normalize,
+                     smt_model **out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(out && table_host, "null argument");
+    *out = nullptr;
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
+    SMT_REQUIRE(V > 0, "empty table");
+    if ((rc = bind_device(ctx))) return rc;
+    smt_model *m = new (std::nothrow) smt_model();
+    if (!m) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    m->ctx = ctx; m->V = V; m->D = D; m->normalize = normalize ? 1 : 0; m->owned = true;
+    const size_t bytes = (size_t)V * D * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_table), bytes);
+    if (e != hipSuccess) { delete m; set_error("hipMalloc(%zu) for the embedding table: %s", bytes, hipGetErrorString(e)); return SMT_E_NOMEM; }
+    e = hipMemcpyAsync(m->d_table, table_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(m->d_table); delete m; set_error("table upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+    *out = m;
+    return SMT_OK;
+}
+
+int smt_model_create_from_device(smt_ctx *ctx, const float *table_dev, uint64_t V, uint32_t D,
+                                 int normalize, smt_model **out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(out && table_dev, "null argument");
+    *out = nullptr;
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported", D); return SMT_E_UNSUPPORTED; }
+    smt_model *m = new (std::nothrow) smt_model();
+    if (!m) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    m->ctx = ctx; m->V = V; m->D = D; m->normalize = normalize ? 1 : 0;
+    m->d_table = const_cast<float *>(table_dev);
+    m->owned = false;
+    *out = m;
+    return SMT_OK;
+}
+
+void smt_model_destroy(smt_model *model)
+{
+    if (!model) return;
+    (void)hipSetDevice(model->ctx->device);
+    (void)hipStreamSynchronize(model->ctx->stream);
+    if (model->owned && model->d_table) (void)hipFree(model->d_table);
+    delete model;
+}
+
+/* --------------------------------------------------------------- corpus ---- */
+
+static int corpus_reserve(smt_corpus *c, uint64_t rows_needed)
+{
+    if (rows_needed <= c->capacity) return SMT_OK;
+    if (!c->owned) { set_error("corpus adopted from device memory cannot grow"); return SMT_E_NOMEM; }
+    uint64_t cap = std::max<uint64_t>(c->capacity * 2, rows_needed);
+    cap = std::max<uint64_t>(cap, 1024);
+    float *nd = nullptr;
+    const size_t bytes = (size_t)cap * c->dim * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&nd), bytes);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) for corpus rows: %s", bytes, hipGetErrorString(e)); return SMT_E_NOMEM; }
+    if (c->rows) {
+        e = hipMemcpyAsync(nd, c->d_rows, (size_t)c->rows * c->dim * sizeof(float), hipMemcpyDeviceToDevice, c->ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(nd); set_error("corpus grow copy: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+    }
+    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    if (c->d_rows) (void)hipFree(c->d_rows);
+    c->d_rows = nd;
+    c->capacity = cap;
+    return SMT_OK;
+}
+
+int smt_corpus_create(smt_ctx *ctx, uint32_t D, uint64_t capacity_rows, smt_corpus **out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(out != nullptr, "out");
+    *out = nullptr;
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
+    if ((rc = bind_device(ctx))) return rc;
+    smt_corpus *c = new (std::nothrow) smt_corpus();
+    if (!c) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    c->ctx = ctx; c->dim = D; c->owned = true;
+    if (capacity_rows) {
+        rc = corpus_reserve(c, capacity_rows);
+        if (rc) { delete c; return rc; }
+    }
+    *out = c;
+    return SMT_OK;
+}
+
+int smt_corpus_from_device(smt_ctx *ctx, const float *rows_dev, uint64_t n_rows, uint32_t D, smt_corpus **out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(out && (rows_dev || n_rows == 0), "null argument");
+    *out = nullptr;
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported", D); return SMT_E_UNSUPPORTED; }
+    smt_corpus *c = new (std::nothrow) smt_corpus();
+    if (!c) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    c->ctx = ctx; c->dim = D; c->owned = false;
+    c->d_rows = const_cast<float *>(rows_dev);
+    c->rows = n_rows; c->capacity = n_rows;
+    *out = c;
+    return SMT_OK;
+}
+
+void smt_corpus_destroy(smt_corpus *corpus)
+{
+    if (!corpus) return;
+    (void)hipSetDevice(corpus->ctx->device);
+    (void)hipStreamSynchronize(corpus->ctx->stream);
+    if (corpus->owned && corpus->d_rows) (void)hipFree(corpus->d_rows);
+    delete corpus;
+}
+
+uint64_t smt_corpus_rows(const smt_corpus *corpus) { return corpus ? corpus->rows : 0; }
+uint32_t smt_corpus_dim(const smt_corpus *corpus) { return corpus ? corpus->dim : 0; }
+
+int smt_corpus_append_host(smt_corpus *c, const float *rows, uint64_t n_rows, uint64_t *first_row)
+{
+    SMT_REQUIRE(c != nullptr, "corpus");
+    SMT_REQUIRE(rows || n_rows == 0, "rows");
+    int rc = bind_device(c->ctx);
+    if (rc) return rc;
+    if (first_row) *first_row = c->rows;
+    if (n_rows == 0) return SMT_OK;
+    if ((rc = corpus_reserve(c, c->rows + n_rows))) return rc;
+    SMT_HIP_CHECK(hipMemcpyAsync(c->d_rows + (size_t)c->rows * c->dim, rows, (size_t)n_rows * c->dim * sizeof(float),
+                                 hipMemcpyHostToDevice, c->ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    c->rows += n_rows;
+    return SMT_OK;
+}
+
+int smt_corpus_write_rows(smt_corpus *c, uint64_t first_row, const float *rows, uint64_t n_rows)
+{
+    SMT_REQUIRE(c != nullptr && (rows || n_rows == 0), "null argument");
+    SMT_REQUIRE(first_row + n_rows <= c->rows, "row range outside the corpus");
+    int rc = bind_device(c->ctx);
+    if (rc) return rc;
+    if (n_rows == 0) return SMT_OK;
+    SMT_HIP_CHECK(hipMemcpyAsync(c->d_rows + (size_t)first_row * c->dim, rows, (size_t)n_rows * c->dim * sizeof(float),
+                                 hipMemcpyHostToDevice, c->ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    return SMT_OK;
+}
+
+int smt_corpus_read_rows(smt_corpus *c, uint64_t first_row, uint64_t n_rows, float *out_host)
+{
+    SMT_REQUIRE(c != nullptr && (out_host || n_rows == 0), "null argument");
+    SMT_REQUIRE(first_row + n_rows <= c->rows, "row range outside the corpus");
+    int rc = bind_device(c->ctx);
+    if (rc) return rc;
+    if (n_rows == 0) return SMT_OK;
+    SMT_HIP_CHECK(hipMemcpyAsync(out_host, c->d_rows + (size_t)first_row * c->dim, (size_t)n_rows * c->dim * sizeof(float),
+                                 hipMemcpyDeviceToHost, c->ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    return SMT_OK;
+}
+
+int smt_corpus_truncate(smt_corpus *c, uint64_t n_rows)
+{
+    SMT_REQUIRE(c != nullptr, "corpus");
+    SMT_REQUIRE(n_rows <= c->rows, "cannot truncate to more rows than stored");
+    c->rows = n_rows;
+    return SMT_OK;
+}
+
+struct CorpusFileHeader {  // 32 bytes, little endian
+    char magic[8];         // "SMTCORP1"
+    uint32_t dim;
+    uint32_t reserved;
+    uint64_t rows;
+    uint64_t reserved2;
+};
+
+int smt_corpus_save(smt_corpus *c, const char *path)
+{
+    SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
+    int rc = bind_device(c->ctx);
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("cannot open '%s' for writing: %s", path, strerror(errno)); return SMT_E_IO; }
+    CorpusFileHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "SMTCORP1", 8);
+    h.dim = c->dim;
+    h.rows = c->rows;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    const uint64_t chunk_rows = 65536;
+    std::vector<float> buf;
+    buf.resize((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(c->rows, 1)) * c->dim);
+    for (uint64_t r = 0; ok && r < c->rows; r += chunk_rows) {
+        const uint64_t n = std::min(chunk_rows, c->rows - r);
+        rc = smt_corpus_read_rows(c, r, n, buf.data());
+        if (rc) { fclose(f); return rc; }
+        ok = fwrite(buf.data(), sizeof(float), (size_t)n * c->dim, f) == (size_t)n * c->dim;
+    }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("short write to '%s'", path); return SMT_E_IO; }
+    return SMT_OK;
+}
+
+int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(path && out, "null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    CorpusFileHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTCORP1", 8) != 0) {
+        fclose(f); set_error("'%s' is not a corpus file", path); return SMT_E_IO;
+    }
+    smt_corpus *c = nullptr;
+    rc = smt_corpus_create(ctx, h.dim, h.rows, &c);
+    if (rc) { fclose(f); return rc; }
+    const uint64_t chunk_rows = 65536;
+    std::vector<float> buf((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(h.rows, 1)) * h.dim);
+    for (uint64_t r = 0; r < h.rows; r += chunk_rows) {
+        const uint64_t n = std::min(chunk_rows, h.rows - r);
+        if (fread(buf.data(), sizeof(float), (size_t)n * h.dim, f) != (size_t)n * h.dim) {
+            fclose(f); smt_corpus_destroy(c); set_error("'%s' is truncated", path); return SMT_E_IO;
+        }
+        rc = smt_corpus_append_host(c, buf.data(), n, nullptr);
+        if (rc) { fclose(f); smt_corpus_destroy(c); return rc; }
+    }
+    fclose(f);
+    *out = c;
+    return SMT_OK;
+}
+
+/* ---------------------------------------------------------------- embed ---- */
+
+int smt_embed_device(smt_model *model, const uint32_t *ids_dev, const uint64_t *offsets_dev, uint64_t n_lines,
+                     uint32_t max_tokens, float *out_dev)
+{
+    SMT_REQUIRE(model != nullptr, "model");
+    SMT_REQUIRE(n_lines == 0 || (offsets_dev && out_dev), "null argument");
+    int rc = bind_device(model->ctx);
+    if (rc) return rc;
+    return launch_embed(model->ctx, model->d_table, model->V, model->normalize, ids_dev, offsets_dev, n_lines,
+                        max_tokens, out_dev);
+}
+
+int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens,
+              float *out_host, smt_corpus *append_to, uint64_t *first_row)
+{
+    SMT_REQUIRE(model != nullptr, "model");
+    SMT_REQUIRE(n_lines == 0 || offsets != nullptr, "offsets");
+    smt_ctx *ctx = model->ctx;
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (append_to) {
+        SMT_REQUIRE(append_to->ctx == ctx, "corpus belongs to a different context");
+        SMT_REQUIRE(append_to->dim == model->D, "corpus dim differs from the model's");
+        if (first_row) *first_row = append_to->rows;
+    }
+    if (n_lines == 0) return SMT_OK;
+    SMT_REQUIRE(offsets[0] == 0 || ids != nullptr, "ids");
+    const uint64_t n_ids = offsets[n_lines] - offsets[0];
+    for (uint64_t i = 0; i < n_lines; ++i) SMT_REQUIRE(offsets[i] <= offsets[i + 1], "offsets must be non-decreasing");
+    SMT_REQUIRE(n_ids == 0 || ids != nullptr, "ids");
+
+    // staging: ids + rebased offsets (+ output rows when not appending)
+    const size_t ids_bytes = ((size_t)n_ids * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t off_bytes = ((size_t)(n_lines + 1) * sizeof(uint64_t) + 15) & ~(size_t)15;
+    const size_t out_bytes = append_to ? 0 : (size_t)n_lines * model->D * sizeof(float);
+    DeviceTemp tmp;
+    {
+        hipError_t e = hipMalloc(&tmp.p, ids_bytes + off_bytes + out_bytes + 16);
+        if (e != hipSuccess) { set_error("hipMalloc for embed staging: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
+    }
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(tmp.p);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(tmp.p) + ids_bytes);
+    float *d_out = reinterpret_cast<float *>(reinterpret_cast<char *>(tmp.p) + ids_bytes + off_bytes);
+
+    std::vector<uint64_t> rebased(n_lines + 1);
+    for (uint64_t i = 0; i <= n_lines; ++i) rebased[i] = offsets[i] - offsets[0];
+    if (n_ids)
+        SMT_HIP_CHECK(hipMemcpyAsync(d_ids, ids + offsets[0], (size_t)n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SMT_HIP_CHECK(hipMemcpyAsync(d_off, rebased.data(), (size_t)(n_lines + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+
+    if (append_to) {
+        if ((rc = corpus_reserve(append_to, append_to->rows + n_lines))) return rc;
+        d_out = append_to->d_rows + (size_t)append_to->rows * append_to->dim;
+    }
+    rc = launch_embed(ctx, model->d_table, model->V, model->normalize, d_ids, d_off, n_lines, max_tokens, d_out);
+    if (rc) return rc;
+    if (out_host)
+        SMT_HIP_CHECK(hipMemcpyAsync(out_host, d_out, (size_t)n_lines * model->D * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (append_to) append_to->rows += n_lines;
+    return SMT_OK;
+}
+
+/* --------------------------------------------------------------- search ---- */
+
+static int validate_ranges(const smt_range *ranges, uint32_t n, uint64_t rows, uint64_t *total)
+{
+    uint64_t prev_end = 0, t = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        SMT_REQUIRE(ranges[i].begin <= ranges[i].end, "range begin > end");
+        SMT_REQUIRE(ranges[i].end <= rows, "range extends past the corpus");
+        SMT_REQUIRE(i == 0 || ranges[i].begin >= prev_end, "ranges must be sorted and disjoint");
+        prev_end = ranges[i].end;
+        t += ranges[i].end - ranges[i].begin;
+    }
+    *total = t;
+    return SMT_OK;
+}
+
+int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+               const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, uint64_t *out_rows, double *out_dist,
+               uint64_t *out_counts, uint64_t out_cap)
+{
+    SMT_REQUIRE(corpus != nullptr, "corpus");
+    SMT_REQUIRE(mode == SMT_MODE_DOCUMENTS || mode == SMT_MODE_WORKSPACE, "mode");
+    SMT_REQUIRE(nq == 0 || (queries && out_counts), "null argument");
+    SMT_REQUIRE(n_ranges == 0 || ranges != nullptr, "ranges");
+    smt_ctx *ctx = corpus->ctx;
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (nq == 0) return SMT_OK;
+    for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+
+    const bool has_thr = !std::isnan(max_distance);
+    const bool all_under_threshold = (mode == SMT_MODE_DOCUMENTS) && has_thr;
+
+    // drop empty ranges; total rows to scan
+    std::vector<smt_range> rr;
+    uint64_t n_virtual = corpus->rows;
+    if (n_ranges) {
+        uint64_t total = 0;
+        if ((rc = validate_ranges(ranges, n_ranges, corpus->rows, &total))) return rc;
+        for (uint32_t i = 0; i < n_ranges; ++i) if (ranges[i].end > ranges[i].begin) rr.push_back(ranges[i]);
+        n_virtual = total;
+    }
+    if (n_virtual == 0) return SMT_OK;
+    if (!all_under_threshold && top_k == 0) return SMT_OK;  // take(0) / store.rs:489-491
+    SMT_REQUIRE(out_rows && out_dist, "null output");
+
+    // ---- device staging: queries, ranges(+prefix)
+    const uint32_t nr = (uint32_t)rr.size();
+    const bool single_full_range = (nr == 1);
+    const size_t q_bytes = (size_t)nq * SMT_DIM * sizeof(float);
+    const size_t r_bytes = (size_t)nr * sizeof(smt_range);
+    const size_t p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
+    DeviceTemp tmp;
+    {
+        hipError_t e = hipMalloc(&tmp.p, q_bytes + r_bytes + p_bytes + 64);
+        if (e != hipSuccess) { set_error("hipMalloc for search staging: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
+    }
+    float *d_q = reinterpret_cast<float *>(tmp.p);
+    smt_range *d_r = reinterpret_cast<smt_range *>(reinterpret_cast<char *>(tmp.p) + q_bytes);
+    uint64_t *d_p = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(tmp.p) + q_bytes + r_bytes);
+    SMT_HIP_CHECK(hipMemcpyAsync(d_q, queries, q_bytes, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint64_t> prefix(nr + 1, 0);
+    if (nr) {
+        for (uint32_t i = 0; i < nr; ++i) prefix[i + 1] = prefix[i] + (rr[i].end - rr[i].begin);
+        SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    (void)single_full_range;
+
+    if (!all_under_threshold) {
+        // ---------------- top-k (optionally with the workspace score threshold)
+        const uint32_t k_eff = (uint32_t)std::min<uint64_t>(top_k, n_virtual);
+        if (k_eff > 64) {
+            set_error("top_k=%u > 64 is not supported by the resident top-k path yet", top_k);
+            return SMT_E_UNSUPPORTED;
+        }
+        const size_t o_rows = (size_t)nq * k_eff * sizeof(uint64_t);
+        const size_t o_dist = (size_t)nq * k_eff * sizeof(double);
+        const size_t o_cnt = (size_t)nq * sizeof(uint64_t);
+        DeviceTemp outs;
+        {
+            hipError_t e = hipMalloc(&outs.p, o_rows + o_dist + o_cnt);
+            if (e != hipSuccess) { set_error("hipMalloc for search outputs: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
+        }
+        uint64_t *d_orow = reinterpret_cast<uint64_t *>(outs.p);
+        double *d_odist = reinterpret_cast<double *>(reinterpret_cast<char *>(outs.p) + o_rows);
+        uint64_t *d_ocnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(outs.p) + o_rows + o_dist);
+
+        ScanArgs a;
+        a.corpus = corpus->d_rows;
+        a.rows = corpus->rows;
+        a.queries = d_q;
+        a.nq = nq;
+        a.k_out = k_eff;
+        a.ranges = nr ? d_r : nullptr;
+        a.range_prefix = nr ? d_p : nullptr;
+        a.n_ranges = nr;
+        a.n_virtual = n_virtual;
+        a.ws_threshold = (mode == SMT_MODE_WORKSPACE && has_thr) ? 1 : 0;
+        a.ws_thr_score = 1.0f - (float)max_distance;  // store.rs:502-503
+        a.row_base = row_base;
+        a.out_rows = d_orow;
+        a.out_dist = d_odist;
+        a.out_counts = d_ocnt;
+        // the MFMA path pays off from 8 queries up (one 32-query tile)
+        rc = (nq >= 8 && nr == 0) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
+        if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
+        if (rc) return rc;
+
+        if ((rc = ensure_pinned(ctx, o_rows + o_dist + o_cnt))) return rc;
+        SMT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, outs.p, o_rows + o_dist + o_cnt, hipMemcpyDeviceToHost, ctx->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
+        const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows);
+        const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows + o_dist);
+        bool truncated = false;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint64_t n = h_cnt[q];
+            out_counts[q] = n;
+            const uint64_t w = std::min<uint64_t>(n, out_cap);
+            if (n > out_cap) truncated = true;
+            for (uint64_t i = 0; i < w; ++i) {
+                out_rows[(size_t)q * out_cap + i] = h_rows[(size_t)q * k_eff + i];
+                out_dist[(size_t)q * out_cap + i] = h_dist[(size_t)q * k_eff + i];
+            }
+        }
+        if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
+        return SMT_OK;
+    }
+
+    // ---------------- all rows with distance < max_distance (mod.rs:88-89,115-116)
+    bool truncated = false;
+    for (uint32_t q = 0; q < nq; ++q) {
+        // f32 prefilter with a guard band, exact f64 test afterwards
+        const float prefilter = (float)(max_distance + 8e-6) + 0.0f;
+        uint64_t cap = std::min<uint64_t>(n_virtual, (uint64_t)1 << 20);
+        for (;;) {
+            const size_t b_rows = ((size_t)cap * sizeof(uint32_t) + 15) & ~(size_t)15;
+            const size_t b_dist = (size_t)cap * sizeof(double);
+            DeviceTemp hits;
+            hipError_t e = hipMalloc(&hits.p, b_rows + b_dist + 16);
+            if (e != hipSuccess) { set_error("hipMalloc for threshold hits: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
+            uint32_t *d_hrows = reinterpret_cast<uint32_t *>(hits.p);
+            double *d_hdist = reinterpret_cast<double *>(reinterpret_cast<char *>(hits.p) + b_rows);
+            unsigned long long *d_hcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(hits.p) + b_rows + b_dist);
+            ThresholdArgs t;
+            t.corpus = corpus->d_rows;
+            t.rows = corpus->rows;
+            t.query = d_q + (size_t)q * SMT_DIM;
+            t.ranges = nr ? d_r : nullptr;
+            t.range_prefix = nr ? d_p : nullptr;
+            t.n_ranges = nr;
+            t.n_virtual = n_virtual;
+            t.prefilter = prefilter;
+            t.hit_rows = d_hrows;
+            t.hit_dist = d_hdist;
+            t.hit_count = d_hcnt;
+            t.cap = cap;
+            if ((rc = launch_threshold_scan(ctx, t))) return rc;
+            unsigned long long n_hits = 0;
+            SMT_HIP_CHECK(hipMemcpyAsync(&n_hits, d_hcnt, sizeof(n_hits), hipMemcpyDeviceToHost, ctx->stream));
+            SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (n_hits > cap) { cap = n_hits; continue; }  // rare: rerun with an exact-size buffer
+            if ((rc = launch_rescore_rows(ctx, corpus->d_rows, t.query, d_hrows, n_hits, d_hdist))) return rc;
+            std::vector<uint32_t> h_rows(n_hits);
+            std::vector<double> h_dist(n_hits);
+            if (n_hits) {
+                SMT_HIP_CHECK(hipMemcpyAsync(h_rows.data(), d_hrows, n_hits * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                SMT_HIP_CHECK(hipMemcpyAsync(h_dist.data(), d_hdist, n_hits * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            // exact strict test, then the reference's order: distance asc, row asc
+            std::vector<uint64_t> order;
+            order.reserve(n_hits);
+            for (uint64_t i = 0; i < n_hits; ++i) if (h_dist[i] < max_distance) order.push_back(i);
+            std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+                if (h_dist[x] != h_dist[y]) return h_dist[x] < h_dist[y];
+                return h_rows[x] < h_rows[y];
+            });
+            out_counts[q] = order.size();
+            const uint64_t w = std::min<uint64_t>(order.size(), out_cap);
+            if (order.size() > out_cap) truncated = true;
+            for (uint64_t i = 0; i < w; ++i) {
+                out_rows[(size_t)q * out_cap + i] = row_base + h_rows[order[i]];
+                out_dist[(size_t)q * out_cap + i] = h_dist[order[i]];
+            }
+            break;
+        }
+    }
+    if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
+    return SMT_OK;
+}
+
+int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,
+                           uint64_t *out_rows_dev, double *out_dist_dev)
+{
+    SMT_REQUIRE(corpus != nullptr, "corpus");
+    SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
+    SMT_REQUIRE(top_k >= 1 && top_k <= 64, "top_k must be in [1, 64]");
+    smt_ctx *ctx = corpus->ctx;
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (nq == 0) return SMT_OK;
+    ScanArgs a;
+    a.corpus = corpus->d_rows;
+    a.rows = corpus->rows;
+    a.queries = queries_dev;
+    a.nq = nq;
+    a.k_out = top_k;
+    a.ranges = nullptr;
+    a.range_prefix = nullptr;
+    a.n_ranges = 0;
+    a.n_virtual = corpus->rows;
+    a.ws_threshold = 0;
+    a.ws_thr_score = 0.f;
+    a.row_base = row_base;
+    a.out_rows = out_rows_dev;
+    a.out_dist = out_dist_dev;
+    a.out_counts = nullptr;
+    if (corpus->rows == 0) {
+        // nothing to scan: fill with padding through the merge kernel on zero lists
+        return launch_merge_topk(ctx, out_rows_dev, out_dist_dev, 0, nq, 1, top_k, out_rows_dev, out_dist_dev);
+    }
+    rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
+    if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
+    return rc;
+}
+
+int smt_merge_topk(const uint64_t *rows, const double *dist, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
+                   uint64_t *out_rows, double *out_dist, uint64_t *out_counts)
+{
+    SMT_REQUIRE((rows && dist) || n_lists == 0 || nq == 0 || k_in == 0, "null input");
+    SMT_REQUIRE(nq == 0 || k_out == 0 || (out_rows && out_dist), "null output");
+    std::vector<std::pair<double, uint64_t>> cand;
+    for (uint32_t q = 0; q < nq; ++q) {
+        cand.clear();
+        for (uint32_t l = 0; l < n_lists; ++l)
+            for (uint32_t i = 0; i < k_in; ++i) {
+                const size_t idx = ((size_t)l * nq + q) * k_in + i;
+                if (rows[idx] != UINT64_MAX) cand.emplace_back(dist[idx], rows[idx]);
+            }
+        std::sort(cand.begin(), cand.end());
+        const uint64_t n = std::min<uint64_t>(cand.size(), k_out);
+        for (uint32_t i = 0; i < k_out; ++i) {
+            out_rows[(size_t)q * k_out + i] = i < n ? cand[i].second : UINT64_MAX;
+            out_dist[(size_t)q * k_out + i] = i < n ? cand[i].first : std::numeric_limits<double>::infinity();
+        }
+        if (out_counts) out_counts[q] = n;
+    }
+    return SMT_OK;
+}
+
+int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *dist_dev, uint32_t n_lists, uint32_t nq,
+                          uint32_t k_in, uint32_t k_out, uint64_t *out_rows_dev, double *out_dist_dev)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(nq == 0 || (out_rows_dev && out_dist_dev), "null output");
+    if ((rc = bind_device(ctx))) return rc;
+    if (nq == 0 || k_out == 0) return SMT_OK;
+    return launch_merge_topk(ctx, rows_dev, dist_dev, n_lists, nq, k_in, k_out, out_rows_dev, out_dist_dev);
+}
+
+/* ------------------------------------------------------------------ ids ---- */
+
+uint64_t smt_fnv1a_hash(const uint8_t *bytes, uint64_t n) { return fnv1a(bytes, n); }
+
+uint64_t smt_doc_meta_id(const char *path)
+{
+    // DocMeta::id, reference src/workspace/store.rs:75-80
+    return path ? fnv1a(reinterpret_cast<const uint8_t *>(path), strlen(path)) : fnv1a(nullptr, 0);
+}
+
+uint64_t smt_line_embedding_id(const char *path, int32_t line_number)
+{
+    // LineEmbedding::id, reference src/workspace/store.rs:82-89: path bytes || i32 LE
+    std::string b(path ? path : "");
+    const uint32_t u = (uint32_t)line_number;
+    for (int i = 0; i < 4; ++i) b.push_back((char)((u >> (8 * i)) & 0xff));
+    return fnv1a(reinterpret_cast<const uint8_t *>(b.data()), b.size());
+}
+
+}  // extern "C"

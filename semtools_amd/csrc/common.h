@@ -1,0 +1,155 @@
+// common.h -- internal declarations shared by the libsemtools_hip.so sources.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/semtools_hip.h"
+
+namespace smt {
+
+void set_error(const char *fmt, ...);
+
+#define SMT_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            smt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                           __FILE__, __LINE__);                                          \
+            return SMT_E_HIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+#define SMT_REQUIRE(cond, msg)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            smt::set_error("invalid argument: %s (%s)", msg, #cond);                     \
+            return SMT_E_INVALID;                                                        \
+        }                                                                                \
+    } while (0)
+
+// One candidate on the device: key = (f32 distance bits << 32) | local row.
+// Distances are clipped to >= 0, so the IEEE bit pattern is order-preserving
+// and ascending u64 order == (distance asc, row asc).
+typedef unsigned long long key_t64;
+static constexpr key_t64 KEY_PAD = 0xFFFFFFFFFFFFFFFFull;
+
+struct ProfEntry {
+    std::vector<hipEvent_t> ev;  // start/stop pairs, grown on demand
+    size_t used = 0;
+};
+
+struct Tuning {
+    int scan_blocks = 0;        // 0 = 2 * CU count
+    int scan_threads = 512;
+    int scan_unroll = 8;
+    int scan_nontemporal = 1;
+    int gemm_blocks = 0;        // 0 = CU count
+};
+
+}  // namespace smt
+
+struct smt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 0;
+    // scratch (grown on demand, reused across calls)
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *h_pinned = nullptr;
+    size_t pinned_bytes = 0;
+    bool prof_on = false;
+    std::map<std::string, smt::ProfEntry> prof;
+    smt::Tuning tune;
+};
+
+struct smt_corpus {
+    smt_ctx *ctx = nullptr;
+    float *d_rows = nullptr;
+    uint64_t rows = 0;
+    uint64_t capacity = 0;
+    uint32_t dim = 0;
+    bool owned = true;
+};
+
+struct smt_model {
+    smt_ctx *ctx = nullptr;
+    float *d_table = nullptr;
+    uint64_t V = 0;
+    uint32_t D = 0;
+    int normalize = 1;
+    bool owned = true;
+};
+
+namespace smt {
+
+int ensure_scratch(smt_ctx *ctx, size_t bytes);
+int ensure_pinned(smt_ctx *ctx, size_t bytes);
+
+// RAII-less helpers for event timing around a kernel family.
+void prof_begin(smt_ctx *ctx, const char *name);
+void prof_end(smt_ctx *ctx, const char *name);
+
+// ---- kernel launchers (defined in the .hip files) -------------------------
+// K2: single/few-query f32 scan with per-wave top-k' lists, then merge +
+// f64 rescoring.  All pointers device.  Results: out_rows[nq][k_out],
+// out_dist[nq][k_out], out_counts[nq] (device).
+struct ScanArgs {
+    const float *corpus;      // [rows x 256]
+    uint64_t rows;            // rows in this shard (< 2^32)
+    const float *queries;     // device [nq x 256]
+    uint32_t nq;
+    uint32_t k_out;           // results wanted per query
+    const smt_range *ranges;  // device, or nullptr
+    const uint64_t *range_prefix;  // device exclusive prefix of range lengths [n_ranges+1]
+    uint32_t n_ranges;
+    uint64_t n_virtual;       // rows to scan (sum of ranges, or rows)
+    int ws_threshold;         // 1: apply score > thr_score (f32) in the final stage
+    float ws_thr_score;
+    uint64_t row_base;
+    uint64_t *out_rows;
+    double *out_dist;
+    uint64_t *out_counts;     // may be nullptr
+};
+int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
+
+// K4: threshold scan -> compacted hit rows (f32 prefilter with guard band),
+// exact f64 distances for every hit.  Outputs device arrays sized cap.
+struct ThresholdArgs {
+    const float *corpus;
+    uint64_t rows;
+    const float *query;       // device [256]
+    const smt_range *ranges;
+    const uint64_t *range_prefix;
+    uint32_t n_ranges;
+    uint64_t n_virtual;
+    float prefilter;          // keep if d32 < prefilter
+    uint32_t *hit_rows;       // device [cap]
+    double *hit_dist;         // device [cap]
+    unsigned long long *hit_count;  // device scalar
+    uint64_t cap;
+};
+int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a);
+int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
+                        uint64_t n, double *out_dist);
+
+int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
+                      uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
+                      double *out_dist);
+
+// K1
+int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
+                 const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out);
+
+// K3: batched queries, f32 MFMA with fused candidate selection.
+int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);
+
+}  // namespace smt

@@ -1,0 +1,594 @@
+// scan_kernels.hip -- K2 (single/few-query cosine scan + per-wave top-k'),
+// K4 (threshold compaction), the merge + f64 rescoring stage, and the
+// cross-shard top-k merge.  gfx950 only (wave64, DPP, 16 B/lane row loads).
+//
+// Replaces the `for doc / for line: f32::cosine(q, e)` loop and the
+// sort/take of search_documents (reference src/search/mod.rs:84-119) and the
+// exact filtered scan behind Store::search_line_embeddings
+// (src/workspace/store.rs:481-546).
+//
+// Data layout: corpus row-major f32 [rows x 256]; one row = 1024 B = one
+// wave-wide 16 B/lane load (perfectly coalesced).  A wave owns U rows per
+// iteration (U independent 1 KiB loads in flight), reduces ab = <q,c> and
+// b2 = <c,c> with DPP butterflies, and keeps its best k' candidates in a
+// lane-distributed sorted list (lane i = i-th best).  The f32 scan only
+// NOMINATES candidates: the merge stage recomputes the distance of the final
+// k' rows with f64 accumulation in index order (simsimd "accurate" formula),
+// so returned distances/ordering do not depend on the reduction tree.
+#include "common.h"
+
+namespace smt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ DPP helpers
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i within 16
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave
+
+// Sum over the 64 lanes, result in every lane.  Fixed tree => deterministic.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
+    const float s0 = readlane_f(v, 0), s1 = readlane_f(v, 16);
+    const float s2 = readlane_f(v, 32), s3 = readlane_f(v, 48);
+    return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ float dist_f32(float ab, float b2, float rq, bool q_zero)
+{
+    // simsimd rules (oracle/semtools_oracle.c cos_finish): both zero -> 0,
+    // ab == 0 -> 1, else max(0, 1 - ab * rsqrt(a2) * rsqrt(b2)).  rq = 0 when
+    // the query is the zero vector, so "ab == 0 -> 1" falls out of the formula.
+    if (b2 == 0.0f) return q_zero ? 0.0f : 1.0f;
+    const float d = 1.0f - ab * rq * __frsqrt_rn(b2);
+    return fmaxf(d, 0.0f);
+}
+
+__device__ __forceinline__ key_t64 make_key(float d, uint32_t row)
+{
+    return ((key_t64)__float_as_uint(d) << 32) | (key_t64)row;
+}
+
+// Map a virtual row (position inside the concatenated ranges) to a corpus row.
+__device__ __forceinline__ uint32_t map_virtual(uint64_t v, const smt_range *ranges,
+                                                const uint64_t *prefix, uint32_t n_ranges)
+{
+    // largest i with prefix[i] <= v
+    uint32_t lo = 0, hi = n_ranges;  // invariant: prefix[lo] <= v < prefix[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= v) lo = mid; else hi = mid;
+    }
+    return (uint32_t)(ranges[lo].begin + (v - prefix[lo]));
+}
+
+struct ScanParams {
+    const float *corpus;
+    const float *queries;  // [NQ x 256] (device)
+    uint64_t n_virtual;
+    const smt_range *ranges;
+    const uint64_t *prefix;
+    uint32_t n_ranges;
+    uint32_t kp;           // candidates kept per wave / per block (<= 64)
+    key_t64 *block_lists;  // [NQ][gridDim.x][kp]
+};
+
+// ------------------------------------------------------------------------- K2
+template <int NQ, int U, bool NT, bool FILTERED>
+__global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    key_t64 *s_keys = reinterpret_cast<key_t64 *>(smem_raw);  // [waves][64]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint64_t stride = (uint64_t)gridDim.x * waves_per_block * U;
+    const int kp = (int)p.kp;
+
+    f32x4 q[NQ];
+    float rq[NQ];
+    bool qz[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        q[n] = reinterpret_cast<const f32x4 *>(p.queries + n * 256)[lane];
+        const float a2 = wave_sum(q[n].x * q[n].x + q[n].y * q[n].y + q[n].z * q[n].z + q[n].w * q[n].w);
+        qz[n] = (a2 == 0.0f);
+        rq[n] = qz[n] ? 0.0f : __frsqrt_rn(a2);
+    }
+
+    // lane-distributed sorted candidate lists
+    float ld[NQ];
+    uint32_t lr[NQ];
+    float thr_d[NQ];
+    uint32_t thr_r[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        ld[n] = __builtin_inff();
+        lr[n] = 0xFFFFFFFFu;
+        thr_d[n] = __builtin_inff();
+        thr_r[n] = 0xFFFFFFFFu;
+    }
+
+    for (uint64_t v0 = wave_global * U; v0 < p.n_virtual; v0 += stride) {
+        f32x4 c[U];
+        uint32_t row[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            uint64_t v = v0 + j;
+            if (v >= p.n_virtual) v = p.n_virtual - 1;  // clamp (result discarded)
+            row[j] = FILTERED ? map_virtual(v, p.ranges, p.prefix, p.n_ranges) : (uint32_t)v;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
+            c[j] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool valid = (v0 + j) < p.n_virtual;  // wave-uniform
+            const float b2 = wave_sum(c[j].x * c[j].x + c[j].y * c[j].y + c[j].z * c[j].z + c[j].w * c[j].w);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const float ab =
+                    wave_sum(c[j].x * q[n].x + c[j].y * q[n].y + c[j].z * q[n].z + c[j].w * q[n].w);
+                const float d = dist_f32(ab, b2, rq[n], qz[n]);
+                const uint32_t r = row[j];
+                if (valid && (d < thr_d[n] || (d == thr_d[n] && r < thr_r[n]))) {
+                    // insert (d, r) keeping (distance asc, row asc) order
+                    const bool less = (ld[n] < d) || (ld[n] == d && lr[n] < r);
+                    const int pos = __popcll(__ballot(less));
+                    const float sd = dpp_f<DPP_WAVE_SHR1>(ld[n]);
+                    const uint32_t sr = dpp_u<DPP_WAVE_SHR1>(lr[n]);
+                    if (lane > pos) { ld[n] = sd; lr[n] = sr; }
+                    else if (lane == pos) { ld[n] = d; lr[n] = r; }
+                    thr_d[n] = readlane_f(ld[n], kp - 1);
+                    thr_r[n] = (uint32_t)__builtin_amdgcn_readlane((int)lr[n], kp - 1);
+                }
+            }
+        }
+    }
+
+    // block merge: rank every wave's candidates among all of the block's.
+    for (int n = 0; n < NQ; ++n) {
+        __syncthreads();
+        s_keys[wave * 64 + lane] = (lane < kp && lr[n] != 0xFFFFFFFFu) ? make_key(ld[n], lr[n]) : KEY_PAD;
+        key_t64 *out = p.block_lists + ((size_t)n * gridDim.x + blockIdx.x) * kp;
+        if ((int)threadIdx.x < kp) out[threadIdx.x] = KEY_PAD;
+        __syncthreads();
+        const key_t64 mine = s_keys[wave * 64 + lane];
+        if (mine != KEY_PAD) {
+            int rank = 0;
+            for (int w = 0; w < waves_per_block; ++w)
+                for (int i = 0; i < kp; ++i) rank += (s_keys[w * 64 + i] < mine) ? 1 : 0;
+            if (rank < kp) out[rank] = mine;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- K4
+struct ThrParams {
+    const float *corpus;
+    const float *query;
+    uint64_t n_virtual;
+    const smt_range *ranges;
+    const uint64_t *prefix;
+    uint32_t n_ranges;
+    float prefilter;
+    uint32_t *hit_rows;
+    unsigned long long *hit_count;
+    uint64_t cap;
+};
+
+template <int U, bool NT, bool FILTERED>
+__global__ void __launch_bounds__(1024) scan_threshold_kernel(ThrParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint64_t stride = (uint64_t)gridDim.x * waves_per_block * U;
+
+    const f32x4 q = reinterpret_cast<const f32x4 *>(p.query)[lane];
+    const float a2 = wave_sum(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const bool qz = (a2 == 0.0f);
+    const float rq = qz ? 0.0f : __frsqrt_rn(a2);
+
+    for (uint64_t v0 = wave_global * U; v0 < p.n_virtual; v0 += stride) {
+        f32x4 c[U];
+        uint32_t row[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            uint64_t v = v0 + j;
+            if (v >= p.n_virtual) v = p.n_virtual - 1;
+            row[j] = FILTERED ? map_virtual(v, p.ranges, p.prefix, p.n_ranges) : (uint32_t)v;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
+            c[j] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+        // lane j (< U) remembers whether row j passed; one wave-aggregated append.
+        bool pass_mine = false;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool valid = (v0 + j) < p.n_virtual;
+            const float b2 = wave_sum(c[j].x * c[j].x + c[j].y * c[j].y + c[j].z * c[j].z + c[j].w * c[j].w);
+            const float ab = wave_sum(c[j].x * q.x + c[j].y * q.y + c[j].z * q.z + c[j].w * q.w);
+            const float d = dist_f32(ab, b2, rq, qz);
+            const bool pass = valid && (d < p.prefilter);
+            if (lane == j) pass_mine = pass;
+        }
+        const unsigned long long m = __ballot(pass_mine);
+        if (m != 0ull) {
+            const int cnt = __popcll(m);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(p.hit_count, (unsigned long long)cnt);
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xFFFFFFFFull));
+            if (pass_mine) {
+                const int off = __popcll(m & ((1ull << lane) - 1ull));
+                uint32_t myrow = 0;
+#pragma unroll
+                for (int j = 0; j < U; ++j) if (lane == j) myrow = row[j];
+                const unsigned long long slot = base + (unsigned long long)off;
+                if (slot < p.cap) p.hit_rows[slot] = myrow;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------- exact f64 distance (A5)
+// Bit-for-bit the oracle's orc_cosine_f32_accurate: f64 accumulators, index
+// order, no FMA contraction, then cos_finish.
+__device__ double exact_distance(const float *__restrict__ q, const float *__restrict__ r)
+{
+#pragma clang fp contract(off)
+    double ab = 0.0, a2 = 0.0, b2 = 0.0;
+    const float4 *q4 = reinterpret_cast<const float4 *>(q);
+    const float4 *r4 = reinterpret_cast<const float4 *>(r);
+#pragma unroll 4
+    for (int i = 0; i < 64; ++i) {
+        const float4 a = q4[i];
+        const float4 b = r4[i];
+        const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
+        const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
+        ab = ab + ax * bx; a2 = a2 + ax * ax; b2 = b2 + bx * bx;
+        ab = ab + ay * by; a2 = a2 + ay * ay; b2 = b2 + by * by;
+        ab = ab + az * bz; a2 = a2 + az * az; b2 = b2 + bz * bz;
+        ab = ab + aw * bw; a2 = a2 + aw * aw; b2 = b2 + bw * bw;
+    }
+    if (a2 == 0.0 && b2 == 0.0) return 0.0;
+    if (ab == 0.0) return 1.0;
+    const double unclipped = 1.0 - ab * (1.0 / sqrt(a2)) * (1.0 / sqrt(b2));
+    return unclipped > 0.0 ? unclipped : 0.0;
+}
+
+__global__ void rescore_rows_kernel(const float *corpus, const float *query, const uint32_t *rows,
+                                    uint64_t n, double *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = exact_distance(query, corpus + (uint64_t)rows[i] * 256);
+}
+
+// -------------------------------------------- merge block lists + f64 rescoring
+struct MergeParams {
+    const float *corpus;
+    const float *queries;
+    const key_t64 *block_lists;  // [nq][n_blocks][kp]
+    uint32_t n_blocks;
+    uint32_t kp;
+    uint32_t k_out;
+    int ws_threshold;
+    float ws_thr_score;
+    uint64_t row_base;
+    uint64_t *out_rows;   // [nq][k_out]
+    double *out_dist;     // [nq][k_out]
+    uint64_t *out_counts; // [nq] or nullptr
+};
+
+constexpr int MERGE_THREADS = 1024;
+constexpr int MERGE_BUF = 4096;
+
+__device__ void bitonic_sort_lds(key_t64 *buf)
+{
+    for (int k = 2; k <= MERGE_BUF; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < MERGE_BUF; i += MERGE_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const key_t64 a = buf[i], b = buf[ixj];
+                    const bool asc = ((i & k) == 0);
+                    if ((a > b) == asc) { buf[i] = b; buf[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(MERGE_THREADS) merge_rescore_kernel(MergeParams p)
+{
+    __shared__ key_t64 buf[MERGE_BUF];
+    __shared__ unsigned int s_cnt;
+    __shared__ key_t64 s_tau;
+    __shared__ double s_d[64 + 8];
+    __shared__ uint32_t s_r[64 + 8];
+    __shared__ unsigned int s_valid;
+
+    const uint32_t qi = blockIdx.x;
+    const key_t64 *lists = p.block_lists + (size_t)qi * p.n_blocks * p.kp;
+    const uint64_t M = (uint64_t)p.n_blocks * p.kp;
+    const int kp = (int)p.kp;
+
+    // tau = min over blocks of the block's kp-th key: an upper bound of the
+    // global kp-th key, so keys > tau can never make the final list.
+    if (threadIdx.x == 0) { s_tau = KEY_PAD; s_cnt = 0; s_valid = 0; }
+    __syncthreads();
+    key_t64 local = KEY_PAD;
+    for (uint32_t b = threadIdx.x; b < p.n_blocks; b += MERGE_THREADS) {
+        const key_t64 kth = lists[(size_t)b * kp + (kp - 1)];
+        local = kth < local ? kth : local;
+    }
+    atomicMin(&s_tau, local);
+    __syncthreads();
+    const key_t64 tau = s_tau;
+
+    for (uint64_t base = 0; base < M; base += MERGE_THREADS) {
+        // make room for up to MERGE_THREADS new keys
+        if (s_cnt > MERGE_BUF - MERGE_THREADS) {
+            for (int i = s_cnt + threadIdx.x; i < MERGE_BUF; i += MERGE_THREADS) buf[i] = KEY_PAD;
+            __syncthreads();
+            bitonic_sort_lds(buf);
+            if (threadIdx.x == 0) s_cnt = kp;
+            __syncthreads();
+        }
+        const uint64_t i = base + threadIdx.x;
+        const key_t64 key = i < M ? lists[i] : KEY_PAD;
+        if (key != KEY_PAD && key <= tau) {
+            const unsigned int slot = atomicAdd(&s_cnt, 1u);
+            buf[slot] = key;
+        }
+        __syncthreads();
+    }
+    for (int i = s_cnt + threadIdx.x; i < MERGE_BUF; i += MERGE_THREADS) buf[i] = KEY_PAD;
+    __syncthreads();
+    bitonic_sort_lds(buf);
+
+    // f64 rescoring of the kp best f32 candidates
+    const float *q = p.queries + (size_t)qi * 256;
+    if ((int)threadIdx.x < kp) {
+        const key_t64 key = buf[threadIdx.x];
+        double d = __builtin_inf();
+        uint32_t r = 0xFFFFFFFFu;
+        if (key != KEY_PAD) {
+            r = (uint32_t)(key & 0xFFFFFFFFull);
+            d = exact_distance(q, p.corpus + (uint64_t)r * 256);
+            if (p.ws_threshold) {
+                // qdrant score_threshold: keep score > threshold (similarity metrics)
+                if (!((1.0 - d) > (double)p.ws_thr_score)) { d = __builtin_inf(); r = 0xFFFFFFFFu; }
+            }
+        }
+        s_d[threadIdx.x] = d;
+        s_r[threadIdx.x] = r;
+        if (r != 0xFFFFFFFFu) atomicAdd(&s_valid, 1u);
+    }
+    __syncthreads();
+    uint64_t *orow = p.out_rows + (size_t)qi * p.k_out;
+    double *odist = p.out_dist + (size_t)qi * p.k_out;
+    if (threadIdx.x < p.k_out) { orow[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull; odist[threadIdx.x] = __builtin_inf(); }
+    __syncthreads();
+    if ((int)threadIdx.x < kp && s_r[threadIdx.x] != 0xFFFFFFFFu) {
+        const double d = s_d[threadIdx.x];
+        const uint32_t r = s_r[threadIdx.x];
+        int rank = 0;
+        for (int i = 0; i < kp; ++i) {
+            const double di = s_d[i];
+            const uint32_t ri = s_r[i];
+            if (ri != 0xFFFFFFFFu && (di < d || (di == d && ri < r))) ++rank;
+        }
+        if ((uint32_t)rank < p.k_out) { orow[rank] = p.row_base + r; odist[rank] = d; }
+    }
+    if (threadIdx.x == 0 && p.out_counts)
+        p.out_counts[qi] = s_valid < p.k_out ? s_valid : p.k_out;
+}
+
+// ------------------------------------------------- cross-shard top-k merge
+// rows/dist laid out [n_lists][nq][k_in]; one block per query.
+__global__ void merge_topk_kernel(const uint64_t *rows, const double *dist, uint32_t n_lists,
+                                  uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
+                                  double *out_dist)
+{
+    const uint32_t qi = blockIdx.x;
+    const uint32_t M = n_lists * k_in;
+    for (uint32_t t = threadIdx.x; t < k_out; t += blockDim.x) {
+        out_rows[(size_t)qi * k_out + t] = 0xFFFFFFFFFFFFFFFFull;
+        out_dist[(size_t)qi * k_out + t] = __builtin_inf();
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < M; e += blockDim.x) {
+        const uint32_t l = e / k_in, i = e % k_in;
+        const size_t idx = ((size_t)l * nq + qi) * k_in + i;
+        const uint64_t r = rows[idx];
+        if (r == 0xFFFFFFFFFFFFFFFFull) continue;
+        const double d = dist[idx];
+        uint32_t rank = 0;
+        for (uint32_t f = 0; f < M; ++f) {
+            const size_t jdx = ((size_t)(f / k_in) * nq + qi) * k_in + (f % k_in);
+            const uint64_t rf = rows[jdx];
+            if (rf == 0xFFFFFFFFFFFFFFFFull) continue;
+            const double df = dist[jdx];
+            if (df < d || (df == d && rf < r)) ++rank;
+        }
+        if (rank < k_out) { out_rows[(size_t)qi * k_out + rank] = r; out_dist[(size_t)qi * k_out + rank] = d; }
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline uint32_t candidates_per_list(uint32_t k_out)
+{
+    // guard band: a few extra f32 candidates so that f32-vs-f64 rank flips at
+    // the k-th boundary cannot drop a true top-k row
+    uint32_t kp = k_out + 8;
+    return kp > 64 ? 64 : kp;
+}
+
+template <int NQ, int U>
+static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt,
+                               bool filtered)
+{
+    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64);
+    dim3 g(blocks), b(threads);
+#define SMT_LAUNCH(NTV, FV) \
+    hipLaunchKernelGGL((scan_topk_kernel<NQ, U, NTV, FV>), g, b, smem, ctx->stream, p)
+    if (nt) { if (filtered) SMT_LAUNCH(true, true); else SMT_LAUNCH(true, false); }
+    else { if (filtered) SMT_LAUNCH(false, true); else SMT_LAUNCH(false, false); }
+#undef SMT_LAUNCH
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
+{
+    SMT_REQUIRE(a.k_out >= 1 && a.k_out <= 64, "top_k for the scan path must be in [1, 64]");
+    SMT_REQUIRE(a.rows < (1ull << 32), "a shard holds fewer than 2^32 rows");
+    const uint32_t kp = candidates_per_list(a.k_out);
+    int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : 2 * ctx->num_cus;
+    const int threads = ctx->tune.scan_threads;
+    const int U = ctx->tune.scan_unroll;
+    const uint64_t waves = (uint64_t)blocks * (threads / 64);
+    if (waves * (uint64_t)U > a.n_virtual) {  // tiny inputs: do not launch idle blocks
+        const uint64_t need = (a.n_virtual + (uint64_t)U * (threads / 64) - 1) / ((uint64_t)U * (threads / 64));
+        blocks = (int)(need > 0 ? need : 1);
+    }
+    const size_t list_bytes = (size_t)a.nq * blocks * kp * sizeof(key_t64);
+    int rc = ensure_scratch(ctx, list_bytes);
+    if (rc != SMT_OK) return rc;
+    key_t64 *lists = reinterpret_cast<key_t64 *>(ctx->d_scratch);
+
+    const bool filtered = a.n_ranges > 0;
+    const bool nt = ctx->tune.scan_nontemporal != 0;
+    prof_begin(ctx, "scan");
+    for (uint32_t q0 = 0; q0 < a.nq;) {
+        ScanParams p;
+        p.corpus = a.corpus;
+        p.queries = a.queries + (size_t)q0 * 256;
+        p.n_virtual = a.n_virtual;
+        p.ranges = a.ranges;
+        p.prefix = a.range_prefix;
+        p.n_ranges = a.n_ranges;
+        p.kp = kp;
+        p.block_lists = lists + (size_t)q0 * blocks * kp;
+        const uint32_t left = a.nq - q0;
+        if (left >= 4) {
+            rc = (U == 4) ? launch_scan_variant<4, 4>(ctx, p, blocks, threads, nt, filtered)
+                          : launch_scan_variant<4, 8>(ctx, p, blocks, threads, nt, filtered);
+            q0 += 4;
+        } else if (left >= 2) {
+            rc = (U == 4) ? launch_scan_variant<2, 4>(ctx, p, blocks, threads, nt, filtered)
+                          : launch_scan_variant<2, 8>(ctx, p, blocks, threads, nt, filtered);
+            q0 += 2;
+        } else {
+            if (U == 4) rc = launch_scan_variant<1, 4>(ctx, p, blocks, threads, nt, filtered);
+            else if (U == 16) rc = launch_scan_variant<1, 16>(ctx, p, blocks, threads, nt, filtered);
+            else rc = launch_scan_variant<1, 8>(ctx, p, blocks, threads, nt, filtered);
+            q0 += 1;
+        }
+        if (rc != SMT_OK) return rc;
+    }
+    prof_end(ctx, "scan");
+
+    MergeParams m;
+    m.corpus = a.corpus;
+    m.queries = a.queries;
+    m.block_lists = lists;
+    m.n_blocks = (uint32_t)blocks;
+    m.kp = kp;
+    m.k_out = a.k_out;
+    m.ws_threshold = a.ws_threshold;
+    m.ws_thr_score = a.ws_thr_score;
+    m.row_base = a.row_base;
+    m.out_rows = a.out_rows;
+    m.out_dist = a.out_dist;
+    m.out_counts = a.out_counts;
+    prof_begin(ctx, "select");
+    hipLaunchKernelGGL(merge_rescore_kernel, dim3(a.nq), dim3(MERGE_THREADS), 0, ctx->stream, m);
+    prof_end(ctx, "select");
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a)
+{
+    SMT_REQUIRE(a.rows < (1ull << 32), "a shard holds fewer than 2^32 rows");
+    int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : 2 * ctx->num_cus;
+    const int threads = ctx->tune.scan_threads;
+    ThrParams p;
+    p.corpus = a.corpus;
+    p.query = a.query;
+    p.n_virtual = a.n_virtual;
+    p.ranges = a.ranges;
+    p.prefix = a.range_prefix;
+    p.n_ranges = a.n_ranges;
+    p.prefilter = a.prefilter;
+    p.hit_rows = a.hit_rows;
+    p.hit_count = a.hit_count;
+    p.cap = a.cap;
+    SMT_HIP_CHECK(hipMemsetAsync(a.hit_count, 0, sizeof(unsigned long long), ctx->stream));
+    const bool nt = ctx->tune.scan_nontemporal != 0;
+    prof_begin(ctx, "scan");
+    dim3 g(blocks), b(threads);
+    if (a.n_ranges > 0) {
+        if (nt) hipLaunchKernelGGL((scan_threshold_kernel<8, true, true>), g, b, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((scan_threshold_kernel<8, false, true>), g, b, 0, ctx->stream, p);
+    } else {
+        if (nt) hipLaunchKernelGGL((scan_threshold_kernel<8, true, false>), g, b, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((scan_threshold_kernel<8, false, false>), g, b, 0, ctx->stream, p);
+    }
+    prof_end(ctx, "scan");
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
+                        uint64_t n, double *out_dist)
+{
+    if (n == 0) return SMT_OK;
+    const int threads = 64;
+    const uint64_t blocks = (n + threads - 1) / threads;
+    prof_begin(ctx, "select");
+    hipLaunchKernelGGL(rescore_rows_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, corpus,
+                       query, rows, n, out_dist);
+    prof_end(ctx, "select");
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
+                      uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows, double *out_dist)
+{
+    SMT_REQUIRE((uint64_t)n_lists * k_in <= 8192, "device merge handles up to 8192 candidates per query");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, ctx->stream, rows, dist, n_lists, nq,
+                       k_in, k_out, out_rows, out_dist);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+}  // namespace smt

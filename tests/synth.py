@@ -1,0 +1,62 @@
+"""Deterministic synthetic inputs shared by tests/ and bench.py.
+
+No model weights or tokenizer files exist offline, so every table, token stream
+and corpus is generated from fixed seeds.
+"""
+import numpy as np
+
+DIM = 256
+
+
+def unit_rows(n, seed, dup_frac=0.01, zero_frac=0.001):
+    """n unit-normalised N(0,1) rows, with exact-duplicate rows (ties) and all-zero rows
+    (empty-line embeddings) planted at seeded positions.  Config c2's corpus generator."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, DIM), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    n_dup = int(n * dup_frac)
+    if n_dup and n > 1:
+        dst = rng.choice(n, size=n_dup, replace=False)
+        src = rng.integers(0, n, size=n_dup)
+        x[dst] = x[src]
+    n_zero = int(n * zero_frac)
+    if n_zero:
+        x[rng.choice(n, size=n_zero, replace=False)] = 0.0
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def unit_query(seed, nq=1):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, DIM), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    return np.ascontiguousarray(q, dtype=np.float32)
+
+
+def table(V, seed=2, scale=0.1):
+    """Synthetic stand-in for the potion-multilingual-128M `embeddings` tensor [V x 256]."""
+    rng = np.random.default_rng(seed)
+    return np.ascontiguousarray(rng.standard_normal((V, DIM), dtype=np.float32) * np.float32(scale))
+
+
+def token_lines(n_lines, V, seed=1, min_tok=0, max_tok=24, zipf_s=1.1):
+    """CSR token stream: Zipf-distributed ids (hot rows, like real text), ragged lengths
+    including empty lines.  Returns (ids uint32[T], offsets uint64[n_lines+1])."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(min_tok, max_tok + 1, size=n_lines)
+    T = int(lens.sum())
+    ranks = rng.zipf(zipf_s, size=T).astype(np.int64)
+    ids = ((ranks - 1) % V).astype(np.uint32)
+    offsets = np.zeros(n_lines + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    return ids, offsets
+
+
+def pseudo_prose(n_lines, vocab_size=50000, seed=1, min_words=5, max_words=20):
+    """Config c1's 'plaintext lines': words w<id> drawn Zipf(1.1) from a synthetic vocab."""
+    rng = np.random.default_rng(seed)
+    lines = []
+    for _ in range(n_lines):
+        k = int(rng.integers(min_words, max_words + 1))
+        ranks = (rng.zipf(1.1, size=k) - 1) % vocab_size
+        lines.append(" ".join(f"w{int(r)}" for r in ranks))
+    return lines

@@ -1,0 +1,75 @@
+"""GPU parity: K1 embed (gather + mean-pool + L2-normalise) vs the oracle's pool_ids (A3/A4).
+The kernel reproduces the CPU code's serial f32 chains, so the bar here is bit-exactness."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(gpu_ctx):
+    import semtools_amd as smt
+
+    table = synth.table(5000, seed=2)
+    m = smt.Model(gpu_ctx, table, normalize=True)
+    yield table, m
+    m.close()
+
+
+def test_embed_bit_exact(model):
+    table, m = model
+    ids, offsets = synth.token_lines(1003, V=5000, seed=1, min_tok=0, max_tok=40)
+    got, _ = m.embed(ids, offsets, max_tokens=2048)
+    ref = orc.embed_lines(table, ids, offsets, normalize=True, max_tokens=2048)
+    assert np.array_equal(got, ref), f"max |diff| {np.abs(got - ref).max()}"
+    # empty lines -> zero vectors
+    empty = np.nonzero(np.diff(offsets.astype(np.int64)) == 0)[0]
+    assert empty.size > 0 and not got[empty].any()
+
+
+def test_embed_truncation_and_long_lines(model):
+    table, m = model
+    rng = np.random.default_rng(5)
+    lens = np.array([0, 1, 2, 511, 512, 513, 3000, 7], dtype=np.int64)
+    ids = rng.integers(0, 5000, size=int(lens.sum())).astype(np.uint32)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for cap in (512, 2048, 0):
+        got, _ = m.embed(ids, offsets, max_tokens=cap)
+        ref = orc.embed_lines(table, ids, offsets, normalize=True, max_tokens=cap)
+        assert np.array_equal(got, ref), cap
+
+
+def test_embed_no_normalize(gpu_ctx):
+    import semtools_amd as smt
+
+    table = synth.table(300, seed=12)
+    m = smt.Model(gpu_ctx, table, normalize=False)
+    ids, offsets = synth.token_lines(77, V=300, seed=3)
+    got, _ = m.embed(ids, offsets)
+    assert np.array_equal(got, orc.embed_lines(table, ids, offsets, normalize=False))
+    m.close()
+
+
+def test_embed_appends_to_corpus_and_search(model, gpu_ctx):
+    """create_document_from_content -> search_documents end to end on ids (mod.rs:49-120)."""
+    import semtools_amd as smt
+
+    table, m = model
+    ids, offsets = synth.token_lines(500, V=5000, seed=9, min_tok=1, max_tok=30)
+    c = smt.Corpus(gpu_ctx)
+    _, first = m.embed(ids, offsets, append_to=c, want_host=False)
+    assert first == 0 and c.rows == 500
+    _, first2 = m.embed(ids[: int(offsets[10])], offsets[:11], append_to=c, want_host=False)
+    assert first2 == 500 and c.rows == 510
+    ref = orc.embed_lines(table, ids, offsets)
+    assert np.array_equal(c.read_rows(0, 500), ref)
+    # query = line 17's tokens, 512-token cap like encode_single
+    q, _ = m.embed(ids[int(offsets[17]): int(offsets[18])], np.array([0, offsets[18] - offsets[17]], np.uint64), 512)
+    rows, dist = c.search(q[0], top_k=3)[0]
+    res = orc.search_documents(np.concatenate([ref, ref[:10]]), [510], q[0], 0, 3, accurate=True)
+    assert rows.tolist() == [r["match_line"] for r in res]
+    assert rows[0] in (17, 507) and dist[0] < 1e-6
+    c.close()

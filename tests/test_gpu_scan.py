@@ -1,0 +1,223 @@
+"""GPU parity: K2 scan + top-k / threshold selection vs the CPU oracle (A5 + A6 + A10).
+
+Bar: indices bit-exact, distances within 1e-5.  The
+library does better -- every returned distance is an f64 re-evaluation in index
+order, so we also assert (near) bit-equality with the oracle's "accurate" mode.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_topk(emb, q, k, accurate=True):
+    res = orc.search_documents(emb, [len(emb)], q, n_lines=0, top_k=k, accurate=accurate)
+    return np.array([r["match_line"] for r in res], dtype=np.uint64), np.array([r["distance"] for r in res])
+
+
+@pytest.fixture(scope="module")
+def corpus20k(gpu_ctx):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(20000, seed=3)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    yield emb, c
+    c.close()
+
+
+@pytest.mark.parametrize("k", [1, 3, 10, 56, 64])
+def test_topk_matches_oracle(corpus20k, k):
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    rows, dist = c.search(q, top_k=k)[0]
+    orows, odist = _oracle_topk(emb, q, k)
+    assert rows.tolist() == orows.tolist()
+    np.testing.assert_allclose(dist, odist, rtol=0, atol=1e-12)
+    # reference serial-f32 cosine agrees within the contract's 1e-5
+    srows, sdist = _oracle_topk(emb, q, k, accurate=False)
+    np.testing.assert_allclose(dist, sdist, rtol=0, atol=1e-5)
+
+
+def test_distances_bit_exact_vs_accurate_oracle(corpus20k):
+    emb, c = corpus20k
+    q = synth.unit_query(11)[0]
+    rows, dist = c.search(q, top_k=64)[0]
+    ref = np.array([orc.cosine(q, emb[int(r)], accurate=True) for r in rows])
+    assert np.array_equal(dist, ref), f"max |diff| = {np.abs(dist - ref).max()}"
+
+
+def test_duplicates_and_zero_rows_order(gpu_ctx):
+    """Exact duplicate rows tie bit-for-bit and must come back in row order (stable sort,
+    src/search/mod.rs:107-111); zero rows have distance exactly 1 (simsimd ab==0 rule)."""
+    import semtools_amd as smt
+
+    rng = np.random.default_rng(7)
+    base = synth.unit_rows(3000, seed=8, dup_frac=0, zero_frac=0)
+    q = synth.unit_query(9)[0]
+    emb = base.copy()
+    emb[[5, 77, 300, 2999]] = q                     # 4 copies of the query itself -> distance 0
+    emb[[10, 20]] = 0.0
+    near = (q + 0.01 * rng.standard_normal(256)).astype(np.float32)
+    emb[[1500, 40, 2200]] = near                    # triple tie, must be returned as 40, 1500, 2200
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    rows, dist = c.search(q, top_k=8)[0]
+    orows, odist = _oracle_topk(emb, q, 8)
+    assert rows.tolist() == orows.tolist()
+    assert rows[:7].tolist() == [5, 77, 300, 2999, 40, 1500, 2200]
+    assert np.array_equal(dist, odist)
+    # zero rows: query them explicitly through a range filter
+    r2, d2 = c.search(q, top_k=3, ranges=[(10, 11), (20, 21)])[0]
+    assert r2.tolist() == [10, 20] and d2.tolist() == [1.0, 1.0]
+    # zero query: zero rows are distance 0, everything else 1 (a2==0 && b2==0 -> 0 ; ab==0 -> 1)
+    z = np.zeros(256, np.float32)
+    r3, d3 = c.search(z, top_k=4)[0]
+    o3, od3 = _oracle_topk(emb, z, 4)
+    assert r3.tolist() == o3.tolist() == [10, 20, 0, 1]
+    assert d3.tolist() == od3.tolist() == [0.0, 0.0, 1.0, 1.0]
+    c.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 513, 4097])
+def test_ragged_sizes(gpu_ctx, n):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(n, seed=100 + n, dup_frac=0.05, zero_frac=0.0)
+    q = synth.unit_query(5)[0]
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    for k in (1, 3, 10):
+        rows, dist = c.search(q, top_k=k)[0]
+        orows, odist = _oracle_topk(emb, q, k)
+        assert rows.tolist() == orows.tolist(), (n, k)
+        assert np.array_equal(dist, odist)
+    c.close()
+
+
+def test_empty_corpus_and_topk_zero(gpu_ctx):
+    import semtools_amd as smt
+
+    c = smt.Corpus(gpu_ctx)
+    q = synth.unit_query(5)[0]
+    assert c.search(q, top_k=3)[0][0].size == 0                       # empty docs -> empty (mod.rs:390)
+    c.append(synth.unit_rows(10, seed=1))
+    assert c.search(q, top_k=0)[0][0].size == 0                       # take(0)
+    assert c.search(q, top_k=0, max_distance=0.5, mode=1)[0][0].size == 0  # store.rs:489-491
+    c.close()
+
+
+def test_threshold_mode_returns_all_under_max_distance(corpus20k):
+    """mod.rs:88-89,115-116: strict <, every hit returned, top_k ignored."""
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    for thr in (0.85, 0.9, 1.0):
+        rows, dist = c.search(q, top_k=3, max_distance=thr)[0]
+        res = orc.search_documents(emb, [len(emb)], q, n_lines=0, top_k=3, max_distance=thr, accurate=True)
+        orows = [r["match_line"] for r in res]
+        assert rows.tolist() == orows, thr
+        assert np.array_equal(dist, np.array([r["distance"] for r in res]))
+        assert (dist < thr).all()
+
+
+def test_threshold_truncation_reports_true_count(corpus20k):
+    import ctypes as C
+    from semtools_amd import _lib as L
+
+    emb, c = corpus20k
+    q = synth.unit_query(4)
+    out_rows = np.zeros((1, 5), np.uint64)
+    out_dist = np.zeros((1, 5), np.float64)
+    counts = np.zeros(1, np.uint64)
+    rc = L.lib().smt_search(c._h, L.np_ptr(q), 1, 3, 0.9, 0, None, 0, 0, L.np_ptr(out_rows), L.np_ptr(out_dist),
+                            L.np_ptr(counts), 5)
+    full = c.search(q[0], max_distance=0.9)[0]
+    assert rc == L.SMT_E_TRUNCATED
+    assert int(counts[0]) == full[0].size > 5
+    assert out_rows[0].tolist() == full[0][:5].tolist()
+
+
+def test_multi_query_small_batches(corpus20k):
+    emb, c = corpus20k
+    qs = synth.unit_query(21, nq=7)
+    got = c.search(qs, top_k=5)
+    for i in range(7):
+        orows, odist = _oracle_topk(emb, qs[i], 5)
+        assert got[i][0].tolist() == orows.tolist()
+        assert np.array_equal(got[i][1], odist)
+
+
+def test_range_filter_and_row_base(corpus20k):
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    ranges = [(100, 164), (1000, 1001), (5000, 9000), (19990, 20000)]
+    rows, dist = c.search(q, top_k=10, ranges=ranges, row_base=1_000_000_000_000)[0]
+    mask = np.zeros(len(emb), bool)
+    for b, e in ranges:
+        mask[b:e] = True
+    idx = np.nonzero(mask)[0]
+    orows, odist = _oracle_topk(emb[idx], q, 10)
+    assert (rows - 1_000_000_000_000).tolist() == idx[orows.astype(np.int64)].tolist()
+    assert np.array_equal(dist, odist)
+
+
+def test_workspace_mode_matches_store_semantics(corpus20k):
+    """A10 (store.rs:481-546): score > 1 - max_distance, then ALWAYS top_k."""
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    row_path = (np.arange(len(emb)) // 100).astype(np.uint32)      # 200 docs x 100 lines
+    row_line = (np.arange(len(emb)) % 100).astype(np.int32)
+    subset = np.array([3, 17, 18, 150], np.uint32)
+    ranges = [(int(p) * 100, int(p) * 100 + 100) for p in subset]
+    for thr in (None, 0.95, 0.5):
+        rows, dist = c.search(q, top_k=4, max_distance=thr, mode=1, ranges=ranges)[0]
+        ref = orc.search_line_embeddings(emb, row_path, row_line, q, subset, 4, thr)
+        assert rows.tolist() == [r["row"] for r in ref], thr
+        np.testing.assert_allclose(dist.astype(np.float32), [r["distance"] for r in ref], atol=1e-5)
+
+
+def test_reference_store_known_answer(gpu_ctx):
+    """src/workspace/store.rs:814-850: stored [0.1;256], [0.5;256], [0.75;256]; query [0.1;256],
+    subset = doc1 only, k=1, max_distance 0.1 -> exactly (doc1, line 0, distance < 0.1)."""
+    import semtools_amd as smt
+
+    emb = np.stack([np.full(256, v, np.float32) for v in (0.1, 0.5, 0.75)])
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    rows, dist = c.search(np.full(256, 0.1, np.float32), top_k=1, max_distance=0.1, mode=1, ranges=[(0, 1)])[0]
+    assert rows.tolist() == [0] and dist[0] < 0.1
+    c.close()
+
+
+def test_deterministic(corpus20k):
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    a = c.search(q, top_k=10)[0]
+    b = c.search(q, top_k=10)[0]
+    assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+
+
+def test_shard_merge_equals_single(gpu_ctx, corpus20k):
+    """Row-sharding + merge of per-shard top-k == single-shard result."""
+    import semtools_amd as smt
+
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    want = c.search(q, top_k=10)[0]
+    bounds = [0, 3000, 3001, 12000, 20000]
+    rows, dist = [], []
+    for b, e in zip(bounds[:-1], bounds[1:]):
+        s = smt.Corpus(gpu_ctx)
+        s.append(emb[b:e])
+        r, d = s.search(q, top_k=10, row_base=b)[0]
+        pr = np.full(10, np.iinfo(np.uint64).max, np.uint64)
+        pd = np.full(10, np.inf)
+        pr[: r.size], pd[: d.size] = r, d
+        rows.append(pr[None])
+        dist.append(pd[None])
+        s.close()
+    mr, md, cnt = smt.merge_topk(np.stack(rows), np.stack(dist), 10)
+    assert mr[0].tolist() == want[0].tolist() and np.array_equal(md[0], want[1])
