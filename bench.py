@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the semtools search hot path on MI355X.
+
+Metric (BASELINE.json): chunk-vectors scanned/sec (whole job).  Workload at N=1:
+config c2 = 1 query x 1M chunks, f32, brute-force cosine, top-k on one MI355X
+(HBM-bound single-vector path).  For N>1 the corpus is row-sharded, every rank
+scans ITS 1M-row shard (weak scaling), and the per-shard top-k lists are
+exchanged with one RCCL all-gather + redundant merge -- the only collective on
+the path.
+
+A step = one query end to end: f32 scan of the resident shard -> hierarchical
+top-k merge -> exact f64 rescoring -> (all-gather + merge when N>1) -> async
+copy of the k (row, distance) pairs to pinned host memory.  Inputs (corpus,
+queries) are resident in HBM before the timed region starts; steps are enqueued
+back to back on one stream and the region ends with a full synchronise.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
+torch.distributed.run (one rank per GPU, RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before semtools_amd: one libamdhip64 per process)
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ROW_BYTES = 1024        # 256 x f32 (algorithmic bytes per row)
+
+
+def make_shard(rows, seed, device):
+    """Config c2 generator on the device: unit-normal rows + 1 % exact duplicates + 0.1 % zero rows."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randn(rows, 256, device=device, generator=g, dtype=torch.float32)
+    x /= x.norm(dim=1, keepdim=True)
+    n_dup, n_zero = rows // 100, rows // 1000
+    if n_dup:
+        dst = torch.randperm(rows, device=device, generator=g)[:n_dup]
+        src = torch.randint(0, rows, (n_dup,), device=device, generator=g)
+        x[dst] = x[src]
+    if n_zero:
+        x[torch.randperm(rows, device=device, generator=g)[:n_zero]] = 0.0
+    return x.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows per GPU (c2: 1M)")
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import semtools_amd as smt
+    from semtools_amd import dist as sdist
+
+    k = args.top_k
+    rows = args.rows
+    shard = make_shard(rows, seed=3 + rank, device=device)
+    n_queries = 16
+    gq = torch.Generator(device=device)
+    gq.manual_seed(4)
+    queries = torch.randn(n_queries, 256, device=device, generator=gq)
+    queries /= queries.norm(dim=1, keepdim=True)
+
+    # the library enqueues on torch's current stream, so its kernels, the RCCL
+    # all-gather and the D2H copies are ordered without extra synchronisation
+    stream = torch.cuda.current_stream(device)
+    ctx = smt.Context(local_rank, stream=stream.cuda_stream)
+    corpus = smt.Corpus(ctx, device_ptr=shard.data_ptr(), rows=rows)
+    row_base = rank * rows
+
+    loc_rows = torch.empty((1, k), dtype=torch.int64, device=device)
+    loc_dist = torch.empty((1, k), dtype=torch.float64, device=device)
+    gathered = (torch.empty((world, 1, k), dtype=torch.int64, device=device),
+                torch.empty((world, 1, k), dtype=torch.float64, device=device))
+    fin = (torch.empty((1, k), dtype=torch.int64, device=device), torch.empty((1, k), dtype=torch.float64, device=device))
+    ring = 64
+    host_rows = torch.empty((ring, k), dtype=torch.int64).pin_memory()
+    host_dist = torch.empty((ring, k), dtype=torch.float64).pin_memory()
+
+    def step(i):
+        q = queries[i % n_queries]
+        corpus.search_topk_device(q.data_ptr(), 1, k, row_base, loc_rows.data_ptr(), loc_dist.data_ptr())
+        if world > 1:
+            r, d = sdist.allgather_merge_topk(loc_rows, loc_dist, k, ctx=ctx, gathered=gathered, out=fin)
+        else:
+            r, d = loc_rows, loc_dist
+        host_rows[i % ring].copy_(r[0], non_blocking=True)
+        host_dist[i % ring].copy_(d[0], non_blocking=True)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    n_scan, scan_ms = ctx.prof_read("scan")
+    n_sel, sel_ms = ctx.prof_read("select")
+    ctx.prof_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- sanity of the last step's result against an independent fp64 torch reference
+    last = (args.steps - 1) % n_queries
+    ref = 1.0 - (shard.double() @ queries[last].double())
+    lv, li = torch.topk(ref, k, largest=False)
+    if world == 1:
+        got_rows = host_rows[(args.steps - 1) % ring].numpy()
+        got_dist = host_dist[(args.steps - 1) % ring].numpy()
+        torch_ok = bool(np.allclose(np.sort(got_dist), np.sort(lv.cpu().numpy()), rtol=0, atol=1e-6))
+    else:
+        torch_ok = None
+
+    result = {
+        "metric": "chunk-vectors scanned/sec (whole job)",
+        "value": world * rows * args.steps / elapsed,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "c2: 1 query x 1M chunks (D=256, f32) per GPU, brute-force cosine + top-k",
+                   "rows_per_gpu": rows, "dim": 256, "top_k": k, "queries_rotated": n_queries,
+                   "sharding": "row-sharded, all-gather top-k merge" if world > 1 else "single shard"},
+    }
+    if rank == 0:
+        scan_us = scan_ms / max(n_scan, 1) * 1e3
+        achieved = rows * ROW_BYTES / (scan_us * 1e-6) / 1e9 if n_scan else None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("rows") == rows:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "kernel": "scan_topk_kernel (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+            "algorithmic_bytes_per_launch": rows * ROW_BYTES, "avg_kernel_us": scan_us, "launches": n_scan,
+            "select_avg_us": sel_ms / max(n_sel, 1) * 1e3,
+        }
+        result["checks"] = {"torch_fp64_topk_distances_match": torch_ok}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+
+        host = shard.cpu().numpy()
+        hq = queries.cpu().numpy()
+        # parity of the last measured step against the oracle (indices exact, distances 1e-5 / f64-exact)
+        res = orc.search_documents(host, [rows], hq[last], n_lines=0, top_k=k, accurate=True)
+        result["checks"]["oracle_rows_match"] = [r["match_line"] for r in res] == got_rows.tolist()
+        result["checks"]["oracle_dist_max_abs_diff"] = float(np.abs(np.array([r["distance"] for r in res]) - got_dist).max())
+        # reference-faithful port: single thread, every row's result materialised, stable sort, take(k)
+        t_cpu, n_cpu = 0.0, 0
+        while t_cpu < args.cpu_seconds and n_cpu < 64:
+            c0 = time.perf_counter()
+            orc.search_documents(host, [rows], hq[n_cpu % n_queries], n_lines=3, top_k=k, accurate=False)
+            t_cpu += time.perf_counter() - c0
+            n_cpu += 1
+        ncores = os.cpu_count() or 1
+        f0 = time.perf_counter()
+        n_fair = 0
+        while time.perf_counter() - f0 < min(args.cpu_seconds, 6.0):
+            orc.scan_topk_threads(host, hq[n_fair % n_queries], k, ncores)
+            n_fair += 1
+        t_fair = time.perf_counter() - f0
+        result["cpu_baseline"] = {
+            "value": rows * n_cpu / t_cpu, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{n_cpu} queries x {rows} rows (same shard copied back), oracle restatement of "
+                      "search_documents (src/search/mod.rs:77-120), gcc -O2, single thread as in the reference",
+            "fair_threads_value": rows * n_fair / t_fair, "fair_threads_cores": ncores,
+            "host_cpu": _cpu_model(),
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -64,9 +64,11 @@ typedef struct smt_range {
 
 /* ------------------------------------------------------------------ context */
 
-/* Bind to GPU `device`.  `stream` is an existing hipStream_t to enqueue on
- * (e.g. the host framework's current stream) or NULL to create a private one. */
-int smt_ctx_create(int device, void *stream, smt_ctx **out);
+/* Bind to GPU `device` and create a private (non-blocking) HIP stream. */
+int smt_ctx_create(int device, smt_ctx **out);
+/* Same, but enqueue on an existing hipStream_t owned by the caller (e.g. the
+ * host framework's current stream).  NULL here means THE NULL STREAM. */
+int smt_ctx_create_on_stream(int device, void *stream, smt_ctx **out);
 void smt_ctx_destroy(smt_ctx *ctx);
 int smt_ctx_synchronize(smt_ctx *ctx);
 const char *smt_last_error(void);

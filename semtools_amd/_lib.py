@@ -18,7 +18,7 @@ MODE_DOCUMENTS, MODE_WORKSPACE = 0, 1
 DIM = 256
 
 EXPORTS = [
-    "smt_ctx_create", "smt_ctx_destroy", "smt_ctx_synchronize", "smt_last_error", "smt_version",
+    "smt_ctx_create", "smt_ctx_create_on_stream", "smt_ctx_destroy", "smt_ctx_synchronize", "smt_last_error", "smt_version",
     "smt_device_count", "smt_prof_enable", "smt_prof_reset", "smt_prof_read",
     "smt_model_create", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
@@ -59,13 +59,23 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SmtError(SMT_E_HIP, f"{LIB_PATH} not built; run semtools_amd/csrc/build.sh (no CPU fallback exists)")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (SONAME libamdhip64.so.7,
+    # the same SONAME the system ROCm one has).  If torch is going to be used in this process it must
+    # be loaded FIRST so that our NEEDED libamdhip64.so.7 resolves to the copy torch already mapped;
+    # the other order maps two runtimes and the second one sees no devices.
+    if os.environ.get("SEMTOOLS_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
     P = C.POINTER
     L.smt_last_error.restype = C.c_char_p
     L.smt_version.restype = C.c_char_p
     L.smt_device_count.restype = i32
-    L.smt_ctx_create.argtypes = [i32, vp, P(vp)]
+    L.smt_ctx_create.argtypes = [i32, P(vp)]
+    L.smt_ctx_create_on_stream.argtypes = [i32, vp, P(vp)]
     L.smt_ctx_destroy.argtypes = [vp]
     L.smt_ctx_destroy.restype = None
     L.smt_ctx_synchronize.argtypes = [vp]

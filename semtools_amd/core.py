@@ -12,11 +12,18 @@ def _f32c(a):
 
 
 class Context:
-    """One GPU + one HIP stream (smt_ctx).  `stream` = raw hipStream_t int or None."""
+    """One GPU + one HIP stream (smt_ctx).
+
+    stream=None: the library creates a private non-blocking stream.
+    stream=<int>: raw hipStream_t to enqueue on (0 = the null stream), e.g.
+    torch.cuda.current_stream().cuda_stream."""
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
-        L.check(L.lib().smt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if stream is None:
+            L.check(L.lib().smt_ctx_create(int(device), C.byref(self._h)))
+        else:
+            L.check(L.lib().smt_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(self._h)))
         self.device = device
 
     def close(self):

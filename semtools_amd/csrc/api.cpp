@@ -111,7 +111,7 @@ int smt_device_count(void)
     return n;
 }
 
-int smt_ctx_create(int device, void *stream, smt_ctx **out)
+static int ctx_create_impl(int device, void *stream, bool use_given, smt_ctx **out)
 {
     SMT_REQUIRE(out != nullptr, "out");
     *out = nullptr;
@@ -130,7 +130,7 @@ int smt_ctx_create(int device, void *stream, smt_ctx **out)
     if (!ctx) { set_error("out of host memory"); return SMT_E_NOMEM; }
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    if (stream) {
+    if (use_given) {
         ctx->stream = reinterpret_cast<hipStream_t>(stream);
         ctx->own_stream = false;
     } else {
@@ -140,6 +140,13 @@ int smt_ctx_create(int device, void *stream, smt_ctx **out)
     }
     *out = ctx;
     return SMT_OK;
+}
+
+int smt_ctx_create(int device, smt_ctx **out) { return ctx_create_impl(device, nullptr, false, out); }
+
+int smt_ctx_create_on_stream(int device, void *stream, smt_ctx **out)
+{
+    return ctx_create_impl(device, stream, true, out);
 }
 
 void smt_ctx_destroy(smt_ctx *ctx)

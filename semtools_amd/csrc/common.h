@@ -47,9 +47,9 @@ struct ProfEntry {
 };
 
 struct Tuning {
-    int scan_blocks = 0;        // 0 = 2 * CU count
-    int scan_threads = 512;
-    int scan_unroll = 8;
+    int scan_blocks = 0;        // 0 = CU count (one block list per CU feeds the select stage)
+    int scan_threads = 1024;
+    int scan_unroll = 4;
     int scan_nontemporal = 1;
     int gemm_blocks = 0;        // 0 = CU count
 };
@@ -140,6 +140,10 @@ struct ThresholdArgs {
 int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a);
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
                         uint64_t n, double *out_dist);
+
+int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
+                  uint32_t n_lists, uint32_t kp, uint32_t k_out, int ws_threshold, float ws_thr_score,
+                  uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts);
 
 int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,

@@ -257,17 +257,32 @@ __global__ void __launch_bounds__(1024) scan_threshold_kernel(ThrParams p)
 
 // --------------------------------------------------- exact f64 distance (A5)
 // Bit-for-bit the oracle's orc_cosine_f32_accurate: f64 accumulators, index
-// order, no FMA contraction, then cos_finish.
-__device__ double exact_distance(const float *__restrict__ q, const float *__restrict__ r)
+// order, then cos_finish.  The product of two f32 values is exact in f64, so
+// fma(a, b, acc) rounds exactly like acc + a*b: letting the compiler contract
+// to v_fma_f64 cannot change a bit (the oracle is built with contraction off).
+// cos_finish of the oracle.  Contraction OFF here: 1 - (ab*ra)*rb must round the
+// products before the subtraction exactly as the CPU code does.
+__device__ __forceinline__ double cos_finish_exact(double ab, double a2, double b2)
 {
 #pragma clang fp contract(off)
+    if (a2 == 0.0 && b2 == 0.0) return 0.0;
+    if (ab == 0.0) return 1.0;
+    const double ra = 1.0 / sqrt(a2);
+    const double rb = 1.0 / sqrt(b2);
+    const double t = ab * ra;
+    const double u = t * rb;
+    const double unclipped = 1.0 - u;
+    return unclipped > 0.0 ? unclipped : 0.0;
+}
+
+template <typename QP, typename RP>
+__device__ __forceinline__ double exact_distance(QP q4, RP r4)
+{
     double ab = 0.0, a2 = 0.0, b2 = 0.0;
-    const float4 *q4 = reinterpret_cast<const float4 *>(q);
-    const float4 *r4 = reinterpret_cast<const float4 *>(r);
 #pragma unroll 4
     for (int i = 0; i < 64; ++i) {
-        const float4 a = q4[i];
-        const float4 b = r4[i];
+        const f32x4 a = q4[i];
+        const f32x4 b = r4[i];
         const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
         const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
         ab = ab + ax * bx; a2 = a2 + ax * ax; b2 = b2 + bx * bx;
@@ -275,25 +290,44 @@ __device__ double exact_distance(const float *__restrict__ q, const float *__res
         ab = ab + az * bz; a2 = a2 + az * az; b2 = b2 + bz * bz;
         ab = ab + aw * bw; a2 = a2 + aw * aw; b2 = b2 + bw * bw;
     }
-    if (a2 == 0.0 && b2 == 0.0) return 0.0;
-    if (ab == 0.0) return 1.0;
-    const double unclipped = 1.0 - ab * (1.0 / sqrt(a2)) * (1.0 / sqrt(b2));
-    return unclipped > 0.0 ? unclipped : 0.0;
+    return cos_finish_exact(ab, a2, b2);
 }
 
 __global__ void rescore_rows_kernel(const float *corpus, const float *query, const uint32_t *rows,
                                     uint64_t n, double *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = exact_distance(query, corpus + (uint64_t)rows[i] * 256);
+    if (i < n)
+        out[i] = exact_distance(reinterpret_cast<const f32x4 *>(query),
+                                reinterpret_cast<const f32x4 *>(corpus + (uint64_t)rows[i] * 256));
 }
 
-// -------------------------------------------- merge block lists + f64 rescoring
-struct MergeParams {
+// ------------------------------------------------ select: prune, rank, rescore
+// Input: n_lists sorted lists (one per scan block) of kp keys each, ascending,
+// padded with KEY_PAD; valid keys are distinct (distinct rows).  We need the kp
+// smallest keys of the union WITHOUT sorting M = n_lists*kp keys.
+//
+// Pruning bound.  For a column j (1-based) let c_j = ceil(kp / j) and let
+// tau_j be the c_j-th smallest of the lists' j-th entries.  At least c_j lists
+// hold >= j keys <= tau_j, i.e. >= kp keys of the union are <= tau_j, so the
+// union's kp-th smallest key is <= tau_j.  tau = min over a dyadic set of
+// columns {1,2,4,..,kp}.  Keys > tau can be dropped.  Survivors are few: if
+// m_b = #keys of list b that are <= tau then #{b : m_b >= j} <= c_j' for the
+// largest used column j' <= j, hence S = sum_b m_b <= sum_j' (gap_j' * c_j')
+// which is <= kp * (log2(kp) + 2) in the WORST case (<= 512 for kp <= 72), and
+// about kp + 2 on uncorrelated data (column 1 alone is then nearly tight).
+// Survivors are ranked by counting (S^2 / threads compares), no sort.
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAX_LISTS = 512;
+constexpr int SEL_MAX_COLS = 8;
+constexpr int SEL_SURV_CAP = 1024;
+constexpr int ROW_STRIDE_F4 = 65;  // LDS row stride in float4 (1040 B): conflict-free b128 reads
+
+struct FinalParams {
     const float *corpus;
     const float *queries;
-    const key_t64 *block_lists;  // [nq][n_blocks][kp]
-    uint32_t n_blocks;
+    const key_t64 *lists;  // [nq][n_lists][kp], n_lists <= SEL_MAX_LISTS
+    uint32_t n_lists;
     uint32_t kp;
     uint32_t k_out;
     int ws_threshold;
@@ -304,93 +338,97 @@ struct MergeParams {
     uint64_t *out_counts; // [nq] or nullptr
 };
 
-constexpr int MERGE_THREADS = 1024;
-constexpr int MERGE_BUF = 4096;
-
-__device__ void bitonic_sort_lds(key_t64 *buf)
+// One block per query.
+__global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p)
 {
-    for (int k = 2; k <= MERGE_BUF; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < MERGE_BUF; i += MERGE_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const key_t64 a = buf[i], b = buf[ixj];
-                    const bool asc = ((i & k) == 0);
-                    if ((a > b) == asc) { buf[i] = b; buf[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__global__ void __launch_bounds__(MERGE_THREADS) merge_rescore_kernel(MergeParams p)
-{
-    __shared__ key_t64 buf[MERGE_BUF];
-    __shared__ unsigned int s_cnt;
-    __shared__ key_t64 s_tau;
-    __shared__ double s_d[64 + 8];
-    __shared__ uint32_t s_r[64 + 8];
-    __shared__ unsigned int s_valid;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int kp = (int)p.kp;
+    const int L = (int)p.n_lists;
+    // LDS carve (all offsets multiples of 16; no static LDS in this kernel):
+    f32x4 *s_rows = reinterpret_cast<f32x4 *>(smem_raw);                       // [kp+1][65] float4
+    key_t64 *s_col = reinterpret_cast<key_t64 *>(s_rows + (size_t)(kp + 1) * ROW_STRIDE_F4);  // [ncols][L]
+    key_t64 *s_surv = s_col + (size_t)SEL_MAX_COLS * L;                        // [SEL_SURV_CAP]
+    key_t64 *s_best = s_surv + SEL_SURV_CAP;                                   // [kp] (+pad to even)
+    double *s_d = reinterpret_cast<double *>(s_best + ((kp + 1) & ~1));        // [kp]
+    uint32_t *s_r = reinterpret_cast<uint32_t *>(s_d + ((kp + 1) & ~1));       // [kp]
+    key_t64 *s_tau = reinterpret_cast<key_t64 *>(s_r + ((kp + 3) & ~3));       // [1]
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_tau + 1);         // [0]=survivors [1]=valid
 
     const uint32_t qi = blockIdx.x;
-    const key_t64 *lists = p.block_lists + (size_t)qi * p.n_blocks * p.kp;
-    const uint64_t M = (uint64_t)p.n_blocks * p.kp;
-    const int kp = (int)p.kp;
+    const key_t64 *lists = p.lists + (size_t)qi * L * kp;
 
-    // tau = min over blocks of the block's kp-th key: an upper bound of the
-    // global kp-th key, so keys > tau can never make the final list.
-    if (threadIdx.x == 0) { s_tau = KEY_PAD; s_cnt = 0; s_valid = 0; }
-    __syncthreads();
-    key_t64 local = KEY_PAD;
-    for (uint32_t b = threadIdx.x; b < p.n_blocks; b += MERGE_THREADS) {
-        const key_t64 kth = lists[(size_t)b * kp + (kp - 1)];
-        local = kth < local ? kth : local;
+    // dyadic columns 1,2,4,.. < kp, plus kp
+    int cols[SEL_MAX_COLS];
+    int ncols = 0;
+    for (int j = 1; j < kp && ncols < SEL_MAX_COLS - 1; j <<= 1) cols[ncols++] = j;
+    cols[ncols++] = kp;
+
+    for (int e = threadIdx.x; e < ncols * L; e += blockDim.x) {
+        const int jj = e / L, b = e - jj * L;
+        s_col[(size_t)jj * L + b] = lists[(size_t)b * kp + (cols[jj] - 1)];
     }
-    atomicMin(&s_tau, local);
+    if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; }
+    for (int t = threadIdx.x; t < kp; t += blockDim.x) s_best[t] = KEY_PAD;
     __syncthreads();
-    const key_t64 tau = s_tau;
 
-    for (uint64_t base = 0; base < M; base += MERGE_THREADS) {
-        // make room for up to MERGE_THREADS new keys
-        if (s_cnt > MERGE_BUF - MERGE_THREADS) {
-            for (int i = s_cnt + threadIdx.x; i < MERGE_BUF; i += MERGE_THREADS) buf[i] = KEY_PAD;
-            __syncthreads();
-            bitonic_sort_lds(buf);
-            if (threadIdx.x == 0) s_cnt = kp;
-            __syncthreads();
-        }
-        const uint64_t i = base + threadIdx.x;
-        const key_t64 key = i < M ? lists[i] : KEY_PAD;
+    // tau_j: the value whose rank inside its column is c_j - 1
+    for (int e = threadIdx.x; e < ncols * L; e += blockDim.x) {
+        const int jj = e / L, b = e - jj * L;
+        const key_t64 v = s_col[(size_t)jj * L + b];
+        if (v == KEY_PAD) continue;
+        const int c = (kp + cols[jj] - 1) / cols[jj];
+        const key_t64 *col = s_col + (size_t)jj * L;
+        int rank = 0;
+        for (int i = 0; i < L; ++i) rank += (col[i] < v) ? 1 : 0;
+        if (rank == c - 1) atomicMin(s_tau, v);
+    }
+    __syncthreads();
+    const key_t64 tau = *s_tau;
+
+    // compact the survivors (keys <= tau); lists are sorted so stop at the first miss
+    for (int e = threadIdx.x; e < L * kp; e += blockDim.x) {
+        const key_t64 key = lists[e];
         if (key != KEY_PAD && key <= tau) {
-            const unsigned int slot = atomicAdd(&s_cnt, 1u);
-            buf[slot] = key;
+            const unsigned int slot = atomicAdd(&s_cnt[0], 1u);
+            if (slot < (unsigned)SEL_SURV_CAP) s_surv[slot] = key;
         }
-        __syncthreads();
     }
-    for (int i = s_cnt + threadIdx.x; i < MERGE_BUF; i += MERGE_THREADS) buf[i] = KEY_PAD;
     __syncthreads();
-    bitonic_sort_lds(buf);
+    const int S = min((int)s_cnt[0], SEL_SURV_CAP);  // bound above guarantees S <= cap for kp <= 72
+    for (int e = threadIdx.x; e < S; e += blockDim.x) {
+        const key_t64 key = s_surv[e];
+        int rank = 0;
+        for (int i = 0; i < S; ++i) rank += (s_surv[i] < key) ? 1 : 0;
+        if (rank < kp) s_best[rank] = key;
+    }
+    __syncthreads();
 
-    // f64 rescoring of the kp best f32 candidates
-    const float *q = p.queries + (size_t)qi * 256;
+    // stage query (slot kp) + candidate rows: one wave per row, 16 B per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (int c = wave; c <= kp; c += n_waves) {
+        const float *g = nullptr;
+        if (c == kp) g = p.queries + (size_t)qi * 256;
+        else if (s_best[c] != KEY_PAD) g = p.corpus + (uint64_t)(uint32_t)(s_best[c] & 0xFFFFFFFFull) * 256;
+        if (g) s_rows[(size_t)c * ROW_STRIDE_F4 + lane] = reinterpret_cast<const f32x4 *>(g)[lane];
+    }
+    __syncthreads();
+
     if ((int)threadIdx.x < kp) {
-        const key_t64 key = buf[threadIdx.x];
+        const key_t64 key = s_best[threadIdx.x];
         double d = __builtin_inf();
         uint32_t r = 0xFFFFFFFFu;
         if (key != KEY_PAD) {
             r = (uint32_t)(key & 0xFFFFFFFFull);
-            d = exact_distance(q, p.corpus + (uint64_t)r * 256);
+            d = exact_distance(s_rows + (size_t)kp * ROW_STRIDE_F4, s_rows + (size_t)threadIdx.x * ROW_STRIDE_F4);
             if (p.ws_threshold) {
-                // qdrant score_threshold: keep score > threshold (similarity metrics)
+                // qdrant score_threshold keeps score > threshold (similarity metrics)
                 if (!((1.0 - d) > (double)p.ws_thr_score)) { d = __builtin_inf(); r = 0xFFFFFFFFu; }
             }
         }
         s_d[threadIdx.x] = d;
         s_r[threadIdx.x] = r;
-        if (r != 0xFFFFFFFFu) atomicAdd(&s_valid, 1u);
+        if (r != 0xFFFFFFFFu) atomicAdd(&s_cnt[1], 1u);
     }
-    __syncthreads();
     uint64_t *orow = p.out_rows + (size_t)qi * p.k_out;
     double *odist = p.out_dist + (size_t)qi * p.k_out;
     if (threadIdx.x < p.k_out) { orow[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull; odist[threadIdx.x] = __builtin_inf(); }
@@ -407,7 +445,13 @@ __global__ void __launch_bounds__(MERGE_THREADS) merge_rescore_kernel(MergeParam
         if ((uint32_t)rank < p.k_out) { orow[rank] = p.row_base + r; odist[rank] = d; }
     }
     if (threadIdx.x == 0 && p.out_counts)
-        p.out_counts[qi] = s_valid < p.k_out ? s_valid : p.k_out;
+        p.out_counts[qi] = s_cnt[1] < p.k_out ? s_cnt[1] : p.k_out;
+}
+
+static size_t final_smem_bytes(uint32_t n_lists, uint32_t kp)
+{
+    return (size_t)(kp + 1) * ROW_STRIDE_F4 * 16 + (size_t)SEL_MAX_COLS * n_lists * 8 + (size_t)SEL_SURV_CAP * 8 +
+           (size_t)(kp + 2) * 8 * 2 + (size_t)(kp + 4) * 4 + 64;
 }
 
 // ------------------------------------------------- cross-shard top-k merge
@@ -465,12 +509,45 @@ static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, in
     return SMT_OK;
 }
 
+// Block lists -> final answer in ONE launch (per query: prune + rank + rescore).
+int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
+                  uint32_t n_lists, uint32_t kp, uint32_t k_out, int ws_threshold, float ws_thr_score,
+                  uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts)
+{
+    SMT_REQUIRE(n_lists >= 1 && n_lists <= (uint32_t)SEL_MAX_LISTS, "select stage accepts 1..512 block lists");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    FinalParams f;
+    f.corpus = corpus;
+    f.queries = queries;
+    f.lists = lists;
+    f.n_lists = n_lists;
+    f.kp = kp;
+    f.k_out = k_out;
+    f.ws_threshold = ws_threshold;
+    f.ws_thr_score = ws_thr_score;
+    f.row_base = row_base;
+    f.out_rows = out_rows;
+    f.out_dist = out_dist;
+    f.out_counts = out_counts;
+    prof_begin(ctx, "select");
+    hipLaunchKernelGGL(final_select_kernel, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
+    prof_end(ctx, "select");
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
 {
     SMT_REQUIRE(a.k_out >= 1 && a.k_out <= 64, "top_k for the scan path must be in [1, 64]");
-    SMT_REQUIRE(a.rows < (1ull << 32), "a shard holds fewer than 2^32 rows");
+    SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const uint32_t kp = candidates_per_list(a.k_out);
-    int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : 2 * ctx->num_cus;
+    int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : ctx->num_cus;
+    if (blocks > SEL_MAX_LISTS) blocks = SEL_MAX_LISTS;
     const int threads = ctx->tune.scan_threads;
     const int U = ctx->tune.scan_unroll;
     const uint64_t waves = (uint64_t)blocks * (threads / 64);
@@ -478,8 +555,8 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         const uint64_t need = (a.n_virtual + (uint64_t)U * (threads / 64) - 1) / ((uint64_t)U * (threads / 64));
         blocks = (int)(need > 0 ? need : 1);
     }
-    const size_t list_bytes = (size_t)a.nq * blocks * kp * sizeof(key_t64);
-    int rc = ensure_scratch(ctx, list_bytes);
+    const size_t list_keys = (size_t)a.nq * blocks * kp;
+    int rc = ensure_scratch(ctx, list_keys * sizeof(key_t64));
     if (rc != SMT_OK) return rc;
     key_t64 *lists = reinterpret_cast<key_t64 *>(ctx->d_scratch);
 
@@ -514,25 +591,8 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         if (rc != SMT_OK) return rc;
     }
     prof_end(ctx, "scan");
-
-    MergeParams m;
-    m.corpus = a.corpus;
-    m.queries = a.queries;
-    m.block_lists = lists;
-    m.n_blocks = (uint32_t)blocks;
-    m.kp = kp;
-    m.k_out = a.k_out;
-    m.ws_threshold = a.ws_threshold;
-    m.ws_thr_score = a.ws_thr_score;
-    m.row_base = a.row_base;
-    m.out_rows = a.out_rows;
-    m.out_dist = a.out_dist;
-    m.out_counts = a.out_counts;
-    prof_begin(ctx, "select");
-    hipLaunchKernelGGL(merge_rescore_kernel, dim3(a.nq), dim3(MERGE_THREADS), 0, ctx->stream, m);
-    prof_end(ctx, "select");
-    SMT_HIP_CHECK(hipGetLastError());
-    return SMT_OK;
+    return launch_select(ctx, a.corpus, a.queries, a.nq, lists, (uint32_t)blocks, kp, a.k_out, a.ws_threshold,
+                         a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts);
 }
 
 int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a)
