@@ -38,8 +38,9 @@ def allgather_merge_topk(local_rows, local_dist, k_out, ctx=None, group=None, ga
     else:
         g_rows, g_dist = gathered
     if world > 1:
-        dist.all_gather_into_tensor(g_rows, local_rows.contiguous(), group=group)
-        dist.all_gather_into_tensor(g_dist, local_dist.contiguous(), group=group)
+        # flat [world*nq, k] views: the layout is [rank][query][k] either way
+        dist.all_gather_into_tensor(g_rows.view(world * nq, k_in), local_rows.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_dist.view(world * nq, k_in), local_dist.contiguous(), group=group)
     else:
         g_rows[0].copy_(local_rows)
         g_dist[0].copy_(local_dist)

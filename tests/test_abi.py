@@ -1,0 +1,106 @@
+"""CPU: the C-ABI library loads, exports every symbol include/semtools_hip.h declares, its host-only
+helpers agree with the oracle, and every compute entry point FAILS LOUDLY without a GPU
+(there is no CPU fallback to fall into)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import semtools_amd as smt
+from semtools_amd import _lib as L
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "semtools_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(L.LIB_PATH), "run semtools_amd/csrc/build.sh (or __graft_entry__.build())"
+    assert os.path.dirname(L.LIB_PATH).startswith(ROOT)
+
+
+def test_every_declared_symbol_is_exported():
+    names = _declared()
+    assert len(names) >= 30
+    lib = L.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in semtools_hip.h but not exported"
+    assert sorted(L.EXPORTS) == names, "semtools_amd/_lib.py EXPORTS out of sync with the header"
+    dyn = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH], text=True)
+    for n in names:
+        assert re.search(rf"\bT {n}\b", dyn), n
+
+
+def test_contains_gfx950_code_object():
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"scan_topk_kernel" in blob
+
+
+def test_host_ids_match_oracle():
+    lib = L.lib()
+    for path, line in (("/test/doc1.txt", 0), ("a", 7), ("päth/ü.txt", 123456), ("x", -1)):
+        assert lib.smt_line_embedding_id(path.encode(), line) == orc.line_embedding_id(path, line)
+        assert lib.smt_doc_meta_id(path.encode()) == orc.doc_meta_id(path)
+    assert lib.smt_fnv1a_hash(b"foobar", 6) == 0x85944171F73967E8
+
+
+def test_host_merge_topk():
+    rng = np.random.default_rng(0)
+    n_lists, nq, k = 5, 3, 6
+    rows = np.full((n_lists, nq, k), np.iinfo(np.uint64).max, np.uint64)
+    dist = np.full((n_lists, nq, k), np.inf)
+    truth = [[] for _ in range(nq)]
+    for l in range(n_lists):
+        for q in range(nq):
+            n = int(rng.integers(0, k + 1))
+            d = np.sort(np.round(rng.random(n), 1))                 # coarse -> ties across lists
+            r = np.sort(rng.choice(1000, n, replace=False)) + 1000 * l
+            order = np.lexsort((r, d))
+            rows[l, q, :n], dist[l, q, :n] = r[order], d[order]
+            truth[q] += list(zip(d[order].tolist(), (r[order]).tolist()))
+    mr, md, cnt = smt.merge_topk(rows, dist, 4)
+    for q in range(nq):
+        want = sorted(truth[q])[:4]
+        assert cnt[q] == len(want)
+        assert mr[q, : len(want)].tolist() == [w[1] for w in want]
+        assert md[q, : len(want)].tolist() == [w[0] for w in want]
+        assert (mr[q, len(want):] == np.iinfo(np.uint64).max).all() and np.isinf(md[q, len(want):]).all()
+
+
+@pytest.mark.skipif(L.lib().smt_device_count() > 0, reason="a GPU is present")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(smt.SmtError) as e:
+        smt.Context(0)
+    assert e.value.code == L.SMT_E_HIP
+    h = C.c_void_p()
+    assert L.lib().smt_ctx_create(0, C.byref(h)) == L.SMT_E_HIP and not h
+    assert b"hip" in L.lib().smt_last_error().lower()
+
+
+def test_null_handles_are_rejected():
+    lib = L.lib()
+    assert lib.smt_corpus_rows(None) == 0 and lib.smt_corpus_dim(None) == 0
+    assert lib.smt_search(None, None, 1, 1, float("nan"), 0, None, 0, 0, None, None, None, 0) == L.SMT_E_INVALID
+    assert lib.smt_embed(None, None, None, 0, 0, None, None, None) == L.SMT_E_INVALID
+    assert lib.smt_ctx_synchronize(None) == L.SMT_E_INVALID
+    lib.smt_ctx_destroy(None); lib.smt_model_destroy(None); lib.smt_corpus_destroy(None)  # no-ops
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "semtools_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.replace("the oracle", "").replace("oracle/", "ORACLE_DOC/").lower() or \
+                    all("import" not in ln and "#include" not in ln and "dlopen" not in ln and "CDLL" not in ln
+                        for ln in text.splitlines() if "oracle" in ln.lower()), f
