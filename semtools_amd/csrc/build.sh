@@ -9,7 +9,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -fno-
 objs=()
 for src in api.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip; do
   obj="$out/${src%.*}.o"
-  if [[ ! -f "$obj" || "$here/$src" -nt "$obj" || "$here/common.h" -nt "$obj" || "$here/../../include/semtools_hip.h" -nt "$obj" ]]; then
+  if [[ ! -f "$obj" || "$here/$src" -nt "$obj" || "$here/common.h" -nt "$obj" || "$here/device_utils.h" -nt "$obj" || "$here/../../include/semtools_hip.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" -x hip -c "$here/$src" -o "$obj" ${EXTRA_HIPCC_FLAGS:-}
   fi
   objs+=("$obj")

@@ -142,8 +142,9 @@ int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, c
                         uint64_t n, double *out_dist);
 
 int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
-                  uint32_t n_lists, uint32_t kp, uint32_t k_out, int ws_threshold, float ws_thr_score,
-                  uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts);
+                  uint32_t n_lists, uint32_t kp, uint64_t list_stride, uint32_t k_out, int ws_threshold,
+                  float ws_thr_score, uint64_t row_base, uint64_t *out_rows, double *out_dist,
+                  uint64_t *out_counts);
 
 int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,

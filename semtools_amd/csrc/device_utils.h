@@ -1,0 +1,60 @@
+// device_utils.h -- wave64 / DPP helpers shared by the gfx950 kernels.
+#pragma once
+#include "common.h"
+
+namespace smt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ DPP helpers
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i within 16
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave
+
+// Sum over the 64 lanes, result in every lane.  Fixed tree => deterministic.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
+    const float s0 = readlane_f(v, 0), s1 = readlane_f(v, 16);
+    const float s2 = readlane_f(v, 32), s3 = readlane_f(v, 48);
+    return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ float dist_f32(float ab, float b2, float rq, bool q_zero)
+{
+    // simsimd rules (oracle/semtools_oracle.c cos_finish): both zero -> 0,
+    // ab == 0 -> 1, else max(0, 1 - ab * rsqrt(a2) * rsqrt(b2)).  rq = 0 when
+    // the query is the zero vector, so "ab == 0 -> 1" falls out of the formula.
+    if (b2 == 0.0f) return q_zero ? 0.0f : 1.0f;
+    const float d = 1.0f - ab * rq * __frsqrt_rn(b2);
+    return fmaxf(d, 0.0f);
+}
+
+__device__ __forceinline__ key_t64 make_key(float d, uint32_t row)
+{
+    return ((key_t64)__float_as_uint(d) << 32) | (key_t64)row;
+}
+
+
+}  // namespace smt

@@ -16,60 +16,9 @@
 // k' rows with f64 accumulation in index order (simsimd "accurate" formula),
 // so returned distances/ordering do not depend on the reduction tree.
 #include "common.h"
+#include "device_utils.h"
 
 namespace smt {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------ DPP helpers
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
-}
-__device__ __forceinline__ float readlane_f(float v, int lane)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-
-constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within 8
-constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i within 16
-constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave
-
-// Sum over the 64 lanes, result in every lane.  Fixed tree => deterministic.
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v += dpp_f<DPP_XOR1>(v);
-    v += dpp_f<DPP_XOR2>(v);
-    v += dpp_f<DPP_HALF_MIRROR>(v);
-    v += dpp_f<DPP_MIRROR>(v);
-    const float s0 = readlane_f(v, 0), s1 = readlane_f(v, 16);
-    const float s2 = readlane_f(v, 32), s3 = readlane_f(v, 48);
-    return (s0 + s1) + (s2 + s3);
-}
-
-__device__ __forceinline__ float dist_f32(float ab, float b2, float rq, bool q_zero)
-{
-    // simsimd rules (oracle/semtools_oracle.c cos_finish): both zero -> 0,
-    // ab == 0 -> 1, else max(0, 1 - ab * rsqrt(a2) * rsqrt(b2)).  rq = 0 when
-    // the query is the zero vector, so "ab == 0 -> 1" falls out of the formula.
-    if (b2 == 0.0f) return q_zero ? 0.0f : 1.0f;
-    const float d = 1.0f - ab * rq * __frsqrt_rn(b2);
-    return fmaxf(d, 0.0f);
-}
-
-__device__ __forceinline__ key_t64 make_key(float d, uint32_t row)
-{
-    return ((key_t64)__float_as_uint(d) << 32) | (key_t64)row;
-}
 
 // Map a virtual row (position inside the concatenated ranges) to a corpus row.
 __device__ __forceinline__ uint32_t map_virtual(uint64_t v, const smt_range *ranges,
@@ -326,8 +275,9 @@ constexpr int ROW_STRIDE_F4 = 65;  // LDS row stride in float4 (1040 B): conflic
 struct FinalParams {
     const float *corpus;
     const float *queries;
-    const key_t64 *lists;  // [nq][n_lists][kp], n_lists <= SEL_MAX_LISTS
-    uint32_t n_lists;
+    const key_t64 *lists;  // query qi's lists start at lists + qi*list_stride: [n_lists][kp]
+    uint64_t list_stride;  // in keys
+    uint32_t n_lists;      // <= SEL_MAX_LISTS
     uint32_t kp;
     uint32_t k_out;
     int ws_threshold;
@@ -355,7 +305,7 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_tau + 1);         // [0]=survivors [1]=valid
 
     const uint32_t qi = blockIdx.x;
-    const key_t64 *lists = p.lists + (size_t)qi * L * kp;
+    const key_t64 *lists = p.lists + (size_t)qi * p.list_stride;
 
     // dyadic columns 1,2,4,.. < kp, plus kp
     int cols[SEL_MAX_COLS];
@@ -511,8 +461,9 @@ static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, in
 
 // Block lists -> final answer in ONE launch (per query: prune + rank + rescore).
 int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
-                  uint32_t n_lists, uint32_t kp, uint32_t k_out, int ws_threshold, float ws_thr_score,
-                  uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts)
+                  uint32_t n_lists, uint32_t kp, uint64_t list_stride, uint32_t k_out, int ws_threshold,
+                  float ws_thr_score, uint64_t row_base, uint64_t *out_rows, double *out_dist,
+                  uint64_t *out_counts)
 {
     SMT_REQUIRE(n_lists >= 1 && n_lists <= (uint32_t)SEL_MAX_LISTS, "select stage accepts 1..512 block lists");
     static bool attr_set = false;
@@ -525,6 +476,7 @@ int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint3
     f.corpus = corpus;
     f.queries = queries;
     f.lists = lists;
+    f.list_stride = list_stride;
     f.n_lists = n_lists;
     f.kp = kp;
     f.k_out = k_out;
@@ -591,8 +543,8 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         if (rc != SMT_OK) return rc;
     }
     prof_end(ctx, "scan");
-    return launch_select(ctx, a.corpus, a.queries, a.nq, lists, (uint32_t)blocks, kp, a.k_out, a.ws_threshold,
-                         a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts);
+    return launch_select(ctx, a.corpus, a.queries, a.nq, lists, (uint32_t)blocks, kp, (uint64_t)blocks * kp, a.k_out,
+                         a.ws_threshold, a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts);
 }
 
 int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a)

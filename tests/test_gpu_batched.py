@@ -1,0 +1,83 @@
+"""GPU parity: K3 batched path (f32 MFMA Q x C^T + fused candidate selection) vs the oracle and
+vs the single-query K2 path.  Same bar: indices exact, distances = oracle f64 values."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_topk(emb, q, k):
+    res = orc.search_documents(emb, [len(emb)], q, n_lines=0, top_k=k, accurate=True)
+    return [r["match_line"] for r in res], [r["distance"] for r in res]
+
+
+@pytest.mark.parametrize("n_rows,nq,k", [(20000, 8, 5), (20000, 33, 10), (4097, 64, 3), (50000, 100, 10),
+                                          (1000, 9, 24), (31, 8, 4), (70000, 40, 1)])
+def test_batched_matches_oracle(gpu_ctx, n_rows, nq, k):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(n_rows, seed=3 + n_rows)
+    qs = synth.unit_query(50 + nq, nq=nq)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    got = c.search(qs, top_k=k)
+    for i in range(nq):
+        orows, odist = _oracle_topk(emb, qs[i], k)
+        assert got[i][0].tolist() == orows, (i, got[i][0].tolist(), orows)
+        assert np.array_equal(got[i][1], np.array(odist)), i
+    c.close()
+
+
+def test_batched_with_ties_zero_rows_and_zero_query(gpu_ctx):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(10000, seed=77, dup_frac=0.1, zero_frac=0.01)
+    qs = synth.unit_query(5, nq=16)
+    qs[3] = 0.0                       # zero query: zero rows rank first (distance 0), the rest are 1
+    qs[7] = emb[1234]                 # exact hit(s)
+    emb[[11, 5000, 9999]] = qs[9]     # three exact copies of query 9 -> rows in ascending order
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    got = c.search(qs, top_k=6)
+    for i in range(16):
+        orows, odist = _oracle_topk(emb, qs[i], 6)
+        assert got[i][0].tolist() == orows, i
+        assert np.array_equal(got[i][1], np.array(odist)), i
+    assert got[9][0][:3].tolist() == [11, 5000, 9999]
+    c.close()
+
+
+def test_batched_equals_single_query_path(gpu_ctx):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(30000, seed=5)
+    qs = synth.unit_query(6, nq=12)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    batch = c.search(qs, top_k=10)
+    for i in range(12):
+        one = c.search(qs[i], top_k=10)[0]
+        assert batch[i][0].tolist() == one[0].tolist() and np.array_equal(batch[i][1], one[1])
+    c.close()
+
+
+def test_batched_sorted_corpus_is_still_exact(gpu_ctx):
+    """Adversarial row order for the level thresholds: rows sorted by similarity to the queries'
+    mean direction, so sampled tiles are unrepresentative.  Whatever path is taken (candidate
+    buffers or the overflow fallback), results must stay exact."""
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(40000, seed=9, dup_frac=0, zero_frac=0)
+    qs = synth.unit_query(10, nq=8)
+    order = np.argsort(emb @ qs.mean(axis=0))          # worst first, best last
+    emb = np.ascontiguousarray(emb[order])
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    got = c.search(qs, top_k=10)
+    for i in range(8):
+        orows, odist = _oracle_topk(emb, qs[i], 10)
+        assert got[i][0].tolist() == orows, i
+    c.close()

@@ -1,0 +1,62 @@
+"""Config c3 on the GPU box: nq batched queries x N rows through the MFMA path (K3).
+Prints achieved TFLOP/s (2*nq*N*256 flops / gemm kernel time from HIP events) and queries/s."""
+import argparse
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import semtools_amd as smt  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--nq", type=int, default=1000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--check", type=int, default=4, help="queries verified against torch fp64")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.randn(args.rows, 256, device=dev, generator=g)
+    x /= x.norm(dim=1, keepdim=True)
+    g.manual_seed(5)
+    q = torch.randn(args.nq, 256, device=dev, generator=g)
+    q /= q.norm(dim=1, keepdim=True)
+    out_rows = torch.empty(args.nq, args.k, dtype=torch.int64, device=dev)
+    out_dist = torch.empty(args.nq, args.k, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=args.rows)
+    ctx.prof_enable(True)
+    corpus.search_topk_device(q.data_ptr(), args.nq, args.k, 0, out_rows.data_ptr(), out_dist.data_ptr())
+    ctx.synchronize()
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        corpus.search_topk_device(q.data_ptr(), args.nq, args.k, 0, out_rows.data_ptr(), out_dist.data_ptr())
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / args.reps
+    n_g, ms_g = ctx.prof_read("gemm")
+    n_s, ms_s = ctx.prof_read("select")
+    gemm_ms = ms_g / args.reps
+    flops = 2.0 * args.nq * args.rows * 256
+    ok = True
+    for i in range(min(args.check, args.nq)):
+        ref = 1.0 - (x.double() @ q[i].double())
+        tv, ti = torch.topk(ref, args.k, largest=False)
+        ok &= bool((out_rows[i].cpu() == ti.cpu()).all()) and bool((out_dist[i] - tv).abs().max() < 1e-6)
+    print(json.dumps(dict(rows=args.rows, nq=args.nq, k=args.k, wall_ms=round(wall * 1e3, 3), gemm_ms=round(gemm_ms, 3),
+                          select_ms=round(ms_s / args.reps, 3), gemm_launches_per_batch=n_g // args.reps,
+                          mfma_TFLOPs=round(flops / (gemm_ms * 1e-3) / 1e12, 2),
+                          mfma_frac_of_157=round(flops / (gemm_ms * 1e-3) / 157.3e12, 3),
+                          qps=round(args.nq / wall, 1), rows_per_s=round(args.nq * args.rows / wall / 1e9, 2),
+                          torch_check_ok=ok)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
