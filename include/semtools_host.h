@@ -1,0 +1,81 @@
+/*
+ * semtools_host.h -- C ABI of the HOST layer of libsemtools_hip.so: the reference's
+ * search module and workspace store re-implemented over the kernel-level ABI
+ * (semtools_hip.h).  These entry points exist so that non-C++ callers (tests, the
+ * CLI replica) can drive the same functions the reference exposes:
+ *
+ *   smt_host_model_*          model2vec_rs::StaticModel (from_pretrained / encode*)
+ *   smt_host_search_files     search_files + print_search_results      (src/search/mod.rs:122-143,
+ *                                                                        src/cmds/search.rs:35-63,245-257)
+ *   smt_host_search_content   the stdin branch of search_cmd            (src/cmds/search.rs:145-176)
+ *   smt_host_search_workspace search_with_workspace + workspace printing (src/search/mod.rs:146-216,
+ *                                                                        src/cmds/search.rs:66-110,197-244)
+ *   smt_host_workspace_*      workspace use / status / prune            (src/cmds/workspace.rs)
+ *
+ * Text comes back as a malloc'd, NUL-terminated UTF-8 string (*out_text) that the caller
+ * releases with smt_host_free; it is byte-for-byte what the reference prints to stdout.
+ * Progress lines go to stderr exactly where the reference prints them.
+ */
+#ifndef SEMTOOLS_HOST_H
+#define SEMTOOLS_HOST_H
+
+#include "semtools_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smt_host_model smt_host_model;
+
+#define SMT_TOK_HASH 0     /* whitespace words hashed (FNV-1a) into [0, V): synthetic tests      */
+#define SMT_TOK_VOCAB 1    /* whitespace words looked up in vocab_path (one token per line)      */
+#define SMT_TOK_CALLBACK 2 /* caller-provided tokenizer (e.g. the real HF tokenizers binding)    */
+
+/* Writes up to `cap` ids of `text` to `ids`, the total count to *n; returns 0 on success. */
+typedef int (*smt_tokenize_cb)(void *user, const char *text, uint64_t len, uint32_t *ids, uint64_t cap,
+                               uint64_t *n);
+
+/* StaticModel::from_pretrained: `table` = the f32 `embeddings` tensor [V x 256] (host);
+ * unk_id = UINT32_MAX when the tokenizer has no unk token; median_len = median vocabulary
+ * token length in characters (used only for callback tokenizers). */
+int smt_host_model_create(smt_ctx *ctx, const float *table, uint64_t V, int normalize, int tok_kind,
+                          const char *vocab_path, const char *unk_token, smt_tokenize_cb cb, void *user,
+                          uint32_t unk_id, uint32_t median_len, smt_host_model **out);
+/* directory with model.safetensors ("embeddings", F32 or F16), vocab.txt, optional config.json */
+int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out);
+void smt_host_model_destroy(smt_host_model *model);
+
+/* encode_with_args(texts, Some(max_length) / None when 0, batch 16384) -> out [n x 256] */
+int smt_host_encode(smt_host_model *model, const char *const *texts, uint64_t n, uint32_t max_length,
+                    float *out);
+
+/* max_distance: NaN = None.  json != 0: SearchOutput JSON (to_string_pretty) instead of text. */
+int smt_host_search_files(smt_host_model *model, const char *query, const char *const *files, uint64_t n_files,
+                          uint64_t n_lines, uint64_t top_k, double max_distance, int ignore_case, int json,
+                          int is_tty, char **out_text);
+int smt_host_search_content(smt_host_model *model, const char *query, const char *filename, const char *content,
+                            uint64_t n_lines, uint64_t top_k, double max_distance, int ignore_case, int json,
+                            int is_tty, char **out_text);
+int smt_host_search_workspace(smt_host_model *model, const char *query, const char *const *files,
+                              uint64_t n_files, uint64_t n_lines, uint64_t top_k, double max_distance,
+                              int ignore_case, const char *workspace_name, int json, int is_tty,
+                              char **out_text);
+
+/* workspace use / status / prune: same stdout text / JSON as src/cmds/workspace.rs */
+int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json, char **out_text);
+int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);
+int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);
+
+void smt_host_free(char *text);
+
+/* Formatting primitives of the output layer, exported for tests: mode 0 = Rust `{}` of an f64,
+ * 1 = Rust `{}` of an f32 (value is narrowed first), 2 = serde_json f64.  Returns malloc'd text. */
+char *smt_host_format_float(double value, int mode);
+/* Rust str::lines() / str::to_lowercase() as the host layer implements them: returned as "<count>\x1f<line>\x1f<line>...". */
+char *smt_host_split_lines(const char *content);
+char *smt_host_to_lowercase(const char *text);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

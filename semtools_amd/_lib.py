@@ -26,6 +26,14 @@ EXPORTS = [
     "smt_corpus_save", "smt_corpus_load", "smt_search", "smt_search_topk_device", "smt_merge_topk",
     "smt_merge_topk_device", "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
 ]
+HOST_EXPORTS = [
+    "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
+    "smt_host_search_files", "smt_host_search_content", "smt_host_search_workspace", "smt_host_workspace_use",
+    "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_free", "smt_host_format_float",
+    "smt_host_split_lines", "smt_host_to_lowercase",
+]
+TOKENIZE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64,
+                          C.POINTER(C.c_uint64))
 
 
 class SmtRange(C.Structure):
@@ -113,6 +121,27 @@ def lib():
     L.smt_line_embedding_id.restype = u64
     L.smt_doc_meta_id.argtypes = [C.c_char_p]
     L.smt_doc_meta_id.restype = u64
+    # ---- host layer (include/semtools_host.h)
+    cpp = P(C.c_char_p)
+    L.smt_host_model_create.argtypes = [vp, vp, u64, i32, i32, C.c_char_p, C.c_char_p, TOKENIZE_CB, vp, u32, u32, P(vp)]
+    L.smt_host_model_from_dir.argtypes = [vp, C.c_char_p, P(vp)]
+    L.smt_host_model_destroy.argtypes = [vp]
+    L.smt_host_model_destroy.restype = None
+    L.smt_host_encode.argtypes = [vp, cpp, u64, u32, vp]
+    L.smt_host_search_files.argtypes = [vp, C.c_char_p, cpp, u64, u64, u64, f64, i32, i32, i32, P(vp)]
+    L.smt_host_search_content.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u64, u64, f64, i32, i32, i32, P(vp)]
+    L.smt_host_search_workspace.argtypes = [vp, C.c_char_p, cpp, u64, u64, u64, f64, i32, C.c_char_p, i32, i32, P(vp)]
+    L.smt_host_workspace_use.argtypes = [vp, C.c_char_p, i32, P(vp)]
+    L.smt_host_workspace_status.argtypes = [vp, C.c_char_p, i32, P(vp)]
+    L.smt_host_workspace_prune.argtypes = [vp, C.c_char_p, i32, P(vp)]
+    L.smt_host_free.argtypes = [vp]
+    L.smt_host_free.restype = None
+    L.smt_host_format_float.argtypes = [f64, i32]
+    L.smt_host_format_float.restype = vp
+    L.smt_host_split_lines.argtypes = [C.c_char_p]
+    L.smt_host_split_lines.restype = vp
+    L.smt_host_to_lowercase.argtypes = [C.c_char_p]
+    L.smt_host_to_lowercase.restype = vp
     _lib = L
     return L
 

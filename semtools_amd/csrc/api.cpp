@@ -599,8 +599,39 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         // ---------------- top-k (optionally with the workspace score threshold)
         const uint32_t k_eff = (uint32_t)std::min<uint64_t>(top_k, n_virtual);
         if (k_eff > 64) {
-            set_error("top_k=%u > 64 is not supported by the resident top-k path yet", top_k);
-            return SMT_E_UNSUPPORTED;
+            // rare large-k request: all keys + sort + exact rescoring of k + guard candidates
+            const uint64_t guard = std::max<uint64_t>(64, k_eff / 16);
+            const uint64_t n_cand = std::min<uint64_t>(n_virtual, (uint64_t)k_eff + guard);
+            const bool ws_thr = (mode == SMT_MODE_WORKSPACE && has_thr);
+            const float thr_score = 1.0f - (float)max_distance;
+            bool truncated = false;
+            for (uint32_t q = 0; q < nq; ++q) {
+                std::vector<uint32_t> c_rows;
+                std::vector<double> c_dist;
+                rc = launch_largek_candidates(ctx, corpus->d_rows, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr,
+                                              nr ? d_p : nullptr, nr, n_virtual, n_cand, c_rows, c_dist);
+                if (rc) return rc;
+                std::vector<uint64_t> order;
+                for (uint64_t i = 0; i < c_rows.size(); ++i) {
+                    if (c_dist[i] != c_dist[i]) continue;                                   // NaN rows never match
+                    if (ws_thr && !((1.0 - c_dist[i]) > (double)thr_score)) continue;      // store.rs:502-503
+                    order.push_back(i);
+                }
+                std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+                    if (c_dist[x] != c_dist[y]) return c_dist[x] < c_dist[y];
+                    return c_rows[x] < c_rows[y];
+                });
+                const uint64_t n = std::min<uint64_t>(order.size(), k_eff);
+                out_counts[q] = n;
+                const uint64_t w = std::min<uint64_t>(n, out_cap);
+                if (n > out_cap) truncated = true;
+                for (uint64_t i = 0; i < w; ++i) {
+                    out_rows[(size_t)q * out_cap + i] = row_base + c_rows[order[i]];
+                    out_dist[(size_t)q * out_cap + i] = c_dist[order[i]];
+                }
+            }
+            if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
+            return SMT_OK;
         }
         const size_t o_rows = (size_t)nq * k_eff * sizeof(uint64_t);
         const size_t o_dist = (size_t)nq * k_eff * sizeof(double);

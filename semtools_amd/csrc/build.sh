@@ -7,12 +7,19 @@ mkdir -p "$out"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -fno-gpu-rdc)
 objs=()
-for src in api.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip; do
-  obj="$out/${src%.*}.o"
-  if [[ ! -f "$obj" || "$here/$src" -nt "$obj" || "$here/common.h" -nt "$obj" || "$here/device_utils.h" -nt "$obj" || "$here/../../include/semtools_hip.h" -nt "$obj" ]]; then
+newest_hdr="$(ls -t "$here"/*.h "$here"/host/*.h "$here"/../../include/*.h | head -1)"
+for src in api.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip largek.hip host/host.cpp host/host_capi.cpp; do
+  base="$(basename "${src%.*}")"
+  obj="$out/$base.o"
+  if [[ ! -f "$obj" || "$here/$src" -nt "$obj" || "$newest_hdr" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" -x hip -c "$here/$src" -o "$obj" ${EXTRA_HIPCC_FLAGS:-}
   fi
   objs+=("$obj")
 done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/libsemtools_hip.so"
 echo "built $out/libsemtools_hip.so"
+# CLI replica (host-only C++), finds the library next to it
+bin="$here/../bin"
+mkdir -p "$bin"
+g++ -O2 -std=c++17 -Wall "$here/host/cli.cpp" -o "$bin/semtools" -L"$out" -lsemtools_hip -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+echo "built $bin/semtools"

@@ -150,6 +150,11 @@ int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, ui
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
                       double *out_dist);
 
+// top_k > 64 (rare): all keys + radix sort + exact rescoring of the best n_cand rows
+int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *query_dev, const smt_range *ranges_dev,
+                             const uint64_t *prefix_dev, uint32_t n_ranges, uint64_t n_virtual, uint64_t n_cand,
+                             std::vector<uint32_t> &rows_out, std::vector<double> &dist_out);
+
 // K1
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
                  const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out);

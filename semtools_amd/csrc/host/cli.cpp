@@ -1,0 +1,145 @@
+// cli.cpp -- `semtools` CLI replica for the search / workspace subcommands
+// (reference: src/bin/semtools.rs:52-83,122-131,134-206; src/cmds/search.rs:113-276;
+// src/cmds/workspace.rs).  Same flags, same stdout/stderr split, same output bytes.
+// The model comes from $SEMTOOLS_MODEL_DIR (model.safetensors + vocab.txt [+ config.json]):
+// the HF-hub download of StaticModel::from_pretrained is out of scope (no network here).
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/semtools_host.h"
+
+static int die(const std::string &msg)
+{
+    fprintf(stderr, "Error: %s\n", msg.c_str());
+    return 1;
+}
+
+static int usage()
+{
+    fprintf(stderr,
+            "Usage: semtools <COMMAND>\n\nCommands:\n"
+            "  search     A CLI tool for fast semantic keyword search\n"
+            "  workspace  Manage semtools workspaces\n\n"
+            "semtools search <QUERY> [FILES]... [-n, --n-lines <N>] [--top-k <K>] [-m, --max-distance <D>]\n"
+            "                [-i, --ignore-case] [-j, --json] [-w, --workspace <NAME>]\n"
+            "semtools workspace [-j, --json] use <NAME> | status [NAME] | prune [NAME]\n");
+    return 2;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return usage();
+    const std::string cmd = argv[1];
+    std::vector<std::string> args(argv + 2, argv + argc);
+
+    smt_ctx *ctx = nullptr;
+    auto need_ctx = [&]() -> bool {
+        if (ctx) return true;
+        const char *dev = getenv("SEMTOOLS_DEVICE");
+        if (smt_ctx_create(dev ? atoi(dev) : 0, &ctx) != SMT_OK) { die(smt_last_error()); return false; }
+        return true;
+    };
+
+    if (cmd == "workspace") {
+        bool json = false;
+        std::vector<std::string> pos;
+        for (auto &a : args) { if (a == "-j" || a == "--json") json = true; else pos.push_back(a); }
+        if (pos.empty()) return usage();
+        char *text = nullptr;
+        int rc;
+        if (pos[0] == "use") {
+            if (pos.size() < 2) return usage();
+            if (json && !need_ctx()) return 1;
+            rc = smt_host_workspace_use(ctx, pos[1].c_str(), json, &text);
+        } else if (pos[0] == "status" || pos[0] == "prune") {
+            if (!need_ctx()) return 1;
+            const char *nm = pos.size() > 1 ? pos[1].c_str() : nullptr;
+            rc = pos[0] == "status" ? smt_host_workspace_status(ctx, nm, json, &text) : smt_host_workspace_prune(ctx, nm, json, &text);
+        } else return usage();
+        if (rc != SMT_OK) return die(smt_last_error());
+        fputs(text, stdout);
+        smt_host_free(text);
+        smt_ctx_destroy(ctx);
+        return 0;
+    }
+    if (cmd != "search") return usage();
+
+    std::string query;
+    std::vector<std::string> files;
+    uint64_t n_lines = 3, top_k = 3;
+    double max_distance = NAN;
+    bool ignore_case = false, json = false, have_query = false;
+    const char *workspace = nullptr;
+    std::string ws_store;
+    for (size_t i = 0; i < args.size(); ++i) {
+        const std::string &a = args[i];
+        auto val = [&](const char *name) -> const char * {
+            if (i + 1 >= args.size()) { fprintf(stderr, "error: a value is required for '%s'\n", name); exit(2); }
+            return args[++i].c_str();
+        };
+        if (a == "-n" || a == "--n-lines" || a == "--context") n_lines = strtoull(val("--n-lines"), nullptr, 10);
+        else if (a == "--top-k") top_k = strtoull(val("--top-k"), nullptr, 10);
+        else if (a == "-m" || a == "--max-distance" || a == "--threshold") max_distance = strtod(val("--max-distance"), nullptr);
+        else if (a == "-i" || a == "--ignore-case") ignore_case = true;
+        else if (a == "-j" || a == "--json") json = true;
+        else if (a == "-w" || a == "--workspace") { ws_store = val("--workspace"); workspace = ws_store.c_str(); }
+        else if (!have_query) { query = a; have_query = true; }
+        else files.push_back(a);
+    }
+    if (!have_query) return usage();
+
+    if (!need_ctx()) return 1;
+    const char *model_dir = getenv("SEMTOOLS_MODEL_DIR");
+    if (!model_dir) return die("SEMTOOLS_MODEL_DIR is not set (directory with model.safetensors + vocab.txt)");
+    smt_host_model *model = nullptr;
+    if (smt_host_model_from_dir(ctx, model_dir, &model) != SMT_OK) return die(smt_last_error());
+
+    const int is_tty = isatty(STDOUT_FILENO);
+    char *text = nullptr;
+    int rc = SMT_OK;
+    bool done = false;
+
+    // stdin input (non-workspace mode): src/cmds/search.rs:145-176
+    if (files.empty() && !isatty(STDIN_FILENO)) {
+        std::stringstream ss;
+        ss << std::cin.rdbuf();
+        const std::string content = ss.str();
+        if (!content.empty()) {
+            rc = smt_host_search_content(model, query.c_str(), "<stdin>", content.c_str(), n_lines, top_k, max_distance,
+                                         ignore_case, json, is_tty, &text);
+            done = true;
+        }
+    }
+    if (!done && files.empty()) {  // src/cmds/search.rs:178-193
+        const char *msg = "No input provided. Either specify files as arguments or pipe input to stdin.";
+        if (json) fprintf(stderr, "{\n  \"error\": \"%s\",\n  \"error_type\": \"NoInput\"\n}\n", msg);
+        else fprintf(stderr, "Error: %s\n", msg);
+        return 1;
+    }
+    if (!done) {
+        std::vector<const char *> fp;
+        for (auto &f : files) fp.push_back(f.c_str());
+        const char *env_ws = getenv("SEMTOOLS_WORKSPACE");
+        const bool ws_active = workspace != nullptr || (env_ws && *env_ws);  // Workspace::active(..).is_ok()
+        if (ws_active)
+            rc = smt_host_search_workspace(model, query.c_str(), fp.data(), fp.size(), n_lines, top_k, max_distance, ignore_case,
+                                           workspace, json, is_tty, &text);
+        else
+            rc = smt_host_search_files(model, query.c_str(), fp.data(), fp.size(), n_lines, top_k, max_distance, ignore_case, json,
+                                       is_tty, &text);
+    }
+    if (rc != SMT_OK) return die(smt_last_error());
+    fputs(text, stdout);
+    smt_host_free(text);
+    smt_host_model_destroy(model);
+    smt_ctx_destroy(ctx);
+    return 0;
+}

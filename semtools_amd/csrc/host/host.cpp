@@ -1,0 +1,917 @@
+// host.cpp -- C++ mirror of the reference's search module and workspace store on
+// top of the C ABI (see host.h).  String handling, file I/O and bookkeeping
+// only: every floating-point result comes from libsemtools_hip's kernels.
+#include "host.h"
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <clocale>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cwctype>
+#include <fstream>
+#include <sstream>
+#include <thread>
+
+#include "fmt.h"
+#include "json.h"
+
+namespace semtools {
+
+static void check(int rc, const char *what)
+{
+    if (rc != SMT_OK) throw Error(std::string(what) + ": " + smt_last_error());
+}
+
+// ------------------------------------------------------------------ strings / files
+std::vector<std::string> lines_of(const std::string &content)
+{
+    std::vector<std::string> out;
+    size_t start = 0;
+    const size_t n = content.size();
+    while (start < n) {
+        size_t nl = content.find('\n', start);
+        if (nl == std::string::npos) {
+            out.emplace_back(content, start, n - start);  // last line, no terminator: kept verbatim
+            break;
+        }
+        size_t end = nl;
+        if (end > start && content[end - 1] == '\r') --end;  // "\r\n" is one line ending
+        out.emplace_back(content, start, end - start);
+        start = nl + 1;
+    }
+    return out;
+}
+
+static size_t utf8_len(unsigned char c) { return c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1; }
+
+std::string to_lowercase(const std::string &s)
+{
+    static bool locale_set = false;
+    if (!locale_set) { setlocale(LC_CTYPE, "C.UTF-8"); locale_set = true; }
+    std::string out;
+    out.reserve(s.size());
+    for (size_t i = 0; i < s.size();) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c < 0x80) { out.push_back((char)((c >= 'A' && c <= 'Z') ? c + 32 : c)); ++i; continue; }
+        const size_t len = std::min(utf8_len(c), s.size() - i);
+        unsigned cp = 0;
+        if (len == 2) cp = ((c & 0x1F) << 6) | ((unsigned char)s[i + 1] & 0x3F);
+        else if (len == 3) cp = ((c & 0x0F) << 12) | (((unsigned char)s[i + 1] & 0x3F) << 6) | ((unsigned char)s[i + 2] & 0x3F);
+        else if (len == 4) cp = ((c & 0x07) << 18) | (((unsigned char)s[i + 1] & 0x3F) << 12) | (((unsigned char)s[i + 2] & 0x3F) << 6) | ((unsigned char)s[i + 3] & 0x3F);
+        else { out.push_back((char)c); ++i; continue; }
+        const unsigned lo = (unsigned)std::towlower((wint_t)cp);
+        if (lo == cp) out.append(s, i, len);
+        else {
+            if (lo < 0x80) out.push_back((char)lo);
+            else if (lo < 0x800) { out.push_back((char)(0xC0 | (lo >> 6))); out.push_back((char)(0x80 | (lo & 0x3F))); }
+            else if (lo < 0x10000) { out.push_back((char)(0xE0 | (lo >> 12))); out.push_back((char)(0x80 | ((lo >> 6) & 0x3F))); out.push_back((char)(0x80 | (lo & 0x3F))); }
+            else { out.push_back((char)(0xF0 | (lo >> 18))); out.push_back((char)(0x80 | ((lo >> 12) & 0x3F))); out.push_back((char)(0x80 | ((lo >> 6) & 0x3F))); out.push_back((char)(0x80 | (lo & 0x3F))); }
+        }
+        i += len;
+    }
+    return out;
+}
+
+std::string read_to_string(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + "): " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+static void write_file_atomic(const std::string &path, const std::string &data)
+{
+    const std::string tmp = path + ".tmp";
+    {
+        std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+        if (!f) throw Error("cannot write " + tmp + ": " + strerror(errno));
+        f.write(data.data(), (std::streamsize)data.size());
+        if (!f) throw Error("short write to " + tmp);
+    }
+    if (rename(tmp.c_str(), path.c_str()) != 0) throw Error("rename " + tmp + ": " + strerror(errno));
+}
+
+static bool path_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+static void mkdir_p(const std::string &dir)
+{
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); ++i) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!cur.empty() && !path_exists(cur) && mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST)
+                throw Error("mkdir " + cur + ": " + strerror(errno));
+        }
+        if (i < dir.size()) cur.push_back(dir[i]);
+    }
+}
+
+// ------------------------------------------------------------------ tokenizers
+namespace {
+
+void split_whitespace(const std::string &text, std::vector<std::pair<size_t, size_t>> &spans)
+{
+    size_t i = 0;
+    const size_t n = text.size();
+    while (i < n) {
+        while (i < n && isspace((unsigned char)text[i])) ++i;
+        const size_t s = i;
+        while (i < n && !isspace((unsigned char)text[i])) ++i;
+        if (i > s) spans.emplace_back(s, i - s);
+    }
+}
+
+class VocabTokenizer : public Tokenizer {
+public:
+    VocabTokenizer(const std::string &path, const std::string &unk_token)
+    {
+        std::ifstream f(path);
+        if (!f) throw Error("cannot open vocab file " + path);
+        std::string line;
+        std::vector<size_t> lens;
+        uint32_t id = 0;
+        while (std::getline(f, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            vocab_.emplace(line, id++);
+            size_t chars = 0;
+            for (unsigned char c : line) if ((c & 0xC0) != 0x80) ++chars;
+            lens.push_back(chars);
+        }
+        size_ = id;
+        if (!unk_token.empty()) {
+            auto it = vocab_.find(unk_token);
+            if (it != vocab_.end()) unk_ = it->second;
+        }
+        if (!lens.empty()) {  // model2vec: median length of the vocabulary's tokens
+            std::sort(lens.begin(), lens.end());
+            median_ = std::max<size_t>(1, lens[lens.size() / 2]);
+        }
+    }
+    void encode(const std::string &text, std::vector<uint32_t> &ids) const override
+    {
+        std::vector<std::pair<size_t, size_t>> spans;
+        split_whitespace(text, spans);
+        for (auto &sp : spans) {
+            auto it = vocab_.find(text.substr(sp.first, sp.second));
+            if (it != vocab_.end()) ids.push_back(it->second);
+            else if (unk_) ids.push_back(*unk_);
+        }
+    }
+    std::optional<uint32_t> unk_id() const override { return unk_; }
+    size_t median_token_length() const override { return median_; }
+    uint64_t vocab_size() const override { return size_; }
+
+private:
+    std::unordered_map<std::string, uint32_t> vocab_;
+    std::optional<uint32_t> unk_;
+    size_t median_ = 5;
+    uint64_t size_ = 0;
+};
+
+class HashTokenizer : public Tokenizer {
+public:
+    explicit HashTokenizer(uint64_t v) : v_(v) {}
+    void encode(const std::string &text, std::vector<uint32_t> &ids) const override
+    {
+        std::vector<std::pair<size_t, size_t>> spans;
+        split_whitespace(text, spans);
+        for (auto &sp : spans)
+            ids.push_back((uint32_t)(smt_fnv1a_hash(reinterpret_cast<const uint8_t *>(text.data() + sp.first), sp.second) % v_));
+    }
+    uint64_t vocab_size() const override { return v_; }
+
+private:
+    uint64_t v_;
+};
+
+class CallbackTokenizer : public Tokenizer {
+public:
+    CallbackTokenizer(TokenizeFn fn, uint64_t v, std::optional<uint32_t> unk, size_t median)
+        : fn_(std::move(fn)), v_(v), unk_(unk), median_(median) {}
+    void encode(const std::string &text, std::vector<uint32_t> &ids) const override { fn_(text, ids); }
+    std::optional<uint32_t> unk_id() const override { return unk_; }
+    size_t median_token_length() const override { return median_; }
+    uint64_t vocab_size() const override { return v_; }
+
+private:
+    TokenizeFn fn_;
+    uint64_t v_;
+    std::optional<uint32_t> unk_;
+    size_t median_;
+};
+
+}  // namespace
+
+std::unique_ptr<Tokenizer> make_vocab_tokenizer(const std::string &vocab_path, const std::string &unk_token)
+{
+    return std::make_unique<VocabTokenizer>(vocab_path, unk_token);
+}
+std::unique_ptr<Tokenizer> make_hash_tokenizer(uint64_t vocab_size) { return std::make_unique<HashTokenizer>(vocab_size); }
+std::unique_ptr<Tokenizer> make_callback_tokenizer(TokenizeFn fn, uint64_t vocab_size, std::optional<uint32_t> unk,
+                                                   size_t median_len)
+{
+    return std::make_unique<CallbackTokenizer>(std::move(fn), vocab_size, unk, median_len);
+}
+
+// ================================================================== search
+namespace search {
+
+StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize)
+    : ctx_(ctx), tok_(std::move(tok))
+{
+    check(smt_model_create(ctx, table, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
+}
+
+StaticModel::~StaticModel() { smt_model_destroy(model_); }
+
+// model2vec-rs truncate_str: keep at most max_tokens * median_token_length characters
+static std::string truncate_str(const std::string &s, size_t max_tokens, size_t median_len)
+{
+    const size_t max_chars = max_tokens * median_len;
+    size_t chars = 0;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (((unsigned char)s[i] & 0xC0) != 0x80) {
+            if (chars == max_chars) return s.substr(0, i);
+            ++chars;
+        }
+    }
+    return s;
+}
+
+void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size_t begin, size_t end,
+                                 std::optional<size_t> max_length, std::vector<uint32_t> &ids,
+                                 std::vector<uint64_t> &offsets) const
+{
+    // encode_batch_fast is rayon-parallel upstream; here: one slice per hardware thread
+    const size_t n = end - begin;
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 256));
+    std::vector<std::vector<uint32_t>> part_ids(n_threads);
+    std::vector<std::vector<uint64_t>> part_len(n_threads);
+    const auto unk = tok_->unk_id();
+    auto work = [&](size_t t) {
+        const size_t b = begin + n * t / n_threads, e = begin + n * (t + 1) / n_threads;
+        std::vector<uint32_t> tmp;
+        for (size_t i = b; i < e; ++i) {
+            tmp.clear();
+            if (max_length) tok_->encode(truncate_str(sentences[i], *max_length, tok_->median_token_length()), tmp);
+            else tok_->encode(sentences[i], tmp);
+            if (unk) tmp.erase(std::remove(tmp.begin(), tmp.end(), *unk), tmp.end());
+            if (max_length && tmp.size() > *max_length) tmp.resize(*max_length);
+            part_ids[t].insert(part_ids[t].end(), tmp.begin(), tmp.end());
+            part_len[t].push_back(tmp.size());
+        }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    ids.clear();
+    offsets.assign(1, 0);
+    for (size_t t = 0; t < n_threads; ++t) {
+        ids.insert(ids.end(), part_ids[t].begin(), part_ids[t].end());
+        for (uint64_t l : part_len[t]) offsets.push_back(offsets.back() + l);
+    }
+}
+
+std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<std::string> &sentences,
+                                                              std::optional<size_t> max_length,
+                                                              size_t batch_size) const
+{
+    std::vector<std::vector<float>> out;
+    out.reserve(sentences.size());
+    std::vector<uint32_t> ids;
+    std::vector<uint64_t> offsets;
+    std::vector<float> buf;
+    if (batch_size == 0) batch_size = 1;
+    for (size_t b = 0; b < sentences.size(); b += batch_size) {
+        const size_t e = std::min(sentences.size(), b + batch_size);
+        tokenize_batch(sentences, b, e, max_length, ids, offsets);
+        buf.resize((e - b) * SMT_DIM);
+        check(smt_embed(model_, ids.data(), offsets.data(), e - b, max_length ? (uint32_t)*max_length : 0, buf.data(),
+                        nullptr, nullptr), "encode_with_args");
+        for (size_t i = 0; i < e - b; ++i) out.emplace_back(buf.begin() + i * SMT_DIM, buf.begin() + (i + 1) * SMT_DIM);
+    }
+    return out;
+}
+
+uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
+                                  size_t batch_size, smt_corpus *corpus) const
+{
+    const uint64_t first = smt_corpus_rows(corpus);
+    std::vector<uint32_t> ids;
+    std::vector<uint64_t> offsets;
+    if (batch_size == 0) batch_size = 1;
+    for (size_t b = 0; b < sentences.size(); b += batch_size) {
+        const size_t e = std::min(sentences.size(), b + batch_size);
+        tokenize_batch(sentences, b, e, max_length, ids, offsets);
+        check(smt_embed(model_, ids.data(), offsets.data(), e - b, max_length ? (uint32_t)*max_length : 0, nullptr, corpus,
+                        nullptr), "encode_into");
+    }
+    return first;
+}
+
+std::vector<float> StaticModel::encode_single(const std::string &sentence) const
+{
+    // StaticModel::encode(&[s]) == encode_with_args(.., Some(512), 1024)  [UPSTREAM-RECALL]
+    return encode_with_args({sentence}, 512, 1024).at(0);
+}
+
+Embeddings::Embeddings(smt_ctx *ctx) { check(smt_corpus_create(ctx, SMT_DIM, 0, &corpus_), "Embeddings"); }
+Embeddings::~Embeddings() { smt_corpus_destroy(corpus_); }
+uint64_t Embeddings::rows() const { return smt_corpus_rows(corpus_); }
+
+std::optional<Document> create_document_from_content(const std::string &filename, const std::string &content,
+                                                     const StaticModel &model, bool ignore_case, Embeddings &emb)
+{
+    std::vector<std::string> lines = lines_of(content);
+    if (lines.empty()) return std::nullopt;  // mod.rs:57-59
+    Document doc;
+    doc.filename = filename;
+    if (ignore_case) {
+        std::vector<std::string> lowered;
+        lowered.reserve(lines.size());
+        for (auto &s : lines) lowered.push_back(to_lowercase(s));
+        doc.first_row = model.encode_into(lowered, 2048, 16384, emb.corpus());  // mod.rs:69
+    } else {
+        doc.first_row = model.encode_into(lines, 2048, 16384, emb.corpus());
+    }
+    doc.lines = std::move(lines);
+    return doc;
+}
+
+std::vector<SearchResult> search_documents(const std::vector<Document> &documents, const Embeddings &emb,
+                                           const std::vector<float> &query_embedding, const SearchConfig &config)
+{
+    std::vector<SearchResult> results;
+    if (documents.empty()) return results;
+    if (query_embedding.size() != SMT_DIM) return results;  // f32::cosine -> None on length mismatch: every row skipped
+
+    // one row range per document, in slice order (== the reference's nested loop order)
+    std::vector<smt_range> ranges;
+    std::vector<uint64_t> starts;  // first row of each document
+    uint64_t total = 0;
+    for (auto &d : documents) {
+        if (!starts.empty() && d.first_row < starts.back())
+            throw Error("search_documents: documents must be in embedding order");
+        starts.push_back(d.first_row);
+        const uint64_t end = d.first_row + d.lines.size();
+        if (!ranges.empty() && ranges.back().end == d.first_row) ranges.back().end = end;
+        else ranges.push_back({d.first_row, end});
+        total += d.lines.size();
+    }
+    if (total == 0) return results;
+
+    const bool all_hits = config.max_distance.has_value();
+    if (!all_hits && config.top_k == 0) return results;
+    uint64_t cap = all_hits ? std::min<uint64_t>(total, 4096) : std::min<uint64_t>(config.top_k, total);
+    std::vector<uint64_t> rows;
+    std::vector<double> dist;
+    uint64_t n = 0;
+    for (;;) {
+        rows.resize(cap);
+        dist.resize(cap);
+        const int rc = smt_search(emb.corpus(), query_embedding.data(), 1, (uint32_t)std::min<size_t>(config.top_k, 0xFFFFFFFFu),
+                                  all_hits ? *config.max_distance : NAN, SMT_MODE_DOCUMENTS, ranges.data(),
+                                  (uint32_t)ranges.size(), 0, rows.data(), dist.data(), &n, cap);
+        if (rc == SMT_E_TRUNCATED) { cap = n; continue; }
+        check(rc, "search_documents");
+        break;
+    }
+    results.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const size_t di = (size_t)(std::upper_bound(starts.begin(), starts.end(), rows[i]) - starts.begin()) - 1;
+        const Document &doc = documents[di];
+        const size_t idx = (size_t)(rows[i] - doc.first_row);
+        const size_t bottom = idx > config.n_lines ? idx - config.n_lines : 0;   // saturating_sub  (mod.rs:90)
+        const size_t top = std::min(doc.lines.size(), idx + config.n_lines + 1);  // (mod.rs:91)
+        SearchResult r;
+        r.filename = doc.filename;
+        r.lines.assign(doc.lines.begin() + bottom, doc.lines.begin() + top);
+        r.distance = dist[i];
+        r.start = bottom;
+        r.end = top;
+        r.match_line = idx;
+        results.push_back(std::move(r));
+    }
+    return results;  // already (distance asc, document/line order) == stable sort; take(top_k) done on device
+}
+
+std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,
+                                       const StaticModel &model, const SearchConfig &config)
+{
+    Embeddings emb(model.ctx());
+    std::vector<Document> documents;
+    for (auto &f : files) {
+        const std::string content = read_to_string(f);  // `?`: first error aborts (mod.rs:130)
+        auto doc = create_document_from_content(f, content, model, config.ignore_case, emb);
+        if (doc) documents.push_back(std::move(*doc));
+    }
+    const std::vector<float> query_embedding = model.encode_single(query);
+    return search_documents(documents, emb, query_embedding, config);
+}
+
+std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::string> &files, const std::string &query,
+                                                         const StaticModel &model, const SearchConfig &config,
+                                                         const std::optional<std::string> &workspace_name)
+{
+    using namespace workspace;
+    const std::vector<float> query_embedding = model.encode_single(query);
+    Workspace ws = Workspace::open(workspace_name);
+    auto store = Store::open(ws.config.root_dir, model.ctx());
+
+    // Step 1: changed / new / unchanged (mod.rs:158)
+    const std::vector<DocumentState> doc_states = store->analyze_document_states(files);
+
+    // Step 2+3: embed new/changed documents straight into the resident store
+    size_t n_lines_upserted = 0;
+    std::vector<DocMeta> docs_to_upsert;
+    std::vector<std::pair<std::string, std::vector<std::string>>> pending;
+    for (auto &st : doc_states) {
+        if (st.kind == DocumentState::Unchanged) continue;
+        std::vector<std::string> lines = lines_of(st.info.content);
+        if (lines.empty()) continue;  // create_document_from_content -> None
+        if (config.ignore_case) for (auto &s : lines) s = to_lowercase(s);
+        n_lines_upserted += lines.size();
+        pending.emplace_back(st.info.filename, std::move(lines));
+        docs_to_upsert.push_back(st.info.meta);
+    }
+    if (n_lines_upserted) {
+        fprintf(stderr, "Updating workspace with %zu lines from new/changed docs...\n", n_lines_upserted);  // mod.rs:194-197
+        for (auto &p : pending) store->upsert_document_lines(p.first, p.second, model);
+        store->flush_line_embeddings();
+    }
+    if (!docs_to_upsert.empty()) {
+        fprintf(stderr, "Updating workspace with %zu new/changed documents...\n", docs_to_upsert.size());  // mod.rs:203-206
+        store->upsert_document_metadata(docs_to_upsert);
+    }
+
+    // Step 4 (mod.rs:211-213)
+    std::optional<float> max_distance;
+    if (config.max_distance) max_distance = (float)*config.max_distance;
+    return store->search_line_embeddings(query_embedding, files, config.top_k, max_distance);
+}
+
+}  // namespace search
+
+// ================================================================== workspace
+namespace workspace {
+
+static std::string home_dir()
+{
+    const char *h = getenv("HOME");
+    if (!h || !*h) throw Error("No home dir found?");
+    return h;
+}
+
+std::string Workspace::root_path(const std::string &name) { return home_dir() + "/.semtools/workspaces/" + name; }
+std::string Workspace::config_path_for(const std::string &name) { return root_path(name) + "/config.json"; }
+
+std::string Workspace::active(const std::optional<std::string> &workspace_name)
+{
+    std::string a;
+    if (workspace_name) a = *workspace_name;
+    else if (const char *e = getenv("SEMTOOLS_WORKSPACE")) a = e;
+    if (a.empty()) throw Error("No active workspace. Run: workspace use <name>");
+    return a;
+}
+
+std::string Workspace::active_path(const std::optional<std::string> &workspace_name) { return root_path(active(workspace_name)); }
+
+Workspace Workspace::open(const std::optional<std::string> &workspace_name)
+{
+    const std::string act = active(workspace_name);
+    Workspace ws;
+    try {
+        const json::Value v = json::parse(read_to_string(config_path_for(act)));
+        if (auto *x = v.get("name")) ws.config.name = x->s;
+        if (auto *x = v.get("root_dir")) ws.config.root_dir = x->s;
+        if (auto *x = v.get("in_batch_size")) ws.config.in_batch_size = (size_t)x->as_u64();
+        if (auto *x = v.get("oversample_factor")) ws.config.oversample_factor = (size_t)x->as_u64();
+    } catch (const std::exception &) {
+        ws.config = WorkspaceConfig();  // unreadable / invalid config -> defaults (mod.rs:36-40)
+    }
+    if (ws.config.root_dir.empty()) ws.config.root_dir = root_path(act);
+    if (ws.config.name.empty() || ws.config.name == "default") ws.config.name = act;
+    return ws;
+}
+
+void Workspace::save() const
+{
+    const std::string path = config_path_for(config.name);
+    mkdir_p(path.substr(0, path.rfind('/')));
+    json::Value v = json::Value::object();
+    v.set("name", json::Value::str(config.name));
+    v.set("root_dir", json::Value::str(config.root_dir));
+    v.set("in_batch_size", json::Value::uint(config.in_batch_size));
+    v.set("oversample_factor", json::Value::uint(config.oversample_factor));
+    write_file_atomic(path, json::to_string_pretty(v));
+}
+
+uint64_t DocMeta::id() const { return smt_doc_meta_id(path.c_str()); }
+uint64_t LineEmbedding::id() const { return smt_line_embedding_id(path.c_str(), line_number); }
+
+std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ctx)
+{
+    std::unique_ptr<Store> s(new Store());
+    s->dir_ = workspace_dir;
+    s->ctx_ = ctx;
+    mkdir_p(workspace_dir);
+    const std::string docs = workspace_dir + "/documents.json";
+    const std::string rows = workspace_dir + "/line_rows.json";
+    const std::string emb = workspace_dir + "/line_embeddings.f32";
+    if (path_exists(docs)) {
+        const json::Value v = json::parse(read_to_string(docs));
+        for (auto &d : v.arr) {
+            DocMeta m;
+            if (auto *x = d.get("path")) m.path = x->s;
+            if (auto *x = d.get("size_bytes")) m.size_bytes = x->as_u64();
+            if (auto *x = d.get("mtime")) m.mtime = x->as_i64();
+            // a store written before `_version` existed counts as version 1 (store.rs:32-33)
+            m._version = 1;
+            if (auto *x = d.get("_version")) m._version = (uint32_t)x->as_u64();
+            s->docs_[m.path] = m;
+        }
+    }
+    if (path_exists(emb)) check(smt_corpus_load(ctx, emb.c_str(), &s->corpus_), "Store::open");
+    else check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
+    if (path_exists(rows)) {
+        const json::Value v = json::parse(read_to_string(rows));
+        uint64_t live = 0;
+        if (auto *arr = v.get("extents"))
+            for (auto &e : arr->arr) {
+                Extent x;
+                x.first_row = e.get("first_row")->as_u64();
+                x.n_rows = e.get("n_rows")->as_u64();
+                if (x.first_row + x.n_rows > smt_corpus_rows(s->corpus_)) continue;  // torn write: drop, doc gets re-embedded
+                s->extents_[e.get("path")->s] = x;
+                live += x.n_rows;
+            }
+        s->dead_rows_ = smt_corpus_rows(s->corpus_) - live;
+    }
+    return s;
+}
+
+Store::~Store() { smt_corpus_destroy(corpus_); }
+
+std::unordered_map<std::string, DocMeta> Store::get_existing_docs(const std::vector<std::string> &paths) const
+{
+    std::unordered_map<std::string, DocMeta> out;
+    for (auto &p : paths) {
+        auto it = docs_.find(p);
+        if (it != docs_.end()) out[p] = it->second;
+    }
+    return out;
+}
+
+void Store::delete_document_metadata(const std::vector<std::string> &paths)
+{
+    if (paths.empty()) return;
+    for (auto &p : paths) {
+        auto it = docs_.find(p);
+        // the reference's delete filter also requires _version == CURRENT (store.rs:262-269)
+        if (it != docs_.end() && it->second._version == CURRENT_EMBEDDING_VERSION) docs_.erase(it);
+    }
+    flush_documents();
+}
+
+void Store::delete_line_embeddings(const std::vector<std::string> &paths)
+{
+    if (paths.empty()) return;
+    for (auto &p : paths) {
+        auto it = extents_.find(p);
+        if (it != extents_.end()) { dead_rows_ += it->second.n_rows; extents_.erase(it); }
+    }
+    compact_if_sparse();
+    flush_line_embeddings();
+}
+
+void Store::delete_documents(const std::vector<std::string> &paths)
+{
+    if (paths.empty()) return;
+    delete_document_metadata(paths);
+    delete_line_embeddings(paths);
+}
+
+void Store::upsert_document_metadata(const std::vector<DocMeta> &metas)
+{
+    if (metas.empty()) return;
+    for (auto &m : metas) docs_[m.path] = m;  // same path -> same id -> replacement (store.rs:951-1000)
+    flush_documents();
+}
+
+void Store::upsert_line_embeddings(const std::vector<LineEmbedding> &line_embeddings)
+{
+    if (line_embeddings.empty()) return;
+    // group by path (ids are per (path, line): an upsert replaces that line, adds it if new)
+    std::map<std::string, std::vector<const LineEmbedding *>> by_path;
+    for (auto &le : line_embeddings) {
+        if (le.embedding.size() != LINE_EMBEDDING_SIZE) throw Error("line embedding must have 256 dimensions");
+        if (le.line_number < 0) throw Error("negative line_number");
+        by_path[le.path].push_back(&le);
+    }
+    for (auto &kv : by_path) {
+        uint64_t max_line = 0;
+        for (auto *le : kv.second) max_line = std::max<uint64_t>(max_line, (uint64_t)le->line_number);
+        auto it = extents_.find(kv.first);
+        const uint64_t old_n = it != extents_.end() ? it->second.n_rows : 0;
+        if (it != extents_.end() && max_line < old_n) {  // in-place replacement
+            for (auto *le : kv.second)
+                check(smt_corpus_write_rows(corpus_, it->second.first_row + (uint64_t)le->line_number, le->embedding.data(), 1),
+                      "upsert_line_embeddings");
+            continue;
+        }
+        const uint64_t new_n = std::max(old_n, max_line + 1);
+        std::vector<float> rows((size_t)new_n * LINE_EMBEDDING_SIZE, 0.0f);
+        if (old_n) check(smt_corpus_read_rows(corpus_, it->second.first_row, old_n, rows.data()), "upsert_line_embeddings");
+        for (auto *le : kv.second)
+            std::copy(le->embedding.begin(), le->embedding.end(), rows.begin() + (size_t)le->line_number * LINE_EMBEDDING_SIZE);
+        uint64_t first = 0;
+        check(smt_corpus_append_host(corpus_, rows.data(), new_n, &first), "upsert_line_embeddings");
+        dead_rows_ += old_n;
+        extents_[kv.first] = Extent{first, new_n};
+    }
+    compact_if_sparse();
+    flush_line_embeddings();
+}
+
+void Store::upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
+                                  const search::StaticModel &model)
+{
+    auto it = extents_.find(path);
+    if (it != extents_.end()) dead_rows_ += it->second.n_rows;  // the whole old document is replaced (no stale tail)
+    const uint64_t first = model.encode_into(lines_for_embedding, 2048, 16384, corpus_);
+    extents_[path] = Extent{first, (uint64_t)lines_for_embedding.size()};
+}
+
+void Store::compact_if_sparse()
+{
+    const uint64_t total = smt_corpus_rows(corpus_);
+    if (dead_rows_ < 4096 || dead_rows_ * 2 < total) return;
+    // rewrite live extents back to back (row order of surviving documents is preserved)
+    std::vector<std::pair<uint64_t, std::string>> order;
+    for (auto &kv : extents_) order.emplace_back(kv.second.first_row, kv.first);
+    std::sort(order.begin(), order.end());
+    smt_corpus *fresh = nullptr;
+    check(smt_corpus_create(ctx_, SMT_DIM, total - dead_rows_, &fresh), "compact");
+    std::vector<float> buf;
+    for (auto &o : order) {
+        Extent &x = extents_[o.second];
+        buf.resize((size_t)x.n_rows * LINE_EMBEDDING_SIZE);
+        check(smt_corpus_read_rows(corpus_, x.first_row, x.n_rows, buf.data()), "compact");
+        uint64_t first = 0;
+        check(smt_corpus_append_host(fresh, buf.data(), x.n_rows, &first), "compact");
+        x.first_row = first;
+    }
+    smt_corpus_destroy(corpus_);
+    corpus_ = fresh;
+    dead_rows_ = 0;
+}
+
+WorkspaceStats Store::get_stats() const
+{
+    WorkspaceStats st;
+    st.total_documents = count_documents();
+    st.has_index = true;
+    st.index_type = "HNSW";  // the reference's hard-coded label (store.rs:443); the scan here is exact, as is the reference's
+    return st;
+}
+
+std::vector<std::string> Store::get_all_document_paths() const
+{
+    std::vector<std::string> out;
+    for (auto &kv : docs_) out.push_back(kv.first);
+    return out;
+}
+
+std::vector<RankedLine> Store::search_line_embeddings(const std::vector<float> &query_vec,
+                                                      const std::vector<std::string> &subset_paths, size_t top_k,
+                                                      std::optional<float> max_distance) const
+{
+    std::vector<RankedLine> out;
+    if (subset_paths.empty() || top_k == 0) return out;  // store.rs:489-491
+    if (query_vec.size() != LINE_EMBEDDING_SIZE) throw Error("query vector must have 256 dimensions");
+    struct Seg { uint64_t first, n; const std::string *path; };
+    std::vector<Seg> segs;
+    for (auto &p : subset_paths) {
+        auto it = extents_.find(p);
+        if (it != extents_.end() && it->second.n_rows) segs.push_back({it->second.first_row, it->second.n_rows, &it->first});
+    }
+    if (segs.empty()) return out;
+    std::sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.first < b.first; });
+    segs.erase(std::unique(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.first == b.first; }), segs.end());
+    std::vector<smt_range> ranges;
+    for (auto &s : segs) {
+        if (!ranges.empty() && ranges.back().end == s.first) ranges.back().end = s.first + s.n;
+        else ranges.push_back({s.first, s.first + s.n});
+    }
+    const uint32_t k = (uint32_t)std::min<size_t>(top_k, 0xFFFFFFFFu);
+    std::vector<uint64_t> rows(top_k);
+    std::vector<double> dist(top_k);
+    uint64_t n = 0;
+    check(smt_search(corpus_, query_vec.data(), 1, k, max_distance ? (double)*max_distance : NAN, SMT_MODE_WORKSPACE,
+                     ranges.data(), (uint32_t)ranges.size(), 0, rows.data(), dist.data(), &n, top_k),
+          "search_line_embeddings");
+    for (uint64_t i = 0; i < n; ++i) {
+        auto it = std::upper_bound(segs.begin(), segs.end(), rows[i], [](uint64_t r, const Seg &s) { return r < s.first; });
+        const Seg &s = *(it - 1);
+        RankedLine rl;
+        rl.path = *s.path;
+        rl.line_number = (int32_t)(rows[i] - s.first);
+        rl.distance = (float)dist[i];  // 1 - score as f32 (store.rs:531)
+        out.push_back(std::move(rl));
+    }
+    return out;
+}
+
+std::vector<DocumentState> Store::analyze_document_states(const std::vector<std::string> &file_paths) const
+{
+    const auto existing = get_existing_docs(file_paths);
+    std::vector<DocumentState> states;
+    for (auto &fp : file_paths) {
+        struct stat st;
+        if (stat(fp.c_str(), &st) != 0) continue;  // file doesn't exist: skipped (store.rs:573-576)
+        DocMeta cur;
+        cur.path = fp;
+        cur.size_bytes = (uint64_t)st.st_size;
+        cur.mtime = (int64_t)st.st_mtime;
+        cur._version = CURRENT_EMBEDDING_VERSION;
+        auto it = existing.find(fp);
+        DocumentState ds;
+        if (it != existing.end()) {
+            const DocMeta &ex = it->second;
+            if (ex.size_bytes != cur.size_bytes || ex.mtime != cur.mtime || ex._version != CURRENT_EMBEDDING_VERSION) {
+                ds.kind = DocumentState::Changed;
+                ds.info = DocumentInfo{fp, read_to_string(fp), cur};
+            } else {
+                ds.kind = DocumentState::Unchanged;
+                ds.filename = fp;
+            }
+        } else {
+            ds.kind = DocumentState::New;
+            ds.info = DocumentInfo{fp, read_to_string(fp), cur};
+        }
+        states.push_back(std::move(ds));
+    }
+    return states;
+}
+
+size_t Store::count_documents() const { return docs_.size(); }
+
+size_t Store::count_line_embeddings() const
+{
+    size_t n = 0;
+    for (auto &kv : extents_) n += (size_t)kv.second.n_rows;
+    return n;
+}
+
+void Store::flush_documents() const
+{
+    json::Value arr = json::Value::array();
+    for (auto &kv : docs_) {
+        json::Value d = json::Value::object();
+        d.set("path", json::Value::str(kv.second.path));
+        d.set("size_bytes", json::Value::uint(kv.second.size_bytes));
+        d.set("mtime", json::Value::sint(kv.second.mtime));
+        d.set("_version", json::Value::uint(kv.second._version));
+        arr.arr.push_back(std::move(d));
+    }
+    write_file_atomic(dir_ + "/documents.json", json::to_string_pretty(arr));
+}
+
+void Store::flush_line_embeddings() const
+{
+    // vectors first, then the extent table that references them (a crash in between leaves extra
+    // rows that no extent points at -- harmless; the reverse order could reference missing rows)
+    check(smt_corpus_save(corpus_, (dir_ + "/line_embeddings.f32").c_str()), "flush_line_embeddings");
+    json::Value root = json::Value::object();
+    json::Value arr = json::Value::array();
+    for (auto &kv : extents_) {
+        json::Value e = json::Value::object();
+        e.set("path", json::Value::str(kv.first));
+        e.set("first_row", json::Value::uint(kv.second.first_row));
+        e.set("n_rows", json::Value::uint(kv.second.n_rows));
+        arr.arr.push_back(std::move(e));
+    }
+    root.set("extents", std::move(arr));
+    write_file_atomic(dir_ + "/line_rows.json", json::to_string_pretty(root));
+}
+
+}  // namespace workspace
+
+// ================================================================== output
+namespace cmds {
+
+static void push_line(std::string &out, size_t line_number_1based, const std::string &line, bool highlight)
+{
+    char num[32];
+    snprintf(num, sizeof(num), "%4zu: ", line_number_1based);  // "{:4}: {}"
+    if (highlight) out += "\x1b[43m\x1b[30m";
+    out += num;
+    out += line;
+    if (highlight) out += "\x1b[0m";
+    out += "\n";
+}
+
+std::string print_search_results(const std::vector<search::SearchResult> &results, bool is_tty)
+{
+    std::string out;
+    for (auto &r : results) {
+        out += r.filename + ":" + std::to_string(r.start) + "::" + std::to_string(r.end) + " (" +
+               fmt::rust_display(r.distance) + ")\n";                                   // search.rs:43
+        for (size_t i = 0; i < r.lines.size(); ++i) {
+            const size_t line_number = r.start + i;
+            push_line(out, line_number + 1, r.lines[i], is_tty && line_number == r.match_line);  // :47-59
+        }
+        out += "\n";                                                                     // :61
+    }
+    return out;
+}
+
+std::string print_workspace_search_results(const std::vector<workspace::RankedLine> &ranked, size_t n_lines, bool is_tty)
+{
+    std::string out;
+    for (auto &rl : ranked) {
+        const size_t match = (size_t)rl.line_number;
+        const size_t start = match > n_lines ? match - n_lines : 0;
+        const size_t end = match + n_lines + 1;  // NOT clamped in the header (search.rs:77-79)
+        out += rl.path + ":" + std::to_string(start) + "::" + std::to_string(end) + " (" + fmt::rust_display(rl.distance) + ")\n";
+        std::string content;
+        bool ok = true;
+        try { content = read_to_string(rl.path); } catch (const Error &) { ok = false; }
+        if (ok) {
+            const std::vector<std::string> lines = lines_of(content);
+            const size_t actual_end = std::min(end, lines.size());
+            // the reference slices lines[start..actual_end] and panics if start > len (stale rows);
+            // we print nothing for that window instead ("do not replicate")
+            for (size_t ln = start; ln < actual_end; ++ln) push_line(out, ln + 1, lines[ln], is_tty && ln == match);
+        } else {
+            out += "    [Error: Could not read file content]\n";
+        }
+        out += "\n";
+    }
+    return out;
+}
+
+static json::Value result_json(const std::string &filename, size_t start, size_t end, size_t match, double distance,
+                               const std::string &content)
+{
+    json::Value o = json::Value::object();  // field order: src/json_mode.rs:17-30
+    o.set("filename", json::Value::str(filename));
+    o.set("start_line_number", json::Value::uint(start));
+    o.set("end_line_number", json::Value::uint(end));
+    o.set("match_line_number", json::Value::uint(match));
+    o.set("distance", json::Value::num(distance));
+    o.set("content", json::Value::str(content));
+    return o;
+}
+
+static std::string join_lines(const std::vector<std::string> &lines, size_t b, size_t e)
+{
+    std::string s;
+    for (size_t i = b; i < e; ++i) { if (i > b) s += "\n"; s += lines[i]; }
+    return s;
+}
+
+std::string search_results_json(const std::vector<search::SearchResult> &results)
+{
+    json::Value arr = json::Value::array();
+    for (auto &r : results)
+        arr.arr.push_back(result_json(r.filename, r.start, r.end, r.match_line, r.distance, join_lines(r.lines, 0, r.lines.size())));
+    json::Value root = json::Value::object();
+    root.set("results", std::move(arr));
+    return json::to_string_pretty(root) + "\n";
+}
+
+std::string workspace_results_json(const std::vector<workspace::RankedLine> &ranked, size_t n_lines)
+{
+    json::Value arr = json::Value::array();
+    for (auto &rl : ranked) {
+        const size_t match = (size_t)rl.line_number;
+        const size_t start = match > n_lines ? match - n_lines : 0;
+        const size_t end = match + n_lines + 1;
+        std::string content;
+        try {
+            const std::vector<std::string> lines = lines_of(read_to_string(rl.path));
+            const size_t actual_end = std::min(end, lines.size());
+            content = start <= actual_end ? join_lines(lines, start, actual_end) : "";
+        } catch (const Error &) {
+            content = "[Error: Could not read file content]";
+        }
+        arr.arr.push_back(result_json(rl.path, start, end, match, (double)rl.distance, content));  // `as f64` (search.rs:233)
+    }
+    json::Value root = json::Value::object();
+    root.set("results", std::move(arr));
+    return json::to_string_pretty(root) + "\n";
+}
+
+}  // namespace cmds
+}  // namespace semtools

@@ -1,0 +1,260 @@
+// host.h -- C++ host layer above the C ABI: the reference's search module
+// (src/search/mod.rs) and workspace store (src/workspace/{mod,store}.rs) with
+// the SAME names, argument meaning and error behaviour, re-implemented as thin
+// callers of libsemtools_hip (embeddings never live on the host: a Document
+// records which corpus rows are its lines).
+//
+// The reference is Rust; no Rust toolchain exists here, so this C++ layer is
+// what the CLI replica and the tests drive.  A Rust maintainer would keep the
+// reference's own host code and call the C ABI as INTEGRATION.md shows.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/semtools_hip.h"
+
+namespace semtools {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Rust str::lines(): split on '\n', strip one trailing '\r', no trailing empty piece.
+std::vector<std::string> lines_of(const std::string &content);
+// Rust str::to_lowercase() (simple per-code-point mapping; see DESIGN.md for the caveat).
+std::string to_lowercase(const std::string &s);
+std::string read_to_string(const std::string &path);  // throws Error like `?` on io::Error
+
+// ------------------------------------------------------------------ tokenizer
+// Stand-in for tokenizers::Tokenizer (the HF crate the reference uses through
+// model2vec-rs).  encode() returns ids with add_special_tokens=false; the
+// model drops unk ids and truncates, exactly where model2vec-rs does.
+class Tokenizer {
+public:
+    virtual ~Tokenizer() = default;
+    virtual void encode(const std::string &text, std::vector<uint32_t> &ids) const = 0;
+    virtual std::optional<uint32_t> unk_id() const { return std::nullopt; }
+    virtual size_t median_token_length() const { return 5; }
+    virtual uint64_t vocab_size() const = 0;
+};
+// whitespace words looked up in a vocab file (one token per line, id = line index)
+std::unique_ptr<Tokenizer> make_vocab_tokenizer(const std::string &vocab_path, const std::string &unk_token);
+// whitespace words hashed with FNV-1a into [0, vocab_size) -- for synthetic tests
+std::unique_ptr<Tokenizer> make_hash_tokenizer(uint64_t vocab_size);
+// caller-provided function (e.g. a binding of the real HF tokenizer)
+using TokenizeFn = std::function<void(const std::string &, std::vector<uint32_t> &)>;
+std::unique_ptr<Tokenizer> make_callback_tokenizer(TokenizeFn fn, uint64_t vocab_size, std::optional<uint32_t> unk,
+                                                   size_t median_len);
+
+namespace search {
+
+constexpr const char *MODEL_NAME = "minishlab/potion-multilingual-128M";  // src/search/mod.rs:16
+
+// model2vec_rs::model::StaticModel
+class StaticModel {
+public:
+    // table: [V x 256] f32 host array (the `embeddings` tensor), uploaded once.
+    StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize);
+    ~StaticModel();
+    StaticModel(const StaticModel &) = delete;
+
+    // encode_with_args(sentences, Some(max_length), batch_size): returns host vectors
+    std::vector<std::vector<float>> encode_with_args(const std::vector<std::string> &sentences,
+                                                     std::optional<size_t> max_length, size_t batch_size) const;
+    // same, but the rows are appended to `corpus` (resident); returns the first new row
+    uint64_t encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
+                         size_t batch_size, smt_corpus *corpus) const;
+    // encode_single(text) = encode(&[text]) -> max_length 512, batch 1024
+    std::vector<float> encode_single(const std::string &sentence) const;
+
+    smt_ctx *ctx() const { return ctx_; }
+    const Tokenizer &tokenizer() const { return *tok_; }
+
+private:
+    void tokenize_batch(const std::vector<std::string> &sentences, size_t begin, size_t end,
+                        std::optional<size_t> max_length, std::vector<uint32_t> &ids,
+                        std::vector<uint64_t> &offsets) const;
+    smt_ctx *ctx_;
+    std::unique_ptr<Tokenizer> tok_;
+    smt_model *model_ = nullptr;
+};
+
+// src/search/mod.rs:18-22.  `embeddings: Vec<Vec<f32>>` became a row range of the resident corpus.
+struct Document {
+    std::string filename;
+    std::vector<std::string> lines;
+    uint64_t first_row = 0;  // rows [first_row, first_row + lines.size()) of the owning corpus
+};
+
+struct SearchConfig {  // src/search/mod.rs:32-38
+    size_t n_lines = 0;
+    size_t top_k = 0;
+    std::optional<double> max_distance;
+    bool ignore_case = false;
+};
+
+struct SearchResult {  // src/search/mod.rs:40-47
+    std::string filename;
+    std::vector<std::string> lines;
+    size_t start = 0;
+    size_t end = 0;
+    size_t match_line = 0;
+    double distance = 0.0;
+};
+
+// The resident embedding matrix that a set of Documents points into.
+class Embeddings {
+public:
+    explicit Embeddings(smt_ctx *ctx);
+    ~Embeddings();
+    Embeddings(const Embeddings &) = delete;
+    smt_corpus *corpus() const { return corpus_; }
+    uint64_t rows() const;
+
+private:
+    smt_corpus *corpus_ = nullptr;
+};
+
+// src/search/mod.rs:49-75: None for empty content; original lines kept; lower-cased copy embedded
+std::optional<Document> create_document_from_content(const std::string &filename, const std::string &content,
+                                                     const StaticModel &model, bool ignore_case, Embeddings &emb);
+
+// src/search/mod.rs:77-120.  `documents` must be in the order their lines were embedded into `emb`.
+std::vector<SearchResult> search_documents(const std::vector<Document> &documents, const Embeddings &emb,
+                                           const std::vector<float> &query_embedding, const SearchConfig &config);
+
+// src/search/mod.rs:122-143 (first unreadable file aborts: throws Error)
+std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,
+                                       const StaticModel &model, const SearchConfig &config);
+
+}  // namespace search
+
+namespace workspace {
+
+constexpr uint32_t CURRENT_EMBEDDING_VERSION = 2;  // src/workspace/store.rs:29-34
+constexpr size_t LINE_EMBEDDING_SIZE = 256;         // src/workspace/store.rs:37
+
+struct WorkspaceConfig {  // src/workspace/mod.rs:8-26
+    std::string name = "default";
+    std::string root_dir;
+    size_t in_batch_size = 5000;
+    size_t oversample_factor = 3;
+};
+
+struct Workspace {  // src/workspace/mod.rs:28-101
+    WorkspaceConfig config;
+    static Workspace open(const std::optional<std::string> &workspace_name);
+    void save() const;
+    static std::string active(const std::optional<std::string> &workspace_name);  // throws "No active workspace..."
+    static std::string active_path(const std::optional<std::string> &workspace_name);
+    static std::string root_path(const std::string &name);
+    static std::string config_path_for(const std::string &name);
+};
+
+struct DocMeta {  // src/workspace/store.rs:52-58
+    std::string path;
+    uint64_t size_bytes = 0;
+    int64_t mtime = 0;
+    uint32_t _version = CURRENT_EMBEDDING_VERSION;
+    uint64_t id() const;  // fnv1a(path)  (:75-80)
+};
+
+struct DocumentInfo {  // src/search/mod.rs:24-30
+    std::string filename;
+    std::string content;
+    DocMeta meta;
+};
+
+struct DocumentState {  // src/workspace/store.rs:60-65
+    enum Kind { Unchanged, Changed, New } kind;
+    std::string filename;  // Unchanged
+    DocumentInfo info;     // Changed / New
+};
+
+struct LineEmbedding {  // src/workspace/store.rs:67-73 (embedding is a row of the resident corpus)
+    std::string path;
+    int32_t line_number = 0;
+    std::vector<float> embedding;  // host copy, only used by upsert_line_embeddings(host form)
+    uint64_t id() const;           // fnv1a(path || line LE)  (:82-89)
+};
+
+struct RankedLine {  // src/workspace/store.rs:91-96
+    std::string path;
+    int32_t line_number = 0;
+    float distance = 0.f;
+};
+
+struct WorkspaceStats {  // src/workspace/store.rs:98-103
+    size_t total_documents = 0;
+    bool has_index = true;
+    std::optional<std::string> index_type;
+};
+
+// Storage wrapper (src/workspace/store.rs:105-647).  The two Qdrant shards became:
+//   <dir>/documents.json      doc metadata (path, size_bytes, mtime, _version)
+//   <dir>/line_rows.bin       per document: path + (first_row, n_rows)  [lines of a doc are contiguous rows]
+//   <dir>/line_embeddings.f32 the resident corpus matrix (smt_corpus_save format)
+class Store {
+public:
+    static std::unique_ptr<Store> open(const std::string &workspace_dir, smt_ctx *ctx);
+    ~Store();
+
+    std::unordered_map<std::string, DocMeta> get_existing_docs(const std::vector<std::string> &paths) const;
+    void delete_document_metadata(const std::vector<std::string> &paths);
+    void delete_line_embeddings(const std::vector<std::string> &paths);
+    void delete_documents(const std::vector<std::string> &paths);
+    void upsert_document_metadata(const std::vector<DocMeta> &metas);
+    // host-vector form (reference signature) ...
+    void upsert_line_embeddings(const std::vector<LineEmbedding> &line_embeddings);
+    // ... and the resident form used by search_with_workspace: embed straight into the store's corpus
+    void upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
+                               const search::StaticModel &model);
+    WorkspaceStats get_stats() const;
+    std::vector<std::string> get_all_document_paths() const;
+    std::vector<RankedLine> search_line_embeddings(const std::vector<float> &query_vec,
+                                                   const std::vector<std::string> &subset_paths, size_t top_k,
+                                                   std::optional<float> max_distance) const;
+    std::vector<DocumentState> analyze_document_states(const std::vector<std::string> &file_paths) const;
+    size_t count_documents() const;
+    size_t count_line_embeddings() const;
+    void flush_documents() const;
+    void flush_line_embeddings() const;
+
+private:
+    Store() = default;
+    struct Extent { uint64_t first_row = 0; uint64_t n_rows = 0; };
+    void compact_if_sparse();
+    std::string dir_;
+    smt_ctx *ctx_ = nullptr;
+    smt_corpus *corpus_ = nullptr;
+    std::map<std::string, DocMeta> docs_;        // documents shard
+    std::map<std::string, Extent> extents_;      // path -> rows holding its lines (line i = first_row + i)
+    uint64_t dead_rows_ = 0;                     // rows of deleted/replaced documents awaiting compaction
+};
+
+}  // namespace workspace
+
+namespace search {
+// src/search/mod.rs:146-216
+std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::string> &files, const std::string &query,
+                                                         const StaticModel &model, const SearchConfig &config,
+                                                         const std::optional<std::string> &workspace_name);
+}  // namespace search
+
+// ------------------------------------------------------------------ output (src/cmds/search.rs, src/json_mode.rs)
+namespace cmds {
+std::string print_search_results(const std::vector<search::SearchResult> &results, bool is_tty);       // :35-63
+std::string print_workspace_search_results(const std::vector<workspace::RankedLine> &ranked, size_t n_lines,
+                                           bool is_tty);                                               // :66-110
+std::string search_results_json(const std::vector<search::SearchResult> &results);                     // :23-32
+std::string workspace_results_json(const std::vector<workspace::RankedLine> &ranked, size_t n_lines);  // :208-241
+}  // namespace cmds
+
+}  // namespace semtools

@@ -1,0 +1,250 @@
+"""GPU: the host layer end to end (config c1: `semtools search` of 1 query over 1k plaintext lines) --
+create_document_from_content / search_documents / search_files / search_with_workspace and the
+CLI replica -- compared BYTE FOR BYTE with the reference's output format filled with oracle numbers."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import refimpl, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "semtools_amd", "bin", "semtools")
+V = 20000
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    """A synthetic potion-style model on disk: model.safetensors (embeddings [V,256] f32), vocab.txt, config.json."""
+    from safetensors.numpy import save_file
+
+    d = tmp_path_factory.mktemp("model")
+    table = synth.table(V, seed=2)
+    save_file({"embeddings": table}, str(d / "model.safetensors"))
+    (d / "vocab.txt").write_text("".join(f"w{i}\n" for i in range(V - 1)) + "[UNK]\n")
+    (d / "config.json").write_text(json.dumps({"normalize": True, "unk_token": "[UNK]"}))
+    return d, table
+
+
+@pytest.fixture(scope="module")
+def model(gpu_ctx, model_dir):
+    from semtools_amd import host
+
+    m = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
+    yield m
+    m.close()
+
+
+def tok(text):
+    """the vocab tokenizer: whitespace words, unknown words -> [UNK] (dropped by the model, like model2vec)"""
+    out = []
+    for w in text.split():
+        if w.startswith("w") and w[1:].isdigit() and int(w[1:]) < V - 1 and str(int(w[1:])) == w[1:]:
+            out.append(int(w[1:]))
+    return out
+
+
+def oracle_embed(table, lines, max_tokens):
+    ids, offsets = [], [0]
+    for ln in lines:
+        t = tok(ln)
+        ids += t
+        offsets.append(len(ids))
+    return orc.embed_lines(table, np.array(ids, np.uint32), np.array(offsets, np.uint64), True, max_tokens)
+
+
+def expected_results(table, docs, query, n_lines, top_k, max_distance=None, lower=False):
+    emb = np.concatenate([oracle_embed(table, [l.lower() for l in lines] if lower else lines, 2048) for _, lines in docs])
+    q = oracle_embed(table, [query.lower() if lower else query], 512)[0]
+    res = orc.search_documents(emb, [len(l) for _, l in docs], q, n_lines, top_k, max_distance, accurate=True)
+    return refimpl.results_from_oracle(docs, res)
+
+
+@pytest.fixture(scope="module")
+def prose_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("corpus")
+    lines = synth.pseudo_prose(1000, vocab_size=V - 1, seed=1)
+    lines[500] = ""                                   # an empty line embeds to the zero vector
+    lines[600] = "unknownword anotherunknown"         # only unk tokens -> zero vector too
+    f1 = d / "doc1.txt"
+    f1.write_text("\n".join(lines) + "\n")
+    lines2 = synth.pseudo_prose(37, vocab_size=V - 1, seed=7)
+    f2 = d / "doc2.txt"
+    f2.write_text("\r\n".join(lines2))               # CRLF, no trailing newline
+    return [(str(f1), lines), (str(f2), lines2)]
+
+
+def test_c1_search_one_query_over_1k_lines_text_and_json(model, model_dir, prose_files):
+    from semtools_amd import host
+
+    table = model_dir[1]
+    docs = prose_files[:1]
+    query = docs[0][1][17]
+    want = expected_results(table, docs, query, 3, 3)
+    assert want[0]["match_line"] == 17 and want[0]["distance"] < 1e-9
+    got = host.search_files(model, query, [docs[0][0]], n_lines=3, top_k=3)
+    assert got == refimpl.print_search_results(want)
+    got_json = host.search_files(model, query, [docs[0][0]], n_lines=3, top_k=3, json=True)
+    assert got_json == refimpl.search_results_json(want)
+    assert host.search_files(model, query, [docs[0][0]], is_tty=True) == refimpl.print_search_results(want, is_tty=True)
+
+
+def test_cli_binary_matches_reference_format(model_dir, prose_files):
+    table = model_dir[1]
+    env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]))
+    env.pop("SEMTOOLS_WORKSPACE", None)
+    files = [p for p, _ in prose_files]
+    query = prose_files[1][1][5]
+    want = expected_results(table, prose_files, query, 2, 4)
+    r = subprocess.run([CLI, "search", query, *files, "-n", "2", "--top-k", "4"], capture_output=True, text=True, env=env,
+                       stdin=subprocess.DEVNULL)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == refimpl.print_search_results(want)
+    r = subprocess.run([CLI, "search", query, *files, "--context", "2", "--top-k", "4", "--json"], capture_output=True,
+                       text=True, env=env, stdin=subprocess.DEVNULL)
+    assert r.stdout == refimpl.search_results_json(want)
+    # threshold mode: every hit under the distance, top_k ignored (src/search/mod.rs:115-116)
+    want_thr = expected_results(table, prose_files, query, 0, 3, max_distance=0.8)
+    r = subprocess.run([CLI, "search", query, *files, "-n", "0", "-m", "0.8"], capture_output=True, text=True, env=env,
+                       stdin=subprocess.DEVNULL)
+    assert r.stdout == refimpl.print_search_results(want_thr) and len(want_thr) > 3
+    # stdin branch (src/cmds/search.rs:145-176)
+    content = "\n".join(prose_files[1][1]) + "\n"
+    want_stdin = expected_results(table, [("<stdin>", prose_files[1][1])], query, 1, 2)
+    r = subprocess.run([CLI, "search", query, "-n", "1", "--top-k", "2"], input=content, capture_output=True, text=True, env=env)
+    assert r.stdout == refimpl.print_search_results(want_stdin)
+    # no input at all
+    r = subprocess.run([CLI, "search", query], capture_output=True, text=True, env=env, stdin=subprocess.DEVNULL)
+    assert r.returncode == 1 and "No input provided" in r.stderr and r.stdout == ""
+    # unreadable file aborts the whole command (src/search/mod.rs:130)
+    r = subprocess.run([CLI, "search", query, files[0], "/nonexistent/file.txt"], capture_output=True, text=True, env=env,
+                       stdin=subprocess.DEVNULL)
+    assert r.returncode == 1 and r.stdout == ""
+
+
+def test_context_window_clamps_at_file_boundaries(model, model_dir, tmp_path):
+    from semtools_amd import host
+
+    f = tmp_path / "small.txt"
+    f.write_text("w1 w2\nw3 w4")
+    docs = [(str(f), ["w1 w2", "w3 w4"])]
+    want = expected_results(model_dir[1], docs, "w1 w2", 5, 3)
+    assert want[0]["start"] == 0 and want[0]["end"] == 2                      # mod.rs:337-357
+    assert host.search_files(model, "w1 w2", [str(f)], n_lines=5, top_k=3) == refimpl.print_search_results(want)
+    e = tmp_path / "empty.txt"
+    e.write_text("")
+    assert host.search_files(model, "w1", [str(e)]) == ""                      # empty content -> no Document
+
+
+def test_ignore_case_embeds_lowercase_but_prints_original(model, model_dir, tmp_path):
+    from semtools_amd import host
+
+    f = tmp_path / "mixed.txt"
+    lines = ["W10 W11 w12", "w20 W21", "W30"]
+    f.write_text("\n".join(lines))
+    want = expected_results(model_dir[1], [(str(f), lines)], "W20 w21", 0, 3, lower=True)
+    got = host.search_files(model, "W20 w21", [str(f)], n_lines=0, top_k=3, ignore_case=True)
+    assert got == refimpl.print_search_results(want)
+    assert "   2: w20 W21" in got and want[0]["match_line"] == 1 and want[0]["distance"] < 1e-9
+    # without -i the upper-case words are unknown tokens
+    plain = host.search_files(model, "W20 w21", [str(f)], n_lines=0, top_k=1)
+    assert plain == refimpl.print_search_results(expected_results(model_dir[1], [(str(f), lines)], "W20 w21", 0, 1))
+
+
+def test_encode_matches_oracle_bit_for_bit(model, model_dir):
+    sents = ["w1 w2 w3", "", "zzz", "w5 " * 600, "w7\tw8  w9"]
+    got = model.encode_with_args(sents, 2048)
+    assert np.array_equal(got, oracle_embed(model_dir[1], sents, 2048))
+    assert np.array_equal(model.encode_single("w5 " * 600), oracle_embed(model_dir[1], ["w5 " * 600], 512)[0])
+
+
+def test_callback_tokenizer_plugs_in(gpu_ctx, model_dir):
+    from semtools_amd import host
+
+    m = host.StaticModel(gpu_ctx, table=model_dir[1], tokenizer=lambda t: tok(t) + [V - 1], unk_id=V - 1)
+    assert np.array_equal(m.encode_with_args(["w3 w4 nope"], 2048), oracle_embed(model_dir[1], ["w3 w4"], 2048))
+    m.close()
+
+
+def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, capfd):
+    """search_with_workspace (src/search/mod.rs:146-216): first run embeds and persists, second run reuses,
+    a modified file is re-embedded, prune drops deleted files, status/stats keep the reference's text."""
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    table = model_dir[1]
+    a = tmp_path / "a.txt"
+    b = tmp_path / "b.txt"
+    la = prose_files[1][1][:20]
+    lb = prose_files[1][1][20:37]
+    a.write_text("\n".join(la) + "\n")
+    b.write_text("\n".join(lb) + "\n")
+    files = [str(a), str(b)]
+    host.workspace_use(None, "t1")
+    query = lb[3]
+
+    def want(docs, k, thr=None):
+        emb = np.concatenate([oracle_embed(table, lines, 2048) for _, lines in docs])
+        path = np.concatenate([np.full(len(l), i, np.uint32) for i, (_, l) in enumerate(docs)])
+        line = np.concatenate([np.arange(len(l), dtype=np.int32) for _, l in docs])
+        q = oracle_embed(table, [query], 512)[0]
+        return orc.search_line_embeddings(emb, path, line, q, np.arange(len(docs), dtype=np.uint32), k, thr)
+
+    def parse(text):
+        hits = []
+        for blk in text.strip("\n").split("\n\n"):
+            head = blk.split("\n")[0]
+            name, rest = head.rsplit(":", 3)[0], head[len(head.rsplit(":", 3)[0]) + 1:]
+            start, rest = rest.split("::")
+            end, dist = rest.split(" (")
+            hits.append((name, int(start), int(end), float(dist[:-1]), blk.split("\n")[1:]))
+        return hits
+
+    out = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=1, top_k=3)
+    err = capfd.readouterr().err
+    assert "Updating workspace with 37 lines from new/changed docs..." in err
+    assert "Updating workspace with 2 new/changed documents..." in err
+    exp = want([(str(a), la), (str(b), lb)], 3)
+    hits = parse(out)
+    assert [(h[0], h[1], h[2]) for h in hits] == [(files[r["path_id"]], max(r["line_number"] - 1, 0), r["line_number"] + 2) for r in exp]
+    assert hits[0][0] == str(b) and hits[0][1] == 2 and hits[0][2] == 5            # header end is NOT clamped
+    np.testing.assert_allclose([h[3] for h in hits], [r["distance"] for r in exp], atol=2e-6)
+    assert hits[0][4] == [f"{i + 1:4}: {lb[i]}" for i in (2, 3, 4)]
+
+    out2 = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=1, top_k=3)
+    assert capfd.readouterr().err == "" and out2 == out                              # unchanged -> nothing re-embedded
+    assert "Documents: 2" in host.workspace_status(model.ctx, "t1") and "Index: Yes (HNSW)" in host.workspace_status(model.ctx, "t1")
+    assert json.loads(host.workspace_status(model.ctx, "t1", json=True))["total_documents"] == 2
+
+    # workspace mode: top_k applies even with a threshold (store.rs:543)
+    out3 = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=0, top_k=2, max_distance=0.99)
+    assert len(parse(out3)) == len(want([(str(a), la), (str(b), lb)], 2, 0.99)) <= 2
+
+    # modify b (shrinks): re-embedded, no stale tail rows survive
+    lb2 = lb[:5]
+    b.write_text("\n".join(lb2) + "\n")
+    os.utime(b, (1_900_000_000, 1_900_000_000))
+    out4 = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=0, top_k=30)
+    assert "Updating workspace with 5 lines" in capfd.readouterr().err
+    assert len(parse(out4)) == 25 and all(h[1] < 5 for h in parse(out4) if h[0] == str(b))
+
+    # JSON output of workspace mode
+    js = json.loads(host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=1, top_k=1, json=True))
+    r0 = js["results"][0]
+    assert list(r0) == ["filename", "start_line_number", "end_line_number", "match_line_number", "distance", "content"]
+    assert r0["filename"] == str(b) and r0["match_line_number"] == 3 and r0["content"] == "\n".join(lb2[2:5])
+
+    # delete a, prune
+    a.unlink()
+    txt = host.workspace_prune(model.ctx, "t1")
+    assert txt == f"Found 1 stale documents:\n  - {a}\nRemoved 1 stale documents from workspace.\n"
+    assert host.workspace_prune(model.ctx, "t1") == "No stale documents found. Workspace is clean.\n"
+    assert json.loads(host.workspace_prune(model.ctx, "t1", json=True)) == {"files_removed": 0, "files_remaining": 1}
+    out5 = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=0, top_k=30)
+    assert all(h[0] == str(b) for h in parse(out5)) and len(parse(out5)) == 5

@@ -221,3 +221,24 @@ def test_shard_merge_equals_single(gpu_ctx, corpus20k):
         s.close()
     mr, md, cnt = smt.merge_topk(np.stack(rows), np.stack(dist), 10)
     assert mr[0].tolist() == want[0].tolist() and np.array_equal(md[0], want[1])
+
+
+@pytest.mark.parametrize("k", [65, 200, 1000])
+def test_large_top_k_falls_back_to_sort_path(corpus20k, k):
+    """top_k > 64 (the reference takes any k after sorting everything, mod.rs:107-119)."""
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    rows, dist = c.search(q, top_k=k)[0]
+    orows, odist = _oracle_topk(emb, q, k)
+    assert rows.tolist() == orows.tolist()
+    assert np.array_equal(dist, odist)
+
+
+def test_large_top_k_with_ranges_and_more_than_rows(corpus20k):
+    emb, c = corpus20k
+    q = synth.unit_query(4)[0]
+    rows, dist = c.search(q, top_k=500, ranges=[(100, 300), (1000, 1100)])[0]
+    idx = np.r_[100:300, 1000:1100]
+    orows, odist = _oracle_topk(emb[idx], q, 500)
+    assert rows.size == 300 and rows.tolist() == idx[orows.astype(np.int64)].tolist()
+    assert np.array_equal(dist, odist)

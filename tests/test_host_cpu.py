@@ -1,0 +1,97 @@
+"""CPU: host-layer pieces that need no GPU -- output formatting primitives (Rust Display / serde_json
+number formats), str::lines / to_lowercase, `workspace use`, CLI argument errors -- and the test-side
+format restatement (tests/refimpl.py) agreeing with the library's."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from semtools_amd import _lib as L, host
+from tests import refimpl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "semtools_amd", "bin", "semtools")
+
+
+def test_host_symbols_exported():
+    lib = L.lib()
+    src = open(os.path.join(ROOT, "include", "semtools_host.h")).read()
+    import re
+    declared = sorted(set(re.findall(r"\b(smt_host_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", src, flags=re.S))))
+    assert declared == sorted(L.HOST_EXPORTS)
+    for n in declared:
+        assert hasattr(lib, n), n
+
+
+@pytest.mark.parametrize("v,disp,js", [
+    (0.1, "0.1", "0.1"), (1e-7, "0.0000001", "1e-7"), (1.0, "1", "1.0"), (0.0, "0", "0.0"),
+    (0.7147720518571459, "0.7147720518571459", "0.7147720518571459"), (1234.5, "1234.5", "1234.5"),
+    (1e16, "10000000000000000", "1e16"), (0.00001, "0.00001", "0.00001"), (2.5e-6, "0.0000025", "2.5e-6"),
+    (123456789012345680000.0, "123456789012345680000", "1.2345678901234568e20"), (5e-324, None, "5e-324"),
+    (100.0, "100", "100.0"), (1.1102230246251565e-16, "0.00000000000000011102230246251565", "1.1102230246251565e-16"),
+])
+def test_number_formats_match_rust_and_serde(v, disp, js):
+    if disp is not None:
+        assert host.format_float(v, 0) == disp == refimpl.rust_f64(v)
+    assert host.format_float(v, 2) == js == refimpl.serde_f64(v)
+
+
+def test_f32_display_is_shortest_f32():
+    for v in (0.1, 0.71477205, 1.0 / 3.0, 1e-7, 16777216.0, 0.30000001192092896):
+        assert host.format_float(v, 1) == refimpl.rust_f32(v)
+    assert host.format_float(0.1, 1) == "0.1" and host.format_float(1.0 / 3.0, 1) == "0.33333334"
+
+
+def test_random_floats_roundtrip_and_agree():
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.random(200), rng.random(50) * 1e-6, 1.0 - rng.random(50) * 1e-9]):
+        d, j = host.format_float(x, 0), host.format_float(x, 2)
+        assert float(d) == x and float(j) == x
+        assert d == refimpl.rust_f64(x) and j == refimpl.serde_f64(x)
+
+
+@pytest.mark.parametrize("content", ["", "a", "a\n", "a\nb", "a\r\nb\r\n", "\n", "\n\n", "a\n\nb\n", "a\rb\n", "x\r", "é\nü\n"])
+def test_lines_like_rust(content):
+    assert host.split_lines(content) == refimpl.rust_lines(content)
+
+
+def test_rust_lines_examples():
+    assert refimpl.rust_lines("Line 1\nLine 2\nLine 3") == ["Line 1", "Line 2", "Line 3"]   # mod.rs:419-430
+    assert refimpl.rust_lines("") == []                                                       # mod.rs:434-441
+    assert refimpl.rust_lines("a\r\nb") == ["a", "b"] and refimpl.rust_lines("\n") == [""]
+
+
+def test_to_lowercase():
+    assert host.to_lowercase("Hello World") == "hello world"
+    assert host.to_lowercase("GOODBYE wOrLd 123 ÄÖÜ Ж") == "goodbye world 123 äöü ж"
+
+
+def test_workspace_use_writes_config_and_prints_reference_text(tmp_path, monkeypatch):
+    monkeypatch.setenv("HOME", str(tmp_path))
+    text = host.workspace_use(None, "proj")
+    assert text == ("Workspace 'proj' configured.\nTo activate it, run:\n  export SEMTOOLS_WORKSPACE=proj\n\n"
+                    "Or add this to your shell profile (.bashrc, .zshrc, etc.)\n\n"
+                    "Or use the `--workspace` option on the commands that support it\n")   # src/cmds/workspace.rs:46-53
+    cfg = json.load(open(tmp_path / ".semtools" / "workspaces" / "proj" / "config.json"))
+    assert cfg == {"name": "proj", "root_dir": str(tmp_path / ".semtools" / "workspaces" / "proj"),
+                   "in_batch_size": 5000, "oversample_factor": 3}                              # src/workspace/mod.rs:15-26
+    assert list(cfg) == ["name", "root_dir", "in_batch_size", "oversample_factor"]
+
+
+def test_cli_binary_argument_handling(tmp_path):
+    env = dict(os.environ, HOME=str(tmp_path))
+    r = subprocess.run([CLI], capture_output=True, text=True, env=env)
+    assert r.returncode == 2 and "search" in r.stderr and "workspace" in r.stderr
+    r = subprocess.run([CLI, "workspace", "use", "w1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("Workspace 'w1' configured.")
+    assert (tmp_path / ".semtools" / "workspaces" / "w1" / "config.json").exists()
+
+
+def test_refimpl_json_layout_matches_serde_pretty():
+    res = [dict(filename="a \"q\".txt", lines=["x", "y\tz"], start=0, end=2, match_line=1, distance=0.25)]
+    txt = refimpl.search_results_json(res)
+    assert json.loads(txt)["results"][0]["content"] == "x\ny\tz"
+    assert txt.splitlines()[0] == "{" and txt.splitlines()[1] == '  "results": [' and '"distance": 0.25,' in txt
+    assert refimpl.search_results_json([]) == '{\n  "results": []\n}\n'
