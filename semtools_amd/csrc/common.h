@@ -52,6 +52,7 @@ struct Tuning {
     int scan_unroll = 4;
     int scan_nontemporal = 1;
     int gemm_blocks = 0;        // 0 = CU count
+    int64_t select_debug_ptr = 0;  // device pointer to 16 u64 for phase stamps (profiling only)
 };
 
 }  // namespace smt

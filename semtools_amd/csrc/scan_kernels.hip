@@ -224,22 +224,45 @@ __device__ __forceinline__ double cos_finish_exact(double ab, double a2, double 
     return unclipped > 0.0 ? unclipped : 0.0;
 }
 
+// ab and b2 chains for one row (index order), a2 supplied by the caller (same for every row).
 template <typename QP, typename RP>
-__device__ __forceinline__ double exact_distance(QP q4, RP r4)
+__device__ __forceinline__ void exact_sums(QP q4, RP r4, double &ab_out, double &b2_out)
 {
-    double ab = 0.0, a2 = 0.0, b2 = 0.0;
-#pragma unroll 4
+    double ab = 0.0, b2 = 0.0;
+#pragma unroll 8
     for (int i = 0; i < 64; ++i) {
         const f32x4 a = q4[i];
         const f32x4 b = r4[i];
         const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
         const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
-        ab = ab + ax * bx; a2 = a2 + ax * ax; b2 = b2 + bx * bx;
-        ab = ab + ay * by; a2 = a2 + ay * ay; b2 = b2 + by * by;
-        ab = ab + az * bz; a2 = a2 + az * az; b2 = b2 + bz * bz;
-        ab = ab + aw * bw; a2 = a2 + aw * aw; b2 = b2 + bw * bw;
+        ab = ab + ax * bx; b2 = b2 + bx * bx;
+        ab = ab + ay * by; b2 = b2 + by * by;
+        ab = ab + az * bz; b2 = b2 + bz * bz;
+        ab = ab + aw * bw; b2 = b2 + bw * bw;
     }
-    return cos_finish_exact(ab, a2, b2);
+    ab_out = ab;
+    b2_out = b2;
+}
+
+template <typename QP>
+__device__ __forceinline__ double exact_norm2(QP q4)
+{
+    double a2 = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        const f32x4 a = q4[i];
+        const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
+        a2 = a2 + ax * ax; a2 = a2 + ay * ay; a2 = a2 + az * az; a2 = a2 + aw * aw;
+    }
+    return a2;
+}
+
+template <typename QP, typename RP>
+__device__ __forceinline__ double exact_distance(QP q4, RP r4)
+{
+    double ab, b2;
+    exact_sums(q4, r4, ab, b2);
+    return cos_finish_exact(ab, exact_norm2(q4), b2);
 }
 
 __global__ void rescore_rows_kernel(const float *corpus, const float *query, const uint32_t *rows,
@@ -272,6 +295,52 @@ constexpr int SEL_MAX_COLS = 8;
 constexpr int SEL_SURV_CAP = 1024;
 constexpr int ROW_STRIDE_F4 = 65;  // LDS row stride in float4 (1040 B): conflict-free b128 reads
 
+// c-th smallest key of `col[0..L)` (PAD = missing), published with atomicMin into *tau.
+// Executed by ONE wave; slots beyond L hold PAD which never satisfies the predicates below.
+template <int NS>
+__device__ __forceinline__ void column_tau(const key_t64 *col, int L, int c, key_t64 *tau)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t vh[NS], vl[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int b = lane + u * 64;
+        const key_t64 x = b < L ? col[b] : KEY_PAD;
+        vh[u] = (uint32_t)(x >> 32);
+        vl[u] = (uint32_t)x;
+    }
+    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    while (lo < hi) {  // smallest distance t with #{vh <= t} >= c   (mid <= 0xFFFFFFFE: PAD never counts)
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) cnt += __popcll(__ballot(vh[u] <= mid));
+        if (cnt >= c) hi = mid; else lo = mid + 1;
+    }
+    if (lo == 0xFFFFFFFFu) return;  // fewer than c entries: no bound from this column
+    const uint32_t dstar = lo;
+    int below = 0, ties = 0;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        below += __popcll(__ballot(vh[u] < dstar));
+        ties += __popcll(__ballot(vh[u] == dstar));
+    }
+    const int need = c - below;  // need-th smallest row among the entries at distance dstar (>= 1)
+    uint32_t rlo = 0xFFFFFFFFu;  // every tie needed: tau = (dstar, max row)
+    if (ties != need) {
+        rlo = 0;
+        uint32_t rhi = 0xFFFFFFFFu;
+        while (rlo < rhi) {
+            const uint32_t mid = rlo + ((rhi - rlo) >> 1);
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) cnt += __popcll(__ballot(vh[u] == dstar && vl[u] <= mid));
+            if (cnt >= need) rhi = mid; else rlo = mid + 1;
+        }
+    }
+    if (lane == 0) atomicMin(tau, ((key_t64)dstar << 32) | (key_t64)rlo);
+}
+
 struct FinalParams {
     const float *corpus;
     const float *queries;
@@ -286,7 +355,10 @@ struct FinalParams {
     uint64_t *out_rows;   // [nq][k_out]
     double *out_dist;     // [nq][k_out]
     uint64_t *out_counts; // [nq] or nullptr
+    unsigned long long *dbg;  // optional: s_memtime stamps of query 0's phases (tuning key select_debug_ptr)
 };
+
+#define SEL_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
 
 // One block per query.
 __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p)
@@ -296,80 +368,174 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     const int L = (int)p.n_lists;
     // LDS carve (all offsets multiples of 16; no static LDS in this kernel):
     f32x4 *s_rows = reinterpret_cast<f32x4 *>(smem_raw);                       // [kp+1][65] float4
-    key_t64 *s_col = reinterpret_cast<key_t64 *>(s_rows + (size_t)(kp + 1) * ROW_STRIDE_F4);  // [ncols][L]
-    key_t64 *s_surv = s_col + (size_t)SEL_MAX_COLS * L;                        // [SEL_SURV_CAP]
-    key_t64 *s_best = s_surv + SEL_SURV_CAP;                                   // [kp] (+pad to even)
+    key_t64 *s_surv = reinterpret_cast<key_t64 *>(s_rows + (size_t)(kp + 1) * ROW_STRIDE_F4);  // [SEL_SURV_CAP]
+    key_t64 *s_col = s_surv + SEL_SURV_CAP;                                      // [ncols][L] column entries
+    unsigned int *s_srank = reinterpret_cast<unsigned int *>(s_col + (size_t)SEL_MAX_COLS * SEL_MAX_LISTS);  // [96]
+    unsigned int *s_rank = s_srank + 96;                                        // [kp+pad] final ranks
+    double *s_qd = reinterpret_cast<double *>(s_rank + 80);                     // [256] query as f64
+    key_t64 *s_best = reinterpret_cast<key_t64 *>(s_qd + 256);                  // [kp] (+pad to even)
     double *s_d = reinterpret_cast<double *>(s_best + ((kp + 1) & ~1));        // [kp]
     uint32_t *s_r = reinterpret_cast<uint32_t *>(s_d + ((kp + 1) & ~1));       // [kp]
     key_t64 *s_tau = reinterpret_cast<key_t64 *>(s_r + ((kp + 3) & ~3));       // [1]
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_tau + 1);         // [0]=survivors [1]=valid
+    double *s_a2 = reinterpret_cast<double *>(s_tau + 1);                       // [1] query norm^2
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_a2 + 1);          // [0]=survivors [1]=valid
 
     const uint32_t qi = blockIdx.x;
     const key_t64 *lists = p.lists + (size_t)qi * p.list_stride;
+    SEL_STAMP(0);
 
-    // dyadic columns 1,2,4,.. < kp, plus kp
-    int cols[SEL_MAX_COLS];
-    int ncols = 0;
-    for (int j = 1; j < kp && ncols < SEL_MAX_COLS - 1; j <<= 1) cols[ncols++] = j;
-    cols[ncols++] = kp;
+    // ---- ONE global-latency phase: every key of the L lists goes to registers (<= 36 per thread)
+    constexpr int KREG = (SEL_MAX_LISTS * 72 + SEL_THREADS - 1) / SEL_THREADS;  // 36
+    const int M = L * kp;
+    const int n_round = (M + SEL_THREADS - 1) / SEL_THREADS;  // block-uniform
+    key_t64 kreg[KREG];
+    if (n_round <= 8) {  // common case (k <= 24): 8 back-to-back loads, one wait
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (int)threadIdx.x + i * SEL_THREADS;
+            const key_t64 x = lists[e < M ? e : M - 1];  // clamped: no branch between the loads
+            kreg[i] = e < M ? x : KEY_PAD;
+        }
+#pragma unroll
+        for (int i = 8; i < KREG; ++i) kreg[i] = KEY_PAD;
+    } else {
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            const int e = (int)threadIdx.x + i * SEL_THREADS;
+            const key_t64 x = lists[e < M ? e : M - 1];
+            kreg[i] = e < M ? x : KEY_PAD;
+        }
+    }
 
-    for (int e = threadIdx.x; e < ncols * L; e += blockDim.x) {
-        const int jj = e / L, b = e - jj * L;
-        s_col[(size_t)jj * L + b] = lists[(size_t)b * kp + (cols[jj] - 1)];
+    // dyadic columns 1,2,4,.. < kp, plus kp: column jj holds entry (1 << jj) except the last = kp
+    int ncols = 1;
+    for (int j = 1; j < kp && ncols < SEL_MAX_COLS; j <<= 1) ++ncols;
+    auto col_of = [&](int jj) { return jj < ncols - 1 ? (1 << jj) : kp; };
+    // the column entries are fetched in the same latency window as the keys (<= 4 per thread)
+    key_t64 cval[(SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS];
+    const int n_col_entries = ncols * L;
+#pragma unroll
+    for (int u = 0; u < (SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS; ++u) {
+        int t = (int)threadIdx.x + u * SEL_THREADS;
+        const bool ok = t < n_col_entries;
+        t = ok ? t : 0;
+        const int jj = t / L, bb = t - jj * L;
+        const key_t64 x = lists[(size_t)bb * kp + (col_of(jj) - 1)];
+        cval[u] = ok ? x : KEY_PAD;
     }
     if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; }
-    for (int t = threadIdx.x; t < kp; t += blockDim.x) s_best[t] = KEY_PAD;
-    __syncthreads();
-
-    // tau_j: the value whose rank inside its column is c_j - 1
-    for (int e = threadIdx.x; e < ncols * L; e += blockDim.x) {
-        const int jj = e / L, b = e - jj * L;
-        const key_t64 v = s_col[(size_t)jj * L + b];
-        if (v == KEY_PAD) continue;
-        const int c = (kp + cols[jj] - 1) / cols[jj];
-        const key_t64 *col = s_col + (size_t)jj * L;
-        int rank = 0;
-        for (int i = 0; i < L; ++i) rank += (col[i] < v) ? 1 : 0;
-        if (rank == c - 1) atomicMin(s_tau, v);
+    for (int t = threadIdx.x; t < kp; t += blockDim.x) { s_best[t] = KEY_PAD; s_rank[t] = 0; }
+#pragma unroll
+    for (int u = 0; u < (SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS; ++u) {
+        const int t = (int)threadIdx.x + u * SEL_THREADS;
+        if (t < n_col_entries) s_col[t] = cval[u];
     }
     __syncthreads();
-    const key_t64 tau = *s_tau;
+    SEL_STAMP(1);
 
-    // compact the survivors (keys <= tau); lists are sorted so stop at the first miss
-    for (int e = threadIdx.x; e < L * kp; e += blockDim.x) {
-        const key_t64 key = lists[e];
-        if (key != KEY_PAD && key <= tau) {
-            const unsigned int slot = atomicAdd(&s_cnt[0], 1u);
-            if (slot < (unsigned)SEL_SURV_CAP) s_surv[slot] = key;
+    // tau_j = c_j-th smallest key of column j.  One wave per column: the column sits in registers
+    // (4 or 8 keys per lane); bisection on the 32 distance bits with ballot counts, then -- only if
+    // several entries share that distance -- on the row bits.  No sort, no O(L^2) ranks.
+    {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (wave < ncols) {
+            const int colv = col_of(wave);
+            const int c = (kp + colv - 1) / colv;
+            if (L <= 256) column_tau<4>(s_col + (size_t)wave * L, L, c, s_tau);
+            else column_tau<8>(s_col + (size_t)wave * L, L, c, s_tau);
         }
     }
     __syncthreads();
+    SEL_STAMP(2);
+    const key_t64 tau = *s_tau;
+
+    // compact the survivors (keys <= tau) straight from the registers
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) {
+        if (i < n_round) {
+            const key_t64 key = kreg[i];
+            if (key != KEY_PAD && key <= tau) {
+                const unsigned int slot = atomicAdd(&s_cnt[0], 1u);
+                if (slot < (unsigned)SEL_SURV_CAP) s_surv[slot] = key;
+            }
+        }
+    }
+    __syncthreads();
+    SEL_STAMP(3);
     const int S = min((int)s_cnt[0], SEL_SURV_CAP);  // bound above guarantees S <= cap for kp <= 72
-    for (int e = threadIdx.x; e < S; e += blockDim.x) {
-        const key_t64 key = s_surv[e];
-        int rank = 0;
-        for (int i = 0; i < S; ++i) rank += (s_surv[i] < key) ? 1 : 0;
-        if (rank < kp) s_best[rank] = key;
+    if (S <= 96) {
+        // pair-parallel ranks: thread <-> (i, j), rank[i] += key[j] < key[i]
+        for (int t = threadIdx.x; t < S; t += blockDim.x) s_srank[t] = 0;
+        __syncthreads();
+        for (int pr = threadIdx.x; pr < S * S; pr += blockDim.x) {
+            const int i = pr / S, j = pr - i * S;
+            if (s_surv[j] < s_surv[i]) atomicAdd(&s_srank[i], 1u);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < S; t += blockDim.x)
+            if ((int)s_srank[t] < kp) s_best[s_srank[t]] = s_surv[t];
+    } else {
+        for (int e = threadIdx.x; e < S; e += blockDim.x) {
+            const key_t64 key = s_surv[e];
+            int rank = 0;
+            int i = 0;
+#pragma unroll 1
+            for (; i + 8 <= S; i += 8) {
+                key_t64 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = s_surv[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += (x[u] < key) ? 1 : 0;
+            }
+            for (; i < S; ++i) rank += (s_surv[i] < key) ? 1 : 0;
+            if (rank < kp) s_best[rank] = key;
+        }
     }
     __syncthreads();
+    SEL_STAMP(4);
+    if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[8] = (unsigned long long)S;
 
-    // stage query (slot kp) + candidate rows: one wave per row, 16 B per lane
+    // stage the candidate rows (one wave per row, 16 B per lane) and the query converted to f64
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    for (int c = wave; c <= kp; c += n_waves) {
-        const float *g = nullptr;
-        if (c == kp) g = p.queries + (size_t)qi * 256;
-        else if (s_best[c] != KEY_PAD) g = p.corpus + (uint64_t)(uint32_t)(s_best[c] & 0xFFFFFFFFull) * 256;
-        if (g) s_rows[(size_t)c * ROW_STRIDE_F4 + lane] = reinterpret_cast<const f32x4 *>(g)[lane];
+    if (threadIdx.x < 256) s_qd[threadIdx.x] = (double)p.queries[(size_t)qi * 256 + threadIdx.x];
+    for (int c = wave; c < kp; c += n_waves) {
+        if (s_best[c] != KEY_PAD) {
+            const float *g = p.corpus + (uint64_t)(uint32_t)(s_best[c] & 0xFFFFFFFFull) * 256;
+            s_rows[(size_t)c * ROW_STRIDE_F4 + lane] = reinterpret_cast<const f32x4 *>(g)[lane];
+        }
     }
     __syncthreads();
+    SEL_STAMP(5);
 
+    // exact rescoring: thread t < kp walks candidate t's row; thread 128 (another wave) walks the query
+    double my_ab = 0.0, my_b2 = 0.0;
+    const key_t64 my_key = (int)threadIdx.x < kp ? s_best[threadIdx.x] : KEY_PAD;
+    if (my_key != KEY_PAD) {
+        const f32x4 *r4 = s_rows + (size_t)threadIdx.x * ROW_STRIDE_F4;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+            const f32x4 b = r4[i];
+            const double a0 = s_qd[4 * i], a1 = s_qd[4 * i + 1], a2 = s_qd[4 * i + 2], a3 = s_qd[4 * i + 3];
+            const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
+            my_ab = my_ab + a0 * bx; my_b2 = my_b2 + bx * bx;
+            my_ab = my_ab + a1 * by; my_b2 = my_b2 + by * by;
+            my_ab = my_ab + a2 * bz; my_b2 = my_b2 + bz * bz;
+            my_ab = my_ab + a3 * bw; my_b2 = my_b2 + bw * bw;
+        }
+    }
+    if (threadIdx.x == 128) {
+        double a2 = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 256; ++i) a2 = a2 + s_qd[i] * s_qd[i];
+        *s_a2 = a2;
+    }
+    __syncthreads();
     if ((int)threadIdx.x < kp) {
-        const key_t64 key = s_best[threadIdx.x];
         double d = __builtin_inf();
         uint32_t r = 0xFFFFFFFFu;
-        if (key != KEY_PAD) {
-            r = (uint32_t)(key & 0xFFFFFFFFull);
-            d = exact_distance(s_rows + (size_t)kp * ROW_STRIDE_F4, s_rows + (size_t)threadIdx.x * ROW_STRIDE_F4);
+        if (my_key != KEY_PAD) {
+            r = (uint32_t)(my_key & 0xFFFFFFFFull);
+            d = cos_finish_exact(my_ab, *s_a2, my_b2);
             if (p.ws_threshold) {
                 // qdrant score_threshold keeps score > threshold (similarity metrics)
                 if (!((1.0 - d) > (double)p.ws_thr_score)) { d = __builtin_inf(); r = 0xFFFFFFFFu; }
@@ -383,25 +549,30 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     double *odist = p.out_dist + (size_t)qi * p.k_out;
     if (threadIdx.x < p.k_out) { orow[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull; odist[threadIdx.x] = __builtin_inf(); }
     __syncthreads();
-    if ((int)threadIdx.x < kp && s_r[threadIdx.x] != 0xFFFFFFFFu) {
-        const double d = s_d[threadIdx.x];
-        const uint32_t r = s_r[threadIdx.x];
-        int rank = 0;
-        for (int i = 0; i < kp; ++i) {
-            const double di = s_d[i];
-            const uint32_t ri = s_r[i];
-            if (ri != 0xFFFFFFFFu && (di < d || (di == d && ri < r))) ++rank;
+    SEL_STAMP(6);
+    for (int pr = threadIdx.x; pr < kp * kp; pr += blockDim.x) {
+        const int i = pr / kp, j = pr - i * kp;
+        const uint32_t ri = s_r[i], rj = s_r[j];
+        if (ri != 0xFFFFFFFFu && rj != 0xFFFFFFFFu) {
+            const double di = s_d[i], dj = s_d[j];
+            if (dj < di || (dj == di && rj < ri)) atomicAdd(&s_rank[i], 1u);
         }
-        if ((uint32_t)rank < p.k_out) { orow[rank] = p.row_base + r; odist[rank] = d; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kp && s_r[threadIdx.x] != 0xFFFFFFFFu) {
+        const unsigned rank = s_rank[threadIdx.x];
+        if (rank < p.k_out) { orow[rank] = p.row_base + s_r[threadIdx.x]; odist[rank] = s_d[threadIdx.x]; }
     }
     if (threadIdx.x == 0 && p.out_counts)
         p.out_counts[qi] = s_cnt[1] < p.k_out ? s_cnt[1] : p.k_out;
+    SEL_STAMP(7);
 }
 
 static size_t final_smem_bytes(uint32_t n_lists, uint32_t kp)
 {
-    return (size_t)(kp + 1) * ROW_STRIDE_F4 * 16 + (size_t)SEL_MAX_COLS * n_lists * 8 + (size_t)SEL_SURV_CAP * 8 +
-           (size_t)(kp + 2) * 8 * 2 + (size_t)(kp + 4) * 4 + 64;
+    (void)n_lists;
+    return (size_t)(kp + 1) * ROW_STRIDE_F4 * 16 + (size_t)SEL_SURV_CAP * 8 + (size_t)SEL_MAX_COLS * SEL_MAX_LISTS * 8 +
+           (size_t)(96 + 80) * 4 + 256 * 8 + (size_t)(kp + 2) * 8 * 2 + (size_t)(kp + 4) * 4 + 96;
 }
 
 // ------------------------------------------------- cross-shard top-k merge
@@ -486,6 +657,7 @@ int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint3
     f.out_rows = out_rows;
     f.out_dist = out_dist;
     f.out_counts = out_counts;
+    f.dbg = reinterpret_cast<unsigned long long *>(ctx->tune.select_debug_ptr);
     prof_begin(ctx, "select");
     hipLaunchKernelGGL(final_select_kernel, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
     prof_end(ctx, "select");
