@@ -101,8 +101,6 @@ def main():
     loc_dist = loc[1:2].view(torch.float64)
     gathered = (torch.empty((world, 1, k), dtype=torch.int64, device=device),
                 torch.empty((world, 1, k), dtype=torch.float64, device=device))
-    fin_buf = torch.empty((2, k), dtype=torch.int64, device=device)
-    fin = (fin_buf[0:1], fin_buf[1:2].view(torch.float64))
     ring = 64
     host = torch.empty((ring, 2, k), dtype=torch.int64).pin_memory()
     host_rows = host[:, 0]
@@ -110,12 +108,15 @@ def main():
 
     def step(i):
         q = queries[i % n_queries]
+        if world == 1:
+            slot = host[i % ring]  # pinned host memory is device-addressable: zero-copy result delivery
+            corpus.search_topk_device(q.data_ptr(), 1, k, row_base, slot[0].data_ptr(), slot[1].data_ptr())
+            return
         corpus.search_topk_device(q.data_ptr(), 1, k, row_base, loc_rows.data_ptr(), loc_dist.data_ptr())
-        if world > 1:
-            sdist.allgather_merge_topk(loc_rows, loc_dist, k, ctx=ctx, gathered=gathered, out=fin)
-            host[i % ring].copy_(fin_buf, non_blocking=True)
-        else:
-            host[i % ring].copy_(loc, non_blocking=True)
+        # N>1: all-gather the per-shard lists (RCCL), merge on the device, merged pairs go to the host ring
+        slot = host[i % ring]
+        sdist.allgather_merge_topk(loc_rows, loc_dist, k, ctx=ctx, gathered=gathered,
+                                   out=(slot[0:1], slot[1:2].view(torch.float64)))
 
     def sync():
         torch.cuda.synchronize(device)

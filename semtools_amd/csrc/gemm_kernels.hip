@@ -188,15 +188,20 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
                 pass &= valid16;
                 if (__builtin_amdgcn_ballot_w64(pass != 0)) {
                     if (pass) {
+                        // ONE slot grab per lane (all of its passing rows at once): the atomic's
+                        // round trip is paid once per tile, not once per candidate
+                        const unsigned n_pass = __popc(pass);
+                        const unsigned base = atomicAdd(&p.counts[q], n_pass);
                         key_t64 *dst = p.cand + (size_t)q * CAND_CAP;
+                        unsigned slot = base;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             if (pass & (1u << r)) {
-                                const unsigned slot = atomicAdd(&p.counts[q], 1u);
                                 if (slot < CAND_CAP) {
                                     const uint32_t row = (uint32_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * h);
                                     dst[slot] = make_key(dist_of(r), row);
                                 }
+                                ++slot;
                             }
                         }
                     }
