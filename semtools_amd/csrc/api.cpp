@@ -218,9 +218,10 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
         SMT_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "scan_threads must be a multiple of 64 in [64,1024]");
         ctx->tune.scan_threads = (int)value;
     } else if (k == "scan_unroll") {
-        SMT_REQUIRE(value == 4 || value == 8 || value == 16, "scan_unroll must be 4, 8 or 16");
+        SMT_REQUIRE(value == 2 || value == 4 || value == 8 || value == 16, "scan_unroll must be 2, 4, 8 or 16");
         ctx->tune.scan_unroll = (int)value;
     } else if (k == "scan_nontemporal") ctx->tune.scan_nontemporal = (int)value;
+    else if (k == "scan_prefetch") ctx->tune.scan_prefetch = (int)value;
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
     else if (k == "select_debug_ptr") ctx->tune.select_debug_ptr = value;
     else { set_error("unknown tuning key '%s'", key); return SMT_E_INVALID; }

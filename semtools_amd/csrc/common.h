@@ -48,9 +48,10 @@ struct ProfEntry {
 
 struct Tuning {
     int scan_blocks = 0;        // 0 = CU count (one block list per CU feeds the select stage)
-    int scan_threads = 1024;
+    int scan_threads = 512;     // 8 waves/CU x (4 + 4 prefetched) rows = 64 KiB in flight per CU (swept on MI355X)
     int scan_unroll = 4;
     int scan_nontemporal = 1;
+    int scan_prefetch = 1;      // software-pipelined row loads (single-query kernel)
     int gemm_blocks = 0;        // 0 = CU count
     int64_t select_debug_ptr = 0;  // device pointer to 16 u64 for phase stamps (profiling only)
 };

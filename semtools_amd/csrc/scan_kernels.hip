@@ -45,7 +45,7 @@ struct ScanParams {
 };
 
 // ------------------------------------------------------------------------- K2
-template <int NQ, int U, bool NT, bool FILTERED>
+template <int NQ, int U, bool NT, bool FILTERED, bool PF>
 __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -82,9 +82,7 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
         thr_r[n] = 0xFFFFFFFFu;
     }
 
-    for (uint64_t v0 = wave_global * U; v0 < p.n_virtual; v0 += stride) {
-        f32x4 c[U];
-        uint32_t row[U];
+    auto issue_loads = [&](uint64_t v0, f32x4 (&c)[U], uint32_t (&row)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             uint64_t v = v0 + j;
@@ -92,6 +90,21 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             row[j] = FILTERED ? map_virtual(v, p.ranges, p.prefix, p.n_ranges) : (uint32_t)v;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
             c[j] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+    };
+    f32x4 cn[U];
+    uint32_t rown[U];
+    if (PF && wave_global * U < p.n_virtual) issue_loads(wave_global * U, cn, rown);
+    for (uint64_t v0 = wave_global * U; v0 < p.n_virtual; v0 += stride) {
+        f32x4 c[U];
+        uint32_t row[U];
+        if (PF) {
+            // software pipeline: the NEXT iteration's rows are requested before this one is reduced
+#pragma unroll
+            for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
+            if (v0 + stride < p.n_virtual) issue_loads(v0 + stride, cn, rown);
+        } else {
+            issue_loads(v0, c, row);
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -617,14 +630,15 @@ static inline uint32_t candidates_per_list(uint32_t k_out)
 
 template <int NQ, int U>
 static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt,
-                               bool filtered)
+                               bool filtered, bool pf = false)
 {
     const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64);
     dim3 g(blocks), b(threads);
-#define SMT_LAUNCH(NTV, FV) \
-    hipLaunchKernelGGL((scan_topk_kernel<NQ, U, NTV, FV>), g, b, smem, ctx->stream, p)
-    if (nt) { if (filtered) SMT_LAUNCH(true, true); else SMT_LAUNCH(true, false); }
-    else { if (filtered) SMT_LAUNCH(false, true); else SMT_LAUNCH(false, false); }
+#define SMT_LAUNCH(NTV, FV, PFV) \
+    hipLaunchKernelGGL((scan_topk_kernel<NQ, U, NTV, FV, PFV>), g, b, smem, ctx->stream, p)
+    if (pf && NQ == 1 && nt && !filtered) SMT_LAUNCH(true, false, true);
+    else if (nt) { if (filtered) SMT_LAUNCH(true, true, false); else SMT_LAUNCH(true, false, false); }
+    else { if (filtered) SMT_LAUNCH(false, true, false); else SMT_LAUNCH(false, false, false); }
 #undef SMT_LAUNCH
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
@@ -707,9 +721,11 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
                           : launch_scan_variant<2, 8>(ctx, p, blocks, threads, nt, filtered);
             q0 += 2;
         } else {
-            if (U == 4) rc = launch_scan_variant<1, 4>(ctx, p, blocks, threads, nt, filtered);
-            else if (U == 16) rc = launch_scan_variant<1, 16>(ctx, p, blocks, threads, nt, filtered);
-            else rc = launch_scan_variant<1, 8>(ctx, p, blocks, threads, nt, filtered);
+            const bool pf = ctx->tune.scan_prefetch != 0;
+            if (U == 2) rc = launch_scan_variant<1, 2>(ctx, p, blocks, threads, nt, filtered, pf);
+            else if (U == 4) rc = launch_scan_variant<1, 4>(ctx, p, blocks, threads, nt, filtered, pf);
+            else if (U == 16) rc = launch_scan_variant<1, 16>(ctx, p, blocks, threads, nt, filtered, pf);
+            else rc = launch_scan_variant<1, 8>(ctx, p, blocks, threads, nt, filtered, pf);
             q0 += 1;
         }
         if (rc != SMT_OK) return rc;

@@ -67,6 +67,11 @@ def main():
         run("sweep", scan_threads=threads, scan_blocks=bpc * 256, scan_unroll=unroll, scan_nontemporal=nt)
     ctx.set_tuning("scan_threads", 1024); ctx.set_tuning("scan_blocks", 0); ctx.set_tuning("scan_unroll", 4)
     ctx.set_tuning("scan_nontemporal", 1)
+    for threads, blocks, unroll, pf in ((1024, 256, 4, 1), (1024, 256, 2, 1), (1024, 256, 8, 1), (512, 256, 4, 1), (512, 256, 8, 1),
+                                        (512, 512, 4, 1), (512, 512, 2, 1), (256, 512, 8, 1), (1024, 256, 2, 0), (1024, 256, 4, 0)):
+        run("prefetch" if pf else "plain", scan_threads=threads, scan_blocks=blocks, scan_unroll=unroll, scan_prefetch=pf)
+    ctx.set_tuning("scan_threads", 1024); ctx.set_tuning("scan_blocks", 0); ctx.set_tuning("scan_unroll", 4)
+    ctx.set_tuning("scan_prefetch", 0)
     for nq in (2, 4):
         run("multiq", nq=nq)
     # torch reference bandwidth: a plain read-reduce of the same matrix
