@@ -99,8 +99,7 @@ def main():
     loc = torch.empty((2, k), dtype=torch.int64, device=device)
     loc_rows = loc[0:1]
     loc_dist = loc[1:2].view(torch.float64)
-    gathered = (torch.empty((world, 1, k), dtype=torch.int64, device=device),
-                torch.empty((world, 1, k), dtype=torch.float64, device=device))
+    gathered = torch.empty((world, 1, 2, k), dtype=torch.int64, device=device)
     ring = 64
     host = torch.empty((ring, 2, k), dtype=torch.int64).pin_memory()
     host_rows = host[:, 0]
@@ -113,10 +112,9 @@ def main():
             corpus.search_topk_device(q.data_ptr(), 1, k, row_base, slot[0].data_ptr(), slot[1].data_ptr())
             return
         corpus.search_topk_device(q.data_ptr(), 1, k, row_base, loc_rows.data_ptr(), loc_dist.data_ptr())
-        # N>1: all-gather the per-shard lists (RCCL), merge on the device, merged pairs go to the host ring
-        slot = host[i % ring]
-        sdist.allgather_merge_topk(loc_rows, loc_dist, k, ctx=ctx, gathered=gathered,
-                                   out=(slot[0:1], slot[1:2].view(torch.float64)))
+        # N>1: ONE all-gather of the packed per-shard lists (RCCL), merge on the device, merged pairs are
+        # stored straight into the pinned host ring
+        sdist.allgather_merge_packed(loc.view(1, 2, k), k, ctx=ctx, gathered=gathered, out=host[i % ring].view(1, 2, k))
 
     def sync():
         torch.cuda.synchronize(device)

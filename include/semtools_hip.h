@@ -182,6 +182,12 @@ int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *
                           uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
                           uint64_t *out_rows_dev, double *out_dist_dev);
 
+/* Packed variant: one buffer per rank [nq][2][k] of 8-byte words -- row ids, then the f64
+ * distance bits -- so that ONE all-gather moves both.  packed_dev is the gathered
+ * [n_lists][nq][2][k_in]; out_packed_dev receives [nq][2][k_out].  Device pointers, async. */
+int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint32_t n_lists, uint32_t nq,
+                                 uint32_t k_in, uint32_t k_out, uint64_t *out_packed_dev);
+
 /* Tuning knobs (0 = library default); for benchmarking sweeps. */
 int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value);
 

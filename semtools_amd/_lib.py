@@ -24,7 +24,7 @@ EXPORTS = [
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
     "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
     "smt_corpus_save", "smt_corpus_load", "smt_search", "smt_search_topk_device", "smt_merge_topk",
-    "smt_merge_topk_device", "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
+    "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
 ]
 HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
@@ -114,6 +114,7 @@ def lib():
     L.smt_search_topk_device.argtypes = [vp, vp, u32, u32, u64, vp, vp]
     L.smt_merge_topk.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
     L.smt_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp]
+    L.smt_merge_topk_packed_device.argtypes = [vp, vp, u32, u32, u32, u32, vp]
     L.smt_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.smt_fnv1a_hash.argtypes = [C.c_char_p, u64]
     L.smt_fnv1a_hash.restype = u64

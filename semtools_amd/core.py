@@ -59,6 +59,11 @@ class Context:
                                               k_in, k_out, C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
 
 
+    def merge_topk_packed_device(self, packed_ptr, n_lists, nq, k_in, k_out, out_packed_ptr):
+        L.check(L.lib().smt_merge_topk_packed_device(self._h, C.c_void_p(packed_ptr), n_lists, nq, k_in, k_out,
+                                                     C.c_void_p(out_packed_ptr)))
+
+
 class Model:
     """Device-resident model2vec table (smt_model)."""
 

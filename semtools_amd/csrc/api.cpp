@@ -822,6 +822,17 @@ int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *
     return launch_merge_topk(ctx, rows_dev, dist_dev, n_lists, nq, k_in, k_out, out_rows_dev, out_dist_dev);
 }
 
+int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint32_t n_lists, uint32_t nq, uint32_t k_in,
+                                 uint32_t k_out, uint64_t *out_packed_dev)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(nq == 0 || k_out == 0 || (packed_dev && out_packed_dev), "null argument");
+    if ((rc = bind_device(ctx))) return rc;
+    if (nq == 0 || k_out == 0) return SMT_OK;
+    return launch_merge_topk_packed(ctx, packed_dev, n_lists, nq, k_in, k_out, out_packed_dev);
+}
+
 /* ------------------------------------------------------------------ ids ---- */
 
 uint64_t smt_fnv1a_hash(const uint8_t *bytes, uint64_t n) { return fnv1a(bytes, n); }

@@ -152,6 +152,9 @@ int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, ui
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
                       double *out_dist);
 
+int launch_merge_topk_packed(smt_ctx *ctx, const uint64_t *packed, uint32_t n_lists, uint32_t nq, uint32_t k_in,
+                             uint32_t k_out, uint64_t *out_packed);
+
 // top_k > 64 (rare): all keys + radix sort + exact rescoring of the best n_cand rows
 int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *query_dev, const smt_range *ranges_dev,
                              const uint64_t *prefix_dev, uint32_t n_ranges, uint64_t n_virtual, uint64_t n_cand,

@@ -589,33 +589,37 @@ static size_t final_smem_bytes(uint32_t n_lists, uint32_t kp)
 }
 
 // ------------------------------------------------- cross-shard top-k merge
-// rows/dist laid out [n_lists][nq][k_in]; one block per query.
-__global__ void merge_topk_kernel(const uint64_t *rows, const double *dist, uint32_t n_lists,
-                                  uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
-                                  double *out_dist)
+// Entry (list l, query qi, slot i): rows[l*list_stride + qi*query_stride + i], same for dist.
+// Plain layout [n_lists][nq][k_in]: list_stride = nq*k_in, query_stride = k_in.  Packed layout
+// [n_lists][nq][2][k_in] (rows then distance bits, one all-gather instead of two):
+// list_stride = nq*2*k_in, query_stride = 2*k_in, dist = rows + k_in.  One block per query.
+__global__ void merge_topk_kernel(const uint64_t *rows, const double *dist, uint32_t n_lists, uint64_t list_stride,
+                                  uint64_t query_stride, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
+                                  double *out_dist, uint64_t out_query_stride)
 {
     const uint32_t qi = blockIdx.x;
     const uint32_t M = n_lists * k_in;
+    uint64_t *orow = out_rows + (size_t)qi * out_query_stride;
+    double *odist = out_dist + (size_t)qi * out_query_stride;
     for (uint32_t t = threadIdx.x; t < k_out; t += blockDim.x) {
-        out_rows[(size_t)qi * k_out + t] = 0xFFFFFFFFFFFFFFFFull;
-        out_dist[(size_t)qi * k_out + t] = __builtin_inf();
+        orow[t] = 0xFFFFFFFFFFFFFFFFull;
+        odist[t] = __builtin_inf();
     }
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < M; e += blockDim.x) {
-        const uint32_t l = e / k_in, i = e % k_in;
-        const size_t idx = ((size_t)l * nq + qi) * k_in + i;
+        const size_t idx = (size_t)(e / k_in) * list_stride + (size_t)qi * query_stride + (e % k_in);
         const uint64_t r = rows[idx];
         if (r == 0xFFFFFFFFFFFFFFFFull) continue;
         const double d = dist[idx];
         uint32_t rank = 0;
         for (uint32_t f = 0; f < M; ++f) {
-            const size_t jdx = ((size_t)(f / k_in) * nq + qi) * k_in + (f % k_in);
+            const size_t jdx = (size_t)(f / k_in) * list_stride + (size_t)qi * query_stride + (f % k_in);
             const uint64_t rf = rows[jdx];
             if (rf == 0xFFFFFFFFFFFFFFFFull) continue;
             const double df = dist[jdx];
             if (df < d || (df == d && rf < r)) ++rank;
         }
-        if (rank < k_out) { out_rows[(size_t)qi * k_out + rank] = r; out_dist[(size_t)qi * k_out + rank] = d; }
+        if (rank < k_out) { orow[rank] = r; odist[rank] = d; }
     }
 }
 
@@ -785,8 +789,19 @@ int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, ui
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows, double *out_dist)
 {
     SMT_REQUIRE((uint64_t)n_lists * k_in <= 8192, "device merge handles up to 8192 candidates per query");
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, ctx->stream, rows, dist, n_lists, nq,
-                       k_in, k_out, out_rows, out_dist);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, ctx->stream, rows, dist, n_lists, (uint64_t)nq * k_in,
+                       (uint64_t)k_in, k_in, k_out, out_rows, out_dist, (uint64_t)k_out);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_merge_topk_packed(smt_ctx *ctx, const uint64_t *packed, uint32_t n_lists, uint32_t nq, uint32_t k_in,
+                             uint32_t k_out, uint64_t *out_packed)
+{
+    SMT_REQUIRE((uint64_t)n_lists * k_in <= 8192, "device merge handles up to 8192 candidates per query");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, ctx->stream, packed,
+                       reinterpret_cast<const double *>(packed + k_in), n_lists, (uint64_t)nq * 2 * k_in, (uint64_t)2 * k_in,
+                       k_in, k_out, out_packed, reinterpret_cast<double *>(out_packed + k_out), (uint64_t)2 * k_out);
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }

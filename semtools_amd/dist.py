@@ -24,6 +24,33 @@ def shard_bounds(n_rows, world_size):
     return [(min(r * per, n_rows), min((r + 1) * per, n_rows)) for r in range(world_size)]
 
 
+def allgather_merge_packed(local_packed, k_out, ctx=None, group=None, gathered=None, out=None):
+    """The one-collective form: local_packed int64 [nq, 2, k] = (row bit patterns, float64 distance bit
+    patterns) exactly as smt_search_topk_device wrote them into ONE buffer.  A single all-gather moves
+    both; the merge kernel (or the host merge on CPU tensors) reads the packed layout directly.
+    Returns int64 [nq, 2, k_out] (rows in [:, 0], distance bits in [:, 1])."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    nq, two, k_in = local_packed.shape
+    assert two == 2 and local_packed.dtype == torch.int64 and local_packed.is_contiguous()
+    g = gathered if gathered is not None else torch.empty((world, nq, 2, k_in), dtype=torch.int64,
+                                                          device=local_packed.device)
+    if world > 1:
+        dist.all_gather_into_tensor(g.view(world * nq * 2, k_in), local_packed.view(nq * 2, k_in), group=group)
+    else:
+        g[0].copy_(local_packed)
+    o = out if out is not None else torch.empty((nq, 2, k_out), dtype=torch.int64, device=local_packed.device)
+    if local_packed.is_cuda:
+        assert ctx is not None, "device merge needs the smt Context bound to torch's current stream"
+        ctx.merge_topk_packed_device(g.data_ptr(), world, nq, k_in, k_out, o.data_ptr())
+        return o
+    rows_u = np.ascontiguousarray(g[:, :, 0, :].numpy()).view(np.uint64)
+    dd = np.ascontiguousarray(g[:, :, 1, :].numpy()).view(np.float64)
+    mr, md, _ = core.merge_topk(rows_u, dd, k_out)
+    o[:, 0, :] = torch.from_numpy(mr.view(np.int64))
+    o[:, 1, :] = torch.from_numpy(md.view(np.int64))
+    return o
+
+
 def allgather_merge_topk(local_rows, local_dist, k_out, ctx=None, group=None, gathered=None, out=None):
     """local_rows int64 [nq,k] (uint64 bit pattern, padding = -1), local_dist float64 [nq,k].
 

@@ -39,6 +39,10 @@ def _worker(rank, world, port, n_rows, k, out_q):
         rows[qi, : len(res)] = [r["match_line"] + b for r in res]
         dd[qi, : len(res)] = [r["distance"] for r in res]
     mr, md = sdist.allgather_merge_topk(torch.from_numpy(rows), torch.from_numpy(dd), k)
+    # the one-collective packed form must give the same answer
+    packed = torch.from_numpy(np.stack([rows, dd.view(np.int64)], axis=1).copy())
+    mp = sdist.allgather_merge_packed(packed, k)
+    assert torch.equal(mp[:, 0], mr) and torch.equal(mp[:, 1], md.view(torch.int64))
     out_q.put((rank, mr.numpy().tolist(), md.numpy().tolist()))
     dist.barrier()
     dist.destroy_process_group()

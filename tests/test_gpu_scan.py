@@ -242,3 +242,44 @@ def test_large_top_k_with_ranges_and_more_than_rows(corpus20k):
     orows, odist = _oracle_topk(emb[idx], q, 500)
     assert rows.size == 300 and rows.tolist() == idx[orows.astype(np.int64)].tolist()
     assert np.array_equal(dist, odist)
+
+
+def test_device_merge_kernels_match_host_merge(gpu_ctx, corpus20k):
+    """merge_topk_kernel (plain and packed layouts) == the host merge == single-shard search."""
+    import torch
+    import semtools_amd as smt
+
+    emb, c = corpus20k
+    qs = synth.unit_query(31, nq=3)
+    k = 6
+    bounds = [0, 7000, 7001, 20000]
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream()
+    ctx = smt.Context(0, stream=stream.cuda_stream)
+    qd = torch.from_numpy(qs).to(dev)
+    packed = torch.empty((len(bounds) - 1, 3, 2, k), dtype=torch.int64, device=dev)
+    shards = []
+    for li, (b, e) in enumerate(zip(bounds[:-1], bounds[1:])):
+        x = torch.from_numpy(emb[b:e]).to(dev)
+        shards.append(x)
+        s = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=e - b)
+        loc = torch.empty((3, 2, k), dtype=torch.int64, device=dev)
+        for qi in range(3):  # K2 path per query, rows/dist of a query share one packed slot
+            s.search_topk_device(qd[qi].data_ptr(), 1, k, b, loc[qi, 0].data_ptr(), loc[qi, 1].data_ptr())
+        packed[li].copy_(loc)
+        s.close()
+    outp = torch.empty((3, 2, k), dtype=torch.int64, device=dev)
+    ctx.merge_topk_packed_device(packed.data_ptr(), len(bounds) - 1, 3, k, k, outp.data_ptr())
+    rows_plain = packed[:, :, 0, :].contiguous()
+    dist_plain = packed[:, :, 1, :].contiguous()
+    o_rows = torch.empty((3, k), dtype=torch.int64, device=dev)
+    o_dist = torch.empty((3, k), dtype=torch.float64, device=dev)
+    ctx.merge_topk_device(rows_plain.data_ptr(), dist_plain.data_ptr(), len(bounds) - 1, 3, k, k, o_rows.data_ptr(), o_dist.data_ptr())
+    torch.cuda.synchronize()
+    hr, hd, _ = smt.merge_topk(rows_plain.cpu().numpy().view(np.uint64), dist_plain.view(torch.float64).cpu().numpy(), k)
+    want = c.search(qs, top_k=k)
+    for qi in range(3):
+        assert outp[qi, 0].cpu().tolist() == o_rows[qi].cpu().tolist() == hr[qi].astype(np.int64).tolist() == want[qi][0].astype(np.int64).tolist()
+        assert np.array_equal(outp[qi, 1].cpu().numpy().view(np.float64), want[qi][1])
+        assert np.array_equal(o_dist[qi].cpu().numpy(), hd[qi])
+    ctx.close()
