@@ -1,0 +1,84 @@
+"""GPU, BASELINE.json's full sizes (c2: 1 query x 1M rows; c3: batched queries x 10M rows), checked through
+size-independent properties instead of the (too slow at this size) CPU oracle:
+  * planted rows: copies of the query come back first, in ascending row order, distance exactly 0;
+  * agreement with an independent fp64 torch evaluation of the same scores on the GPU;
+  * row-sharding + merge == single shard;  batched path == single-query path;  determinism."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(rows, seed):
+    import torch
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.randn(rows, 256, device=dev, generator=g)
+    x /= x.norm(dim=1, keepdim=True)
+    return x
+
+
+def test_c2_one_query_one_million_rows(gpu_ctx):
+    import torch
+    import semtools_amd as smt
+
+    rows = 1_000_000
+    x = _make(rows, 3)
+    q = _make(1, 4)[0]
+    planted = [7, 123_456, 999_999]
+    x[planted] = q
+    x[[11, 500_000]] = 0.0
+    near = q + 0.02 * _make(1, 5)[0]
+    x[[42, 77_777]] = near                                  # exact tie pair -> ascending rows
+    torch.cuda.synchronize()
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=rows)
+    qh = q.cpu().numpy()
+    r, d = c.search(qh, top_k=10)[0]
+    assert r[:5].tolist() == planted + [42, 77_777]
+    assert d[:3].tolist() == [0.0, 0.0, 0.0] or (d[:3] < 2.3e-16).all()
+    assert d[3] == d[4] and (np.diff(d) >= 0).all()
+    ref = 1.0 - (x.double() @ q.double()) / (x.double().norm(dim=1).clamp_min(1e-300) * q.double().norm())
+    ref[[11, 500_000]] = 1.0
+    tv, ti = torch.topk(ref, 10, largest=False)
+    np.testing.assert_allclose(d, np.sort(tv.cpu().numpy()), rtol=0, atol=1e-9)
+    assert set(r[5:].tolist()) == set(ti.cpu().tolist()) - set(r[:5].tolist())
+    # determinism + threshold mode consistency at full size
+    r2, d2 = c.search(qh, top_k=10)[0]
+    assert r2.tolist() == r.tolist() and np.array_equal(d2, d)
+    rt, dt = c.search(qh, max_distance=float(d[9]) + 1e-12)[0]
+    assert rt.tolist() == r.tolist() and np.array_equal(dt, d)
+    # 4 contiguous shards + merge == single shard
+    lists_r, lists_d = [], []
+    for b, e in ((0, 250_000), (250_000, 500_001), (500_001, 999_000), (999_000, rows)):
+        s = smt.Corpus(gpu_ctx, device_ptr=x[b:e].data_ptr(), rows=e - b)
+        rr, dd = s.search(qh, top_k=10, row_base=b)[0]
+        lists_r.append(rr[None]); lists_d.append(dd[None]); s.close()
+    mr, md, _ = smt.merge_topk(np.stack(lists_r), np.stack(lists_d), 10)
+    assert mr[0].tolist() == r.tolist() and np.array_equal(md[0], d)
+    c.close()
+
+
+def test_c3_batched_queries_ten_million_rows(gpu_ctx):
+    import torch
+    import semtools_amd as smt
+
+    rows, nq, k = 10_000_000, 96, 10
+    x = _make(rows, 3)
+    q = _make(nq, 5)
+    x[1_234_567] = q[0]
+    x[[9_999_999, 5]] = q[1]
+    torch.cuda.synchronize()
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=rows)
+    got = c.search(q.cpu().numpy(), top_k=k)                # K3 path (nq >= 8)
+    assert got[0][0][0] == 1_234_567 and got[0][1][0] < 2.3e-16
+    assert got[1][0][:2].tolist() == [5, 9_999_999]
+    xn = x.double().norm(dim=1)
+    for i in (0, 1, 2, 50, 95):                              # independent fp64 check + single-query path
+        ref = 1.0 - (x.double() @ q[i].double()) / (xn * q[i].double().norm())
+        tv, ti = torch.topk(ref.clamp_min(0.0), k, largest=False)
+        np.testing.assert_allclose(got[i][1], tv.cpu().numpy(), rtol=0, atol=1e-9)
+        one = c.search(q[i].cpu().numpy(), top_k=k)[0]       # K2 path
+        assert one[0].tolist() == got[i][0].tolist() and np.array_equal(one[1], got[i][1])
+    c.close()

@@ -1,0 +1,56 @@
+"""GPU: randomised shapes (hypothesis) -- rows, k, ranges, duplicates, zero rows, query count --
+K2/K3/threshold/large-k all against the oracle.  Small sizes, many cases."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(emb, q, k, thr=None):
+    res = orc.search_documents(emb, [len(emb)], q, 0, k, thr, accurate=True)
+    return [r["match_line"] for r in res], [r["distance"] for r in res]
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(1, 3000), k=st.integers(1, 80), nq=st.sampled_from([1, 1, 2, 3, 5, 8, 9, 33]),
+       seed=st.integers(0, 10_000), dup=st.sampled_from([0.0, 0.05, 0.5]), use_ranges=st.booleans())
+def test_topk_random_shapes(gpu_ctx, n, k, nq, seed, dup, use_ranges):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(n, seed=seed, dup_frac=dup, zero_frac=0.01)
+    qs = synth.unit_query(seed + 1, nq=nq)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    ranges, idx = None, np.arange(n)
+    if use_ranges and n > 4:
+        rng = np.random.default_rng(seed)
+        cuts = np.sort(rng.choice(np.arange(1, n), size=min(6, n - 1), replace=False))
+        segs = [(int(a), int(b)) for a, b in zip(cuts[::2], cuts[1::2])]
+        if segs:
+            ranges = segs
+            idx = np.concatenate([np.arange(a, b) for a, b in segs])
+    got = c.search(qs, top_k=k, ranges=ranges)
+    for i in range(nq):
+        orows, odist = _oracle(emb[idx], qs[i], k)
+        assert got[i][0].tolist() == idx[np.array(orows, dtype=np.int64)].tolist() if orows else got[i][0].size == 0
+        assert np.array_equal(got[i][1], np.array(odist))
+    c.close()
+
+
+@settings(max_examples=15, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(1, 5000), seed=st.integers(0, 10_000), thr=st.floats(0.5, 1.2))
+def test_threshold_random(gpu_ctx, n, seed, thr):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(n, seed=seed, dup_frac=0.1, zero_frac=0.02)
+    q = synth.unit_query(seed + 7)[0]
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    rows, dist = c.search(q, top_k=3, max_distance=thr)[0]
+    orows, odist = _oracle(emb, q, 3, thr)
+    assert rows.tolist() == orows and np.array_equal(dist, np.array(odist))
+    c.close()
