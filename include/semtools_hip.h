@@ -188,6 +188,35 @@ int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *
 int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint32_t n_lists, uint32_t nq,
                                  uint32_t k_in, uint32_t k_out, uint64_t *out_packed_dev);
 
+/* ----------------------------------------------------------------- IVF-PQ
+ * Approximate index over a resident corpus (BASELINE config 5).  There is NO reference
+ * counterpart: the reference's workspace store scans exactly (README's "IVF_PQ" is a stale
+ * label); the contract is recall against smt_search on the same corpus.  Every returned
+ * (row, distance) is exact -- candidates from the ADC scan are re-ranked with the exact f64
+ * distance -- only top-k membership is approximate.  The index keeps a pointer to `corpus`,
+ * which must stay alive and unchanged. */
+typedef struct smt_ivfpq smt_ivfpq;
+typedef struct smt_ivfpq_params {
+    uint32_t nlist;        /* coarse lists: multiple of 32 in [32, 4096]                  */
+    uint32_t m;            /* PQ sub-quantisers: 32 (dsub = 8)                            */
+    uint32_t nbits;        /* 8                                                           */
+    uint32_t train_iters;  /* k-means iterations for both quantisers (0 = 10)            */
+    uint64_t train_sample; /* training rows, evenly spaced (0 = 64 * nlist)              */
+} smt_ivfpq_params;
+int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *params, smt_ivfpq **out);
+void smt_ivfpq_destroy(smt_ivfpq *index);
+/* nprobe lists scanned per query; in every probed list the `rerank` best ADC candidates
+ * (0 = 256; range [4, 256]) are re-scored against the full-precision rows inside the scan
+ * kernel, and the best top_k + 8 of all lists get the exact f64 distance.  top_k <= 56.
+ * Outputs as in smt_search. */
+int smt_ivfpq_search(smt_ivfpq *index, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe,
+                     uint32_t rerank, uint64_t row_base, uint64_t *out_rows, double *out_dist,
+                     uint64_t *out_counts, uint64_t out_cap);
+/* build_ms4 = {coarse k-means, assign all rows, PQ training, sort + encode} */
+int smt_ivfpq_info(const smt_ivfpq *index, uint64_t *n_rows, uint32_t *nlist, uint64_t *index_bytes,
+                   double *build_ms4);
+int smt_ivfpq_list_sizes(const smt_ivfpq *index, uint64_t *sizes_host /* [nlist] */);
+
 /* Tuning knobs (0 = library default); for benchmarking sweeps. */
 int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value);
 

@@ -24,7 +24,8 @@ EXPORTS = [
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
     "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
     "smt_corpus_save", "smt_corpus_load", "smt_search", "smt_search_topk_device", "smt_merge_topk",
-    "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
+    "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_info", "smt_ivfpq_list_sizes",
+    "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
 ]
 HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
@@ -38,6 +39,11 @@ TOKENIZE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER
 
 class SmtRange(C.Structure):
     _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64)]
+
+
+class SmtIvfPqParams(C.Structure):
+    _fields_ = [("nlist", C.c_uint32), ("m", C.c_uint32), ("nbits", C.c_uint32), ("train_iters", C.c_uint32),
+                ("train_sample", C.c_uint64)]
 
 
 class SmtError(RuntimeError):
@@ -115,6 +121,12 @@ def lib():
     L.smt_merge_topk.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
     L.smt_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp]
     L.smt_merge_topk_packed_device.argtypes = [vp, vp, u32, u32, u32, u32, vp]
+    L.smt_ivfpq_build.argtypes = [vp, P(SmtIvfPqParams), P(vp)]
+    L.smt_ivfpq_destroy.argtypes = [vp]
+    L.smt_ivfpq_destroy.restype = None
+    L.smt_ivfpq_search.argtypes = [vp, vp, u32, u32, u32, u32, u64, vp, vp, vp, u64]
+    L.smt_ivfpq_info.argtypes = [vp, P(u64), P(u32), P(u64), P(f64)]
+    L.smt_ivfpq_list_sizes.argtypes = [vp, vp]
     L.smt_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.smt_fnv1a_hash.argtypes = [C.c_char_p, u64]
     L.smt_fnv1a_hash.restype = u64

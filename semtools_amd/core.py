@@ -206,6 +206,50 @@ class Corpus:
                                                C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
 
 
+class IvfPq:
+    """IVF-PQ index over a resident Corpus (smt_ivfpq).  Approximate top-k membership, exact distances."""
+
+    def __init__(self, corpus, nlist=4096, train_iters=10, train_sample=0):
+        self.corpus = corpus
+        self._h = C.c_void_p()
+        prm = L.SmtIvfPqParams(int(nlist), 32, 8, int(train_iters), int(train_sample))
+        L.check(L.lib().smt_ivfpq_build(corpus._h, C.byref(prm), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_ivfpq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        n, nl, nb = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        ms = (C.c_double * 4)()
+        L.check(L.lib().smt_ivfpq_info(self._h, C.byref(n), C.byref(nl), C.byref(nb), ms))
+        return dict(rows=int(n.value), nlist=int(nl.value), index_bytes=int(nb.value),
+                    build_ms=dict(coarse_kmeans=ms[0], assign_all=ms[1], pq_train=ms[2], sort_encode=ms[3]))
+
+    def list_sizes(self):
+        out = np.empty(self.info()["nlist"], dtype=np.uint64)
+        L.check(L.lib().smt_ivfpq_list_sizes(self._h, L.np_ptr(out)))
+        return out
+
+    def search(self, queries, top_k=10, nprobe=32, rerank=0, row_base=0):
+        q = _f32c(queries).reshape(-1, L.DIM)
+        nq = q.shape[0]
+        cap = max(int(top_k), 1)
+        out_rows = np.empty((nq, cap), dtype=np.uint64)
+        out_dist = np.empty((nq, cap), dtype=np.float64)
+        counts = np.zeros(nq, dtype=np.uint64)
+        L.check(L.lib().smt_ivfpq_search(self._h, L.np_ptr(q), nq, int(top_k), int(nprobe), int(rerank), int(row_base),
+                                         L.np_ptr(out_rows), L.np_ptr(out_dist), L.np_ptr(counts), cap))
+        return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
+
+
 def merge_topk(rows, dist, k_out):
     """Host merge of per-shard sorted top-k lists laid out [n_lists][nq][k_in]."""
     rows = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -33,16 +33,10 @@
 // by the K2 scan.
 #include "common.h"
 #include "device_utils.h"
+#include "mfma_tile.h"
 
 namespace smt {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int GEMM_THREADS = 512;              // 8 waves: 2 per SIMD
-constexpr int GEMM_WAVES = GEMM_THREADS / 64;
-constexpr int QT_ROWS = 32;                    // queries per tile
-constexpr int QT_STRIDE_F4 = 65;               // 1040-B LDS rows: conflict-free ds_read_b128
-constexpr int QT_F4 = QT_ROWS * QT_STRIDE_F4;  // float4 per staged tile
 constexpr uint32_t CAND_CAP = 2048;            // candidate slots per query
 constexpr int LEVEL_RATIO = 16;
 constexpr int LEVEL0_MAX_TILES = 32;           // level 0 appends every row: <= 1024 per query

@@ -60,3 +60,27 @@ def pseudo_prose(n_lines, vocab_size=50000, seed=1, min_words=5, max_words=20):
         ranks = (rng.zipf(1.1, size=k) - 1) % vocab_size
         lines.append(" ".join(f"w{int(r)}" for r in ranks))
     return lines
+
+
+def clustered_rows_torch(n, n_centers, latent, seed, device, spread=0.35, noise=0.01):
+    """Config c5's clustered corpus, generated on the device (torch): row = topic centre + spread * z . B_topic
+    + noise, normalised; z ~ N(0, I_latent), B_topic a per-topic latent x 256 basis.  Nearest neighbours of a row
+    are the rows of its topic that are close in the latent space -- a graded, well-defined top-k with structure a
+    quantiser can encode (isotropic 256-d noise has none)."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    centers = torch.randn(n_centers, 256, device=device, generator=g)
+    centers /= centers.norm(dim=1, keepdim=True)
+    basis = torch.randn(n_centers, latent, 256, device=device, generator=g) / 16.0
+    which = torch.randint(0, n_centers, (n,), device=device, generator=g)
+    x = torch.empty(n, 256, device=device)
+    step = 500_000
+    for b in range(0, n, step):
+        e = min(n, b + step)
+        z = torch.randn(e - b, 1, latent, device=device, generator=g) * (spread / latent ** 0.5)
+        xs = centers[which[b:e]] + torch.bmm(z, basis[which[b:e]]).squeeze(1)
+        xs += (noise / 16.0) * torch.randn(e - b, 256, device=device, generator=g)
+        x[b:e] = xs / xs.norm(dim=1, keepdim=True)
+    return x

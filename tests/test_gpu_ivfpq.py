@@ -1,0 +1,110 @@
+"""GPU: IVF-PQ index (BASELINE config 5).  No reference semantics exist, so the checks are:
+recall@k against this library's own exact search on clustered data, exactness of every returned
+(row, distance) pair, monotone recall in nprobe, determinism of build + query."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def clustered(n, n_centers, seed, latent=8, spread=0.35, noise=0.01):
+    """Clustered corpus with graded neighbourhoods (config c5's 'clustered variant'): row = topic centre +
+    spread * z . B_topic + noise, normalised, z ~ N(0, I_latent), B_topic a per-topic latent x 256 basis.
+    Nearest neighbours of a row = rows of its topic that are close in the latent space: a well-defined top-k
+    with structure a quantiser can encode (isotropic 256-d noise has none)."""
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((n_centers, 256)).astype(np.float32)
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    basis = rng.standard_normal((n_centers, latent, 256)).astype(np.float32) / 16.0
+    which = rng.integers(0, n_centers, n)
+    z = rng.standard_normal((n, latent)).astype(np.float32) * (spread / np.sqrt(latent))
+    x = centers[which] + np.einsum("nl,nld->nd", z, basis[which]) + (noise / 16.0) * rng.standard_normal((n, 256)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return np.ascontiguousarray(x.astype(np.float32)), centers
+
+
+@pytest.fixture(scope="module")
+def index(gpu_ctx):
+    import semtools_amd as smt
+
+    x, centers = clustered(60000, 256, seed=1)
+    c = smt.Corpus(gpu_ctx)
+    c.append(x)
+    ix = smt.IvfPq(c, nlist=256, train_iters=8)
+    yield x, c, ix
+    ix.close(); c.close()
+
+
+def recall(ix_res, exact_res):
+    hit = tot = 0
+    for (r, _), (e, _) in zip(ix_res, exact_res):
+        hit += len(set(r.tolist()) & set(e.tolist()))
+        tot += len(e)
+    return hit / tot
+
+
+def test_build_partitions_every_row_once(index):
+    x, c, ix = index
+    info = ix.info()
+    sizes = ix.list_sizes()
+    assert info["rows"] == len(x) and info["nlist"] == 256 and int(sizes.sum()) == len(x)
+    assert sizes.max() < 20 * sizes.mean()                     # k-means on blobs: no giant list
+    assert info["index_bytes"] < len(x) * 40 + 2_000_000       # 32 B codes + 4 B ids per row + codebooks
+
+
+def test_recall_and_exact_distances(index):
+    x, c, ix = index
+    rng = np.random.default_rng(5)
+    qs = x[rng.choice(len(x), 64, replace=False)] + 0.002 * rng.standard_normal((64, 256)).astype(np.float32)
+    exact = c.search(qs, top_k=10)
+    prev = 0.0
+    for nprobe in (1, 4, 16, 64):
+        got = ix.search(qs, top_k=10, nprobe=nprobe)
+        r = recall(got, exact)
+        assert r >= prev - 0.02, (nprobe, r, prev)              # more lists never hurts (up to ADC noise)
+        prev = r
+        for qi, (rows, dist) in enumerate(got):                  # every returned pair is an exact pair
+            want = np.array([orc.cosine(qs[qi], x[int(rr)], accurate=True) for rr in rows])
+            assert np.array_equal(dist, want) and (np.diff(dist) >= 0).all() and len(set(rows.tolist())) == len(rows)
+    assert prev >= 0.97, prev                                    # nprobe=64 of 256 lists, default rerank (256/list)
+    shallow = ix.search(qs, top_k=10, nprobe=64, rerank=16)     # fewer re-scored candidates: recall may only drop
+    assert recall(shallow, exact) <= prev + 1e-9
+
+
+def test_self_queries_are_found_first(index):
+    x, c, ix = index
+    ids = [0, 123, 59999, 31415]
+    got = ix.search(x[ids], top_k=3, nprobe=8)
+    for i, (rows, dist) in zip(ids, got):
+        assert dist[0] < 1e-12 and int(rows[0]) in np.nonzero((x == x[i]).all(axis=1))[0].tolist()
+
+
+def test_build_and_search_are_deterministic(gpu_ctx):
+    import semtools_amd as smt
+
+    x, _ = clustered(20000, 64, seed=2)
+    c = smt.Corpus(gpu_ctx)
+    c.append(x)
+    a = smt.IvfPq(c, nlist=64, train_iters=5)
+    b = smt.IvfPq(c, nlist=64, train_iters=5)
+    assert a.list_sizes().tolist() == b.list_sizes().tolist()   # fixed-point accumulation: order independent
+    q = x[:16] + 0.01
+    ra, rb = a.search(q, top_k=5, nprobe=4), b.search(q, top_k=5, nprobe=4)
+    for (r1, d1), (r2, d2) in zip(ra, rb):
+        assert r1.tolist() == r2.tolist() and np.array_equal(d1, d2)
+    a.close(); b.close(); c.close()
+
+
+def test_argument_validation(index):
+    import semtools_amd as smt
+
+    x, c, ix = index
+    with pytest.raises(smt.SmtError):
+        smt.IvfPq(c, nlist=100)             # not a multiple of 32
+    with pytest.raises(smt.SmtError):
+        ix.search(x[:1], top_k=10, nprobe=0)
+    with pytest.raises(smt.SmtError):
+        ix.search(x[:1], top_k=57, nprobe=4)
+    assert ix.search(x[:1], top_k=0, nprobe=4)[0][0].size == 0
