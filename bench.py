@@ -217,10 +217,20 @@ def main():
             orc.search_documents(host, [rows], hq[n_cpu % n_queries], n_lines=3, top_k=k, accurate=False)
             t_cpu += time.perf_counter() - c0
             n_cpu += 1
-        ncores = os.cpu_count() or 1
+        # "fair CPU" variant: threaded, vectorised, bounded per-thread lists.  Thread count: best of a few
+        # candidates (containers often expose more logical CPUs than they may use)
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        best_t, best_rate = 1, 0.0
+        for t_try in sorted({1, 8, 16, 32, 64, 128, avail} & set(range(1, avail + 1))):
+            f0 = time.perf_counter()
+            orc.scan_topk_threads(host, hq[0], k, t_try)
+            rate = rows / (time.perf_counter() - f0)
+            if rate > best_rate:
+                best_t, best_rate = t_try, rate
+        ncores = best_t
         f0 = time.perf_counter()
         n_fair = 0
-        while time.perf_counter() - f0 < min(args.cpu_seconds, 6.0):
+        while time.perf_counter() - f0 < min(args.cpu_seconds, 4.0):
             orc.scan_topk_threads(host, hq[n_fair % n_queries], k, ncores)
             n_fair += 1
         t_fair = time.perf_counter() - f0
