@@ -320,7 +320,7 @@ def bench_c5(smt, ctx, device, rows, k, nq=1000, nlist=4096, nprobe=8):
     del x
     torch.cuda.empty_cache()
     return {"config": {"workload": f"c5 on one GPU: IVF-PQ nlist={nlist} m=32 over {rows} clustered chunks, {nq} queries, "
-                                   f"nprobe={nprobe}, 256 ADC candidates per list re-scored, top-{k}"},
+                                   f"nprobe={nprobe}, 512 ADC candidates per list re-scored, top-{k}"},
             "build_s": build_s, "build_ms": info["build_ms"], "index_bytes": info["index_bytes"],
             "recall_at_k_vs_exact": hit / (nq * k), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3}
 

@@ -206,7 +206,7 @@ typedef struct smt_ivfpq_params {
 int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *params, smt_ivfpq **out);
 void smt_ivfpq_destroy(smt_ivfpq *index);
 /* nprobe lists scanned per query; in every probed list the `rerank` best ADC candidates
- * (0 = 256; range [4, 256]) are re-scored against the full-precision rows inside the scan
+ * (0 = 512; range [4, 512]) are re-scored against the full-precision rows inside the scan
  * kernel, and the best top_k + 8 of all lists get the exact f64 distance.  top_k <= 56.
  * Outputs as in smt_search. */
 int smt_ivfpq_search(smt_ivfpq *index, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe,

@@ -365,13 +365,12 @@ struct AdcParams {
     const uint8_t *codes;      // [N][32] in list order
     const uint32_t *ids;       // [N] corpus row of each code
     const float *corpus;       // full-precision rows for the in-kernel re-score
-    uint32_t shortlist;        // ADC candidates kept per WAVE (<= 64); 4 waves per (query, list)
+    uint32_t shortlist;        // ADC candidates kept per WAVE (<= 64); 4 or 8 waves per (query, list)
     uint32_t kp;               // re-scored candidates emitted per (query, list)  (<= 64)
     key_t64 *lists;            // [nq][nprobe][kp]
 };
 
-constexpr int ADC_THREADS = 256;
-
+template <int ADC_THREADS>
 __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
 {
     __shared__ __attribute__((aligned(16))) float s_lut[PQ_M * PQ_K];  // 32 KiB
@@ -728,9 +727,10 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     SMT_REQUIRE(ix->corpus->rows == ix->n_rows, "the corpus changed after the index was built");
     SMT_REQUIRE(nprobe >= 1 && nprobe <= ix->nlist && nprobe <= 512, "nprobe must be in [1, min(nlist, 512)]");
     SMT_REQUIRE(top_k <= 56, "top_k must be <= 56 for the IVF-PQ path");
-    if (rerank == 0) rerank = 256;
-    SMT_REQUIRE(rerank >= 4 && rerank <= 256, "rerank (full-precision re-scored ADC candidates per probed list) must be in [4, 256]");
-    const uint32_t shortlist = (rerank + 3) / 4;  // per wave, 4 waves per (query, list)
+    if (rerank == 0) rerank = 512;
+    SMT_REQUIRE(rerank >= 4 && rerank <= 512, "rerank (full-precision re-scored ADC candidates per probed list) must be in [4, 512]");
+    const int adc_waves = rerank > 256 ? 8 : 4;   // waves per (query, list) block
+    const uint32_t shortlist = (rerank + adc_waves - 1) / adc_waves;  // per wave
     const uint32_t kp = top_k + 8;                // re-scored candidates handed to the exact select stage
 
     DevBuf b;
@@ -774,7 +774,8 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     ap.kp = kp;
     ap.lists = reinterpret_cast<key_t64 *>(base + o_lists);
     prof_begin(ctx, "ivf_adc");
-    hipLaunchKernelGGL(ivf_adc_kernel, dim3(nprobe, nq), dim3(ADC_THREADS), 0, ctx->stream, ap);
+    if (adc_waves == 8) hipLaunchKernelGGL(ivf_adc_kernel<512>, dim3(nprobe, nq), dim3(512), 0, ctx->stream, ap);
+    else hipLaunchKernelGGL(ivf_adc_kernel<256>, dim3(nprobe, nq), dim3(256), 0, ctx->stream, ap);
     prof_end(ctx, "ivf_adc");
     IVF_HIP(hipGetLastError());
     uint64_t *d_or = reinterpret_cast<uint64_t *>(base + o_or);

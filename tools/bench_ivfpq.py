@@ -33,7 +33,7 @@ def main():
     print(json.dumps(dict(rows=args.rows, nlist=args.nlist, build_s=round(build_s, 3), build_ms=info["build_ms"],
                           index_MB=round(info["index_bytes"] / 1e6, 1), list_size_mean=float(sizes.mean()), list_size_max=int(sizes.max()),
                           exact_batch_s=round(exact_s, 4), exact_qps=round(args.nq / exact_s, 1))), flush=True)
-    for nprobe, rerank in ((1, 0), (4, 0), (8, 0), (32, 0), (8, 64), (8, 16), (128, 0)):
+    for nprobe, rerank in ((1, 0), (4, 0), (8, 0), (32, 0), (8, 64), (8, 512), (32, 512), (128, 512)):
         ix.search(qh[:8], top_k=args.k, nprobe=nprobe, rerank=rerank)
         ctx.prof_enable(True); ctx.prof_reset()
         t0 = time.perf_counter()
