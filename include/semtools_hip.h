@@ -132,6 +132,9 @@ uint32_t smt_corpus_dim(const smt_corpus *corpus);
 /* flat little-endian file: 32-byte header + rows*D f32 */
 int smt_corpus_save(smt_corpus *corpus, const char *path);
 int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out);
+/* Incremental flush: `path` must already hold exactly the first `rows_on_disk` rows of this corpus;
+ * rows [rows_on_disk, rows) are appended and the header is updated (O(new rows), not O(corpus)). */
+int smt_corpus_append_to_file(smt_corpus *corpus, const char *path, uint64_t rows_on_disk);
 
 /* ------------------------------------------------------------------- search
  * Replaces f32::cosine + the selection in search_documents

@@ -23,7 +23,7 @@ EXPORTS = [
     "smt_model_create", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
     "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
-    "smt_corpus_save", "smt_corpus_load", "smt_search", "smt_search_topk_device", "smt_merge_topk",
+    "smt_corpus_save", "smt_corpus_load", "smt_corpus_append_to_file", "smt_search", "smt_search_topk_device", "smt_merge_topk",
     "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_info", "smt_ivfpq_list_sizes",
     "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
 ]
@@ -116,6 +116,7 @@ def lib():
     L.smt_corpus_dim.restype = u32
     L.smt_corpus_save.argtypes = [vp, C.c_char_p]
     L.smt_corpus_load.argtypes = [vp, C.c_char_p, P(vp)]
+    L.smt_corpus_append_to_file.argtypes = [vp, C.c_char_p, u64]
     L.smt_search.argtypes = [vp, vp, u32, u32, f64, i32, vp, u32, u64, vp, vp, vp, u64]
     L.smt_search_topk_device.argtypes = [vp, vp, u32, u32, u64, vp, vp]
     L.smt_merge_topk.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]

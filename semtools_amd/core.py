@@ -132,6 +132,9 @@ class Corpus:
     def save(self, path):
         L.check(L.lib().smt_corpus_save(self._h, str(path).encode()))
 
+    def append_to_file(self, path, rows_on_disk):
+        L.check(L.lib().smt_corpus_append_to_file(self._h, str(path).encode(), int(rows_on_disk)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             L.lib().smt_corpus_destroy(self._h)

@@ -434,6 +434,36 @@ int smt_corpus_save(smt_corpus *c, const char *path)
     return SMT_OK;
 }
 
+int smt_corpus_append_to_file(smt_corpus *c, const char *path, uint64_t rows_on_disk)
+{
+    SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
+    SMT_REQUIRE(rows_on_disk <= c->rows, "file holds more rows than the corpus");
+    int rc = bind_device(c->ctx);
+    if (rc) return rc;
+    FILE *f = fopen(path, "r+b");
+    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
+    CorpusFileHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTCORP1", 8) != 0 || h.dim != c->dim || h.rows != rows_on_disk) {
+        fclose(f);
+        set_error("'%s' does not hold exactly the first %llu rows of this corpus", path, (unsigned long long)rows_on_disk);
+        return SMT_E_IO;
+    }
+    bool ok = fseek(f, (long)(sizeof(h) + (size_t)rows_on_disk * c->dim * sizeof(float)), SEEK_SET) == 0;
+    const uint64_t chunk_rows = 65536;
+    std::vector<float> buf((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(c->rows - rows_on_disk, 1)) * c->dim);
+    for (uint64_t r = rows_on_disk; ok && r < c->rows; r += chunk_rows) {
+        const uint64_t n = std::min(chunk_rows, c->rows - r);
+        rc = smt_corpus_read_rows(c, r, n, buf.data());
+        if (rc) { fclose(f); return rc; }
+        ok = fwrite(buf.data(), sizeof(float), (size_t)n * c->dim, f) == (size_t)n * c->dim;
+    }
+    h.rows = c->rows;  // header last: a crash before this point leaves the old, consistent prefix
+    ok = ok && fflush(f) == 0 && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1;
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("short write to '%s'", path); return SMT_E_IO; }
+    return SMT_OK;
+}
+
 int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
 {
     int rc = check_ctx(ctx);

@@ -541,8 +541,13 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
             s->docs_[m.path] = m;
         }
     }
-    if (path_exists(emb)) check(smt_corpus_load(ctx, emb.c_str(), &s->corpus_), "Store::open");
-    else check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
+    if (path_exists(emb)) {
+        check(smt_corpus_load(ctx, emb.c_str(), &s->corpus_), "Store::open");
+        s->rows_on_disk_ = smt_corpus_rows(s->corpus_);
+        s->rows_on_disk_valid_ = true;
+    } else {
+        check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
+    }
     if (path_exists(rows)) {
         const json::Value v = json::parse(read_to_string(rows));
         uint64_t live = 0;
@@ -627,6 +632,7 @@ void Store::upsert_line_embeddings(const std::vector<LineEmbedding> &line_embedd
             for (auto *le : kv.second)
                 check(smt_corpus_write_rows(corpus_, it->second.first_row + (uint64_t)le->line_number, le->embedding.data(), 1),
                       "upsert_line_embeddings");
+            rows_on_disk_valid_ = false;  // rows already on disk changed: the next flush rewrites the file
             continue;
         }
         const uint64_t new_n = std::max(old_n, max_line + 1);
@@ -674,6 +680,7 @@ void Store::compact_if_sparse()
     smt_corpus_destroy(corpus_);
     corpus_ = fresh;
     dead_rows_ = 0;
+    rows_on_disk_valid_ = false;  // rows moved: the file must be rewritten
 }
 
 WorkspaceStats Store::get_stats() const
@@ -791,7 +798,15 @@ void Store::flush_line_embeddings() const
 {
     // vectors first, then the extent table that references them (a crash in between leaves extra
     // rows that no extent points at -- harmless; the reverse order could reference missing rows)
-    check(smt_corpus_save(corpus_, (dir_ + "/line_embeddings.f32").c_str()), "flush_line_embeddings");
+    const std::string emb = dir_ + "/line_embeddings.f32";
+    const uint64_t rows = smt_corpus_rows(corpus_);
+    if (rows_on_disk_valid_ && rows >= rows_on_disk_ && path_exists(emb)) {
+        if (rows > rows_on_disk_) check(smt_corpus_append_to_file(corpus_, emb.c_str(), rows_on_disk_), "flush_line_embeddings");
+    } else {
+        check(smt_corpus_save(corpus_, emb.c_str()), "flush_line_embeddings");  // first flush or after a compaction
+    }
+    rows_on_disk_ = rows;
+    rows_on_disk_valid_ = true;
     json::Value root = json::Value::object();
     json::Value arr = json::Value::array();
     for (auto &kv : extents_) {

@@ -237,6 +237,8 @@ private:
     std::map<std::string, DocMeta> docs_;        // documents shard
     std::map<std::string, Extent> extents_;      // path -> rows holding its lines (line i = first_row + i)
     uint64_t dead_rows_ = 0;                     // rows of deleted/replaced documents awaiting compaction
+    mutable uint64_t rows_on_disk_ = 0;          // prefix of the corpus already in line_embeddings.f32
+    mutable bool rows_on_disk_valid_ = false;
 };
 
 }  // namespace workspace

@@ -283,3 +283,24 @@ def test_device_merge_kernels_match_host_merge(gpu_ctx, corpus20k):
         assert np.array_equal(outp[qi, 1].cpu().numpy().view(np.float64), want[qi][1])
         assert np.array_equal(o_dist[qi].cpu().numpy(), hd[qi])
     ctx.close()
+
+
+def test_corpus_save_load_and_incremental_append(gpu_ctx, tmp_path):
+    """smt_corpus_save / _load round trip and the O(new rows) flush used by the workspace store."""
+    import semtools_amd as smt
+
+    a = synth.unit_rows(1000, seed=1)
+    b = synth.unit_rows(337, seed=2)
+    c = smt.Corpus(gpu_ctx)
+    c.append(a)
+    f = tmp_path / "rows.f32"
+    c.save(f)
+    c.append(b)
+    c.append_to_file(f, 1000)
+    d = smt.Corpus.load(gpu_ctx, f)
+    assert d.rows == 1337 and np.array_equal(d.read_rows(0, 1337), np.concatenate([a, b]))
+    with pytest.raises(smt.SmtError):
+        c.append_to_file(f, 1000)            # the file no longer holds exactly 1000 rows
+    q = synth.unit_query(3)[0]
+    assert d.search(q, top_k=5)[0][0].tolist() == c.search(q, top_k=5)[0][0].tolist()
+    c.close(); d.close()
