@@ -676,9 +676,9 @@ int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint3
     f.out_dist = out_dist;
     f.out_counts = out_counts;
     f.dbg = reinterpret_cast<unsigned long long *>(ctx->tune.select_debug_ptr);
-    prof_begin(ctx, "select");
+    if (ctx->tune.prof_select) prof_begin(ctx, "select");
     hipLaunchKernelGGL(final_select_kernel, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
-    prof_end(ctx, "select");
+    if (ctx->tune.prof_select) prof_end(ctx, "select");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }
