@@ -16,7 +16,7 @@ for src in api.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip largek.hi
   fi
   objs+=("$obj")
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/libsemtools_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -pthread "${objs[@]}" -o "$out/libsemtools_hip.so"
 echo "built $out/libsemtools_hip.so"
 # CLI replica (host-only C++), finds the library next to it
 bin="$here/../bin"

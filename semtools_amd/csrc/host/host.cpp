@@ -306,15 +306,26 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
 uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
                                   size_t batch_size, smt_corpus *corpus) const
 {
+    // Double-buffered pipeline: while the GPU gathers/pools batch i (H2D of the ids + K1),
+    // the host threads already tokenise batch i+1.  Batches are appended in order, so rows == line order.
     const uint64_t first = smt_corpus_rows(corpus);
-    std::vector<uint32_t> ids;
-    std::vector<uint64_t> offsets;
     if (batch_size == 0) batch_size = 1;
-    for (size_t b = 0; b < sentences.size(); b += batch_size) {
-        const size_t e = std::min(sentences.size(), b + batch_size);
-        tokenize_batch(sentences, b, e, max_length, ids, offsets);
-        check(smt_embed(model_, ids.data(), offsets.data(), e - b, max_length ? (uint32_t)*max_length : 0, nullptr, corpus,
-                        nullptr), "encode_into");
+    struct Slot { std::vector<uint32_t> ids; std::vector<uint64_t> offsets; };
+    Slot slots[2];
+    const size_t n = sentences.size();
+    if (n == 0) return first;
+    auto tokenize = [&](size_t b, Slot &s) { tokenize_batch(sentences, b, std::min(n, b + batch_size), max_length, s.ids, s.offsets); };
+    tokenize(0, slots[0]);
+    int cur = 0;
+    for (size_t b = 0; b < n; b += batch_size) {
+        const size_t e = std::min(n, b + batch_size);
+        std::thread next;
+        if (e < n) next = std::thread([&, e, cur]() { tokenize(e, slots[cur ^ 1]); });
+        const int rc = smt_embed(model_, slots[cur].ids.data(), slots[cur].offsets.data(), e - b,
+                                 max_length ? (uint32_t)*max_length : 0, nullptr, corpus, nullptr);
+        if (next.joinable()) next.join();
+        check(rc, "encode_into");
+        cur ^= 1;
     }
     return first;
 }
