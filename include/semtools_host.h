@@ -61,6 +61,19 @@ int smt_host_search_workspace(smt_host_model *model, const char *query, const ch
                               int ignore_case, const char *workspace_name, int json, int is_tty,
                               char **out_text);
 
+/* Resident session (no reference counterpart -- the reference reloads the model and
+ * re-embeds the files for every query): the files are embedded ONCE, then any number of query batches are
+ * answered against the resident corpus.  out_texts[i] (malloc'd, release each with smt_host_free) is
+ * byte-for-byte what `semtools search <queries[i]> <files...>` prints. */
+typedef struct smt_host_session smt_host_session;
+int smt_host_session_open(smt_host_model *model, const char *const *files, uint64_t n_files, int ignore_case,
+                          smt_host_session **out);
+int smt_host_session_search(smt_host_session *session, const char *const *queries, uint64_t n_queries,
+                            uint64_t n_lines, uint64_t top_k, double max_distance, int json, int is_tty,
+                            char **out_texts);
+uint64_t smt_host_session_lines(const smt_host_session *session);
+void smt_host_session_close(smt_host_session *session);
+
 /* workspace use / status / prune: same stdout text / JSON as src/cmds/workspace.rs */
 int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json, char **out_text);
 int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);

@@ -29,7 +29,8 @@ EXPORTS = [
 ]
 HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
-    "smt_host_search_files", "smt_host_search_content", "smt_host_search_workspace", "smt_host_workspace_use",
+    "smt_host_search_files", "smt_host_search_content", "smt_host_search_workspace", "smt_host_session_open",
+    "smt_host_session_search", "smt_host_session_lines", "smt_host_session_close", "smt_host_workspace_use",
     "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_free", "smt_host_format_float",
     "smt_host_split_lines", "smt_host_to_lowercase",
 ]
@@ -145,6 +146,12 @@ def lib():
     L.smt_host_search_files.argtypes = [vp, C.c_char_p, cpp, u64, u64, u64, f64, i32, i32, i32, P(vp)]
     L.smt_host_search_content.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u64, u64, f64, i32, i32, i32, P(vp)]
     L.smt_host_search_workspace.argtypes = [vp, C.c_char_p, cpp, u64, u64, u64, f64, i32, C.c_char_p, i32, i32, P(vp)]
+    L.smt_host_session_open.argtypes = [vp, cpp, u64, i32, P(vp)]
+    L.smt_host_session_search.argtypes = [vp, cpp, u64, u64, u64, f64, i32, i32, P(vp)]
+    L.smt_host_session_lines.argtypes = [vp]
+    L.smt_host_session_lines.restype = u64
+    L.smt_host_session_close.argtypes = [vp]
+    L.smt_host_session_close.restype = None
     L.smt_host_workspace_use.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_workspace_status.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_workspace_prune.argtypes = [vp, C.c_char_p, i32, P(vp)]

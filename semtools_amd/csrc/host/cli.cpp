@@ -5,6 +5,7 @@
 // the HF-hub download of StaticModel::from_pretrained is out of scope (no network here).
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,10 @@ static int usage()
             "  workspace  Manage semtools workspaces\n\n"
             "semtools search <QUERY> [FILES]... [-n, --n-lines <N>] [--top-k <K>] [-m, --max-distance <D>]\n"
             "                [-i, --ignore-case] [-j, --json] [-w, --workspace <NAME>]\n"
-            "semtools workspace [-j, --json] use <NAME> | status [NAME] | prune [NAME]\n");
+            "semtools workspace [-j, --json] use <NAME> | status [NAME] | prune [NAME]\n"
+            "semtools serve <FILES>... [-n N] [--top-k K] [-m D] [-i] [-j] [--batch B]\n"
+            "               (resident mode, not in the reference: files embedded once, one query per stdin line;\n"
+            "                each answer is what `semtools search <query> <FILES>` prints, preceded by `### <query>`)\n");
     return 2;
 }
 
@@ -67,6 +71,67 @@ int main(int argc, char **argv)
         if (rc != SMT_OK) return die(smt_last_error());
         fputs(text, stdout);
         smt_host_free(text);
+        smt_ctx_destroy(ctx);
+        return 0;
+    }
+    if (cmd == "serve") {
+        std::vector<std::string> files;
+        uint64_t n_lines = 3, top_k = 3, batch = 64;
+        double max_distance = NAN;
+        bool ignore_case = false, json = false;
+        for (size_t i = 0; i < args.size(); ++i) {
+            const std::string &a = args[i];
+            auto val = [&](const char *name) -> const char * {
+                if (i + 1 >= args.size()) { fprintf(stderr, "error: a value is required for '%s'\n", name); exit(2); }
+                return args[++i].c_str();
+            };
+            if (a == "-n" || a == "--n-lines" || a == "--context") n_lines = strtoull(val("--n-lines"), nullptr, 10);
+            else if (a == "--top-k") top_k = strtoull(val("--top-k"), nullptr, 10);
+            else if (a == "-m" || a == "--max-distance" || a == "--threshold") max_distance = strtod(val("--max-distance"), nullptr);
+            else if (a == "--batch") batch = std::max<uint64_t>(1, strtoull(val("--batch"), nullptr, 10));
+            else if (a == "-i" || a == "--ignore-case") ignore_case = true;
+            else if (a == "-j" || a == "--json") json = true;
+            else files.push_back(a);
+        }
+        if (files.empty()) return usage();
+        if (!need_ctx()) return 1;
+        const char *model_dir = getenv("SEMTOOLS_MODEL_DIR");
+        if (!model_dir) return die("SEMTOOLS_MODEL_DIR is not set (directory with model.safetensors + vocab.txt)");
+        smt_host_model *model = nullptr;
+        if (smt_host_model_from_dir(ctx, model_dir, &model) != SMT_OK) return die(smt_last_error());
+        std::vector<const char *> fp;
+        for (auto &f : files) fp.push_back(f.c_str());
+        smt_host_session *session = nullptr;
+        if (smt_host_session_open(model, fp.data(), fp.size(), ignore_case, &session) != SMT_OK) return die(smt_last_error());
+        fprintf(stderr, "semtools serve: %llu lines resident\n", (unsigned long long)smt_host_session_lines(session));
+        const int is_tty = isatty(STDOUT_FILENO);
+        std::vector<std::string> pending;
+        std::string line;
+        auto flush_batch = [&]() -> int {
+            if (pending.empty()) return 0;
+            std::vector<const char *> qp;
+            for (auto &q : pending) qp.push_back(q.c_str());
+            std::vector<char *> outs(pending.size(), nullptr);
+            if (smt_host_session_search(session, qp.data(), qp.size(), n_lines, top_k, max_distance, json, is_tty, outs.data()) != SMT_OK)
+                return die(smt_last_error());
+            for (size_t i = 0; i < pending.size(); ++i) {
+                printf("### %s\n", pending[i].c_str());
+                fputs(outs[i], stdout);
+                smt_host_free(outs[i]);
+            }
+            fflush(stdout);
+            pending.clear();
+            return 0;
+        };
+        while (std::getline(std::cin, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty()) { if (flush_batch()) return 1; continue; }  // blank line = answer what is queued
+            pending.push_back(line);
+            if (pending.size() >= batch && flush_batch()) return 1;
+        }
+        if (flush_batch()) return 1;
+        smt_host_session_close(session);
+        smt_host_model_destroy(model);
         smt_ctx_destroy(ctx);
         return 0;
     }

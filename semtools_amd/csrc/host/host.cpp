@@ -362,9 +362,22 @@ std::optional<Document> create_document_from_content(const std::string &filename
 std::vector<SearchResult> search_documents(const std::vector<Document> &documents, const Embeddings &emb,
                                            const std::vector<float> &query_embedding, const SearchConfig &config)
 {
-    std::vector<SearchResult> results;
-    if (documents.empty()) return results;
-    if (query_embedding.size() != SMT_DIM) return results;  // f32::cosine -> None on length mismatch: every row skipped
+    if (query_embedding.size() != SMT_DIM) return {};  // f32::cosine -> None on length mismatch: every row skipped
+    return std::move(search_documents_batch(documents, emb, {query_embedding}, config).at(0));
+}
+
+std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<Document> &documents, const Embeddings &emb,
+                                                              const std::vector<std::vector<float>> &query_embeddings,
+                                                              const SearchConfig &config)
+{
+    const size_t nq = query_embeddings.size();
+    std::vector<std::vector<SearchResult>> all(nq);
+    if (documents.empty() || nq == 0) return all;
+    std::vector<float> qflat(nq * SMT_DIM);
+    for (size_t q = 0; q < nq; ++q) {
+        if (query_embeddings[q].size() != SMT_DIM) throw Error("query embedding must have 256 dimensions");
+        std::copy(query_embeddings[q].begin(), query_embeddings[q].end(), qflat.begin() + q * SMT_DIM);
+    }
 
     // one row range per document, in slice order (== the reference's nested loop order)
     std::vector<smt_range> ranges;
@@ -379,41 +392,46 @@ std::vector<SearchResult> search_documents(const std::vector<Document> &document
         else ranges.push_back({d.first_row, end});
         total += d.lines.size();
     }
-    if (total == 0) return results;
+    if (total == 0) return all;
+    // the whole corpus in order is the common case: no filter needed (lets batches take the MFMA path)
+    const bool whole = ranges.size() == 1 && ranges[0].begin == 0 && ranges[0].end == emb.rows();
 
     const bool all_hits = config.max_distance.has_value();
-    if (!all_hits && config.top_k == 0) return results;
+    if (!all_hits && config.top_k == 0) return all;
     uint64_t cap = all_hits ? std::min<uint64_t>(total, 4096) : std::min<uint64_t>(config.top_k, total);
-    std::vector<uint64_t> rows;
+    std::vector<uint64_t> rows, counts(nq);
     std::vector<double> dist;
-    uint64_t n = 0;
     for (;;) {
-        rows.resize(cap);
-        dist.resize(cap);
-        const int rc = smt_search(emb.corpus(), query_embedding.data(), 1, (uint32_t)std::min<size_t>(config.top_k, 0xFFFFFFFFu),
-                                  all_hits ? *config.max_distance : NAN, SMT_MODE_DOCUMENTS, ranges.data(),
-                                  (uint32_t)ranges.size(), 0, rows.data(), dist.data(), &n, cap);
-        if (rc == SMT_E_TRUNCATED) { cap = n; continue; }
+        rows.resize(cap * nq);
+        dist.resize(cap * nq);
+        const int rc = smt_search(emb.corpus(), qflat.data(), (uint32_t)nq, (uint32_t)std::min<size_t>(config.top_k, 0xFFFFFFFFu),
+                                  all_hits ? *config.max_distance : NAN, SMT_MODE_DOCUMENTS, whole ? nullptr : ranges.data(),
+                                  whole ? 0 : (uint32_t)ranges.size(), 0, rows.data(), dist.data(), counts.data(), cap);
+        if (rc == SMT_E_TRUNCATED) { cap = *std::max_element(counts.begin(), counts.end()); continue; }
         check(rc, "search_documents");
         break;
     }
-    results.reserve(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        const size_t di = (size_t)(std::upper_bound(starts.begin(), starts.end(), rows[i]) - starts.begin()) - 1;
-        const Document &doc = documents[di];
-        const size_t idx = (size_t)(rows[i] - doc.first_row);
-        const size_t bottom = idx > config.n_lines ? idx - config.n_lines : 0;   // saturating_sub  (mod.rs:90)
-        const size_t top = std::min(doc.lines.size(), idx + config.n_lines + 1);  // (mod.rs:91)
-        SearchResult r;
-        r.filename = doc.filename;
-        r.lines.assign(doc.lines.begin() + bottom, doc.lines.begin() + top);
-        r.distance = dist[i];
-        r.start = bottom;
-        r.end = top;
-        r.match_line = idx;
-        results.push_back(std::move(r));
+    for (size_t q = 0; q < nq; ++q) {
+        std::vector<SearchResult> &results = all[q];
+        results.reserve(counts[q]);
+        for (uint64_t i = 0; i < counts[q]; ++i) {
+            const uint64_t row = rows[q * cap + i];
+            const size_t di = (size_t)(std::upper_bound(starts.begin(), starts.end(), row) - starts.begin()) - 1;
+            const Document &doc = documents[di];
+            const size_t idx = (size_t)(row - doc.first_row);
+            const size_t bottom = idx > config.n_lines ? idx - config.n_lines : 0;   // saturating_sub  (mod.rs:90)
+            const size_t top = std::min(doc.lines.size(), idx + config.n_lines + 1);  // (mod.rs:91)
+            SearchResult r;
+            r.filename = doc.filename;
+            r.lines.assign(doc.lines.begin() + bottom, doc.lines.begin() + top);
+            r.distance = dist[q * cap + i];
+            r.start = bottom;
+            r.end = top;
+            r.match_line = idx;
+            results.push_back(std::move(r));
+        }
     }
-    return results;  // already (distance asc, document/line order) == stable sort; take(top_k) done on device
+    return all;  // each already (distance asc, document/line order) == stable sort; take(top_k) done on device
 }
 
 std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,

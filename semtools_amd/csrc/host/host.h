@@ -130,6 +130,12 @@ std::optional<Document> create_document_from_content(const std::string &filename
 std::vector<SearchResult> search_documents(const std::vector<Document> &documents, const Embeddings &emb,
                                            const std::vector<float> &query_embedding, const SearchConfig &config);
 
+// Batched form (no reference counterpart: the reference answers one query per process).  Same semantics per
+// query as search_documents; all queries share ONE pass over the corpus (K3 when there are >= 8 of them).
+std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<Document> &documents, const Embeddings &emb,
+                                                              const std::vector<std::vector<float>> &query_embeddings,
+                                                              const SearchConfig &config);
+
 // src/search/mod.rs:122-143 (first unreadable file aborts: throws Error)
 std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,
                                        const StaticModel &model, const SearchConfig &config);

@@ -17,6 +17,13 @@ struct smt_host_model {
     std::unique_ptr<search::StaticModel> m;
 };
 
+struct smt_host_session {
+    smt_host_model *model = nullptr;
+    std::unique_ptr<search::Embeddings> emb;
+    std::vector<search::Document> docs;
+    bool ignore_case = false;
+};
+
 namespace {
 
 int fail(const std::exception &e)
@@ -207,6 +214,45 @@ int smt_host_search_workspace(smt_host_model *model, const char *query, const ch
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
 }
+
+int smt_host_session_open(smt_host_model *model, const char *const *files, uint64_t n_files, int ignore_case, smt_host_session **out)
+{
+    if (!model || !out || (n_files && !files)) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    *out = nullptr;
+    try {
+        std::unique_ptr<smt_host_session> s(new smt_host_session());
+        s->model = model;
+        s->ignore_case = ignore_case != 0;
+        s->emb = std::make_unique<search::Embeddings>(model->m->ctx());
+        for (uint64_t i = 0; i < n_files; ++i) {
+            const std::string content = read_to_string(files[i]);
+            auto doc = search::create_document_from_content(files[i], content, *model->m, s->ignore_case, *s->emb);
+            if (doc) s->docs.push_back(std::move(*doc));
+        }
+        *out = s.release();
+        return SMT_OK;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
+int smt_host_session_search(smt_host_session *s, const char *const *queries, uint64_t n_queries, uint64_t n_lines, uint64_t top_k,
+                            double max_distance, int json, int is_tty, char **out_texts)
+{
+    if (!s || (n_queries && (!queries || !out_texts))) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    for (uint64_t i = 0; i < n_queries; ++i) out_texts[i] = nullptr;
+    try {
+        const auto cfg = make_config(n_lines, top_k, max_distance, s->ignore_case);
+        std::vector<std::string> qs;
+        for (uint64_t i = 0; i < n_queries; ++i) qs.push_back(s->ignore_case ? to_lowercase(queries[i]) : std::string(queries[i]));
+        const auto qemb = s->model->m->encode_with_args(qs, 512, 1024);  // encode_single per query
+        const auto res = search::search_documents_batch(s->docs, *s->emb, qemb, cfg);
+        for (uint64_t i = 0; i < n_queries; ++i)
+            out_texts[i] = dup_text(json ? cmds::search_results_json(res[i]) : cmds::print_search_results(res[i], is_tty != 0));
+        return SMT_OK;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
+uint64_t smt_host_session_lines(const smt_host_session *s) { return s ? s->emb->rows() : 0; }
+void smt_host_session_close(smt_host_session *s) { delete s; }
 
 int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json_out, char **out_text)
 {

@@ -108,6 +108,36 @@ def search_with_workspace(model, query, files, workspace_name=None, n_lines=3, t
     return _take_text(out)
 
 
+class Session:
+    """Resident session: files embedded once, batches of queries answered against the resident corpus."""
+
+    def __init__(self, model, files, ignore_case=False):
+        self.model = model
+        self._h = C.c_void_p()
+        L.check(L.lib().smt_host_session_open(model._h, _cstrs(files), len(files), int(ignore_case), C.byref(self._h)))
+
+    @property
+    def lines(self):
+        return int(L.lib().smt_host_session_lines(self._h))
+
+    def search(self, queries, n_lines=3, top_k=3, max_distance=None, json=False, is_tty=False):
+        outs = (C.c_void_p * max(len(queries), 1))()
+        L.check(L.lib().smt_host_session_search(self._h, _cstrs(queries), len(queries), n_lines, top_k,
+                                                NAN if max_distance is None else max_distance, int(json), int(is_tty), outs))
+        return [_take_text(outs[i]) for i in range(len(queries))]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_host_session_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def workspace_use(ctx, name, json=False):
     out = C.c_void_p()
     L.check(L.lib().smt_host_workspace_use(ctx._h if ctx is not None else None, name.encode(), int(json), C.byref(out)))

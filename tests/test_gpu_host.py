@@ -248,3 +248,29 @@ def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, ca
     assert json.loads(host.workspace_prune(model.ctx, "t1", json=True)) == {"files_removed": 0, "files_remaining": 1}
     out5 = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=0, top_k=30)
     assert all(h[0] == str(b) for h in parse(out5)) and len(parse(out5)) == 5
+
+
+def test_resident_session_and_serve_mode(model, model_dir, prose_files):
+    """Batched-query surface: one embedding pass, many queries; every answer equals what a
+    one-shot `semtools search` prints -- for small batches (K2) and batches >= 8 queries (K3 MFMA path)."""
+    from semtools_amd import host
+
+    files = [p for p, _ in prose_files]
+    queries = [prose_files[0][1][i] for i in (3, 17, 99, 250, 400, 512, 640, 777, 801, 930, 998)] + [prose_files[1][1][5]]
+    s = host.Session(model, files)
+    assert s.lines == 1037
+    for qs in (queries[:3], queries):                           # 3 queries -> K2, 12 queries -> K3
+        got = s.search(qs, n_lines=2, top_k=4)
+        for q, text in zip(qs, got):
+            assert text == host.search_files(model, q, files, n_lines=2, top_k=4)
+    thr = s.search(queries[:2], n_lines=0, max_distance=0.8)
+    assert thr[0] == host.search_files(model, queries[0], files, n_lines=0, max_distance=0.8)
+    js = s.search(queries[:9], n_lines=1, top_k=2, json=True)
+    assert js[4] == host.search_files(model, queries[4], files, n_lines=1, top_k=2, json=True)
+    s.close()
+    env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]))
+    r = subprocess.run([CLI, "serve", *files, "-n", "2", "--top-k", "4", "--batch", "16"], input="\n".join(queries) + "\n",
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    want = "".join(f"### {q}\n" + host.search_files(model, q, files, n_lines=2, top_k=4) for q in queries)
+    assert r.stdout == want and "1037 lines resident" in r.stderr
