@@ -304,3 +304,39 @@ def test_corpus_save_load_and_incremental_append(gpu_ctx, tmp_path):
     q = synth.unit_query(3)[0]
     assert d.search(q, top_k=5)[0][0].tolist() == c.search(q, top_k=5)[0][0].tolist()
     c.close(); d.close()
+
+
+def test_error_codes_and_argument_validation(gpu_ctx, tmp_path):
+    """Error behaviour of the ABI: status codes + message, nothing aborts."""
+    import ctypes as C
+    import semtools_amd as smt
+    from semtools_amd import _lib as L
+
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.smt_corpus_create(gpu_ctx._h, 128, 0, C.byref(h)) == L.SMT_E_UNSUPPORTED       # dim is fixed at 256
+    assert b"256" in lib.smt_last_error()
+    assert lib.smt_corpus_load(gpu_ctx._h, str(tmp_path / "missing.f32").encode(), C.byref(h)) == L.SMT_E_IO
+    (tmp_path / "junk.f32").write_bytes(b"not a corpus file at all, just bytes" * 4)
+    assert lib.smt_corpus_load(gpu_ctx._h, str(tmp_path / "junk.f32").encode(), C.byref(h)) == L.SMT_E_IO
+    c = smt.Corpus(gpu_ctx)
+    c.append(synth.unit_rows(100, seed=1))
+    q = synth.unit_query(1)[0]
+    for bad in ([(10, 5)], [(0, 101)], [(50, 60), (55, 70)], [(60, 70), (10, 20)]):
+        with pytest.raises(smt.SmtError) as e:
+            c.search(q, top_k=3, ranges=bad)
+        assert e.value.code == L.SMT_E_INVALID
+    with pytest.raises(smt.SmtError):
+        c.read_rows(90, 20)
+    with pytest.raises(smt.SmtError):
+        c.truncate(101)
+    c.truncate(40)
+    assert c.rows == 40 and c.search(q, top_k=100)[0][0].size == 40
+    assert c.search(q, top_k=3, ranges=[(5, 5)])[0][0].size == 0                                # empty range -> nothing
+    table = synth.table(10, seed=1)
+    m = smt.Model(gpu_ctx, table)
+    with pytest.raises(smt.SmtError):
+        m.embed(np.array([1, 2, 3], np.uint32), np.array([0, 3, 2], np.uint64))                 # decreasing offsets
+    out, _ = m.embed(np.array([1, 999, 2], np.uint32), np.array([0, 3], np.uint64))             # id >= V contributes nothing
+    assert np.array_equal(out, orc.embed_lines(table, np.array([1, 999, 2], np.uint32), np.array([0, 3], np.uint64)))
+    m.close(); c.close()
