@@ -61,6 +61,9 @@ __device__ __forceinline__ uint64_t level_tile(uint64_t i, uint64_t stride, int 
     return u * stride;
 }
 
+__device__ __forceinline__ void append_candidates(const f32x16 &acc, const float (&rbv)[16], unsigned valid16, uint32_t q,
+                                                  float tau, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts);
+
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -168,38 +171,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
                 }
                 // ---- epilogue: lane owns query q = qt*32 + j and 16 rows
                 const uint32_t q = qt * QT_ROWS + j;
-                const float tau = s_tau[q];
-                const float rq = s_rq[q];
-                unsigned pass = 0;
-                auto dist_of = [&](int r) {
-                    float d = fmaxf(1.0f - acc[r] * rbv[r] * rq, 0.0f);
-                    if (rbv[r] == 0.0f && rq == 0.0f) d = 0.0f;  // zero row vs zero query (simsimd rule)
-                    return d;
-                };
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (dist_of(r) <= tau) pass |= 1u << r;
-                pass &= valid16;
-                if (__builtin_amdgcn_ballot_w64(pass != 0)) {
-                    if (pass) {
-                        // ONE slot grab per lane (all of its passing rows at once): the atomic's
-                        // round trip is paid once per tile, not once per candidate
-                        const unsigned n_pass = __popc(pass);
-                        const unsigned base = atomicAdd(&p.counts[q], n_pass);
-                        key_t64 *dst = p.cand + (size_t)q * CAND_CAP;
-                        unsigned slot = base;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if (pass & (1u << r)) {
-                                if (slot < CAND_CAP) {
-                                    const uint32_t row = (uint32_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                                    dst[slot] = make_key(dist_of(r), row);
-                                }
-                                ++slot;
-                            }
-                        }
-                    }
-                }
+                append_candidates(acc, rbv, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
             }
 
             if (restage) {
@@ -209,6 +181,118 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
                 cur ^= 1;
             }
         }
+    }
+}
+
+// ---- shared epilogue: lane (j, h) owns query q and the 16 rows acc_row(r, h) of the tile at row0
+__device__ __forceinline__ void append_candidates(const f32x16 &acc, const float (&rbv)[16], unsigned valid16, uint32_t q,
+                                                  float tau, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts)
+{
+    unsigned pass = 0;
+    auto dist_of = [&](int r) {
+        float d = fmaxf(1.0f - acc[r] * rbv[r] * rq, 0.0f);
+        if (rbv[r] == 0.0f && rq == 0.0f) d = 0.0f;  // zero row vs zero query (simsimd rule)
+        return d;
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (dist_of(r) <= tau) pass |= 1u << r;
+    pass &= valid16;
+    if (__builtin_amdgcn_ballot_w64(pass != 0)) {
+        if (pass) {
+            const unsigned base = atomicAdd(&counts[q], (unsigned)__popc(pass));  // one slot grab per lane per tile
+            key_t64 *dst = cand + (size_t)q * CAND_CAP;
+            unsigned slot = base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (pass & (1u << r)) {
+                    if (slot < CAND_CAP) dst[slot] = make_key(dist_of(r), (uint32_t)(row0 + acc_row(r, h)));
+                    ++slot;
+                }
+            }
+        }
+    }
+}
+
+// ---- small / medium batches (nq <= 128): every query tile stays in LDS for the whole kernel, so the
+// block needs NO barrier in its main loop, and each wave (one per SIMD, 512 registers) double-buffers its
+// corpus row tile: the 32 loads of tile i+1 are in flight while tile i is multiplied.  With one or two
+// query tiles there are only 128-256 MFMAs (4-8 us) per 32 KiB of corpus, i.e. this regime is bound by
+// how fast rows arrive, and the K3 main kernel (row tile loaded, then used) leaves that latency exposed.
+constexpr int RES_THREADS = 256;
+constexpr int RES_WAVES = RES_THREADS / 64;
+
+template <int NQT>
+__global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *s_q = reinterpret_cast<f32x4 *>(smem_raw);            // [NQT][32][65] float4
+    float *s_tau = reinterpret_cast<float *>(s_q + NQT * QT_F4); // [NQT*32]
+    float *s_rq = s_tau + NQT * QT_ROWS;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    for (uint32_t q = threadIdx.x; q < NQT * QT_ROWS; q += RES_THREADS) s_tau[q] = q < p.nq ? p.tau[q] : -1.0f;
+    for (uint32_t q = wave; q < NQT * QT_ROWS; q += RES_WAVES) {
+        float rq = 0.0f;
+        if (q < p.nq) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(p.queries + (size_t)q * 256)[lane];
+            const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+            rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
+        }
+        if (lane == 0) s_rq[q] = rq;
+    }
+    for (int idx = threadIdx.x; idx < NQT * QT_ROWS * 64; idx += RES_THREADS) {
+        const uint32_t q = idx >> 6;
+        s_q[(idx >> 6) * QT_STRIDE_F4 + (idx & 63)] =
+            q < p.nq ? reinterpret_cast<const f32x4 *>(p.queries + (size_t)q * 256)[idx & 63] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const uint64_t W = (uint64_t)gridDim.x * RES_WAVES;
+    const uint64_t first = (uint64_t)blockIdx.x * RES_WAVES + wave;
+
+    auto issue = [&](uint64_t it, f32x4 (&A)[32]) {
+        const uint64_t my_row = level_tile(it, p.stride, p.skip16) * 32 + j;
+        const bool row_ok = my_row < p.n_rows;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (row_ok ? my_row : 0) * 256) + h;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) A[m] = row_ok ? __builtin_nontemporal_load(src + 2 * m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute = [&](uint64_t it, const f32x4 (&A)[32]) {
+        const uint64_t row0 = level_tile(it, p.stride, p.skip16) * 32;
+        float part = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) part += A[m].x * A[m].x + A[m].y * A[m].y + A[m].z * A[m].z + A[m].w * A[m].w;
+        const float b2 = part + __shfl_xor(part, 32);
+        const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);
+        float rbv[16];
+        unsigned valid16 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            rbv[r] = __shfl(rb, acc_row(r, h));
+            if (row0 + acc_row(r, h) < p.n_rows) valid16 |= 1u << r;
+        }
+#pragma unroll 1
+        for (int qt = 0; qt < NQT; ++qt) {  // not unrolled: one accumulator set and one B stream live at a time
+            const f32x16 acc = mfma_tile_32x32x256(A, s_q + qt * QT_F4 + j * QT_STRIDE_F4 + h);
+            const uint32_t q = qt * QT_ROWS + j;
+            append_candidates(acc, rbv, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
+        }
+    };
+
+    f32x4 A0[32], A1[32];
+    uint64_t it = first;
+    if (it < p.level_tiles) issue(it, A0);
+    while (it < p.level_tiles) {
+        if (it + W < p.level_tiles) issue(it + W, A1);      // next tile in flight while this one is multiplied
+        compute(it, A0);
+        it += W;
+        if (it >= p.level_tiles) break;
+        if (it + W < p.level_tiles) issue(it + W, A0);
+        compute(it, A1);
+        it += W;
     }
 }
 
@@ -274,6 +358,12 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (!attr_set) {
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
 
@@ -315,7 +405,16 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.tau = tau;
         g.cand = cand;
         g.counts = counts;
-        if (g.level_tiles > 0) {
+        if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident) {
+            const uint64_t need_blocks = (g.level_tiles + RES_WAVES - 1) / RES_WAVES;
+            const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
+            const size_t smem = (size_t)(nqt <= 1 ? 1 : nqt <= 2 ? 2 : 4) * (QT_F4 * 16 + QT_ROWS * 8) + 64;
+            prof_begin(ctx, "gemm");
+            if (nqt <= 1) hipLaunchKernelGGL(gemm_resident_kernel<1>, dim3(nb), dim3(RES_THREADS), smem, ctx->stream, g);
+            else if (nqt <= 2) hipLaunchKernelGGL(gemm_resident_kernel<2>, dim3(nb), dim3(RES_THREADS), smem, ctx->stream, g);
+            else hipLaunchKernelGGL(gemm_resident_kernel<4>, dim3(nb), dim3(RES_THREADS), smem, ctx->stream, g);
+            prof_end(ctx, "gemm");
+        } else if (g.level_tiles > 0) {
             const uint64_t need_blocks = (g.level_tiles + GEMM_WAVES - 1) / GEMM_WAVES;
             const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
             prof_begin(ctx, "gemm");

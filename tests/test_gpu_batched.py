@@ -81,3 +81,27 @@ def test_batched_sorted_corpus_is_still_exact(gpu_ctx):
         orows, odist = _oracle_topk(emb, qs[i], 10)
         assert got[i][0].tolist() == orows, i
     c.close()
+
+
+def test_candidate_buffer_overflow_falls_back_to_exact_scan(gpu_ctx):
+    """Adversarial order for the level thresholds: every tile the early levels sample (tile index = 0 mod 16)
+    holds far rows, everything else is near the queries, so the main level floods the 2048-slot candidate buffers.
+    The overflow flag must route those queries through the exact K2 scan: results stay exact."""
+    import semtools_amd as smt
+
+    n = 70_000
+    rng = np.random.default_rng(3)
+    qs = synth.unit_query(8, nq=9)
+    far = synth.unit_rows(n, seed=4, dup_frac=0, zero_frac=0)
+    near = qs[rng.integers(0, 9, n)] + 0.05 * rng.standard_normal((n, 256)).astype(np.float32)
+    near /= np.linalg.norm(near, axis=1, keepdims=True)
+    tile = np.arange(n) // 32
+    emb = np.where((tile % 16 == 0)[:, None], far, near).astype(np.float32)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    got = c.search(qs, top_k=10)
+    for i in range(9):
+        res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
+        assert got[i][0].tolist() == [r["match_line"] for r in res], i
+        assert np.array_equal(got[i][1], np.array([r["distance"] for r in res]))
+    c.close()

@@ -82,3 +82,25 @@ def test_c3_batched_queries_ten_million_rows(gpu_ctx):
         one = c.search(q[i].cpu().numpy(), top_k=k)[0]       # K2 path
         assert one[0].tolist() == got[i][0].tolist() and np.array_equal(one[1], got[i][1])
     c.close()
+
+
+def test_threshold_mode_with_more_than_a_million_hits(gpu_ctx):
+    """Unbounded-result mode at scale (mod.rs:115-116 returns ALL hits): the hit buffer starts at 2^20 rows and
+    must be re-sized when every one of 1.2M rows is under the threshold."""
+    import torch
+    import semtools_amd as smt
+
+    rows = 1_200_000
+    x = _make(rows, 9)
+    q = _make(1, 10)[0]
+    x[[5, 600_000]] = q
+    torch.cuda.synchronize()
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=rows)
+    r, d = c.search(q.cpu().numpy(), top_k=3, max_distance=2.5)[0]
+    assert r.size == rows and r[:2].tolist() == [5, 600_000] and d[0] < 1e-15
+    assert (np.diff(d) >= 0).all() and len(np.unique(r)) == rows
+    ties = np.nonzero(np.diff(d) == 0)[0]
+    assert (r[ties] < r[ties + 1]).all()                    # equal distances come back in row order
+    r10, d10 = c.search(q.cpu().numpy(), top_k=10)[0]
+    assert r[:10].tolist() == r10.tolist() and np.array_equal(d[:10], d10)
+    c.close()
