@@ -161,7 +161,15 @@ def main():
         got_dist = host_dist[(args.steps - 1) % ring].numpy()
         torch_ok = bool(np.allclose(np.sort(got_dist), np.sort(lv.cpu().numpy()), rtol=0, atol=1e-6))
     else:
-        torch_ok = None
+        # N>1: every rank contributes its local fp64 top-k; the merged truth must equal the pipeline's output
+        try:
+            allv = [torch.empty_like(lv) for _ in range(world)]
+            dist.all_gather(allv, lv.contiguous())
+            truth = torch.sort(torch.cat(allv))[0][:k].cpu().numpy()
+            got_dist = host_dist[(args.steps - 1) % ring].numpy()
+            torch_ok = bool(np.allclose(got_dist, truth, rtol=0, atol=1e-6))
+        except Exception:
+            torch_ok = None
 
     result = {
         "metric": "chunk-vectors scanned/sec (whole job)",
