@@ -20,10 +20,13 @@ def main():
     ap.add_argument("--vocab", type=int, default=500_000)
     ap.add_argument("--max-tok", type=int, default=32)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--uniform", action="store_true", help="uniform token ids (no hot rows: every gather goes to HBM)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     table = torch.randn(args.vocab, 256, device=dev) * 0.1
     ids, offsets = synth.token_lines(args.lines, V=args.vocab, seed=1, min_tok=0, max_tok=args.max_tok)
+    if args.uniform:
+        ids = np.random.default_rng(7).integers(0, args.vocab, size=ids.size).astype(np.uint32)
     d_ids = torch.from_numpy(ids.astype(np.int32)).to(dev)
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
     out = torch.empty(args.lines, 256, device=dev)
@@ -47,7 +50,7 @@ def main():
     ref = table[torch.from_numpy(ids[int(offsets[i]):int(offsets[i + 1])].astype(np.int64)).to(dev)].sum(0)
     ref = ref / max(int(offsets[i + 1] - offsets[i]), 1)
     ref = ref / ref.norm().clamp_min(1e-12)
-    print(json.dumps(dict(lines=args.lines, tokens=T, vocab=args.vocab, kernel_ms=round(ker * 1e3, 3),
+    print(json.dumps(dict(lines=args.lines, tokens=T, vocab=args.vocab, uniform_ids=bool(args.uniform), kernel_ms=round(ker * 1e3, 3),
                           wall_ms=round(wall * 1e3, 3), lines_per_s=round(args.lines / ker / 1e6, 1),
                           tokens_per_s_G=round(T / ker / 1e9, 2), gather_GBps=round(alg_bytes / ker / 1e9, 1),
                           frac_of_8TBps=round(alg_bytes / ker / 8e12, 3),
