@@ -274,3 +274,40 @@ def test_resident_session_and_serve_mode(model, model_dir, prose_files):
     assert r.returncode == 0, r.stderr
     want = "".join(f"### {q}\n" + host.search_files(model, q, files, n_lines=2, top_k=4) for q in queries)
     assert r.stdout == want and "1037 lines resident" in r.stderr
+
+
+def test_real_hf_tokenizer_json_plugs_into_the_host_layer(gpu_ctx, tmp_path):
+    """A model2vec-style directory with a REAL tokenizer.json (WordPiece built with the HF `tokenizers` package,
+    BERT normaliser/pre-tokeniser, [UNK]) + model.safetensors: the host layer must embed exactly what the
+    reference pipeline embeds -- HF ids (no special tokens) -> drop unk -> truncate -> pool."""
+    from safetensors.numpy import save_file
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, trainers
+    from semtools_amd import hf, host
+
+    corpus_lines = synth.pseudo_prose(400, vocab_size=300, seed=3) + ["Hello World, semantic search!", "naïve café déjà vu"]
+    tok = Tokenizer(models.WordPiece(unk_token="[UNK]"))
+    tok.normalizer = normalizers.BertNormalizer(lowercase=True)
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.train_from_iterator(corpus_lines, trainers.WordPieceTrainer(vocab_size=400, special_tokens=["[PAD]", "[UNK]"]))
+    d = tmp_path / "hfmodel"
+    d.mkdir()
+    tok.save(str(d / "tokenizer.json"))
+    V = tok.get_vocab_size()
+    table = synth.table(V, seed=5)
+    save_file({"embeddings": table}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"normalize": True}))
+    m = hf.load_static_model(gpu_ctx, str(d))
+    unk = tok.token_to_id("[UNK]")
+    sents = ["Hello World, semantic search!", "w1 w2 zzzzqqq w3", "", "naïve café déjà vu", "🙂 emoji only"]
+    ids, offsets = [], [0]
+    for s in sents:
+        t = [i for i in tok.encode(s, add_special_tokens=False).ids if i != unk][:2048]
+        ids += t
+        offsets.append(len(ids))
+    want = orc.embed_lines(table, np.array(ids, np.uint32), np.array(offsets, np.uint64), True, 2048)
+    assert np.array_equal(m.encode_with_args(sents, 2048), want)
+    f = tmp_path / "doc.txt"
+    f.write_text("\n".join(corpus_lines))
+    out = host.search_files(m, corpus_lines[7], [str(f)], n_lines=0, top_k=1)
+    assert out.startswith(f"{f}:7::8 (") and float(out.split("(")[1].split(")")[0]) < 1e-9
+    m.close()
