@@ -219,6 +219,11 @@ int smt_ivfpq_search(smt_ivfpq *index, const float *queries, uint32_t nq, uint32
 int smt_ivfpq_info(const smt_ivfpq *index, uint64_t *n_rows, uint32_t *nlist, uint64_t *index_bytes,
                    double *build_ms4);
 int smt_ivfpq_list_sizes(const smt_ivfpq *index, uint64_t *sizes_host /* [nlist] */);
+/* Persist / restore the index (centroids, codebooks, list table, ids, codes: ~36 B per row).  The file
+ * refers to corpus rows by position: load fails with SMT_E_INVALID unless `corpus` holds exactly the
+ * row count the index was built on (then rebuild -- 0.34 s per 10 M rows). */
+int smt_ivfpq_save(smt_ivfpq *index, const char *path);
+int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out);
 
 /* Tuning knobs (0 = library default); for benchmarking sweeps. */
 int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value);

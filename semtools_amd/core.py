@@ -212,9 +212,12 @@ class Corpus:
 class IvfPq:
     """IVF-PQ index over a resident Corpus (smt_ivfpq).  Approximate top-k membership, exact distances."""
 
-    def __init__(self, corpus, nlist=4096, train_iters=10, train_sample=0):
+    def __init__(self, corpus, nlist=4096, train_iters=10, train_sample=0, _path=None):
         self.corpus = corpus
         self._h = C.c_void_p()
+        if _path is not None:
+            L.check(L.lib().smt_ivfpq_load(corpus._h, str(_path).encode(), C.byref(self._h)))
+            return
         prm = L.SmtIvfPqParams(int(nlist), 32, 8, int(train_iters), int(train_sample))
         L.check(L.lib().smt_ivfpq_build(corpus._h, C.byref(prm), C.byref(self._h)))
 
@@ -228,6 +231,14 @@ class IvfPq:
             self.close()
         except Exception:
             pass
+
+    def save(self, path):
+        L.check(L.lib().smt_ivfpq_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, corpus, path):
+        """Restore an index saved beside `corpus` (fails unless the row count matches)."""
+        return cls(corpus, _path=path)
 
     def info(self):
         n, nl, nb = C.c_uint64(), C.c_uint32(), C.c_uint64()

@@ -805,3 +805,130 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- persistence
+// File = 64-byte little-endian header + the six device arrays in a fixed order.  The index refers to
+// rows of a corpus by position, so it is only valid beside the corpus it was built on: load checks
+// the row count (the workspace store keeps both files in one directory and rebuilds on mismatch).
+namespace {
+struct IvfFileHeader {
+    char magic[8];      // "SMTIVFP1"
+    uint32_t nlist, m, nbits, dim;
+    uint64_t n_rows;
+    uint8_t pad[32];
+};
+static_assert(sizeof(IvfFileHeader) == 64, "header layout");
+
+bool write_dev(FILE *f, const void *d, size_t bytes, hipStream_t st, std::vector<char> &buf)
+{
+    const size_t chunk = (size_t)64 << 20;
+    if (buf.size() < std::min(bytes, chunk)) buf.resize(std::min(bytes, chunk));
+    for (size_t o = 0; o < bytes; o += chunk) {
+        const size_t n = std::min(chunk, bytes - o);
+        if (hipMemcpyAsync(buf.data(), (const char *)d + o, n, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        if (fwrite(buf.data(), 1, n, f) != n) return false;
+    }
+    return true;
+}
+
+bool read_dev(FILE *f, void *d, size_t bytes, hipStream_t st, std::vector<char> &buf)
+{
+    const size_t chunk = (size_t)64 << 20;
+    if (buf.size() < std::min(bytes, chunk)) buf.resize(std::min(bytes, chunk));
+    for (size_t o = 0; o < bytes; o += chunk) {
+        const size_t n = std::min(chunk, bytes - o);
+        if (fread(buf.data(), 1, n, f) != n) return false;
+        if (hipMemcpyAsync((char *)d + o, buf.data(), n, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
+{
+    SMT_REQUIRE(ix && path, "null argument");
+    smt_ctx *ctx = ix->corpus->ctx;
+    IVF_HIP(hipSetDevice(ctx->device));
+    IVF_HIP(hipStreamSynchronize(ctx->stream));
+    FILE *f = fopen(path, "wb");
+    if (!f) { smt::set_error("cannot open '%s' for writing: %s", path, strerror(errno)); return SMT_E_IO; }
+    IvfFileHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "SMTIVFP1", 8);
+    h.nlist = ix->nlist;
+    h.m = PQ_M;
+    h.nbits = 8;
+    h.dim = 256;
+    h.n_rows = ix->n_rows;
+    std::vector<char> buf;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && write_dev(f, ix->d_centroids, (size_t)ix->nlist * 256 * 4, ctx->stream, buf);
+    ok = ok && write_dev(f, ix->d_cnorm_half, (size_t)ix->nlist * 4, ctx->stream, buf);
+    ok = ok && write_dev(f, ix->d_codebooks, (size_t)PQ_M * PQ_K * PQ_DSUB * 4, ctx->stream, buf);
+    ok = ok && write_dev(f, ix->d_offsets, (size_t)(ix->nlist + 1) * 8, ctx->stream, buf);
+    ok = ok && write_dev(f, ix->d_ids, (size_t)ix->n_rows * 4, ctx->stream, buf);
+    ok = ok && write_dev(f, ix->d_codes, (size_t)ix->n_rows * PQ_M, ctx->stream, buf);
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { smt::set_error("short write to '%s'", path); return SMT_E_IO; }
+    return SMT_OK;
+}
+
+int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
+{
+    SMT_REQUIRE(corpus && path && out, "null argument");
+    *out = nullptr;
+    smt_ctx *ctx = corpus->ctx;
+    IVF_HIP(hipSetDevice(ctx->device));
+    FILE *f = fopen(path, "rb");
+    if (!f) { smt::set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    std::unique_ptr<FILE, int (*)(FILE *)> fguard(f, fclose);
+    IvfFileHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTIVFP1", 8) != 0) {
+        smt::set_error("'%s' is not an IVF-PQ index file", path);
+        return SMT_E_IO;
+    }
+    if (h.m != PQ_M || h.nbits != 8 || h.dim != 256 || h.nlist < 32 || h.nlist > PROBE_MAX_LISTS || h.nlist % 32) {
+        smt::set_error("'%s': unsupported index geometry (nlist %u, m %u, nbits %u, dim %u)", path, h.nlist, h.m, h.nbits, h.dim);
+        return SMT_E_UNSUPPORTED;
+    }
+    if (h.n_rows != corpus->rows) {
+        smt::set_error("'%s' indexes %llu rows but the corpus holds %llu: rebuild", path, (unsigned long long)h.n_rows,
+                       (unsigned long long)corpus->rows);
+        return SMT_E_INVALID;
+    }
+    smt_ivfpq *ix = new (std::nothrow) smt_ivfpq();
+    if (!ix) { smt::set_error("out of host memory"); return SMT_E_NOMEM; }
+    std::unique_ptr<smt_ivfpq, void (*)(smt_ivfpq *)> guard(ix, smt_ivfpq_destroy);
+    ix->corpus = corpus;
+    ix->n_rows = h.n_rows;
+    ix->nlist = h.nlist;
+    const size_t N = (size_t)h.n_rows;
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_centroids), (size_t)h.nlist * 256 * 4));
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_cnorm_half), (size_t)h.nlist * 4));
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codebooks), (size_t)PQ_M * PQ_K * PQ_DSUB * 4));
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_offsets), (size_t)(h.nlist + 1) * 8));
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_ids), std::max<size_t>(N * 4, 16)));
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codes), std::max<size_t>(N * PQ_M, 16)));
+    std::vector<char> buf;
+    bool ok = read_dev(f, ix->d_centroids, (size_t)h.nlist * 256 * 4, ctx->stream, buf);
+    ok = ok && read_dev(f, ix->d_cnorm_half, (size_t)h.nlist * 4, ctx->stream, buf);
+    ok = ok && read_dev(f, ix->d_codebooks, (size_t)PQ_M * PQ_K * PQ_DSUB * 4, ctx->stream, buf);
+    ok = ok && read_dev(f, ix->d_offsets, (size_t)(h.nlist + 1) * 8, ctx->stream, buf);
+    ok = ok && read_dev(f, ix->d_ids, N * 4, ctx->stream, buf);
+    ok = ok && read_dev(f, ix->d_codes, N * PQ_M, ctx->stream, buf);
+    if (!ok) { smt::set_error("'%s' is truncated or unreadable", path); return SMT_E_IO; }
+    // the list table must be consistent with the row count, or the ADC kernel would read out of bounds
+    std::vector<uint64_t> offs((size_t)h.nlist + 1);
+    IVF_HIP(hipMemcpy(offs.data(), ix->d_offsets, offs.size() * 8, hipMemcpyDeviceToHost));
+    bool sane = offs[0] == 0 && offs[h.nlist] == h.n_rows;
+    for (uint32_t l = 0; sane && l < h.nlist; ++l) sane = offs[l] <= offs[l + 1];
+    if (!sane) { smt::set_error("'%s': corrupt list offsets", path); return SMT_E_IO; }
+    *out = guard.release();
+    return SMT_OK;
+}
+
+}  // extern "C"

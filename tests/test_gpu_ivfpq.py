@@ -108,3 +108,35 @@ def test_argument_validation(index):
     with pytest.raises(smt.SmtError):
         ix.search(x[:1], top_k=57, nprobe=4)
     assert ix.search(x[:1], top_k=0, nprobe=4)[0][0].size == 0
+
+
+def test_save_load_round_trip(index, gpu_ctx, tmp_path):
+    """A restored index answers exactly like the one that was saved; a file that does not match the corpus
+    (row count) or is damaged is refused, never searched."""
+    import semtools_amd as smt
+
+    x, c, ix = index
+    path = tmp_path / "lines.ivfpq"
+    ix.save(path)
+    assert path.stat().st_size == 64 + 256 * 1024 + 256 * 4 + 32 * 256 * 8 * 4 + 257 * 8 + len(x) * 36
+    back = smt.IvfPq.load(c, path)
+    assert back.info()["rows"] == len(x) and np.array_equal(back.list_sizes(), ix.list_sizes())
+    qs = x[[5, 999, 42424]] + np.float32(0.001)
+    for (r1, d1), (r2, d2) in zip(ix.search(qs, top_k=10, nprobe=8), back.search(qs, top_k=10, nprobe=8)):
+        assert r1.tolist() == r2.tolist() and np.array_equal(d1, d2)
+    back.close()
+
+    other = smt.Corpus(gpu_ctx)
+    other.append(x[:1000])
+    with pytest.raises(smt.SmtError, match="rebuild"):
+        smt.IvfPq.load(other, path)
+    other.close()
+    blob = path.read_bytes()
+    (tmp_path / "short.ivfpq").write_bytes(blob[: len(blob) // 2])
+    with pytest.raises(smt.SmtError):
+        smt.IvfPq.load(c, tmp_path / "short.ivfpq")
+    (tmp_path / "magic.ivfpq").write_bytes(b"NOTANIDX" + blob[8:])
+    with pytest.raises(smt.SmtError):
+        smt.IvfPq.load(c, tmp_path / "magic.ivfpq")
+    with pytest.raises(smt.SmtError):
+        smt.IvfPq.load(c, tmp_path / "missing.ivfpq")
