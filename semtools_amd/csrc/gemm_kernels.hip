@@ -50,6 +50,7 @@ struct GemmParams {
     uint64_t level_tiles;     // tiles visited by this launch
     uint64_t stride;          // visited tile = stride * u(i)
     int skip16;               // 1: u skips multiples of 16 (they belong to earlier levels)
+    uint32_t qsplit;          // gemm_level_kernel: blocks per row-tile group, each sweeping 1/qsplit of the query tiles
     const float *tau;         // [nqt*32] distance thresholds (+inf = take everything, <0 = padding)
     key_t64 *cand;            // [nq][CAND_CAP]
     unsigned int *counts;     // [nq]
@@ -74,12 +75,17 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const uint32_t nq_pad = p.nqt * QT_ROWS;
-    const bool resident = p.nqt <= 2;  // both query tiles live in LDS for the whole kernel
+    // small levels have fewer row-tile groups than CUs: qsplit blocks share one group and split the query tiles
+    const uint32_t qs = blockIdx.x % p.qsplit;
+    const uint32_t row_block = blockIdx.x / p.qsplit, row_blocks = gridDim.x / p.qsplit;
+    const uint32_t qt_lo = (uint32_t)((uint64_t)qs * p.nqt / p.qsplit);
+    const uint32_t qt_hi = (uint32_t)((uint64_t)(qs + 1) * p.nqt / p.qsplit);
+    const uint32_t q_lo = qt_lo * QT_ROWS, q_hi = qt_hi * QT_ROWS;
+    const bool resident = qt_hi - qt_lo <= 2;  // both query tiles live in LDS for the whole kernel
 
     // ---- per-query constants: tau and 1/|q|
-    for (uint32_t q = threadIdx.x; q < nq_pad; q += GEMM_THREADS) s_tau[q] = q < p.nq ? p.tau[q] : -1.0f;
-    for (uint32_t q = wave; q < nq_pad; q += GEMM_WAVES) {
+    for (uint32_t q = q_lo + threadIdx.x; q < q_hi; q += GEMM_THREADS) s_tau[q] = q < p.nq ? p.tau[q] : -1.0f;
+    for (uint32_t q = q_lo + wave; q < q_hi; q += GEMM_WAVES) {
         float rq = 0.0f;
         if (q < p.nq) {
             const f32x4 v = reinterpret_cast<const f32x4 *>(p.queries + (size_t)q * 256)[lane];
@@ -108,15 +114,15 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
     };
     {
         f32x4 r[4];
-        stage_load(0, r);
+        stage_load(qt_lo, r);
         stage_store(0, r);
-        if (p.nqt > 1) { stage_load(1, r); stage_store(1, r); }
+        if (qt_hi - qt_lo > 1) { stage_load(qt_lo + 1, r); stage_store(1, r); }
     }
     __syncthreads();
 
-    const uint64_t W = (uint64_t)gridDim.x * GEMM_WAVES;
+    const uint64_t W = (uint64_t)row_blocks * GEMM_WAVES;
     const uint64_t steps = (p.level_tiles + W - 1) / W;  // block-uniform trip count
-    uint64_t it = (uint64_t)blockIdx.x * GEMM_WAVES + wave;
+    uint64_t it = (uint64_t)row_block * GEMM_WAVES + wave;
     int cur = 0;  // LDS buffer holding the current query tile (streaming mode)
 
     for (uint64_t step = 0; step < steps; ++step, it += W) {
@@ -149,11 +155,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             }
         }
 
-        for (uint32_t qt = 0; qt < p.nqt; ++qt) {
-            const int buf = resident ? (int)qt : cur;
+        for (uint32_t qt = qt_lo; qt < qt_hi; ++qt) {
+            const int buf = resident ? (int)(qt - qt_lo) : cur;
             f32x4 nxt[4];
             const bool restage = !resident;
-            const uint32_t qt_next = (qt + 1 == p.nqt) ? 0 : qt + 1;
+            const uint32_t qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
             if (restage) stage_load(qt_next, nxt);
 
             if (has) {
@@ -402,6 +408,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.level_tiles = multiples - parents;
         g.stride = stride;
         g.skip16 = lev == 0 ? 0 : 1;
+        g.qsplit = 1;
         g.tau = tau;
         g.cand = cand;
         g.counts = counts;
@@ -416,7 +423,13 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             prof_end(ctx, "gemm");
         } else if (g.level_tiles > 0) {
             const uint64_t need_blocks = (g.level_tiles + GEMM_WAVES - 1) / GEMM_WAVES;
-            const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
+            int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
+            // a level with fewer row-tile groups than CUs is a latency-bound sweep over the query tiles:
+            // spread the query tiles over about two blocks per CU
+            if (ctx->tune.gemm_qsplit && need_blocks < (uint64_t)blocks) {
+                g.qsplit = (uint32_t)std::min<uint64_t>(nqt, std::max<uint64_t>(1, (uint64_t)2 * blocks / need_blocks));
+                nb = (int)(need_blocks * g.qsplit);
+            }
             prof_begin(ctx, "gemm");
             hipLaunchKernelGGL(gemm_level_kernel, dim3(nb), dim3(GEMM_THREADS), gemm_smem_bytes(nqt), ctx->stream, g);
             prof_end(ctx, "gemm");

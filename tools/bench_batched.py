@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", type=int, default=4, help="queries verified against torch fp64")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for smt_set_tuning (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
@@ -33,6 +34,9 @@ def main():
     torch.cuda.synchronize()
     ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=args.rows)
+    for kv in args.tune:
+        key, val = kv.split("=")
+        ctx.set_tuning(key, int(val))
     ctx.prof_enable(True)
     corpus.search_topk_device(q.data_ptr(), args.nq, args.k, 0, out_rows.data_ptr(), out_dist.data_ptr())
     ctx.synchronize()
