@@ -225,6 +225,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
     else if (k == "gemm_resident") ctx->tune.gemm_resident = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
+    else if (k == "scan_debug_ptr") ctx->tune.scan_debug_ptr = value;
     else if (k == "select_debug_ptr") ctx->tune.select_debug_ptr = value;
     else if (k == "prof_select") ctx->tune.prof_select = (int)value;
     else { set_error("unknown tuning key '%s'", key); return SMT_E_INVALID; }

@@ -56,6 +56,7 @@ struct Tuning {
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel
     int prof_select = 1;        // 0: do not bracket the select stage with events (2 fewer event records per query)
+    int64_t scan_debug_ptr = 0;    // device pointer to (2*waves + blocks) u64 wall_clock64 stamps (profiling only)
     int64_t select_debug_ptr = 0;  // device pointer to 16 u64 for phase stamps (profiling only)
 };
 

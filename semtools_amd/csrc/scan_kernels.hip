@@ -42,6 +42,7 @@ struct ScanParams {
     uint32_t n_ranges;
     uint32_t kp;           // candidates kept per wave / per block (<= 64)
     key_t64 *block_lists;  // [NQ][gridDim.x][kp]
+    unsigned long long *stamps;  // optional (tuning key scan_debug_ptr): wall_clock64 per wave [start, loop end], per block [end]
 };
 
 // ------------------------------------------------------------------------- K2
@@ -54,9 +55,10 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
+    uint32_t *s_next = reinterpret_cast<uint32_t *>(s_keys + waves_per_block * 64);  // the block's next unclaimed chunk
     const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
-    const uint64_t stride = (uint64_t)gridDim.x * waves_per_block * U;
     const int kp = (int)p.kp;
+    if (p.stamps && lane == 0) p.stamps[wave_global * 2] = wall_clock64();
 
     f32x4 q[NQ];
     float rq[NQ];
@@ -92,20 +94,42 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             c[j] = NT ? __builtin_nontemporal_load(src) : *src;
         }
     };
+    // The block owns the chunks (U rows each) c(t) = ((t / waves) * gridDim.x + blockIdx.x) * waves + t % waves,
+    // t = 0, 1, ... -- the same rows a static grid-stride deal would give it -- but its waves CLAIM them from
+    // an LDS counter.  The CU's arbiter favours the older wave of each SIMD: with a static deal waves 0-3
+    // finished 12 us before waves 4-7 (of 145) and the CU ran half empty at the end.  Which wave reduces a
+    // chunk cannot change the block's top-k' (same row set), so the output is still a function of the data.
+    auto chunk_v0 = [&](uint32_t t) -> uint64_t {
+        return (((uint64_t)(t / waves_per_block) * gridDim.x + blockIdx.x) * waves_per_block + t % waves_per_block) * U;
+    };
+    auto claim = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(s_next, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    if (threadIdx.x == 0) *s_next = (uint32_t)waves_per_block;  // chunks 0..waves-1 are dealt: wave w starts on chunk w
+    __syncthreads();
+
     f32x4 cn[U];
     uint32_t rown[U];
-    if (PF && wave_global * U < p.n_virtual) issue_loads(wave_global * U, cn, rown);
-    for (uint64_t v0 = wave_global * U; v0 < p.n_virtual; v0 += stride) {
+    uint64_t v0 = chunk_v0((uint32_t)wave);
+    uint64_t v0n = 0;
+    if (PF && v0 < p.n_virtual) {
+        issue_loads(v0, cn, rown);
+        v0n = chunk_v0(claim());
+    }
+    while (v0 < p.n_virtual) {
         f32x4 c[U];
         uint32_t row[U];
         if (PF) {
-            // software pipeline: the NEXT iteration's rows are requested before this one is reduced
+            // software pipeline: the NEXT chunk's rows are requested (and the one after claimed) before this one is reduced
 #pragma unroll
             for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
-            if (v0 + stride < p.n_virtual) issue_loads(v0 + stride, cn, rown);
+            if (v0n < p.n_virtual) issue_loads(v0n, cn, rown);
         } else {
             issue_loads(v0, c, row);
         }
+        const uint64_t v0nn = chunk_v0(claim());
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const bool valid = (v0 + j) < p.n_virtual;  // wave-uniform
@@ -129,7 +153,11 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
                 }
             }
         }
+        if (PF) { v0 = v0n; v0n = v0nn; }
+        else v0 = v0nn;
     }
+
+    if (p.stamps && lane == 0) p.stamps[wave_global * 2 + 1] = wall_clock64();
 
     // block merge: rank every wave's candidates among all of the block's.
     for (int n = 0; n < NQ; ++n) {
@@ -146,6 +174,7 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             if (rank < kp) out[rank] = mine;
         }
     }
+    if (p.stamps && threadIdx.x == 0) p.stamps[(uint64_t)gridDim.x * waves_per_block * 2 + blockIdx.x] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------- K4
@@ -636,7 +665,7 @@ template <int NQ, int U>
 static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt,
                                bool filtered, bool pf = false)
 {
-    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64);
+    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16;  // per-wave key slots + chunk counter
     dim3 g(blocks), b(threads);
 #define SMT_LAUNCH(NTV, FV, PFV) \
     hipLaunchKernelGGL((scan_topk_kernel<NQ, U, NTV, FV, PFV>), g, b, smem, ctx->stream, p)
@@ -715,6 +744,7 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         p.n_ranges = a.n_ranges;
         p.kp = kp;
         p.block_lists = lists + (size_t)q0 * blocks * kp;
+        p.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
         const uint32_t left = a.nq - q0;
         if (left >= 4) {
             rc = (U == 4) ? launch_scan_variant<4, 4>(ctx, p, blocks, threads, nt, filtered)
