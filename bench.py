@@ -54,8 +54,11 @@ def make_shard(rows, seed, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--settle-steps", type=int, default=256,
+                    help="untimed steps run BEFORE the warmup (same count on every rank): the first ~15 ms of sustained "
+                         "HBM load after idle run up to 25 %% slower (clock / power ramp, see DESIGN.md section 8)")
     ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows per GPU (c2: 1M)")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,6 +149,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    for i in range(args.settle_steps):
+        step(i)
+    sync()
     for i in range(args.warmup):
         step(i)
     sync()
@@ -200,6 +206,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle_steps": args.settle_steps,
         "ms_per_step": elapsed / args.steps * 1e3,
         "host_issue_ms_per_step": issued / args.steps * 1e3,
         "higher_is_better": True,

@@ -104,3 +104,55 @@ def test_threshold_mode_with_more_than_a_million_hits(gpu_ctx):
     r10, d10 = c.search(q.cpu().numpy(), top_k=10)[0]
     assert r[:10].tolist() == r10.tolist() and np.array_equal(d[:10], d10)
     c.close()
+
+
+def test_c2_spec_corpus_duplicates_zero_rows_k_sweep_and_threshold(gpu_ctx):
+    """SURVEY 8(d) config c2 as specified: 1 M unit rows, 1 % exact-duplicate rows, 0.1 % all-zero rows,
+    k in {3, 10, 100}, and the threshold run max_distance = 0.9 -- at a size the CPU oracle does not finish
+    in seconds, so checked through properties: agreement with an independent fp64 evaluation on the GPU,
+    (distance, row) order with exact ties among duplicates, count + index checksum of the threshold hits."""
+    import torch
+    import semtools_amd as smt
+
+    rows = 1_000_000
+    dev = torch.device("cuda:0")
+    x = _make(rows, 3)
+    q = _make(1, 4)[0]
+    g = torch.Generator(device=dev)
+    g.manual_seed(33)
+    perm = torch.randperm(rows, generator=g, device=dev)
+    dup_dst, zero = perm[:10_000], perm[10_000:11_000]
+    x[dup_dst] = x[torch.randint(0, rows, (10_000,), generator=g, device=dev)]
+    best = torch.topk(x @ q, 3).indices                         # make sure duplicates sit INSIDE the top-k
+    x[perm[11_000:11_006]] = x[best.repeat(2)]
+    x[zero] = 0.0
+    torch.cuda.synchronize()
+    xd = x.double()
+    ref = 1.0 - (xd @ q.double()) / (xd.norm(dim=1).clamp_min(1e-300) * q.double().norm())
+    ref[zero] = 1.0                                             # simsimd: ab == 0 -> distance 1
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=rows)
+    qh = q.cpu().numpy()
+
+    for k in (3, 10, 100):                                      # 100 > 64 goes through the large-k path
+        r, d = c.search(qh, top_k=k)[0]
+        assert len(r) == k
+        tv, _ = torch.topk(ref, k, largest=False)
+        np.testing.assert_allclose(d, np.sort(tv.cpu().numpy()), rtol=0, atol=1e-9)
+        assert all((d[i], r[i]) < (d[i + 1], r[i + 1]) for i in range(k - 1))      # distance asc, row asc on ties
+        must = torch.nonzero(ref < tv[-1] - 1e-9).flatten().cpu().tolist()
+        assert set(must) <= set(r.tolist())
+        if k >= 10:                                             # 3 best rows x 3 copies each: exact ties, ascending rows
+            assert d[0] == d[1] == d[2] and d[3] == d[4] == d[5] and d[6] == d[7] == d[8]
+            assert sorted(r[:9].tolist()) == sorted(best.tolist() + perm[11_000:11_006].tolist())
+
+    rt, dt = c.search(qh, max_distance=0.9)[0]
+    inside = ref < 0.9
+    near = int(((ref - 0.9).abs() < 1e-9).sum())
+    assert abs(len(rt) - int(inside.sum())) <= near and len(rt) > 10_000
+    assert (dt < 0.9).all() and all(np.diff(dt) >= 0)
+    tie = np.nonzero(np.diff(dt) == 0)[0]
+    assert len(tie) > 0 and (np.diff(rt.astype(np.int64))[tie] > 0).all()          # duplicates: ties in row order
+    if near == 0:
+        assert int(rt.astype(np.int64).sum()) == int(torch.nonzero(inside).sum())
+        assert not bool(inside[zero].any()) and not (set(zero.cpu().tolist()) & set(rt.tolist()))
+    c.close()

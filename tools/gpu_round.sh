@@ -10,7 +10,7 @@ SEMTOOLS_NO_TORCH_PRELOAD=1 python -c "import ctypes; L=ctypes.CDLL('semtools_am
 python __graft_entry__.py smoke > "$out/smoke_$tag.log" 2>&1; tail -3 "$out/smoke_$tag.log"
 python bench.py > "$out/bench_$tag.json" 2> "$out/bench_$tag.err"; cat "$out/bench_$tag.json"; tail -5 "$out/bench_$tag.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$tag" -o bench -- python "$root/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-ivfpq > "$out/prof_$tag.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$tag" -o bench -- python "$root/bench.py" --steps 1000 --warmup 100 --no-cpu-baseline --no-secondary --no-ivfpq > "$out/prof_$tag.log" 2>&1
 tail -3 "$out/prof_$tag.log"
 find "$out/prof_$tag" -name "*stats*" | head
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch_$tag" -o bench -- python "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-ivfpq > "$out/pmc_fetch_$tag.log" 2>&1
