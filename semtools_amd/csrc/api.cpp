@@ -35,6 +35,19 @@ int ensure_scratch(smt_ctx *ctx, size_t bytes)
     return SMT_OK;
 }
 
+int ensure_stage(smt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes) return SMT_OK;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) SMT_HIP_CHECK(hipFree(ctx->d_stage));
+    ctx->d_stage = nullptr;
+    ctx->stage_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 16);
+    SMT_HIP_CHECK(hipMalloc(&ctx->d_stage, want));
+    ctx->stage_bytes = want;
+    return SMT_OK;
+}
+
 int ensure_pinned(smt_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->pinned_bytes) return SMT_OK;
@@ -158,6 +171,7 @@ void smt_ctx_destroy(smt_ctx *ctx)
         for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -614,21 +628,30 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
     const size_t q_bytes = (size_t)nq * SMT_DIM * sizeof(float);
     const size_t r_bytes = (size_t)nr * sizeof(smt_range);
     const size_t p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
-    DeviceTemp tmp;
-    {
-        hipError_t e = hipMalloc(&tmp.p, q_bytes + r_bytes + p_bytes + 64);
-        if (e != hipSuccess) { set_error("hipMalloc for search staging: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
-    }
-    float *d_q = reinterpret_cast<float *>(tmp.p);
-    smt_range *d_r = reinterpret_cast<smt_range *>(reinterpret_cast<char *>(tmp.p) + q_bytes);
-    uint64_t *d_p = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(tmp.p) + q_bytes + r_bytes);
+    // one persistent staging buffer per context: [queries | ranges | prefix | result lists] (no per-call hipMalloc/hipFree)
+    const size_t in_bytes = (q_bytes + r_bytes + 2 * p_bytes + 255) & ~(size_t)255;
+    const uint32_t k_stage = all_under_threshold ? 0u : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(top_k, n_virtual), 64);
+    const size_t out_bytes_stage = (size_t)nq * k_stage * 16 + (size_t)nq * sizeof(uint64_t);
+    if ((rc = ensure_stage(ctx, in_bytes + out_bytes_stage + 64))) return rc;
+    char *stage = reinterpret_cast<char *>(ctx->d_stage);
+    float *d_q = reinterpret_cast<float *>(stage);
+    smt_range *d_r = reinterpret_cast<smt_range *>(stage + q_bytes);
+    uint64_t *d_p = reinterpret_cast<uint64_t *>(stage + q_bytes + r_bytes);
+    uint64_t *d_cp = reinterpret_cast<uint64_t *>(stage + q_bytes + r_bytes + p_bytes);
     SMT_HIP_CHECK(hipMemcpyAsync(d_q, queries, q_bytes, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<uint64_t> prefix(nr + 1, 0);
+    // prefix: rows before range i (large-k path); chunk_prefix: FILTER_CHUNK-row chunks before range i (K2/K4)
+    std::vector<uint64_t> prefix(nr + 1, 0), chunk_prefix(nr + 1, 0);
     if (nr) {
-        for (uint32_t i = 0; i < nr; ++i) prefix[i + 1] = prefix[i] + (rr[i].end - rr[i].begin);
+        for (uint32_t i = 0; i < nr; ++i) {
+            const uint64_t len = rr[i].end - rr[i].begin;
+            prefix[i + 1] = prefix[i] + len;
+            chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
+        }
         SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
         SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
+    const uint64_t n_chunks = chunk_prefix[nr];
     (void)single_full_range;
 
     if (!all_under_threshold) {
@@ -672,14 +695,10 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         const size_t o_rows = (size_t)nq * k_eff * sizeof(uint64_t);
         const size_t o_dist = (size_t)nq * k_eff * sizeof(double);
         const size_t o_cnt = (size_t)nq * sizeof(uint64_t);
-        DeviceTemp outs;
-        {
-            hipError_t e = hipMalloc(&outs.p, o_rows + o_dist + o_cnt);
-            if (e != hipSuccess) { set_error("hipMalloc for search outputs: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
-        }
-        uint64_t *d_orow = reinterpret_cast<uint64_t *>(outs.p);
-        double *d_odist = reinterpret_cast<double *>(reinterpret_cast<char *>(outs.p) + o_rows);
-        uint64_t *d_ocnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(outs.p) + o_rows + o_dist);
+        char *outs = stage + in_bytes;
+        uint64_t *d_orow = reinterpret_cast<uint64_t *>(outs);
+        double *d_odist = reinterpret_cast<double *>(outs + o_rows);
+        uint64_t *d_ocnt = reinterpret_cast<uint64_t *>(outs + o_rows + o_dist);
 
         ScanArgs a;
         a.corpus = corpus->d_rows;
@@ -689,6 +708,8 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         a.k_out = k_eff;
         a.ranges = nr ? d_r : nullptr;
         a.range_prefix = nr ? d_p : nullptr;
+        a.range_chunk_prefix = nr ? d_cp : nullptr;
+        a.n_chunks = n_chunks;
         a.n_ranges = nr;
         a.n_virtual = n_virtual;
         a.ws_threshold = (mode == SMT_MODE_WORKSPACE && has_thr) ? 1 : 0;
@@ -703,7 +724,7 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         if (rc) return rc;
 
         if ((rc = ensure_pinned(ctx, o_rows + o_dist + o_cnt))) return rc;
-        SMT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, outs.p, o_rows + o_dist + o_cnt, hipMemcpyDeviceToHost, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, outs, o_rows + o_dist + o_cnt, hipMemcpyDeviceToHost, ctx->stream));
         SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
         const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows);
@@ -726,60 +747,26 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
     // ---------------- all rows with distance < max_distance (mod.rs:88-89,115-116)
     bool truncated = false;
     for (uint32_t q = 0; q < nq; ++q) {
-        // f32 prefilter with a guard band, exact f64 test afterwards
-        const float prefilter = (float)(max_distance + 8e-6) + 0.0f;
-        uint64_t cap = std::min<uint64_t>(n_virtual, (uint64_t)1 << 20);
-        for (;;) {
-            const size_t b_rows = ((size_t)cap * sizeof(uint32_t) + 15) & ~(size_t)15;
-            const size_t b_dist = (size_t)cap * sizeof(double);
-            DeviceTemp hits;
-            hipError_t e = hipMalloc(&hits.p, b_rows + b_dist + 16);
-            if (e != hipSuccess) { set_error("hipMalloc for threshold hits: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
-            uint32_t *d_hrows = reinterpret_cast<uint32_t *>(hits.p);
-            double *d_hdist = reinterpret_cast<double *>(reinterpret_cast<char *>(hits.p) + b_rows);
-            unsigned long long *d_hcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(hits.p) + b_rows + b_dist);
-            ThresholdArgs t;
-            t.corpus = corpus->d_rows;
-            t.rows = corpus->rows;
-            t.query = d_q + (size_t)q * SMT_DIM;
-            t.ranges = nr ? d_r : nullptr;
-            t.range_prefix = nr ? d_p : nullptr;
-            t.n_ranges = nr;
-            t.n_virtual = n_virtual;
-            t.prefilter = prefilter;
-            t.hit_rows = d_hrows;
-            t.hit_dist = d_hdist;
-            t.hit_count = d_hcnt;
-            t.cap = cap;
-            if ((rc = launch_threshold_scan(ctx, t))) return rc;
-            unsigned long long n_hits = 0;
-            SMT_HIP_CHECK(hipMemcpyAsync(&n_hits, d_hcnt, sizeof(n_hits), hipMemcpyDeviceToHost, ctx->stream));
-            SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if (n_hits > cap) { cap = n_hits; continue; }  // rare: rerun with an exact-size buffer
-            if ((rc = launch_rescore_rows(ctx, corpus->d_rows, t.query, d_hrows, n_hits, d_hdist))) return rc;
-            std::vector<uint32_t> h_rows(n_hits);
-            std::vector<double> h_dist(n_hits);
-            if (n_hits) {
-                SMT_HIP_CHECK(hipMemcpyAsync(h_rows.data(), d_hrows, n_hits * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                SMT_HIP_CHECK(hipMemcpyAsync(h_dist.data(), d_hdist, n_hits * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            }
-            SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            // exact strict test, then the reference's order: distance asc, row asc
-            std::vector<uint64_t> order;
-            order.reserve(n_hits);
-            for (uint64_t i = 0; i < n_hits; ++i) if (h_dist[i] < max_distance) order.push_back(i);
-            std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
-                if (h_dist[x] != h_dist[y]) return h_dist[x] < h_dist[y];
-                return h_rows[x] < h_rows[y];
-            });
-            out_counts[q] = order.size();
-            const uint64_t w = std::min<uint64_t>(order.size(), out_cap);
-            if (order.size() > out_cap) truncated = true;
-            for (uint64_t i = 0; i < w; ++i) {
-                out_rows[(size_t)q * out_cap + i] = row_base + h_rows[order[i]];
-                out_dist[(size_t)q * out_cap + i] = h_dist[order[i]];
-            }
-            break;
+        ThresholdQuery t;
+        t.corpus = corpus->d_rows;
+        t.rows = corpus->rows;
+        t.query = d_q + (size_t)q * SMT_DIM;
+        t.ranges = nr ? d_r : nullptr;
+        t.range_chunk_prefix = nr ? d_cp : nullptr;
+        t.n_chunks = n_chunks;
+        t.n_ranges = nr;
+        t.n_virtual = n_virtual;
+        t.max_distance = max_distance;
+        const uint32_t *h_rows = nullptr;
+        const double *h_dist = nullptr;
+        uint64_t n_ok = 0;
+        if ((rc = run_threshold_query(ctx, t, &h_rows, &h_dist, &n_ok))) return rc;
+        out_counts[q] = n_ok;
+        const uint64_t w = std::min<uint64_t>(n_ok, out_cap);
+        if (n_ok > out_cap) truncated = true;
+        for (uint64_t i = 0; i < w; ++i) {
+            out_rows[(size_t)q * out_cap + i] = row_base + h_rows[i];
+            out_dist[(size_t)q * out_cap + i] = h_dist[i];
         }
     }
     if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
@@ -804,6 +791,8 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
     a.k_out = top_k;
     a.ranges = nullptr;
     a.range_prefix = nullptr;
+    a.range_chunk_prefix = nullptr;
+    a.n_chunks = 0;
     a.n_ranges = 0;
     a.n_virtual = corpus->rows;
     a.ws_threshold = 0;

@@ -72,6 +72,8 @@ struct smt_ctx {
     size_t scratch_bytes = 0;
     void *h_pinned = nullptr;
     size_t pinned_bytes = 0;
+    void *d_stage = nullptr;   // smt_search's per-call inputs/outputs (queries, ranges, result lists)
+    size_t stage_bytes = 0;
     bool prof_on = false;
     std::map<std::string, smt::ProfEntry> prof;
     smt::Tuning tune;
@@ -99,6 +101,7 @@ namespace smt {
 
 int ensure_scratch(smt_ctx *ctx, size_t bytes);
 int ensure_pinned(smt_ctx *ctx, size_t bytes);
+int ensure_stage(smt_ctx *ctx, size_t bytes);
 
 // RAII-less helpers for event timing around a kernel family.
 void prof_begin(smt_ctx *ctx, const char *name);
@@ -115,9 +118,11 @@ struct ScanArgs {
     uint32_t nq;
     uint32_t k_out;           // results wanted per query
     const smt_range *ranges;  // device, or nullptr
-    const uint64_t *range_prefix;  // device exclusive prefix of range lengths [n_ranges+1]
+    const uint64_t *range_prefix;  // device exclusive prefix of range lengths [n_ranges+1] (large-k path)
+    const uint64_t *range_chunk_prefix;  // device exclusive prefix of ceil(len / FILTER_CHUNK) [n_ranges+1]
     uint32_t n_ranges;
     uint64_t n_virtual;       // rows to scan (sum of ranges, or rows)
+    uint64_t n_chunks;        // with ranges: total chunks = range_chunk_prefix[n_ranges]
     int ws_threshold;         // 1: apply score > thr_score (f32) in the final stage
     float ws_thr_score;
     uint64_t row_base;
@@ -127,23 +132,26 @@ struct ScanArgs {
 };
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
 
-// K4: threshold scan -> compacted hit rows (f32 prefilter with guard band),
-// exact f64 distances for every hit.  Outputs device arrays sized cap.
-struct ThresholdArgs {
+// Range-filtered scans stream FILTER_CHUNK-row chunks described by a per-chunk table (scan_kernels.hip).
+constexpr int FILTER_CHUNK = 4;
+int launch_build_chunk_table(smt_ctx *ctx, const smt_range *ranges, const uint64_t *chunk_prefix, uint32_t n_ranges,
+                             uint64_t n_chunks, uint64_t *table);
+
+// K4 (threshold.hip): every row with distance < max_distance, ordered (distance asc, row asc).
+// Returns pointers into the context's pinned staging buffer, valid until the next call on the context.
+struct ThresholdQuery {
     const float *corpus;
     uint64_t rows;
     const float *query;       // device [256]
     const smt_range *ranges;
-    const uint64_t *range_prefix;
+    const uint64_t *range_chunk_prefix;  // see ScanArgs
     uint32_t n_ranges;
     uint64_t n_virtual;
-    float prefilter;          // keep if d32 < prefilter
-    uint32_t *hit_rows;       // device [cap]
-    double *hit_dist;         // device [cap]
-    unsigned long long *hit_count;  // device scalar
-    uint64_t cap;
+    uint64_t n_chunks;
+    double max_distance;
 };
-int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a);
+int run_threshold_query(smt_ctx *ctx, const ThresholdQuery &t, const uint32_t **rows_host, const double **dist_host,
+                        uint64_t *n_pass);
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
                         uint64_t n, double *out_dist);
 

@@ -51,6 +51,17 @@ __device__ __forceinline__ float dist_f32(float ab, float b2, float rq, bool q_z
     return fmaxf(d, 0.0f);
 }
 
+// Read-only data produced by an EARLIER kernel, addressed uniformly: loads go through the scalar cache.
+typedef const uint64_t __attribute__((address_space(4))) *const_u64_ptr;
+
+// A value that is the same in every lane, moved to SGPRs (lets address arithmetic and loads go scalar).
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ key_t64 make_key(float d, uint32_t row)
 {
     return ((key_t64)__float_as_uint(d) << 32) | (key_t64)row;

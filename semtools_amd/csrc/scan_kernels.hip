@@ -20,35 +20,54 @@
 
 namespace smt {
 
-// Map a virtual row (position inside the concatenated ranges) to a corpus row.
-__device__ __forceinline__ uint32_t map_virtual(uint64_t v, const smt_range *ranges,
-                                                const uint64_t *prefix, uint32_t n_ranges)
-{
-    // largest i with prefix[i] <= v
-    uint32_t lo = 0, hi = n_ranges;  // invariant: prefix[lo] <= v < prefix[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (prefix[mid] <= v) lo = mid; else hi = mid;
-    }
-    return (uint32_t)(ranges[lo].begin + (v - prefix[lo]));
-}
-
 struct ScanParams {
     const float *corpus;
     const float *queries;  // [NQ x 256] (device)
-    uint64_t n_virtual;
-    const smt_range *ranges;
-    const uint64_t *prefix;
-    uint32_t n_ranges;
+    uint64_t n_virtual;    // unfiltered: rows to scan
+    const uint64_t *chunk_table;  // FILTERED: one descriptor per chunk (row0 | valid rows << 32), see build_chunk_table_kernel
+    uint64_t n_chunks;     // chunks to scan (FILTERED: table entries; else ceil(n_virtual / U))
     uint32_t kp;           // candidates kept per wave / per block (<= 64)
     key_t64 *block_lists;  // [NQ][gridDim.x][kp]
     unsigned long long *stamps;  // optional (tuning key scan_debug_ptr): wall_clock64 per wave [start, loop end], per block [end]
 };
 
+// Range filter (path-subset search, src/workspace/store.rs:507-515): the rows to scan are the concatenation
+// of sorted, disjoint row ranges.  Each range is cut into chunks of FILTER_CHUNK rows (the last one short),
+// and ONE descriptor per chunk says where it starts and how many of its rows are valid, so the streaming
+// kernels never search the range list: they read descriptor c (a wave-uniform 8-byte load, requested one
+// pipeline stage before the rows) and stream row0 .. row0+cnt-1.  2 B per scanned row of extra traffic.
+// (The first version binary-searched the ranges per ROW inside the scan loop: 3 dependent scalar loads in
+// front of every row load made a 2-range search of 1 M rows 3x slower than the unfiltered one.)
+__global__ void build_chunk_table_kernel(const smt_range *ranges, const uint64_t *chunk_prefix, uint32_t n_ranges,
+                                         uint64_t n_chunks, uint64_t *table)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    uint32_t lo = 0, hi = n_ranges;  // invariant: chunk_prefix[lo] <= c < chunk_prefix[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_prefix[mid] <= c) lo = mid; else hi = mid;
+    }
+    const uint64_t row0 = ranges[lo].begin + (c - chunk_prefix[lo]) * FILTER_CHUNK;
+    const uint64_t cnt = ranges[lo].end - row0 < (uint64_t)FILTER_CHUNK ? ranges[lo].end - row0 : (uint64_t)FILTER_CHUNK;
+    table[c] = row0 | (cnt << 32);
+}
+
+int launch_build_chunk_table(smt_ctx *ctx, const smt_range *ranges, const uint64_t *chunk_prefix, uint32_t n_ranges,
+                             uint64_t n_chunks, uint64_t *table)
+{
+    if (n_chunks == 0) return SMT_OK;
+    hipLaunchKernelGGL(build_chunk_table_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream, ranges,
+                       chunk_prefix, n_ranges, n_chunks, table);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
 // ------------------------------------------------------------------------- K2
-template <int NQ, int U, bool NT, bool FILTERED, bool PF>
+template <int NQ, int U, bool NT, bool FILTERED>
 __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
 {
+    static_assert(!FILTERED || U == FILTER_CHUNK, "filtered scans use the chunk table's chunk size");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     key_t64 *s_keys = reinterpret_cast<key_t64 *>(smem_raw);  // [waves][64]
 
@@ -84,55 +103,48 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
         thr_r[n] = 0xFFFFFFFFu;
     }
 
-    auto issue_loads = [&](uint64_t v0, f32x4 (&c)[U], uint32_t (&row)[U]) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            uint64_t v = v0 + j;
-            if (v >= p.n_virtual) v = p.n_virtual - 1;  // clamp (result discarded)
-            row[j] = FILTERED ? map_virtual(v, p.ranges, p.prefix, p.n_ranges) : (uint32_t)v;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
-            c[j] = NT ? __builtin_nontemporal_load(src) : *src;
-        }
-    };
     // The block owns the chunks (U rows each) c(t) = ((t / waves) * gridDim.x + blockIdx.x) * waves + t % waves,
     // t = 0, 1, ... -- the same rows a static grid-stride deal would give it -- but its waves CLAIM them from
     // an LDS counter.  The CU's arbiter favours the older wave of each SIMD: with a static deal waves 0-3
     // finished 12 us before waves 4-7 (of 145) and the CU ran half empty at the end.  Which wave reduces a
     // chunk cannot change the block's top-k' (same row set), so the output is still a function of the data.
-    auto chunk_v0 = [&](uint32_t t) -> uint64_t {
-        return (((uint64_t)(t / waves_per_block) * gridDim.x + blockIdx.x) * waves_per_block + t % waves_per_block) * U;
+    const uint64_t n_chunks = p.n_chunks;
+    // the table was written by an earlier kernel and is read-only here: constant address space => scalar loads
+    // (a plain global load is a VECTOR load that returns in order with the row loads and drains the pipeline)
+    const const_u64_ptr const_table = (const_u64_ptr)(uintptr_t)p.chunk_table;
+    auto chunk_id = [&](uint32_t t) -> uint64_t {
+        const uint64_t c = ((uint64_t)(t / waves_per_block) * gridDim.x + blockIdx.x) * waves_per_block + t % waves_per_block;
+        return uniform_u64(c);  // the division runs on the VALU: tell the compiler the result is wave-uniform (scalar loads)
     };
     auto claim = [&]() -> uint32_t {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(s_next, 1u);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
+    // descriptor of chunk c: first corpus row | valid rows << 32 (0 rows beyond the end)
+    auto fetch_desc = [&](uint64_t c) -> uint64_t {
+        if (c >= n_chunks) return 0ull;
+        if (FILTERED) return const_table[c];  // wave-uniform address in the constant address space: s_load
+        const uint64_t v0 = c * U;
+        const uint64_t left = p.n_virtual - v0;
+        return v0 | ((left < (uint64_t)U ? left : (uint64_t)U) << 32);
+    };
+    auto issue_loads = [&](uint64_t desc, f32x4 (&c)[U], uint32_t (&row)[U]) {
+        const uint32_t row0 = (uint32_t)desc, cnt = (uint32_t)(desc >> 32);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            row[j] = row0 + ((uint32_t)j < cnt ? (uint32_t)j : 0u);  // rows beyond cnt re-read row0 (result discarded)
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
+            c[j] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+    };
     if (threadIdx.x == 0) *s_next = (uint32_t)waves_per_block;  // chunks 0..waves-1 are dealt: wave w starts on chunk w
     __syncthreads();
 
-    f32x4 cn[U];
-    uint32_t rown[U];
-    uint64_t v0 = chunk_v0((uint32_t)wave);
-    uint64_t v0n = 0;
-    if (PF && v0 < p.n_virtual) {
-        issue_loads(v0, cn, rown);
-        v0n = chunk_v0(claim());
-    }
-    while (v0 < p.n_virtual) {
-        f32x4 c[U];
-        uint32_t row[U];
-        if (PF) {
-            // software pipeline: the NEXT chunk's rows are requested (and the one after claimed) before this one is reduced
-#pragma unroll
-            for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
-            if (v0n < p.n_virtual) issue_loads(v0n, cn, rown);
-        } else {
-            issue_loads(v0, c, row);
-        }
-        const uint64_t v0nn = chunk_v0(claim());
+    auto reduce = [&](const f32x4 (&c)[U], const uint32_t (&row)[U], uint32_t cnt) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const bool valid = (v0 + j) < p.n_virtual;  // wave-uniform
+            const bool valid = (uint32_t)j < cnt;  // wave-uniform
             const float b2 = wave_sum(c[j].x * c[j].x + c[j].y * c[j].y + c[j].z * c[j].z + c[j].w * c[j].w);
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
@@ -153,8 +165,35 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
                 }
             }
         }
-        if (PF) { v0 = v0n; v0n = v0nn; }
-        else v0 = v0nn;
+    };
+
+    // Three-stage software pipeline: [claim chunk c+2, request its descriptor] -> [request the rows of c+1] ->
+    // [reduce c].  The rows of c+1 are requested right after c's rows ARRIVED (the register copy below waits
+    // for them) and fly during c's reduction.  A true ping-pong over two register buffers (c+1 requested
+    // before the wait for c, two chunks in flight per wave) was measured and is SLOWER: 160 vs 149 us at
+    // 1 M rows -- like 16 waves/CU or U = 8, more requests in flight than ~32 KiB per CU cost bandwidth.
+    f32x4 cn[U];
+    uint32_t rown[U];
+    uint64_t cA = chunk_id((uint32_t)wave), cB = n_chunks, cC = n_chunks;
+    uint64_t dA = fetch_desc(cA), dB = 0;
+    if (cA < n_chunks) {
+        issue_loads(dA, cn, rown);
+        cB = chunk_id(claim());
+        dB = fetch_desc(cB);
+        cC = chunk_id(claim());
+    }
+    while (cA < n_chunks) {
+        f32x4 c[U];
+        uint32_t row[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
+        if (cB < n_chunks) issue_loads(dB, cn, rown);
+        const uint64_t dC = fetch_desc(cC);
+        const uint64_t cD = chunk_id(claim());
+        reduce(c, row, (uint32_t)(dA >> 32));
+        cA = cB; dA = dB;
+        cB = cC; dB = dC;
+        cC = cD;
     }
 
     if (p.stamps && lane == 0) p.stamps[wave_global * 2 + 1] = wall_clock64();
@@ -175,75 +214,6 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
         }
     }
     if (p.stamps && threadIdx.x == 0) p.stamps[(uint64_t)gridDim.x * waves_per_block * 2 + blockIdx.x] = wall_clock64();
-}
-
-// ------------------------------------------------------------------------- K4
-struct ThrParams {
-    const float *corpus;
-    const float *query;
-    uint64_t n_virtual;
-    const smt_range *ranges;
-    const uint64_t *prefix;
-    uint32_t n_ranges;
-    float prefilter;
-    uint32_t *hit_rows;
-    unsigned long long *hit_count;
-    uint64_t cap;
-};
-
-template <int U, bool NT, bool FILTERED>
-__global__ void __launch_bounds__(1024) scan_threshold_kernel(ThrParams p)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int waves_per_block = blockDim.x >> 6;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
-    const uint64_t stride = (uint64_t)gridDim.x * waves_per_block * U;
-
-    const f32x4 q = reinterpret_cast<const f32x4 *>(p.query)[lane];
-    const float a2 = wave_sum(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    const bool qz = (a2 == 0.0f);
-    const float rq = qz ? 0.0f : __frsqrt_rn(a2);
-
-    for (uint64_t v0 = wave_global * U; v0 < p.n_virtual; v0 += stride) {
-        f32x4 c[U];
-        uint32_t row[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            uint64_t v = v0 + j;
-            if (v >= p.n_virtual) v = p.n_virtual - 1;
-            row[j] = FILTERED ? map_virtual(v, p.ranges, p.prefix, p.n_ranges) : (uint32_t)v;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
-            c[j] = NT ? __builtin_nontemporal_load(src) : *src;
-        }
-        // lane j (< U) remembers whether row j passed; one wave-aggregated append.
-        bool pass_mine = false;
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const bool valid = (v0 + j) < p.n_virtual;
-            const float b2 = wave_sum(c[j].x * c[j].x + c[j].y * c[j].y + c[j].z * c[j].z + c[j].w * c[j].w);
-            const float ab = wave_sum(c[j].x * q.x + c[j].y * q.y + c[j].z * q.z + c[j].w * q.w);
-            const float d = dist_f32(ab, b2, rq, qz);
-            const bool pass = valid && (d < p.prefilter);
-            if (lane == j) pass_mine = pass;
-        }
-        const unsigned long long m = __ballot(pass_mine);
-        if (m != 0ull) {
-            const int cnt = __popcll(m);
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(p.hit_count, (unsigned long long)cnt);
-            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xFFFFFFFFull));
-            if (pass_mine) {
-                const int off = __popcll(m & ((1ull << lane) - 1ull));
-                uint32_t myrow = 0;
-#pragma unroll
-                for (int j = 0; j < U; ++j) if (lane == j) myrow = row[j];
-                const unsigned long long slot = base + (unsigned long long)off;
-                if (slot < p.cap) p.hit_rows[slot] = myrow;
-            }
-        }
-    }
 }
 
 // --------------------------------------------------- exact f64 distance (A5)
@@ -662,17 +632,23 @@ static inline uint32_t candidates_per_list(uint32_t k_out)
 }
 
 template <int NQ, int U>
-static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt,
-                               bool filtered, bool pf = false)
+static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt)
 {
     const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16;  // per-wave key slots + chunk counter
     dim3 g(blocks), b(threads);
-#define SMT_LAUNCH(NTV, FV, PFV) \
-    hipLaunchKernelGGL((scan_topk_kernel<NQ, U, NTV, FV, PFV>), g, b, smem, ctx->stream, p)
-    if (pf && NQ == 1 && nt && !filtered) SMT_LAUNCH(true, false, true);
-    else if (nt) { if (filtered) SMT_LAUNCH(true, true, false); else SMT_LAUNCH(true, false, false); }
-    else { if (filtered) SMT_LAUNCH(false, true, false); else SMT_LAUNCH(false, false, false); }
-#undef SMT_LAUNCH
+    if (nt) hipLaunchKernelGGL((scan_topk_kernel<NQ, U, true, false>), g, b, smem, ctx->stream, p);
+    else hipLaunchKernelGGL((scan_topk_kernel<NQ, U, false, false>), g, b, smem, ctx->stream, p);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+template <int NQ>
+static int launch_scan_filtered(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt)
+{
+    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16;
+    dim3 g(blocks), b(threads);
+    if (nt) hipLaunchKernelGGL((scan_topk_kernel<NQ, FILTER_CHUNK, true, true>), g, b, smem, ctx->stream, p);
+    else hipLaunchKernelGGL((scan_topk_kernel<NQ, FILTER_CHUNK, false, true>), g, b, smem, ctx->stream, p);
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }
@@ -716,50 +692,55 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
 {
     SMT_REQUIRE(a.k_out >= 1 && a.k_out <= 64, "top_k for the scan path must be in [1, 64]");
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
+    const bool filtered = a.n_ranges > 0;
     const uint32_t kp = candidates_per_list(a.k_out);
     int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : ctx->num_cus;
     if (blocks > SEL_MAX_LISTS) blocks = SEL_MAX_LISTS;
     const int threads = ctx->tune.scan_threads;
-    const int U = ctx->tune.scan_unroll;
-    const uint64_t waves = (uint64_t)blocks * (threads / 64);
-    if (waves * (uint64_t)U > a.n_virtual) {  // tiny inputs: do not launch idle blocks
-        const uint64_t need = (a.n_virtual + (uint64_t)U * (threads / 64) - 1) / ((uint64_t)U * (threads / 64));
+    const int U = filtered ? FILTER_CHUNK : ctx->tune.scan_unroll;
+    const uint64_t n_chunks = filtered ? a.n_chunks : (a.n_virtual + (uint64_t)U - 1) / (uint64_t)U;
+    const uint64_t waves_per_block = (uint64_t)(threads / 64);
+    if ((uint64_t)blocks * waves_per_block > n_chunks) {  // tiny inputs: do not launch idle blocks
+        const uint64_t need = (n_chunks + waves_per_block - 1) / waves_per_block;
         blocks = (int)(need > 0 ? need : 1);
     }
-    const size_t list_keys = (size_t)a.nq * blocks * kp;
-    int rc = ensure_scratch(ctx, list_keys * sizeof(key_t64));
+    const size_t list_bytes = (((size_t)a.nq * blocks * kp * sizeof(key_t64)) + 255) & ~(size_t)255;
+    const size_t table_bytes = filtered ? (size_t)n_chunks * sizeof(uint64_t) : 0;
+    int rc = ensure_scratch(ctx, list_bytes + table_bytes);
     if (rc != SMT_OK) return rc;
     key_t64 *lists = reinterpret_cast<key_t64 *>(ctx->d_scratch);
+    uint64_t *table = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(ctx->d_scratch) + list_bytes);
 
-    const bool filtered = a.n_ranges > 0;
     const bool nt = ctx->tune.scan_nontemporal != 0;
     prof_begin(ctx, "scan");
+    if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, table))) return rc;
     for (uint32_t q0 = 0; q0 < a.nq;) {
         ScanParams p;
         p.corpus = a.corpus;
         p.queries = a.queries + (size_t)q0 * 256;
         p.n_virtual = a.n_virtual;
-        p.ranges = a.ranges;
-        p.prefix = a.range_prefix;
-        p.n_ranges = a.n_ranges;
+        p.chunk_table = filtered ? table : nullptr;
+        p.n_chunks = n_chunks;
         p.kp = kp;
         p.block_lists = lists + (size_t)q0 * blocks * kp;
         p.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
         const uint32_t left = a.nq - q0;
         if (left >= 4) {
-            rc = (U == 4) ? launch_scan_variant<4, 4>(ctx, p, blocks, threads, nt, filtered)
-                          : launch_scan_variant<4, 8>(ctx, p, blocks, threads, nt, filtered);
+            rc = filtered ? launch_scan_filtered<4>(ctx, p, blocks, threads, nt)
+                 : (U == 4) ? launch_scan_variant<4, 4>(ctx, p, blocks, threads, nt)
+                            : launch_scan_variant<4, 8>(ctx, p, blocks, threads, nt);
             q0 += 4;
         } else if (left >= 2) {
-            rc = (U == 4) ? launch_scan_variant<2, 4>(ctx, p, blocks, threads, nt, filtered)
-                          : launch_scan_variant<2, 8>(ctx, p, blocks, threads, nt, filtered);
+            rc = filtered ? launch_scan_filtered<2>(ctx, p, blocks, threads, nt)
+                 : (U == 4) ? launch_scan_variant<2, 4>(ctx, p, blocks, threads, nt)
+                            : launch_scan_variant<2, 8>(ctx, p, blocks, threads, nt);
             q0 += 2;
         } else {
-            const bool pf = ctx->tune.scan_prefetch != 0;
-            if (U == 2) rc = launch_scan_variant<1, 2>(ctx, p, blocks, threads, nt, filtered, pf);
-            else if (U == 4) rc = launch_scan_variant<1, 4>(ctx, p, blocks, threads, nt, filtered, pf);
-            else if (U == 16) rc = launch_scan_variant<1, 16>(ctx, p, blocks, threads, nt, filtered, pf);
-            else rc = launch_scan_variant<1, 8>(ctx, p, blocks, threads, nt, filtered, pf);
+            if (filtered) rc = launch_scan_filtered<1>(ctx, p, blocks, threads, nt);
+            else if (U == 2) rc = launch_scan_variant<1, 2>(ctx, p, blocks, threads, nt);
+            else if (U == 4) rc = launch_scan_variant<1, 4>(ctx, p, blocks, threads, nt);
+            else if (U == 16) rc = launch_scan_variant<1, 16>(ctx, p, blocks, threads, nt);
+            else rc = launch_scan_variant<1, 8>(ctx, p, blocks, threads, nt);
             q0 += 1;
         }
         if (rc != SMT_OK) return rc;
@@ -767,38 +748,6 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
     prof_end(ctx, "scan");
     return launch_select(ctx, a.corpus, a.queries, a.nq, lists, (uint32_t)blocks, kp, (uint64_t)blocks * kp, a.k_out,
                          a.ws_threshold, a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts);
-}
-
-int launch_threshold_scan(smt_ctx *ctx, const ThresholdArgs &a)
-{
-    SMT_REQUIRE(a.rows < (1ull << 32), "a shard holds fewer than 2^32 rows");
-    int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : 2 * ctx->num_cus;
-    const int threads = ctx->tune.scan_threads;
-    ThrParams p;
-    p.corpus = a.corpus;
-    p.query = a.query;
-    p.n_virtual = a.n_virtual;
-    p.ranges = a.ranges;
-    p.prefix = a.range_prefix;
-    p.n_ranges = a.n_ranges;
-    p.prefilter = a.prefilter;
-    p.hit_rows = a.hit_rows;
-    p.hit_count = a.hit_count;
-    p.cap = a.cap;
-    SMT_HIP_CHECK(hipMemsetAsync(a.hit_count, 0, sizeof(unsigned long long), ctx->stream));
-    const bool nt = ctx->tune.scan_nontemporal != 0;
-    prof_begin(ctx, "scan");
-    dim3 g(blocks), b(threads);
-    if (a.n_ranges > 0) {
-        if (nt) hipLaunchKernelGGL((scan_threshold_kernel<8, true, true>), g, b, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((scan_threshold_kernel<8, false, true>), g, b, 0, ctx->stream, p);
-    } else {
-        if (nt) hipLaunchKernelGGL((scan_threshold_kernel<8, true, false>), g, b, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((scan_threshold_kernel<8, false, false>), g, b, 0, ctx->stream, p);
-    }
-    prof_end(ctx, "scan");
-    SMT_HIP_CHECK(hipGetLastError());
-    return SMT_OK;
 }
 
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,

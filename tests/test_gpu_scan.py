@@ -340,3 +340,57 @@ def test_error_codes_and_argument_validation(gpu_ctx, tmp_path):
     out, _ = m.embed(np.array([1, 999, 2], np.uint32), np.array([0, 3], np.uint64))             # id >= V contributes nothing
     assert np.array_equal(out, orc.embed_lines(table, np.array([1, 999, 2], np.uint32), np.array([0, 3], np.uint64)))
     m.close(); c.close()
+
+
+def test_many_small_ranges_all_paths(corpus20k):
+    """Path-subset search (store.rs:507-515): hundreds of ranges whose lengths are not multiples of the
+    4-row chunk the filtered kernels stream (1, 2, 3, 5, 7 ... rows, adjacent and far apart), through the
+    single-query scan, the 2- and 4-query scans, the threshold scan and the large-k path; the answer must
+    equal the oracle run on the gathered subset."""
+    emb, c = corpus20k
+    rng = np.random.default_rng(21)
+    ranges, pos = [], 0
+    while pos < 19_000:
+        length = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 64, 100]))
+        ranges.append((pos, pos + length))
+        pos += length + int(rng.choice([0, 1, 3, 50, 400]))       # gap 0 = adjacent ranges
+    assert len(ranges) > 100
+    idx = np.concatenate([np.arange(b, e) for b, e in ranges])
+    sub = emb[idx]
+    qs = synth.unit_query(4, nq=7)
+    for nq in (1, 2, 3, 4, 7):                                       # 7 = 4 + 2 + 1 query launches
+        got = c.search(qs[:nq], top_k=10, ranges=ranges)
+        for qi in range(nq):
+            orows, odist = _oracle_topk(sub, qs[qi], 10)
+            assert got[qi][0].tolist() == idx[orows.astype(np.int64)].tolist(), (nq, qi)
+            assert np.array_equal(got[qi][1], odist)
+    # threshold mode: few hits (host-ordered) and many hits (device-ordered, > 2048)
+    for md in (0.85, 1.06):
+        rows, dist = c.search(qs[0], max_distance=md, ranges=ranges)[0]
+        res = orc.search_documents(sub, [len(sub)], qs[0], n_lines=0, top_k=3, max_distance=md, accurate=True)
+        assert rows.tolist() == [int(idx[r["match_line"]]) for r in res], md
+        assert np.array_equal(dist, np.array([r["distance"] for r in res]))
+    assert len(c.search(qs[0], max_distance=1.06, ranges=ranges)[0][0]) > 2048
+    # large k (> 64) keeps its own per-row range lookup
+    rows, dist = c.search(qs[0], top_k=200, ranges=ranges)[0]
+    orows, odist = _oracle_topk(sub, qs[0], 200)
+    assert rows.tolist() == idx[orows.astype(np.int64)].tolist() and np.array_equal(dist, odist)
+
+
+def test_threshold_many_hits_device_order_matches_oracle(corpus20k):
+    """More than 2048 hits take the device-side ordering (radix sort by row, exact rescoring, stable radix sort
+    by distance); exact duplicates must come back in row order."""
+    emb, c = corpus20k
+    x = emb.copy()
+    x[5000:5600] = x[100:700]                                        # 600 exact duplicates -> distance ties
+    import semtools_amd as smt
+    c2 = smt.Corpus(c.ctx)
+    c2.append(x)
+    q = synth.unit_query(4)[0]
+    for md in (0.95, 1.02):
+        rows, dist = c2.search(q, max_distance=md)[0]
+        res = orc.search_documents(x, [len(x)], q, n_lines=0, top_k=3, max_distance=md, accurate=True)
+        assert len(res) > 2048
+        assert rows.tolist() == [r["match_line"] for r in res], md
+        assert np.array_equal(dist, np.array([r["distance"] for r in res]))
+    c2.close()
