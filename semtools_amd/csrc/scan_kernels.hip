@@ -123,11 +123,7 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
     };
     // descriptor of chunk c: first corpus row | valid rows << 32 (0 rows beyond the end)
     auto fetch_desc = [&](uint64_t c) -> uint64_t {
-        if (c >= n_chunks) return 0ull;
-        if (FILTERED) return const_table[c];  // wave-uniform address in the constant address space: s_load
-        const uint64_t v0 = c * U;
-        const uint64_t left = p.n_virtual - v0;
-        return v0 | ((left < (uint64_t)U ? left : (uint64_t)U) << 32);
+        return c < n_chunks ? const_table[c] : 0ull;  // wave-uniform address in the constant address space: s_load
     };
     auto issue_loads = [&](uint64_t desc, f32x4 (&c)[U], uint32_t (&row)[U]) {
         const uint32_t row0 = (uint32_t)desc, cnt = (uint32_t)(desc >> 32);
@@ -141,60 +137,101 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
     if (threadIdx.x == 0) *s_next = (uint32_t)waves_per_block;  // chunks 0..waves-1 are dealt: wave w starts on chunk w
     __syncthreads();
 
-    auto reduce = [&](const f32x4 (&c)[U], const uint32_t (&row)[U], uint32_t cnt) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const bool valid = (uint32_t)j < cnt;  // wave-uniform
-            const float b2 = wave_sum(c[j].x * c[j].x + c[j].y * c[j].y + c[j].z * c[j].z + c[j].w * c[j].w);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const float ab =
-                    wave_sum(c[j].x * q[n].x + c[j].y * q[n].y + c[j].z * q[n].z + c[j].w * q[n].w);
-                const float d = dist_f32(ab, b2, rq[n], qz[n]);
-                const uint32_t r = row[j];
-                if (valid && (d < thr_d[n] || (d == thr_d[n] && r < thr_r[n]))) {
-                    // insert (d, r) keeping (distance asc, row asc) order
-                    const bool less = (ld[n] < d) || (ld[n] == d && lr[n] < r);
-                    const int pos = __popcll(__ballot(less));
-                    const float sd = dpp_f<DPP_WAVE_SHR1>(ld[n]);
-                    const uint32_t sr = dpp_u<DPP_WAVE_SHR1>(lr[n]);
-                    if (lane > pos) { ld[n] = sd; lr[n] = sr; }
-                    else if (lane == pos) { ld[n] = d; lr[n] = r; }
-                    thr_d[n] = readlane_f(ld[n], kp - 1);
-                    thr_r[n] = (uint32_t)__builtin_amdgcn_readlane((int)lr[n], kp - 1);
-                }
-            }
-        }
-    };
+    // One row against the NQ queries.  `valid` is wave-uniform and gates only the (rare) insert, never the
+    // arithmetic: the four rows' DPP chains must stay free to interleave.  How `valid` is WRITTEN matters: with
+    // "j < rows_in_chunk" clang hoists a branch in front of every row's reduction (+2 us per 1 M-row launch,
+    // A/B on one box); "(v0 + j) < n" below does not trigger that, so the unfiltered loop keeps that form.
+#define SMT_REDUCE_ROW(cj, rj, valid_expr)                                                                        \
+    do {                                                                                                          \
+        const bool valid = (valid_expr);                                                                          \
+        const float b2 = wave_sum((cj).x * (cj).x + (cj).y * (cj).y + (cj).z * (cj).z + (cj).w * (cj).w);         \
+        _Pragma("unroll") for (int n = 0; n < NQ; ++n) {                                                          \
+            const float ab = wave_sum((cj).x * q[n].x + (cj).y * q[n].y + (cj).z * q[n].z + (cj).w * q[n].w);     \
+            const float d = dist_f32(ab, b2, rq[n], qz[n]);                                                       \
+            const uint32_t r = (rj);                                                                              \
+            if (valid && (d < thr_d[n] || (d == thr_d[n] && r < thr_r[n]))) {                                     \
+                /* insert (d, r) keeping (distance asc, row asc) order */                                         \
+                const bool less = (ld[n] < d) || (ld[n] == d && lr[n] < r);                                       \
+                const int pos = __popcll(__ballot(less));                                                         \
+                const float sd = dpp_f<DPP_WAVE_SHR1>(ld[n]);                                                     \
+                const uint32_t sr = dpp_u<DPP_WAVE_SHR1>(lr[n]);                                                  \
+                if (lane > pos) { ld[n] = sd; lr[n] = sr; }                                                       \
+                else if (lane == pos) { ld[n] = d; lr[n] = r; }                                                   \
+                thr_d[n] = readlane_f(ld[n], kp - 1);                                                             \
+                thr_r[n] = (uint32_t)__builtin_amdgcn_readlane((int)lr[n], kp - 1);                               \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
 
-    // Three-stage software pipeline: [claim chunk c+2, request its descriptor] -> [request the rows of c+1] ->
-    // [reduce c].  The rows of c+1 are requested right after c's rows ARRIVED (the register copy below waits
-    // for them) and fly during c's reduction.  A true ping-pong over two register buffers (c+1 requested
-    // before the wait for c, two chunks in flight per wave) was measured and is SLOWER: 160 vs 149 us at
-    // 1 M rows -- like 16 waves/CU or U = 8, more requests in flight than ~32 KiB per CU cost bandwidth.
-    f32x4 cn[U];
-    uint32_t rown[U];
-    uint64_t cA = chunk_id((uint32_t)wave), cB = n_chunks, cC = n_chunks;
-    uint64_t dA = fetch_desc(cA), dB = 0;
-    if (cA < n_chunks) {
-        issue_loads(dA, cn, rown);
-        cB = chunk_id(claim());
-        dB = fetch_desc(cB);
-        cC = chunk_id(claim());
-    }
-    while (cA < n_chunks) {
-        f32x4 c[U];
-        uint32_t row[U];
+    // Software pipeline: the rows of the next chunk are requested right after the current chunk's rows arrived
+    // (the register copy below waits for them) and fly during the current reduction; the chunk after that is
+    // claimed meanwhile.  Measured alternatives, all slower at 1 M rows: a ping-pong over two register buffers
+    // (two chunks in flight per wave: 160 vs 149 us), 16 waves/CU, U = 8 -- more than ~32 KiB of requests in
+    // flight per CU costs bandwidth.
+    if constexpr (!FILTERED) {
+        auto issue_rows = [&](uint64_t v0, f32x4 (&c)[U], uint32_t (&row)[U]) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
-        if (cB < n_chunks) issue_loads(dB, cn, rown);
-        const uint64_t dC = fetch_desc(cC);
-        const uint64_t cD = chunk_id(claim());
-        reduce(c, row, (uint32_t)(dA >> 32));
-        cA = cB; dA = dB;
-        cB = cC; dB = dC;
-        cC = cD;
+            for (int j = 0; j < U; ++j) {
+                uint64_t v = v0 + j;
+                if (v >= p.n_virtual) v = p.n_virtual - 1;  // clamp (result discarded)
+                row[j] = (uint32_t)v;
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row[j] * 256) + lane;
+                c[j] = NT ? __builtin_nontemporal_load(src) : *src;
+            }
+        };
+        auto chunk_v0 = [&](uint32_t t) -> uint64_t {
+            return (((uint64_t)(t / waves_per_block) * gridDim.x + blockIdx.x) * waves_per_block + t % waves_per_block) * U;
+        };
+        f32x4 cn[U];
+        uint32_t rown[U];
+        uint64_t v0 = chunk_v0((uint32_t)wave);
+        uint64_t v0n = 0;
+        if (v0 < p.n_virtual) {
+            issue_rows(v0, cn, rown);
+            v0n = chunk_v0(claim());
+        }
+        while (v0 < p.n_virtual) {
+            f32x4 c[U];
+            uint32_t row[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
+            if (v0n < p.n_virtual) issue_rows(v0n, cn, rown);
+            const uint64_t v0nn = chunk_v0(claim());
+#pragma unroll
+            for (int j = 0; j < U; ++j) SMT_REDUCE_ROW(c[j], row[j], (v0 + j) < p.n_virtual);
+            v0 = v0n;
+            v0n = v0nn;
+        }
+    } else {
+        // range-filtered: one more stage in front -- [claim chunk c+2, request its descriptor (scalar load)] ->
+        // [request the rows of c+1] -> [reduce c]
+        f32x4 cn[U];
+        uint32_t rown[U];
+        uint64_t cA = chunk_id((uint32_t)wave), cB = n_chunks, cC = n_chunks;
+        uint64_t dA = fetch_desc(cA), dB = 0;
+        if (cA < n_chunks) {
+            issue_loads(dA, cn, rown);
+            cB = chunk_id(claim());
+            dB = fetch_desc(cB);
+            cC = chunk_id(claim());
+        }
+        while (cA < n_chunks) {
+            f32x4 c[U];
+            uint32_t row[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
+            if (cB < n_chunks) issue_loads(dB, cn, rown);
+            const uint64_t dC = fetch_desc(cC);
+            const uint64_t cD = chunk_id(claim());
+            const uint64_t end = (dA & 0xFFFFFFFFull) + (dA >> 32);  // first row past this chunk
+#pragma unroll
+            for (int j = 0; j < U; ++j) SMT_REDUCE_ROW(c[j], row[j], (dA & 0xFFFFFFFFull) + j < end);
+            cA = cB; dA = dB;
+            cB = cC; dB = dC;
+            cC = cD;
+        }
     }
+#undef SMT_REDUCE_ROW
 
     if (p.stamps && lane == 0) p.stamps[wave_global * 2 + 1] = wall_clock64();
 

@@ -105,24 +105,25 @@ __global__ void __launch_bounds__(1024) scan_threshold_kernel(ThrParams p)
         issue_loads(dA, cn, rown);
         cB = chunk_id(claim());
         dB = fetch_desc(cB);
-        cC = chunk_id(claim());
+        if (FILTERED) cC = chunk_id(claim());  // only a table descriptor needs a stage of its own
     }
     while (cA < n_chunks) {
         f32x4 c[U];
         uint32_t row[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
-        const uint32_t cnt_valid = (uint32_t)(dA >> 32);
+        const uint64_t first = dA & 0xFFFFFFFFull, end = first + (dA >> 32);  // rows [first, end) of this chunk are real
         if (cB < n_chunks) issue_loads(dB, cn, rown);
-        const uint64_t dC = fetch_desc(cC);
-        const uint64_t cD = chunk_id(claim());
+        uint64_t cN, dN;  // the chunk after B
+        if (FILTERED) { cN = cC; dN = fetch_desc(cC); cC = chunk_id(claim()); }
+        else { cN = chunk_id(claim()); dN = fetch_desc(cN); }
 
         // lane j (< U) remembers whether row j passed
         bool pass_mine = false;
         uint32_t my_row = 0;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const bool valid = (uint32_t)j < cnt_valid;
+            const bool valid = first + j < end;  // written like K2's test: "j < count" makes clang branch around every row
             const float b2 = wave_sum(c[j].x * c[j].x + c[j].y * c[j].y + c[j].z * c[j].z + c[j].w * c[j].w);
             const float ab = wave_sum(c[j].x * q.x + c[j].y * q.y + c[j].z * q.z + c[j].w * q.w);
             const float d = dist_f32(ab, b2, rq, qz);
@@ -136,8 +137,7 @@ __global__ void __launch_bounds__(1024) scan_threshold_kernel(ThrParams p)
             n_buf += cnt;
         }
         cA = cB; dA = dB;
-        cB = cC; dB = dC;
-        cC = cD;
+        cB = cN; dB = dN;
     }
     flush();
 }

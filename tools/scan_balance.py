@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("SMT_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import semtools_amd as smt
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
