@@ -1,5 +1,6 @@
-"""A/B of two builds of the library in ONE process is impossible (same SONAME), so: run this script once per
-build root (argv[1]) inside one gpurun call, alternating, and compare the steady-state K2 kernel time."""
+"""A/B of two builds of the library (one gpurun call = one box; boxes differ by more than the 1-2 % under test).
+Setup: git worktree add -f ab_old <rev> && bash ab_old/semtools_amd/csrc/build.sh  (ab_old/ is git-ignored, travels with gpurun).
+Run once per build root (argv[1]) inside ONE gpurun call, alternating, and compare the steady-state K2 kernel time."""
 import os, sys, json
 root = os.path.abspath(sys.argv[1])
 sys.path.insert(0, root)
