@@ -343,6 +343,8 @@ constexpr int SEL_MAX_LISTS = 512;
 constexpr int SEL_MAX_COLS = 8;
 constexpr int SEL_SURV_CAP = 1024;
 constexpr int ROW_STRIDE_F4 = 65;  // LDS row stride in float4 (1040 B): conflict-free b128 reads
+constexpr int PROD_STRIDE = 258;   // LDS row stride of the f64 product tables (2064 B)
+constexpr int SEL_FAST_KP = 34;    // product tables fit the 160 KiB LDS up to this k' (k <= 26)
 
 // c-th smallest key of `col[0..L)` (PAD = missing), published with atomicMin into *tau.
 // Executed by ONE wave; slots beyond L hold PAD which never satisfies the predicates below.
@@ -415,19 +417,27 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int kp = (int)p.kp;
     const int L = (int)p.n_lists;
-    // LDS carve (all offsets multiples of 16; no static LDS in this kernel):
-    f32x4 *s_rows = reinterpret_cast<f32x4 *>(smem_raw);                       // [kp+1][65] float4
-    key_t64 *s_surv = reinterpret_cast<key_t64 *>(s_rows + (size_t)(kp + 1) * ROW_STRIDE_F4);  // [SEL_SURV_CAP]
-    key_t64 *s_col = s_surv + SEL_SURV_CAP;                                      // [ncols][L] column entries
-    unsigned int *s_srank = reinterpret_cast<unsigned int *>(s_col + (size_t)SEL_MAX_COLS * SEL_MAX_LISTS);  // [96]
+    // LDS carve (all offsets multiples of 16; no static LDS in this kernel): small arrays first, then one big
+    // region used twice -- [candidate-row tiles | survivors | column entries] until the best k' are known,
+    // then (fast path) the exact-product tables of the rescoring stage.
+    unsigned int *s_srank = reinterpret_cast<unsigned int *>(smem_raw);        // [96]
     unsigned int *s_rank = s_srank + 96;                                        // [kp+pad] final ranks
-    double *s_qd = reinterpret_cast<double *>(s_rank + 80);                     // [256] query as f64
+    double *s_qd = reinterpret_cast<double *>(s_rank + 80);                     // [256] query as f64 (slow path)
     key_t64 *s_best = reinterpret_cast<key_t64 *>(s_qd + 256);                  // [kp] (+pad to even)
     double *s_d = reinterpret_cast<double *>(s_best + ((kp + 1) & ~1));        // [kp]
-    uint32_t *s_r = reinterpret_cast<uint32_t *>(s_d + ((kp + 1) & ~1));       // [kp]
+    double *s_b2 = s_d + ((kp + 1) & ~1);                                       // [kp] row norms^2 (fast path)
+    uint32_t *s_r = reinterpret_cast<uint32_t *>(s_b2 + ((kp + 1) & ~1));      // [kp]
     key_t64 *s_tau = reinterpret_cast<key_t64 *>(s_r + ((kp + 3) & ~3));       // [1]
     double *s_a2 = reinterpret_cast<double *>(s_tau + 1);                       // [1] query norm^2
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_a2 + 1);          // [0]=survivors [1]=valid
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_a2 + 1);          // [0]=survivors [1]=valid (+2 pad)
+    unsigned char *s_big = reinterpret_cast<unsigned char *>(s_cnt + 4);
+    f32x4 *s_rows = reinterpret_cast<f32x4 *>(s_big);                           // [kp+1][65] float4
+    key_t64 *s_surv = reinterpret_cast<key_t64 *>(s_rows + (size_t)(kp + 1) * ROW_STRIDE_F4);  // [SEL_SURV_CAP]
+    key_t64 *s_col = s_surv + SEL_SURV_CAP;                                      // [ncols][L] column entries
+    double *s_P = reinterpret_cast<double *>(s_big);                            // [kp][PROD_STRIDE] q_i * c_i (exact in f64)
+    double *s_B = s_P + (size_t)kp * PROD_STRIDE;                               // [kp][PROD_STRIDE] c_i * c_i
+    double *s_Q = s_B + (size_t)kp * PROD_STRIDE;                               // [256]            q_i * q_i
+    const bool fast_rescore = kp <= SEL_FAST_KP;
 
     const uint32_t qi = blockIdx.x;
     const key_t64 *lists = p.lists + (size_t)qi * p.list_stride;
@@ -544,41 +554,96 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     SEL_STAMP(4);
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[8] = (unsigned long long)S;
 
-    // stage the candidate rows (one wave per row, 16 B per lane) and the query converted to f64
+    // ---- exact rescoring (bit-identical to the oracle's index-order f64 sums, see exact_sums()).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    if (threadIdx.x < 256) s_qd[threadIdx.x] = (double)p.queries[(size_t)qi * 256 + threadIdx.x];
-    for (int c = wave; c < kp; c += n_waves) {
-        if (s_best[c] != KEY_PAD) {
-            const float *g = p.corpus + (uint64_t)(uint32_t)(s_best[c] & 0xFFFFFFFFull) * 256;
-            s_rows[(size_t)c * ROW_STRIDE_F4 + lane] = reinterpret_cast<const f32x4 *>(g)[lane];
-        }
-    }
-    __syncthreads();
-    SEL_STAMP(5);
-
-    // exact rescoring: thread t < kp walks candidate t's row; thread 128 (another wave) walks the query
     double my_ab = 0.0, my_b2 = 0.0;
     const key_t64 my_key = (int)threadIdx.x < kp ? s_best[threadIdx.x] : KEY_PAD;
-    if (my_key != KEY_PAD) {
-        const f32x4 *r4 = s_rows + (size_t)threadIdx.x * ROW_STRIDE_F4;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) {
-            const f32x4 b = r4[i];
-            const double a0 = s_qd[4 * i], a1 = s_qd[4 * i + 1], a2 = s_qd[4 * i + 2], a3 = s_qd[4 * i + 3];
-            const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
-            my_ab = my_ab + a0 * bx; my_b2 = my_b2 + bx * bx;
-            my_ab = my_ab + a1 * by; my_b2 = my_b2 + by * by;
-            my_ab = my_ab + a2 * bz; my_b2 = my_b2 + bz * bz;
-            my_ab = my_ab + a3 * bw; my_b2 = my_b2 + bw * bw;
+    if (fast_rescore) {
+        // The product of two f32 values is EXACT in f64, so "acc = acc + (double)a * (double)b" only rounds in
+        // the add.  All 1024 threads compute the products q_i*c_i, c_i*c_i, q_i*q_i into LDS in parallel (one
+        // wave per candidate row, coalesced 16 B per lane); what stays sequential is one chain of 256 dependent
+        // f64 ADDS per sum, run by 2*k'+1 threads in three different waves.  (Before: each of the k' threads
+        // converted and multiplied inside its chain -- 9.2k cycles for this stage, now the adds alone.)
+        const f32x4 qv = reinterpret_cast<const f32x4 *>(p.queries + (size_t)qi * 256)[lane];
+        // a wave owns candidates wave, wave+16, (wave+32): request all its rows first (ONE global latency)
+        constexpr int ROWS_PER_WAVE = (SEL_FAST_KP + SEL_THREADS / 64 - 1) / (SEL_THREADS / 64);  // 3
+        f32x4 bv[ROWS_PER_WAVE];
+        bool have[ROWS_PER_WAVE];
+#pragma unroll
+        for (int u = 0; u < ROWS_PER_WAVE; ++u) {
+            const int c = wave + u * n_waves;
+            have[u] = c < kp && s_best[c] != KEY_PAD;
+            const uint32_t row = have[u] ? (uint32_t)(s_best[c] & 0xFFFFFFFFull) : 0u;
+            bv[u] = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)row * 256)[lane];
         }
-    }
-    if (threadIdx.x == 128) {
-        double a2 = 0.0;
+        // (conversions only now: the query and all row loads above are in flight together)
+        const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
+        if (wave == n_waves - 1) {
+            double *dst = s_Q + 4 * lane;
+            dst[0] = q0 * q0; dst[1] = q1 * q1; dst[2] = q2 * q2; dst[3] = q3 * q3;
+        }
+#pragma unroll
+        for (int u = 0; u < ROWS_PER_WAVE; ++u) {
+            if (have[u]) {
+                const int c = wave + u * n_waves;
+                const double b0 = bv[u].x, b1 = bv[u].y, b2 = bv[u].z, b3 = bv[u].w;
+                double *dp = s_P + (size_t)c * PROD_STRIDE + 4 * lane;
+                double *db = s_B + (size_t)c * PROD_STRIDE + 4 * lane;
+                dp[0] = q0 * b0; dp[1] = q1 * b1; dp[2] = q2 * b2; dp[3] = q3 * b3;
+                db[0] = b0 * b0; db[1] = b1 * b1; db[2] = b2 * b2; db[3] = b3 * b3;
+            }
+        }
+        __syncthreads();
+        SEL_STAMP(5);
+        // chains: threads [0,kp) sum P, threads [64,64+kp) sum B, thread 128 sums Q
+        const int role = (int)threadIdx.x >> 6, idx = (int)threadIdx.x & 63;
+        const double *src = nullptr;
+        if (role == 0 && idx < kp && s_best[idx] != KEY_PAD) src = s_P + (size_t)idx * PROD_STRIDE;
+        else if (role == 1 && idx < kp && s_best[idx] != KEY_PAD) src = s_B + (size_t)idx * PROD_STRIDE;
+        else if (threadIdx.x == 128) src = s_Q;
+        if (src) {
+            double acc = 0.0;
+#pragma unroll 16
+            for (int i = 0; i < 256; ++i) acc = acc + src[i];
+            if (role == 0) my_ab = acc;
+            else if (role == 1) s_b2[idx] = acc;
+            else *s_a2 = acc;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < kp) my_b2 = s_b2[threadIdx.x];
+    } else {
+        // large k': stage the candidate rows (one wave per row, 16 B per lane) and the query converted to f64
+        if (threadIdx.x < 256) s_qd[threadIdx.x] = (double)p.queries[(size_t)qi * 256 + threadIdx.x];
+        for (int c = wave; c < kp; c += n_waves) {
+            if (s_best[c] != KEY_PAD) {
+                const float *g = p.corpus + (uint64_t)(uint32_t)(s_best[c] & 0xFFFFFFFFull) * 256;
+                s_rows[(size_t)c * ROW_STRIDE_F4 + lane] = reinterpret_cast<const f32x4 *>(g)[lane];
+            }
+        }
+        __syncthreads();
+        SEL_STAMP(5);
+        // thread t < kp walks candidate t's row; thread 128 (another wave) walks the query
+        if (my_key != KEY_PAD) {
+            const f32x4 *r4 = s_rows + (size_t)threadIdx.x * ROW_STRIDE_F4;
 #pragma unroll 8
-        for (int i = 0; i < 256; ++i) a2 = a2 + s_qd[i] * s_qd[i];
-        *s_a2 = a2;
+            for (int i = 0; i < 64; ++i) {
+                const f32x4 b = r4[i];
+                const double a0 = s_qd[4 * i], a1 = s_qd[4 * i + 1], a2 = s_qd[4 * i + 2], a3 = s_qd[4 * i + 3];
+                const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
+                my_ab = my_ab + a0 * bx; my_b2 = my_b2 + bx * bx;
+                my_ab = my_ab + a1 * by; my_b2 = my_b2 + by * by;
+                my_ab = my_ab + a2 * bz; my_b2 = my_b2 + bz * bz;
+                my_ab = my_ab + a3 * bw; my_b2 = my_b2 + bw * bw;
+            }
+        }
+        if (threadIdx.x == 128) {
+            double a2 = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < 256; ++i) a2 = a2 + s_qd[i] * s_qd[i];
+            *s_a2 = a2;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if ((int)threadIdx.x < kp) {
         double d = __builtin_inf();
         uint32_t r = 0xFFFFFFFFu;
@@ -620,8 +685,11 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
 static size_t final_smem_bytes(uint32_t n_lists, uint32_t kp)
 {
     (void)n_lists;
-    return (size_t)(kp + 1) * ROW_STRIDE_F4 * 16 + (size_t)SEL_SURV_CAP * 8 + (size_t)SEL_MAX_COLS * SEL_MAX_LISTS * 8 +
-           (size_t)(96 + 80) * 4 + 256 * 8 + (size_t)(kp + 2) * 8 * 2 + (size_t)(kp + 4) * 4 + 96;
+    const size_t kp2 = (kp + 1) & ~1u;
+    const size_t small = (size_t)(96 + 80) * 4 + 256 * 8 + kp2 * 8 * 3 + (size_t)((kp + 3) & ~3u) * 4 + 8 + 8 + 16;
+    const size_t big_select = (size_t)(kp + 1) * ROW_STRIDE_F4 * 16 + (size_t)SEL_SURV_CAP * 8 + (size_t)SEL_MAX_COLS * SEL_MAX_LISTS * 8;
+    const size_t big_rescore = kp <= (uint32_t)SEL_FAST_KP ? ((size_t)2 * kp * PROD_STRIDE + 256) * 8 : 0;
+    return small + std::max(big_select, big_rescore) + 64;
 }
 
 // ------------------------------------------------- cross-shard top-k merge
