@@ -225,7 +225,16 @@ int smt_ivfpq_list_sizes(const smt_ivfpq *index, uint64_t *sizes_host /* [nlist]
 int smt_ivfpq_save(smt_ivfpq *index, const char *path);
 int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out);
 
-/* Tuning knobs (0 = library default); for benchmarking sweeps. */
+/* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
+ *   scan_blocks, scan_threads, scan_unroll (2/4/8/16), scan_nontemporal   K2 launch shape
+ *   gemm_blocks, gemm_resident, gemm_qsplit                               K3
+ *   prof_select (0/1), prof_every (N: HIP events on one launch in N)       profiling cost control
+ *   scan_debug_ptr, select_debug_ptr                                       device pointers for phase stamps
+ *   async_select (0/1)   smt_search_topk_device with ONE query: the select stage of call i runs on an
+ *                        internal second stream WHILE the scan of call i+1 runs (device-scope flags between
+ *                        the two kernels).  Outputs are complete after smt_ctx_synchronize (or any other
+ *                        call on the context, which drains the pipeline first).  Throughput mode for
+ *                        back-to-back single queries; off by default. */
 int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ host ids

@@ -24,14 +24,42 @@ void set_error(const char *fmt, ...)
 int ensure_scratch(smt_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->scratch_bytes) return SMT_OK;
-    // stream-ordered safety: earlier kernels may still read the old buffer
+    // stream-ordered safety: earlier kernels (main stream, async selects on the aux stream) may still read the old buffer
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) SMT_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
     if (ctx->d_scratch) SMT_HIP_CHECK(hipFree(ctx->d_scratch));
     ctx->d_scratch = nullptr;
     ctx->scratch_bytes = 0;
     size_t want = std::max(bytes, (size_t)1 << 20);
     SMT_HIP_CHECK(hipMalloc(&ctx->d_scratch, want));
     ctx->scratch_bytes = want;
+    return SMT_OK;
+}
+
+int ensure_async(smt_ctx *ctx)
+{
+    if (ctx->aux_stream) return SMT_OK;
+    SMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    SMT_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_flags), 64));
+    SMT_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->async_step = 0;
+    return SMT_OK;
+}
+
+int drain_async(smt_ctx *ctx)
+{
+    if (!ctx->async_pending) return SMT_OK;
+    ctx->async_pending = false;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // the scans the selects are waiting for
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+    unsigned long long timed_out = 0;
+    SMT_HIP_CHECK(hipMemcpy(&timed_out, ctx->d_flags + 3, sizeof(timed_out), hipMemcpyDeviceToHost));
+    if (timed_out) {
+        (void)hipMemset(ctx->d_flags + 3, 0, sizeof(timed_out));
+        set_error("async select: a kernel gave up waiting for its partner (flag wait timed out)");
+        return SMT_E_HIP;
+    }
     return SMT_OK;
 }
 
@@ -65,6 +93,9 @@ void prof_begin(smt_ctx *ctx, const char *name)
 {
     if (!ctx->prof_on) return;
     ProfEntry &e = ctx->prof[name];
+    const uint64_t every = ctx->tune.prof_every > 1 ? (uint64_t)ctx->tune.prof_every : 1;
+    e.armed = (e.calls++ % every) == 0;
+    if (!e.armed) return;
     if (e.used + 2 > e.ev.size()) {
         const size_t old = e.ev.size();
         e.ev.resize(old + 256);
@@ -77,6 +108,8 @@ void prof_end(smt_ctx *ctx, const char *name)
 {
     if (!ctx->prof_on) return;
     ProfEntry &e = ctx->prof[name];
+    if (!e.armed) return;
+    e.armed = false;
     (void)hipEventRecord(e.ev[e.used + 1], ctx->stream);
     e.used += 2;
 }
@@ -87,10 +120,10 @@ static int check_ctx(const smt_ctx *ctx)
     return SMT_OK;
 }
 
-static int bind_device(const smt_ctx *ctx)
+static int bind_device(smt_ctx *ctx, bool drain = true)
 {
     SMT_HIP_CHECK(hipSetDevice(ctx->device));
-    return SMT_OK;
+    return drain ? drain_async(ctx) : SMT_OK;
 }
 
 // Device buffers carved out of one temporary allocation, freed on scope exit.
@@ -167,6 +200,8 @@ void smt_ctx_destroy(smt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     for (auto &kv : ctx->prof)
         for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -180,8 +215,9 @@ int smt_ctx_synchronize(smt_ctx *ctx)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
+    SMT_HIP_CHECK(hipSetDevice(ctx->device));
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return SMT_OK;
+    return drain_async(ctx);
 }
 
 int smt_prof_enable(smt_ctx *ctx, int on)
@@ -197,7 +233,7 @@ int smt_prof_reset(smt_ctx *ctx)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (auto &kv : ctx->prof) kv.second.used = 0;
+    for (auto &kv : ctx->prof) { kv.second.used = 0; kv.second.calls = 0; kv.second.armed = false; }
     return SMT_OK;
 }
 
@@ -239,6 +275,12 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
     else if (k == "gemm_resident") ctx->tune.gemm_resident = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
+    else if (k == "prof_every") ctx->tune.prof_every = (int)value;
+    else if (k == "async_select") {
+        int rc2 = drain_async(ctx);
+        if (rc2) return rc2;
+        ctx->tune.async_select = (int)value;
+    }
     else if (k == "scan_debug_ptr") ctx->tune.scan_debug_ptr = value;
     else if (k == "select_debug_ptr") ctx->tune.select_debug_ptr = value;
     else if (k == "prof_select") ctx->tune.prof_select = (int)value;
@@ -780,7 +822,8 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
     SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
     SMT_REQUIRE(top_k >= 1 && top_k <= 64, "top_k must be in [1, 64]");
     smt_ctx *ctx = corpus->ctx;
-    int rc = bind_device(ctx);
+    const bool async = ctx->tune.async_select && nq == 1 && corpus->rows > 0;  // launch_scan_topk keeps the pipeline going
+    int rc = bind_device(ctx, !async);
     if (rc) return rc;
     if (nq == 0) return SMT_OK;
     ScanArgs a;
@@ -801,6 +844,7 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
     a.out_rows = out_rows_dev;
     a.out_dist = out_dist_dev;
     a.out_counts = nullptr;
+    a.allow_async = async;
     if (corpus->rows == 0) {
         // nothing to scan: fill with padding through the merge kernel on zero lists
         return launch_merge_topk(ctx, out_rows_dev, out_dist_dev, 0, nq, 1, top_k, out_rows_dev, out_dist_dev);

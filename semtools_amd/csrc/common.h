@@ -44,6 +44,8 @@ static constexpr key_t64 KEY_PAD = 0xFFFFFFFFFFFFFFFFull;
 struct ProfEntry {
     std::vector<hipEvent_t> ev;  // start/stop pairs, grown on demand
     size_t used = 0;
+    uint64_t calls = 0;          // prof_begin calls since the last reset (sampling: tuning key prof_every)
+    bool armed = false;          // the current begin/end pair is being recorded
 };
 
 struct Tuning {
@@ -53,6 +55,8 @@ struct Tuning {
     int scan_nontemporal = 1;
     int scan_prefetch = 1;      // software-pipelined row loads (single-query kernel)
     int gemm_blocks = 0;        // 0 = CU count
+    int prof_every = 1;         // HIP events bracket one launch in N (an event pair costs ~6 us of stream time)
+    int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel
     int prof_select = 1;        // 0: do not bracket the select stage with events (2 fewer event records per query)
@@ -74,6 +78,12 @@ struct smt_ctx {
     size_t pinned_bytes = 0;
     void *d_stage = nullptr;   // smt_search's per-call inputs/outputs (queries, ranges, result lists)
     size_t stage_bytes = 0;
+    // async select (tuning key async_select): the select of query i runs on aux_stream WHILE query i+1 scans;
+    // the two kernels meet through device-scope flags, not stream events
+    hipStream_t aux_stream = nullptr;
+    unsigned long long *d_flags = nullptr;  // [0] scan_done step, [1] select_done step, [2] blocks finished, [3] timeout flag
+    uint64_t async_step = 0;
+    bool async_pending = false;
     bool prof_on = false;
     std::map<std::string, smt::ProfEntry> prof;
     smt::Tuning tune;
@@ -102,6 +112,10 @@ namespace smt {
 int ensure_scratch(smt_ctx *ctx, size_t bytes);
 int ensure_pinned(smt_ctx *ctx, size_t bytes);
 int ensure_stage(smt_ctx *ctx, size_t bytes);
+// Wait for select kernels still running on the aux stream (no-op unless async_select was used).  Every entry
+// point that touches the context's scratch or reads results on the main stream calls this first.
+int drain_async(smt_ctx *ctx);
+int ensure_async(smt_ctx *ctx);  // aux stream + flags
 
 // RAII-less helpers for event timing around a kernel family.
 void prof_begin(smt_ctx *ctx, const char *name);
@@ -129,6 +143,7 @@ struct ScanArgs {
     uint64_t *out_rows;
     double *out_dist;
     uint64_t *out_counts;     // may be nullptr
+    bool allow_async = false; // the caller does not read the outputs on the main stream before smt_ctx_synchronize
 };
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
 
@@ -158,7 +173,7 @@ int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, c
 int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
                   uint32_t n_lists, uint32_t kp, uint64_t list_stride, uint32_t k_out, int ws_threshold,
                   float ws_thr_score, uint64_t row_base, uint64_t *out_rows, double *out_dist,
-                  uint64_t *out_counts);
+                  uint64_t *out_counts, uint64_t async_step = 0 /* != 0: on the aux stream, gated by the flags */);
 
 int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,

@@ -578,6 +578,7 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     *out = nullptr;
     smt_ctx *ctx = corpus->ctx;
     IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     const uint64_t N = corpus->rows;
     SMT_REQUIRE(prm->m == PQ_M && prm->nbits == 8, "this build supports m = 32 sub-quantisers of 8 bits (dsub = 8)");
     SMT_REQUIRE(prm->nlist >= 32 && prm->nlist <= PROBE_MAX_LISTS && prm->nlist % 32 == 0, "nlist must be a multiple of 32 in [32, 4096]");
@@ -721,6 +722,7 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     SMT_REQUIRE(nq == 0 || (queries && out_rows && out_dist && out_counts), "null argument");
     smt_ctx *ctx = ix->corpus->ctx;
     IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     if (nq == 0) return SMT_OK;
     for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
     if (top_k == 0) return SMT_OK;
@@ -853,6 +855,7 @@ int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
     SMT_REQUIRE(ix && path, "null argument");
     smt_ctx *ctx = ix->corpus->ctx;
     IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     IVF_HIP(hipStreamSynchronize(ctx->stream));
     FILE *f = fopen(path, "wb");
     if (!f) { smt::set_error("cannot open '%s' for writing: %s", path, strerror(errno)); return SMT_E_IO; }
@@ -883,6 +886,7 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     *out = nullptr;
     smt_ctx *ctx = corpus->ctx;
     IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     FILE *f = fopen(path, "rb");
     if (!f) { smt::set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
     std::unique_ptr<FILE, int (*)(FILE *)> fguard(f, fclose);

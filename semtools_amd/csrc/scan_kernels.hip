@@ -29,7 +29,30 @@ struct ScanParams {
     uint32_t kp;           // candidates kept per wave / per block (<= 64)
     key_t64 *block_lists;  // [NQ][gridDim.x][kp]
     unsigned long long *stamps;  // optional (tuning key scan_debug_ptr): wall_clock64 per wave [start, loop end], per block [end]
+    unsigned long long *flags;   // async select (or nullptr): [0] scan_done step, [1] select_done step, [2] blocks done, [3] timeout
+    unsigned long long step;     // this launch's step number (>= 1)
 };
+
+// ---- async select: device-scope flags between the scan of step i (main stream) and its select (aux stream) ----
+__device__ __forceinline__ unsigned long long flag_load(const unsigned long long *f)
+{
+    return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(unsigned long long *f, unsigned long long v)
+{
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One thread waits until *f >= want.  Gives up after ~0.5 s of the 100 MHz wall clock and raises flags[3]:
+// a missing partner kernel must end in an error code, never in a hung GPU.
+__device__ __forceinline__ void flag_wait(unsigned long long *flags, int which, unsigned long long want)
+{
+    if (flag_load(flags + which) >= want) return;
+    const unsigned long long t0 = wall_clock64();
+    while (flag_load(flags + which) < want) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 50000000ull) { flag_store(flags + 3, 1ull); break; }
+    }
+}
 
 // Range filter (path-subset search, src/workspace/store.rs:507-515): the rows to scan are the concatenation
 // of sorted, disjoint row ranges.  Each range is cut into chunks of FILTER_CHUNK rows (the last one short),
@@ -235,6 +258,11 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
 
     if (p.stamps && lane == 0) p.stamps[wave_global * 2 + 1] = wall_clock64();
 
+    // async select: this launch fills the list buffer that the select of step-2 read, and the aux stream must
+    // not fall behind: wait for the select of step-1 (it started when this scan did and takes ~14 us -- by the
+    // time a block gets here the flag is long up, the wait normally reads it once)
+    if (p.flags && threadIdx.x == 0 && p.step >= 2) flag_wait(p.flags, 1, p.step - 1);
+
     // block merge: rank every wave's candidates among all of the block's.
     for (int n = 0; n < NQ; ++n) {
         __syncthreads();
@@ -248,6 +276,19 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             for (int w = 0; w < waves_per_block; ++w)
                 for (int i = 0; i < kp; ++i) rank += (s_keys[w * 64 + i] < mine) ? 1 : 0;
             if (rank < kp) out[rank] = mine;
+        }
+    }
+    if (p.flags) {
+        // publish: the block's list stores are ordered before its barrier (workgroup scope); ONE thread then
+        // does the agent-scope release (one L2 write-back per block -- a __threadfence() in every thread cost
+        // 50 us per launch), and the LAST block raises scan_done
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long prev = __hip_atomic_fetch_add(p.flags + 2, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == (unsigned long long)gridDim.x - 1) {
+                flag_store(p.flags + 2, 0ull);
+                __hip_atomic_store(p.flags + 0, p.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (p.stamps && threadIdx.x == 0) p.stamps[(uint64_t)gridDim.x * waves_per_block * 2 + blockIdx.x] = wall_clock64();
@@ -407,11 +448,17 @@ struct FinalParams {
     double *out_dist;     // [nq][k_out]
     uint64_t *out_counts; // [nq] or nullptr
     unsigned long long *dbg;  // optional: s_memtime stamps of query 0's phases (tuning key select_debug_ptr)
+    unsigned long long *flags;  // async select (or nullptr), see ScanParams
+    unsigned long long step;
 };
 
 #define SEL_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
 
 // One block per query.
+// KREG = keys a thread holds in registers: 8 covers n_lists * k' <= 8192 (every k <= 24 at 256 lists) in 70
+// VGPRs, so that the 16-wave block fits on a CU NEXT TO a scan block (async select); 36 covers the maximum
+// (512 lists x 72) and takes the whole register file.
+template <int KREG>
 __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -441,14 +488,24 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
 
     const uint32_t qi = blockIdx.x;
     const key_t64 *lists = p.lists + (size_t)qi * p.list_stride;
+    if (p.flags) {
+        // launched on the aux stream while the scan of this step may still be running on the main stream
+        if (threadIdx.x == 0) {
+            flag_wait(p.flags, 0, p.step);
+            // acquire at agent scope by ONE thread (invalidates this CU's vector L1 and the XCD's non-coherent
+            // L2 lines: the lists were written through other XCDs' L2s); the barrier hands it to the block
+            (void)__hip_atomic_load(p.flags + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     SEL_STAMP(0);
 
     // ---- ONE global-latency phase: every key of the L lists goes to registers (<= 36 per thread)
-    constexpr int KREG = (SEL_MAX_LISTS * 72 + SEL_THREADS - 1) / SEL_THREADS;  // 36
+    static_assert(KREG == 8 || KREG == (SEL_MAX_LISTS * 72 + SEL_THREADS - 1) / SEL_THREADS, "8 or 36");
     const int M = L * kp;
     const int n_round = (M + SEL_THREADS - 1) / SEL_THREADS;  // block-uniform
     key_t64 kreg[KREG];
-    if (n_round <= 8) {  // common case (k <= 24): 8 back-to-back loads, one wait
+    if (KREG == 8 || n_round <= 8) {  // common case (k <= 24): 8 back-to-back loads, one wait
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = (int)threadIdx.x + i * SEL_THREADS;
@@ -679,6 +736,11 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     }
     if (threadIdx.x == 0 && p.out_counts)
         p.out_counts[qi] = s_cnt[1] < p.k_out ? s_cnt[1] : p.k_out;
+    if (p.flags) {
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x == 0)  // async mode: one query per launch
+            __hip_atomic_store(p.flags + 1, p.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     SEL_STAMP(7);
 }
 
@@ -762,12 +824,15 @@ static int launch_scan_filtered(smt_ctx *ctx, const ScanParams &p, int blocks, i
 int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
                   uint32_t n_lists, uint32_t kp, uint64_t list_stride, uint32_t k_out, int ws_threshold,
                   float ws_thr_score, uint64_t row_base, uint64_t *out_rows, double *out_dist,
-                  uint64_t *out_counts)
+                  uint64_t *out_counts, uint64_t async_step)
 {
     SMT_REQUIRE(n_lists >= 1 && n_lists <= (uint32_t)SEL_MAX_LISTS, "select stage accepts 1..512 block lists");
+    SMT_REQUIRE(async_step == 0 || (nq == 1 && ctx->aux_stream && ctx->d_flags), "async select handles one query per launch");
     static bool attr_set = false;
     if (!attr_set) {
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<36>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -786,8 +851,19 @@ int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint3
     f.out_dist = out_dist;
     f.out_counts = out_counts;
     f.dbg = reinterpret_cast<unsigned long long *>(ctx->tune.select_debug_ptr);
+    f.flags = async_step ? ctx->d_flags : nullptr;
+    f.step = async_step;
+    const bool small = (uint64_t)n_lists * kp <= (uint64_t)8 * SEL_THREADS;
+    if (async_step) {
+        if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->aux_stream, f);
+        else hipLaunchKernelGGL(final_select_kernel<36>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->aux_stream, f);
+        ctx->async_pending = true;
+        SMT_HIP_CHECK(hipGetLastError());
+        return SMT_OK;
+    }
     if (ctx->tune.prof_select) prof_begin(ctx, "select");
-    hipLaunchKernelGGL(final_select_kernel, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
+    if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
+    else hipLaunchKernelGGL(final_select_kernel<36>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
     if (ctx->tune.prof_select) prof_end(ctx, "select");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
@@ -809,12 +885,19 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         const uint64_t need = (n_chunks + waves_per_block - 1) / waves_per_block;
         blocks = (int)(need > 0 ? need : 1);
     }
+    // async select (one query per call): two list buffers alternate, the select of step i reads buffer i&1 on
+    // the aux stream while the scan of step i+1 fills the other one
+    const bool async = a.allow_async && ctx->tune.async_select && a.nq == 1;
+    int rc = SMT_OK;
+    if (async && (rc = ensure_async(ctx))) return rc;
+    if (!async && (rc = drain_async(ctx))) return rc;
+    const uint64_t step = async ? ++ctx->async_step : 0;
     const size_t list_bytes = (((size_t)a.nq * blocks * kp * sizeof(key_t64)) + 255) & ~(size_t)255;
     const size_t table_bytes = filtered ? (size_t)n_chunks * sizeof(uint64_t) : 0;
-    int rc = ensure_scratch(ctx, list_bytes + table_bytes);
+    rc = ensure_scratch(ctx, 2 * list_bytes + table_bytes);
     if (rc != SMT_OK) return rc;
-    key_t64 *lists = reinterpret_cast<key_t64 *>(ctx->d_scratch);
-    uint64_t *table = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(ctx->d_scratch) + list_bytes);
+    key_t64 *lists = reinterpret_cast<key_t64 *>(reinterpret_cast<char *>(ctx->d_scratch) + (step & 1) * list_bytes);
+    uint64_t *table = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(ctx->d_scratch) + 2 * list_bytes);
 
     const bool nt = ctx->tune.scan_nontemporal != 0;
     prof_begin(ctx, "scan");
@@ -829,6 +912,8 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         p.kp = kp;
         p.block_lists = lists + (size_t)q0 * blocks * kp;
         p.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
+        p.flags = async ? ctx->d_flags : nullptr;
+        p.step = step;
         const uint32_t left = a.nq - q0;
         if (left >= 4) {
             rc = filtered ? launch_scan_filtered<4>(ctx, p, blocks, threads, nt)
@@ -852,7 +937,7 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
     }
     prof_end(ctx, "scan");
     return launch_select(ctx, a.corpus, a.queries, a.nq, lists, (uint32_t)blocks, kp, (uint64_t)blocks * kp, a.k_out,
-                         a.ws_threshold, a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts);
+                         a.ws_threshold, a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts, step);
 }
 
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,

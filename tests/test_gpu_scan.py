@@ -394,3 +394,45 @@ def test_threshold_many_hits_device_order_matches_oracle(corpus20k):
         assert rows.tolist() == [r["match_line"] for r in res], md
         assert np.array_equal(dist, np.array([r["distance"] for r in res]))
     c2.close()
+
+
+def test_async_select_pipeline_equals_stream_order(gpu_ctx):
+    """async_select: the select of query i runs on the aux stream while query i+1 scans (device-scope flags).
+    Same answers as the in-order path, for a long back-to-back series, across a change of k and corpus, and
+    after switching the mode off again (drain)."""
+    import torch
+    import semtools_amd as smt
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    x = torch.randn(300_000, 256, device=dev, generator=g)
+    x /= x.norm(dim=1, keepdim=True)
+    qs = torch.randn(64, 256, device=dev, generator=g)
+    torch.cuda.synchronize()
+    ctx = smt.Context(0)
+    big = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=300_000)
+    small = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=5_000)
+
+    def series(corpus, k, n):
+        rows = torch.full((n, k), -7, dtype=torch.int64, device=dev)
+        dist = torch.full((n, k), -7.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        for i in range(n):
+            corpus.search_topk_device(qs[i % 64].data_ptr(), 1, k, 0, rows[i].data_ptr(), dist[i].data_ptr())
+        ctx.synchronize()
+        return rows.cpu().numpy(), dist.cpu().numpy()
+
+    want = {(name, k): series(c, k, 200) for name, c in (("big", big), ("small", small)) for k in (10, 3)}
+    ctx.set_tuning("async_select", 1)
+    for rep in range(2):
+        for (name, k), (wr, wd) in want.items():
+            gr, gd = series(big if name == "big" else small, k, 200)
+            assert np.array_equal(gr, wr) and np.array_equal(gd, wd), (rep, name, k)
+    # a host-level search in between must see finished results and must not be async itself
+    r, d = big.search(qs[0].cpu().numpy(), top_k=10)[0]
+    assert r.tolist() == want[("big", 10)][0][0].tolist()
+    ctx.set_tuning("async_select", 0)
+    gr, gd = series(big, 10, 50)
+    assert np.array_equal(gr, want[("big", 10)][0][:50])
+    big.close(); small.close(); ctx.close()
