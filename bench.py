@@ -119,15 +119,27 @@ def main():
     # region (sync() flushes the last one).
     depth = 2
     pipelined = os.environ.get("SEMTOOLS_BENCH_PIPELINE", "1") != "0"
+    async_exchange = os.environ.get("SEMTOOLS_BENCH_ASYNC_SELECT", "1") != "0" and pipelined
+    async_select = async_exchange if exchange else os.environ.get("SEMTOOLS_BENCH_ASYNC_SELECT", "1") != "0"
     locs = [torch.empty((2, k), dtype=torch.int64, device=device) for _ in range(depth)]
     gath = [torch.empty((world, 1, 2, k), dtype=torch.int64, device=device) for _ in range(depth)]
     pending = []
 
+    # N > 1: the main stream carries nothing but scans.  The select of step i runs on the library's aux stream
+    # (async select), the all-gather of its output is enqueued from that stream (RCCL waits for the select, not
+    # for the next scan), and the merge of the gathered lists follows on the aux stream one step later.
+    aux = torch.cuda.ExternalStream(ctx.aux_stream(), device=device) if exchange and async_exchange else None
+
     def flush():
         while pending:
             work, s, i = pending.pop(0)
-            work.wait()                               # stream-level wait: the host does not block
-            ctx.merge_topk_packed_device(gath[s].data_ptr(), world, 1, k, k, host[i % ring].data_ptr())
+            if aux is not None:
+                with torch.cuda.stream(aux):
+                    work.wait()                       # stream-level wait on the aux stream
+                ctx.merge_topk_packed_device(gath[s].data_ptr(), world, 1, k, k, host[i % ring].data_ptr())  # merge_on_aux
+            else:
+                work.wait()                           # stream-level wait: the host does not block
+                ctx.merge_topk_packed_device(gath[s].data_ptr(), world, 1, k, k, host[i % ring].data_ptr())
 
     def step(i):
         q = queries[i % n_queries]
@@ -137,7 +149,11 @@ def main():
             return
         s = i % depth
         corpus.search_topk_device(q.data_ptr(), 1, k, row_base, locs[s][0:1].data_ptr(), locs[s][1:2].data_ptr())
-        work = dist.all_gather_into_tensor(gath[s].view(world * 2, k), locs[s], async_op=True)
+        if aux is not None:
+            with torch.cuda.stream(aux):
+                work = dist.all_gather_into_tensor(gath[s].view(world * 2, k), locs[s], async_op=True)
+        else:
+            work = dist.all_gather_into_tensor(gath[s].view(world * 2, k), locs[s], async_op=True)
         if pipelined:
             flush()                                   # merge of step i-1 (its all-gather overlapped this scan)
         pending.append((work, s, i))
@@ -153,9 +169,9 @@ def main():
 
     # N = 1: the select stage of query i runs on the library's aux stream WHILE query i+1 scans (device-scope
     # flags between the two kernels); every select finishes inside the timed region (sync()).
-    # With the exchange (N > 1) the all-gather consumes the select's output in stream order, so it stays off.
-    async_select = (not exchange) and os.environ.get("SEMTOOLS_BENCH_ASYNC_SELECT", "1") != "0"
+    # With the exchange (N > 1) the all-gather and the merge follow the select on that aux stream.
     ctx.set_tuning("async_select", 1 if async_select else 0)
+    ctx.set_tuning("merge_on_aux", 1 if (exchange and async_exchange) else 0)
     for i in range(args.settle_steps):
         step(i)
     sync()
@@ -177,7 +193,10 @@ def main():
     elapsed = time.perf_counter() - t0
     n_scan, scan_ms = ctx.prof_read("scan")
     ctx.set_tuning("prof_every", 1)
+    flush()
+    ctx.set_tuning("merge_on_aux", 0)
     ctx.set_tuning("async_select", 0)             # the select stage is timed on its own, back to back with the scan
+    aux = None
     ctx.set_tuning("prof_select", 1)
     ctx.prof_reset()
     for i in range(20):

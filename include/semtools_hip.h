@@ -225,6 +225,11 @@ int smt_ivfpq_list_sizes(const smt_ivfpq *index, uint64_t *sizes_host /* [nlist]
 int smt_ivfpq_save(smt_ivfpq *index, const char *path);
 int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out);
 
+/* The context's second stream (hipStream_t), created on first use: async selects run on it.  A host that
+ * chains more work behind an async select (an RCCL all-gather of its output, the merge of the gathered
+ * lists with tuning key merge_on_aux) enqueues it here so that the main stream carries nothing but scans. */
+int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
+
 /* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
  *   scan_blocks, scan_threads, scan_unroll (2/4/8/16), scan_nontemporal   K2 launch shape
  *   gemm_blocks, gemm_resident, gemm_qsplit                               K3
@@ -234,7 +239,8 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out);
  *                        internal second stream WHILE the scan of call i+1 runs (device-scope flags between
  *                        the two kernels).  Outputs are complete after smt_ctx_synchronize (or any other
  *                        call on the context, which drains the pipeline first).  Throughput mode for
- *                        back-to-back single queries; off by default. */
+ *                        back-to-back single queries; off by default.
+ *   merge_on_aux (0/1)   smt_merge_topk_packed_device is enqueued on the aux stream (see smt_ctx_aux_stream) */
 int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ host ids

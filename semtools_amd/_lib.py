@@ -18,7 +18,7 @@ MODE_DOCUMENTS, MODE_WORKSPACE = 0, 1
 DIM = 256
 
 EXPORTS = [
-    "smt_ctx_create", "smt_ctx_create_on_stream", "smt_ctx_destroy", "smt_ctx_synchronize", "smt_last_error", "smt_version",
+    "smt_ctx_create", "smt_ctx_create_on_stream", "smt_ctx_aux_stream", "smt_ctx_destroy", "smt_ctx_synchronize", "smt_last_error", "smt_version",
     "smt_device_count", "smt_prof_enable", "smt_prof_reset", "smt_prof_read",
     "smt_model_create", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
@@ -91,6 +91,7 @@ def lib():
     L.smt_device_count.restype = i32
     L.smt_ctx_create.argtypes = [i32, P(vp)]
     L.smt_ctx_create_on_stream.argtypes = [i32, vp, P(vp)]
+    L.smt_ctx_aux_stream.argtypes = [vp, P(vp)]
     L.smt_ctx_destroy.argtypes = [vp]
     L.smt_ctx_destroy.restype = None
     L.smt_ctx_synchronize.argtypes = [vp]

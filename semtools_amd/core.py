@@ -40,6 +40,13 @@ class Context:
     def synchronize(self):
         L.check(L.lib().smt_ctx_synchronize(self._h))
 
+    def aux_stream(self):
+        """Raw hipStream_t of the context's second stream (async selects run there); wrap it with
+        torch.cuda.ExternalStream to chain torch / RCCL work behind an async select."""
+        st = C.c_void_p()
+        L.check(L.lib().smt_ctx_aux_stream(self._h, C.byref(st)))
+        return int(st.value or 0)
+
     def set_tuning(self, key, value):
         L.check(L.lib().smt_set_tuning(self._h, key.encode(), int(value)))
 

@@ -220,6 +220,17 @@ int smt_ctx_synchronize(smt_ctx *ctx)
     return drain_async(ctx);
 }
 
+int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(stream_out != nullptr, "null argument");
+    SMT_HIP_CHECK(hipSetDevice(ctx->device));
+    if ((rc = ensure_async(ctx))) return rc;
+    *stream_out = reinterpret_cast<void *>(ctx->aux_stream);
+    return SMT_OK;
+}
+
 int smt_prof_enable(smt_ctx *ctx, int on)
 {
     int rc = check_ctx(ctx);
@@ -276,6 +287,11 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_resident") ctx->tune.gemm_resident = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
     else if (k == "prof_every") ctx->tune.prof_every = (int)value;
+    else if (k == "merge_on_aux") {
+        int rc2 = drain_async(ctx);
+        if (rc2) return rc2;
+        ctx->tune.merge_on_aux = (int)value;
+    }
     else if (k == "async_select") {
         int rc2 = drain_async(ctx);
         if (rc2) return rc2;
@@ -895,7 +911,7 @@ int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint3
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(nq == 0 || k_out == 0 || (packed_dev && out_packed_dev), "null argument");
-    if ((rc = bind_device(ctx))) return rc;
+    if ((rc = bind_device(ctx, !(ctx->tune.merge_on_aux && ctx->aux_stream)))) return rc;
     if (nq == 0 || k_out == 0) return SMT_OK;
     return launch_merge_topk_packed(ctx, packed_dev, n_lists, nq, k_in, k_out, out_packed_dev);
 }

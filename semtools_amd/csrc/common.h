@@ -56,6 +56,7 @@ struct Tuning {
     int scan_prefetch = 1;      // software-pipelined row loads (single-query kernel)
     int gemm_blocks = 0;        // 0 = CU count
     int prof_every = 1;         // HIP events bracket one launch in N (an event pair costs ~6 us of stream time)
+    int merge_on_aux = 0;       // 1: smt_merge_topk_packed_device runs on the aux stream (behind the async select it consumes)
     int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel
