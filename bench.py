@@ -170,6 +170,10 @@ def main():
     # N = 1: the select stage of query i runs on the library's aux stream WHILE query i+1 scans (device-scope
     # flags between the two kernels); every select finishes inside the timed region (sync()).
     # With the exchange (N > 1) the all-gather and the merge follow the select on that aux stream.
+    if exchange:
+        # RCCL sets its channels up on the first collective (can take a second): do that before the pipeline starts
+        dist.all_gather_into_tensor(gath[0].view(world * 2, k), locs[0])
+        torch.cuda.synchronize(device)
     ctx.set_tuning("async_select", 1 if async_select else 0)
     ctx.set_tuning("merge_on_aux", 1 if (exchange and async_exchange) else 0)
     for i in range(args.settle_steps):

@@ -42,15 +42,17 @@ __device__ __forceinline__ void flag_store(unsigned long long *f, unsigned long 
 {
     __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// One thread waits until *f >= want.  Gives up after ~0.5 s of the 100 MHz wall clock and raises flags[3]:
-// a missing partner kernel must end in an error code, never in a hung GPU.
+// One thread waits until *f >= want.  Gives up after ~2 s of the 100 MHz wall clock and raises flags[3]
+// (after which no kernel waits any more): a missing partner kernel must end in an error code at the next
+// synchronise, never in a hung GPU.
 __device__ __forceinline__ void flag_wait(unsigned long long *flags, int which, unsigned long long want)
 {
     if (flag_load(flags + which) >= want) return;
     const unsigned long long t0 = wall_clock64();
     while (flag_load(flags + which) < want) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 50000000ull) { flag_store(flags + 3, 1ull); break; }
+        if (flag_load(flags + 3) != 0ull) break;
+        if (wall_clock64() - t0 > 200000000ull) { flag_store(flags + 3, 1ull); break; }
     }
 }
 
