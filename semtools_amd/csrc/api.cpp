@@ -51,6 +51,7 @@ int drain_async(smt_ctx *ctx)
 {
     if (!ctx->async_pending) return SMT_OK;
     ctx->async_pending = false;
+    if (!ctx->aux_stream || !ctx->d_flags) return SMT_OK;
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // the scans the selects are waiting for
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
     unsigned long long timed_out = 0;

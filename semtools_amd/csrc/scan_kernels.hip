@@ -971,8 +971,9 @@ int launch_merge_topk_packed(smt_ctx *ctx, const uint64_t *packed, uint32_t n_li
 {
     SMT_REQUIRE((uint64_t)n_lists * k_in <= 8192, "device merge handles up to 8192 candidates per query");
     // async pipeline: the merge follows the select it consumes on the aux stream (tuning key merge_on_aux)
-    hipStream_t st = (ctx->tune.merge_on_aux && ctx->aux_stream) ? ctx->aux_stream : ctx->stream;
-    if (st == ctx->aux_stream) ctx->async_pending = true;
+    const bool on_aux = ctx->tune.merge_on_aux && ctx->aux_stream != nullptr;
+    hipStream_t st = on_aux ? ctx->aux_stream : ctx->stream;  // (ctx->stream may itself be the null stream)
+    if (on_aux) ctx->async_pending = true;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, st, packed,
                        reinterpret_cast<const double *>(packed + k_in), n_lists, (uint64_t)nq * 2 * k_in, (uint64_t)2 * k_in,
                        k_in, k_out, out_packed, reinterpret_cast<double *>(out_packed + k_out), (uint64_t)2 * k_out);
