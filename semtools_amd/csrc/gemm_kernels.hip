@@ -62,8 +62,20 @@ __device__ __forceinline__ uint64_t level_tile(uint64_t i, uint64_t stride, int 
     return u * stride;
 }
 
-__device__ __forceinline__ void append_candidates(const f32x16 &acc, const float (&rbv)[16], unsigned valid16, uint32_t q,
-                                                  float tau, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts);
+__device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned zero16, unsigned valid16, uint32_t q,
+                                                  float thr, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts);
+// The candidate test in the SCORE domain.  The row tile is scaled by 1/|row| once when it is loaded, so an
+// accumulator is already cos * |q|; "distance <= tau" becomes acc >= (1 - tau) / |q|^-1 ... i.e. ONE compare
+// per (row, query) in the epilogue instead of two multiplies, a subtract, a max and a compare (the epilogue
+// cost 5 % of a 1000 x 10 M batch).  The bound is lowered by two ulps: a borderline row is admitted rather
+// than lost (candidates are nominations; the final distances are exact).  Zero query (rq == 0): every
+// distance is 1 (0 against a zero row), the slot then carries tau itself.
+__device__ __forceinline__ float score_threshold(float tau, float rq)
+{
+    if (rq == 0.0f) return tau;
+    const float t = (1.0f - tau) / rq;  // tau = +inf (first level) -> -inf: everything passes
+    return t - fabsf(t) * 2.4e-7f;
+}
 
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams p)
 {
@@ -84,7 +96,6 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
     const bool resident = qt_hi - qt_lo <= 2;  // both query tiles live in LDS for the whole kernel
 
     // ---- per-query constants: tau and 1/|q|
-    for (uint32_t q = q_lo + threadIdx.x; q < q_hi; q += GEMM_THREADS) s_tau[q] = q < p.nq ? p.tau[q] : -1.0f;
     for (uint32_t q = q_lo + wave; q < q_hi; q += GEMM_WAVES) {
         float rq = 0.0f;
         if (q < p.nq) {
@@ -92,7 +103,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
             rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
         }
-        if (lane == 0) s_rq[q] = rq;
+        if (lane == 0) {
+            s_rq[q] = rq;
+            s_tau[q] = score_threshold(q < p.nq ? p.tau[q] : -1.0f, rq);  // padding: zero query, tau < 0 -> never passes
+        }
     }
 
     // ---- stage a query tile into LDS buffer `buf` (zero rows beyond nq)
@@ -131,8 +145,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
 
         // ---- A operand: this wave's 32 corpus rows, register resident
         f32x4 A[32];
-        float rbv[16];
-        unsigned valid16 = 0;
+        unsigned zero16 = 0;   // bit r: tile row acc_row(r, h) is the zero vector
+        unsigned valid16 = 0;  // bit r: that row exists
         if (has) {
             const uint64_t my_row = row0 + j;
             const bool row_ok = my_row < p.n_rows;
@@ -140,7 +154,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             float part = 0.0f;
 #pragma unroll
             for (int m = 0; m < 32; ++m) {
-                A[m] = row_ok ? __builtin_nontemporal_load(src + 2 * m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                A[m] = __builtin_nontemporal_load(src + 2 * m);  // unconditional (address clamped above): 32 loads in flight
+            }
+            if (!row_ok) {  // rows past the end of the corpus contribute zeros (one test, not one branch per load)
+#pragma unroll
+                for (int m = 0; m < 32; ++m) A[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int m = 0; m < 32; ++m)
@@ -148,9 +166,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             const float b2 = part + __shfl_xor(part, 32);
             const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);  // row l&31, same in both halves
 #pragma unroll
+            for (int m = 0; m < 32; ++m) A[m] *= rb;  // unit rows: the accumulators are cosines times |q|
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;  // accumulator reg r <-> tile row i
-                rbv[r] = __shfl(rb, i);
+                if (__shfl(rb, i) == 0.0f) zero16 |= 1u << r;
                 if (row0 + i < p.n_rows) valid16 |= 1u << r;
             }
         }
@@ -177,7 +197,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
                 }
                 // ---- epilogue: lane owns query q = qt*32 + j and 16 rows
                 const uint32_t q = qt * QT_ROWS + j;
-                append_candidates(acc, rbv, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
+                append_candidates(acc, zero16, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
             }
 
             if (restage) {
@@ -191,18 +211,23 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
 }
 
 // ---- shared epilogue: lane (j, h) owns query q and the 16 rows acc_row(r, h) of the tile at row0
-__device__ __forceinline__ void append_candidates(const f32x16 &acc, const float (&rbv)[16], unsigned valid16, uint32_t q,
-                                                  float tau, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts)
+__device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned zero16, unsigned valid16, uint32_t q,
+                                                  float thr, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts)
 {
     unsigned pass = 0;
     auto dist_of = [&](int r) {
-        float d = fmaxf(1.0f - acc[r] * rbv[r] * rq, 0.0f);
-        if (rbv[r] == 0.0f && rq == 0.0f) d = 0.0f;  // zero row vs zero query (simsimd rule)
-        return d;
+        if (rq == 0.0f) return (zero16 >> r) & 1u ? 0.0f : 1.0f;  // zero query: 0 against a zero row, else 1 (simsimd rules)
+        return fmaxf(1.0f - acc[r] * rq, 0.0f);                    // a zero row has acc == 0 -> 1
     };
+    if (rq != 0.0f) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (dist_of(r) <= tau) pass |= 1u << r;
+        for (int r = 0; r < 16; ++r)
+            if (acc[r] >= thr) pass |= 1u << r;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (dist_of(r) <= thr) pass |= 1u << r;
+    }
     pass &= valid16;
     if (__builtin_amdgcn_ballot_w64(pass != 0)) {
         if (pass) {
@@ -239,7 +264,6 @@ __global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParam
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    for (uint32_t q = threadIdx.x; q < NQT * QT_ROWS; q += RES_THREADS) s_tau[q] = q < p.nq ? p.tau[q] : -1.0f;
     for (uint32_t q = wave; q < NQT * QT_ROWS; q += RES_WAVES) {
         float rq = 0.0f;
         if (q < p.nq) {
@@ -247,7 +271,10 @@ __global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParam
             const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
             rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
         }
-        if (lane == 0) s_rq[q] = rq;
+        if (lane == 0) {
+            s_rq[q] = rq;
+            s_tau[q] = score_threshold(q < p.nq ? p.tau[q] : -1.0f, rq);
+        }
     }
     for (int idx = threadIdx.x; idx < NQT * QT_ROWS * 64; idx += RES_THREADS) {
         const uint32_t q = idx >> 6;
@@ -264,27 +291,32 @@ __global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParam
         const bool row_ok = my_row < p.n_rows;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (row_ok ? my_row : 0) * 256) + h;
 #pragma unroll
-        for (int m = 0; m < 32; ++m) A[m] = row_ok ? __builtin_nontemporal_load(src + 2 * m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 32; ++m) A[m] = __builtin_nontemporal_load(src + 2 * m);  // unconditional, address clamped
+        if (!row_ok) {
+#pragma unroll
+            for (int m = 0; m < 32; ++m) A[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     };
-    auto compute = [&](uint64_t it, const f32x4 (&A)[32]) {
+    auto compute = [&](uint64_t it, f32x4 (&A)[32]) {
         const uint64_t row0 = level_tile(it, p.stride, p.skip16) * 32;
         float part = 0.0f;
 #pragma unroll
         for (int m = 0; m < 32; ++m) part += A[m].x * A[m].x + A[m].y * A[m].y + A[m].z * A[m].z + A[m].w * A[m].w;
         const float b2 = part + __shfl_xor(part, 32);
         const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);
-        float rbv[16];
-        unsigned valid16 = 0;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) A[m] *= rb;  // unit rows (see score_threshold)
+        unsigned zero16 = 0, valid16 = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            rbv[r] = __shfl(rb, acc_row(r, h));
+            if (__shfl(rb, acc_row(r, h)) == 0.0f) zero16 |= 1u << r;
             if (row0 + acc_row(r, h) < p.n_rows) valid16 |= 1u << r;
         }
 #pragma unroll 1
         for (int qt = 0; qt < NQT; ++qt) {  // not unrolled: one accumulator set and one B stream live at a time
             const f32x16 acc = mfma_tile_32x32x256(A, s_q + qt * QT_F4 + j * QT_STRIDE_F4 + h);
             const uint32_t q = qt * QT_ROWS + j;
-            append_candidates(acc, rbv, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
+            append_candidates(acc, zero16, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
         }
     };
 
