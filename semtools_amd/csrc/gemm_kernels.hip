@@ -40,6 +40,7 @@ namespace smt {
 constexpr uint32_t CAND_CAP = 2048;            // candidate slots per query
 constexpr int LEVEL_RATIO = 16;
 constexpr int LEVEL0_MAX_TILES = 32;           // level 0 appends every row: <= 1024 per query
+constexpr uint32_t GEMM_MAX_NQ = 3584;         // 4 x 32.5 KiB tile slots + 8 B per query fit the 160 KiB LDS
 
 struct GemmParams {
     const float *corpus;
@@ -80,8 +81,8 @@ __device__ __forceinline__ float score_threshold(float tau, float rq)
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    f32x4 *s_q = reinterpret_cast<f32x4 *>(smem_raw);                  // [2][32][65] float4
-    float *s_tau = reinterpret_cast<float *>(s_q + 2 * QT_F4);        // [nqt*32]
+    f32x4 *s_q = reinterpret_cast<f32x4 *>(smem_raw);                  // [4][32][65] float4: two PAIRS of query tiles
+    float *s_tau = reinterpret_cast<float *>(s_q + 4 * QT_F4);        // [nqt*32]
     float *s_rq = s_tau + (size_t)p.nqt * QT_ROWS;                    // [nqt*32]  1/|q| (0 for a zero query)
 
     const int lane = threadIdx.x & 63;
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
     const uint32_t qt_lo = (uint32_t)((uint64_t)qs * p.nqt / p.qsplit);
     const uint32_t qt_hi = (uint32_t)((uint64_t)(qs + 1) * p.nqt / p.qsplit);
     const uint32_t q_lo = qt_lo * QT_ROWS, q_hi = qt_hi * QT_ROWS;
-    const bool resident = qt_hi - qt_lo <= 2;  // both query tiles live in LDS for the whole kernel
+    const uint32_t n_qt = qt_hi - qt_lo;
+    const bool resident = n_qt <= 4;  // all of this block's query tiles live in LDS for the whole kernel
 
     // ---- per-query constants: tau and 1/|q|
     for (uint32_t q = q_lo + wave; q < q_hi; q += GEMM_WAVES) {
@@ -109,28 +111,30 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
         }
     }
 
-    // ---- stage a query tile into LDS buffer `buf` (zero rows beyond nq)
-    auto stage_load = [&](uint32_t qt, f32x4 (&r)[4]) {
+    // ---- stage query tile qt into LDS slot `slot` with LDS-DMA loads (global_load_lds_dwordx4: one wave
+    // instruction moves one 1 KiB query row straight into its 1040-B LDS row -- no staging registers, no ds_write;
+    // the old path went global -> 4 VGPR quads -> 4 ds_write_b128 per thread and cost 1.5 ms of a 43 ms batch).
+    // Each wave owns 4 of the tile's 32 rows.  Completion is tracked by vmcnt: wait before the barrier.
+    auto stage_tile = [&](uint32_t qt, int slot) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = threadIdx.x + u * GEMM_THREADS;  // float4 index inside the 32x64 tile
-            const uint32_t q = qt * QT_ROWS + (idx >> 6);
-            r[u] = q < p.nq ? reinterpret_cast<const f32x4 *>(p.queries + (size_t)q * 256)[idx & 63]
-                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < QT_ROWS / GEMM_WAVES; ++u) {
+            const int r = wave * (QT_ROWS / GEMM_WAVES) + u;  // wave-uniform
+            const uint32_t q = qt * QT_ROWS + r;
+            f32x4 *dst = s_q + slot * QT_F4 + r * QT_STRIDE_F4;
+            if (q < p.nq) {
+                __builtin_amdgcn_global_load_lds(p.queries + (size_t)q * 256 + lane * 4,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            } else {
+                dst[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};  // padding rows of the last tile
+            }
         }
     };
-    auto stage_store = [&](int buf, const f32x4 (&r)[4]) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = threadIdx.x + u * GEMM_THREADS;
-            s_q[buf * QT_F4 + (idx >> 6) * QT_STRIDE_F4 + (idx & 63)] = r[u];
-        }
-    };
+    auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };  // vmcnt(0): the DMA writes have landed
     {
-        f32x4 r[4];
-        stage_load(qt_lo, r);
-        stage_store(0, r);
-        if (qt_hi - qt_lo > 1) { stage_load(qt_lo + 1, r); stage_store(1, r); }
+        // resident: tiles 0..n_qt-1 -> slots 0..n_qt-1; streaming: the first pair -> slots 0, 1
+        const uint32_t first = resident ? n_qt : 2u;
+        for (uint32_t t = 0; t < first; ++t) stage_tile(qt_lo + t, (int)t);
+        stage_wait();
     }
     __syncthreads();
 
@@ -175,34 +179,42 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             }
         }
 
-        for (uint32_t qt = qt_lo; qt < qt_hi; ++qt) {
-            const int buf = resident ? (int)(qt - qt_lo) : cur;
-            f32x4 nxt[4];
-            const bool restage = !resident;
-            const uint32_t qt_next = (qt + 1 == qt_hi) ? qt_lo : qt + 1;
-            if (restage) stage_load(qt_next, nxt);
-
-            if (has) {
-                f32x16 acc;
+        // one (row tile x query tile) product + epilogue; the tile sits in LDS slot `slot`
+        auto tile_product = [&](uint32_t qt, int slot) {
+            f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                const f32x4 *bq = s_q + buf * QT_F4 + j * QT_STRIDE_F4 + h;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const f32x4 *bq = s_q + slot * QT_F4 + j * QT_STRIDE_F4 + h;
+            // lane owns query q = qt*32 + j: its threshold and 1/|q| are fetched now, under the MFMAs
+            const uint32_t q = qt * QT_ROWS + j;
+            const float thr_q = s_tau[q], rq_q = s_rq[q];
 #pragma unroll
-                for (int m = 0; m < 32; ++m) {
-                    const f32x4 b = bq[2 * m];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, b.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, b.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, b.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, b.w, acc, 0, 0, 0);
-                }
-                // ---- epilogue: lane owns query q = qt*32 + j and 16 rows
-                const uint32_t q = qt * QT_ROWS + j;
-                append_candidates(acc, zero16, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
+            for (int m = 0; m < 32; ++m) {
+                const f32x4 b = bq[2 * m];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, b.w, acc, 0, 0, 0);
             }
+            append_candidates(acc, zero16, valid16, q, thr_q, rq_q, row0, h, p.cand, p.counts);  // 16 rows x this lane's query
+        };
 
-            if (restage) {
-                // the next tile replaces the buffer last read one iteration ago (everyone passed that barrier)
-                stage_store(cur ^ 1, nxt);
+        if (resident) {
+            if (has)
+                for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t);
+        } else {
+            // streaming: TWO query tiles per barrier (the block's 8 waves meet half as often: the barrier cost
+            // 2.6 ms of a 43 ms batch).  While pair P is multiplied, the next pair lands in the other two slots.
+            for (uint32_t t = 0; t < n_qt; t += 2) {
+                const bool two = t + 1 < n_qt;  // block-uniform
+                const uint32_t tn0 = (t + 2) % n_qt, tn1 = (t + 3) % n_qt;  // wraps into the next row tile's sweep
+                // (when n_qt is odd the last pair holds one tile: the next sweep restarts at tile 0 in slot 0)
+                const uint32_t nx0 = two ? tn0 : 0u, nx1 = two ? tn1 : 1u;
+                stage_tile(qt_lo + nx0, (cur ^ 1) * 2);      // both DMA batches fly under the two products
+                stage_tile(qt_lo + nx1, (cur ^ 1) * 2 + 1);
+                if (has) tile_product(qt_lo + t, cur * 2);
+                if (has && two) tile_product(qt_lo + t + 1, cur * 2 + 1);
+                stage_wait();
                 __syncthreads();
                 cur ^= 1;
             }
@@ -380,7 +392,7 @@ __global__ void fill_f32_kernel(float *p, float v, uint32_t n)
 
 static size_t gemm_smem_bytes(uint32_t nqt)
 {
-    return (size_t)2 * QT_F4 * 16 + (size_t)nqt * QT_ROWS * 4 * 2 + 64;
+    return (size_t)4 * QT_F4 * 16 + (size_t)nqt * QT_ROWS * 4 * 2 + 64;
 }
 
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
@@ -390,7 +402,22 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const uint32_t kp = a.k_out + 8;
     const uint32_t nqt = (a.nq + QT_ROWS - 1) / QT_ROWS;
-    if (gemm_smem_bytes(nqt) > 150 * 1024) { set_error("batch too large for one launch (nq <= ~8000)"); return SMT_E_UNSUPPORTED; }
+    if (a.nq > GEMM_MAX_NQ) {
+        // the per-query thresholds of one launch live in LDS beside the four query-tile slots: larger batches
+        // are answered in chunks (each chunk is its own sweep over the corpus -- inherent at this batch size)
+        for (uint32_t q0 = 0; q0 < a.nq; q0 += GEMM_MAX_NQ) {
+            ScanArgs c = a;
+            c.nq = std::min<uint32_t>(GEMM_MAX_NQ, a.nq - q0);
+            c.queries = a.queries + (size_t)q0 * 256;
+            c.out_rows = a.out_rows + (size_t)q0 * a.k_out;
+            c.out_dist = a.out_dist + (size_t)q0 * a.k_out;
+            c.out_counts = a.out_counts ? a.out_counts + q0 : nullptr;
+            const int rc_chunk = launch_gemm_topk(ctx, c);
+            if (rc_chunk) return rc_chunk;
+        }
+        return SMT_OK;
+    }
+    if (gemm_smem_bytes(nqt) > 160 * 1024) { set_error("batch too large for one launch"); return SMT_E_UNSUPPORTED; }
 
     static bool attr_set = false;
     if (!attr_set) {
