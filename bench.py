@@ -128,7 +128,12 @@ def main():
     # N > 1: the main stream carries nothing but scans.  The select of step i runs on the library's aux stream
     # (async select), the all-gather of its output is enqueued from that stream (RCCL waits for the select, not
     # for the next scan), and the merge of the gathered lists follows on the aux stream one step later.
-    aux = torch.cuda.ExternalStream(ctx.aux_stream(), device=device) if exchange and async_exchange else None
+    aux = None
+    if exchange and async_exchange:
+        try:
+            aux = torch.cuda.ExternalStream(ctx.aux_stream(), device=device)
+        except Exception:                       # no ExternalStream in this torch: keep everything in stream order
+            aux, async_exchange, async_select = None, False, False
 
     def flush():
         while pending:
