@@ -1,5 +1,7 @@
 """GPU: randomised shapes (hypothesis) -- rows, k, ranges, duplicates, zero rows, query count --
 K2/K3/threshold/large-k all against the oracle.  Small sizes, many cases."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -8,6 +10,7 @@ from oracle import oracle as orc
 from tests import synth
 
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("SMT_FUZZ_SCALE", "1"))  # SMT_FUZZ_SCALE=10: ten times the examples (soak run)
 
 
 def _oracle(emb, q, k, thr=None):
@@ -15,7 +18,7 @@ def _oracle(emb, q, k, thr=None):
     return [r["match_line"] for r in res], [r["distance"] for r in res]
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=40 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(1, 3000), k=st.integers(1, 80), nq=st.sampled_from([1, 1, 2, 3, 5, 8, 9, 33]),
        seed=st.integers(0, 10_000), dup=st.sampled_from([0.0, 0.05, 0.5]), use_ranges=st.booleans())
 def test_topk_random_shapes(gpu_ctx, n, k, nq, seed, dup, use_ranges):
@@ -41,7 +44,7 @@ def test_topk_random_shapes(gpu_ctx, n, k, nq, seed, dup, use_ranges):
     c.close()
 
 
-@settings(max_examples=15, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=15 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(1, 5000), seed=st.integers(0, 10_000), thr=st.floats(0.5, 1.2))
 def test_threshold_random(gpu_ctx, n, seed, thr):
     import semtools_amd as smt
