@@ -41,6 +41,18 @@ __device__ __forceinline__ float wave_sum(float v)
     return (s0 + s1) + (s2 + s3);
 }
 
+// Integer sum over the 64 lanes, result in every lane.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += dpp_u<DPP_XOR1>(v);
+    v += dpp_u<DPP_XOR2>(v);
+    v += dpp_u<DPP_HALF_MIRROR>(v);
+    v += dpp_u<DPP_MIRROR>(v);
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), s1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), s3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return (s0 + s1) + (s2 + s3);
+}
+
 __device__ __forceinline__ float dist_f32(float ab, float b2, float rq, bool q_zero)
 {
     // simsimd rules (oracle/semtools_oracle.c cos_finish): both zero -> 0,

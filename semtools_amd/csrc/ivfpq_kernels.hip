@@ -304,41 +304,95 @@ struct ProbeParams {
     float *probe_dot;         // [nq][nprobe]  q . c
 };
 
-__global__ void __launch_bounds__(PROBE_THREADS) ivf_probe_kernel(ProbeParams p)
+// Coarse probe, two kernels (the first version was one block per query: 4096 wave-level dot products against
+// centroids re-read from L2 by every query, then a 78-stage bitonic sort of all 4096 keys -- 0.45 ms per 1000
+// queries, as much as the ADC scan itself):
+//   ivf_score_kernel   S[q][c] = 0.5|c|^2 - q.c for all (query, centroid) pairs on the MFMA pipe; one block per
+//                      centroid tile (32 centroids staged in LDS once), its waves sweep the query tiles;
+//   ivf_probe_select_kernel   one WAVE per query holds its nlist scores in registers (64 per lane), finds the
+//                      nprobe-th smallest by bisection on the orderable bit pattern, and emits the nprobe lists
+//                      (order is irrelevant downstream; ties go to the smaller list id).
+__global__ void __launch_bounds__(GEMM_THREADS, 2) ivf_score_kernel(const float *queries, uint32_t nq, const float *centroids,
+                                                                    const float *cnorm_half, uint32_t nlist, float *scores)
 {
-    __shared__ unsigned long long s_key[PROBE_MAX_LISTS];
-    __shared__ float s_dot[PROBE_MAX_LISTS];
-    const uint32_t qi = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    const f32x4 q = reinterpret_cast<const f32x4 *>(p.queries + (size_t)qi * 256)[lane];
-    for (uint32_t c = wave; c < PROBE_MAX_LISTS; c += n_waves) {
-        unsigned long long key = KEY_PAD;
-        if (c < p.nlist) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(p.centroids + (size_t)c * 256)[lane];
-            const float dot = wave_sum(v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w);
-            // ascending key == descending (q.c - 0.5|c|^2) == ascending |q - c|^2
-            key = ((unsigned long long)f32_orderable(p.cnorm_half[c] - dot) << 32) | c;
-            if (lane == 0) s_dot[c] = dot;
-        }
-        if (lane == 0) s_key[c] = key;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *s_c = reinterpret_cast<f32x4 *>(smem_raw);  // [32][65] float4: this block's centroid tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const uint32_t ct = blockIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = threadIdx.x + u * GEMM_THREADS;
+        s_c[(idx >> 6) * QT_STRIDE_F4 + (idx & 63)] =
+            reinterpret_cast<const f32x4 *>(centroids + (size_t)(ct * QT_ROWS + (idx >> 6)) * 256)[idx & 63];
     }
+    const uint32_t cid = ct * QT_ROWS + j;
+    const float cn = cnorm_half[cid];
     __syncthreads();
-    for (int k = 2; k <= PROBE_MAX_LISTS; k <<= 1) {
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int i = threadIdx.x; i < PROBE_MAX_LISTS; i += PROBE_THREADS) {
-                const int ixj = i ^ jj;
-                if (ixj > i) {
-                    const unsigned long long a = s_key[i], b = s_key[ixj];
-                    if ((a > b) == ((i & k) == 0)) { s_key[i] = b; s_key[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    const uint32_t n_tiles = (nq + 31) / 32;
+    for (uint32_t tile = wave; tile < n_tiles; tile += GEMM_WAVES) {
+        const uint32_t qrow = tile * 32 + j;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(queries + (size_t)(qrow < nq ? qrow : 0) * 256) + h;
+        f32x4 A[32];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) A[m] = src[2 * m];
+        const f32x16 acc = mfma_tile_32x32x256(A, s_c + j * QT_STRIDE_F4 + h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = tile * 32 + acc_row(r, h);
+            if (row < nq) scores[(size_t)row * nlist + cid] = cn - acc[r];
         }
     }
-    if (threadIdx.x < p.nprobe) {
-        const uint32_t c = (uint32_t)(s_key[threadIdx.x] & 0xFFFFFFFFull);
-        p.probe_list[(size_t)qi * p.nprobe + threadIdx.x] = c;
-        p.probe_dot[(size_t)qi * p.nprobe + threadIdx.x] = s_dot[c];
+}
+
+constexpr int SEL_SLOTS = PROBE_MAX_LISTS / 64;  // scores per lane
+
+__global__ void __launch_bounds__(256) ivf_probe_select_kernel(ProbeParams p, const float *scores, uint32_t nq)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= nq) return;  // wave-uniform
+    const float *sc = scores + (size_t)qi * p.nlist;
+    uint32_t v[SEL_SLOTS];
+#pragma unroll
+    for (int u = 0; u < SEL_SLOTS; ++u) {
+        const uint32_t c = (uint32_t)u * 64u + (uint32_t)lane;
+        v[u] = c < p.nlist ? f32_orderable(sc[c]) : 0xFFFFFFFFu;
+    }
+    // smallest T with #(v <= T) >= nprobe
+    uint32_t lo = 0u, hi = 0xFFFFFFFFu;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < SEL_SLOTS; ++u) cnt += v[u] <= mid ? 1u : 0u;
+        cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(cnt));
+        if (cnt >= p.nprobe) hi = mid; else lo = mid + 1u;
+    }
+    const uint32_t T = lo;
+    uint32_t n_lt = 0;
+#pragma unroll
+    for (int u = 0; u < SEL_SLOTS; ++u) n_lt += v[u] < T ? 1u : 0u;
+    n_lt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(n_lt));
+    uint32_t pos_lt = 0, pos_eq = n_lt;  // wave-uniform write cursors: "< T" first, then ties in list-id order
+    uint32_t *out_l = p.probe_list + (size_t)qi * p.nprobe;
+    float *out_d = p.probe_dot + (size_t)qi * p.nprobe;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int u = 0; u < SEL_SLOTS; ++u) {
+        const uint32_t c = (uint32_t)u * 64u + (uint32_t)lane;
+        const bool lt = v[u] < T, eq = v[u] == T && c < p.nlist;
+        const unsigned long long m_lt = __ballot(lt), m_eq = __ballot(eq);
+        uint32_t slot = 0xFFFFFFFFu;
+        if (lt) slot = pos_lt + (uint32_t)__popcll(m_lt & below);
+        else if (eq) slot = pos_eq + (uint32_t)__popcll(m_eq & below);
+        if (slot < p.nprobe) {
+            out_l[slot] = c;
+            out_d[slot] = p.cnorm_half[c] - sc[c];  // q . c
+        }
+        pos_lt += (uint32_t)__popcll(m_lt);
+        pos_eq += (uint32_t)__popcll(m_eq);
     }
 }
 
@@ -735,21 +789,29 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     const uint32_t shortlist = (rerank + adc_waves - 1) / adc_waves;  // per wave
     const uint32_t kp = top_k + 8;                // re-scored candidates handed to the exact select stage
 
-    DevBuf b;
-    const size_t o_q = 0, b_q = (size_t)nq * 256 * 4;
-    const size_t o_pl = o_q + b_q, b_pl = (((size_t)nq * nprobe * 4) + 15) & ~(size_t)15;
+    // every temporary lives in the context's scratch (no hipMalloc/hipFree per call), results come back through
+    // the pinned staging buffer
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_q = 0, b_q = al((size_t)nq * 256 * 4);
+    const size_t o_pl = o_q + b_q, b_pl = al((size_t)nq * nprobe * 4);
     const size_t o_pd = o_pl + b_pl, b_pd = b_pl;
-    const size_t o_lut = o_pd + b_pd, b_lut = (size_t)nq * PQ_M * PQ_K * 4;
-    const size_t o_lists = o_lut + b_lut, b_lists = (size_t)nq * nprobe * kp * 8;
-    const size_t o_or = o_lists + b_lists, b_or = (size_t)nq * top_k * 8;
+    const size_t o_lut = o_pd + b_pd, b_lut = al((size_t)nq * PQ_M * PQ_K * 4);
+    const size_t o_lists = o_lut + b_lut, b_lists = al((size_t)nq * nprobe * kp * 8);
+    const size_t o_or = o_lists + b_lists, b_or = (size_t)nq * top_k * 8;   // rows | dist | counts contiguous: one D2H
     const size_t o_od = o_or + b_or, b_od = b_or;
-    const size_t o_oc = o_od + b_od, b_oc = (size_t)nq * 8;
-    int rc = dev_alloc(b, o_oc + b_oc);
+    const size_t o_oc = o_od + b_od, b_oc = al((size_t)nq * 8);
+    const size_t o_sc = o_oc + b_oc, b_sc = al((size_t)nq * ix->nlist * 4);
+    int rc = smt::ensure_scratch(ctx, o_sc + b_sc);
     if (rc) return rc;
-    char *base = b.as<char>();
+    char *base = reinterpret_cast<char *>(ctx->d_scratch);
     float *d_q = reinterpret_cast<float *>(base + o_q);
-    IVF_HIP(hipMemcpyAsync(d_q, queries, b_q, hipMemcpyHostToDevice, ctx->stream));
+    IVF_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * 256 * 4, hipMemcpyHostToDevice, ctx->stream));
 
+    static bool score_attr = false;
+    if (!score_attr) {
+        IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        score_attr = true;
+    }
     ProbeParams pp;
     pp.queries = d_q;
     pp.centroids = ix->d_centroids;
@@ -758,8 +820,11 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     pp.nprobe = nprobe;
     pp.probe_list = reinterpret_cast<uint32_t *>(base + o_pl);
     pp.probe_dot = reinterpret_cast<float *>(base + o_pd);
+    float *d_scores = reinterpret_cast<float *>(base + o_sc);
     prof_begin(ctx, "ivf_probe");
-    hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(PROBE_THREADS), 0, ctx->stream, pp);
+    hipLaunchKernelGGL(ivf_score_kernel, dim3(ix->nlist / QT_ROWS), dim3(GEMM_THREADS), (size_t)QT_F4 * 16 + 64, ctx->stream, d_q, nq,
+                       ix->d_centroids, ix->d_cnorm_half, ix->nlist, d_scores);
+    hipLaunchKernelGGL(ivf_probe_select_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, pp, d_scores, nq);
     hipLaunchKernelGGL(ivf_lut_kernel, dim3(nq, PQ_M), dim3(PQ_K), 0, ctx->stream, d_q, ix->d_codebooks, reinterpret_cast<float *>(base + o_lut));
     prof_end(ctx, "ivf_probe");
     AdcParams ap;
@@ -786,12 +851,13 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     rc = launch_select(ctx, ix->corpus->d_rows, d_q, nq, ap.lists, nprobe, kp, (uint64_t)nprobe * kp, top_k, 0, 0.f, row_base, d_or, d_od,
                        d_oc);
     if (rc) return rc;
-    std::vector<uint64_t> h_rows((size_t)nq * top_k), h_cnt(nq);
-    std::vector<double> h_dist((size_t)nq * top_k);
-    IVF_HIP(hipMemcpyAsync(h_rows.data(), d_or, b_or, hipMemcpyDeviceToHost, ctx->stream));
-    IVF_HIP(hipMemcpyAsync(h_dist.data(), d_od, b_od, hipMemcpyDeviceToHost, ctx->stream));
-    IVF_HIP(hipMemcpyAsync(h_cnt.data(), d_oc, b_oc, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t out_bytes = b_or + b_od + (size_t)nq * 8;
+    if ((rc = smt::ensure_pinned(ctx, out_bytes))) return rc;
+    IVF_HIP(hipMemcpyAsync(ctx->h_pinned, d_or, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     IVF_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
+    const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + b_or);
+    const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(ctx->h_pinned) + b_or + b_od);
     bool truncated = false;
     for (uint32_t q = 0; q < nq; ++q) {
         out_counts[q] = h_cnt[q];
