@@ -215,6 +215,11 @@ void smt_ivfpq_destroy(smt_ivfpq *index);
 int smt_ivfpq_search(smt_ivfpq *index, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe,
                      uint32_t rerank, uint64_t row_base, uint64_t *out_rows, double *out_dist,
                      uint64_t *out_counts, uint64_t out_cap);
+/* Device-resident form: queries [nq x 256] f32 and the outputs [nq x top_k] (rows u64, padded with
+ * UINT64_MAX; exact f64 distances, padded with +inf) live in device (or pinned host) memory; enqueued on
+ * the context's stream, complete after smt_ctx_synchronize. */
+int smt_ivfpq_search_device(smt_ivfpq *index, const float *queries_dev, uint32_t nq, uint32_t top_k, uint32_t nprobe,
+                            uint32_t rerank, uint64_t row_base, uint64_t *out_rows_dev, double *out_dist_dev);
 /* build_ms4 = {coarse k-means, assign all rows, PQ training, sort + encode} */
 int smt_ivfpq_info(const smt_ivfpq *index, uint64_t *n_rows, uint32_t *nlist, uint64_t *index_bytes,
                    double *build_ms4);

@@ -271,6 +271,12 @@ class IvfPq:
         return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
 
 
+    def search_device(self, queries_ptr, nq, top_k, nprobe, rerank, row_base, out_rows_ptr, out_dist_ptr):
+        """Device-resident form (raw pointers; asynchronous on the context's stream)."""
+        L.check(L.lib().smt_ivfpq_search_device(self._h, C.c_void_p(queries_ptr), int(nq), int(top_k), int(nprobe), int(rerank),
+                                                int(row_base), C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
+
+
 def merge_topk(rows, dist, k_out):
     """Host merge of per-shard sorted top-k lists laid out [n_lists][nq][k_in]."""
     rows = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -769,17 +769,14 @@ int smt_ivfpq_list_sizes(const smt_ivfpq *ix, uint64_t *sizes_host)
     return SMT_OK;
 }
 
-int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
-                     uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
+// Shared by the host and the device entry points.  queries: host pointer (queries_on_device = false, staged into
+// the scratch) or device pointer; the k best (row, exact distance) pairs and the counts are written to the DEVICE
+// buffers d_or [nq][top_k], d_od [nq][top_k], d_oc [nq] (d_oc may be null).
+static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_on_device, uint32_t nq, uint32_t top_k, uint32_t nprobe,
+                             uint32_t rerank, uint64_t row_base, uint64_t *d_or_user, double *d_od_user, uint64_t *d_oc_user,
+                             uint64_t **d_or_out, size_t *out_bytes_contig)
 {
-    SMT_REQUIRE(ix != nullptr, "index");
-    SMT_REQUIRE(nq == 0 || (queries && out_rows && out_dist && out_counts), "null argument");
     smt_ctx *ctx = ix->corpus->ctx;
-    IVF_HIP(hipSetDevice(ctx->device));
-    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
-    if (nq == 0) return SMT_OK;
-    for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
-    if (top_k == 0) return SMT_OK;
     SMT_REQUIRE(ix->corpus->rows == ix->n_rows, "the corpus changed after the index was built");
     SMT_REQUIRE(nprobe >= 1 && nprobe <= ix->nlist && nprobe <= 512, "nprobe must be in [1, min(nlist, 512)]");
     SMT_REQUIRE(top_k <= 56, "top_k must be <= 56 for the IVF-PQ path");
@@ -804,8 +801,11 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     int rc = smt::ensure_scratch(ctx, o_sc + b_sc);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(ctx->d_scratch);
-    float *d_q = reinterpret_cast<float *>(base + o_q);
-    IVF_HIP(hipMemcpyAsync(d_q, queries, (size_t)nq * 256 * 4, hipMemcpyHostToDevice, ctx->stream));
+    const float *d_q = queries;
+    if (!queries_on_device) {
+        IVF_HIP(hipMemcpyAsync(base + o_q, queries, (size_t)nq * 256 * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_q = reinterpret_cast<const float *>(base + o_q);
+    }
 
     static bool score_attr = false;
     if (!score_attr) {
@@ -845,13 +845,33 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     else hipLaunchKernelGGL(ivf_adc_kernel<256>, dim3(nprobe, nq), dim3(256), 0, ctx->stream, ap);
     prof_end(ctx, "ivf_adc");
     IVF_HIP(hipGetLastError());
-    uint64_t *d_or = reinterpret_cast<uint64_t *>(base + o_or);
-    double *d_od = reinterpret_cast<double *>(base + o_od);
-    uint64_t *d_oc = reinterpret_cast<uint64_t *>(base + o_oc);
+    uint64_t *d_or = d_or_user ? d_or_user : reinterpret_cast<uint64_t *>(base + o_or);
+    double *d_od = d_od_user ? d_od_user : reinterpret_cast<double *>(base + o_od);
+    uint64_t *d_oc = d_or_user ? d_oc_user : reinterpret_cast<uint64_t *>(base + o_oc);
     rc = launch_select(ctx, ix->corpus->d_rows, d_q, nq, ap.lists, nprobe, kp, (uint64_t)nprobe * kp, top_k, 0, 0.f, row_base, d_or, d_od,
                        d_oc);
     if (rc) return rc;
-    const size_t out_bytes = b_or + b_od + (size_t)nq * 8;
+    if (d_or_out) *d_or_out = d_or;
+    if (out_bytes_contig) *out_bytes_contig = b_or + b_od + (size_t)nq * 8;
+    return SMT_OK;
+}
+
+int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
+                     uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
+{
+    SMT_REQUIRE(ix != nullptr, "index");
+    SMT_REQUIRE(nq == 0 || (queries && out_rows && out_dist && out_counts), "null argument");
+    smt_ctx *ctx = ix->corpus->ctx;
+    IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
+    if (nq == 0) return SMT_OK;
+    for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    if (top_k == 0) return SMT_OK;
+    uint64_t *d_or = nullptr;
+    size_t out_bytes = 0;
+    int rc = ivfpq_search_core(ix, queries, false, nq, top_k, nprobe, rerank, row_base, nullptr, nullptr, nullptr, &d_or, &out_bytes);
+    if (rc) return rc;
+    const size_t b_or = (size_t)nq * top_k * 8, b_od = b_or;
     if ((rc = smt::ensure_pinned(ctx, out_bytes))) return rc;
     IVF_HIP(hipMemcpyAsync(ctx->h_pinned, d_or, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     IVF_HIP(hipStreamSynchronize(ctx->stream));
@@ -870,6 +890,19 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     }
     if (truncated) { smt::set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
     return SMT_OK;
+}
+
+int smt_ivfpq_search_device(smt_ivfpq *ix, const float *queries_dev, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
+                            uint64_t row_base, uint64_t *out_rows_dev, double *out_dist_dev)
+{
+    SMT_REQUIRE(ix != nullptr, "index");
+    SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
+    SMT_REQUIRE(top_k >= 1, "top_k");
+    smt_ctx *ctx = ix->corpus->ctx;
+    IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
+    if (nq == 0) return SMT_OK;
+    return ivfpq_search_core(ix, queries_dev, true, nq, top_k, nprobe, rerank, row_base, out_rows_dev, out_dist_dev, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

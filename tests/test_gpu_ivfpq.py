@@ -140,3 +140,21 @@ def test_save_load_round_trip(index, gpu_ctx, tmp_path):
         smt.IvfPq.load(c, tmp_path / "magic.ivfpq")
     with pytest.raises(smt.SmtError):
         smt.IvfPq.load(c, tmp_path / "missing.ivfpq")
+
+
+def test_device_resident_search_equals_host_search(index):
+    import torch
+
+    x, c, ix = index
+    qs = x[[3, 1000, 20000, 59999]] + np.float32(0.001)
+    want = ix.search(qs, top_k=7, nprobe=8, row_base=12345)
+    qd = torch.from_numpy(np.ascontiguousarray(qs)).cuda()
+    rows = torch.empty((4, 7), dtype=torch.int64, device="cuda")
+    dist = torch.empty((4, 7), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ix.search_device(qd.data_ptr(), 4, 7, 8, 0, 12345, rows.data_ptr(), dist.data_ptr())
+    c.ctx.synchronize()
+    r = rows.cpu().numpy().view(np.uint64)
+    d = dist.cpu().numpy()
+    for i, (wr, wd) in enumerate(want):
+        assert r[i, : len(wr)].tolist() == wr.tolist() and np.array_equal(d[i, : len(wd)], wd)
