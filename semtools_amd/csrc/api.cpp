@@ -419,6 +419,7 @@ void smt_corpus_destroy(smt_corpus *corpus)
     if (!corpus) return;
     (void)hipSetDevice(corpus->ctx->device);
     (void)hipStreamSynchronize(corpus->ctx->stream);
+    (void)drain_async(corpus->ctx);  // an async select may still be rescoring rows of this corpus
     if (corpus->owned && corpus->d_rows) (void)hipFree(corpus->d_rows);
     delete corpus;
 }
