@@ -205,6 +205,11 @@ typedef struct smt_ivfpq_params {
     uint32_t nbits;        /* 8                                                           */
     uint32_t train_iters;  /* k-means iterations for both quantisers (0 = 10)            */
     uint64_t train_sample; /* training rows, evenly spaced (0 = 64 * nlist)              */
+    uint32_t refine;       /* 0 = off: 36 B/row index, every ADC candidate is re-scored;      */
+                           /* 1 = keep an int8 copy of the rows (+260 B/row) and prune the    */
+                           /* ADC shortlist with it before the full-precision re-score        */
+                           /* (same recall, ~6 % faster queries: measured, rarely worth it)   */
+    uint32_t reserved;     /* 0                                                           */
 } smt_ivfpq_params;
 int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *params, smt_ivfpq **out);
 void smt_ivfpq_destroy(smt_ivfpq *index);

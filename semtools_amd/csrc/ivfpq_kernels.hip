@@ -408,6 +408,24 @@ __global__ void ivf_lut_kernel(const float *queries, const float *codebooks, flo
     lut[((size_t)qi * PQ_M + s) * PQ_K + code] = acc;
 }
 
+// int8 copy of the rows in LIST order: x ~= scale * q, scale = max|x| / 127 (one wave per row)
+__global__ void quantize_rows_kernel(const float *rows, const uint32_t *ids, uint64_t n, uint8_t *out, float *scale)
+{
+    const uint64_t pos = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pos >= n) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4 v = reinterpret_cast<const f32x4 *>(rows + (uint64_t)ids[pos] * 256)[lane];
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float sc = m > 0.0f ? m / 127.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    const uint32_t b0 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.x * inv), b1 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.y * inv);
+    const uint32_t b2 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.z * inv), b3 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.w * inv);
+    reinterpret_cast<uint32_t *>(out + pos * 256)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    if (lane == 0) scale[pos] = sc;
+}
+
 // ------------------------------------------------------------------ query: ADC scan
 struct AdcParams {
     const float *queries;
@@ -419,6 +437,9 @@ struct AdcParams {
     const uint8_t *codes;      // [N][32] in list order
     const uint32_t *ids;       // [N] corpus row of each code
     const float *corpus;       // full-precision rows for the in-kernel re-score
+    const uint8_t *i8;         // [N][256] int8 rows in LIST order (same index as codes), or nullptr
+    const float *i8_scale;     // [N] row = scale * int8
+    uint32_t refine_keep;      // per wave: ADC shortlist -> this many by the int8 dot product -> full-precision re-score
     uint32_t shortlist;        // ADC candidates kept per WAVE (<= 64); 4 or 8 waves per (query, list)
     uint32_t kp;               // re-scored candidates emitted per (query, list)  (<= 64)
     key_t64 *lists;            // [nq][nprobe][kp]
@@ -482,7 +503,7 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
                 acc += s_lut[(4 * u + 3) * PQ_K + (w[u] >> 24)];
             }
             d = fmaxf(1.0f - acc * rq, 0.0f);  // rows are unit-norm (model2vec output), zero rows score ~0
-            row = p.ids[i];
+            row = (uint32_t)i;                  // position in list order (codes / ids / int8 rows share it)
         }
         unsigned long long pass = __ballot(d < thr_d || (d == thr_d && row < thr_r));
         while (pass) {  // rare after warm-up
@@ -492,27 +513,68 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         }
     }
 
-    // ---- stage 2: re-score the shortlist with the full-precision rows (coalesced 1 KiB loads, f32),
-    //      keep the kp best; the select stage then recomputes those exactly in f64
+    // ---- stage 1.5 (opt-in, smt_ivfpq_params.refine): int8 refinement.  A full-precision re-score reads 1 KiB per
+    // candidate; the int8 copy of a row is 256 B and ranks the shortlist well enough (same recall) that only
+    // `refine_keep` candidates per wave go on to stage 2.  Measured: the kernel is bound by the shortlist
+    // maintenance of stage 1, not by the re-score reads -- 8x fewer full-precision reads buy 6 % (0.875 -> 0.82 ms
+    // per 1000 queries), which does not pay for 260 B/row of index, hence off by default.
     const int n_short = __popcll(__ballot(lane < ks && lr != 0xFFFFFFFFu));
+    unsigned long long go = n_short >= 64 ? ~0ull : ((1ull << n_short) - 1ull);  // lanes whose candidate is re-scored
+    if (p.i8 != nullptr && n_short > (int)p.refine_keep) {
+        float rd = __builtin_inff();  // lane i: refined distance of shortlist entry i
+        for (int i0 = 0; i0 < n_short; i0 += 4) {
+            uint32_t w[4];
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u < n_short ? i0 + u : n_short - 1;
+                const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)lr, i);
+                w[u] = reinterpret_cast<const uint32_t *>(p.i8 + (uint64_t)pos * 256)[lane];  // 256 B per row, coalesced
+                sc[u] = p.i8_scale[pos];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x0 = (float)(int8_t)(w[u] & 0xFF), x1 = (float)(int8_t)((w[u] >> 8) & 0xFF);
+                const float x2 = (float)(int8_t)((w[u] >> 16) & 0xFF), x3 = (float)(int8_t)(w[u] >> 24);
+                const float dot = wave_sum(x0 * qv.x + x1 * qv.y + x2 * qv.z + x3 * qv.w) * sc[u];
+                if (lane == i0 + u) rd = fmaxf(1.0f - dot * rq, 0.0f);
+            }
+        }
+        // rank of my candidate among the wave's (refined distance, position): keep the refine_keep best
+        const unsigned long long mykey = ((unsigned long long)__float_as_uint(rd) << 32) | lr;
+        int rank = 0;
+        for (int i = 0; i < n_short; ++i) {
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), i);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mykey, i);
+            rank += ((((unsigned long long)hi << 32) | lo) < mykey) ? 1 : 0;
+        }
+        go = __ballot(lane < n_short && rank < (int)p.refine_keep);
+    }
+
+    // ---- stage 2: re-score the survivors with the full-precision rows (coalesced 1 KiB loads, f32),
+    //      keep the kp best; the select stage then recomputes those exactly in f64
+    const uint32_t my_row = (lane < n_short && ((go >> lane) & 1ull)) ? p.ids[lr] : 0xFFFFFFFFu;  // one gather, before the loop
     float ld2 = __builtin_inff();
     uint32_t lr2 = 0xFFFFFFFFu;
     float thr2_d = __builtin_inff();
     uint32_t thr2_r = 0xFFFFFFFFu;
-    for (int i0 = 0; i0 < n_short; i0 += 4) {
+    while (go) {
         f32x4 c[4];
         uint32_t rr[4];
+        bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u < n_short ? i0 + u : n_short - 1;
-            rr[u] = (uint32_t)__builtin_amdgcn_readlane((int)lr, i);
-            c[u] = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)rr[u] * 256)[lane];
+            ok[u] = go != 0ull;
+            const int src = ok[u] ? __ffsll((long long)go) - 1 : 0;
+            if (ok[u]) go &= go - 1;
+            rr[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_row, src);
+            c[u] = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)(ok[u] ? rr[u] : 0u) * 256)[lane];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float b2 = wave_sum(c[u].x * c[u].x + c[u].y * c[u].y + c[u].z * c[u].z + c[u].w * c[u].w);
             const float ab = wave_sum(c[u].x * qv.x + c[u].y * qv.y + c[u].z * qv.z + c[u].w * qv.w);
-            if (i0 + u < n_short) insert(dist_f32(ab, b2, rq, qz), rr[u], ld2, lr2, thr2_d, thr2_r, kp);
+            if (ok[u]) insert(dist_f32(ab, b2, rq, qz), rr[u], ld2, lr2, thr2_d, thr2_r, kp);
         }
     }
 
@@ -545,6 +607,8 @@ struct smt_ivfpq {
     uint8_t *d_codes = nullptr;     // [N][32] list order
     uint32_t *d_ids = nullptr;      // [N]
     uint64_t *d_offsets = nullptr;  // [nlist+1]
+    uint8_t *d_i8 = nullptr;        // [N][256] int8 rows, list order (refinement stage; nullptr = off)
+    float *d_i8_scale = nullptr;    // [N]
     double build_ms[4] = {0, 0, 0, 0};  // coarse train, assign all, pq train, encode+lists
 };
 
@@ -621,7 +685,7 @@ void smt_ivfpq_destroy(smt_ivfpq *ix)
     if (!ix) return;
     if (ix->corpus) { (void)hipSetDevice(ix->corpus->ctx->device); (void)hipStreamSynchronize(ix->corpus->ctx->stream); }
     for (void *p : {(void *)ix->d_centroids, (void *)ix->d_cnorm_half, (void *)ix->d_codebooks, (void *)ix->d_codes, (void *)ix->d_ids,
-                    (void *)ix->d_offsets})
+                    (void *)ix->d_offsets, (void *)ix->d_i8, (void *)ix->d_i8_scale})
         if (p) (void)hipFree(p);
     delete ix;
 }
@@ -735,6 +799,12 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
                            PQ_SMEM, ctx->stream, q);
     }
     hipLaunchKernelGGL(cnorm_half_kernel, dim3((nlist + 3) / 4), dim3(256), 0, ctx->stream, ix->d_centroids, nlist, ix->d_cnorm_half);
+    if (prm->refine == 1) {  // opt-in: keep an int8 copy of the rows (256 B + 4 B per row) for the refinement stage
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), (size_t)N * 256));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), (size_t)N * 4));
+        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
+                           N, ix->d_i8, ix->d_i8_scale);
+    }
     IVF_HIP(hipEventRecord(ev[4], ctx->stream));
     IVF_HIP(hipGetLastError());
     IVF_HIP(hipStreamSynchronize(ctx->stream));
@@ -754,7 +824,7 @@ int smt_ivfpq_info(const smt_ivfpq *ix, uint64_t *n_rows, uint32_t *nlist, uint6
     if (nlist) *nlist = ix->nlist;
     if (index_bytes)
         *index_bytes = (uint64_t)ix->n_rows * (PQ_M + 4) + (uint64_t)ix->nlist * 256 * 4 + (uint64_t)PQ_M * PQ_K * PQ_DSUB * 4 +
-                       (uint64_t)(ix->nlist + 1) * 8;
+                       (uint64_t)(ix->nlist + 1) * 8 + (ix->d_i8 ? (uint64_t)ix->n_rows * 260 : 0);
     if (build_ms4) for (int i = 0; i < 4; ++i) build_ms4[i] = ix->build_ms[i];
     return SMT_OK;
 }
@@ -837,6 +907,9 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     ap.codes = ix->d_codes;
     ap.ids = ix->d_ids;
     ap.corpus = ix->corpus->d_rows;
+    ap.i8 = ix->d_i8;
+    ap.i8_scale = ix->d_i8_scale;
+    ap.refine_keep = std::max<uint32_t>(8u, (kp + adc_waves - 1) / adc_waves);
     ap.shortlist = shortlist;
     ap.kp = kp;
     ap.lists = reinterpret_cast<key_t64 *>(base + o_lists);
@@ -966,6 +1039,7 @@ int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
     h.nbits = 8;
     h.dim = 256;
     h.n_rows = ix->n_rows;
+    h.pad[0] = ix->d_i8 ? 1 : 0;  // 1 = built with the int8 refinement copy (never stored: load re-derives it from the corpus)
     std::vector<char> buf;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     ok = ok && write_dev(f, ix->d_centroids, (size_t)ix->nlist * 256 * 4, ctx->stream, buf);
@@ -1030,6 +1104,14 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     bool sane = offs[0] == 0 && offs[h.nlist] == h.n_rows;
     for (uint32_t l = 0; sane && l < h.nlist; ++l) sane = offs[l] <= offs[l + 1];
     if (!sane) { smt::set_error("'%s': corrupt list offsets", path); return SMT_E_IO; }
+    if (h.pad[0] == 1 && N > 0) {  // the int8 refinement copy is a function of (corpus, ids): re-derive it
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), N * 256));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), N * 4));
+        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
+                           (uint64_t)N, ix->d_i8, ix->d_i8_scale);
+        IVF_HIP(hipGetLastError());
+        IVF_HIP(hipStreamSynchronize(ctx->stream));
+    }
     *out = guard.release();
     return SMT_OK;
 }
