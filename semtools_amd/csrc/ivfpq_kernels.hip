@@ -481,36 +481,89 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         }
     };
 
-    // ---- stage 1: ADC scan of the list's codes -> the wave's `ks` best approximate candidates
-    float ld = __builtin_inff();
+    // ---- stage 1: ADC scan of the list's codes -> the wave's `ks` best approximate candidates (an unordered SET:
+    // lane i < n_short ends up holding one of them in (ld, lr)).  A wave takes 64 x ADC_R codes per pass, keeps
+    // their ADC distances in registers next to the set carried over from the previous pass, finds the ks-th
+    // smallest by bisection on the distance bits (ballot-free: per-lane counts + one DPP sum per step) and
+    // compacts the winners through LDS.  (The first version inserted candidates one at a time into a sorted
+    // lane-distributed list: ~160 serial inserts per wave at ks = 64 -- that, not the re-score reads, was what
+    // bounded this kernel.)
+    constexpr int ADC_R = 8;
+    float ld = __builtin_inff();       // carried set: lane i < n_carry holds a real entry
     uint32_t lr = 0xFFFFFFFFu;
-    float thr_d = __builtin_inff();
-    uint32_t thr_r = 0xFFFFFFFFu;
-    for (uint64_t i0 = begin + (uint64_t)wave * 64; i0 < end; i0 += ADC_THREADS) {
-        const uint64_t i = i0 + lane;
-        float d = __builtin_inff();
-        uint32_t row = 0xFFFFFFFFu;
-        if (i < end) {
-            const uint4 c0 = reinterpret_cast<const uint4 *>(p.codes + i * PQ_M)[0];
-            const uint4 c1 = reinterpret_cast<const uint4 *>(p.codes + i * PQ_M)[1];
-            const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            float acc = base;
+    key_t64 *s_short = s_keys + wave * 64;  // per-wave compaction scratch (s_keys is reused by the block merge later)
+    // (64-code groups are dealt to the waves round-robin, so every wave sees codes from the whole list: lists are in
+    // row order and neighbours cluster -- contiguous 512-code chunks per wave cost a point of recall)
+    for (uint64_t base_i = begin; base_i < end; base_i += (uint64_t)(ADC_THREADS / 64) * 64 * ADC_R) {
+        uint32_t kd[ADC_R + 1], kpos[ADC_R + 1];  // orderable distance bits (0xFFFFFFFF = empty) and list positions
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                acc += s_lut[(4 * u + 0) * PQ_K + (w[u] & 0xFF)];
-                acc += s_lut[(4 * u + 1) * PQ_K + ((w[u] >> 8) & 0xFF)];
-                acc += s_lut[(4 * u + 2) * PQ_K + ((w[u] >> 16) & 0xFF)];
-                acc += s_lut[(4 * u + 3) * PQ_K + (w[u] >> 24)];
+        for (int r = 0; r < ADC_R; ++r) {
+            const uint64_t i = base_i + ((uint64_t)r * (ADC_THREADS / 64) + wave) * 64 + lane;
+            kd[r] = 0xFFFFFFFFu;
+            kpos[r] = 0xFFFFFFFFu;
+            if (i < end) {
+                const uint4 c0 = reinterpret_cast<const uint4 *>(p.codes + i * PQ_M)[0];
+                const uint4 c1 = reinterpret_cast<const uint4 *>(p.codes + i * PQ_M)[1];
+                const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                float acc = base;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc += s_lut[(4 * u + 0) * PQ_K + (w[u] & 0xFF)];
+                    acc += s_lut[(4 * u + 1) * PQ_K + ((w[u] >> 8) & 0xFF)];
+                    acc += s_lut[(4 * u + 2) * PQ_K + ((w[u] >> 16) & 0xFF)];
+                    acc += s_lut[(4 * u + 3) * PQ_K + (w[u] >> 24)];
+                }
+                const float d = fmaxf(1.0f - acc * rq, 0.0f);  // rows are unit-norm (model2vec output), zero rows score ~0
+                if (acc == acc) {                                // a NaN score never becomes a candidate
+                    kd[r] = min(__float_as_uint(d), 0xFFFFFFFEu);  // d >= 0: the bit pattern orders like the value
+                    kpos[r] = (uint32_t)i;                         // position in list order (codes / ids / int8 rows share it)
+                }
             }
-            d = fmaxf(1.0f - acc * rq, 0.0f);  // rows are unit-norm (model2vec output), zero rows score ~0
-            row = (uint32_t)i;                  // position in list order (codes / ids / int8 rows share it)
         }
-        unsigned long long pass = __ballot(d < thr_d || (d == thr_d && row < thr_r));
-        while (pass) {  // rare after warm-up
-            const int src = __ffsll((long long)pass) - 1;
-            pass &= pass - 1;
-            insert(readlane_f(d, src), (uint32_t)__builtin_amdgcn_readlane((int)row, src), ld, lr, thr_d, thr_r, ks);
+        kd[ADC_R] = lr != 0xFFFFFFFFu ? __float_as_uint(ld) : 0xFFFFFFFFu;
+        kpos[ADC_R] = lr;
+        uint32_t total = 0;
+#pragma unroll
+        for (int r = 0; r <= ADC_R; ++r) total += kd[r] != 0xFFFFFFFFu ? 1u : 0u;
+        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(total));
+        uint32_t T = 0xFFFFFFFEu, need_eq = 0xFFFFFFFFu;  // winners: kd < T, plus the first need_eq entries with kd == T
+        if (total > (uint32_t)ks) {
+            uint32_t lo = 0u, hi = 0xFFFFFFFEu;           // smallest T with #(kd <= T) >= ks
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int r = 0; r <= ADC_R; ++r) cnt += kd[r] <= mid ? 1u : 0u;
+                cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(cnt));
+                if (cnt >= (uint32_t)ks) hi = mid; else lo = mid + 1u;
+            }
+            T = lo;
+            uint32_t n_lt = 0;
+#pragma unroll
+            for (int r = 0; r <= ADC_R; ++r) n_lt += kd[r] < T ? 1u : 0u;
+            n_lt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(n_lt));
+            need_eq = (uint32_t)ks - n_lt;
         }
+        // compaction: winners take consecutive LDS slots, then lane i reads slot i
+        uint32_t n_out = 0, n_eq_seen = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int r = 0; r <= ADC_R; ++r) {
+            const bool valid = kd[r] != 0xFFFFFFFFu;
+            const bool lt = valid && kd[r] < T;
+            const bool eq = valid && kd[r] == T;
+            const unsigned long long m_eq = __ballot(eq);
+            const bool eq_win = eq && (n_eq_seen + (uint32_t)__popcll(m_eq & below)) < need_eq;
+            const unsigned long long m_win = __ballot(lt || eq_win);
+            if (lt || eq_win) s_short[n_out + (uint32_t)__popcll(m_win & below)] = ((key_t64)kd[r] << 32) | kpos[r];
+            n_out += (uint32_t)__popcll(m_win);
+            n_eq_seen += (uint32_t)__popcll(m_eq);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const key_t64 mine = (uint32_t)lane < n_out ? reinterpret_cast<volatile key_t64 *>(s_short)[lane] : KEY_PAD;
+        __builtin_amdgcn_wave_barrier();
+        ld = mine != KEY_PAD ? __uint_as_float((uint32_t)(mine >> 32)) : __builtin_inff();
+        lr = mine != KEY_PAD ? (uint32_t)(mine & 0xFFFFFFFFull) : 0xFFFFFFFFu;
     }
 
     // ---- stage 1.5 (opt-in, smt_ivfpq_params.refine): int8 refinement.  A full-precision re-score reads 1 KiB per
@@ -518,7 +571,7 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
     // `refine_keep` candidates per wave go on to stage 2.  Measured: the kernel is bound by the shortlist
     // maintenance of stage 1, not by the re-score reads -- 8x fewer full-precision reads buy 6 % (0.875 -> 0.82 ms
     // per 1000 queries), which does not pay for 260 B/row of index, hence off by default.
-    const int n_short = __popcll(__ballot(lane < ks && lr != 0xFFFFFFFFu));
+    const int n_short = __popcll(__ballot(lr != 0xFFFFFFFFu));  // the set sits in lanes 0..n_short-1
     unsigned long long go = n_short >= 64 ? ~0ull : ((1ull << n_short) - 1ull);  // lanes whose candidate is re-scored
     if (p.i8 != nullptr && n_short > (int)p.refine_keep) {
         float rd = __builtin_inff();  // lane i: refined distance of shortlist entry i
