@@ -520,15 +520,19 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
                 }
             }
         }
-        kd[ADC_R] = lr != 0xFFFFFFFFu ? __float_as_uint(ld) : 0xFFFFFFFFu;
+        kd[ADC_R] = lr != 0xFFFFFFFFu ? __float_as_uint(ld) : 0xFFFFFFFFu;  // (ld keeps only the top 16 bits: enough here)
         kpos[ADC_R] = lr;
         uint32_t total = 0;
 #pragma unroll
         for (int r = 0; r <= ADC_R; ++r) total += kd[r] != 0xFFFFFFFFu ? 1u : 0u;
         total = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(total));
+        // The ADC distance is itself an approximation (error ~1e-2): its top 16 bits (relative step 2^-8 of the value)
+        // are all the selection needs, which halves the bisection; ties in that bucket go by scan order.
+#pragma unroll
+        for (int r = 0; r <= ADC_R; ++r) kd[r] = kd[r] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (kd[r] >> 16);
         uint32_t T = 0xFFFFFFFEu, need_eq = 0xFFFFFFFFu;  // winners: kd < T, plus the first need_eq entries with kd == T
         if (total > (uint32_t)ks) {
-            uint32_t lo = 0u, hi = 0xFFFFFFFEu;           // smallest T with #(kd <= T) >= ks
+            uint32_t lo = 0u, hi = 0xFFFFu;               // smallest T with #(kd <= T) >= ks
             while (lo < hi) {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
                 uint32_t cnt = 0;
@@ -562,7 +566,7 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         __builtin_amdgcn_wave_barrier();
         const key_t64 mine = (uint32_t)lane < n_out ? reinterpret_cast<volatile key_t64 *>(s_short)[lane] : KEY_PAD;
         __builtin_amdgcn_wave_barrier();
-        ld = mine != KEY_PAD ? __uint_as_float((uint32_t)(mine >> 32)) : __builtin_inff();
+        ld = mine != KEY_PAD ? __uint_as_float((uint32_t)(mine >> 32) << 16) : __builtin_inff();
         lr = mine != KEY_PAD ? (uint32_t)(mine & 0xFFFFFFFFull) : 0xFFFFFFFFu;
     }
 
