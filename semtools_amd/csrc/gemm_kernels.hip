@@ -10,14 +10,16 @@
 // Decomposition (corpus-stationary):
 //   * a wave owns one ROW TILE = 32 corpus rows and keeps it in REGISTERS for the
 //     whole sweep over the queries (128 VGPRs: 32 rows x 256 dims / 64 lanes);
-//   * the queries stream through LDS in QUERY TILES of 32 (32 KiB, double
-//     buffered, shared by the block's 8 waves; resident when nq <= 64);
+//   * the queries stream through LDS in QUERY TILES of 32 (32.5 KiB each): four slots hold the PAIR of tiles
+//     being multiplied and the pair being fetched (LDS-DMA loads), one barrier per pair, shared by the
+//     block's 8 waves; resident when a block sweeps <= 4 tiles;
 //   * per (row tile, query tile): 128 MFMAs (K = 256 in steps of 2) accumulate
 //     a 32x32 block in 16 accumulator VGPRs.  A = corpus rows, B = queries, so
 //     each LANE owns one query (column) and 16 rows: the candidate test is
-//     lane-local -- scale by 1/|c_row|, turn into a distance, compare with the
-//     query's current threshold tau, and (rarely) append (distance,row) to the
-//     query's candidate buffer with one atomic slot grab.
+//     lane-local -- the row tile was scaled by 1/|c_row| when it was loaded, so
+//     the test is one compare of the accumulator with the query's score bound
+//     (1 - tau) * |q|; on a (rare) hit (distance,row) goes to the query's
+//     candidate buffer with one atomic slot grab.
 //   * K order: lane l < 32 feeds dims 8m..8m+3 and lane l >= 32 dims 8m+4..8m+7 of
 //     instruction group m (one 16-B load per 4 MFMAs for either operand).  The
 //     same permutation is applied to A and B, so the dot product is unchanged.
