@@ -15,11 +15,13 @@
 //     codebooks staged in LDS as [code][subspace][8] (conflict-free for lanes = subspaces);
 //   inverted lists: rocPRIM radix sort of (list id, row), codes written in list order (32 B/row).
 // Query:
-//   probe: 2 q.c - |c|^2 for all centroids, top-nprobe per query (LDS bitonic sort of 4096 keys);
+//   probe: 0.5|c|^2 - q.c for all (query, centroid) pairs on the MFMA pipe, then one wave per query selects the
+//     nprobe smallest of its 4096 scores held in registers (bisection on the orderable bit pattern);
 //   LUT[s][code] = <q_s, codebook[s][code]> (inner product: rows are unit-norm, so the ADC score
 //     q.c_list + sum_s LUT[s][code_s] approximates cos(q, x)); 32 KiB per query, LDS resident;
-//   ADC scan: one block per (query, probed list) streams 32-B codes (HBM-bound: nprobe/nlist * N * 32 B
-//     per query), 32 LDS lookups per row, per-wave candidate lists as in K2;
+//   ADC scan: one block per (query, probed list) streams 32-B codes (nprobe/nlist * N * 32 B per query),
+//     32 LDS lookups per row; each wave keeps its best candidates by threshold selection in registers,
+//     (optionally prunes them with an int8 copy of the rows,) and re-scores them against the full-precision rows;
 //   select: the K2 select stage merges the per-list candidate lists and rescoring is EXACT.
 #include <rocprim/device/device_radix_sort.hpp>
 

@@ -1,6 +1,8 @@
-// scan_kernels.hip -- K2 (single/few-query cosine scan + per-wave top-k'),
-// K4 (threshold compaction), the merge + f64 rescoring stage, and the
-// cross-shard top-k merge.  gfx950 only (wave64, DPP, 16 B/lane row loads).
+// scan_kernels.hip -- K2 (single/few-query cosine scan + per-wave top-k'), the
+// chunk table of range-filtered scans, the select stage (merge + exact f64
+// rescoring, optionally overlapped with the next scan: async select), and the
+// cross-shard top-k merge.  K4 (threshold mode) lives in threshold.hip.
+// gfx950 only (wave64, DPP, 16 B/lane row loads).
 //
 // Replaces the `for doc / for line: f32::cosine(q, e)` loop and the
 // sort/take of search_documents (reference src/search/mod.rs:84-119) and the
