@@ -87,7 +87,11 @@ std::vector<float> read_safetensors_embeddings(const std::string &path, uint64_t
             else bits = (s << 31) | ((e - 15 + 127) << 23) | (m << 13);
             memcpy(&out[i], &bits, 4);
         }
-    } else throw Error("unsupported embeddings dtype " + dtype);
+    } else if (dtype == "I8") {  // model2vec-rs converts each byte `as i8 as f32` (no scale)
+        std::vector<int8_t> raw(out.size());
+        f.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)raw.size());
+        for (size_t i = 0; i < raw.size(); ++i) out[i] = (float)raw[i];
+    } else throw Error("unsupported embeddings dtype " + dtype + " (F32, F16, I8)");
     if (!f) throw Error("truncated safetensors file " + path);
     return out;
 }

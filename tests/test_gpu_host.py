@@ -311,3 +311,30 @@ def test_real_hf_tokenizer_json_plugs_into_the_host_layer(gpu_ctx, tmp_path):
     out = host.search_files(m, corpus_lines[7], [str(f)], n_lines=0, top_k=1)
     assert out.startswith(f"{f}:7::8 (") and float(out.split("(")[1].split(")")[0]) < 1e-9
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["float16", "int8"])
+def test_model_tables_stored_as_f16_or_i8_are_widened_like_model2vec(gpu_ctx, tmp_path, dtype):
+    """StaticModel::from_pretrained accepts F32 / F16 / I8 `embeddings` and widens to f32 (SURVEY A1): the
+    embeddings must equal the oracle's on the widened table, bit for bit."""
+    from safetensors.numpy import save_file
+    from semtools_amd import host
+
+    small_v = 500
+    table = synth.table(small_v, seed=5)
+    stored = table.astype(np.float16) if dtype == "float16" else np.clip(np.rint(table * 400), -127, 127).astype(np.int8)
+    d = tmp_path / "m"
+    d.mkdir()
+    save_file({"embeddings": stored}, str(d / "model.safetensors"))
+    (d / "vocab.txt").write_text("".join(f"w{i}\n" for i in range(small_v - 1)) + "[UNK]\n")
+    (d / "config.json").write_text(json.dumps({"normalize": True, "unk_token": "[UNK]"}))
+    m = host.StaticModel(gpu_ctx, model_dir=d)
+    lines = ["w1 w2 w3 w499 w77", "w5", "", "w400 w401 nothing w3"]
+    got = m.encode_with_args(lines, 2048)
+    ids, offsets = [], [0]
+    for ln in lines:
+        ids += [int(w[1:]) for w in ln.split() if w.startswith("w") and w[1:].isdigit() and int(w[1:]) < small_v - 1]
+        offsets.append(len(ids))
+    want = orc.embed_lines(stored.astype(np.float32), np.array(ids, np.uint32), np.array(offsets, np.uint64), True, 2048)
+    assert np.array_equal(np.asarray(got, np.float32).view(np.uint32), want.view(np.uint32))
+    m.close()
