@@ -61,6 +61,7 @@ def main():
                          "HBM load after idle run up to 25 %% slower (clock / power ramp, see DESIGN.md section 8)")
     ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows per GPU (c2: 1M)")
     ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--corpus-copies", type=int, default=2, help="distinct shards of --rows rows scanned in rotation")
     ap.add_argument("--event-every", type=int, default=8,
                     help="HIP events bracket every N-th K2 launch of the timed region (1 = every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +91,10 @@ def main():
 
     k = args.top_k
     rows = args.rows
-    shard = make_shard(rows, seed=3 + rank, device=device)
+    # a 1 GB shard is 4x the 256 MiB Infinity Cache, but rotate >= 2 copies anyway so that no residue
+    # of the previous pass can flatter the HBM figure (measured effect: 149.3 us with one copy, 149.9 with two)
+    shards = [make_shard(rows, seed=3 + rank + 1000 * c, device=device) for c in range(max(1, args.corpus_copies))]
+    shard = shards[0]
     n_queries = 16
     gq = torch.Generator(device=device)
     gq.manual_seed(4)
@@ -106,7 +110,8 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(device))
     stream = torch.cuda.current_stream(device)
     ctx = smt.Context(local_rank, stream=stream.cuda_stream)
-    corpus = smt.Corpus(ctx, device_ptr=shard.data_ptr(), rows=rows)
+    corpora = [smt.Corpus(ctx, device_ptr=sh.data_ptr(), rows=rows) for sh in shards]
+    corpus = corpora[0]
     row_base = rank * rows
 
     # rows and distances of one query share one 2k x 8 B buffer: one D2H store per step
@@ -150,10 +155,10 @@ def main():
         q = queries[i % n_queries]
         if not exchange:
             slot = host[i % ring]  # pinned host memory is device-addressable: zero-copy result delivery
-            corpus.search_topk_device(q.data_ptr(), 1, k, row_base, slot[0].data_ptr(), slot[1].data_ptr())
+            corpora[i % len(corpora)].search_topk_device(q.data_ptr(), 1, k, row_base, slot[0].data_ptr(), slot[1].data_ptr())
             return
         s = i % depth
-        corpus.search_topk_device(q.data_ptr(), 1, k, row_base, locs[s][0:1].data_ptr(), locs[s][1:2].data_ptr())
+        corpora[i % len(corpora)].search_topk_device(q.data_ptr(), 1, k, row_base, locs[s][0:1].data_ptr(), locs[s][1:2].data_ptr())
         if aux is not None:
             with torch.cuda.stream(aux):
                 work = dist.all_gather_into_tensor(gath[s].view(world * 2, k), locs[s], async_op=True)
@@ -201,6 +206,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     n_scan, scan_ms = ctx.prof_read("scan")
+    got_rows = host_rows[(args.steps - 1) % ring].numpy().copy()   # the last timed step's answer (checked below)
+    got_dist = host_dist[(args.steps - 1) % ring].numpy().copy()
     ctx.set_tuning("prof_every", 1)
     flush()
     ctx.set_tuning("merge_on_aux", 0)
@@ -221,10 +228,9 @@ def main():
 
     # ---- sanity of the last step's result against an independent fp64 torch reference
     last = (args.steps - 1) % n_queries
+    shard = shards[(args.steps - 1) % len(shards)]   # the copy the last timed step scanned
     ref = 1.0 - (shard.double() @ queries[last].double())
     lv, li = torch.topk(ref, k, largest=False)
-    got_rows = host_rows[(args.steps - 1) % ring].numpy()
-    got_dist = host_dist[(args.steps - 1) % ring].numpy()
     if not exchange:
         torch_ok = bool(np.allclose(np.sort(got_dist), np.sort(lv.cpu().numpy()), rtol=0, atol=1e-6))
     else:
@@ -254,6 +260,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "c2: 1 query x 1M chunks (D=256, f32) per GPU, brute-force cosine + top-k",
                    "rows_per_gpu": rows, "dim": 256, "top_k": k, "queries_rotated": n_queries,
+                   "corpus_copies_rotated": len(shards),
                    "sharding": "row-sharded, all-gather top-k merge (pipelined one step deep)" if exchange else "single shard",
                    "select_stage": "overlapped with the next query's scan (aux stream)" if async_select else "in stream order"},
     }
