@@ -442,7 +442,9 @@ struct AdcParams {
     const uint8_t *i8;         // [N][256] int8 rows in LIST order (same index as codes), or nullptr
     const float *i8_scale;     // [N] row = scale * int8
     uint32_t refine_keep;      // per wave: ADC shortlist -> this many by the int8 dot product -> full-precision re-score
-    uint32_t shortlist;        // ADC candidates kept per WAVE (<= 64); 4 or 8 waves per (query, list)
+    uint32_t n_seg;            // blocks per (query, probed list): a list is cut into segments of seg_len codes, each
+    uint32_t seg_len;          //   with its own shortlist -- the re-scored fraction of a LONG list stays what it is for a short one
+    uint32_t shortlist;        // ADC candidates kept per WAVE (<= 64); 4 or 8 waves per (query, list segment)
     uint32_t kp;               // re-scored candidates emitted per (query, list)  (<= 64)
     key_t64 *lists;            // [nq][nprobe][kp]
 };
@@ -452,11 +454,21 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
 {
     __shared__ __attribute__((aligned(16))) float s_lut[PQ_M * PQ_K];  // 32 KiB
     __shared__ key_t64 s_keys[(ADC_THREADS / 64) * 64];
-    const uint32_t pi = blockIdx.x, qi = blockIdx.y;
+    const uint32_t pi = blockIdx.x / p.n_seg, seg = blockIdx.x % p.n_seg, qi = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kp = (int)p.kp;
     const int ks = (int)p.shortlist;
+    key_t64 *out = p.lists + ((size_t)qi * p.nprobe * p.n_seg + blockIdx.x) * kp;
+    {
+        // this block's segment of the probed list; most lists are shorter than n_seg segments: leave an empty list
+        const uint32_t l0 = p.probe_list[(size_t)qi * p.nprobe + pi];
+        const uint64_t b0 = p.list_offsets[l0], e0 = p.list_offsets[l0 + 1];
+        if (b0 + (uint64_t)seg * p.seg_len >= e0) {  // block-uniform
+            if ((int)threadIdx.x < kp) out[threadIdx.x] = KEY_PAD;
+            return;
+        }
+    }
 
     const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(p.lut + (size_t)qi * PQ_M * PQ_K);
     for (int e = threadIdx.x; e < PQ_M * PQ_K / 4; e += ADC_THREADS) reinterpret_cast<f32x4 *>(s_lut)[e] = lsrc[e];
@@ -466,7 +478,9 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
     const float rq = qz ? 0.0f : __frsqrt_rn(a2);
     const uint32_t list = p.probe_list[(size_t)qi * p.nprobe + pi];
     const float base = p.probe_dot[(size_t)qi * p.nprobe + pi];
-    const uint64_t begin = p.list_offsets[list], end = p.list_offsets[list + 1];
+    const uint64_t begin = p.list_offsets[list] + (uint64_t)seg * p.seg_len;
+    const uint64_t list_end = p.list_offsets[list + 1];
+    const uint64_t end = seg + 1 == p.n_seg ? list_end : min(list_end, begin + (uint64_t)p.seg_len);  // the last segment takes the rest
     __syncthreads();
 
     // wave-uniform insert of (cd, cr) into a lane-distributed sorted list of `cap` entries
@@ -639,7 +653,6 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
 
     // block merge of the wave lists (rank by counting), as in K2
     s_keys[wave * 64 + lane] = (lane < kp && lr2 != 0xFFFFFFFFu) ? make_key(ld2, lr2) : KEY_PAD;
-    key_t64 *out = p.lists + ((size_t)qi * p.nprobe + pi) * kp;
     if ((int)threadIdx.x < kp) out[threadIdx.x] = KEY_PAD;
     __syncthreads();
     const key_t64 mine = s_keys[wave * 64 + lane];
@@ -668,6 +681,7 @@ struct smt_ivfpq {
     uint64_t *d_offsets = nullptr;  // [nlist+1]
     uint8_t *d_i8 = nullptr;        // [N][256] int8 rows, list order (refinement stage; nullptr = off)
     float *d_i8_scale = nullptr;    // [N]
+    uint64_t max_list = 0;          // longest inverted list (segments per probed list at query time)
     double build_ms[4] = {0, 0, 0, 0};  // coarse train, assign all, pq train, encode+lists
 };
 
@@ -736,6 +750,15 @@ double ms_since(hipEvent_t a, hipEvent_t b)
 }
 
 }  // namespace
+
+static int compute_max_list(smt_ivfpq *ix)
+{
+    std::vector<uint64_t> off(ix->nlist + 1);
+    IVF_HIP(hipMemcpy(off.data(), ix->d_offsets, off.size() * 8, hipMemcpyDeviceToHost));
+    ix->max_list = 0;
+    for (uint32_t l = 0; l < ix->nlist; ++l) ix->max_list = std::max<uint64_t>(ix->max_list, off[l + 1] - off[l]);
+    return SMT_OK;
+}
 
 extern "C" {
 
@@ -872,6 +895,7 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     ix->build_ms[2] = ms_since(ev[1], ev[2]);
     ix->build_ms[3] = ms_since(ev[3], ev[4]);
     for (auto &e : ev) (void)hipEventDestroy(e);
+    if ((rc = compute_max_list(ix))) return rc;
     *out = guard.release();
     return SMT_OK;
 }
@@ -911,9 +935,20 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     SMT_REQUIRE(top_k <= 56, "top_k must be <= 56 for the IVF-PQ path");
     if (rerank == 0) rerank = 512;
     SMT_REQUIRE(rerank >= 4 && rerank <= 512, "rerank (full-precision re-scored ADC candidates per probed list) must be in [4, 512]");
-    const int adc_waves = rerank > 256 ? 8 : 4;   // waves per (query, list) block
+    const int adc_waves = rerank > 256 ? 8 : 4;   // waves per (query, list segment) block
     const uint32_t shortlist = (rerank + adc_waves - 1) / adc_waves;  // per wave
     const uint32_t kp = top_k + 8;                // re-scored candidates handed to the exact select stage
+    // A list longer than ADC_SEGMENT codes is scanned by several blocks, each with its own shortlist of `rerank`
+    // candidates (config 5's 100 M rows over 4096 lists: 24 k codes per list -- one shortlist of 512 would re-score
+    // 2 % of them and recall@10 drops to 0.75); the select stage takes at most 512 lists per query.
+    constexpr uint64_t ADC_SEGMENT = 8192;
+    // sized by the TYPICAL list (1.5 x the mean), not the longest: a block that finds its segment empty still costs a
+    // launch slot (+0.3 ms per 1000 queries when every list got a second, almost always empty, segment); the last
+    // segment of an unusually long list simply takes the rest
+    const uint64_t typical = (ix->n_rows / std::max<uint32_t>(ix->nlist, 1u)) * 3 / 2;
+    uint32_t n_seg = (uint32_t)std::max<uint64_t>(1, (typical + ADC_SEGMENT - 1) / ADC_SEGMENT);
+    n_seg = std::min<uint32_t>(n_seg, std::max<uint32_t>(1u, 512u / nprobe));
+    const uint32_t seg_len = (uint32_t)ADC_SEGMENT;
 
     // every temporary lives in the context's scratch (no hipMalloc/hipFree per call), results come back through
     // the pinned staging buffer
@@ -922,7 +957,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     const size_t o_pl = o_q + b_q, b_pl = al((size_t)nq * nprobe * 4);
     const size_t o_pd = o_pl + b_pl, b_pd = b_pl;
     const size_t o_lut = o_pd + b_pd, b_lut = al((size_t)nq * PQ_M * PQ_K * 4);
-    const size_t o_lists = o_lut + b_lut, b_lists = al((size_t)nq * nprobe * kp * 8);
+    const size_t o_lists = o_lut + b_lut, b_lists = al((size_t)nq * nprobe * n_seg * kp * 8);
     const size_t o_or = o_lists + b_lists, b_or = (size_t)nq * top_k * 8;   // rows | dist | counts contiguous: one D2H
     const size_t o_od = o_or + b_or, b_od = b_or;
     const size_t o_oc = o_od + b_od, b_oc = al((size_t)nq * 8);
@@ -969,19 +1004,21 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     ap.i8 = ix->d_i8;
     ap.i8_scale = ix->d_i8_scale;
     ap.refine_keep = std::max<uint32_t>(8u, (kp + adc_waves - 1) / adc_waves);
+    ap.n_seg = n_seg;
+    ap.seg_len = seg_len ? seg_len : 512;
     ap.shortlist = shortlist;
     ap.kp = kp;
     ap.lists = reinterpret_cast<key_t64 *>(base + o_lists);
     prof_begin(ctx, "ivf_adc");
-    if (adc_waves == 8) hipLaunchKernelGGL(ivf_adc_kernel<512>, dim3(nprobe, nq), dim3(512), 0, ctx->stream, ap);
-    else hipLaunchKernelGGL(ivf_adc_kernel<256>, dim3(nprobe, nq), dim3(256), 0, ctx->stream, ap);
+    if (adc_waves == 8) hipLaunchKernelGGL(ivf_adc_kernel<512>, dim3(nprobe * n_seg, nq), dim3(512), 0, ctx->stream, ap);
+    else hipLaunchKernelGGL(ivf_adc_kernel<256>, dim3(nprobe * n_seg, nq), dim3(256), 0, ctx->stream, ap);
     prof_end(ctx, "ivf_adc");
     IVF_HIP(hipGetLastError());
     uint64_t *d_or = d_or_user ? d_or_user : reinterpret_cast<uint64_t *>(base + o_or);
     double *d_od = d_od_user ? d_od_user : reinterpret_cast<double *>(base + o_od);
     uint64_t *d_oc = d_or_user ? d_oc_user : reinterpret_cast<uint64_t *>(base + o_oc);
-    rc = launch_select(ctx, ix->corpus->d_rows, d_q, nq, ap.lists, nprobe, kp, (uint64_t)nprobe * kp, top_k, 0, 0.f, row_base, d_or, d_od,
-                       d_oc);
+    rc = launch_select(ctx, ix->corpus->d_rows, d_q, nq, ap.lists, nprobe * n_seg, kp, (uint64_t)nprobe * n_seg * kp, top_k, 0, 0.f, row_base,
+                       d_or, d_od, d_oc);
     if (rc) return rc;
     if (d_or_out) *d_or_out = d_or;
     if (out_bytes_contig) *out_bytes_contig = b_or + b_od + (size_t)nq * 8;
@@ -1163,6 +1200,8 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     bool sane = offs[0] == 0 && offs[h.nlist] == h.n_rows;
     for (uint32_t l = 0; sane && l < h.nlist; ++l) sane = offs[l] <= offs[l + 1];
     if (!sane) { smt::set_error("'%s': corrupt list offsets", path); return SMT_E_IO; }
+    ix->max_list = 0;
+    for (uint32_t l = 0; l < h.nlist; ++l) ix->max_list = std::max<uint64_t>(ix->max_list, offs[l + 1] - offs[l]);
     if (h.pad[0] == 1 && N > 0) {  // the int8 refinement copy is a function of (corpus, ids): re-derive it
         IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), N * 256));
         IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), N * 4));
