@@ -190,3 +190,35 @@ def test_int8_refinement_is_opt_in_and_keeps_recall(gpu_ctx, tmp_path):
         ix.close()
     assert recall[True] >= recall[False] - 0.01 and recall[True] > 0.9, recall
     c.close()
+
+
+def test_long_lists_are_scanned_in_segments(gpu_ctx):
+    """Lists longer than 8192 codes (here: 200 k rows over 32 lists, 6250 per list => two segments per probed list, the
+    second one partial, and any longer list spilling into the last segment): results keep the exact distances, good
+    recall, and the device-resident entry point agrees with the host one."""
+    import torch
+    import semtools_amd as smt
+
+    from tests import synth
+
+    x = synth.clustered_rows_torch(200_000, 32, 8, 21, "cuda")
+    torch.cuda.synchronize()
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=200_000)
+    ix = smt.IvfPq(c, nlist=32, train_iters=5)
+    assert ix.list_sizes().mean() * 1.5 > 8192
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    qi = torch.randint(0, 200_000, (64,), device="cuda", generator=g)
+    qs = (x[qi] + 0.002 * torch.randn(64, 256, device="cuda", generator=g)).cpu().numpy()
+    exact = c.search(qs, top_k=10)
+    got = ix.search(qs, top_k=10, nprobe=4)
+    again = ix.search(qs, top_k=10, nprobe=4)
+    hit = 0
+    for (r, d), (r2, d2), (er, ed) in zip(got, again, exact):
+        assert r.tolist() == r2.tolist() and np.array_equal(d, d2)           # deterministic
+        lut = dict(zip(er.tolist(), ed.tolist()))
+        assert all(dd == lut[rr] for rr, dd in zip(r.tolist(), d.tolist()) if rr in lut)
+        hit += len(set(r.tolist()) & set(er.tolist()))
+    assert hit / 640 > 0.85, hit / 640
+    ix.close()
+    c.close()
