@@ -338,3 +338,49 @@ def test_model_tables_stored_as_f16_or_i8_are_widened_like_model2vec(gpu_ctx, tm
     want = orc.embed_lines(stored.astype(np.float32), np.array(ids, np.uint32), np.array(offsets, np.uint64), True, 2048)
     assert np.array_equal(np.asarray(got, np.float32).view(np.uint32), want.view(np.uint32))
     m.close()
+
+
+def test_reference_search_unit_tests_through_the_abi(model, model_dir, tmp_path):
+    """The reference's own tests of the path (src/search/mod.rs:252-415), driven through smt_host_search_files
+    with the same structure of assertions (their model is the real potion model, ours the synthetic table --
+    the asserted properties are the ones the reference asserts)."""
+    from semtools_amd import host
+
+    def search(query, files, **kw):
+        return json.loads(host.search_files(model, query, files, json=True, **kw))["results"]
+
+    doc1 = tmp_path / "doc1.txt"
+    doc1.write_text("w1 w2 w3\nw4 w5 w6\nw7 w8 w9\nw10 w11 w12\nw1 w2 w13\n")
+    doc2 = tmp_path / "doc2.txt"
+    doc2.write_text("w100 w101\nw1 w2 w3 w4\nw200\n")
+
+    # test_search_documents_basic (:252-274): results sorted by distance ascending
+    r = search("w1 w2 w3", [str(doc1)], n_lines=1, top_k=5)
+    assert len(r) == 5 and all(r[i]["distance"] <= r[i + 1]["distance"] for i in range(4))
+    assert r[0]["match_line_number"] == 0 and r[0]["distance"] < 1e-9
+
+    # test_search_documents_with_max_distance (:276-293): every result strictly under the threshold, top_k ignored
+    thr = (r[1]["distance"] + r[2]["distance"]) / 2
+    rt = search("w1 w2 w3", [str(doc1)], n_lines=1, top_k=1, max_distance=thr)
+    assert len(rt) == 2 and all(x["distance"] < thr for x in rt)
+    assert search("w1 w2 w3", [str(doc1)], n_lines=1, top_k=3, max_distance=r[1]["distance"])[-1]["distance"] < r[1]["distance"]
+
+    # test_search_documents_top_k_limit (:295-313)
+    assert len(search("w1 w2 w3", [str(doc1)], n_lines=1, top_k=2)) == 2
+
+    # test_search_result_context_calculation (:315-335): n_lines = 1 around line 2 -> start 1, end 4 (exclusive)
+    r = search("w7 w8 w9", [str(doc1)], n_lines=1, top_k=1)[0]
+    assert (r["match_line_number"], r["start_line_number"], r["end_line_number"]) == (2, 1, 4)
+
+    # test_context_at_file_boundaries (:337-357): clamped to the file
+    r = search("w1 w2 w3", [str(doc1)], n_lines=10, top_k=1)[0]
+    assert (r["start_line_number"], r["end_line_number"]) == (0, 5)
+
+    # test_multiple_documents_search (:359-379): hits come from both files, best match first
+    r = search("w1 w2 w3 w4", [str(doc1), str(doc2)], n_lines=0, top_k=4)
+    assert {x["filename"] for x in r} == {str(doc1), str(doc2)} and r[0]["filename"] == str(doc2) and r[0]["distance"] < 1e-9
+
+    # test_empty_documents_handling (:381-391)
+    empty = tmp_path / "empty.txt"
+    empty.write_text("")
+    assert search("w1", [str(empty)], n_lines=1, top_k=3) == []
