@@ -21,9 +21,10 @@
  *   - Host buffers are owned by the caller; device memory lives behind handles.
  *   - Handles are not thread-safe: serialise calls per handle (the reference
  *     calls this path synchronously from one task, src/bin/semtools.rs:134).
- *   - One smt_ctx == one GPU + one HIP stream == one process rank.  Multi-GPU is
- *     one process per GPU; ranks exchange per-shard top-k lists with an RCCL
- *     all-gather (smt_search_topk_device -> all_gather -> smt_merge_topk*).
+ *   - One smt_ctx == one GPU + one HIP stream.  Multi-GPU lives behind smt_group /
+ *     smt_sharded_corpus (bottom of this file): the library owns one context per GPU and
+ *     the RCCL communicator; a single host thread drives the whole node, or one rank
+ *     per process joins the same communicator (smt_group_create_rank).
  *   - "_device" entry points take/return DEVICE pointers and enqueue on the
  *     context's stream without synchronising (bench / multi-GPU pipelines).
  *   - There is no CPU fallback: every compute entry point fails with
@@ -168,7 +169,7 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
 
 /* Resident top-k (mode DOCUMENTS, no threshold, no ranges): queries_dev
  * [nq x D] and outputs [nq x top_k] are device pointers; unused slots are
- * (row = UINT64_MAX, dist = +inf).  Enqueues on the stream, no sync. */
+ * (row = UINT64_MAX, dist = +inf).  Enqueues on the stream, no sync.  1 <= top_k <= 56. */
 int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq,
                            uint32_t top_k, uint64_t row_base, uint64_t *out_rows_dev,
                            double *out_dist_dev);
@@ -234,6 +235,85 @@ int smt_ivfpq_list_sizes(const smt_ivfpq *index, uint64_t *sizes_host /* [nlist]
  * row count the index was built on (then rebuild -- 0.34 s per 10 M rows). */
 int smt_ivfpq_save(smt_ivfpq *index, const char *path);
 int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out);
+
+/* ------------------------------------------------------- groups of GPUs (RCCL)
+ * The reference runs the whole search synchronously from ONE task of ONE process (src/bin/semtools.rs:134-135,
+ * src/cmds/search.rs:197-206); these entry points let that one caller use every GPU of the node.  There is no
+ * reference counterpart for the sharding itself; the contract is: sharded result == single-shard result.
+ *
+ *   smt_init(devices, n)            process-wide default group; NULL / 0 = every visible GPU;
+ *                                   idempotent for the same list.  smt_shutdown() releases it.
+ *   smt_group_create(devices, n)    single process: one context + stream per device, ncclCommInitAll.
+ *   smt_group_unique_id / smt_group_create_rank
+ *                                   one rank per process (torchrun / MPI): rank 0 makes the 128-byte id, the host
+ *                                   broadcasts it by any means, every process joins with its device and rank
+ *                                   (ncclCommInitRank).  Calls on the group are then SPMD: every process makes
+ *                                   the same calls with the same host arguments.
+ * RCCL (librccl.so.1) is loaded when the first group is created, not when the library is. */
+typedef struct smt_group smt_group;
+typedef struct smt_sharded_corpus smt_sharded_corpus;
+#define SMT_UNIQUE_ID_BYTES 128
+int smt_init(const int *devices, int n_dev);
+int smt_shutdown(void);
+smt_group *smt_default_group(void);
+int smt_group_create(const int *devices, int n_dev, smt_group **out);
+/* n_shards logical ranks on ONE device, exchanging through device copies instead of RCCL (RCCL refuses two
+ * ranks on one GPU): lets a single-GPU box run the whole sharded path -- the GPU tests do -- and splits a
+ * corpus into independently growable shards.  smt_group_info reports rccl_ranks = 0 for such a group. */
+int smt_group_create_logical(int device, int n_shards, smt_group **out);
+int smt_group_unique_id(void *id_out /* SMT_UNIQUE_ID_BYTES */);
+int smt_group_create_rank(int device, int rank, int n_ranks, const void *unique_id, smt_group **out);
+void smt_group_destroy(smt_group *group);
+/* n_ranks: size of the group; n_local: GPUs driven by this process (ranks first_rank .. first_rank+n_local-1);
+ * rccl_ranks: what ncclCommCount reports for the communicator; rccl_version: ncclGetVersion.  Any may be NULL. */
+int smt_group_info(const smt_group *group, int *n_ranks, int *n_local, int *first_rank, int *rccl_ranks, int *rccl_version);
+/* the context of local device i (tuning keys, profiling, smt_model_create / smt_embed on that GPU); NULL if out of range */
+smt_ctx *smt_group_ctx(smt_group *group, int local_index);
+int smt_group_synchronize(smt_group *group); /* every local stream, async pipelines drained */
+int smt_group_barrier(smt_group *group);     /* + an all-gather across the ranks */
+
+/* A corpus row-sharded over the group by contiguous ranges, rows_per_rank = ceil(N / n_ranks) (SURVEY.md 8(e):
+ * a document's lines and the path-subset ranges stay ranges).  Global row = position in the whole corpus.
+ *   from_host    `rows` is the WHOLE matrix [total_rows x D]; every process uploads the slices of its local ranks.
+ *   from_device  adopt one resident buffer per LOCAL device (not copied, not freed); the ranks' sizes are
+ *                exchanged with one all-gather.
+ *   load / save  the smt_corpus_save file format; every rank streams its own slice of the file.
+ *   append_host  global rows are insertion order, so new rows extend the LAST rank's range.
+ *   shard        the smt_corpus behind local device i (+ its first global row and row count), e.g. as the
+ *                `append_to` target of smt_embed with a model created on smt_group_ctx(group, i). */
+int smt_sharded_corpus_from_host(smt_group *group, const float *rows, uint64_t total_rows, uint32_t D, smt_sharded_corpus **out);
+int smt_sharded_corpus_from_device(smt_group *group, const float *const *shard_rows_dev, const uint64_t *shard_rows,
+                                   uint32_t D, smt_sharded_corpus **out);
+int smt_sharded_corpus_load(smt_group *group, const char *path, smt_sharded_corpus **out);
+int smt_sharded_corpus_save(smt_sharded_corpus *corpus, const char *path);
+void smt_sharded_corpus_destroy(smt_sharded_corpus *corpus);
+uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *corpus);
+int smt_sharded_corpus_rank_rows(const smt_sharded_corpus *corpus, uint64_t *rows_per_rank /* [n_ranks] */);
+int smt_sharded_corpus_shard(smt_sharded_corpus *corpus, int local_index, smt_corpus **shard, uint64_t *row_base, uint64_t *rows);
+int smt_sharded_corpus_append_host(smt_sharded_corpus *corpus, const float *rows, uint64_t n_rows, uint64_t *first_row);
+
+/* smt_search over the sharded corpus: same arguments and semantics (ranges and returned rows are GLOBAL), same
+ * result as smt_search on the unsharded matrix.  top_k <= 56 without "all under threshold": per-device scan +
+ * select -> ONE ncclAllGather of the packed [nq][2][k] lists -> merge_topk_kernel.  Threshold mode and larger k:
+ * all-gather of the hit counts, one all-gather of a max-count-padded buffer, host merge. */
+int smt_sharded_search(smt_sharded_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance,
+                       int mode, const smt_range *ranges, uint32_t n_ranges, uint64_t *out_rows, double *out_dist,
+                       uint64_t *out_counts, uint64_t out_cap);
+/* Device-resident top-k (mode DOCUMENTS, no threshold, no ranges), nothing synchronises: queries_dev[i] is a
+ * pointer ON LOCAL DEVICE i to the nq queries; out_packed[i] (NULL = this device does not need the answer) is
+ * device-addressable memory of local device i -- HBM or pinned host -- receiving [nq][2][top_k] 8-byte words:
+ * global rows (padding UINT64_MAX), then the f64 distance bit patterns (padding +inf).  With tuning key
+ * async_select set on the contexts and nq == 1, the select, the all-gather and the merge of call i run on the
+ * contexts' aux streams while the scan of call i+1 streams. */
+int smt_sharded_search_topk_device(smt_sharded_corpus *corpus, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
+                                   uint64_t *const *out_packed);
+
+/* Exactness bookkeeping.  The f32 scan nominates top_k + 8 rows per list and the select stage PROVES per query
+ * that no other row can belong to the exact answer (the k-th exact distance lies more than the f32 error bound
+ * below the worst nominated f32 distance).  When the proof fails -- more than 8 near-ties around the k-th place --
+ * smt_search / smt_sharded_search re-answer that query exhaustively; the *_device entry points cannot (nothing
+ * synchronises), they count such queries here.  reset != 0 clears the counter. */
+int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset);
 
 /* The context's second stream (hipStream_t), created on first use: async selects run on it.  A host that
  * chains more work behind an async select (an RCCL all-gather of its output, the merge of the gathered

@@ -63,6 +63,10 @@ def lib():
         L.orc_doc_meta_id.restype = C.c_uint64
         L.orc_scan_topk_threads.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint64, C.c_int, u64p, f64p]
         L.orc_scan_topk_threads.restype = C.c_uint64
+        L.orc_search_documents_simd.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint64, C.c_uint64, C.c_int,
+                                                C.c_double, C.POINTER(OrcResult), C.c_uint64]
+        L.orc_search_documents_simd.restype = C.c_uint64
+        L.orc_simd_backend.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -155,3 +159,20 @@ def scan_topk_threads(emb, query, top_k, n_threads):
     n = lib().orc_scan_topk_threads(_p(emb, C.c_float), emb.shape[0], q.size, _p(q, C.c_float), top_k,
                                     n_threads, _p(rows, C.c_uint64), _p(dist, C.c_double))
     return rows[:n], dist[:n]
+
+
+def search_documents_simd(emb, query, n_lines=3, top_k=3, max_distance=None):
+    """The reference's control flow with a SIMD cosine, single thread (bench.py's "port-simd" baseline)."""
+    q = _f32(query)
+    emb = _f32(emb).reshape(-1, q.size)
+    cap = max(int(top_k) if max_distance is None else emb.shape[0], 1)
+    out = (OrcResult * cap)()
+    n = lib().orc_search_documents_simd(_p(emb, C.c_float), emb.shape[0], q.size, _p(q, C.c_float), n_lines, top_k,
+                                        int(max_distance is not None),
+                                        float(max_distance if max_distance is not None else 0.0), out, cap)
+    return [dict(doc=0, match_line=int(r.match_line), start=int(r.start), end=int(r.end), distance=float(r.distance))
+            for r in out[:min(n, cap)]]
+
+
+def simd_backend():
+    return lib().orc_simd_backend().decode()

@@ -15,7 +15,7 @@
  * and the reference's own tests pin no numeric embedding/distance value
  * (src/search/mod.rs:218-464 assert properties only).  The control flow
  * (threshold, ordering, top-k, context window, ids) IS in-tree and is pinned by
- * the reference's tests, restated in tests/test_oracle_reference_cases.py.
+ * the reference's tests, restated in tests/test_oracle.py.
  * Each function cites the reference file:line (relative to /root/reference)
  * or the upstream crate algorithm it restates.
  */
@@ -93,6 +93,12 @@ uint64_t orc_doc_meta_id(const char *path);
 uint64_t orc_scan_topk_threads(const float *emb, uint64_t N, uint32_t D,
                                const float *query, uint64_t top_k, int n_threads,
                                uint64_t *out_rows, double *out_dist);
+
+/* bench.py's honest single-core baseline: the reference's control flow with a SIMD (runtime-dispatched AVX-512 /
+ * AVX2+FMA) f32 cosine, see cpu_fast.c */
+uint64_t orc_search_documents_simd(const float *emb, uint64_t N, uint32_t D, const float *query, uint64_t n_lines,
+                                   uint64_t top_k, int has_max_distance, double max_distance, orc_result *out, uint64_t cap);
+const char *orc_simd_backend(void);
 
 #ifdef __cplusplus
 }

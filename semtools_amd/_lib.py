@@ -26,7 +26,14 @@ EXPORTS = [
     "smt_corpus_save", "smt_corpus_load", "smt_corpus_append_to_file", "smt_search", "smt_search_topk_device", "smt_merge_topk",
     "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_search_device", "smt_ivfpq_info", "smt_ivfpq_list_sizes", "smt_ivfpq_save", "smt_ivfpq_load",
     "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
+    "smt_ctx_uncertain_count",
+    "smt_init", "smt_shutdown", "smt_default_group", "smt_group_create", "smt_group_create_logical", "smt_group_unique_id", "smt_group_create_rank",
+    "smt_group_destroy", "smt_group_info", "smt_group_ctx", "smt_group_synchronize", "smt_group_barrier",
+    "smt_sharded_corpus_from_host", "smt_sharded_corpus_from_device", "smt_sharded_corpus_load", "smt_sharded_corpus_save",
+    "smt_sharded_corpus_destroy", "smt_sharded_corpus_rows", "smt_sharded_corpus_rank_rows", "smt_sharded_corpus_shard",
+    "smt_sharded_corpus_append_host", "smt_sharded_search", "smt_sharded_search_topk_device",
 ]
+UNIQUE_ID_BYTES = 128
 HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
     "smt_host_search_files", "smt_host_search_content", "smt_host_search_workspace", "smt_host_session_open",
@@ -140,6 +147,36 @@ def lib():
     L.smt_line_embedding_id.restype = u64
     L.smt_doc_meta_id.argtypes = [C.c_char_p]
     L.smt_doc_meta_id.restype = u64
+    L.smt_ctx_uncertain_count.argtypes = [vp, P(u64), i32]
+    # ---- groups of GPUs
+    L.smt_init.argtypes = [P(i32), i32]
+    L.smt_shutdown.argtypes = []
+    L.smt_default_group.argtypes = []
+    L.smt_default_group.restype = vp
+    L.smt_group_create.argtypes = [P(i32), i32, P(vp)]
+    L.smt_group_create_logical.argtypes = [i32, i32, P(vp)]
+    L.smt_group_unique_id.argtypes = [vp]
+    L.smt_group_create_rank.argtypes = [i32, i32, i32, vp, P(vp)]
+    L.smt_group_destroy.argtypes = [vp]
+    L.smt_group_destroy.restype = None
+    L.smt_group_info.argtypes = [vp, P(i32), P(i32), P(i32), P(i32), P(i32)]
+    L.smt_group_ctx.argtypes = [vp, i32]
+    L.smt_group_ctx.restype = vp
+    L.smt_group_synchronize.argtypes = [vp]
+    L.smt_group_barrier.argtypes = [vp]
+    L.smt_sharded_corpus_from_host.argtypes = [vp, vp, u64, u32, P(vp)]
+    L.smt_sharded_corpus_from_device.argtypes = [vp, P(vp), P(u64), u32, P(vp)]
+    L.smt_sharded_corpus_load.argtypes = [vp, C.c_char_p, P(vp)]
+    L.smt_sharded_corpus_save.argtypes = [vp, C.c_char_p]
+    L.smt_sharded_corpus_destroy.argtypes = [vp]
+    L.smt_sharded_corpus_destroy.restype = None
+    L.smt_sharded_corpus_rows.argtypes = [vp]
+    L.smt_sharded_corpus_rows.restype = u64
+    L.smt_sharded_corpus_rank_rows.argtypes = [vp, vp]
+    L.smt_sharded_corpus_shard.argtypes = [vp, i32, P(vp), P(u64), P(u64)]
+    L.smt_sharded_corpus_append_host.argtypes = [vp, vp, u64, P(u64)]
+    L.smt_sharded_search.argtypes = [vp, vp, u32, u32, f64, i32, vp, u32, vp, vp, vp, u64]
+    L.smt_sharded_search_topk_device.argtypes = [vp, P(vp), u32, u32, P(vp)]
     # ---- host layer (include/semtools_host.h)
     cpp = P(C.c_char_p)
     L.smt_host_model_create.argtypes = [vp, vp, u64, i32, i32, C.c_char_p, C.c_char_p, TOKENIZE_CB, vp, u32, u32, P(vp)]

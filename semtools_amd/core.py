@@ -18,9 +18,12 @@ class Context:
     stream=<int>: raw hipStream_t to enqueue on (0 = the null stream), e.g.
     torch.cuda.current_stream().cuda_stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, _borrowed=None):
         self._h = C.c_void_p()
-        if stream is None:
+        self._owned = _borrowed is None
+        if _borrowed is not None:          # a context owned by a Group (smt_group_ctx)
+            self._h = C.c_void_p(_borrowed)
+        elif stream is None:
             L.check(L.lib().smt_ctx_create(int(device), C.byref(self._h)))
         else:
             L.check(L.lib().smt_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(self._h)))
@@ -28,7 +31,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            L.lib().smt_ctx_destroy(self._h)
+            if getattr(self, "_owned", True):
+                L.lib().smt_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):  # best effort
@@ -39,6 +43,12 @@ class Context:
 
     def synchronize(self):
         L.check(L.lib().smt_ctx_synchronize(self._h))
+
+    def uncertain_count(self, reset=True):
+        """Selects whose exactness certificate failed since the last reset (device entry points only count them)."""
+        n = C.c_uint64()
+        L.check(L.lib().smt_ctx_uncertain_count(self._h, C.byref(n), int(bool(reset))))
+        return int(n.value)
 
     def aux_stream(self):
         """Raw hipStream_t of the context's second stream (async selects run there); wrap it with
@@ -120,9 +130,10 @@ class Model:
 class Corpus:
     """Row-major f32 [rows x 256] matrix resident in HBM (smt_corpus)."""
 
-    def __init__(self, ctx, capacity_rows=0, device_ptr=None, rows=None, _handle=None):
+    def __init__(self, ctx, capacity_rows=0, device_ptr=None, rows=None, _handle=None, _borrowed=False):
         self.ctx = ctx
         self._h = C.c_void_p()
+        self._borrowed = _borrowed     # a shard owned by a ShardedCorpus
         if _handle is not None:
             self._h = _handle
         elif device_ptr is not None:
@@ -144,7 +155,8 @@ class Corpus:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            L.lib().smt_corpus_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                L.lib().smt_corpus_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -275,6 +287,177 @@ class IvfPq:
         """Device-resident form (raw pointers; asynchronous on the context's stream)."""
         L.check(L.lib().smt_ivfpq_search_device(self._h, C.c_void_p(queries_ptr), int(nq), int(top_k), int(nprobe), int(rerank),
                                                 int(row_base), C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
+
+
+def _ranges_arg(ranges):
+    if ranges is None:
+        return None, 0
+    n = len(ranges)
+    rng = (L.SmtRange * max(n, 1))()
+    for i, (b, e) in enumerate(ranges):
+        rng[i].begin, rng[i].end = int(b), int(e)
+    return rng, n
+
+
+class Group:
+    """A group of GPUs behind the C ABI (smt_group): one context + stream per device and one RCCL communicator.
+
+    Group(devices=[0, 1, ...])                 single process drives every listed GPU (ncclCommInitAll)
+    Group.from_rank(device, rank, n, id)       one rank per process; `id` = Group.unique_id() made on rank 0 and
+                                               broadcast by the host (see semtools_amd.dist.group_from_torch)"""
+
+    def __init__(self, devices=None, _handle=None):
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            if devices is None:
+                n = L.lib().smt_device_count()
+                L.check(min(n, 0))
+                devices = range(n)
+            devs = list(devices)
+            arr = (C.c_int * len(devs))(*devs)
+            L.check(L.lib().smt_group_create(arr, len(devs), C.byref(self._h)))
+        self._ctx = {}
+
+    @classmethod
+    def logical(cls, device, n_shards):
+        """n logical ranks on one device (copy transport instead of RCCL): the sharded path on a 1-GPU box."""
+        h = C.c_void_p()
+        L.check(L.lib().smt_group_create_logical(int(device), int(n_shards), C.byref(h)))
+        return cls(_handle=h)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * L.UNIQUE_ID_BYTES)()
+        L.check(L.lib().smt_group_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_rank(cls, device, rank, n_ranks, unique_id):
+        assert len(unique_id) == L.UNIQUE_ID_BYTES
+        h = C.c_void_p()
+        buf = (C.c_ubyte * L.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        L.check(L.lib().smt_group_create_rank(int(device), int(rank), int(n_ranks), buf, C.byref(h)))
+        return cls(_handle=h)
+
+    def info(self):
+        v = [C.c_int() for _ in range(5)]
+        L.check(L.lib().smt_group_info(self._h, *[C.byref(x) for x in v]))
+        return dict(n_ranks=v[0].value, n_local=v[1].value, first_rank=v[2].value, rccl_ranks=v[3].value,
+                    rccl_version=v[4].value)
+
+    def ctx(self, local_index=0):
+        """The library-owned Context of local device i (tuning keys, profiling, Model(...) on that GPU)."""
+        if local_index not in self._ctx:
+            h = L.lib().smt_group_ctx(self._h, int(local_index))
+            if not h:
+                raise IndexError(local_index)
+            self._ctx[local_index] = Context(_borrowed=h)
+        return self._ctx[local_index]
+
+    def synchronize(self):
+        L.check(L.lib().smt_group_synchronize(self._h))
+
+    def barrier(self):
+        L.check(L.lib().smt_group_barrier(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedCorpus:
+    """Corpus row-sharded over a Group by contiguous ranges, ceil(N / n_ranks) rows per rank (smt_sharded_corpus).
+    search() has Corpus.search's arguments and returns the same answer as the unsharded matrix would."""
+
+    def __init__(self, group, rows=None, device_ptrs=None, shard_rows=None, path=None):
+        self.group = group
+        self._h = C.c_void_p()
+        if path is not None:
+            L.check(L.lib().smt_sharded_corpus_load(group._h, str(path).encode(), C.byref(self._h)))
+        elif device_ptrs is not None:
+            n = len(device_ptrs)
+            ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in device_ptrs])
+            cnt = (C.c_uint64 * n)(*[int(r) for r in shard_rows])
+            L.check(L.lib().smt_sharded_corpus_from_device(group._h, ptrs, cnt, L.DIM, C.byref(self._h)))
+        else:
+            rows = _f32c(rows).reshape(-1, L.DIM)
+            L.check(L.lib().smt_sharded_corpus_from_host(group._h, L.np_ptr(rows), rows.shape[0], L.DIM, C.byref(self._h)))
+
+    @classmethod
+    def load(cls, group, path):
+        return cls(group, path=path)
+
+    def save(self, path):
+        L.check(L.lib().smt_sharded_corpus_save(self._h, str(path).encode()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_sharded_corpus_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def rows(self):
+        return int(L.lib().smt_sharded_corpus_rows(self._h))
+
+    def rank_rows(self):
+        out = np.zeros(self.group.info()["n_ranks"], dtype=np.uint64)
+        L.check(L.lib().smt_sharded_corpus_rank_rows(self._h, L.np_ptr(out)))
+        return out
+
+    def shard(self, local_index=0):
+        """(Corpus view of local device i's shard, its first global row, its row count)."""
+        h, base, n = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().smt_sharded_corpus_shard(self._h, int(local_index), C.byref(h), C.byref(base), C.byref(n)))
+        return Corpus(self.group.ctx(local_index), _handle=h, _borrowed=True), int(base.value), int(n.value)
+
+    def append(self, rows):
+        rows = _f32c(rows).reshape(-1, L.DIM)
+        first = C.c_uint64(0)
+        L.check(L.lib().smt_sharded_corpus_append_host(self._h, L.np_ptr(rows), rows.shape[0], C.byref(first)))
+        return int(first.value)
+
+    def search(self, queries, top_k=3, max_distance=None, mode=L.MODE_DOCUMENTS, ranges=None, out_cap=None):
+        q = _f32c(queries).reshape(-1, L.DIM)
+        nq = q.shape[0]
+        if out_cap is None:
+            out_cap = max(int(top_k), 1)
+        rng, n_rng = _ranges_arg(ranges)
+        while True:
+            out_rows = np.empty((nq, out_cap), dtype=np.uint64)
+            out_dist = np.empty((nq, out_cap), dtype=np.float64)
+            counts = np.zeros(nq, dtype=np.uint64)
+            rc = L.lib().smt_sharded_search(self._h, L.np_ptr(q), nq, int(top_k),
+                                            float("nan") if max_distance is None else float(max_distance), int(mode),
+                                            C.cast(rng, C.c_void_p) if rng is not None else None, n_rng,
+                                            L.np_ptr(out_rows), L.np_ptr(out_dist), L.np_ptr(counts), int(out_cap))
+            if rc == L.SMT_E_TRUNCATED:
+                out_cap = int(counts.max())
+                continue
+            L.check(rc)
+            break
+        return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
+
+    def search_topk_device(self, query_ptrs, nq, top_k, out_packed_ptrs):
+        """Device-resident form: one queries pointer and one output pointer (or 0/None) per LOCAL device."""
+        n = len(query_ptrs)
+        qp = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in query_ptrs])
+        op = (C.c_void_p * n)(*[C.c_void_p(int(p)) if p else C.c_void_p(None) for p in out_packed_ptrs])
+        L.check(L.lib().smt_sharded_search_topk_device(self._h, qp, int(nq), int(top_k), op))
 
 
 def merge_topk(rows, dist, k_out):

@@ -6,6 +6,9 @@
 #include <cerrno>
 #include <cmath>
 #include <limits>
+#include <string>
+
+#include <unistd.h>
 
 #include "common.h"
 
@@ -185,6 +188,15 @@ static int ctx_create_impl(int device, void *stream, bool use_given, smt_ctx **o
         if (e != hipSuccess) { delete ctx; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return SMT_E_HIP; }
         ctx->own_stream = true;
     }
+    // sticky counter of selects whose exactness certificate failed (SelectArgs::f32_err)
+    hipError_t es = hipMalloc(reinterpret_cast<void **>(&ctx->d_status), 64);
+    if (es == hipSuccess) es = hipMemset(ctx->d_status, 0, 64);
+    if (es != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        set_error("context status word: %s", hipGetErrorString(es));
+        return SMT_E_HIP;
+    }
     *out = ctx;
     return SMT_OK;
 }
@@ -203,6 +215,7 @@ void smt_ctx_destroy(smt_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     for (auto &kv : ctx->prof)
         for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -219,6 +232,20 @@ int smt_ctx_synchronize(smt_ctx *ctx)
     SMT_HIP_CHECK(hipSetDevice(ctx->device));
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return drain_async(ctx);
+}
+
+int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(count != nullptr, "null argument");
+    if ((rc = bind_device(ctx))) return rc;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    unsigned long long v = 0;
+    SMT_HIP_CHECK(hipMemcpy(&v, ctx->d_status, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset && v) SMT_HIP_CHECK(hipMemset(ctx->d_status, 0, sizeof(v)));
+    *count = v;
+    return SMT_OK;
 }
 
 int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out)
@@ -485,30 +512,175 @@ struct CorpusFileHeader {  // 32 bytes, little endian
     uint64_t reserved2;
 };
 
-int smt_corpus_save(smt_corpus *c, const char *path)
+}  // extern "C"
+
+namespace smt {
+
+// Two pinned staging buffers + one event each: the file transfer of chunk j+1 overlaps the PCIe transfer of
+// chunk j (the first version read 64 K-row chunks into a pageable vector and copied them synchronously).
+struct PinnedPair {
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    size_t bytes = 0;
+    int init(size_t want)
+    {
+        bytes = want;
+        for (int i = 0; i < 2; ++i) {
+            SMT_HIP_CHECK(hipHostMalloc(&buf[i], bytes, hipHostMallocDefault));
+            SMT_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        return SMT_OK;
+    }
+    int wait(int i)
+    {
+        if (busy[i]) { SMT_HIP_CHECK(hipEventSynchronize(ev[i])); busy[i] = false; }
+        return SMT_OK;
+    }
+    ~PinnedPair()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (ev[i]) { if (busy[i]) (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+    }
+};
+
+static size_t io_chunk_rows(uint64_t n_rows)
 {
-    SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
-    int rc = bind_device(c->ctx);
+    // 32 MiB chunks for big files, two chunks for small ones (a 1 k-line corpus must not pin 64 MiB)
+    const uint64_t big = 32768;
+    return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(big, (n_rows + 1) / 2));
+}
+
+int corpus_file_info(const char *path, uint64_t *rows, uint32_t *dim)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    CorpusFileHeader h;
+    const bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "SMTCORP1", 8) == 0;
+    bool sized = false;
+    if (ok && fseek(f, 0, SEEK_END) == 0) {
+        const long long sz = ftello(f);
+        sized = sz >= 0 && (uint64_t)sz >= sizeof(h) + h.rows * (uint64_t)h.dim * sizeof(float);
+    }
+    fclose(f);
+    if (!ok) { set_error("'%s' is not a corpus file", path); return SMT_E_IO; }
+    if (!sized) { set_error("'%s' is truncated", path); return SMT_E_IO; }
+    *rows = h.rows;
+    *dim = h.dim;
+    return SMT_OK;
+}
+
+// Append rows [first_row, first_row + n_rows) of the corpus file to `c`.
+int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint64_t n_rows)
+{
+    if (n_rows == 0) return SMT_OK;
+    smt_ctx *ctx = c->ctx;
+    int rc = bind_device(ctx);
     if (rc) return rc;
+    if ((rc = corpus_reserve(c, c->rows + n_rows))) return rc;
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    const size_t row_bytes = (size_t)c->dim * sizeof(float);
+    if (fseeko(f, (off_t)(sizeof(CorpusFileHeader) + first_row * row_bytes), SEEK_SET) != 0) {
+        fclose(f); set_error("seek in '%s': %s", path, strerror(errno)); return SMT_E_IO;
+    }
+    const size_t chunk = io_chunk_rows(n_rows);
+    PinnedPair pp;
+    if ((rc = pp.init(chunk * row_bytes))) { fclose(f); return rc; }
+    int j = 0;
+    for (uint64_t r = 0; r < n_rows; r += chunk, j ^= 1) {
+        const size_t n = (size_t)std::min<uint64_t>(chunk, n_rows - r);
+        if ((rc = pp.wait(j))) { fclose(f); return rc; }
+        if (fread(pp.buf[j], row_bytes, n, f) != n) { fclose(f); set_error("'%s' is truncated", path); return SMT_E_IO; }
+        hipError_t e = hipMemcpyAsync(c->d_rows + (size_t)(c->rows + r) * c->dim, pp.buf[j], n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
+        if (e != hipSuccess) { fclose(f); set_error("corpus upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+        pp.busy[j] = true;
+    }
+    fclose(f);
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    pp.busy[0] = pp.busy[1] = false;
+    c->rows += n_rows;
+    return SMT_OK;
+}
+
+// Create `path` with a header announcing total_rows and its final size (slices are then written in place).
+int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows)
+{
     FILE *f = fopen(path, "wb");
     if (!f) { set_error("cannot open '%s' for writing: %s", path, strerror(errno)); return SMT_E_IO; }
     CorpusFileHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "SMTCORP1", 8);
-    h.dim = c->dim;
-    h.rows = c->rows;
+    h.dim = dim;
+    h.rows = total_rows;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
-    const uint64_t chunk_rows = 65536;
-    std::vector<float> buf;
-    buf.resize((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(c->rows, 1)) * c->dim);
-    for (uint64_t r = 0; ok && r < c->rows; r += chunk_rows) {
-        const uint64_t n = std::min(chunk_rows, c->rows - r);
-        rc = smt_corpus_read_rows(c, r, n, buf.data());
-        if (rc) { fclose(f); return rc; }
-        ok = fwrite(buf.data(), sizeof(float), (size_t)n * c->dim, f) == (size_t)n * c->dim;
-    }
+    ok = ok && fflush(f) == 0 && ftruncate(fileno(f), (off_t)(sizeof(h) + total_rows * (uint64_t)dim * sizeof(float))) == 0;
     if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("short write to '%s'", path); return SMT_E_IO; }
+    if (!ok) { set_error("cannot write '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    return SMT_OK;
+}
+
+// Write every row of `c` into the (existing) corpus file at row position file_first_row.
+int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row)
+{
+    smt_ctx *ctx = c->ctx;
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (c->rows == 0) return SMT_OK;
+    FILE *f = fopen(path, "r+b");
+    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
+    const size_t row_bytes = (size_t)c->dim * sizeof(float);
+    if (fseeko(f, (off_t)(sizeof(CorpusFileHeader) + file_first_row * row_bytes), SEEK_SET) != 0) {
+        fclose(f); set_error("seek in '%s': %s", path, strerror(errno)); return SMT_E_IO;
+    }
+    const size_t chunk = io_chunk_rows(c->rows);
+    PinnedPair pp;
+    if ((rc = pp.init(chunk * row_bytes))) { fclose(f); return rc; }
+    // D2H of chunk j+1 flies while chunk j is written
+    auto issue = [&](uint64_t r, int j) -> int {
+        const size_t n = (size_t)std::min<uint64_t>(chunk, c->rows - r);
+        hipError_t e = hipMemcpyAsync(pp.buf[j], c->d_rows + (size_t)r * c->dim, n * row_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
+        if (e != hipSuccess) { set_error("corpus download: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+        pp.busy[j] = true;
+        return SMT_OK;
+    };
+    if ((rc = issue(0, 0))) { fclose(f); return rc; }
+    int j = 0;
+    bool ok = true;
+    for (uint64_t r = 0; r < c->rows && ok; r += chunk, j ^= 1) {
+        if (r + chunk < c->rows && (rc = issue(r + chunk, j ^ 1))) { fclose(f); return rc; }
+        if ((rc = pp.wait(j))) { fclose(f); return rc; }
+        const size_t n = (size_t)std::min<uint64_t>(chunk, c->rows - r);
+        ok = fwrite(pp.buf[j], row_bytes, n, f) == n;
+    }
+    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("short write to '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    return SMT_OK;
+}
+
+}  // namespace smt
+
+extern "C" {
+
+int smt_corpus_save(smt_corpus *c, const char *path)
+{
+    SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
+    // never rewrite the live file in place: a crash or ENOSPC half way would leave a truncated corpus that
+    // every later workspace command rejects.  Write a sibling, fsync, rename.
+    const std::string tmp = std::string(path) + ".tmp";
+    int rc = corpus_file_begin(tmp.c_str(), c->dim, c->rows);
+    if (!rc) rc = corpus_save_slice(c, tmp.c_str(), 0);
+    if (rc) { (void)remove(tmp.c_str()); return rc; }
+    if (rename(tmp.c_str(), path) != 0) {
+        set_error("rename '%s' -> '%s': %s", tmp.c_str(), path, strerror(errno));
+        (void)remove(tmp.c_str());
+        return SMT_E_IO;
+    }
     return SMT_OK;
 }
 
@@ -548,26 +720,12 @@ int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
     if (rc) return rc;
     SMT_REQUIRE(path && out, "null argument");
     *out = nullptr;
-    FILE *f = fopen(path, "rb");
-    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    CorpusFileHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTCORP1", 8) != 0) {
-        fclose(f); set_error("'%s' is not a corpus file", path); return SMT_E_IO;
-    }
+    uint64_t rows = 0;
+    uint32_t dim = 0;
+    if ((rc = corpus_file_info(path, &rows, &dim))) return rc;
     smt_corpus *c = nullptr;
-    rc = smt_corpus_create(ctx, h.dim, h.rows, &c);
-    if (rc) { fclose(f); return rc; }
-    const uint64_t chunk_rows = 65536;
-    std::vector<float> buf((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(h.rows, 1)) * h.dim);
-    for (uint64_t r = 0; r < h.rows; r += chunk_rows) {
-        const uint64_t n = std::min(chunk_rows, h.rows - r);
-        if (fread(buf.data(), sizeof(float), (size_t)n * h.dim, f) != (size_t)n * h.dim) {
-            fclose(f); smt_corpus_destroy(c); set_error("'%s' is truncated", path); return SMT_E_IO;
-        }
-        rc = smt_corpus_append_host(c, buf.data(), n, nullptr);
-        if (rc) { fclose(f); smt_corpus_destroy(c); return rc; }
-    }
-    fclose(f);
+    if ((rc = smt_corpus_create(ctx, dim, rows, &c))) return rc;
+    if ((rc = corpus_load_slice(c, path, 0, rows))) { smt_corpus_destroy(c); return rc; }
     *out = c;
     return SMT_OK;
 }
@@ -638,6 +796,10 @@ int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, ui
 
 /* --------------------------------------------------------------- search ---- */
 
+}  // extern "C"
+
+namespace smt {
+
 static int validate_ranges(const smt_range *ranges, uint32_t n, uint64_t rows, uint64_t *total)
 {
     uint64_t prev_end = 0, t = 0;
@@ -652,19 +814,55 @@ static int validate_ranges(const smt_range *ranges, uint32_t n, uint64_t rows, u
     return SMT_OK;
 }
 
-int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
-               const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, uint64_t *out_rows, double *out_dist,
-               uint64_t *out_counts, uint64_t out_cap)
+// Exhaustive answer for ONE query whose f32 nomination failed its exactness certificate: K4 collects every row
+// whose exact distance is <= bound (its own f32 prefilter carries an 8e-6 guard band; rescoring is exact f64), in
+// (distance asc, row asc) order; the answer is the first k_eff of them (after the workspace score filter).
+// `bound` is the k-th exact distance found so far -- an upper bound of the true k-th -- or, when fewer than k rows
+// passed the workspace threshold, the largest distance that threshold admits.  O(rows <= bound): a cluster of
+// near-duplicates costs its own size, exactly what the reference pays for every query (it sorts all N).
+static int exact_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *query_dev, const smt_range *ranges_dev,
+                          const uint64_t *chunk_prefix_dev, uint32_t nr, uint64_t n_virtual, uint64_t n_chunks, double bound,
+                          uint32_t k_eff, bool ws_thr, float thr_score, uint64_t row_base, LocalHits &out)
+{
+    ThresholdQuery t;
+    t.corpus = corpus->d_rows;
+    t.rows = corpus->rows;
+    t.query = query_dev;
+    t.ranges = ranges_dev;
+    t.range_chunk_prefix = chunk_prefix_dev;
+    t.n_chunks = n_chunks;
+    t.n_ranges = nr;
+    t.n_virtual = n_virtual;
+    t.max_distance = std::nextafter(bound, std::numeric_limits<double>::infinity());  // K4 keeps d < max_distance: include == bound
+    const uint32_t *h_rows = nullptr;
+    const double *h_dist = nullptr;
+    uint64_t n_ok = 0;
+    int rc = run_threshold_query(ctx, t, &h_rows, &h_dist, &n_ok);
+    if (rc) return rc;
+    out.rows.clear();
+    out.dist.clear();
+    for (uint64_t i = 0; i < n_ok && out.rows.size() < k_eff; ++i) {
+        if (ws_thr && !((1.0 - h_dist[i]) > (double)thr_score)) continue;  // store.rs:502-503
+        out.rows.push_back(row_base + h_rows[i]);
+        out.dist.push_back(h_dist[i]);
+    }
+    return SMT_OK;
+}
+
+// The body of smt_search with per-query result vectors instead of caller arrays: group.cpp runs it once per
+// local shard (threshold mode / top_k > 64, whose result sizes are not known up front) and exchanges the lists.
+int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+                      const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out)
 {
     SMT_REQUIRE(corpus != nullptr, "corpus");
     SMT_REQUIRE(mode == SMT_MODE_DOCUMENTS || mode == SMT_MODE_WORKSPACE, "mode");
-    SMT_REQUIRE(nq == 0 || (queries && out_counts), "null argument");
+    SMT_REQUIRE(nq == 0 || queries, "null argument");
     SMT_REQUIRE(n_ranges == 0 || ranges != nullptr, "ranges");
     smt_ctx *ctx = corpus->ctx;
     int rc = bind_device(ctx);
     if (rc) return rc;
+    out.assign(nq, LocalHits());
     if (nq == 0) return SMT_OK;
-    for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
 
     const bool has_thr = !std::isnan(max_distance);
     const bool all_under_threshold = (mode == SMT_MODE_DOCUMENTS) && has_thr;
@@ -680,18 +878,16 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
     }
     if (n_virtual == 0) return SMT_OK;
     if (!all_under_threshold && top_k == 0) return SMT_OK;  // take(0) / store.rs:489-491
-    SMT_REQUIRE(out_rows && out_dist, "null output");
 
     // ---- device staging: queries, ranges(+prefix)
     const uint32_t nr = (uint32_t)rr.size();
-    const bool single_full_range = (nr == 1);
     const size_t q_bytes = (size_t)nq * SMT_DIM * sizeof(float);
     const size_t r_bytes = (size_t)nr * sizeof(smt_range);
     const size_t p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
     // one persistent staging buffer per context: [queries | ranges | prefix | result lists] (no per-call hipMalloc/hipFree)
     const size_t in_bytes = (q_bytes + r_bytes + 2 * p_bytes + 255) & ~(size_t)255;
     const uint32_t k_stage = all_under_threshold ? 0u : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(top_k, n_virtual), 64);
-    const size_t out_bytes_stage = (size_t)nq * k_stage * 16 + (size_t)nq * sizeof(uint64_t);
+    const size_t out_bytes_stage = (size_t)nq * k_stage * 16 + (size_t)2 * nq * sizeof(uint64_t);
     if ((rc = ensure_stage(ctx, in_bytes + out_bytes_stage + 64))) return rc;
     char *stage = reinterpret_cast<char *>(ctx->d_stage);
     float *d_q = reinterpret_cast<float *>(stage);
@@ -712,23 +908,23 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     const uint64_t n_chunks = chunk_prefix[nr];
-    (void)single_full_range;
 
     if (!all_under_threshold) {
         // ---------------- top-k (optionally with the workspace score threshold)
         const uint32_t k_eff = (uint32_t)std::min<uint64_t>(top_k, n_virtual);
-        if (k_eff > 64) {
-            // rare large-k request: all keys + sort + exact rescoring of k + guard candidates
+        if (k_eff > SCAN_MAX_K) {
+            // large-k request (also k in 57..64, where the f32 scan's candidate lists have no room left for the
+            // guard band): all keys + sort + exact rescoring of k + guard candidates
             const uint64_t guard = std::max<uint64_t>(64, k_eff / 16);
             const uint64_t n_cand = std::min<uint64_t>(n_virtual, (uint64_t)k_eff + guard);
             const bool ws_thr = (mode == SMT_MODE_WORKSPACE && has_thr);
             const float thr_score = 1.0f - (float)max_distance;
-            bool truncated = false;
             for (uint32_t q = 0; q < nq; ++q) {
                 std::vector<uint32_t> c_rows;
                 std::vector<double> c_dist;
+                float next_d32 = 0.f;
                 rc = launch_largek_candidates(ctx, corpus->d_rows, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr,
-                                              nr ? d_p : nullptr, nr, n_virtual, n_cand, c_rows, c_dist);
+                                              nr ? d_p : nullptr, nr, n_virtual, n_cand, c_rows, c_dist, &next_d32);
                 if (rc) return rc;
                 std::vector<uint64_t> order;
                 for (uint64_t i = 0; i < c_rows.size(); ++i) {
@@ -741,20 +937,28 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
                     return c_rows[x] < c_rows[y];
                 });
                 const uint64_t n = std::min<uint64_t>(order.size(), k_eff);
-                out_counts[q] = n;
-                const uint64_t w = std::min<uint64_t>(n, out_cap);
-                if (n > out_cap) truncated = true;
-                for (uint64_t i = 0; i < w; ++i) {
-                    out_rows[(size_t)q * out_cap + i] = row_base + c_rows[order[i]];
-                    out_dist[(size_t)q * out_cap + i] = c_dist[order[i]];
+                out[q].rows.resize(n);
+                out[q].dist.resize(n);
+                for (uint64_t i = 0; i < n; ++i) {
+                    out[q].rows[i] = row_base + c_rows[order[i]];
+                    out[q].dist[i] = c_dist[order[i]];
+                }
+                // exactness certificate (SelectArgs::f32_err): rows outside the candidates have exact distance >= floor_out
+                const double floor_out = (double)next_d32 - F32_ERR_SCAN;
+                const bool certain = n == k_eff ? floor_out > out[q].dist[n - 1]
+                                                : (ws_thr ? !((1.0 - floor_out) > (double)thr_score) : next_d32 == __builtin_inff());
+                if (!certain) {
+                    const double bound = n == k_eff ? out[q].dist[n - 1] : 1.0 - (double)thr_score;
+                    rc = exact_fallback(ctx, corpus, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr, nr ? d_cp : nullptr, nr,
+                                        n_virtual, n_chunks, bound, k_eff, ws_thr, thr_score, row_base, out[q]);
+                    if (rc) return rc;
                 }
             }
-            if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
             return SMT_OK;
         }
         const size_t o_rows = (size_t)nq * k_eff * sizeof(uint64_t);
         const size_t o_dist = (size_t)nq * k_eff * sizeof(double);
-        const size_t o_cnt = (size_t)nq * sizeof(uint64_t);
+        const size_t o_cnt = (size_t)2 * nq * sizeof(uint64_t);  // counts, then the "uncertain" flags
         char *outs = stage + in_bytes;
         uint64_t *d_orow = reinterpret_cast<uint64_t *>(outs);
         double *d_odist = reinterpret_cast<double *>(outs + o_rows);
@@ -778,8 +982,9 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         a.out_rows = d_orow;
         a.out_dist = d_odist;
         a.out_counts = d_ocnt;
+        a.out_uncertain = d_ocnt + nq;
         // the MFMA path pays off from 8 queries up (one 32-query tile)
-        rc = (nq >= 8 && nr == 0) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
+        rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
         if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
         if (rc) return rc;
 
@@ -789,23 +994,26 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
         const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows);
         const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows + o_dist);
-        bool truncated = false;
+        std::vector<uint32_t> redo;
         for (uint32_t q = 0; q < nq; ++q) {
             const uint64_t n = h_cnt[q];
-            out_counts[q] = n;
-            const uint64_t w = std::min<uint64_t>(n, out_cap);
-            if (n > out_cap) truncated = true;
-            for (uint64_t i = 0; i < w; ++i) {
-                out_rows[(size_t)q * out_cap + i] = h_rows[(size_t)q * k_eff + i];
-                out_dist[(size_t)q * out_cap + i] = h_dist[(size_t)q * k_eff + i];
-            }
+            out[q].rows.assign(h_rows + (size_t)q * k_eff, h_rows + (size_t)q * k_eff + n);
+            out[q].dist.assign(h_dist + (size_t)q * k_eff, h_dist + (size_t)q * k_eff + n);
+            if (h_cnt[nq + q]) redo.push_back(q);  // (h_pinned is reused by the fallback: copy everything out first)
         }
-        if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
+        // queries whose f32 nomination could not be proven sufficient (a cluster of near-ties around the k-th
+        // place that is wider than the guard band): answer them exhaustively
+        for (uint32_t q : redo) {
+            const bool ws_thr = a.ws_threshold != 0;
+            const double bound = out[q].rows.size() == k_eff ? out[q].dist.back() : 1.0 - (double)a.ws_thr_score;
+            rc = exact_fallback(ctx, corpus, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr, nr ? d_cp : nullptr, nr, n_virtual,
+                                n_chunks, bound, k_eff, ws_thr, a.ws_thr_score, row_base, out[q]);
+            if (rc) return rc;
+        }
         return SMT_OK;
     }
 
     // ---------------- all rows with distance < max_distance (mod.rs:88-89,115-116)
-    bool truncated = false;
     for (uint32_t q = 0; q < nq; ++q) {
         ThresholdQuery t;
         t.corpus = corpus->d_rows;
@@ -821,16 +1029,126 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
         const double *h_dist = nullptr;
         uint64_t n_ok = 0;
         if ((rc = run_threshold_query(ctx, t, &h_rows, &h_dist, &n_ok))) return rc;
-        out_counts[q] = n_ok;
-        const uint64_t w = std::min<uint64_t>(n_ok, out_cap);
-        if (n_ok > out_cap) truncated = true;
-        for (uint64_t i = 0; i < w; ++i) {
-            out_rows[(size_t)q * out_cap + i] = row_base + h_rows[i];
-            out_dist[(size_t)q * out_cap + i] = h_dist[i];
+        out[q].rows.resize(n_ok);
+        for (uint64_t i = 0; i < n_ok; ++i) out[q].rows[i] = row_base + h_rows[i];
+        out[q].dist.assign(h_dist, h_dist + n_ok);
+    }
+    return SMT_OK;
+}
+
+// Copy per-query hit lists into the caller's [nq x out_cap] arrays; counts hold the TRUE sizes.
+int deliver_hits(const std::vector<LocalHits> &hits, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
+{
+    bool truncated = false;
+    for (size_t q = 0; q < hits.size(); ++q) {
+        const uint64_t n = hits[q].rows.size();
+        out_counts[q] = n;
+        const uint64_t w = std::min<uint64_t>(n, out_cap);
+        if (n > out_cap) truncated = true;
+        if (w) {
+            SMT_REQUIRE(out_rows && out_dist, "null output");
+            memcpy(out_rows + q * out_cap, hits[q].rows.data(), (size_t)w * sizeof(uint64_t));
+            memcpy(out_dist + q * out_cap, hits[q].dist.data(), (size_t)w * sizeof(double));
         }
     }
     if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
     return SMT_OK;
+}
+
+// One shard's top-k with everything on the device (the exchange path of group.cpp).  queries_dev [nq x 256];
+// ranges_local = sorted, disjoint LOCAL row ranges (host array); filtered && n_ranges == 0 means "the filter
+// leaves this shard nothing to scan".  packed_dev [nq][2][k_pad] receives global rows, then f64 distance bit
+// patterns, padded with (UINT64_MAX, +inf).  1 <= k_pad <= SCAN_MAX_K.  Enqueued on the context's stream (the
+// select stage on the aux stream when allow_async and the async_select tuning key say so); no host sync.
+int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t k_pad, int ws_threshold,
+                             float ws_thr_score, const smt_range *ranges_local, uint32_t n_ranges, bool filtered,
+                             uint64_t row_base, uint64_t *packed_dev, uint64_t *uncertain_dev, bool allow_async)
+{
+    SMT_REQUIRE(corpus && queries_dev && packed_dev, "null argument");
+    SMT_REQUIRE(k_pad >= 1 && k_pad <= SCAN_MAX_K, "top_k of the device exchange path must be in [1, 56]");
+    smt_ctx *ctx = corpus->ctx;
+    uint64_t n_virtual = corpus->rows;
+    std::vector<smt_range> rr;
+    if (filtered) {
+        uint64_t total = 0;
+        int rcv = validate_ranges(ranges_local, n_ranges, corpus->rows, &total);
+        if (rcv) return rcv;
+        for (uint32_t i = 0; i < n_ranges; ++i) if (ranges_local[i].end > ranges_local[i].begin) rr.push_back(ranges_local[i]);
+        n_virtual = total;
+    }
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k_pad, n_virtual);
+    const bool async = allow_async && ctx->tune.async_select && nq == 1 && !filtered && k_eff == k_pad;
+    int rc = bind_device(ctx, !async);
+    if (rc) return rc;
+    if (k_eff < k_pad) {  // short or empty shard: padding first, the select then overwrites the head of each list
+        if ((rc = launch_merge_topk_packed_on(ctx, ctx->stream, packed_dev, 0, nq, 1, k_pad, packed_dev))) return rc;
+        if (k_eff == 0) {
+            if (uncertain_dev) SMT_HIP_CHECK(hipMemsetAsync(uncertain_dev, 0, (size_t)nq * sizeof(uint64_t), ctx->stream));
+            return SMT_OK;
+        }
+    }
+    const uint32_t nr = (uint32_t)rr.size();
+    smt_range *d_r = nullptr;
+    uint64_t *d_p = nullptr, *d_cp = nullptr;
+    uint64_t n_chunks = 0;
+    if (nr) {
+        const size_t r_bytes = (size_t)nr * sizeof(smt_range), p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
+        if ((rc = ensure_stage(ctx, r_bytes + 2 * p_bytes + 64))) return rc;
+        char *stage = reinterpret_cast<char *>(ctx->d_stage);
+        d_r = reinterpret_cast<smt_range *>(stage);
+        d_p = reinterpret_cast<uint64_t *>(stage + r_bytes);
+        d_cp = reinterpret_cast<uint64_t *>(stage + r_bytes + p_bytes);
+        std::vector<uint64_t> prefix(nr + 1, 0), chunk_prefix(nr + 1, 0);
+        for (uint32_t i = 0; i < nr; ++i) {
+            const uint64_t len = rr[i].end - rr[i].begin;
+            prefix[i + 1] = prefix[i] + len;
+            chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
+        }
+        n_chunks = chunk_prefix[nr];
+        SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    }
+    ScanArgs a;
+    a.corpus = corpus->d_rows;
+    a.rows = corpus->rows;
+    a.queries = queries_dev;
+    a.nq = nq;
+    a.k_out = k_eff;
+    a.ranges = d_r;
+    a.range_prefix = d_p;
+    a.range_chunk_prefix = d_cp;
+    a.n_chunks = n_chunks;
+    a.n_ranges = nr;
+    a.n_virtual = n_virtual;
+    a.ws_threshold = ws_threshold;
+    a.ws_thr_score = ws_thr_score;
+    a.row_base = row_base;
+    a.out_rows = packed_dev;
+    a.out_dist = reinterpret_cast<double *>(packed_dev + k_pad);
+    a.out_counts = nullptr;
+    a.out_uncertain = uncertain_dev;
+    a.allow_async = async;
+    a.out_stride = (uint64_t)2 * k_pad;
+    rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
+    if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
+    return rc;
+}
+
+}  // namespace smt
+
+extern "C" {
+
+int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+               const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, uint64_t *out_rows, double *out_dist,
+               uint64_t *out_counts, uint64_t out_cap)
+{
+    SMT_REQUIRE(nq == 0 || out_counts, "null argument");
+    std::vector<LocalHits> hits;
+    int rc = search_local_host(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, hits);
+    if (rc) return rc;
+    return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
 }
 
 int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,
@@ -838,7 +1156,7 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
 {
     SMT_REQUIRE(corpus != nullptr, "corpus");
     SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
-    SMT_REQUIRE(top_k >= 1 && top_k <= 64, "top_k must be in [1, 64]");
+    SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
     smt_ctx *ctx = corpus->ctx;
     const bool async = ctx->tune.async_select && nq == 1 && corpus->rows > 0;  // launch_scan_topk keeps the pipeline going
     int rc = bind_device(ctx, !async);

@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -fno-gpu-rdc)
 objs=()
 newest_hdr="$(ls -t "$here"/*.h "$here"/host/*.h "$here"/../../include/*.h | head -1)"
-for src in api.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip largek.hip threshold.hip ivfpq_kernels.hip host/host.cpp host/host_capi.cpp; do
+for src in api.cpp group.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip largek.hip threshold.hip ivfpq_kernels.hip host/host.cpp host/host_capi.cpp; do
   base="$(basename "${src%.*}")"
   obj="$out/$base.o"
   if [[ ! -f "$obj" || "$here/$src" -nt "$obj" || "$newest_hdr" -nt "$obj" ]]; then
@@ -16,7 +16,7 @@ for src in api.cpp scan_kernels.hip embed_kernels.hip gemm_kernels.hip largek.hi
   fi
   objs+=("$obj")
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -pthread "${objs[@]}" -o "$out/libsemtools_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -pthread "${objs[@]}" -ldl -o "$out/libsemtools_hip.so"
 echo "built $out/libsemtools_hip.so"
 # CLI replica (host-only C++), finds the library next to it
 bin="$here/../bin"

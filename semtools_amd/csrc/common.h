@@ -35,6 +35,9 @@ void set_error(const char *fmt, ...);
         }                                                                                \
     } while (0)
 
+// bits of smt_ctx::attr_done
+enum : uint32_t { ATTR_SELECT = 1u, ATTR_GEMM = 2u, ATTR_IVF_ASSIGN = 4u, ATTR_IVF_SCORE = 8u, ATTR_GEMM_LDS = 16u };
+
 // One candidate on the device: key = (f32 distance bits << 32) | local row.
 // Distances are clipped to >= 0, so the IEEE bit pattern is order-preserving
 // and ascending u64 order == (distance asc, row asc).
@@ -82,10 +85,15 @@ struct smt_ctx {
     // async select (tuning key async_select): the select of query i runs on aux_stream WHILE query i+1 scans;
     // the two kernels meet through device-scope flags, not stream events
     hipStream_t aux_stream = nullptr;
+    unsigned long long *d_status = nullptr; // [0] selects whose exactness certificate failed since the last read (sticky)
     unsigned long long *d_flags = nullptr;  // [0] scan_done step, [1] select_done step, [2] blocks finished, [3] timeout flag
     uint64_t async_step = 0;
     bool async_pending = false;
     bool prof_on = false;
+    // kernels whose >64 KiB dynamic-LDS attribute has been set ON THIS DEVICE (bit per kernel family, smt::ATTR_*).
+    // Per context, not per process: hipFuncSetAttribute applies to the current device's copy of the function, and a
+    // group (group.cpp) owns one context per GPU inside one process.
+    uint32_t attr_done = 0;
     std::map<std::string, smt::ProfEntry> prof;
     smt::Tuning tune;
 };
@@ -144,7 +152,12 @@ struct ScanArgs {
     uint64_t *out_rows;
     double *out_dist;
     uint64_t *out_counts;     // may be nullptr
+    uint64_t *out_uncertain = nullptr;  // device [nq] or nullptr: 1 where the f32 nomination could not be PROVEN to
+                                        // contain the exact top-k (see SelectArgs::f32_err); the host API then
+                                        // re-answers that query exhaustively
     bool allow_async = false; // the caller does not read the outputs on the main stream before smt_ctx_synchronize
+    uint64_t out_stride = 0;  // words between the output lists of consecutive queries (0 = k_out); the packed
+                              // [nq][2][k] exchange layout of group.cpp uses 2*k with out_dist = out_rows + k
 };
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
 
@@ -171,10 +184,60 @@ int run_threshold_query(smt_ctx *ctx, const ThresholdQuery &t, const uint32_t **
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
                         uint64_t n, double *out_dist);
 
-int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
-                  uint32_t n_lists, uint32_t kp, uint64_t list_stride, uint32_t k_out, int ws_threshold,
-                  float ws_thr_score, uint64_t row_base, uint64_t *out_rows, double *out_dist,
-                  uint64_t *out_counts, uint64_t async_step = 0 /* != 0: on the aux stream, gated by the flags */);
+// Select stage: block lists -> best k_out per query with exact f64 distances (scan_kernels.hip).
+struct SelectArgs {
+    const float *corpus = nullptr;
+    const float *queries = nullptr;
+    uint32_t nq = 0;
+    key_t64 *lists = nullptr;      // query qi's lists start at lists + qi * list_stride: [n_lists][kp]
+    uint32_t n_lists = 0;
+    uint32_t kp = 0;
+    uint64_t list_stride = 0;
+    uint32_t k_out = 0;
+    int ws_threshold = 0;
+    float ws_thr_score = 0.f;
+    uint64_t row_base = 0;
+    uint64_t *out_rows = nullptr;
+    double *out_dist = nullptr;
+    uint64_t *out_counts = nullptr;
+    uint64_t async_step = 0;       // != 0: on the aux stream, gated by the flags
+    uint64_t out_stride = 0;       // 0 = k_out
+    // Exactness certificate.  The lists hold the kp best rows by the SCAN's f32 distance; every other row has
+    // d32 >= tau32 (the kp-th nominated), hence exact distance >= tau32 - f32_err when f32_err bounds the scan
+    // kernel's |d32 - d64|.  If the k_out-th exact distance is below that, no row outside the lists can belong to
+    // the answer: it is the exact top-k.  Otherwise the query is flagged (out_uncertain[q] = 1, the context's
+    // sticky counter is bumped) and the host entry points re-answer it exhaustively.  0 = no certificate (IVF-PQ).
+    double f32_err = 0.0;
+    uint64_t *out_uncertain = nullptr;
+};
+int launch_select(smt_ctx *ctx, const SelectArgs &s);
+
+// |f32 scan distance - exact distance| bounds used for the certificate: K2/K4 reduce 4 FMAs per lane + an 8-step
+// tree (<= 12 roundings of terms whose absolute sum is <= 1, plus two rsqrt/multiplies): < 1e-6; the MFMA path
+// accumulates 256 products sequentially: <= 256 * 2^-24 = 1.5e-5 in the worst case.
+constexpr double F32_ERR_SCAN = 4e-6;
+constexpr double F32_ERR_MFMA = 2e-5;
+// K2/K3 keep k + 8 <= 64 candidates per list: top_k above this goes to the all-keys path (largek.hip)
+constexpr uint32_t SCAN_MAX_K = 56;
+
+// per-query result list of the host-side search (api.cpp)
+struct LocalHits {
+    std::vector<uint64_t> rows;  // global rows (row_base added)
+    std::vector<double> dist;
+};
+int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+                      const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out);
+int deliver_hits(const std::vector<LocalHits> &hits, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap);
+int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t k_pad, int ws_threshold,
+                             float ws_thr_score, const smt_range *ranges_local, uint32_t n_ranges, bool filtered,
+                             uint64_t row_base, uint64_t *packed_dev, uint64_t *uncertain_dev, bool allow_async);
+// corpus file slices (api.cpp): shared by smt_corpus_save/load and the sharded corpus of group.cpp
+int corpus_file_info(const char *path, uint64_t *rows, uint32_t *dim);
+int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint64_t n_rows);
+int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows);
+int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row);
+int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *packed, uint32_t n_lists, uint32_t nq,
+                                uint32_t k_in, uint32_t k_out, uint64_t *out_packed, uint64_t list_stride_words = 0);
 
 int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
@@ -186,7 +249,8 @@ int launch_merge_topk_packed(smt_ctx *ctx, const uint64_t *packed, uint32_t n_li
 // top_k > 64 (rare): all keys + radix sort + exact rescoring of the best n_cand rows
 int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *query_dev, const smt_range *ranges_dev,
                              const uint64_t *prefix_dev, uint32_t n_ranges, uint64_t n_virtual, uint64_t n_cand,
-                             std::vector<uint32_t> &rows_out, std::vector<double> &dist_out);
+                             std::vector<uint32_t> &rows_out, std::vector<double> &dist_out, float *next_d32 = nullptr
+                             /* f32 distance of the best row NOT among the candidates (+inf if none) */);
 
 // K1
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,

@@ -404,6 +404,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const uint32_t kp = a.k_out + 8;
     const uint32_t nqt = (a.nq + QT_ROWS - 1) / QT_ROWS;
+    const uint64_t ostride = a.out_stride ? a.out_stride : a.k_out;
     if (a.nq > GEMM_MAX_NQ) {
         // the per-query thresholds of one launch live in LDS beside the four query-tile slots: larger batches
         // are answered in chunks (each chunk is its own sweep over the corpus -- inherent at this batch size)
@@ -411,9 +412,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             ScanArgs c = a;
             c.nq = std::min<uint32_t>(GEMM_MAX_NQ, a.nq - q0);
             c.queries = a.queries + (size_t)q0 * 256;
-            c.out_rows = a.out_rows + (size_t)q0 * a.k_out;
-            c.out_dist = a.out_dist + (size_t)q0 * a.k_out;
+            c.out_rows = a.out_rows + (size_t)q0 * ostride;
+            c.out_dist = a.out_dist + (size_t)q0 * ostride;
             c.out_counts = a.out_counts ? a.out_counts + q0 : nullptr;
+            c.out_uncertain = a.out_uncertain ? a.out_uncertain + q0 : nullptr;
             const int rc_chunk = launch_gemm_topk(ctx, c);
             if (rc_chunk) return rc_chunk;
         }
@@ -421,8 +423,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     }
     if (gemm_smem_bytes(nqt) > 160 * 1024) { set_error("batch too large for one launch"); return SMT_E_UNSUPPORTED; }
 
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->attr_done & ATTR_GEMM)) {  // per context == per device
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<1>),
@@ -431,7 +432,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        ctx->attr_done |= ATTR_GEMM;
     }
 
     // scratch: cand [nq][CAP] keys | counts [nq] | overflow [nq] | tau [nqt*32]
@@ -508,8 +509,25 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     SMT_HIP_CHECK(hipGetLastError());
 
     // each query now has ONE sorted list of kp keys at the head of its buffer
-    rc = launch_select(ctx, a.corpus, a.queries, a.nq, cand, 1, kp, CAND_CAP, a.k_out, a.ws_threshold, a.ws_thr_score,
-                       a.row_base, a.out_rows, a.out_dist, a.out_counts);
+    SelectArgs sel;
+    sel.corpus = a.corpus;
+    sel.queries = a.queries;
+    sel.nq = a.nq;
+    sel.lists = cand;
+    sel.n_lists = 1;
+    sel.kp = kp;
+    sel.list_stride = CAND_CAP;
+    sel.k_out = a.k_out;
+    sel.ws_threshold = a.ws_threshold;
+    sel.ws_thr_score = a.ws_thr_score;
+    sel.row_base = a.row_base;
+    sel.out_rows = a.out_rows;
+    sel.out_dist = a.out_dist;
+    sel.out_counts = a.out_counts;
+    sel.out_stride = a.out_stride;
+    sel.f32_err = F32_ERR_MFMA;
+    sel.out_uncertain = a.out_uncertain;
+    rc = launch_select(ctx, sel);
     if (rc) return rc;
 
     // overflow check (host sync: a batch is tens of milliseconds, the flag read is noise)
@@ -521,9 +539,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         ScanArgs one = a;  // exact fallback for this query through K2
         one.queries = a.queries + (size_t)q * 256;
         one.nq = 1;
-        one.out_rows = a.out_rows + (size_t)q * a.k_out;
-        one.out_dist = a.out_dist + (size_t)q * a.k_out;
+        one.out_rows = a.out_rows + (size_t)q * ostride;
+        one.out_dist = a.out_dist + (size_t)q * ostride;
         one.out_counts = a.out_counts ? a.out_counts + q : nullptr;
+        one.out_uncertain = a.out_uncertain ? a.out_uncertain + q : nullptr;
         if ((rc = launch_scan_topk(ctx, one))) return rc;
     }
     return SMT_OK;

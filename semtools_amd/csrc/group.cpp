@@ -1,0 +1,897 @@
+// group.cpp -- the multi-GPU half of libsemtools_hip.so: a GROUP of GPUs behind the C ABI, a corpus row-sharded
+// over them, and searches whose only collective is one RCCL all-gather of the per-shard top-k lists.
+//
+// No reference counterpart: the reference is single-process CPU code (src/bin/semtools.rs:134-135 runs the whole
+// search synchronously from one task).  That caller is what this file is shaped for: ONE host thread calls
+// smt_init / smt_sharded_search and the library drives every GPU of the node from it --
+//   * single process:     smt_group_create(devices, n)  -> ncclCommInitAll, one context + stream per device;
+//   * one rank per process (torchrun, MPI): smt_group_unique_id on rank 0, broadcast the 128 bytes by any
+//     means, smt_group_create_rank(device, rank, n_ranks, id) -> ncclCommInitRank.  Calls are then SPMD: every
+//     process makes the same calls with the same host arguments.
+// Partitioning: contiguous row ranges, rows_per_rank = ceil(N / n_ranks), so a document's lines and
+// the path-subset ranges of workspace searches stay ranges.  Exchange: rank r's select stage writes its k best
+// (global row, exact f64 distance) pairs into one packed buffer; ncclAllGather moves k x 16 B per query per rank
+// (latency-bound: xGMI bandwidth is irrelevant); merge_topk_kernel reduces the n_ranks lists to the global
+// top-k.  Threshold mode (variable result sizes): all-gather of the counts, then ONE all-gather of a
+// max-count-padded buffer, then a host merge of the sorted lists.
+//
+// RCCL is loaded lazily (dlopen) when the first group is created: single-GPU users -- the `semtools search` CLI
+// -- never pay for mapping it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <thread>
+
+#include "common.h"
+
+namespace smt {
+
+// ------------------------------------------------------------------ RCCL, loaded on demand
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl()
+{
+    if (g_rccl.handle) return SMT_OK;
+    // An RCCL already mapped into the process (PyTorch ships its own copy under the same SONAME) wins: two RCCLs
+    // in one process would each own a set of IPC handles and proxy threads.
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { set_error("cannot load RCCL (librccl.so.1): %s", dlerror()); return SMT_E_HIP; }
+#define SMT_RCCL_SYM(name)                                                                  \
+    g_rccl.name = reinterpret_cast<decltype(g_rccl.name)>(dlsym(h, "nccl" #name));          \
+    if (!g_rccl.name) { set_error("RCCL lacks nccl" #name); dlclose(h); return SMT_E_HIP; }
+    SMT_RCCL_SYM(GetVersion)
+    SMT_RCCL_SYM(GetUniqueId)
+    SMT_RCCL_SYM(CommInitRank)
+    SMT_RCCL_SYM(CommInitAll)
+    SMT_RCCL_SYM(CommDestroy)
+    SMT_RCCL_SYM(CommCount)
+    SMT_RCCL_SYM(CommUserRank)
+    SMT_RCCL_SYM(AllGather)
+    SMT_RCCL_SYM(AllReduce)
+    SMT_RCCL_SYM(GroupStart)
+    SMT_RCCL_SYM(GroupEnd)
+    SMT_RCCL_SYM(GetErrorString)
+#undef SMT_RCCL_SYM
+    g_rccl.handle = h;
+    return SMT_OK;
+}
+
+#define SMT_NCCL_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        ncclResult_t _r = (expr);                                                              \
+        if (_r != ncclSuccess) {                                                               \
+            smt::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+            return SMT_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+}  // namespace smt
+
+using namespace smt;
+
+// One exchange workspace per local device, grown on demand.
+struct GroupBuf {
+    void *dev = nullptr;
+    size_t dev_bytes = 0;
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+struct smt_group {
+    int n_ranks = 0;
+    int n_local = 0;
+    int first_rank = 0;              // local device i is rank first_rank + i
+    std::vector<smt_ctx *> ctx;      // [n_local], owned
+    std::vector<ncclComm_t> comm;    // [n_local]
+    std::vector<GroupBuf> buf;       // [n_local]
+    int rccl_version = 0;
+    // Copy transport (smt_group_create_logical): every rank is a context of THIS process, possibly several on one
+    // device; the all-gather is n x n device copies ordered by events instead of an RCCL collective.
+    bool copies = false;
+    std::vector<hipEvent_t> ev_ready;   // [n_local] rank j's send buffer is complete
+    std::vector<hipEvent_t> ev_done;    // [n_local] rank i has finished reading everybody's send buffer
+};
+
+struct smt_sharded_corpus {
+    smt_group *group = nullptr;
+    uint32_t dim = SMT_DIM;
+    std::vector<smt_corpus *> shard;   // [n_local], owned handles (rows themselves may be adopted device memory)
+    std::vector<uint64_t> rank_rows;   // [n_ranks]
+    std::vector<uint64_t> rank_base;   // [n_ranks + 1] exclusive prefix
+};
+
+namespace smt {
+
+static smt_group *g_default_group = nullptr;
+
+static int group_bind(smt_group *g, int i)
+{
+    SMT_HIP_CHECK(hipSetDevice(g->ctx[i]->device));
+    return SMT_OK;
+}
+
+static int ensure_dev(smt_group *g, int i, size_t bytes)
+{
+    GroupBuf &b = g->buf[i];
+    if (bytes <= b.dev_bytes) return SMT_OK;
+    smt_ctx *c = g->ctx[i];
+    int rc = drain_async(c);
+    if (rc) return rc;
+    SMT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->aux_stream) SMT_HIP_CHECK(hipStreamSynchronize(c->aux_stream));
+    if (b.dev) SMT_HIP_CHECK(hipFree(b.dev));
+    b.dev = nullptr;
+    b.dev_bytes = 0;
+    const size_t want = std::max(bytes, (size_t)1 << 16);
+    SMT_HIP_CHECK(hipMalloc(&b.dev, want));
+    b.dev_bytes = want;
+    return SMT_OK;
+}
+
+static int ensure_host(smt_group *g, int i, size_t bytes)
+{
+    GroupBuf &b = g->buf[i];
+    if (bytes <= b.pinned_bytes) return SMT_OK;
+    SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));
+    if (b.pinned) SMT_HIP_CHECK(hipHostFree(b.pinned));
+    b.pinned = nullptr;
+    b.pinned_bytes = 0;
+    const size_t want = std::max(bytes, (size_t)1 << 16);
+    SMT_HIP_CHECK(hipHostMalloc(&b.pinned, want, hipHostMallocDefault));
+    b.pinned_bytes = want;
+    return SMT_OK;
+}
+
+// All-gather `words` u64 per rank: send_off/recv_off are BYTE offsets into each local device's exchange buffer.
+// The streams are the contexts' main streams, or their aux streams where on_aux[i] (async select pipeline).
+static int allgather_words(smt_group *g, size_t send_off, size_t recv_off, size_t words, const std::vector<char> *on_aux = nullptr)
+{
+    if (g->copies) {
+        auto stream_of = [&](int i) { return (on_aux && (*on_aux)[i]) ? g->ctx[i]->aux_stream : g->ctx[i]->stream; };
+        for (int j = 0; j < g->n_local; ++j) {
+            SMT_HIP_CHECK(hipSetDevice(g->ctx[j]->device));
+            SMT_HIP_CHECK(hipEventRecord(g->ev_ready[j], stream_of(j)));
+        }
+        for (int i = 0; i < g->n_local; ++i) {
+            SMT_HIP_CHECK(hipSetDevice(g->ctx[i]->device));
+            char *dst = reinterpret_cast<char *>(g->buf[i].dev) + recv_off;
+            for (int j = 0; j < g->n_local; ++j) {
+                if (j != i) SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(i), g->ev_ready[j], 0));
+                const char *src = reinterpret_cast<const char *>(g->buf[j].dev) + send_off;
+                SMT_HIP_CHECK(hipMemcpyPeerAsync(dst + (size_t)j * words * 8, g->ctx[i]->device, src, g->ctx[j]->device, words * 8,
+                                                 stream_of(i)));
+            }
+            SMT_HIP_CHECK(hipEventRecord(g->ev_done[i], stream_of(i)));
+        }
+        // a rank may not overwrite its send buffer (next call) before every reader is done with it
+        for (int j = 0; j < g->n_local; ++j) {
+            SMT_HIP_CHECK(hipSetDevice(g->ctx[j]->device));
+            for (int i = 0; i < g->n_local; ++i)
+                if (i != j) SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(j), g->ev_done[i], 0));
+        }
+        return SMT_OK;
+    }
+    SMT_NCCL_CHECK(g_rccl.GroupStart());
+    for (int i = 0; i < g->n_local; ++i) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        char *base = reinterpret_cast<char *>(g->buf[i].dev);
+        hipStream_t st = (on_aux && (*on_aux)[i]) ? g->ctx[i]->aux_stream : g->ctx[i]->stream;
+        ncclResult_t r = g_rccl.AllGather(base + send_off, base + recv_off, words, ncclUint64, g->comm[i], st);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            set_error("ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+            return SMT_E_HIP;
+        }
+    }
+    SMT_NCCL_CHECK(g_rccl.GroupEnd());
+    return SMT_OK;
+}
+
+static int group_sync_all(smt_group *g)
+{
+    for (int i = 0; i < g->n_local; ++i) {
+        int rc = group_bind(g, i);
+        if (rc) return rc;
+        SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));
+        if ((rc = drain_async(g->ctx[i]))) return rc;
+    }
+    return SMT_OK;
+}
+
+// A barrier across ranks that also proves the communicator works: all-gather one word per rank.
+static int group_barrier(smt_group *g)
+{
+    const size_t words = 1;
+    for (int i = 0; i < g->n_local; ++i) {
+        int rc = group_bind(g, i);
+        if (rc) return rc;
+        if ((rc = ensure_dev(g, i, (size_t)(1 + g->n_ranks) * 8 + 64))) return rc;
+        const uint64_t me = (uint64_t)(g->first_rank + i);
+        SMT_HIP_CHECK(hipMemcpyAsync(g->buf[i].dev, &me, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    int rc = allgather_words(g, 0, 8, words);
+    if (rc) return rc;
+    for (int i = 0; i < g->n_local; ++i) {
+        if ((rc = group_bind(g, i))) return rc;
+        std::vector<uint64_t> got(g->n_ranks);
+        SMT_HIP_CHECK(hipMemcpyAsync(got.data(), reinterpret_cast<char *>(g->buf[i].dev) + 8, (size_t)g->n_ranks * 8,
+                                     hipMemcpyDeviceToHost, g->ctx[i]->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));
+        for (int r = 0; r < g->n_ranks; ++r)
+            if (got[r] != (uint64_t)r) { set_error("RCCL all-gather returned rank %llu in slot %d", (unsigned long long)got[r], r); return SMT_E_HIP; }
+    }
+    return SMT_OK;
+}
+
+static void group_free(smt_group *g)
+{
+    if (!g) return;
+    for (int i = 0; i < (int)g->ctx.size(); ++i) {
+        if (!g->ctx[i]) continue;
+        (void)hipSetDevice(g->ctx[i]->device);
+        (void)hipStreamSynchronize(g->ctx[i]->stream);
+        (void)drain_async(g->ctx[i]);
+        if (i < (int)g->comm.size() && g->comm[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm[i]);
+        if (i < (int)g->ev_ready.size() && g->ev_ready[i]) (void)hipEventDestroy(g->ev_ready[i]);
+        if (i < (int)g->ev_done.size() && g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
+        if (i < (int)g->buf.size()) {
+            if (g->buf[i].dev) (void)hipFree(g->buf[i].dev);
+            if (g->buf[i].pinned) (void)hipHostFree(g->buf[i].pinned);
+        }
+        smt_ctx_destroy(g->ctx[i]);
+    }
+    delete g;
+}
+
+static int group_make_contexts(smt_group *g, const int *devices, int n)
+{
+    g->ctx.assign(n, nullptr);
+    g->comm.assign(n, nullptr);
+    g->buf.assign(n, GroupBuf());
+    for (int i = 0; i < n; ++i) {
+        int rc = smt_ctx_create(devices[i], &g->ctx[i]);
+        if (rc) return rc;
+    }
+    return SMT_OK;
+}
+
+// Global ranges -> the part inside [base, base + rows), in local row numbers.
+static void localize_ranges(const smt_range *ranges, uint32_t n, uint64_t base, uint64_t rows, std::vector<smt_range> &out)
+{
+    out.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t b = std::max(ranges[i].begin, base), e = std::min(ranges[i].end, base + rows);
+        if (e > b) out.push_back(smt_range{b - base, e - base});
+    }
+}
+
+static int validate_global_ranges(const smt_range *ranges, uint32_t n, uint64_t rows)
+{
+    uint64_t prev_end = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        SMT_REQUIRE(ranges[i].begin <= ranges[i].end, "range begin > end");
+        SMT_REQUIRE(ranges[i].end <= rows, "range extends past the corpus");
+        SMT_REQUIRE(i == 0 || ranges[i].begin >= prev_end, "ranges must be sorted and disjoint");
+        prev_end = ranges[i].end;
+    }
+    return SMT_OK;
+}
+
+// ---------------------------------------------------------------- generic (host-list) exchange
+// Every local shard holds per-query hit lists of any length, sorted (distance asc, row asc), rows global.  All-gather
+// of the counts, one all-gather of a max-count-padded buffer, host merge.  `keep` truncates after the merge
+// (UINT64_MAX = keep all: search_documents with a threshold, src/search/mod.rs:115-116).
+static int exchange_host_lists(smt_group *g, const std::vector<std::vector<LocalHits>> &local /* [n_local][nq] */, uint32_t nq,
+                               uint64_t keep, std::vector<LocalHits> &merged)
+{
+    merged.assign(nq, LocalHits());
+    if (nq == 0) return SMT_OK;
+    const int R = g->n_ranks;
+    int rc;
+    // ---- counts
+    for (int i = 0; i < g->n_local; ++i) {
+        if ((rc = group_bind(g, i))) return rc;
+        if ((rc = ensure_dev(g, i, (size_t)(1 + R) * nq * 8 + 64))) return rc;
+        std::vector<uint64_t> cnt(nq);
+        for (uint32_t q = 0; q < nq; ++q) cnt[q] = local[i][q].rows.size();
+        SMT_HIP_CHECK(hipMemcpyAsync(g->buf[i].dev, cnt.data(), (size_t)nq * 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    if ((rc = allgather_words(g, 0, (size_t)nq * 8, nq))) return rc;
+    std::vector<uint64_t> counts((size_t)R * nq);
+    if ((rc = group_bind(g, 0))) return rc;
+    SMT_HIP_CHECK(hipMemcpyAsync(counts.data(), reinterpret_cast<char *>(g->buf[0].dev) + (size_t)nq * 8, counts.size() * 8,
+                                 hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    if ((rc = group_sync_all(g))) return rc;
+    std::vector<uint64_t> width(nq, 0), off(nq + 1, 0);
+    for (uint32_t q = 0; q < nq; ++q) {
+        for (int r = 0; r < R; ++r) width[q] = std::max(width[q], counts[(size_t)r * nq + q]);
+        off[q + 1] = off[q] + 2 * width[q];
+    }
+    const size_t words = off[nq];  // per rank
+    if (words == 0) return SMT_OK;
+    // ---- padded payload: per query [rows | distance bits], width[q] each
+    const size_t send_bytes = words * 8, recv_off = (send_bytes + 255) & ~(size_t)255;
+    for (int i = 0; i < g->n_local; ++i) {
+        if ((rc = group_bind(g, i))) return rc;
+        if ((rc = ensure_dev(g, i, recv_off + (size_t)R * send_bytes + 64))) return rc;
+        if ((rc = ensure_host(g, i, std::max(send_bytes, i == 0 ? (size_t)R * send_bytes : (size_t)0)))) return rc;
+        uint64_t *h = reinterpret_cast<uint64_t *>(g->buf[i].pinned);
+        for (uint32_t q = 0; q < nq; ++q) {
+            const LocalHits &l = local[i][q];
+            uint64_t *rows = h + off[q], *bits = rows + width[q];
+            for (uint64_t e = 0; e < width[q]; ++e) {
+                if (e < l.rows.size()) { rows[e] = l.rows[e]; memcpy(bits + e, &l.dist[e], 8); }
+                else { rows[e] = UINT64_MAX; bits[e] = 0x7FF0000000000000ull; }
+            }
+        }
+        SMT_HIP_CHECK(hipMemcpyAsync(g->buf[i].dev, h, send_bytes, hipMemcpyHostToDevice, g->ctx[i]->stream));
+    }
+    if ((rc = allgather_words(g, 0, recv_off, words))) return rc;
+    if ((rc = group_bind(g, 0))) return rc;
+    uint64_t *all = reinterpret_cast<uint64_t *>(g->buf[0].pinned);
+    SMT_HIP_CHECK(hipMemcpyAsync(all, reinterpret_cast<char *>(g->buf[0].dev) + recv_off, (size_t)R * send_bytes,
+                                 hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    if ((rc = group_sync_all(g))) return rc;
+    // ---- merge.  Shards are ascending contiguous row ranges and every list is (distance, row)-sorted, so sorting
+    // the union by (distance, row) reproduces the reference's stable sort over the whole corpus (mod.rs:107-111).
+    std::vector<std::pair<double, uint64_t>> cand;
+    for (uint32_t q = 0; q < nq; ++q) {
+        cand.clear();
+        for (int r = 0; r < R; ++r) {
+            const uint64_t *rows = all + (size_t)r * words + off[q], *bits = rows + width[q];
+            const uint64_t n = counts[(size_t)r * nq + q];
+            for (uint64_t e = 0; e < n; ++e) {
+                double d;
+                memcpy(&d, bits + e, 8);
+                cand.emplace_back(d, rows[e]);
+            }
+        }
+        std::sort(cand.begin(), cand.end());
+        const uint64_t n = std::min<uint64_t>(cand.size(), keep);
+        merged[q].rows.resize(n);
+        merged[q].dist.resize(n);
+        for (uint64_t e = 0; e < n; ++e) { merged[q].dist[e] = cand[e].first; merged[q].rows[e] = cand[e].second; }
+    }
+    return SMT_OK;
+}
+
+// Per-shard host search of a query subset on every local device (one host thread per device when there are
+// several: the K4 / large-k paths synchronise internally and would otherwise serialise the GPUs).
+static int local_host_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq, uint32_t top_k, double max_distance,
+                             int mode, const smt_range *ranges, uint32_t n_ranges, std::vector<std::vector<LocalHits>> &local)
+{
+    smt_group *g = sc->group;
+    local.assign(g->n_local, std::vector<LocalHits>(nq));
+    std::vector<int> rcs(g->n_local, SMT_OK);
+    std::vector<std::string> errs(g->n_local);
+    auto work = [&](int i) {
+        const int r = g->first_rank + i;
+        std::vector<smt_range> lr;
+        if (n_ranges) {
+            localize_ranges(ranges, n_ranges, sc->rank_base[r], sc->rank_rows[r], lr);
+            if (lr.empty()) return;  // the filter leaves this shard nothing
+        }
+        rcs[i] = search_local_host(sc->shard[i], queries, nq, top_k, max_distance, mode, lr.empty() ? nullptr : lr.data(),
+                                   (uint32_t)lr.size(), sc->rank_base[r], local[i]);
+        if (rcs[i]) errs[i] = smt_last_error();
+    };
+    if (g->n_local == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < g->n_local; ++i) th.emplace_back(work, i);
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < g->n_local; ++i)
+        if (rcs[i]) { set_error("shard %d: %s", g->first_rank + i, errs[i].c_str()); return rcs[i]; }
+    return SMT_OK;
+}
+
+}  // namespace smt
+
+extern "C" {
+
+/* ------------------------------------------------------------------ group ---- */
+
+int smt_group_create(const int *devices, int n_dev, smt_group **out)
+{
+    SMT_REQUIRE(out != nullptr, "out");
+    *out = nullptr;
+    SMT_REQUIRE(devices != nullptr && n_dev >= 1, "device list");
+    for (int i = 0; i < n_dev; ++i)
+        for (int j = 0; j < i; ++j) SMT_REQUIRE(devices[i] != devices[j], "a device may appear once in a group");
+    int rc = load_rccl();
+    if (rc) return rc;
+    smt_group *g = new (std::nothrow) smt_group();
+    if (!g) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    g->n_ranks = g->n_local = n_dev;
+    g->first_rank = 0;
+    if ((rc = group_make_contexts(g, devices, n_dev))) { group_free(g); return rc; }
+    (void)g_rccl.GetVersion(&g->rccl_version);
+    ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), n_dev, devices);
+    if (r != ncclSuccess) { set_error("ncclCommInitAll(%d devices): %s", n_dev, g_rccl.GetErrorString(r)); group_free(g); return SMT_E_HIP; }
+    if ((rc = group_barrier(g))) { group_free(g); return rc; }  // channel set-up happens on the first collective: do it now
+    *out = g;
+    return SMT_OK;
+}
+
+int smt_group_create_logical(int device, int n_shards, smt_group **out)
+{
+    SMT_REQUIRE(out != nullptr, "out");
+    *out = nullptr;
+    SMT_REQUIRE(n_shards >= 1 && n_shards <= 64, "1..64 logical shards");
+    smt_group *g = new (std::nothrow) smt_group();
+    if (!g) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    g->n_ranks = g->n_local = n_shards;
+    g->first_rank = 0;
+    g->copies = true;
+    std::vector<int> devs(n_shards, device);
+    int rc = group_make_contexts(g, devs.data(), n_shards);
+    if (rc) { group_free(g); return rc; }
+    g->ev_ready.assign(n_shards, nullptr);
+    g->ev_done.assign(n_shards, nullptr);
+    for (int i = 0; i < n_shards; ++i) {
+        hipError_t e = hipEventCreateWithFlags(&g->ev_ready[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); group_free(g); return SMT_E_HIP; }
+    }
+    if ((rc = group_barrier(g))) { group_free(g); return rc; }
+    *out = g;
+    return SMT_OK;
+}
+
+int smt_group_unique_id(void *id_out)
+{
+    SMT_REQUIRE(id_out != nullptr, "id_out");
+    int rc = load_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == SMT_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    SMT_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return SMT_OK;
+}
+
+int smt_group_create_rank(int device, int rank, int n_ranks, const void *unique_id, smt_group **out)
+{
+    SMT_REQUIRE(out != nullptr, "out");
+    *out = nullptr;
+    SMT_REQUIRE(unique_id != nullptr, "unique_id");
+    SMT_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank / n_ranks");
+    int rc = load_rccl();
+    if (rc) return rc;
+    smt_group *g = new (std::nothrow) smt_group();
+    if (!g) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    g->n_ranks = n_ranks;
+    g->n_local = 1;
+    g->first_rank = rank;
+    if ((rc = group_make_contexts(g, &device, 1))) { group_free(g); return rc; }
+    (void)g_rccl.GetVersion(&g->rccl_version);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    (void)hipSetDevice(device);
+    ncclResult_t r = g_rccl.CommInitRank(&g->comm[0], n_ranks, id, rank);
+    if (r != ncclSuccess) { set_error("ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, g_rccl.GetErrorString(r)); group_free(g); return SMT_E_HIP; }
+    if ((rc = group_barrier(g))) { group_free(g); return rc; }
+    *out = g;
+    return SMT_OK;
+}
+
+void smt_group_destroy(smt_group *group)
+{
+    if (group == g_default_group) g_default_group = nullptr;
+    group_free(group);
+}
+
+int smt_group_info(const smt_group *group, int *n_ranks, int *n_local, int *first_rank, int *rccl_ranks, int *rccl_version)
+{
+    SMT_REQUIRE(group != nullptr, "group");
+    if (n_ranks) *n_ranks = group->n_ranks;
+    if (n_local) *n_local = group->n_local;
+    if (first_rank) *first_rank = group->first_rank;
+    if (rccl_version) *rccl_version = group->rccl_version;
+    if (rccl_ranks) {
+        int count = 0;  // copy transport: no communicator
+        if (!group->copies) SMT_NCCL_CHECK(g_rccl.CommCount(group->comm[0], &count));  // what the communicator itself reports
+        *rccl_ranks = count;
+    }
+    return SMT_OK;
+}
+
+smt_ctx *smt_group_ctx(smt_group *group, int local_index)
+{
+    if (!group || local_index < 0 || local_index >= group->n_local) return nullptr;
+    return group->ctx[local_index];
+}
+
+int smt_group_synchronize(smt_group *group)
+{
+    SMT_REQUIRE(group != nullptr, "group");
+    return group_sync_all(group);
+}
+
+int smt_group_barrier(smt_group *group)
+{
+    SMT_REQUIRE(group != nullptr, "group");
+    int rc = group_sync_all(group);
+    if (rc) return rc;
+    return group_barrier(group);
+}
+
+int smt_init(const int *devices, int n_dev)
+{
+    if (g_default_group) {
+        // idempotent for the same device list
+        bool same = g_default_group->n_local == n_dev;
+        for (int i = 0; same && i < n_dev; ++i) same = devices && g_default_group->ctx[i]->device == devices[i];
+        if (same) return SMT_OK;
+        set_error("smt_init was already called with a different device list (call smt_shutdown first)");
+        return SMT_E_INVALID;
+    }
+    std::vector<int> all;
+    if (!devices || n_dev <= 0) {  // NULL / 0 = every visible GPU
+        const int n = smt_device_count();
+        if (n <= 0) { if (n == 0) set_error("no HIP device visible: libsemtools_hip has no CPU fallback"); return SMT_E_HIP; }
+        for (int i = 0; i < n; ++i) all.push_back(i);
+        devices = all.data();
+        n_dev = n;
+    }
+    return smt_group_create(devices, n_dev, &g_default_group);
+}
+
+int smt_shutdown(void)
+{
+    smt_group *g = g_default_group;
+    g_default_group = nullptr;
+    group_free(g);
+    return SMT_OK;
+}
+
+smt_group *smt_default_group(void) { return g_default_group; }
+
+/* --------------------------------------------------------- sharded corpus ---- */
+
+static int sharded_set_rows(smt_sharded_corpus *sc, const std::vector<uint64_t> &rank_rows)
+{
+    sc->rank_rows = rank_rows;
+    sc->rank_base.assign(rank_rows.size() + 1, 0);
+    for (size_t r = 0; r < rank_rows.size(); ++r) sc->rank_base[r + 1] = sc->rank_base[r] + rank_rows[r];
+    return SMT_OK;
+}
+
+// rows_per_rank = ceil(N / n_ranks): SURVEY 8(e)
+static void partition_rows(uint64_t total, int n_ranks, std::vector<uint64_t> &rank_rows)
+{
+    const uint64_t per = n_ranks > 0 ? (total + (uint64_t)n_ranks - 1) / (uint64_t)n_ranks : 0;
+    rank_rows.assign(n_ranks, 0);
+    for (int r = 0; r < n_ranks; ++r) {
+        const uint64_t b = std::min<uint64_t>((uint64_t)r * per, total), e = std::min<uint64_t>((uint64_t)(r + 1) * per, total);
+        rank_rows[r] = e - b;
+    }
+}
+
+void smt_sharded_corpus_destroy(smt_sharded_corpus *sc)
+{
+    if (!sc) return;
+    for (smt_corpus *c : sc->shard) smt_corpus_destroy(c);
+    delete sc;
+}
+
+int smt_sharded_corpus_from_host(smt_group *group, const float *rows, uint64_t total_rows, uint32_t D, smt_sharded_corpus **out)
+{
+    SMT_REQUIRE(group && out, "null argument");
+    *out = nullptr;
+    SMT_REQUIRE(rows || total_rows == 0, "rows");
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
+    smt_sharded_corpus *sc = new (std::nothrow) smt_sharded_corpus();
+    if (!sc) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    sc->group = group;
+    std::vector<uint64_t> rr;
+    partition_rows(total_rows, group->n_ranks, rr);
+    sharded_set_rows(sc, rr);
+    sc->shard.assign(group->n_local, nullptr);
+    for (int i = 0; i < group->n_local; ++i) {
+        const int r = group->first_rank + i;
+        int rc = smt_corpus_create(group->ctx[i], D, sc->rank_rows[r], &sc->shard[i]);
+        if (!rc && sc->rank_rows[r])
+            rc = smt_corpus_append_host(sc->shard[i], rows + (size_t)sc->rank_base[r] * D, sc->rank_rows[r], nullptr);
+        if (rc) { smt_sharded_corpus_destroy(sc); return rc; }
+    }
+    *out = sc;
+    return SMT_OK;
+}
+
+int smt_sharded_corpus_from_device(smt_group *group, const float *const *shard_rows_dev, const uint64_t *shard_rows, uint32_t D,
+                                   smt_sharded_corpus **out)
+{
+    SMT_REQUIRE(group && out && shard_rows_dev && shard_rows, "null argument");
+    *out = nullptr;
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported", D); return SMT_E_UNSUPPORTED; }
+    smt_sharded_corpus *sc = new (std::nothrow) smt_sharded_corpus();
+    if (!sc) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    sc->group = group;
+    sc->shard.assign(group->n_local, nullptr);
+    int rc = SMT_OK;
+    for (int i = 0; i < group->n_local && !rc; ++i)
+        rc = smt_corpus_from_device(group->ctx[i], shard_rows_dev[i], shard_rows[i], D, &sc->shard[i]);
+    // every rank's row count (the bases of the global row numbering): one all-gather of a word per rank
+    for (int i = 0; i < group->n_local && !rc; ++i) {
+        if ((rc = group_bind(group, i))) break;
+        if ((rc = ensure_dev(group, i, (size_t)(1 + group->n_ranks) * 8 + 64))) break;
+        hipError_t e = hipMemcpyAsync(group->buf[i].dev, &shard_rows[i], 8, hipMemcpyHostToDevice, group->ctx[i]->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(group->ctx[i]->stream);
+        if (e != hipSuccess) { set_error("shard size upload: %s", hipGetErrorString(e)); rc = SMT_E_HIP; }
+    }
+    if (!rc) rc = allgather_words(group, 0, 8, 1);
+    std::vector<uint64_t> rr(group->n_ranks, 0);
+    if (!rc && !(rc = group_bind(group, 0))) {
+        hipError_t e = hipMemcpyAsync(rr.data(), reinterpret_cast<char *>(group->buf[0].dev) + 8, (size_t)group->n_ranks * 8,
+                                      hipMemcpyDeviceToHost, group->ctx[0]->stream);
+        if (e != hipSuccess) { set_error("shard size download: %s", hipGetErrorString(e)); rc = SMT_E_HIP; }
+    }
+    if (!rc) rc = group_sync_all(group);
+    if (rc) { smt_sharded_corpus_destroy(sc); return rc; }
+    sharded_set_rows(sc, rr);
+    *out = sc;
+    return SMT_OK;
+}
+
+int smt_sharded_corpus_load(smt_group *group, const char *path, smt_sharded_corpus **out)
+{
+    SMT_REQUIRE(group && path && out, "null argument");
+    *out = nullptr;
+    uint64_t total = 0;
+    uint32_t dim = 0;
+    int rc = corpus_file_info(path, &total, &dim);
+    if (rc) return rc;
+    if (dim != SMT_DIM) { set_error("'%s' holds %u-dimensional rows; kernels are specialised for 256", path, dim); return SMT_E_UNSUPPORTED; }
+    smt_sharded_corpus *sc = new (std::nothrow) smt_sharded_corpus();
+    if (!sc) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    sc->group = group;
+    std::vector<uint64_t> rr;
+    partition_rows(total, group->n_ranks, rr);
+    sharded_set_rows(sc, rr);
+    sc->shard.assign(group->n_local, nullptr);
+    // every local rank streams ITS slice of the file (pinned double buffers), one host thread per device
+    std::vector<int> rcs(group->n_local, SMT_OK);
+    std::vector<std::string> errs(group->n_local);
+    auto work = [&](int i) {
+        const int r = group->first_rank + i;
+        rcs[i] = smt_corpus_create(group->ctx[i], dim, sc->rank_rows[r], &sc->shard[i]);
+        if (!rcs[i]) rcs[i] = corpus_load_slice(sc->shard[i], path, sc->rank_base[r], sc->rank_rows[r]);
+        if (rcs[i]) errs[i] = smt_last_error();
+    };
+    if (group->n_local == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < group->n_local; ++i) th.emplace_back(work, i);
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < group->n_local; ++i)
+        if (rcs[i]) { set_error("shard %d: %s", group->first_rank + i, errs[i].c_str()); rc = rcs[i]; smt_sharded_corpus_destroy(sc); return rc; }
+    *out = sc;
+    return SMT_OK;
+}
+
+int smt_sharded_corpus_save(smt_sharded_corpus *sc, const char *path)
+{
+    SMT_REQUIRE(sc && path, "null argument");
+    smt_group *g = sc->group;
+    const uint64_t total = sc->rank_base[g->n_ranks];
+    const std::string tmp = std::string(path) + ".tmp";
+    int rc = SMT_OK;
+    if (g->first_rank == 0) rc = corpus_file_begin(tmp.c_str(), sc->dim, total);  // header + final size
+    int rc2 = smt_group_barrier(g);  // the file exists before any other process opens it
+    if (rc) return rc;
+    if (rc2) return rc2;
+    for (int i = 0; i < g->n_local && !rc; ++i) {
+        const int r = g->first_rank + i;
+        rc = corpus_save_slice(sc->shard[i], tmp.c_str(), sc->rank_base[r]);
+    }
+    rc2 = smt_group_barrier(g);      // every slice is on disk before the rename publishes the file
+    if (rc) return rc;
+    if (rc2) return rc2;
+    if (g->first_rank == 0 && rename(tmp.c_str(), path) != 0) { set_error("rename '%s' -> '%s': %s", tmp.c_str(), path, strerror(errno)); return SMT_E_IO; }
+    return smt_group_barrier(g);
+}
+
+uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *sc) { return sc ? sc->rank_base[sc->group->n_ranks] : 0; }
+
+int smt_sharded_corpus_shard(smt_sharded_corpus *sc, int local_index, smt_corpus **shard, uint64_t *row_base, uint64_t *rows)
+{
+    SMT_REQUIRE(sc != nullptr, "corpus");
+    SMT_REQUIRE(local_index >= 0 && local_index < sc->group->n_local, "local index");
+    const int r = sc->group->first_rank + local_index;
+    if (shard) *shard = sc->shard[local_index];
+    if (row_base) *row_base = sc->rank_base[r];
+    if (rows) *rows = sc->rank_rows[r];
+    return SMT_OK;
+}
+
+int smt_sharded_corpus_rank_rows(const smt_sharded_corpus *sc, uint64_t *rows_per_rank)
+{
+    SMT_REQUIRE(sc && rows_per_rank, "null argument");
+    for (int r = 0; r < sc->group->n_ranks; ++r) rows_per_rank[r] = sc->rank_rows[r];
+    return SMT_OK;
+}
+
+int smt_sharded_corpus_append_host(smt_sharded_corpus *sc, const float *rows, uint64_t n_rows, uint64_t *first_row)
+{
+    SMT_REQUIRE(sc != nullptr && (rows || n_rows == 0), "null argument");
+    smt_group *g = sc->group;
+    const int last = g->n_ranks - 1;
+    if (first_row) *first_row = sc->rank_base[g->n_ranks];
+    if (n_rows == 0) return SMT_OK;
+    // global row numbers are insertion order, so new rows can only extend the LAST rank's range
+    const int li = last - g->first_rank;
+    if (li >= 0 && li < g->n_local) {
+        int rc = smt_corpus_append_host(sc->shard[li], rows, n_rows, nullptr);
+        if (rc) return rc;
+    }
+    std::vector<uint64_t> rr = sc->rank_rows;
+    rr[last] += n_rows;
+    return sharded_set_rows(sc, rr);
+}
+
+/* ----------------------------------------------------------------- search ---- */
+
+int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+                       const smt_range *ranges, uint32_t n_ranges, uint64_t *out_rows, double *out_dist, uint64_t *out_counts,
+                       uint64_t out_cap)
+{
+    SMT_REQUIRE(sc != nullptr, "corpus");
+    SMT_REQUIRE(mode == SMT_MODE_DOCUMENTS || mode == SMT_MODE_WORKSPACE, "mode");
+    SMT_REQUIRE(nq == 0 || (queries && out_counts), "null argument");
+    SMT_REQUIRE(n_ranges == 0 || ranges != nullptr, "ranges");
+    smt_group *g = sc->group;
+    if (nq == 0) return SMT_OK;
+    for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    const uint64_t total = sc->rank_base[g->n_ranks];
+    int rc;
+    if (n_ranges && (rc = validate_global_ranges(ranges, n_ranges, total))) return rc;
+    uint64_t n_virtual = total;
+    if (n_ranges) {
+        n_virtual = 0;
+        for (uint32_t i = 0; i < n_ranges; ++i) n_virtual += ranges[i].end - ranges[i].begin;
+    }
+    const bool has_thr = !std::isnan(max_distance);
+    const bool all_under_threshold = (mode == SMT_MODE_DOCUMENTS) && has_thr;
+    if (n_virtual == 0) return SMT_OK;
+    if (!all_under_threshold && top_k == 0) return SMT_OK;
+
+    std::vector<LocalHits> hits(nq);
+    const uint32_t K = (uint32_t)std::min<uint64_t>(top_k, n_virtual);
+    const bool device_exchange = !all_under_threshold && K <= SCAN_MAX_K && (uint64_t)g->n_ranks * K <= 8192;
+    std::vector<uint32_t> redo;  // queries answered through the host-list exchange
+    if (device_exchange) {
+        // ---- per-shard scan + select -> packed lists -> ONE all-gather -> device merge
+        const size_t list_words = (size_t)nq * 2 * K, rank_words = list_words + nq;  // + one "uncertain" word per query
+        const size_t q_bytes = ((size_t)nq * SMT_DIM * 4 + 255) & ~(size_t)255;
+        const size_t loc_off = q_bytes;
+        const size_t gath_off = loc_off + ((rank_words * 8 + 255) & ~(size_t)255);
+        const size_t out_off = gath_off + (((size_t)g->n_ranks * rank_words * 8 + 255) & ~(size_t)255);
+        const size_t dev_bytes = out_off + list_words * 8 + 64;
+        const int ws = (mode == SMT_MODE_WORKSPACE && has_thr) ? 1 : 0;
+        const float thr_score = 1.0f - (float)max_distance;  // store.rs:502-503
+        for (int i = 0; i < g->n_local; ++i) {
+            const int r = g->first_rank + i;
+            if ((rc = group_bind(g, i))) return rc;
+            if ((rc = ensure_dev(g, i, dev_bytes))) return rc;
+            char *base = reinterpret_cast<char *>(g->buf[i].dev);
+            SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
+            std::vector<smt_range> lr;
+            if (n_ranges) localize_ranges(ranges, n_ranges, sc->rank_base[r], sc->rank_rows[r], lr);
+            uint64_t *loc = reinterpret_cast<uint64_t *>(base + loc_off);
+            rc = search_topk_packed_local(sc->shard[i], reinterpret_cast<const float *>(base), nq, K, ws, thr_score, lr.data(),
+                                          (uint32_t)lr.size(), n_ranges != 0, sc->rank_base[r], loc, loc + list_words, false);
+            if (rc) return rc;
+        }
+        if ((rc = allgather_words(g, loc_off, gath_off, rank_words))) return rc;
+        // the caller is one host thread and needs ONE copy of the answer: merge on local device 0
+        if ((rc = group_bind(g, 0))) return rc;
+        char *base0 = reinterpret_cast<char *>(g->buf[0].dev);
+        uint64_t *gath = reinterpret_cast<uint64_t *>(base0 + gath_off), *merged = reinterpret_cast<uint64_t *>(base0 + out_off);
+        if ((rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, gath, (uint32_t)g->n_ranks, nq, K, K, merged, rank_words)))
+            return rc;
+        const size_t flag_words = (size_t)g->n_ranks * nq;
+        if ((rc = ensure_host(g, 0, (list_words + flag_words) * 8))) return rc;
+        uint64_t *h = reinterpret_cast<uint64_t *>(g->buf[0].pinned);
+        SMT_HIP_CHECK(hipMemcpyAsync(h, merged, list_words * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        for (int r = 0; r < g->n_ranks; ++r)  // every rank's flags: all processes take the same fallback decision
+            SMT_HIP_CHECK(hipMemcpyAsync(h + list_words + (size_t)r * nq, gath + (size_t)r * rank_words + list_words, (size_t)nq * 8,
+                                         hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        if ((rc = group_sync_all(g))) return rc;
+        for (uint32_t q = 0; q < nq; ++q) {
+            bool uncertain = false;
+            for (int r = 0; r < g->n_ranks; ++r) uncertain |= h[list_words + (size_t)r * nq + q] != 0;
+            if (uncertain) { redo.push_back(q); continue; }
+            const uint64_t *rws = h + (size_t)q * 2 * K, *bits = rws + K;
+            for (uint32_t e = 0; e < K && rws[e] != UINT64_MAX; ++e) {
+                double d;
+                memcpy(&d, bits + e, 8);
+                hits[q].rows.push_back(rws[e]);
+                hits[q].dist.push_back(d);
+            }
+        }
+    } else {
+        for (uint32_t q = 0; q < nq; ++q) redo.push_back(q);
+    }
+    if (!redo.empty()) {
+        // threshold mode, top_k > 56, or queries whose exactness certificate failed on some shard: per-shard host
+        // lists (each shard's own search is exact, fallback included), exchanged at their true sizes
+        std::vector<float> sub((size_t)redo.size() * SMT_DIM);
+        for (size_t j = 0; j < redo.size(); ++j) memcpy(&sub[j * SMT_DIM], queries + (size_t)redo[j] * SMT_DIM, SMT_DIM * 4);
+        std::vector<std::vector<LocalHits>> local;
+        if ((rc = local_host_search(sc, sub.data(), (uint32_t)redo.size(), top_k, max_distance, mode, ranges, n_ranges, local))) return rc;
+        std::vector<LocalHits> merged;
+        if ((rc = exchange_host_lists(g, local, (uint32_t)redo.size(), all_under_threshold ? UINT64_MAX : (uint64_t)top_k, merged)))
+            return rc;
+        for (size_t j = 0; j < redo.size(); ++j) hits[redo[j]] = std::move(merged[j]);
+    }
+    return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
+}
+
+int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
+                                   uint64_t *const *out_packed)
+{
+    SMT_REQUIRE(sc && queries_dev && out_packed, "null argument");
+    SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
+    smt_group *g = sc->group;
+    SMT_REQUIRE((uint64_t)g->n_ranks * top_k <= 8192, "device merge handles up to 8192 candidates per query");
+    if (nq == 0) return SMT_OK;
+    const size_t list_words = (size_t)nq * 2 * top_k;
+    const size_t gath_off = (list_words * 8 + 255) & ~(size_t)255;
+    const size_t dev_bytes = gath_off + (size_t)g->n_ranks * list_words * 8 + 64;
+    std::vector<char> on_aux(g->n_local, 0);
+    int rc;
+    for (int i = 0; i < g->n_local; ++i) {
+        const int r = g->first_rank + i;
+        SMT_REQUIRE(queries_dev[i] != nullptr, "queries_dev");
+        if ((rc = group_bind(g, i))) return rc;
+        if ((rc = ensure_dev(g, i, dev_bytes))) return rc;
+        smt_ctx *c = g->ctx[i];
+        // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select);
+        // the all-gather and the merge then follow it there, and the main stream carries nothing but scans
+        const bool async = c->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k;
+        rc = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false, sc->rank_base[r],
+                                      reinterpret_cast<uint64_t *>(g->buf[i].dev), nullptr, async);
+        if (rc) return rc;
+        on_aux[i] = async ? 1 : 0;
+        if (async) c->async_pending = true;
+    }
+    if ((rc = allgather_words(g, 0, gath_off, list_words, &on_aux))) return rc;
+    for (int i = 0; i < g->n_local; ++i) {
+        if (!out_packed[i]) continue;
+        if ((rc = group_bind(g, i))) return rc;
+        smt_ctx *c = g->ctx[i];
+        const uint64_t *gath = reinterpret_cast<const uint64_t *>(reinterpret_cast<char *>(g->buf[i].dev) + gath_off);
+        rc = launch_merge_topk_packed_on(c, on_aux[i] ? c->aux_stream : c->stream, gath, (uint32_t)g->n_ranks, nq, top_k, top_k,
+                                         out_packed[i], 0);
+        if (rc) return rc;
+    }
+    return SMT_OK;
+}
+
+}  // extern "C"

@@ -716,13 +716,12 @@ size_t assign_smem(uint32_t nlist) { return (size_t)2 * QT_F4 * 16 + (size_t)nli
 int run_assign(smt_ctx *ctx, const float *rows, uint64_t n_points, uint64_t stride, uint64_t n_rows_total, const smt_ivfpq *ix,
                uint32_t *d_assign)
 {
-    static bool attr = false;
-    if (!attr) {
+    if (!(ctx->attr_done & ATTR_IVF_ASSIGN)) {  // per context == per device
         IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
         IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-        attr = true;
+        ctx->attr_done |= ATTR_IVF_ASSIGN;
     }
     hipLaunchKernelGGL(cnorm_half_kernel, dim3((ix->nlist + 3) / 4), dim3(256), 0, ctx->stream, ix->d_centroids, ix->nlist,
                        ix->d_cnorm_half);
@@ -971,10 +970,9 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
         d_q = reinterpret_cast<const float *>(base + o_q);
     }
 
-    static bool score_attr = false;
-    if (!score_attr) {
+    if (!(ctx->attr_done & ATTR_IVF_SCORE)) {
         IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        score_attr = true;
+        ctx->attr_done |= ATTR_IVF_SCORE;
     }
     ProbeParams pp;
     pp.queries = d_q;
@@ -1017,8 +1015,20 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     uint64_t *d_or = d_or_user ? d_or_user : reinterpret_cast<uint64_t *>(base + o_or);
     double *d_od = d_od_user ? d_od_user : reinterpret_cast<double *>(base + o_od);
     uint64_t *d_oc = d_or_user ? d_oc_user : reinterpret_cast<uint64_t *>(base + o_oc);
-    rc = launch_select(ctx, ix->corpus->d_rows, d_q, nq, ap.lists, nprobe * n_seg, kp, (uint64_t)nprobe * n_seg * kp, top_k, 0, 0.f, row_base,
-                       d_or, d_od, d_oc);
+    SelectArgs sel;  // no exactness certificate: the index is approximate by contract (f32_err = 0)
+    sel.corpus = ix->corpus->d_rows;
+    sel.queries = d_q;
+    sel.nq = nq;
+    sel.lists = ap.lists;
+    sel.n_lists = nprobe * n_seg;
+    sel.kp = kp;
+    sel.list_stride = (uint64_t)nprobe * n_seg * kp;
+    sel.k_out = top_k;
+    sel.row_base = row_base;
+    sel.out_rows = d_or;
+    sel.out_dist = d_od;
+    sel.out_counts = d_oc;
+    rc = launch_select(ctx, sel);
     if (rc) return rc;
     if (d_or_out) *d_or_out = d_or;
     if (out_bytes_contig) *out_bytes_contig = b_or + b_od + (size_t)nq * 8;

@@ -76,7 +76,7 @@ __global__ void keys_to_rows_kernel(const key_t64 *keys, uint32_t *rows, uint64_
 // applies thresholds and the final (f64, row) order.
 int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *query_dev, const smt_range *ranges_dev,
                              const uint64_t *prefix_dev, uint32_t n_ranges, uint64_t n_virtual, uint64_t n_cand,
-                             std::vector<uint32_t> &rows_out, std::vector<double> &dist_out)
+                             std::vector<uint32_t> &rows_out, std::vector<double> &dist_out, float *next_d32)
 {
     SMT_REQUIRE(n_cand <= n_virtual, "candidate count");
     key_t64 *keys = nullptr, *sorted = nullptr;
@@ -129,7 +129,16 @@ int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *que
     dist_out.resize(n_cand);
     LK_CHECK(hipMemcpyAsync(rows_out.data(), d_rows, n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     LK_CHECK(hipMemcpyAsync(dist_out.data(), d_dist, n_cand * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    key_t64 next_key = KEY_PAD;
+    if (next_d32 && n_cand < n_virtual)
+        LK_CHECK(hipMemcpyAsync(&next_key, sorted + n_cand, sizeof(key_t64), hipMemcpyDeviceToHost, ctx->stream));
     LK_CHECK(hipStreamSynchronize(ctx->stream));
+    if (next_d32) {
+        const uint32_t bits = (uint32_t)(next_key >> 32);
+        float f = __builtin_inff();
+        if (next_key != KEY_PAD) memcpy(&f, &bits, sizeof(f));
+        *next_d32 = f;
+    }
 #undef LK_CHECK
     cleanup();
     return SMT_OK;

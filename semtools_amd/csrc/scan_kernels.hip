@@ -451,6 +451,10 @@ struct FinalParams {
     uint64_t *out_rows;   // [nq][k_out]
     double *out_dist;     // [nq][k_out]
     uint64_t *out_counts; // [nq] or nullptr
+    uint64_t out_stride;  // words between consecutive queries' output lists (>= k_out)
+    double f32_err;       // > 0: exactness certificate (SelectArgs::f32_err)
+    uint64_t *out_uncertain;       // [nq] or nullptr
+    unsigned long long *status;    // the context's sticky "uncertain selects" counter
     unsigned long long *dbg;  // optional: s_memtime stamps of query 0's phases (tuning key select_debug_ptr)
     unsigned long long *flags;  // async select (or nullptr), see ScanParams
     unsigned long long step;
@@ -720,9 +724,10 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         s_r[threadIdx.x] = r;
         if (r != 0xFFFFFFFFu) atomicAdd(&s_cnt[1], 1u);
     }
-    uint64_t *orow = p.out_rows + (size_t)qi * p.k_out;
-    double *odist = p.out_dist + (size_t)qi * p.k_out;
+    uint64_t *orow = p.out_rows + (size_t)qi * p.out_stride;
+    double *odist = p.out_dist + (size_t)qi * p.out_stride;
     if (threadIdx.x < p.k_out) { orow[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull; odist[threadIdx.x] = __builtin_inf(); }
+    if (threadIdx.x == 0 && p.out_uncertain) p.out_uncertain[qi] = 0;
     __syncthreads();
     SEL_STAMP(6);
     for (int pr = threadIdx.x; pr < kp * kp; pr += blockDim.x) {
@@ -737,6 +742,25 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     if ((int)threadIdx.x < kp && s_r[threadIdx.x] != 0xFFFFFFFFu) {
         const unsigned rank = s_rank[threadIdx.x];
         if (rank < p.k_out) { orow[rank] = p.row_base + s_r[threadIdx.x]; odist[rank] = s_d[threadIdx.x]; }
+    }
+    if (p.f32_err > 0.0 && s_best[kp - 1] != KEY_PAD) {
+        // Exactness certificate (SelectArgs::f32_err).  kp rows were nominated, so rows outside the lists may
+        // exist; each of them has f32 distance >= tau32, hence exact distance >= tau32 - f32_err.  Exactly one
+        // thread decides: the owner of the k_out-th result, or thread 0 when fewer than k_out rows qualified
+        // (only possible with the workspace score threshold, which then bounds what an outside row would need).
+        const double floor_out = (double)__uint_as_float((unsigned)(s_best[kp - 1] >> 32)) - p.f32_err;
+        bool decide = false, uncertain = false;
+        if ((int)threadIdx.x < kp && s_r[threadIdx.x] != 0xFFFFFFFFu && s_rank[threadIdx.x] == p.k_out - 1) {
+            decide = true;
+            uncertain = !(floor_out > s_d[threadIdx.x]);
+        } else if (threadIdx.x == 0 && s_cnt[1] < p.k_out) {
+            decide = true;
+            uncertain = p.ws_threshold ? ((1.0 - floor_out) > (double)p.ws_thr_score) : true;
+        }
+        if (decide && uncertain) {
+            if (p.out_uncertain) p.out_uncertain[qi] = 1;
+            if (p.status) atomicAdd(p.status, 1ull);
+        }
     }
     if (threadIdx.x == 0 && p.out_counts)
         p.out_counts[qi] = s_cnt[1] < p.k_out ? s_cnt[1] : p.k_out;
@@ -796,10 +820,10 @@ __global__ void merge_topk_kernel(const uint64_t *rows, const double *dist, uint
 // ------------------------------------------------------------------ launchers
 static inline uint32_t candidates_per_list(uint32_t k_out)
 {
-    // guard band: a few extra f32 candidates so that f32-vs-f64 rank flips at
-    // the k-th boundary cannot drop a true top-k row
-    uint32_t kp = k_out + 8;
-    return kp > 64 ? 64 : kp;
+    // guard band: 8 extra f32 candidates so that f32-vs-f64 rank flips at the k-th boundary do not drop a true
+    // top-k row; the select stage PROVES per query that the band was wide enough (SelectArgs::f32_err) and flags
+    // the query otherwise.  k_out <= SCAN_MAX_K = 56, so the band never shrinks.
+    return k_out + 8;
 }
 
 template <int NQ, int U>
@@ -825,49 +849,50 @@ static int launch_scan_filtered(smt_ctx *ctx, const ScanParams &p, int blocks, i
 }
 
 // Block lists -> final answer in ONE launch (per query: prune + rank + rescore).
-int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint32_t nq, key_t64 *lists,
-                  uint32_t n_lists, uint32_t kp, uint64_t list_stride, uint32_t k_out, int ws_threshold,
-                  float ws_thr_score, uint64_t row_base, uint64_t *out_rows, double *out_dist,
-                  uint64_t *out_counts, uint64_t async_step)
+int launch_select(smt_ctx *ctx, const SelectArgs &a)
 {
-    SMT_REQUIRE(n_lists >= 1 && n_lists <= (uint32_t)SEL_MAX_LISTS, "select stage accepts 1..512 block lists");
-    SMT_REQUIRE(async_step == 0 || (nq == 1 && ctx->aux_stream && ctx->d_flags), "async select handles one query per launch");
-    static bool attr_set = false;
-    if (!attr_set) {
+    SMT_REQUIRE(a.n_lists >= 1 && a.n_lists <= (uint32_t)SEL_MAX_LISTS, "select stage accepts 1..512 block lists");
+    SMT_REQUIRE(a.async_step == 0 || (a.nq == 1 && ctx->aux_stream && ctx->d_flags), "async select handles one query per launch");
+    if (!(ctx->attr_done & ATTR_SELECT)) {  // per context == per device (a group runs several GPUs in one process)
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<36>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        ctx->attr_done |= ATTR_SELECT;
     }
     FinalParams f;
-    f.corpus = corpus;
-    f.queries = queries;
-    f.lists = lists;
-    f.list_stride = list_stride;
-    f.n_lists = n_lists;
-    f.kp = kp;
-    f.k_out = k_out;
-    f.ws_threshold = ws_threshold;
-    f.ws_thr_score = ws_thr_score;
-    f.row_base = row_base;
-    f.out_rows = out_rows;
-    f.out_dist = out_dist;
-    f.out_counts = out_counts;
+    f.corpus = a.corpus;
+    f.queries = a.queries;
+    f.lists = a.lists;
+    f.list_stride = a.list_stride;
+    f.n_lists = a.n_lists;
+    f.kp = a.kp;
+    f.k_out = a.k_out;
+    f.ws_threshold = a.ws_threshold;
+    f.ws_thr_score = a.ws_thr_score;
+    f.row_base = a.row_base;
+    f.out_rows = a.out_rows;
+    f.out_dist = a.out_dist;
+    f.out_counts = a.out_counts;
+    f.out_stride = a.out_stride ? a.out_stride : a.k_out;
+    f.f32_err = a.f32_err;
+    f.out_uncertain = a.out_uncertain;
+    f.status = ctx->d_status;
     f.dbg = reinterpret_cast<unsigned long long *>(ctx->tune.select_debug_ptr);
-    f.flags = async_step ? ctx->d_flags : nullptr;
-    f.step = async_step;
-    const bool small = (uint64_t)n_lists * kp <= (uint64_t)8 * SEL_THREADS;
-    if (async_step) {
-        if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->aux_stream, f);
-        else hipLaunchKernelGGL(final_select_kernel<36>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->aux_stream, f);
+    f.flags = a.async_step ? ctx->d_flags : nullptr;
+    f.step = a.async_step;
+    const bool small = (uint64_t)a.n_lists * a.kp <= (uint64_t)8 * SEL_THREADS;
+    const size_t smem = final_smem_bytes(a.n_lists, a.kp);
+    if (a.async_step) {
+        if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->aux_stream, f);
+        else hipLaunchKernelGGL(final_select_kernel<36>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->aux_stream, f);
         ctx->async_pending = true;
         SMT_HIP_CHECK(hipGetLastError());
         return SMT_OK;
     }
     if (ctx->tune.prof_select) prof_begin(ctx, "select");
-    if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
-    else hipLaunchKernelGGL(final_select_kernel<36>, dim3(nq), dim3(SEL_THREADS), final_smem_bytes(n_lists, kp), ctx->stream, f);
+    if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
+    else hipLaunchKernelGGL(final_select_kernel<36>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
     if (ctx->tune.prof_select) prof_end(ctx, "select");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
@@ -875,7 +900,7 @@ int launch_select(smt_ctx *ctx, const float *corpus, const float *queries, uint3
 
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
 {
-    SMT_REQUIRE(a.k_out >= 1 && a.k_out <= 64, "top_k for the scan path must be in [1, 64]");
+    SMT_REQUIRE(a.k_out >= 1 && a.k_out <= SCAN_MAX_K, "top_k for the scan path must be in [1, 56]");
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const bool filtered = a.n_ranges > 0;
     const uint32_t kp = candidates_per_list(a.k_out);
@@ -940,8 +965,26 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         if (rc != SMT_OK) return rc;
     }
     prof_end(ctx, "scan");
-    return launch_select(ctx, a.corpus, a.queries, a.nq, lists, (uint32_t)blocks, kp, (uint64_t)blocks * kp, a.k_out,
-                         a.ws_threshold, a.ws_thr_score, a.row_base, a.out_rows, a.out_dist, a.out_counts, step);
+    SelectArgs s;
+    s.corpus = a.corpus;
+    s.queries = a.queries;
+    s.nq = a.nq;
+    s.lists = lists;
+    s.n_lists = (uint32_t)blocks;
+    s.kp = kp;
+    s.list_stride = (uint64_t)blocks * kp;
+    s.k_out = a.k_out;
+    s.ws_threshold = a.ws_threshold;
+    s.ws_thr_score = a.ws_thr_score;
+    s.row_base = a.row_base;
+    s.out_rows = a.out_rows;
+    s.out_dist = a.out_dist;
+    s.out_counts = a.out_counts;
+    s.async_step = step;
+    s.out_stride = a.out_stride;
+    s.f32_err = F32_ERR_SCAN;
+    s.out_uncertain = a.out_uncertain;
+    return launch_select(ctx, s);
 }
 
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
@@ -968,19 +1011,29 @@ int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, ui
     return SMT_OK;
 }
 
+// Packed lists [n_lists][nq][2][k_in] (list_stride_words apart: the exchange buffers of group.cpp carry a few status
+// words behind each rank's lists; 0 = dense) -> out_packed [nq][2][k_out], on stream `st`.  n_lists == 0 writes padding.
+int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *packed, uint32_t n_lists, uint32_t nq, uint32_t k_in,
+                                uint32_t k_out, uint64_t *out_packed, uint64_t list_stride_words)
+{
+    (void)ctx;
+    SMT_REQUIRE((uint64_t)n_lists * k_in <= 8192, "device merge handles up to 8192 candidates per query");
+    const uint64_t ls = list_stride_words ? list_stride_words : (uint64_t)nq * 2 * k_in;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, st, packed, reinterpret_cast<const double *>(packed + k_in),
+                       n_lists, ls, (uint64_t)2 * k_in, k_in, k_out, out_packed, reinterpret_cast<double *>(out_packed + k_out),
+                       (uint64_t)2 * k_out);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
 int launch_merge_topk_packed(smt_ctx *ctx, const uint64_t *packed, uint32_t n_lists, uint32_t nq, uint32_t k_in,
                              uint32_t k_out, uint64_t *out_packed)
 {
-    SMT_REQUIRE((uint64_t)n_lists * k_in <= 8192, "device merge handles up to 8192 candidates per query");
     // async pipeline: the merge follows the select it consumes on the aux stream (tuning key merge_on_aux)
     const bool on_aux = ctx->tune.merge_on_aux && ctx->aux_stream != nullptr;
     hipStream_t st = on_aux ? ctx->aux_stream : ctx->stream;  // (ctx->stream may itself be the null stream)
     if (on_aux) ctx->async_pending = true;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, st, packed,
-                       reinterpret_cast<const double *>(packed + k_in), n_lists, (uint64_t)nq * 2 * k_in, (uint64_t)2 * k_in,
-                       k_in, k_out, out_packed, reinterpret_cast<double *>(out_packed + k_out), (uint64_t)2 * k_out);
-    SMT_HIP_CHECK(hipGetLastError());
-    return SMT_OK;
+    return launch_merge_topk_packed_on(ctx, st, packed, n_lists, nq, k_in, k_out, out_packed, 0);
 }
 
 }  // namespace smt

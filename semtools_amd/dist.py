@@ -1,13 +1,13 @@
-"""Multi-GPU glue: one process per GPU, corpus row-sharded, ONE exchange step.
+"""Multi-GPU glue for Python hosts: one process per GPU (torchrun), corpus row-sharded, ONE exchange step.
 
-Each rank scans its own contiguous row range and produces a sorted top-k list
-(distance asc, global row asc).  The only collective on the path is an
-all-gather of those fixed-size lists (k x 16 B per query per rank: latency
-bound, xGMI bandwidth irrelevant), after which every rank merges redundantly.
-With backend "nccl" the all-gather is RCCL over xGMI on device buffers; the
-same code runs on "gloo"/CPU tensors, which is how it is tested without GPUs.
-There is no reference counterpart (the reference is single-process CPU code);
-the contract is: sharded result == single-shard result (tests/).
+On GPUs the exchange lives INSIDE libsemtools_hip.so (csrc/group.cpp: smt_group_* / smt_sharded_*: per-shard scan ->
+ncclAllGather of the packed k-lists -> merge_topk_kernel); this module is a thin caller: `group_from_torch` joins the
+ranks of a torch.distributed job into one library group (rank 0's ncclUniqueId travels through torch's store), and
+`ShardedCorpus` / `ShardedIvfPq` hand the work to it.  What remains here in Python is the same exchange written over
+torch.distributed tensors ("gloo" on CPU tensors), which is how the protocol -- padding, packed layout, threshold
+mode's count-then-padded-gather, (distance, row) merge -- is tested on a box without GPUs (tests/test_dist_cpu.py).
+There is no reference counterpart (the reference is single-process CPU code); the contract is: sharded result ==
+single-shard result (tests/).
 """
 import numpy as np
 import torch
@@ -17,6 +17,18 @@ from . import core
 from ._lib import MODE_DOCUMENTS
 
 PAD_ROW = -1  # UINT64_MAX viewed as int64
+
+
+def group_from_torch(device, group=None):
+    """One library group (smt_group) spanning the ranks of the current torch.distributed job: rank 0 creates the
+    ncclUniqueId, every rank joins with its GPU (ncclCommInitRank inside the library).  Works with any torch
+    backend -- the 128 bytes go through broadcast_object_list."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    box = [core.Group.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return core.Group.from_rank(int(device), rank, world, box[0])
 
 
 def shard_bounds(n_rows, world_size):
@@ -183,6 +195,8 @@ class ShardedCorpus:
 
     def search(self, queries, top_k, max_distance=None, mode=MODE_DOCUMENTS):
         q = np.ascontiguousarray(np.asarray(queries, np.float32).reshape(-1, 256))
+        if isinstance(self.corpus, core.ShardedCorpus):     # the library does scan + all-gather + merge itself
+            return self.corpus.search(q, top_k=top_k, max_distance=max_distance, mode=mode)
         local = self.corpus.search(q, top_k=top_k, max_distance=max_distance, mode=mode, row_base=self.row_base)
         threshold_all = max_distance is not None and mode == MODE_DOCUMENTS
         out = []

@@ -5,6 +5,7 @@ import pytest
 
 from oracle import oracle as orc
 from tests import synth
+from tests.compare import assert_topk_tie_aware, reference_distances
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +29,8 @@ def test_batched_matches_oracle(gpu_ctx, n_rows, nq, k):
         orows, odist = _oracle_topk(emb, qs[i], k)
         assert got[i][0].tolist() == orows, (i, got[i][0].tolist(), orows)
         assert np.array_equal(got[i][1], np.array(odist)), i
+        if i < 4:   # tie-aware contract against the serial-f32 restatement
+            assert_topk_tie_aware(got[i][0], got[i][1], reference_distances(emb, qs[i]), k)
     c.close()
 
 

@@ -8,6 +8,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 
 from oracle import oracle as orc
 from tests import synth
+from tests.compare import assert_topk_tie_aware, reference_distances
 
 pytestmark = pytest.mark.gpu
 SCALE = int(os.environ.get("SMT_FUZZ_SCALE", "1"))  # SMT_FUZZ_SCALE=10: ten times the examples (soak run)
@@ -41,6 +42,9 @@ def test_topk_random_shapes(gpu_ctx, n, k, nq, seed, dup, use_ranges):
         orows, odist = _oracle(emb[idx], qs[i], k)
         assert got[i][0].tolist() == idx[np.array(orows, dtype=np.int64)].tolist() if orows else got[i][0].size == 0
         assert np.array_equal(got[i][1], np.array(odist))
+        if i == 0:  # and the tie-aware contract against the serial-f32 restatement
+            assert_topk_tie_aware(got[i][0], got[i][1], reference_distances(emb, qs[i]), k,
+                                  rows_subset=idx.tolist() if ranges else None)
     c.close()
 
 

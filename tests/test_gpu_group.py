@@ -1,0 +1,169 @@
+"""GPU: groups of GPUs behind the C ABI (include/semtools_hip.h: smt_group_* / smt_sharded_*).
+
+A 1-GPU box offers two things: (i) the real RCCL path with ONE rank -- ncclCommInitAll / ncclCommInitRank,
+ncclAllGather, device merge -- and (ii) "logical" groups, N ranks on one device whose exchange is device copies
+(RCCL refuses two ranks on one GPU).  (ii) drives everything except the RCCL call itself with N > 1: HIP scan on every
+shard -> gather -> merge kernel, range localisation, global row numbering, the variable-length threshold exchange.
+Contract everywhere: sharded result == smt_search on the unsharded matrix (which the other GPU tests pin to the
+oracle)."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for (gr, gd), (wr, wd) in zip(got, want):
+        assert gr.tolist() == wr.tolist()
+        assert np.array_equal(gd, wd)
+
+
+CASES = [
+    dict(top_k=7),
+    dict(top_k=56),
+    dict(top_k=7, max_distance=0.93),                                   # all rows under the threshold (A6)
+    dict(top_k=4, max_distance=0.95, mode=1),                           # workspace: score threshold, then top-k (A10)
+    dict(top_k=100),                                                    # beyond the scan path: all-keys path per shard
+    dict(top_k=5, ranges=[(10, 50), (2999, 3001), (4000, 5999)]),       # path-subset filter crossing shard borders
+    dict(top_k=3, ranges=[(5990, 6000)]),                               # a filter that leaves most shards nothing
+    dict(top_k=9, max_distance=0.9, ranges=[(100, 4100)]),
+]
+
+
+@pytest.fixture(scope="module")
+def plain(gpu_ctx):
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(6000, seed=3)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    yield emb, c
+    c.close()
+
+
+def test_rccl_group_of_one_rank(plain):
+    """smt_group_create -> ncclCommInitAll on the one GPU there is; the communicator itself reports its size."""
+    import semtools_amd as smt
+
+    emb, c = plain
+    g = smt.Group([0])
+    info = g.info()
+    assert info["n_ranks"] == 1 and info["n_local"] == 1 and info["rccl_ranks"] == 1 and info["rccl_version"] > 20000
+    sc = smt.ShardedCorpus(g, rows=emb)
+    assert sc.rows == len(emb) and sc.rank_rows().tolist() == [len(emb)]
+    qs = synth.unit_query(4, nq=3)
+    for kw in CASES:
+        _same(sc.search(qs, **kw), c.search(qs, **kw))
+    qb = synth.unit_query(5, nq=12)                      # >= 8 queries: the MFMA path inside the shard
+    _same(sc.search(qb, top_k=10), c.search(qb, top_k=10))
+    sc.close()
+    g.close()
+
+
+def test_rank_per_process_group_of_one(plain):
+    """The torchrun form: unique id -> ncclCommInitRank."""
+    import semtools_amd as smt
+
+    emb, c = plain
+    uid = smt.Group.unique_id()
+    assert len(uid) == 128
+    g = smt.Group.from_rank(device=0, rank=0, n_ranks=1, unique_id=uid)
+    assert g.info()["rccl_ranks"] == 1
+    sc = smt.ShardedCorpus(g, rows=emb)
+    qs = synth.unit_query(6, nq=2)
+    _same(sc.search(qs, top_k=5), c.search(qs, top_k=5))
+    sc.close()
+    g.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_logical_shards_equal_the_unsharded_search(plain, n_shards):
+    import semtools_amd as smt
+
+    emb, c = plain
+    g = smt.Group.logical(0, n_shards)
+    assert g.info()["n_ranks"] == n_shards and g.info()["rccl_ranks"] == 0
+    sc = smt.ShardedCorpus(g, rows=emb)
+    per = -(-len(emb) // n_shards)
+    assert sc.rank_rows().tolist() == [max(0, min(per, len(emb) - r * per)) for r in range(n_shards)]
+    qs = synth.unit_query(4, nq=3)
+    for kw in CASES:
+        _same(sc.search(qs, **kw), c.search(qs, **kw))
+    qb = synth.unit_query(5, nq=12)
+    _same(sc.search(qb, top_k=10), c.search(qb, top_k=10))
+    # rows appended later extend the last rank's range
+    extra = synth.unit_rows(700, seed=77)
+    first = sc.append(extra)
+    assert first == len(emb) and sc.rows == len(emb) + 700
+    c2 = smt.Corpus(c.ctx)
+    c2.append(np.concatenate([emb, extra]))
+    _same(sc.search(qs, top_k=12), c2.search(qs, top_k=12))
+    c2.close()
+    sc.close()
+    g.close()
+
+
+def test_sharded_device_form_and_file_round_trip(plain, tmp_path):
+    """smt_sharded_search_topk_device (what bench.py --gpus N times) + save/load through the corpus file."""
+    import torch
+    import semtools_amd as smt
+
+    emb, c = plain
+    g = smt.Group.logical(0, 4)
+    sc = smt.ShardedCorpus(g, rows=emb)
+    path = tmp_path / "corpus.f32"
+    sc.save(path)
+    c_file = smt.Corpus.load(c.ctx, path)
+    assert np.array_equal(c_file.read_rows(0, len(emb)), emb)
+    c_file.close()
+    sc2 = smt.ShardedCorpus.load(g, path)
+    assert sc2.rank_rows().tolist() == sc.rank_rows().tolist()
+    k, nq = 10, 3
+    qs = synth.unit_query(8, nq=nq)
+    qd = torch.from_numpy(qs).cuda()
+    outs = [torch.empty((nq, 2, k), dtype=torch.int64, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    sc2.search_topk_device([qd.data_ptr()] * 4, nq, k, [o.data_ptr() for o in outs])
+    g.synchronize()
+    want = c.search(qs, top_k=k)
+    for o in outs:                                     # every rank holds the same merged answer
+        m = o.cpu().numpy()
+        for i in range(nq):
+            assert np.ascontiguousarray(m[i, 0]).view(np.uint64).tolist() == want[i][0].tolist()
+            assert np.array_equal(np.ascontiguousarray(m[i, 1]).view(np.float64), want[i][1])
+    # pipelined single-query form (async select + gather + merge on the aux streams), answers land in pinned memory
+    for i in range(4):
+        g.ctx(i).set_tuning("async_select", 1)
+    ring = torch.empty((6, 2, k), dtype=torch.int64).pin_memory()
+    for step in range(6):
+        q1 = qd[step % nq]
+        sc2.search_topk_device([q1.data_ptr()] * 4, 1, k, [ring[step].data_ptr(), 0, 0, 0])
+    g.synchronize()
+    for step in range(6):
+        assert ring[step, 0].numpy().view(np.uint64).tolist() == want[step % nq][0].tolist()
+        assert np.array_equal(ring[step, 1].numpy().view(np.float64), want[step % nq][1])
+    for i in range(4):
+        g.ctx(i).set_tuning("async_select", 0)
+        assert g.ctx(i).uncertain_count() == 0
+    sc.close(); sc2.close(); g.close()
+
+
+def test_adopted_device_shards_of_unequal_size(plain):
+    import torch
+    import semtools_amd as smt
+
+    emb, c = plain
+    g = smt.Group.logical(0, 3)
+    cuts = [0, 1000, 1000, 6000]                       # the middle shard is empty
+    parts = [torch.from_numpy(emb[cuts[i]:cuts[i + 1]].copy()).cuda() for i in range(3)]
+    torch.cuda.synchronize()
+    sc = smt.ShardedCorpus(g, device_ptrs=[p.data_ptr() if p.numel() else 0 for p in parts],
+                           shard_rows=[len(p) for p in parts])
+    assert sc.rank_rows().tolist() == [1000, 0, 5000]
+    qs = synth.unit_query(4, nq=2)
+    for kw in (dict(top_k=6), dict(top_k=6, max_distance=0.92), dict(top_k=3, ranges=[(900, 1100)])):
+        _same(sc.search(qs, **kw), c.search(qs, **kw))
+    sc.close(); g.close()

@@ -1,0 +1,154 @@
+"""GPU: adversarial near-ties around the k-th place.
+
+The f32 scan nominates k + 8 rows per list; more than 8 rows within f32 noise of the k-th distance used to be an
+unproven assumption.  Now the select stage carries an exactness certificate and the host entry points re-answer a
+query exhaustively when it fails.  Two contracts are pinned here:
+  * vs the oracle's f64-accurate ordering (what the library promises): indices EXACT, distances bit-equal;
+  * vs the serial-f32 restatement (the closest thing to what the reference executes): tie-aware.
+Rows of the cluster are rescaled and 1-ulp-perturbed copies of one vector -- what "foo" vs "foo foo foo" or the
+same tokens in another order produce in a real corpus."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+from tests.compare import assert_topk_tie_aware, reference_distances
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(x):
+    return (x / np.linalg.norm(x)).astype(np.float32)
+
+
+def adversarial_corpus(n=4000, n_better=5, n_cluster=40, seed=21):
+    rng = np.random.default_rng(seed)
+    q = _unit(rng.standard_normal(256))
+    emb = synth.unit_rows(n, seed=seed + 1, dup_frac=0.0, zero_frac=0.0)
+    v = _unit(q + 0.9 * _unit(rng.standard_normal(256)))                 # the cluster's direction
+    pos = rng.choice(n, size=n_better + n_cluster, replace=False)
+    for i, p in enumerate(pos[:n_better]):                               # clearly better rows
+        emb[p] = _unit(q + (0.3 + 0.05 * i) * _unit(rng.standard_normal(256)))
+    for i, p in enumerate(pos[n_better:]):
+        if i % 3 == 0:
+            row = (v * np.float32(0.37 + 0.11 * i)).astype(np.float32)   # rescaled copy ("foo foo foo" vs "foo")
+        elif i % 3 == 1:
+            row = v.copy()                                               # 1-ulp perturbations (another summation order)
+            idx = rng.choice(256, size=6, replace=False)
+            row[idx] = np.nextafter(row[idx], np.float32(np.inf if i % 2 else -np.inf), dtype=np.float32)
+        else:
+            row = v.copy()                                               # exact duplicates: must come back in row order
+        emb[p] = row
+    return q, np.ascontiguousarray(emb), sorted(pos[n_better:].tolist())
+
+
+def _oracle_topk(emb, q, k):
+    res = orc.search_documents(emb, [len(emb)], q, n_lines=0, top_k=k, accurate=True)
+    return [r["match_line"] for r in res], np.array([r["distance"] for r in res])
+
+
+@pytest.mark.parametrize("k", [3, 10, 20, 44, 56, 60, 64, 100])
+def test_cluster_around_the_kth_place_single_query(gpu_ctx, k):
+    import semtools_amd as smt
+
+    q, emb, cluster = adversarial_corpus()
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    rows, dist = c.search(q, top_k=k)[0]
+    orows, odist = _oracle_topk(emb, q, k)
+    assert rows.tolist() == orows                       # the promise: exact f64 ordering, ties by row
+    assert np.array_equal(dist, odist)
+    ref = reference_distances(emb, q, accurate=False)   # the reference's arithmetic (serial f32)
+    assert_topk_tie_aware(rows, dist, ref, k)
+    if 5 < k < 45:                                      # the k-th place lies inside the 40-row cluster
+        assert set(rows[5:k].tolist()) <= set(cluster)
+    c.close()
+
+
+def test_cluster_batched_mfma_path_and_ranges(gpu_ctx):
+    import semtools_amd as smt
+
+    q, emb, cluster = adversarial_corpus(n=6000, seed=33)
+    qs = np.concatenate([q[None], synth.unit_query(2, nq=11)])     # 12 queries -> K3; query 0 is the adversarial one
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    for k in (10, 30):
+        got = c.search(qs, top_k=k)
+        for i in range(len(qs)):
+            orows, odist = _oracle_topk(emb, qs[i], k)
+            assert got[i][0].tolist() == orows, (k, i)
+            assert np.array_equal(got[i][1], odist)
+            assert_topk_tie_aware(got[i][0], got[i][1], reference_distances(emb, qs[i]), k)
+    # range-filtered (workspace path subset): K2 with the chunk table, same certificate
+    ranges = [(0, 2500), (3000, 6000)]
+    elig = [r for b, e in ranges for r in range(b, e)]
+    rows, dist = c.search(q, top_k=10, ranges=ranges)[0]
+    sub = emb[elig]
+    res = orc.search_documents(sub, [len(sub)], q, n_lines=0, top_k=10, accurate=True)
+    assert rows.tolist() == [elig[r["match_line"]] for r in res]
+    assert_topk_tie_aware(rows, dist, reference_distances(emb, q), 10, rows_subset=elig)
+    c.close()
+
+
+def test_threshold_through_the_cluster(gpu_ctx):
+    """max_distance inside the cluster: strict `<` on the exact f64 value (mod.rs:88-89); against the serial-f32
+    restatement membership may differ only within 1e-5 of the threshold."""
+    import semtools_amd as smt
+
+    q, emb, cluster = adversarial_corpus(seed=44)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    acc = reference_distances(emb, q, accurate=True)
+    md = float(np.median(acc[cluster]))
+    rows, dist = c.search(q, top_k=3, max_distance=md)[0]
+    want = orc.search_documents(emb, [len(emb)], q, n_lines=0, top_k=3, max_distance=md, accurate=True)
+    assert rows.tolist() == [r["match_line"] for r in want]
+    assert np.array_equal(dist, [r["distance"] for r in want])
+    ser = reference_distances(emb, q, accurate=False)
+    got = set(rows.tolist())
+    assert set(np.nonzero(ser < md - 1e-5)[0].tolist()) <= got
+    assert not (got & set(np.nonzero(ser >= md + 1e-5)[0].tolist()))
+    # workspace semantics: score threshold, then ALWAYS top-k (store.rs:502-503, :543)
+    rows_w, dist_w = c.search(q, top_k=8, max_distance=md, mode=smt.MODE_WORKSPACE)[0]
+    keep = [(d, r) for r, d in enumerate(acc) if (1.0 - d) > float(np.float32(1.0) - np.float32(md))]
+    keep.sort()
+    assert rows_w.tolist() == [r for _, r in keep[:8]]
+    c.close()
+
+
+def test_device_entry_point_counts_what_it_cannot_prove(gpu_ctx):
+    import torch
+    import semtools_amd as smt
+
+    q, emb, _ = adversarial_corpus(seed=55)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    gpu_ctx.uncertain_count()                                  # reset
+    qd = torch.from_numpy(q).cuda()
+    o_rows = torch.empty(10, dtype=torch.int64, device="cuda")
+    o_dist = torch.empty(10, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    c.search_topk_device(qd.data_ptr(), 1, 10, 0, o_rows.data_ptr(), o_dist.data_ptr())
+    gpu_ctx.synchronize()
+    assert gpu_ctx.uncertain_count() == 1                      # 40 near-ties around the 10th place: no certificate
+    easy = torch.from_numpy(synth.unit_query(3)[0]).cuda()
+    torch.cuda.synchronize()
+    c.search_topk_device(easy.data_ptr(), 1, 10, 0, o_rows.data_ptr(), o_dist.data_ptr())
+    gpu_ctx.synchronize()
+    assert gpu_ctx.uncertain_count() == 0
+    c.close()
+
+
+def test_sharded_search_redoes_uncertain_queries(gpu_ctx):
+    import semtools_amd as smt
+
+    q, emb, _ = adversarial_corpus(seed=66)
+    qs = np.concatenate([q[None], synth.unit_query(9, nq=2)])
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, rows=emb)
+    got = sc.search(qs, top_k=10)
+    for i in range(len(qs)):
+        orows, odist = _oracle_topk(emb, qs[i], 10)
+        assert got[i][0].tolist() == orows
+        assert np.array_equal(got[i][1], odist)
+    sc.close(); g.close()
