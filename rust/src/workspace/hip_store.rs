@@ -1,0 +1,114 @@
+//! GPU-resident replacement for the `line_embeddings.qdrant` shard of `src/workspace/store.rs` (reference v3.0.0):
+//! `upsert_line_embeddings` (:402-434), `search_line_embeddings` (:481-546), `delete_line_embeddings`,
+//! `count_line_embeddings`.  UNCOMPILED here -- see rust/README.md.
+//!
+//! Storage: one flat corpus file `line_embeddings.f32` (smt_corpus_save format) + `line_rows.json`
+//! (path -> first_row, n_lines).  A document's lines are contiguous rows, so the reference's payload filter
+//! `path IN subset` (:507-515) becomes a sorted list of row ranges, and a re-embedded document simply gets a fresh
+//! extent (the reference's stale-tail-rows quirk of upsert-only storage is not reproduced).
+use crate::search::hip_ffi::*;
+use crate::workspace::store::RankedLine;
+use anyhow::Result;
+use std::collections::BTreeMap;
+use std::ffi::CString;
+use std::path::{Path, PathBuf};
+use std::ptr;
+
+#[derive(Clone, Copy, serde::Serialize, serde::Deserialize)]
+struct Extent {
+    first_row: u64,
+    n_lines: u64,
+}
+
+pub struct HipLineStore {
+    corpus: *mut SmtCorpus,
+    extents: BTreeMap<String, Extent>,
+    dir: PathBuf,
+    rows_on_disk: u64,
+}
+
+impl HipLineStore {
+    pub fn open(ctx: *mut SmtCtx, root_dir: &str) -> Result<Self> {
+        let dir = Path::new(root_dir).to_path_buf();
+        let file = dir.join("line_embeddings.f32");
+        let mut corpus = ptr::null_mut();
+        let mut extents = BTreeMap::new();
+        if file.exists() {
+            let c = CString::new(file.to_string_lossy().as_bytes())?;
+            check(unsafe { smt_corpus_load(ctx, c.as_ptr(), &mut corpus) })?;
+            if let Ok(text) = std::fs::read_to_string(dir.join("line_rows.json")) {
+                extents = serde_json::from_str(&text)?;
+            }
+        } else {
+            check(unsafe { smt_corpus_create(ctx, SMT_DIM, 0, &mut corpus) })?;
+        }
+        let rows_on_disk = if file.exists() { unsafe { smt_corpus_rows(corpus) } } else { 0 };
+        Ok(Self { corpus, extents, dir, rows_on_disk })
+    }
+
+    /// `upsert_line_embeddings` for one document: its lines are pooled on the GPU straight into fresh corpus rows.
+    pub fn upsert_document(&mut self, model: *mut SmtModel, path: &str, ids: &[u32], offsets: &[u64]) -> Result<()> {
+        let n = (offsets.len() - 1) as u64;
+        let mut first = 0u64;
+        check(unsafe { smt_embed(model, ids.as_ptr(), offsets.as_ptr(), n, 2048, ptr::null_mut(), self.corpus, &mut first) })?;
+        self.extents.insert(path.to_string(), Extent { first_row: first, n_lines: n });
+        Ok(())
+    }
+
+    /// `flush_line_embeddings`: append the new rows to the file (O(new rows)), then the row table.
+    pub fn flush(&mut self) -> Result<()> {
+        let file = CString::new(self.dir.join("line_embeddings.f32").to_string_lossy().as_bytes())?;
+        if self.rows_on_disk == 0 {
+            check(unsafe { smt_corpus_save(self.corpus, file.as_ptr()) })?;
+        } else {
+            check(unsafe { smt_corpus_append_to_file(self.corpus, file.as_ptr(), self.rows_on_disk) })?;
+        }
+        self.rows_on_disk = unsafe { smt_corpus_rows(self.corpus) };
+        std::fs::write(self.dir.join("line_rows.json"), serde_json::to_string(&self.extents)?)?;
+        Ok(())
+    }
+
+    pub fn delete_line_embeddings(&mut self, paths: &[String]) {
+        for p in paths {
+            self.extents.remove(p);
+        }
+    }
+
+    pub fn count_line_embeddings(&self) -> u64 {
+        self.extents.values().map(|e| e.n_lines).sum()
+    }
+
+    /// `Store::search_line_embeddings` (:481-546): rows with score > 1 - max_distance (f32), then ALWAYS the best
+    /// top_k (:543); empty subset or top_k == 0 -> [] (:489-491).
+    pub fn search_line_embeddings(&self, query_vec: &[f32], subset_paths: &[String], top_k: usize,
+                                  max_distance: Option<f32>) -> Result<Vec<RankedLine>> {
+        if subset_paths.is_empty() || top_k == 0 {
+            return Ok(Vec::new());
+        }
+        let mut owners: Vec<(SmtRange, &str)> = subset_paths.iter()
+            .filter_map(|p| self.extents.get(p).map(|e| (SmtRange { begin: e.first_row, end: e.first_row + e.n_lines }, p.as_str())))
+            .collect();
+        owners.sort_by_key(|(r, _)| r.begin);
+        owners.dedup_by_key(|(r, _)| r.begin);
+        if owners.is_empty() {
+            return Ok(Vec::new());
+        }
+        let ranges: Vec<SmtRange> = owners.iter().map(|(r, _)| *r).collect();
+        let (mut rows, mut dist, mut n) = (vec![0u64; top_k], vec![0f64; top_k], 0u64);
+        check(unsafe { smt_search(self.corpus, query_vec.as_ptr(), 1, top_k as u32,
+                                  max_distance.map(|d| d as f64).unwrap_or(f64::NAN), SMT_MODE_WORKSPACE,
+                                  ranges.as_ptr(), ranges.len() as u32, 0, rows.as_mut_ptr(), dist.as_mut_ptr(), &mut n,
+                                  top_k as u64) })?;
+        Ok((0..n as usize).map(|i| {
+            let j = owners.partition_point(|(r, _)| r.end <= rows[i]);
+            let (r, path) = owners[j];
+            RankedLine { path: path.to_string(), line_number: (rows[i] - r.begin) as i32, distance: dist[i] as f32 }  // :527-532
+        }).collect())
+    }
+}
+
+impl Drop for HipLineStore {
+    fn drop(&mut self) {
+        unsafe { smt_corpus_destroy(self.corpus) };
+    }
+}
