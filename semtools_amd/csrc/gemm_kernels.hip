@@ -33,6 +33,8 @@
 // answer is the exact top-k of a superset of the true top-k' => deterministic.
 // A query whose buffer overflows (adversarial row order) is flagged and redone
 // by the K2 scan.
+#include <type_traits>
+
 #include "common.h"
 #include "device_utils.h"
 #include "mfma_tile.h"
@@ -57,6 +59,10 @@ struct GemmParams {
     const float *tau;         // [nqt*32] distance thresholds (+inf = take everything, <0 = padding)
     key_t64 *cand;            // [nq][CAND_CAP]
     unsigned int *counts;     // [nq]
+    // range-filtered batches (gemm_ldsrow_kernel<.., true>): the rows to scan are the FILTER_CHUNK-row chunks of the
+    // chunk table (scan_kernels.hip: row0 | valid rows << 32); a "tile" is then 8 consecutive chunks
+    const uint64_t *chunk_table;
+    uint64_t n_chunks;
 };
 
 __device__ __forceinline__ uint64_t level_tile(uint64_t i, uint64_t stride, int skip16)
@@ -348,6 +354,228 @@ __global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParam
     }
 }
 
+// ---- small / medium batches, second generation (nq <= 64 per pass): ROW TILES LAND IN LDS BY LDS-DMA.
+// The resident kernel above pulls its 32-row tile straight into registers with fragment-shaped loads: one wave
+// instruction touches 32 B of 32 different rows, every 128-B line is requested four times and the vector L1 thrashes
+// (32 queries x 10 M rows: 3.0 ms against an HBM bound of 1.28 ms).  Here
+//   * the QUERY tiles are the register-resident MFMA operand (B: 128 VGPRs per 32 queries, loaded once per kernel),
+//   * the corpus streams through a per-wave LDS ring of four 8 KiB K-SLICES (32 rows x 64 dims) filled by
+//     global_load_lds_dwordx4: one instruction moves 4 rows x 256 contiguous bytes, no staging registers, no ds_write,
+//   * A fragments are read from the ring with ds_read_b128 (one read feeds 4 x NQT MFMAs), double-buffered in
+//     registers so the LDS latency of slice s+1 hides under the MFMAs of slice s,
+//   * a slot is refilled (next tile, same slice) the moment its fragments sit in registers: three slices = 24 KiB
+//     per wave = 96 KiB per CU are in flight at any time, counted with s_waitcnt vmcnt(24) -- no barrier anywhere,
+//     every wave runs its own pipeline.
+// LDS image: rows are 256 B apart inside a slice (no padding: LDS-DMA writes lane-linear), so the 16-B chunk c of
+// row i is stored at position c ^ (i & 7): the swizzle is applied to the SOURCE address of the DMA and to the
+// fragment read (same involution on both sides), which spreads the 8 lanes of a read phase over all 32 banks.
+// Row norms come from the fragments (each lane squares the half row it reads anyway); the scale 1/|row| moves to
+// the epilogue (acc * rb >= threshold), since rows are never in registers as rows.
+// FILTERED: tile t = chunks 8t .. 8t+7 of the chunk table (4 rows each, the last of a range short): DMA instruction
+// u of a slice covers exactly chunk u, whose descriptor is a wave-uniform scalar load.
+constexpr int LR_THREADS = 256;
+constexpr int LR_WAVES = LR_THREADS / 64;
+constexpr int LR_SLICES = 4;                       // K-slices per tile (64 dims each)
+constexpr int LR_SLICE_BYTES = 32 * 256;           // 8 KiB
+constexpr int LR_WAVE_BYTES = LR_SLICES * LR_SLICE_BYTES;
+
+// LDS-DMA of K-slice S of a tile: 8 instructions, each moves 4 rows x 256 B (1 KiB, lane-linear in LDS).
+// (A free function template, not a generic lambda inside the kernel: with __builtin_amdgcn_global_load_lds inside a
+// generic lambda hipcc 7.2 silently drops the kernel's HOST stub -- undefined __device_stub__ at link time.)
+template <int S>
+__device__ __forceinline__ void lr_fill_slice(const float *const (&ptr)[8], unsigned char *ring)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        __builtin_amdgcn_global_load_lds(ptr[u] + 64 * S, (__attribute__((address_space(3))) void *)(ring + S * LR_SLICE_BYTES + u * 1024),
+                                         16, 0, 0);
+}
+
+template <int NQT, bool FILTERED>
+__global__ void __launch_bounds__(LR_THREADS, 1) gemm_ldsrow_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    unsigned char *ring = smem_raw + wave * LR_WAVE_BYTES;
+
+    // ---- B operand: this lane's query of every tile, K-permuted like the A fragments (dims 8m+4h .. +3 in group m)
+    f32x4 Bq[NQT][32];
+    float thr[NQT], rq[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = t * QT_ROWS + j;
+        const bool ok = q < p.nq;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.queries + (size_t)(ok ? q : 0) * 256) + h;
+        float part = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            f32x4 v = src[2 * m];
+            if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Bq[t][m] = v;
+            part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        const float a2 = part + __shfl_xor(part, 32);
+        rq[t] = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
+        thr[t] = score_threshold(ok ? p.tau[q] : -1.0f, rq[t]);  // padding: zero query, tau < 0 -> never passes
+    }
+    // (every ordinary global load above has been consumed: none is pending when the first LDS-DMA is issued)
+
+    const uint64_t W = (uint64_t)gridDim.x * LR_WAVES;
+    uint64_t it = (uint64_t)blockIdx.x * LR_WAVES + wave;
+    if (it >= p.level_tiles) return;
+    const const_u64_ptr table = (const_u64_ptr)(uintptr_t)p.chunk_table;
+
+    // lane geometry of one DMA instruction (rows 4u .. 4u+3 of the tile, 256 B of each) and of a fragment read
+    const int rl = lane >> 4, pos = lane & 15;
+    uint32_t foff[8];  // byte offset of fragment m' inside a slice: row j, chunk (2m'+h) stored at chunk ^ (j & 7)
+#pragma unroll
+    for (int mp = 0; mp < 8; ++mp) foff[mp] = (uint32_t)(j * 256 + (((2 * mp + h) ^ (j & 7)) << 4));
+
+    struct TileSrc {
+        const float *ptr[8];   // per DMA instruction: this lane's source (row base + swizzled chunk), slice 0
+        uint32_t row0[8];      // FILTERED: first row of chunk u (wave-uniform)
+        uint32_t valid32;      // bit i: tile row i exists (wave-uniform)
+        uint64_t first_row;    // unfiltered: row of tile row 0
+    };
+    auto describe = [&](uint64_t tile, TileSrc &d) {
+        d.valid32 = 0;
+        d.first_row = tile * 32;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 4 * u + rl;  // tile row this lane moves
+            uint64_t row;
+            if constexpr (FILTERED) {
+                const uint64_t c = tile * 8 + u;
+                const uint64_t desc = c < p.n_chunks ? table[c] : 0ull;  // wave-uniform: scalar load
+                const uint32_t r0 = (uint32_t)desc, cnt = (uint32_t)(desc >> 32);
+                d.row0[u] = r0;
+                d.valid32 |= ((1u << cnt) - 1u) << (4 * u);
+                row = (uint64_t)r0 + ((uint32_t)rl < cnt ? (uint32_t)rl : (cnt ? cnt - 1 : 0u));
+            } else {
+                d.row0[u] = 0;
+                row = d.first_row + i;
+                if (row >= p.n_rows) row = p.n_rows - 1;  // clamp: fetched, never used (valid32)
+            }
+            d.ptr[u] = p.corpus + row * 256 + ((pos ^ (i & 7)) << 2);
+        }
+        if constexpr (!FILTERED) {
+            const uint64_t left = p.n_rows > d.first_row ? p.n_rows - d.first_row : 0;
+            d.valid32 = left >= 32 ? 0xFFFFFFFFu : ((1u << (uint32_t)left) - 1u);
+        }
+    };
+    auto fill = [&](const TileSrc &d, auto S) { lr_fill_slice<decltype(S)::value>(d.ptr, ring); };
+    auto read_frags = [&](int s, f32x4 (&f)[8]) {
+#pragma unroll
+        for (int mp = 0; mp < 8; ++mp) f[mp] = *reinterpret_cast<const f32x4 *>(ring + s * LR_SLICE_BYTES + foff[mp]);
+    };
+    // counted waits (imm: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+    auto wait_vm24 = [&]() { __builtin_amdgcn_s_waitcnt(0x4F78); asm volatile("" ::: "memory"); };  // vmcnt(24)
+    auto wait_lgkm0 = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); }; // lgkmcnt(0), vmcnt untouched
+
+    TileSrc cur_t, nxt_t;
+    describe(level_tile(it, p.stride, p.skip16), cur_t);
+    fill(cur_t, std::integral_constant<int, 0>{});
+    fill(cur_t, std::integral_constant<int, 1>{});
+    fill(cur_t, std::integral_constant<int, 2>{});
+    fill(cur_t, std::integral_constant<int, 3>{});
+    wait_vm24();  // slice 0 has landed (24 younger instructions may still fly)
+    f32x4 fa[8], fb[8];
+    read_frags(0, fa);
+
+    for (; it < p.level_tiles; it += W) {
+        const bool more = it + W < p.level_tiles;  // wave-uniform
+        if (more) describe(level_tile(it + W, p.stride, p.skip16), nxt_t);
+        else nxt_t = cur_t;                        // dummy refills keep the vmcnt arithmetic uniform (valid addresses)
+
+        f32x16 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        float part = 0.0f;
+
+        // one K-slice: `cur` holds slice S's fragments; refill its slot, fetch the next slice's fragments, multiply
+        auto step = [&](auto S, f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
+            constexpr int s = decltype(S)::value;
+            wait_lgkm0();                      // the ds_reads of slot s have returned: the slot is free
+            fill(nxt_t, S);                    // slot s <- (next tile, slice s)
+            wait_vm24();                       // slice s+1 (or the next tile's slice 0) has landed
+            read_frags((s + 1) & 3, nxt);
+#pragma unroll
+            for (int mp = 0; mp < 8; ++mp) {
+                const f32x4 a = cur[mp];
+                part += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) {
+                    const f32x4 b = Bq[t][8 * s + mp];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        step(std::integral_constant<int, 0>{}, fa, fb);
+        step(std::integral_constant<int, 1>{}, fb, fa);
+        step(std::integral_constant<int, 2>{}, fa, fb);
+        step(std::integral_constant<int, 3>{}, fb, fa);  // leaves the NEXT tile's slice-0 fragments in fa
+
+        // ---- epilogue: lane (j, h) owns query j of every tile and the 16 rows acc_row(r, h)
+        const float b2 = part + __shfl_xor(part, 32);   // row j's norm^2 (both halves hold it)
+        const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);
+        float rbv[16];
+        unsigned zero16 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            rbv[r] = __shfl(rb, acc_row(r, h));
+            if (rbv[r] == 0.0f) zero16 |= 1u << r;
+        }
+        const uint32_t v = cur_t.valid32 >> (4 * h);
+        const unsigned valid16 = (v & 0xFu) | (((v >> 8) & 0xFu) << 4) | (((v >> 16) & 0xFu) << 8) | (((v >> 24) & 0xFu) << 12);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            const uint32_t q = t * QT_ROWS + j;
+            unsigned pass = 0;
+            auto dist_of = [&](int r) {
+                if (rq[t] == 0.0f) return (zero16 >> r) & 1u ? 0.0f : 1.0f;   // zero query (simsimd rules)
+                return fmaxf(1.0f - acc[t][r] * rbv[r] * rq[t], 0.0f);         // a zero row has rb == 0 -> 1
+            };
+            if (rq[t] != 0.0f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[t][r] * rbv[r] >= thr[t]) pass |= 1u << r;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (dist_of(r) <= thr[t]) pass |= 1u << r;
+            }
+            pass &= valid16;
+            if (__builtin_amdgcn_ballot_w64(pass != 0)) {
+                if (pass) {
+                    const unsigned base = atomicAdd(&p.counts[q], (unsigned)__popc(pass));
+                    key_t64 *dst = p.cand + (size_t)q * CAND_CAP;
+                    unsigned slot = base;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (pass & (1u << r)) {
+                            const int i = acc_row(r, h);
+                            // (constant indices only: a lane-dependent index would send row0[] to scratch)
+                            const uint32_t r0 = h ? cur_t.row0[2 * (r >> 2) + 1] : cur_t.row0[2 * (r >> 2)];
+                            const uint32_t row = FILTERED ? r0 + (uint32_t)(i & 3) : (uint32_t)(cur_t.first_row + i);
+                            if (slot < CAND_CAP) dst[slot] = make_key(dist_of(r), row);
+                            ++slot;
+                        }
+                    }
+                }
+            }
+        }
+        cur_t = nxt_t;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no LDS-DMA may outlive the wave's LDS allocation
+}
+
 // Per query: keep the kp best of the candidates gathered so far (sorted, at the
 // head of the buffer), publish tau = kp-th distance, flag overflow.
 struct LevelSelectParams {
@@ -399,18 +627,25 @@ static size_t gemm_smem_bytes(uint32_t nqt)
 
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
 {
-    if (a.n_ranges != 0) { set_error("the batched MFMA path does not take row ranges"); return SMT_E_UNSUPPORTED; }
     if (a.k_out + 8 > 64 || a.k_out < 1) { set_error("batched path: top_k must be in [1, 56]"); return SMT_E_UNSUPPORTED; }
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
+    const bool filtered = a.n_ranges != 0;
     const uint32_t kp = a.k_out + 8;
     const uint32_t nqt = (a.nq + QT_ROWS - 1) / QT_ROWS;
     const uint64_t ostride = a.out_stride ? a.out_stride : a.k_out;
-    if (a.nq > GEMM_MAX_NQ) {
-        // the per-query thresholds of one launch live in LDS beside the four query-tile slots: larger batches
-        // are answered in chunks (each chunk is its own sweep over the corpus -- inherent at this batch size)
-        for (uint32_t q0 = 0; q0 < a.nq; q0 += GEMM_MAX_NQ) {
+    // Which kernel: up to 128 queries (and every range-filtered batch) take the LDS-row kernel in passes of <= 64
+    // queries -- two query tiles are what fits the register file as the resident MFMA operand; a pass re-reads the
+    // corpus, which a 64-query pass (MFMA time 1.6x the HBM time) does not notice.  Larger batches stream the query
+    // tiles through LDS instead (gemm_level_kernel), one sweep over the corpus for up to 3584 queries.
+    const bool lds_rows = ctx->tune.gemm_ldsrow && (filtered || nqt <= 4);
+    if (filtered && !lds_rows) { set_error("range-filtered batches need the LDS-row kernel (tuning key gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
+    const uint32_t pass_nq = lds_rows ? 2 * QT_ROWS : GEMM_MAX_NQ;
+    if (a.nq > pass_nq) {
+        // (GEMM_MAX_NQ: the per-query thresholds of one gemm_level_kernel launch live in LDS beside the four
+        // query-tile slots: larger batches are answered in chunks, each its own sweep over the corpus)
+        for (uint32_t q0 = 0; q0 < a.nq; q0 += pass_nq) {
             ScanArgs c = a;
-            c.nq = std::min<uint32_t>(GEMM_MAX_NQ, a.nq - q0);
+            c.nq = std::min<uint32_t>(pass_nq, a.nq - q0);
             c.queries = a.queries + (size_t)q0 * 256;
             c.out_rows = a.out_rows + (size_t)q0 * ostride;
             c.out_dist = a.out_dist + (size_t)q0 * ostride;
@@ -432,6 +667,14 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_done |= ATTR_GEMM;
     }
 
@@ -439,19 +682,23 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const size_t b_cand = (size_t)a.nq * CAND_CAP * sizeof(key_t64);
     const size_t b_cnt = (((size_t)a.nq * 4) + 15) & ~(size_t)15;
     const size_t b_tau = (size_t)nqt * QT_ROWS * 4;
-    int rc = ensure_scratch(ctx, b_cand + 2 * b_cnt + b_tau + 64);
+    const uint64_t n_chunks = filtered ? a.n_chunks : 0;
+    const size_t b_head = (b_cand + 2 * b_cnt + b_tau + 255) & ~(size_t)255;
+    int rc = ensure_scratch(ctx, b_head + (size_t)n_chunks * sizeof(uint64_t) + 64);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(ctx->d_scratch);
     key_t64 *cand = reinterpret_cast<key_t64 *>(base);
     unsigned int *counts = reinterpret_cast<unsigned int *>(base + b_cand);
     unsigned int *overflow = reinterpret_cast<unsigned int *>(base + b_cand + b_cnt);
     float *tau = reinterpret_cast<float *>(base + b_cand + 2 * b_cnt);
+    uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
+    if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
                        __builtin_inff(), nqt * QT_ROWS);
 
     // level plan: strides 16^(L-1) ... 16, 1 with level 0 <= LEVEL0_MAX_TILES tiles
-    const uint64_t n_tiles = (a.rows + 31) / 32;
+    const uint64_t n_tiles = filtered ? (n_chunks + 7) / 8 : (a.rows + 31) / 32;  // filtered: a tile = 8 chunks of <= 4 rows
     int L = 1;
     uint64_t s0 = 1;
     while ((n_tiles + s0 - 1) / s0 > (uint64_t)LEVEL0_MAX_TILES) { s0 *= LEVEL_RATIO; ++L; }
@@ -474,7 +721,22 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.tau = tau;
         g.cand = cand;
         g.counts = counts;
-        if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident) {
+        g.chunk_table = filtered ? chunk_table : nullptr;
+        g.n_chunks = n_chunks;
+        if (g.level_tiles > 0 && lds_rows) {
+            const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
+            const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
+            const size_t smem = (size_t)LR_WAVES * LR_WAVE_BYTES;
+            prof_begin(ctx, "gemm");
+            if (nqt <= 1) {
+                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<1, true>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                else hipLaunchKernelGGL((gemm_ldsrow_kernel<1, false>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+            } else {
+                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<2, true>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                else hipLaunchKernelGGL((gemm_ldsrow_kernel<2, false>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+            }
+            prof_end(ctx, "gemm");
+        } else if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident) {
             const uint64_t need_blocks = (g.level_tiles + RES_WAVES - 1) / RES_WAVES;
             const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
             const size_t smem = (size_t)(nqt <= 1 ? 1 : nqt <= 2 ? 2 : 4) * (QT_F4 * 16 + QT_ROWS * 8) + 64;

@@ -108,3 +108,52 @@ def test_candidate_buffer_overflow_falls_back_to_exact_scan(gpu_ctx):
         assert got[i][0].tolist() == [r["match_line"] for r in res], i
         assert np.array_equal(got[i][1], np.array([r["distance"] for r in res]))
     c.close()
+
+
+@pytest.mark.parametrize("nq", [8, 33, 70])
+def test_batched_with_row_ranges_reaches_the_mfma_path(gpu_ctx, nq):
+    """Range-filtered batches (the workspace path-subset filter with several queries, store.rs:507-515) run on the
+    LDS-row MFMA kernel through the chunk-descriptor table: same answer as the oracle on the eligible rows and as
+    the single-query (K2) path."""
+    import semtools_amd as smt
+
+    n = 30011
+    emb = synth.unit_rows(n, seed=19)
+    qs = synth.unit_query(21, nq=nq)
+    ranges = [(3, 1001), (1002, 1003), (5000, 5002), (7777, 20000), (29990, 30011)]   # ragged: lengths 998, 1, 2, 12223, 21
+    elig = np.concatenate([np.arange(b, e) for b, e in ranges])
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    for k in (1, 10):
+        got = c.search(qs, top_k=k, ranges=ranges)
+        for i in range(nq):
+            orows, odist = _oracle_topk(emb[elig], qs[i], k)
+            assert got[i][0].tolist() == elig[np.array(orows, dtype=np.int64)].tolist(), (k, i)
+            assert np.array_equal(got[i][1], np.array(odist))
+        one = c.search(qs[0], top_k=k, ranges=ranges)[0]
+        assert got[0][0].tolist() == one[0].tolist() and np.array_equal(got[0][1], one[1])
+    # workspace semantics over ranges, batched
+    got = c.search(qs, top_k=5, max_distance=0.95, mode=smt.MODE_WORKSPACE, ranges=ranges)
+    for i in (0, nq - 1):
+        one = c.search(qs[i], top_k=5, max_distance=0.95, mode=smt.MODE_WORKSPACE, ranges=ranges)[0]
+        assert got[i][0].tolist() == one[0].tolist()
+    c.close()
+
+
+def test_both_small_batch_kernels_agree(gpu_ctx):
+    """The first-generation resident-query kernel stays selectable (tuning key gemm_ldsrow = 0) for A/B runs."""
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(40000, seed=23)
+    qs = synth.unit_query(24, nq=100)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    new = c.search(qs, top_k=10)
+    gpu_ctx.set_tuning("gemm_ldsrow", 0)
+    try:
+        old = c.search(qs, top_k=10)
+    finally:
+        gpu_ctx.set_tuning("gemm_ldsrow", 1)
+    for a, b in zip(new, old):
+        assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+    c.close()
