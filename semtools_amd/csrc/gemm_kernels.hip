@@ -42,8 +42,15 @@
 namespace smt {
 
 constexpr uint32_t CAND_CAP = 2048;            // candidate slots per query
-constexpr int LEVEL_RATIO = 16;
-constexpr int LEVEL0_MAX_TILES = 32;           // level 0 appends every row: <= 1024 per query
+// Level plan: tiles are visited in levels of geometrically growing size (every ratio^j-th tile first).  Level 0
+// (<= LEVEL0_MAX_TILES tiles = 1024 rows) appends every row; each later level appends about ratio x k' candidates
+// per query.  Measured alternative (MI355X, 10 M rows): ratio 64 with 4096 slots -- three levels instead of five --
+// LOSES: its middle level (4.8 k tiles) leaves every wave two tiles, the O(n^2) level select over ~3 k candidates
+// costs 90 us per level instead of 8 (32 queries: 2.34 vs 2.07 ms per batch; 1000 queries: 41.2 vs 39.8 ms).
+constexpr int LEVEL_RATIO_SMALL_K = 16;
+constexpr int LEVEL_RATIO_LARGE_K = 16;
+constexpr uint32_t LEVEL_RATIO_KP_LIMIT = 24;
+constexpr int LEVEL0_MAX_TILES = 32;
 constexpr uint32_t GEMM_MAX_NQ = 3584;         // 4 x 32.5 KiB tile slots + 8 B per query fit the 160 KiB LDS
 
 struct GemmParams {
@@ -54,7 +61,7 @@ struct GemmParams {
     uint32_t nqt;             // ceil(nq / 32)
     uint64_t level_tiles;     // tiles visited by this launch
     uint64_t stride;          // visited tile = stride * u(i)
-    int skip16;               // 1: u skips multiples of 16 (they belong to earlier levels)
+    int skip16;               // LEVEL_RATIO (64 or 16) when u skips the multiples of the ratio (they belong to earlier levels), else 0
     uint32_t qsplit;          // gemm_level_kernel: blocks per row-tile group, each sweeping 1/qsplit of the query tiles
     const float *tau;         // [nqt*32] distance thresholds (+inf = take everything, <0 = padding)
     key_t64 *cand;            // [nq][CAND_CAP]
@@ -67,7 +74,10 @@ struct GemmParams {
 
 __device__ __forceinline__ uint64_t level_tile(uint64_t i, uint64_t stride, int skip16)
 {
-    const uint64_t u = skip16 ? (i / (LEVEL_RATIO - 1)) * LEVEL_RATIO + (i % (LEVEL_RATIO - 1)) + 1 : i;
+    if (!skip16) return i * stride;
+    // i-th positive integer that is not a multiple of the ratio (constant divisors: no runtime division)
+    const uint64_t d = skip16 == 64 ? i / 63 : i / 15;
+    const uint64_t u = d * (uint64_t)skip16 + (i - d * (uint64_t)(skip16 - 1)) + 1;
     return u * stride;
 }
 
@@ -358,131 +368,184 @@ __global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParam
 // The resident kernel above pulls its 32-row tile straight into registers with fragment-shaped loads: one wave
 // instruction touches 32 B of 32 different rows, every 128-B line is requested four times and the vector L1 thrashes
 // (32 queries x 10 M rows: 3.0 ms against an HBM bound of 1.28 ms).  Here
-//   * the QUERY tiles are the register-resident MFMA operand (B: 128 VGPRs per 32 queries, loaded once per kernel),
-//   * the corpus streams through a per-wave LDS ring of four 8 KiB K-SLICES (32 rows x 64 dims) filled by
-//     global_load_lds_dwordx4: one instruction moves 4 rows x 256 contiguous bytes, no staging registers, no ds_write,
-//   * A fragments are read from the ring with ds_read_b128 (one read feeds 4 x NQT MFMAs), double-buffered in
-//     registers so the LDS latency of slice s+1 hides under the MFMAs of slice s,
-//   * a slot is refilled (next tile, same slice) the moment its fragments sit in registers: three slices = 24 KiB
-//     per wave = 96 KiB per CU are in flight at any time, counted with s_waitcnt vmcnt(24) -- no barrier anywhere,
-//     every wave runs its own pipeline.
+//   * the corpus streams through a per-wave LDS ring of 8 KiB K-SLICES (32 rows x 64 dims) filled by
+//     global_load_lds_dwordx4: one instruction moves 4 rows x 256 contiguous bytes, no staging registers, no ds_write;
+//   * A fragments are read from the ring with ds_read_b128 (one read feeds 4 x NQT MFMAs); a slot is refilled the
+//     moment its fragments sit in registers, so the ring only ever holds bytes in flight;
+//   * NQT = 1 (<= 32 queries, HBM-bound): the query tile is the register-resident MFMA operand (128 VGPRs), the
+//     ring has two slots per wave (16 KiB/wave, 128 KiB/CU in flight), counted s_waitcnt vmcnt(8);
+//     NQT = 2 (<= 64 queries, MFMA-bound): both operands come from LDS (64 KiB of swizzled queries + one slot per
+//     wave), the 64 MFMAs of a slice cover the refill of its slot;
+//   * EIGHT waves per CU, two per SIMD (<= 256 VGPRs): the first version ran one wave per SIMD and measured
+//     MFMA time + everything else, back to back (ablations on MI355X, 32 queries x 10 M rows: MFMAs alone 1.04 ms,
+//     LDS reads + address work alone 0.63 ms, together 1.68 ms; epilogue +0.25 ms; DMA waits +0.25 ms) -- a lone
+//     wave issues in order, so its own LDS waits, norm FMAs and epilogue stall its MFMA stream; the second wave of
+//     the SIMD fills those holes (the gemm_level_kernel below already worked that way);
+//   * no barrier anywhere: every wave runs its own pipeline (s_waitcnt vmcnt(N) covers the issuing wave's LDS-DMA).
 // LDS image: rows are 256 B apart inside a slice (no padding: LDS-DMA writes lane-linear), so the 16-B chunk c of
 // row i is stored at position c ^ (i & 7): the swizzle is applied to the SOURCE address of the DMA and to the
 // fragment read (same involution on both sides), which spreads the 8 lanes of a read phase over all 32 banks.
 // Row norms come from the fragments (each lane squares the half row it reads anyway); the scale 1/|row| moves to
-// the epilogue (acc * rb >= threshold), since rows are never in registers as rows.
+// the epilogue (acc * rb >= threshold) and travels through a 128-B LDS scratch (one write, four b128 reads per lane
+// instead of 16 ds_bpermute round trips).
 // FILTERED: tile t = chunks 8t .. 8t+7 of the chunk table (4 rows each, the last of a range short): DMA instruction
 // u of a slice covers exactly chunk u, whose descriptor is a wave-uniform scalar load.
-constexpr int LR_THREADS = 256;
+constexpr int LR_THREADS = 512;
 constexpr int LR_WAVES = LR_THREADS / 64;
-constexpr int LR_SLICES = 4;                       // K-slices per tile (64 dims each)
-constexpr int LR_SLICE_BYTES = 32 * 256;           // 8 KiB
-constexpr int LR_WAVE_BYTES = LR_SLICES * LR_SLICE_BYTES;
+constexpr int LR_SLICE_BYTES = 32 * 256;           // one K-slice: 32 rows x 64 dims = 8 KiB
+constexpr int LR_QTILE_BYTES = 32 * 1024;          // NQT = 2: a query tile in LDS, swizzled, unpadded
 
-// LDS-DMA of K-slice S of a tile: 8 instructions, each moves 4 rows x 256 B (1 KiB, lane-linear in LDS).
-// (A free function template, not a generic lambda inside the kernel: with __builtin_amdgcn_global_load_lds inside a
-// generic lambda hipcc 7.2 silently drops the kernel's HOST stub -- undefined __device_stub__ at link time.)
-template <int S>
-__device__ __forceinline__ void lr_fill_slice(const float *const (&ptr)[8], unsigned char *ring)
+template <int NQT>
+struct LrGeom {
+    static constexpr int SLOTS = NQT == 1 ? 2 : 1;                        // ring slots per wave
+    static constexpr int Q_BYTES = NQT == 1 ? 0 : NQT * LR_QTILE_BYTES;   // queries in LDS (NQT = 1: in registers)
+    static constexpr int RING_BYTES = SLOTS * LR_SLICE_BYTES;             // per wave
+    static constexpr int SCRATCH_OFF = Q_BYTES + LR_WAVES * RING_BYTES;   // 128 B per wave: row scales for the epilogue
+    static constexpr int SMEM = SCRATCH_OFF + LR_WAVES * 128;
+};
+
+// LDS-DMA of one K-slice (dims 64*S ..) of a tile into `slot`: 8 instructions, each moves 4 rows x 256 B (1 KiB,
+// lane-linear in LDS).  rows[u] = this lane's row for instruction u; swz = its swizzled chunk offset in floats for
+// even / odd u.  (A free function template, not a generic lambda inside the kernel: with
+// __builtin_amdgcn_global_load_lds inside a generic lambda hipcc 7.2 silently drops the kernel's HOST stub.)
+template <int S, int AUX>
+__device__ __forceinline__ void lr_fill_slice(const float *corpus, const uint32_t (&rows)[8], uint32_t swz_even, uint32_t swz_odd,
+                                              unsigned char *slot)
 {
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        __builtin_amdgcn_global_load_lds(ptr[u] + 64 * S, (__attribute__((address_space(3))) void *)(ring + S * LR_SLICE_BYTES + u * 1024),
-                                         16, 0, 0);
+    for (int u = 0; u < 8; ++u) {
+        const float *src = corpus + (uint64_t)rows[u] * 256 + ((u & 1) ? swz_odd : swz_even) + 64 * S;
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(slot + u * 1024), 16, 0, AUX);
+    }
 }
 
-template <int NQT, bool FILTERED>
-__global__ void __launch_bounds__(LR_THREADS, 1) gemm_ldsrow_kernel(GemmParams p)
+// AUX: cache-policy bits of the row DMA (0 = default, 2 = nt: the corpus is streamed once)
+template <int NQT, bool FILTERED, int AUX>
+__global__ void __launch_bounds__(LR_THREADS) gemm_ldsrow_kernel(GemmParams p)
 {
+    using G = LrGeom<NQT>;
+    constexpr bool B_REGS = NQT == 1;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    unsigned char *ring = smem_raw + wave * LR_WAVE_BYTES;
+    unsigned char *ring = smem_raw + G::Q_BYTES + wave * G::RING_BYTES;
+    float *scale = reinterpret_cast<float *>(smem_raw + G::SCRATCH_OFF + wave * 128);
+
+    // fragment geometry: lane (j, h) reads chunk 2m'+h of row j, stored at position chunk ^ (j & 7)
+    uint32_t foff[8];  // byte offset of fragment m' inside a slice
+#pragma unroll
+    for (int mp = 0; mp < 8; ++mp) foff[mp] = (uint32_t)(j * 256 + (((2 * mp + h) ^ (j & 7)) << 4));
 
     // ---- B operand: this lane's query of every tile, K-permuted like the A fragments (dims 8m+4h .. +3 in group m)
-    f32x4 Bq[NQT][32];
+    f32x4 Bq[B_REGS ? 32 : 1];
     float thr[NQT], rq[NQT];
+    if constexpr (!B_REGS) {
+        // queries -> LDS by LDS-DMA, one 1 KiB row per instruction, chunk c of row r at position c ^ (r & 7)
+        for (int r = wave; r < NQT * QT_ROWS; r += LR_WAVES) {  // wave-uniform
+            unsigned char *dst = smem_raw + r * 1024;
+            if ((uint32_t)r < p.nq)
+                __builtin_amdgcn_global_load_lds(p.queries + (size_t)r * 256 + ((lane ^ (r & 7)) << 2),
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            else
+                reinterpret_cast<f32x4 *>(dst)[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();                     // the only barrier: the query image is shared by the block's waves
+    }
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
         const uint32_t q = t * QT_ROWS + j;
         const bool ok = q < p.nq;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.queries + (size_t)(ok ? q : 0) * 256) + h;
         float part = 0.0f;
+        if constexpr (B_REGS) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.queries + (size_t)(ok ? q : 0) * 256) + h;
 #pragma unroll
-        for (int m = 0; m < 32; ++m) {
-            f32x4 v = src[2 * m];
-            if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            Bq[t][m] = v;
-            part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            for (int m = 0; m < 32; ++m) {
+                f32x4 v = src[2 * m];
+                if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                Bq[m] = v;
+                part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        } else {
+            const unsigned char *qrow = smem_raw + t * LR_QTILE_BYTES + j * 1024;
+#pragma unroll 8
+            for (int m = 0; m < 32; ++m) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(qrow + (((2 * m + h) ^ (j & 7)) << 4));
+                part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
         }
         const float a2 = part + __shfl_xor(part, 32);
         rq[t] = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
         thr[t] = score_threshold(ok ? p.tau[q] : -1.0f, rq[t]);  // padding: zero query, tau < 0 -> never passes
     }
-    // (every ordinary global load above has been consumed: none is pending when the first LDS-DMA is issued)
+    // (every ordinary global load above has been consumed: none is pending when the first row DMA is issued)
 
     const uint64_t W = (uint64_t)gridDim.x * LR_WAVES;
     uint64_t it = (uint64_t)blockIdx.x * LR_WAVES + wave;
     if (it >= p.level_tiles) return;
     const const_u64_ptr table = (const_u64_ptr)(uintptr_t)p.chunk_table;
 
-    // lane geometry of one DMA instruction (rows 4u .. 4u+3 of the tile, 256 B of each) and of a fragment read
+    // lane geometry of one DMA instruction: rows 4u .. 4u+3 of the tile, 256 B of each
     const int rl = lane >> 4, pos = lane & 15;
-    uint32_t foff[8];  // byte offset of fragment m' inside a slice: row j, chunk (2m'+h) stored at chunk ^ (j & 7)
-#pragma unroll
-    for (int mp = 0; mp < 8; ++mp) foff[mp] = (uint32_t)(j * 256 + (((2 * mp + h) ^ (j & 7)) << 4));
+    const uint32_t swz_even = (uint32_t)((pos ^ rl) << 2);        // tile row i = 4u + rl: i & 7 = rl (u even)
+    const uint32_t swz_odd = (uint32_t)((pos ^ (4 + rl)) << 2);   //                             4 + rl (u odd)
 
     struct TileSrc {
-        const float *ptr[8];   // per DMA instruction: this lane's source (row base + swizzled chunk), slice 0
+        uint32_t rows[8];      // per DMA instruction: this lane's corpus row
         uint32_t row0[8];      // FILTERED: first row of chunk u (wave-uniform)
         uint32_t valid32;      // bit i: tile row i exists (wave-uniform)
-        uint64_t first_row;    // unfiltered: row of tile row 0
+        uint32_t first_row;    // unfiltered: row of tile row 0
     };
     auto describe = [&](uint64_t tile, TileSrc &d) {
         d.valid32 = 0;
-        d.first_row = tile * 32;
+        d.first_row = (uint32_t)(tile * 32);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = 4 * u + rl;  // tile row this lane moves
-            uint64_t row;
             if constexpr (FILTERED) {
                 const uint64_t c = tile * 8 + u;
                 const uint64_t desc = c < p.n_chunks ? table[c] : 0ull;  // wave-uniform: scalar load
                 const uint32_t r0 = (uint32_t)desc, cnt = (uint32_t)(desc >> 32);
                 d.row0[u] = r0;
                 d.valid32 |= ((1u << cnt) - 1u) << (4 * u);
-                row = (uint64_t)r0 + ((uint32_t)rl < cnt ? (uint32_t)rl : (cnt ? cnt - 1 : 0u));
+                d.rows[u] = r0 + ((uint32_t)rl < cnt ? (uint32_t)rl : (cnt ? cnt - 1 : 0u));
             } else {
                 d.row0[u] = 0;
-                row = d.first_row + i;
-                if (row >= p.n_rows) row = p.n_rows - 1;  // clamp: fetched, never used (valid32)
+                const uint64_t row = tile * 32 + 4 * u + rl;
+                d.rows[u] = (uint32_t)(row < p.n_rows ? row : p.n_rows - 1);  // clamp: fetched, never used (valid32)
             }
-            d.ptr[u] = p.corpus + row * 256 + ((pos ^ (i & 7)) << 2);
         }
         if constexpr (!FILTERED) {
-            const uint64_t left = p.n_rows > d.first_row ? p.n_rows - d.first_row : 0;
+            const uint64_t left = p.n_rows > tile * 32 ? p.n_rows - tile * 32 : 0;
             d.valid32 = left >= 32 ? 0xFFFFFFFFu : ((1u << (uint32_t)left) - 1u);
         }
     };
-    auto fill = [&](const TileSrc &d, auto S) { lr_fill_slice<decltype(S)::value>(d.ptr, ring); };
-    auto read_frags = [&](int s, f32x4 (&f)[8]) {
+    auto fill = [&](const TileSrc &d, auto S, int slot) {
+        lr_fill_slice<decltype(S)::value, AUX>(p.corpus, d.rows, swz_even, swz_odd, ring + slot * LR_SLICE_BYTES);
+    };
+    auto read_frags = [&](int slot, f32x4 (&f)[8]) {
 #pragma unroll
-        for (int mp = 0; mp < 8; ++mp) f[mp] = *reinterpret_cast<const f32x4 *>(ring + s * LR_SLICE_BYTES + foff[mp]);
+        for (int mp = 0; mp < 8; ++mp) f[mp] = *reinterpret_cast<const f32x4 *>(ring + slot * LR_SLICE_BYTES + foff[mp]);
     };
     // counted waits (imm: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-    auto wait_vm24 = [&]() { __builtin_amdgcn_s_waitcnt(0x4F78); asm volatile("" ::: "memory"); };  // vmcnt(24)
-    auto wait_lgkm0 = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); }; // lgkmcnt(0), vmcnt untouched
+    auto wait_landed = [&]() {   // the NEXT slice has landed; with two slots 8 younger instructions may still fly
+        if constexpr (G::SLOTS == 2) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+        asm volatile("" ::: "memory");
+    };
+    auto wait_lgkm0 = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };  // lgkmcnt(0), vmcnt untouched
 
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
     TileSrc cur_t, nxt_t;
     describe(level_tile(it, p.stride, p.skip16), cur_t);
-    fill(cur_t, std::integral_constant<int, 0>{});
-    fill(cur_t, std::integral_constant<int, 1>{});
-    fill(cur_t, std::integral_constant<int, 2>{});
-    fill(cur_t, std::integral_constant<int, 3>{});
-    wait_vm24();  // slice 0 has landed (24 younger instructions may still fly)
-    f32x4 fa[8], fb[8];
-    read_frags(0, fa);
+    fill(cur_t, S0{}, 0);
+    if constexpr (G::SLOTS == 2) fill(cur_t, S1{}, 1);
+    wait_landed();
+    f32x4 fr[8];
+    read_frags(0, fr);
 
     for (; it < p.level_tiles; it += W) {
         const bool more = it + W < p.level_tiles;  // wave-uniform
@@ -496,42 +559,62 @@ __global__ void __launch_bounds__(LR_THREADS, 1) gemm_ldsrow_kernel(GemmParams p
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         float part = 0.0f;
 
-        // one K-slice: `cur` holds slice S's fragments; refill its slot, fetch the next slice's fragments, multiply
-        auto step = [&](auto S, f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
+        // One K-slice.  `fr` holds slice S's fragments (its slot is free): refill that slot with the slice SLOTS
+        // ahead, multiply, then pull the next slice's fragments into `fr`.
+        auto step = [&](auto S, auto SAHEAD, const TileSrc &ahead_tile) {
             constexpr int s = decltype(S)::value;
-            wait_lgkm0();                      // the ds_reads of slot s have returned: the slot is free
-            fill(nxt_t, S);                    // slot s <- (next tile, slice s)
-            wait_vm24();                       // slice s+1 (or the next tile's slice 0) has landed
-            read_frags((s + 1) & 3, nxt);
+            constexpr int slot = G::SLOTS == 2 ? (s & 1) : 0;
+            constexpr int next_slot = G::SLOTS == 2 ? ((s + 1) & 1) : 0;
+            wait_lgkm0();                              // the ds_reads of `fr` have returned: its slot is free
+            fill(ahead_tile, SAHEAD, slot);
 #pragma unroll
             for (int mp = 0; mp < 8; ++mp) {
-                const f32x4 a = cur[mp];
+                const f32x4 a = fr[mp];
                 part += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
 #pragma unroll
                 for (int t = 0; t < NQT; ++t) {
-                    const f32x4 b = Bq[t][8 * s + mp];
+                    f32x4 b;
+                    if constexpr (B_REGS) b = Bq[8 * s + mp];
+                    else b = *reinterpret_cast<const f32x4 *>(smem_raw + t * LR_QTILE_BYTES + j * 1024 +
+                                                              (((2 * (8 * s + mp) + h) ^ (j & 7)) << 4));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);         // the MFMAs stay above: `fr` is single-buffered (register budget)
+            wait_landed();                             // the next slice is in LDS
+            read_frags(next_slot, fr);
+            __builtin_amdgcn_sched_barrier(0);
         };
-        step(std::integral_constant<int, 0>{}, fa, fb);
-        step(std::integral_constant<int, 1>{}, fb, fa);
-        step(std::integral_constant<int, 2>{}, fa, fb);
-        step(std::integral_constant<int, 3>{}, fb, fa);  // leaves the NEXT tile's slice-0 fragments in fa
+        if constexpr (G::SLOTS == 2) {
+            step(S0{}, S2{}, cur_t);   // slot 0 <- (this tile, slice 2)
+            step(S1{}, S3{}, cur_t);   // slot 1 <- (this tile, slice 3)
+            step(S2{}, S0{}, nxt_t);   // slot 0 <- (next tile, slice 0)
+            step(S3{}, S1{}, nxt_t);   // slot 1 <- (next tile, slice 1); leaves the next tile's slice-0 fragments in fr
+        } else {
+            step(S0{}, S1{}, cur_t);
+            step(S1{}, S2{}, cur_t);
+            step(S2{}, S3{}, cur_t);
+            step(S3{}, S0{}, nxt_t);
+        }
 
         // ---- epilogue: lane (j, h) owns query j of every tile and the 16 rows acc_row(r, h)
         const float b2 = part + __shfl_xor(part, 32);   // row j's norm^2 (both halves hold it)
         const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);
+        if (h == 0) scale[j] = rb;                      // wave-private scratch: no barrier, an lgkmcnt wait orders it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float rbv[16];
         unsigned zero16 = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            rbv[r] = __shfl(rb, acc_row(r, h));
-            if (rbv[r] == 0.0f) zero16 |= 1u << r;
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 8 * gq + 4 * h);  // rows acc_row(4gq .. 4gq+3, h)
+            rbv[4 * gq + 0] = sc.x; rbv[4 * gq + 1] = sc.y; rbv[4 * gq + 2] = sc.z; rbv[4 * gq + 3] = sc.w;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (rbv[r] == 0.0f) zero16 |= 1u << r;
         const uint32_t v = cur_t.valid32 >> (4 * h);
         const unsigned valid16 = (v & 0xFu) | (((v >> 8) & 0xFu) << 4) | (((v >> 16) & 0xFu) << 8) | (((v >> 24) & 0xFu) << 12);
 #pragma unroll
@@ -563,7 +646,7 @@ __global__ void __launch_bounds__(LR_THREADS, 1) gemm_ldsrow_kernel(GemmParams p
                             const int i = acc_row(r, h);
                             // (constant indices only: a lane-dependent index would send row0[] to scratch)
                             const uint32_t r0 = h ? cur_t.row0[2 * (r >> 2) + 1] : cur_t.row0[2 * (r >> 2)];
-                            const uint32_t row = FILTERED ? r0 + (uint32_t)(i & 3) : (uint32_t)(cur_t.first_row + i);
+                            const uint32_t row = FILTERED ? r0 + (uint32_t)(i & 3) : cur_t.first_row + (uint32_t)i;
                             if (slot < CAND_CAP) dst[slot] = make_key(dist_of(r), row);
                             ++slot;
                         }
@@ -633,11 +716,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const uint32_t kp = a.k_out + 8;
     const uint32_t nqt = (a.nq + QT_ROWS - 1) / QT_ROWS;
     const uint64_t ostride = a.out_stride ? a.out_stride : a.k_out;
-    // Which kernel: up to 128 queries (and every range-filtered batch) take the LDS-row kernel in passes of <= 64
-    // queries -- two query tiles are what fits the register file as the resident MFMA operand; a pass re-reads the
-    // corpus, which a 64-query pass (MFMA time 1.6x the HBM time) does not notice.  Larger batches stream the query
-    // tiles through LDS instead (gemm_level_kernel), one sweep over the corpus for up to 3584 queries.
-    const bool lds_rows = ctx->tune.gemm_ldsrow && (filtered || nqt <= 4);
+    // Which kernel (measured on MI355X, 10 M rows, ms per batch: LDS-row kernel / gemm_level_kernel):
+    //   8..32 queries 1.84 / 3.1;  64 queries 3.05 / 3.24;  96 queries 4.96 (two passes) / 4.32;  128: 6.04 / 5.48.
+    // So: up to 64 queries, and every range-filtered batch (in passes of 64), take the LDS-row kernel; larger batches
+    // stream the query tiles through LDS (gemm_level_kernel), one sweep over the corpus for up to 3584 queries.
+    const bool lds_rows = ctx->tune.gemm_ldsrow && (filtered || nqt <= 2);
     if (filtered && !lds_rows) { set_error("range-filtered batches need the LDS-row kernel (tuning key gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
     const uint32_t pass_nq = lds_rows ? 2 * QT_ROWS : GEMM_MAX_NQ;
     if (a.nq > pass_nq) {
@@ -667,13 +750,17 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, false>),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, false, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, false>),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, false, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, true>),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, false, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, true>),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, false, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, true, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, true, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_done |= ATTR_GEMM;
     }
@@ -697,7 +784,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
                        __builtin_inff(), nqt * QT_ROWS);
 
-    // level plan: strides 16^(L-1) ... 16, 1 with level 0 <= LEVEL0_MAX_TILES tiles
+    // level plan: strides ratio^(L-1) ... ratio, 1 with level 0 <= LEVEL0_MAX_TILES tiles
+    const int LEVEL_RATIO = kp <= LEVEL_RATIO_KP_LIMIT ? LEVEL_RATIO_SMALL_K : LEVEL_RATIO_LARGE_K;
     const uint64_t n_tiles = filtered ? (n_chunks + 7) / 8 : (a.rows + 31) / 32;  // filtered: a tile = 8 chunks of <= 4 rows
     int L = 1;
     uint64_t s0 = 1;
@@ -716,7 +804,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.nqt = nqt;
         g.level_tiles = multiples - parents;
         g.stride = stride;
-        g.skip16 = lev == 0 ? 0 : 1;
+        g.skip16 = lev == 0 ? 0 : LEVEL_RATIO;
         g.qsplit = 1;
         g.tau = tau;
         g.cand = cand;
@@ -726,17 +814,20 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         if (g.level_tiles > 0 && lds_rows) {
             const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
             const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
-            const size_t smem = (size_t)LR_WAVES * LR_WAVE_BYTES;
+            const size_t smem = nqt <= 1 ? (size_t)LrGeom<1>::SMEM : (size_t)LrGeom<2>::SMEM;
             prof_begin(ctx, "gemm");
+            const bool nt = ctx->tune.gemm_dma_nt != 0;
             if (nqt <= 1) {
-                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<1, true>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-                else hipLaunchKernelGGL((gemm_ldsrow_kernel<1, false>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<1, true, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                else if (nt) hipLaunchKernelGGL((gemm_ldsrow_kernel<1, false, 2>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                else hipLaunchKernelGGL((gemm_ldsrow_kernel<1, false, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
             } else {
-                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<2, true>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-                else hipLaunchKernelGGL((gemm_ldsrow_kernel<2, false>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<2, true, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                else if (nt) hipLaunchKernelGGL((gemm_ldsrow_kernel<2, false, 2>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+                else hipLaunchKernelGGL((gemm_ldsrow_kernel<2, false, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
             }
             prof_end(ctx, "gemm");
-        } else if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident) {
+        } else if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident && !ctx->tune.gemm_ldsrow) {  // first generation, A/B only
             const uint64_t need_blocks = (g.level_tiles + RES_WAVES - 1) / RES_WAVES;
             const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
             const size_t smem = (size_t)(nqt <= 1 ? 1 : nqt <= 2 ? 2 : 4) * (QT_F4 * 16 + QT_ROWS * 8) + 64;

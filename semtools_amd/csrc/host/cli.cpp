@@ -23,6 +23,15 @@ static int die(const std::string &msg)
     return 1;
 }
 
+// `--max-distance NaN`: the reference keeps a row iff distance < max_distance (src/search/mod.rs:88-89), which is
+// false for every row when max_distance is NaN -- it prints nothing.  The C ABI uses NaN for "no threshold", so the
+// CLI maps a NaN argument to a threshold nothing passes (-1: cosine distances are >= 0).
+static double parse_max_distance(const char *text)
+{
+    const double v = strtod(text, nullptr);
+    return v != v ? -1.0 : v;
+}
+
 static int usage()
 {
     fprintf(stderr,
@@ -87,7 +96,7 @@ int main(int argc, char **argv)
             };
             if (a == "-n" || a == "--n-lines" || a == "--context") n_lines = strtoull(val("--n-lines"), nullptr, 10);
             else if (a == "--top-k") top_k = strtoull(val("--top-k"), nullptr, 10);
-            else if (a == "-m" || a == "--max-distance" || a == "--threshold") max_distance = strtod(val("--max-distance"), nullptr);
+            else if (a == "-m" || a == "--max-distance" || a == "--threshold") max_distance = parse_max_distance(val("--max-distance"));
             else if (a == "--batch") batch = std::max<uint64_t>(1, strtoull(val("--batch"), nullptr, 10));
             else if (a == "-i" || a == "--ignore-case") ignore_case = true;
             else if (a == "-j" || a == "--json") json = true;
@@ -152,7 +161,7 @@ int main(int argc, char **argv)
         };
         if (a == "-n" || a == "--n-lines" || a == "--context") n_lines = strtoull(val("--n-lines"), nullptr, 10);
         else if (a == "--top-k") top_k = strtoull(val("--top-k"), nullptr, 10);
-        else if (a == "-m" || a == "--max-distance" || a == "--threshold") max_distance = strtod(val("--max-distance"), nullptr);
+        else if (a == "-m" || a == "--max-distance" || a == "--threshold") max_distance = parse_max_distance(val("--max-distance"));
         else if (a == "-i" || a == "--ignore-case") ignore_case = true;
         else if (a == "-j" || a == "--json") json = true;
         else if (a == "-w" || a == "--workspace") { ws_store = val("--workspace"); workspace = ws_store.c_str(); }

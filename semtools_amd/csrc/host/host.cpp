@@ -2,18 +2,18 @@
 // top of the C ABI (see host.h).  String handling, file I/O and bookkeeping
 // only: every floating-point result comes from libsemtools_hip's kernels.
 #include "host.h"
+#include "unicode_lower.h"
 
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
-#include <clocale>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <cwctype>
+#include <exception>
 #include <fstream>
 #include <sstream>
 #include <thread>
@@ -50,28 +50,110 @@ std::vector<std::string> lines_of(const std::string &content)
 
 static size_t utf8_len(unsigned char c) { return c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1; }
 
+// ---- Unicode lower-casing with Rust's str::to_lowercase semantics (reference src/search/mod.rs:63): the full
+// lower-case mapping of every code point (incl. the one multi-code-point case, U+0130 -> "i" + U+0307) and the
+// Final_Sigma rule (U+03A3 -> U+03C2 at the end of a word, U+03C3 otherwise).  Table driven (unicode_lower.h,
+// generated from the UCD): the process locale is never touched -- a library has no business calling setlocale.
+static bool in_ranges(const unicode::CpRange *r, size_t n, uint32_t cp)
+{
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (cp > r[mid].last) lo = mid + 1;
+        else if (cp < r[mid].first) hi = mid;
+        else return true;
+    }
+    return false;
+}
+static bool is_cased(uint32_t cp)
+{
+    if (cp < 0x80) return (cp >= 'A' && cp <= 'Z') || (cp >= 'a' && cp <= 'z');
+    return in_ranges(unicode::CASED, sizeof(unicode::CASED) / sizeof(unicode::CASED[0]), cp);
+}
+static bool is_case_ignorable(uint32_t cp)
+{
+    return in_ranges(unicode::CASE_IGNORABLE, sizeof(unicode::CASE_IGNORABLE) / sizeof(unicode::CASE_IGNORABLE[0]), cp);
+}
+static uint32_t lower_simple(uint32_t cp)
+{
+    const size_t n = sizeof(unicode::LOWER_RUNS) / sizeof(unicode::LOWER_RUNS[0]);
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        const unicode::LowerRun &r = unicode::LOWER_RUNS[mid];
+        if (cp > r.last) lo = mid + 1;
+        else if (cp < r.first) hi = mid;
+        else return ((cp - r.first) % r.stride == 0) ? (uint32_t)((int64_t)cp + r.delta) : cp;
+    }
+    return cp;
+}
+static void push_utf8(std::string &out, uint32_t cp)
+{
+    if (cp < 0x80) out.push_back((char)cp);
+    else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+    else { out.push_back((char)(0xF0 | (cp >> 18))); out.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+}
+// decode the code point starting at s[i]; *len = its byte length (malformed bytes pass through one by one)
+static uint32_t decode_utf8(const std::string &s, size_t i, size_t *len)
+{
+    const unsigned char c = (unsigned char)s[i];
+    const size_t want = utf8_len(c);
+    if (c < 0x80 || want == 1 || i + want > s.size()) { *len = 1; return c < 0x80 ? c : 0xFFFFFFFFu; }
+    for (size_t k = 1; k < want; ++k)
+        if (((unsigned char)s[i + k] & 0xC0) != 0x80) { *len = 1; return 0xFFFFFFFFu; }
+    *len = want;
+    if (want == 2) return ((c & 0x1Fu) << 6) | ((unsigned char)s[i + 1] & 0x3Fu);
+    if (want == 3) return ((c & 0x0Fu) << 12) | (((unsigned char)s[i + 1] & 0x3Fu) << 6) | ((unsigned char)s[i + 2] & 0x3Fu);
+    return ((c & 0x07u) << 18) | (((unsigned char)s[i + 1] & 0x3Fu) << 12) | (((unsigned char)s[i + 2] & 0x3Fu) << 6) | ((unsigned char)s[i + 3] & 0x3Fu);
+}
+
 std::string to_lowercase(const std::string &s)
 {
-    static bool locale_set = false;
-    if (!locale_set) { setlocale(LC_CTYPE, "C.UTF-8"); locale_set = true; }
     std::string out;
     out.reserve(s.size());
     for (size_t i = 0; i < s.size();) {
         const unsigned char c = (unsigned char)s[i];
         if (c < 0x80) { out.push_back((char)((c >= 'A' && c <= 'Z') ? c + 32 : c)); ++i; continue; }
-        const size_t len = std::min(utf8_len(c), s.size() - i);
-        unsigned cp = 0;
-        if (len == 2) cp = ((c & 0x1F) << 6) | ((unsigned char)s[i + 1] & 0x3F);
-        else if (len == 3) cp = ((c & 0x0F) << 12) | (((unsigned char)s[i + 1] & 0x3F) << 6) | ((unsigned char)s[i + 2] & 0x3F);
-        else if (len == 4) cp = ((c & 0x07) << 18) | (((unsigned char)s[i + 1] & 0x3F) << 12) | (((unsigned char)s[i + 2] & 0x3F) << 6) | ((unsigned char)s[i + 3] & 0x3F);
-        else { out.push_back((char)c); ++i; continue; }
-        const unsigned lo = (unsigned)std::towlower((wint_t)cp);
-        if (lo == cp) out.append(s, i, len);
-        else {
-            if (lo < 0x80) out.push_back((char)lo);
-            else if (lo < 0x800) { out.push_back((char)(0xC0 | (lo >> 6))); out.push_back((char)(0x80 | (lo & 0x3F))); }
-            else if (lo < 0x10000) { out.push_back((char)(0xE0 | (lo >> 12))); out.push_back((char)(0x80 | ((lo >> 6) & 0x3F))); out.push_back((char)(0x80 | (lo & 0x3F))); }
-            else { out.push_back((char)(0xF0 | (lo >> 18))); out.push_back((char)(0x80 | ((lo >> 12) & 0x3F))); out.push_back((char)(0x80 | ((lo >> 6) & 0x3F))); out.push_back((char)(0x80 | (lo & 0x3F))); }
+        size_t len = 1;
+        const uint32_t cp = decode_utf8(s, i, &len);
+        if (cp == 0xFFFFFFFFu) { out.push_back((char)c); ++i; continue; }  // malformed: copied verbatim
+        if (cp == 0x03A3) {
+            // Final_Sigma: preceded by a cased letter (skipping case-ignorables) and NOT followed by one
+            bool before = false, after = false;
+            for (size_t k = i; k > 0;) {
+                size_t b = k - 1;
+                while (b > 0 && ((unsigned char)s[b] & 0xC0) == 0x80) --b;
+                size_t l2 = 1;
+                const uint32_t p = decode_utf8(s, b, &l2);
+                k = b;
+                if (p != 0xFFFFFFFFu && is_case_ignorable(p)) continue;
+                before = p != 0xFFFFFFFFu && is_cased(p);
+                break;
+            }
+            for (size_t k = i + len; k < s.size();) {
+                size_t l2 = 1;
+                const uint32_t n = decode_utf8(s, k, &l2);
+                k += l2;
+                if (n != 0xFFFFFFFFu && is_case_ignorable(n)) continue;
+                after = n != 0xFFFFFFFFu && is_cased(n);
+                break;
+            }
+            push_utf8(out, (before && !after) ? 0x03C2u : 0x03C3u);
+            i += len;
+            continue;
+        }
+        bool multi = false;
+        for (const unicode::LowerMulti &m : unicode::LOWER_MULTI)
+            if (m.cp == cp) {
+                for (uint32_t k = 0; k < m.n; ++k) push_utf8(out, m.to[k]);
+                multi = true;
+                break;
+            }
+        if (!multi) {
+            const uint32_t lo = lower_simple(cp);
+            if (lo == cp) out.append(s, i, len);
+            else push_utf8(out, lo);
         }
         i += len;
     }
@@ -140,9 +222,7 @@ public:
         while (std::getline(f, line)) {
             if (!line.empty() && line.back() == '\r') line.pop_back();
             vocab_.emplace(line, id++);
-            size_t chars = 0;
-            for (unsigned char c : line) if ((c & 0xC0) != 0x80) ++chars;
-            lens.push_back(chars);
+            lens.push_back(line.size());  // model2vec-rs takes the median of tk.len(): BYTES, not characters
         }
         size_ = id;
         if (!unk_token.empty()) {
@@ -255,7 +335,11 @@ void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size
     std::vector<std::vector<uint32_t>> part_ids(n_threads);
     std::vector<std::vector<uint64_t>> part_len(n_threads);
     const auto unk = tok_->unk_id();
+    // a throwing tokenizer (callback failure, bad_alloc) must reach the caller -- and through it the extern "C"
+    // wrappers' catch blocks -- not std::terminate the process from a worker thread
+    std::vector<std::exception_ptr> failed(n_threads);
     auto work = [&](size_t t) {
+      try {
         const size_t b = begin + n * t / n_threads, e = begin + n * (t + 1) / n_threads;
         std::vector<uint32_t> tmp;
         for (size_t i = b; i < e; ++i) {
@@ -267,6 +351,7 @@ void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size
             part_ids[t].insert(part_ids[t].end(), tmp.begin(), tmp.end());
             part_len[t].push_back(tmp.size());
         }
+      } catch (...) { failed[t] = std::current_exception(); }
     };
     if (n_threads == 1) work(0);
     else {
@@ -274,6 +359,7 @@ void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size
         for (size_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
         for (auto &x : th) x.join();
     }
+    for (auto &f : failed) if (f) std::rethrow_exception(f);
     ids.clear();
     offsets.assign(1, 0);
     for (size_t t = 0; t < n_threads; ++t) {
@@ -320,10 +406,14 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
     for (size_t b = 0; b < n; b += batch_size) {
         const size_t e = std::min(n, b + batch_size);
         std::thread next;
-        if (e < n) next = std::thread([&, e, cur]() { tokenize(e, slots[cur ^ 1]); });
+        std::exception_ptr next_failed;
+        if (e < n) next = std::thread([&, e, cur]() {
+            try { tokenize(e, slots[cur ^ 1]); } catch (...) { next_failed = std::current_exception(); }
+        });
         const int rc = smt_embed(model_, slots[cur].ids.data(), slots[cur].offsets.data(), e - b,
                                  max_length ? (uint32_t)*max_length : 0, nullptr, corpus, nullptr);
         if (next.joinable()) next.join();
+        if (next_failed) std::rethrow_exception(next_failed);
         check(rc, "encode_into");
         cur ^= 1;
     }
@@ -476,6 +566,7 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
     if (n_lines_upserted) {
         fprintf(stderr, "Updating workspace with %zu lines from new/changed docs...\n", n_lines_upserted);  // mod.rs:194-197
         for (auto &p : pending) store->upsert_document_lines(p.first, p.second, model);
+        store->compact_if_sparse();  // every re-embedded document left its old rows behind: bound the dead rows
         store->flush_line_embeddings();
     }
     if (!docs_to_upsert.empty()) {
@@ -570,14 +661,23 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
             s->docs_[m.path] = m;
         }
     }
+    bool corpus_ok = false;
     if (path_exists(emb)) {
-        check(smt_corpus_load(ctx, emb.c_str(), &s->corpus_), "Store::open");
-        s->rows_on_disk_ = smt_corpus_rows(s->corpus_);
-        s->rows_on_disk_valid_ = true;
-    } else {
-        check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
+        // A truncated / foreign file must not brick the workspace: start from an empty store, every document then
+        // counts as Changed (no extent, see analyze_document_states) and is re-embedded by the next search.
+        const int rc = smt_corpus_load(ctx, emb.c_str(), &s->corpus_);
+        if (rc == SMT_OK) {
+            s->rows_on_disk_ = smt_corpus_rows(s->corpus_);
+            s->rows_on_disk_valid_ = true;
+            corpus_ok = true;
+        } else if (rc != SMT_E_IO) {
+            check(rc, "Store::open");
+        } else {
+            fprintf(stderr, "warning: %s is unreadable (%s); the workspace will be re-embedded\n", emb.c_str(), smt_last_error());
+        }
     }
-    if (path_exists(rows)) {
+    if (!corpus_ok) check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
+    if (corpus_ok && path_exists(rows)) {
         const json::Value v = json::parse(read_to_string(rows));
         uint64_t live = 0;
         if (auto *arr = v.get("extents"))
@@ -585,7 +685,8 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
                 Extent x;
                 x.first_row = e.get("first_row")->as_u64();
                 x.n_rows = e.get("n_rows")->as_u64();
-                if (x.first_row + x.n_rows > smt_corpus_rows(s->corpus_)) continue;  // torn write: drop, doc gets re-embedded
+                // torn write: drop the extent; analyze_document_states reports a document without one as Changed
+                if (x.first_row + x.n_rows > smt_corpus_rows(s->corpus_)) continue;
                 s->extents_[e.get("path")->s] = x;
                 live += x.n_rows;
             }
@@ -784,7 +885,10 @@ std::vector<DocumentState> Store::analyze_document_states(const std::vector<std:
         DocumentState ds;
         if (it != existing.end()) {
             const DocMeta &ex = it->second;
-            if (ex.size_bytes != cur.size_bytes || ex.mtime != cur.mtime || ex._version != CURRENT_EMBEDDING_VERSION) {
+            // (a document whose line rows are gone -- torn write, unreadable corpus file -- must be re-embedded even
+            // though its metadata says "unchanged": it would otherwise silently drop out of every search)
+            const bool rows_missing = extents_.find(fp) == extents_.end();
+            if (rows_missing || ex.size_bytes != cur.size_bytes || ex.mtime != cur.mtime || ex._version != CURRENT_EMBEDDING_VERSION) {
                 ds.kind = DocumentState::Changed;
                 ds.info = DocumentInfo{fp, read_to_string(fp), cur};
             } else {

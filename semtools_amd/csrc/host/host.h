@@ -232,11 +232,13 @@ public:
     size_t count_line_embeddings() const;
     void flush_documents() const;
     void flush_line_embeddings() const;
+    // Rows of replaced / deleted documents stay behind until they exceed half the matrix; then live extents are
+    // rewritten back to back (row order preserved).  Called after every batch of upserts and deletes.
+    void compact_if_sparse();
 
 private:
     Store() = default;
     struct Extent { uint64_t first_row = 0; uint64_t n_rows = 0; };
-    void compact_if_sparse();
     std::string dir_;
     smt_ctx *ctx_ = nullptr;
     smt_corpus *corpus_ = nullptr;

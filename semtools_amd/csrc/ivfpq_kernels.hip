@@ -1126,6 +1126,16 @@ bool read_dev(FILE *f, void *d, size_t bytes, hipStream_t st, std::vector<char> 
 }
 }  // namespace
 
+namespace smt {
+__global__ void count_ids_out_of_range_kernel(const uint32_t *ids, uint64_t n, uint32_t n_rows, unsigned int *bad)
+{
+    unsigned int mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        mine += ids[i] >= n_rows ? 1u : 0u;
+    if (mine) atomicAdd(bad, mine);
+}
+}  // namespace smt
+
 extern "C" {
 
 int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
@@ -1210,6 +1220,20 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     bool sane = offs[0] == 0 && offs[h.nlist] == h.n_rows;
     for (uint32_t l = 0; sane && l < h.nlist; ++l) sane = offs[l] <= offs[l + 1];
     if (!sane) { smt::set_error("'%s': corrupt list offsets", path); return SMT_E_IO; }
+    // ... and every stored row id must name a row of THIS corpus: the re-score and the int8 refinement gather
+    // corpus rows by id (a stale or corrupt file would otherwise read out of bounds)
+    if (N > 0) {
+        int rc_s = smt::ensure_scratch(ctx, 64);
+        if (rc_s) return rc_s;
+        unsigned int *d_bad = reinterpret_cast<unsigned int *>(ctx->d_scratch);
+        IVF_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(count_ids_out_of_range_kernel, dim3((unsigned)std::min<uint64_t>((N + 255) / 256, 65535)), dim3(256), 0,
+                           ctx->stream, ix->d_ids, N, (uint32_t)std::min<uint64_t>(h.n_rows, 0xFFFFFFFFull), d_bad);
+        unsigned int bad = 0;
+        IVF_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        IVF_HIP(hipStreamSynchronize(ctx->stream));
+        if (bad) { smt::set_error("'%s': %u row ids outside the corpus (stale or corrupt index file)", path, bad); return SMT_E_IO; }
+    }
     ix->max_list = 0;
     for (uint32_t l = 0; l < h.nlist; ++l) ix->max_list = std::max<uint64_t>(ix->max_list, offs[l + 1] - offs[l]);
     if (h.pad[0] == 1 && N > 0) {  // the int8 refinement copy is a function of (corpus, ids): re-derive it

@@ -250,6 +250,49 @@ def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, ca
     assert all(h[0] == str(b) for h in parse(out5)) and len(parse(out5)) == 5
 
 
+def test_workspace_survives_a_damaged_store(model, model_dir, prose_files, tmp_path, monkeypatch, capfd):
+    """Crash consistency: a truncated line_embeddings.f32, or metadata whose line rows are gone, must
+    lead to a re-embed -- not to a dead workspace, and not to documents that silently drop out of the search."""
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    la, lb = prose_files[1][1][:12], prose_files[1][1][12:30]
+    a.write_text("\n".join(la) + "\n")
+    b.write_text("\n".join(lb) + "\n")
+    files = [str(a), str(b)]
+    host.workspace_use(None, "dmg")
+    good = host.search_with_workspace(model, lb[4], files, workspace_name="dmg", n_lines=0, top_k=5)
+    capfd.readouterr()
+    root = tmp_path / ".semtools" / "workspaces" / "dmg"
+    emb = root / "line_embeddings.f32"
+    assert emb.exists() and not (root / "line_embeddings.f32.tmp").exists()
+    # (1) the vectors file loses its tail (crash / ENOSPC during a rewrite)
+    data = emb.read_bytes()
+    emb.write_bytes(data[: len(data) // 2])
+    again = host.search_with_workspace(model, lb[4], files, workspace_name="dmg", n_lines=0, top_k=5)
+    err = capfd.readouterr().err
+    assert "is unreadable" in err and "Updating workspace with 30 lines from new/changed docs..." in err
+    assert again == good
+    # (2) the extent table forgets one document while its metadata still says "unchanged"
+    rows = json.loads((root / "line_rows.json").read_text())
+    rows["extents"] = [e for e in rows["extents"] if e["path"] != str(b)]
+    (root / "line_rows.json").write_text(json.dumps(rows))
+    third = host.search_with_workspace(model, lb[4], files, workspace_name="dmg", n_lines=0, top_k=5)
+    assert "Updating workspace with 18 lines from new/changed docs..." in capfd.readouterr().err
+    assert third == good
+    # (3) repeated edits do not grow the matrix without bound: dead rows are compacted before the flush
+    for i in range(6):
+        b.write_text("\n".join(lb) + f"\nedit {i}\n")
+        os.utime(b, (1_800_000_000 + i, 1_800_000_000 + i))
+        host.search_with_workspace(model, lb[4], files, workspace_name="dmg", n_lines=0, top_k=5)
+    capfd.readouterr()
+    assert json.loads(host.workspace_status(model.ctx, "dmg", json=True))["total_documents"] == 2
+    live = len(la) + len(lb) + 1
+    assert (emb.stat().st_size - 32) // 1024 <= 4096 + 2 * live   # bounded (compaction threshold: 4096 dead rows or half)
+
+
 def test_resident_session_and_serve_mode(model, model_dir, prose_files):
     """Batched-query surface: one embedding pass, many queries; every answer equals what a
     one-shot `semtools search` prints -- for small batches (K2) and batches >= 8 queries (K3 MFMA path)."""

@@ -68,6 +68,22 @@ def test_to_lowercase():
     assert host.to_lowercase("GOODBYE wOrLd 123 ÄÖÜ Ж") == "goodbye world 123 äöü ж"
 
 
+def test_to_lowercase_is_rusts_not_the_locales():
+    """Rust's str::to_lowercase (src/search/mod.rs:63) = the Unicode lower-case mapping incl. the multi-code-point
+    case (U+0130) and Final_Sigma -- which is what Python's str.lower() implements too.  No locale involved."""
+    import random
+
+    cases = ["İstanbul", "ΟΔΥΣΣΕΥΣ", "ΣΑΣ ΣΟΦΟΣ.", "ΑΣ", "Σ", "aΣ", "AΣ'", "Σa", "ΧΑΟΣ-ΧΑΟΣ ΧΑΟΣ", "ǅ ǈ ǋ ǲ", "ẞ STRASSE",
+             "ԱԲԳ ႠႡႢ ᲐᲑᲒ", "ＦＵＬＬ Ｗｉｄｔｈ", "Ⅻ Ⓐ Ꙁ Ⰰ", "𐐀𐐁 𞤀𞤁", "ÀÉÎÕÜ ĀĂĄ ŁŃŚ ƁƂƄ ǍǏ", "ΆΈΉΊΌΎΏ ΪΫ ϏϘϚ", "ЀЁЂ АБВ ЯѠ ҐҒ ӁӃ ԀԂ",
+             "mixed ASCII and ÜNÏCÖDÉ 123 !?", "\udcff".encode("utf-8", "surrogatepass").decode("utf-8", "replace")]
+    rng = random.Random(7)
+    pool = [c for c in (chr(cp) for cp in list(range(0x20, 0x250)) + list(range(0x370, 0x530)) + list(range(0x1E00, 0x2000))
+                        + [0x3A3, 0x3A3, 0x27, 0x2E, 0x300, 0x301, 0xAD]) if c.isprintable() or c in "\u0300\u0301\u00ad"]
+    cases += ["".join(rng.choice(pool) for _ in range(rng.randint(1, 40))) for _ in range(400)]
+    for s in cases:
+        assert host.to_lowercase(s) == s.lower(), repr(s)
+
+
 def test_workspace_use_writes_config_and_prints_reference_text(tmp_path, monkeypatch):
     monkeypatch.setenv("HOME", str(tmp_path))
     text = host.workspace_use(None, "proj")

@@ -20,9 +20,11 @@ def main():
     ap.add_argument("--nq", type=int, nargs="+", default=[8, 16, 32, 64, 128])
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--variants", type=int, nargs="+", default=[1, 0], help="values of the gemm_ldsrow tuning key")
+    ap.add_argument("--variants", type=int, nargs="+", default=[1, 0, 2],
+                    help="1 = LDS-row kernel, 0 = first-generation resident-query kernel, 2 = gemm_level_kernel")
     ap.add_argument("--ranges", action="store_true", help="also time a range-filtered batch (two ranges, 90 %% of the rows)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--tune", action="append", default=[], help="key=value for smt_set_tuning (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
@@ -37,6 +39,9 @@ def main():
     torch.cuda.synchronize()
     ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=args.rows)
+    for kv in args.tune:
+        key, val = kv.split("=")
+        ctx.set_tuning(key, int(val))
     results = []
     for nq in args.nq:
         q = qall[:nq].contiguous()
@@ -48,7 +53,9 @@ def main():
             corpus.search_topk_device(q[i:i + n].data_ptr(), n, args.k, 0, k2_rows[i:i + n].data_ptr(), k2_dist[i:i + n].data_ptr())
         ctx.synchronize()
         for variant in args.variants:
-            ctx.set_tuning("gemm_ldsrow", variant)
+            ctx.set_tuning("gemm_ldsrow", 1 if variant in (1, 3) else 0)  # 1 = default routing (LDS-row kernel up to 64 queries,
+            ctx.set_tuning("gemm_resident", 0 if variant == 2 else 1)     # level kernel above), 0 = first-generation resident-query
+                                                                          # kernel, 2 = gemm_level_kernel for every size
             out_rows = torch.empty(nq, args.k, dtype=torch.int64, device=dev)
             out_dist = torch.empty(nq, args.k, dtype=torch.float64, device=dev)
             ctx.prof_enable(True)
@@ -75,6 +82,7 @@ def main():
             print(json.dumps(r), flush=True)
         if args.ranges:
             ctx.set_tuning("gemm_ldsrow", 1)
+            ctx.set_tuning("gemm_resident", 1)
             cut = args.rows // 20
             rng = [(cut, args.rows // 2), (args.rows // 2 + cut, args.rows)]
             qh = q.cpu().numpy()
