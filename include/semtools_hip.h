@@ -210,7 +210,11 @@ typedef struct smt_ivfpq_params {
                            /* 1 = keep an int8 copy of the rows (+260 B/row) and prune the    */
                            /* ADC shortlist with it before the full-precision re-score        */
                            /* (same recall, ~6 % faster queries: measured, rarely worth it)   */
-    uint32_t reserved;     /* 0                                                           */
+    uint32_t local_pca;    /* 0 = one global residual codebook set (8 dims x 256 codes per sub-quantiser);    */
+                           /* 1 = per-list PCA: every list gets its own orthonormal basis of its 32 principal */
+                           /* residual directions and one 8-bit scalar quantiser per direction (still 32 B    */
+                           /* per row; + 32 KiB per list).  Ranks the rows inside a list far better on        */
+                           /* clustered data -- the workspace store builds its index this way                 */
 } smt_ivfpq_params;
 int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *params, smt_ivfpq **out);
 void smt_ivfpq_destroy(smt_ivfpq *index);
@@ -230,11 +234,16 @@ int smt_ivfpq_search_device(smt_ivfpq *index, const float *queries_dev, uint32_t
 int smt_ivfpq_info(const smt_ivfpq *index, uint64_t *n_rows, uint32_t *nlist, uint64_t *index_bytes,
                    double *build_ms4);
 int smt_ivfpq_list_sizes(const smt_ivfpq *index, uint64_t *sizes_host /* [nlist] */);
-/* Persist / restore the index (centroids, codebooks, list table, ids, codes: ~36 B per row).  The file
- * refers to corpus rows by position: load fails with SMT_E_INVALID unless `corpus` holds exactly the
- * row count the index was built on (then rebuild -- 0.34 s per 10 M rows). */
+/* Persist / restore the index (centroids, quantisers, list table, ids, codes: ~36 B per row).  The file
+ * refers to corpus rows by position: load fails with SMT_E_INVALID unless `corpus` holds AT LEAST the
+ * row count the index covers (then smt_ivfpq_append if the corpus only grew, else rebuild -- 0.5 s per 10 M rows). */
 int smt_ivfpq_save(smt_ivfpq *index, const char *path);
 int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out);
+/* Incremental insert: rows appended to the corpus since the index was built (or last extended) are assigned to
+ * their nearest list and encoded with that list's EXISTING quantiser (no retraining), then merged into the
+ * inverted lists -- O(new rows) arithmetic plus one 36 B/row re-layout.  *n_added = rows taken in (may be NULL).
+ * The quantisers drift away from the data as it grows: rebuild when the corpus has roughly doubled. */
+int smt_ivfpq_append(smt_ivfpq *index, uint64_t *n_added);
 
 /* ------------------------------------------------------- groups of GPUs (RCCL)
  * The reference runs the whole search synchronously from ONE task of ONE process (src/bin/semtools.rs:134-135,

@@ -27,7 +27,7 @@ pub struct SmtIvfpqParams {
     pub train_iters: u32,
     pub train_sample: u64,
     pub refine: u32,
-    pub reserved: u32,
+    pub local_pca: u32,
 }
 
 pub const SMT_OK: c_int = 0;
@@ -202,6 +202,7 @@ extern "C" {
     pub fn smt_ivfpq_list_sizes(index: *const SmtIvfpq, sizes_host: *mut u64) -> c_int;
     pub fn smt_ivfpq_save(index: *mut SmtIvfpq, path: *const c_char) -> c_int;
     pub fn smt_ivfpq_load(corpus: *mut SmtCorpus, path: *const c_char, out: *mut *mut SmtIvfpq) -> c_int;
+    pub fn smt_ivfpq_append(index: *mut SmtIvfpq, n_added: *mut u64) -> c_int;
     pub fn smt_init(devices: *const c_int, n_dev: c_int) -> c_int;
     pub fn smt_shutdown() -> c_int;
     pub fn smt_default_group() -> *mut SmtGroup;

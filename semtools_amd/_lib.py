@@ -24,7 +24,7 @@ EXPORTS = [
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
     "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
     "smt_corpus_save", "smt_corpus_load", "smt_corpus_append_to_file", "smt_search", "smt_search_topk_device", "smt_merge_topk",
-    "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_search_device", "smt_ivfpq_info", "smt_ivfpq_list_sizes", "smt_ivfpq_save", "smt_ivfpq_load",
+    "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_search_device", "smt_ivfpq_info", "smt_ivfpq_list_sizes", "smt_ivfpq_save", "smt_ivfpq_load", "smt_ivfpq_append",
     "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
     "smt_ctx_uncertain_count",
     "smt_init", "smt_shutdown", "smt_default_group", "smt_group_create", "smt_group_create_logical", "smt_group_unique_id", "smt_group_create_rank",
@@ -51,7 +51,7 @@ class SmtRange(C.Structure):
 
 class SmtIvfPqParams(C.Structure):
     _fields_ = [("nlist", C.c_uint32), ("m", C.c_uint32), ("nbits", C.c_uint32), ("train_iters", C.c_uint32),
-                ("train_sample", C.c_uint64), ("refine", C.c_uint32), ("reserved", C.c_uint32)]
+                ("train_sample", C.c_uint64), ("refine", C.c_uint32), ("local_pca", C.c_uint32)]
 
 
 class SmtError(RuntimeError):
@@ -138,6 +138,7 @@ def lib():
     L.smt_ivfpq_search_device.argtypes = [vp, vp, u32, u32, u32, u32, u64, vp, vp]
     L.smt_ivfpq_info.argtypes = [vp, P(u64), P(u32), P(u64), P(f64)]
     L.smt_ivfpq_list_sizes.argtypes = [vp, vp]
+    L.smt_ivfpq_append.argtypes = [vp, P(u64)]
     L.smt_ivfpq_save.argtypes = [vp, C.c_char_p]
     L.smt_ivfpq_load.argtypes = [vp, C.c_char_p, P(vp)]
     L.smt_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]

@@ -36,7 +36,7 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // bits of smt_ctx::attr_done
-enum : uint32_t { ATTR_SELECT = 1u, ATTR_GEMM = 2u, ATTR_IVF_ASSIGN = 4u, ATTR_IVF_SCORE = 8u, ATTR_GEMM_LDS = 16u };
+enum : uint32_t { ATTR_SELECT = 1u, ATTR_GEMM = 2u, ATTR_IVF_ASSIGN = 4u, ATTR_IVF_SCORE = 8u, ATTR_GEMM_LDS = 16u, ATTR_IVF_LPCA = 32u };
 
 // One candidate on the device: key = (f32 distance bits << 32) | local row.
 // Distances are clipped to >= 0, so the IEEE bit pattern is order-preserving

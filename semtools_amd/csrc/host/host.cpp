@@ -546,6 +546,11 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
     const std::vector<float> query_embedding = model.encode_single(query);
     Workspace ws = Workspace::open(workspace_name);
     auto store = Store::open(ws.config.root_dir, model.ctx());
+    {
+        const char *min_rows = getenv("SEMTOOLS_INDEX_MIN_ROWS"), *nprobe = getenv("SEMTOOLS_INDEX_NPROBE");
+        store->set_index_policy(ws.config.oversample_factor, min_rows ? strtoull(min_rows, nullptr, 10) : 2'000'000ull,
+                                nprobe ? (uint32_t)strtoul(nprobe, nullptr, 10) : 16u);
+    }
 
     // Step 1: changed / new / unchanged (mod.rs:158)
     const std::vector<DocumentState> doc_states = store->analyze_document_states(files);
@@ -677,6 +682,7 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
         }
     }
     if (!corpus_ok) check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
+    s->index_on_disk_ = corpus_ok && path_exists(workspace_dir + "/line_index.ivf");
     if (corpus_ok && path_exists(rows)) {
         const json::Value v = json::parse(read_to_string(rows));
         uint64_t live = 0;
@@ -695,7 +701,66 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
     return s;
 }
 
-Store::~Store() { smt_corpus_destroy(corpus_); }
+Store::~Store()
+{
+    if (index_) smt_ivfpq_destroy(index_);  // (before the corpus it points into)
+    smt_corpus_destroy(corpus_);
+}
+
+void Store::set_index_policy(size_t oversample_factor, uint64_t min_rows, uint32_t nprobe)
+{
+    oversample_factor_ = std::max<size_t>(1, oversample_factor);
+    index_min_rows_ = min_rows;
+    index_nprobe_ = std::max<uint32_t>(1, nprobe);
+}
+
+// Bring the approximate index in line with the corpus: load it from disk, extend it by the rows appended since, or
+// (re)build it.  Returns false when no usable index exists (then the caller scans exactly).
+bool Store::ensure_index() const
+{
+    const uint64_t rows = smt_corpus_rows(corpus_);
+    const std::string file = dir_ + "/line_index.ivf";
+    bool changed = false;
+    if (!index_ && index_on_disk_) {
+        if (smt_ivfpq_load(corpus_, file.c_str(), &index_) != SMT_OK) index_ = nullptr;  // stale / corrupt: rebuild below
+        if (index_) { uint64_t n = 0; smt_ivfpq_info(index_, &n, nullptr, nullptr, nullptr); index_built_rows_ = n; }
+    }
+    if (index_) {
+        uint64_t covered = 0;
+        smt_ivfpq_info(index_, &covered, nullptr, nullptr, nullptr);
+        if (covered < rows) {
+            // the corpus only grew: incremental insert with the existing quantisers -- until it has doubled
+            uint64_t added = 0;
+            if (rows > 2 * std::max<uint64_t>(index_built_rows_, 1) || smt_ivfpq_append(index_, &added) != SMT_OK) {
+                smt_ivfpq_destroy(index_);
+                index_ = nullptr;
+            } else {
+                changed = true;
+            }
+        }
+    }
+    if (!index_) {
+        smt_ivfpq_params prm;
+        memset(&prm, 0, sizeof(prm));
+        // ~ sqrt(N) lists (a multiple of 32 in [32, 4096]): 10 M rows -> 4096 lists of ~2.4 k rows
+        uint64_t nlist = (uint64_t)std::sqrt((double)rows) * 4 / 3;
+        nlist = std::min<uint64_t>(4096, std::max<uint64_t>(32, nlist / 32 * 32));
+        prm.nlist = (uint32_t)nlist;
+        prm.m = 32;
+        prm.nbits = 8;
+        prm.train_iters = 10;
+        prm.local_pca = 1;
+        if (rows < nlist || smt_ivfpq_build(corpus_, &prm, &index_) != SMT_OK) { index_ = nullptr; return false; }
+        index_built_rows_ = rows;
+        changed = true;
+    }
+    if (changed) {  // persist beside the vectors: write a sibling, then rename
+        const std::string tmp = file + ".tmp";
+        if (smt_ivfpq_save(index_, tmp.c_str()) == SMT_OK && rename(tmp.c_str(), file.c_str()) == 0) index_on_disk_ = true;
+        else (void)remove(tmp.c_str());
+    }
+    return true;
+}
 
 std::unordered_map<std::string, DocMeta> Store::get_existing_docs(const std::vector<std::string> &paths) const
 {
@@ -811,14 +876,18 @@ void Store::compact_if_sparse()
     corpus_ = fresh;
     dead_rows_ = 0;
     rows_on_disk_valid_ = false;  // rows moved: the file must be rewritten
+    if (index_) { smt_ivfpq_destroy(index_); index_ = nullptr; }  // ... and the index names rows by position
+    if (index_on_disk_) { (void)remove((dir_ + "/line_index.ivf").c_str()); index_on_disk_ = false; }
 }
 
 WorkspaceStats Store::get_stats() const
 {
     WorkspaceStats st;
     st.total_documents = count_documents();
-    st.has_index = true;
-    st.index_type = "HNSW";  // the reference's hard-coded label (store.rs:443); the scan here is exact, as is the reference's
+    // The reference prints a hard-coded "HNSW" (store.rs:437-445) although its store scans exactly; here the line
+    // says what is there: the IVF index once a workspace is large enough to have one, "No" for the exact scan.
+    st.has_index = has_index();
+    if (st.has_index) st.index_type = "IVF_PQ";
     return st;
 }
 
@@ -854,9 +923,37 @@ std::vector<RankedLine> Store::search_line_embeddings(const std::vector<float> &
     std::vector<uint64_t> rows(top_k);
     std::vector<double> dist(top_k);
     uint64_t n = 0;
-    check(smt_search(corpus_, query_vec.data(), 1, k, max_distance ? (double)*max_distance : NAN, SMT_MODE_WORKSPACE,
-                     ranges.data(), (uint32_t)ranges.size(), 0, rows.data(), dist.data(), &n, top_k),
-          "search_line_embeddings");
+    bool answered = false;
+    // ---- approximate path: whole-workspace search over a large store (see set_index_policy)
+    uint64_t ranged = 0;
+    for (auto &r : ranges) ranged += r.end - r.begin;
+    if (smt_corpus_rows(corpus_) >= index_min_rows_ && top_k <= 24 && ranged == count_line_embeddings() && ensure_index()) {
+        const uint32_t fetch = (uint32_t)std::min<size_t>(56, 2 * top_k + 8);  // head-room for dead rows and the threshold
+        const uint32_t rerank = (uint32_t)std::min<size_t>(512, std::max<size_t>(64, 2 * top_k * oversample_factor_));
+        std::vector<uint64_t> c_rows(fetch);
+        std::vector<double> c_dist(fetch);
+        uint64_t c_n = 0;
+        uint32_t n_lists = 0;
+        check(smt_ivfpq_info(index_, nullptr, &n_lists, nullptr, nullptr), "search_line_embeddings (index)");
+        check(smt_ivfpq_search(index_, query_vec.data(), 1, fetch, std::min<uint32_t>(std::min<uint32_t>(index_nprobe_, n_lists), 512),
+                               rerank, 0, c_rows.data(), c_dist.data(), &c_n, fetch), "search_line_embeddings (index)");
+        const float thr_score = max_distance ? 1.0f - *max_distance : 0.0f;
+        for (uint64_t i = 0; i < c_n && n < top_k; ++i) {
+            auto it = std::upper_bound(segs.begin(), segs.end(), c_rows[i], [](uint64_t r, const Seg &s) { return r < s.first; });
+            if (it == segs.begin() || c_rows[i] >= (it - 1)->first + (it - 1)->n) continue;       // a dead row (replaced document)
+            if (max_distance && !((1.0 - c_dist[i]) > (double)thr_score)) continue;               // store.rs:502-503
+            rows[n] = c_rows[i];
+            dist[n] = c_dist[i];
+            ++n;
+        }
+        // fewer than top_k survivors although the index returned a full list: dead rows crowded it -> scan exactly
+        answered = n == top_k || c_n < fetch;
+        if (!answered) n = 0;
+    }
+    if (!answered)
+        check(smt_search(corpus_, query_vec.data(), 1, k, max_distance ? (double)*max_distance : NAN, SMT_MODE_WORKSPACE,
+                         ranges.data(), (uint32_t)ranges.size(), 0, rows.data(), dist.data(), &n, top_k),
+              "search_line_embeddings");
     for (uint64_t i = 0; i < n; ++i) {
         auto it = std::upper_bound(segs.begin(), segs.end(), rows[i], [](uint64_t r, const Seg &s) { return r < s.first; });
         const Seg &s = *(it - 1);

@@ -235,6 +235,16 @@ public:
     // Rows of replaced / deleted documents stay behind until they exceed half the matrix; then live extents are
     // rewritten back to back (row order preserved).  Called after every batch of upserts and deletes.
     void compact_if_sparse();
+    // Approximate index policy.  Whole-workspace searches (the path subset covers every stored document) over at
+    // least `min_rows` rows go through an IVF index with per-list PCA codes (smt_ivfpq_*, local_pca = 1) that lives
+    // beside the vectors (`line_index.ivf`), is extended incrementally when rows are appended and rebuilt when rows
+    // move (compaction) or the corpus has doubled.  oversample_factor (WorkspaceConfig, src/workspace/mod.rs:13,22 --
+    // vestigial in the reference, whose store scans exactly) sets the re-score depth: 2 * top_k * oversample_factor
+    // ADC candidates per probed list (at least 64) are re-scored against the full-precision rows.  Every returned
+    // distance is exact; only membership is approximate.  Searches over a path subset, top_k > 24, or smaller
+    // stores use the exact scan.
+    void set_index_policy(size_t oversample_factor, uint64_t min_rows, uint32_t nprobe);
+    bool has_index() const { return index_ != nullptr || index_on_disk_; }
 
 private:
     Store() = default;
@@ -247,6 +257,14 @@ private:
     uint64_t dead_rows_ = 0;                     // rows of deleted/replaced documents awaiting compaction
     mutable uint64_t rows_on_disk_ = 0;          // prefix of the corpus already in line_embeddings.f32
     mutable bool rows_on_disk_valid_ = false;
+    // approximate index (built / extended lazily by the first search that qualifies)
+    bool ensure_index() const;
+    mutable smt_ivfpq *index_ = nullptr;
+    mutable bool index_on_disk_ = false;
+    mutable uint64_t index_built_rows_ = 0;      // corpus rows when the quantisers were trained
+    size_t oversample_factor_ = 3;
+    uint64_t index_min_rows_ = 2'000'000;
+    uint32_t index_nprobe_ = 16;
 };
 
 }  // namespace workspace

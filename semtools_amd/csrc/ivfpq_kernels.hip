@@ -428,10 +428,200 @@ __global__ void quantize_rows_kernel(const float *rows, const uint32_t *ids, uin
     if (lane == 0) scale[pos] = sc;
 }
 
+// ------------------------------------------------------------------ per-list PCA codes (index kind 1)
+// A global residual codebook (8 dims x 256 codes per sub-quantiser, above) spends its bits on all 256 coordinates
+// of a residual alike: 25 % relative distortion per sub-vector, which on clustered data ranks the rows INSIDE a
+// list poorly (10 M rows: recall@10 0.69 with 64 re-scored rows per list; 512 were needed for 0.98).  But the rows
+// of one list differ from their centroid mostly inside a low-dimensional subspace that is the LIST's own.  Kind 1
+// therefore gives every list its own orthonormal basis Q_l (the top 32 principal directions of its residuals:
+// "locally optimised" product quantisation, Kalantidis & Avrithis 2014) and stores y = Q_l^T (x - c_l) with one
+// 8-bit scalar quantiser per direction -- still m = 32 codes of 8 bits, 32 B per row, with dsub = 1 in the rotated
+// space.  For unit rows  q.x = q.c_l + (Q_l^T q).y + (the part of q outside the subspace).(the part of x outside),
+// so the ADC score is  base + sum_d w_d * code_d  with w = scale_l * Q_l^T q: 32 multiply-adds on the code bytes,
+// no 32 KiB look-up table per query, no LDS gathers.
+//
+// lpca_train_kernel: one block per list, subspace (block power) iteration on the scatter matrix S = sum r r^T
+// without ever forming it: Q <- orth(S Q) with S Q = sum over 32-row tiles of R^T (R Q^T)^T.  Deterministic: fixed
+// tile order, fixed reduction trees, hash-seeded start vectors.
+constexpr int LP_DIMS = 32;            // directions kept per list == code bytes per row
+constexpr int LP_TILE = 32;            // residual rows per tile
+constexpr int LP_RSTRIDE = 257;        // LDS row stride of the residual tile (conflict-free column walks)
+
+__device__ __forceinline__ float lp_hash_unit(uint32_t k, uint32_t d)
+{
+    uint32_t x = k * 0x9E3779B9u + d * 0x85EBCA6Bu + 0x165667B1u;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return (float)(int32_t)x * (1.0f / 2147483648.0f);
+}
+
+// sum over the block's 256 threads (4 waves), result in every thread; `red` = 4 floats of LDS
+__device__ __forceinline__ float lp_block_sum(float v, float *red)
+{
+    const float w = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) lpca_train_kernel(const float *corpus, const uint32_t *ids, const uint64_t *offsets,
+                                                          const float *centroids, uint32_t iters, float *basis, float *lscale)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sQ = reinterpret_cast<float *>(smem_raw);            // [32][256]
+    float *sR = sQ + LP_DIMS * 256;                             // [32][257]
+    float *sZ = sR + LP_TILE * LP_RSTRIDE;                      // [32][33]
+    float *sP = sZ + LP_TILE * 33;                              // [32] projections
+    float *red = sP + LP_DIMS;                                  // [4]
+    float *sLam = red + 4;                                      // [32] |S q_k| of the last iteration
+    const uint32_t l = blockIdx.x;
+    const int d = threadIdx.x;                                  // this thread's coordinate
+    const uint64_t begin = offsets[l], n = offsets[l + 1] - begin;
+    const float cd = centroids[(size_t)l * 256 + d];
+#pragma unroll
+    for (int k = 0; k < LP_DIMS; ++k) sQ[k * 256 + d] = lp_hash_unit(k + 131u * l, d);
+    if (d < LP_DIMS) sLam[d] = 0.0f;
+    __syncthreads();
+
+    // orthonormalise the 32 vectors held in sQ (thread d owns coordinate d of each): classical Gram-Schmidt with
+    // re-orthogonalisation; a vector that vanishes (rank-deficient list) is replaced by a hash vector
+    auto orthonormalise = [&](bool keep_norms) {
+        for (int k = 0; k < LP_DIMS; ++k) {
+            float v = sQ[k * 256 + d];
+            float norm2_before = lp_block_sum(v * v, red);
+            for (int pass = 0; pass < 3; ++pass) {
+                for (int jj = 0; jj < k; ++jj) {
+                    const float part = wave_sum(v * sQ[jj * 256 + d]);
+                    if ((threadIdx.x & 63) == 0) sZ[jj * 4 + (threadIdx.x >> 6)] = part;   // sZ doubles as reduction scratch here
+                }
+                __syncthreads();
+                float corr = 0.0f;
+                for (int jj = 0; jj < k; ++jj) {
+                    const float pj = (sZ[jj * 4] + sZ[jj * 4 + 1]) + (sZ[jj * 4 + 2] + sZ[jj * 4 + 3]);
+                    corr += pj * sQ[jj * 256 + d];
+                }
+                __syncthreads();
+                v -= corr;
+                if (pass == 1) {
+                    const float n2 = lp_block_sum(v * v, red);
+                    if (n2 > 1e-30f && n2 > 1e-12f * norm2_before) break;   // a healthy direction: done after two passes
+                    v = lp_hash_unit(977u + k + 131u * l, d);               // degenerate: restart from a hash vector (third pass cleans it)
+                    norm2_before = 0.0f;
+                }
+            }
+            const float n2 = lp_block_sum(v * v, red);
+            if (keep_norms && d == 0) sLam[k] = norm2_before > 0.0f ? sqrtf(norm2_before) : 0.0f;  // |S q_k| ~ eigenvalue of the scatter matrix
+            sQ[k * 256 + d] = n2 > 0.0f ? v * __frsqrt_rn(n2) : (d == k ? 1.0f : 0.0f);
+            __syncthreads();
+        }
+    };
+    orthonormalise(false);
+
+    for (uint32_t it = 0; it < iters; ++it) {
+        float acc[LP_DIMS];
+#pragma unroll
+        for (int k = 0; k < LP_DIMS; ++k) acc[k] = 0.0f;
+        for (uint64_t t0 = 0; t0 < n; t0 += LP_TILE) {
+            // residual tile: 32 rows x 256 dims (rows beyond the list are zero)
+            for (int e = threadIdx.x; e < LP_TILE * 64; e += 256) {
+                const int row = e >> 6, c4 = e & 63;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (t0 + row < n) {
+                    v = reinterpret_cast<const f32x4 *>(corpus + (uint64_t)ids[begin + t0 + row] * 256)[c4];
+                    const f32x4 c = reinterpret_cast<const f32x4 *>(centroids + (size_t)l * 256)[c4];
+                    v -= c;
+                }
+                float *dst = sR + row * LP_RSTRIDE + 4 * c4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+            __syncthreads();
+            {   // Z = R Q^T: thread -> (row, 4 directions)
+                const int row = threadIdx.x >> 3, cg = threadIdx.x & 7;
+                float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+                const float *r = sR + row * LP_RSTRIDE;
+                const float *q0 = sQ + (4 * cg) * 256;
+#pragma unroll 8
+                for (int i = 0; i < 256; ++i) {
+                    const float ri = r[i];
+                    z0 += ri * q0[i]; z1 += ri * q0[256 + i]; z2 += ri * q0[512 + i]; z3 += ri * q0[768 + i];
+                }
+                float *z = sZ + row * 33 + 4 * cg;
+                z[0] = z0; z[1] = z1; z[2] = z2; z[3] = z3;
+            }
+            __syncthreads();
+            // (S Q)[k][d] += sum_row R[row][d] Z[row][k]
+#pragma unroll 4
+            for (int row = 0; row < LP_TILE; ++row) {
+                const float r = sR[row * LP_RSTRIDE + d];
+                const float *z = sZ + row * 33;
+#pragma unroll
+                for (int k = 0; k < LP_DIMS; ++k) acc[k] += r * z[k];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < LP_DIMS; ++k) sQ[k * 256 + d] = acc[k];
+        __syncthreads();
+        orthonormalise(it + 1 == iters);
+    }
+#pragma unroll
+    for (int k = 0; k < LP_DIMS; ++k) basis[((size_t)l * LP_DIMS + k) * 256 + d] = sQ[k * 256 + d];
+    if (d < LP_DIMS) {
+        // coefficient y_k has variance lambda_k / n: one 8-bit scalar quantiser per direction, range +-4 sigma
+        const float lk = sLam[d];
+        const float sigma = n > 0 ? sqrtf(lk / (float)n) : 0.0f;
+        lscale[(size_t)l * LP_DIMS + d] = fmaxf(4.0f * sigma, 1e-12f) / 127.0f;
+    }
+}
+
+// one wave per row (list order): code_k = clamp(round(Q_l[k] . (x - c_l) / scale_l[k]))
+__global__ void __launch_bounds__(256) lpca_encode_kernel(const float *corpus, const uint32_t *ids, const uint32_t *sorted_lists,
+                                                           uint64_t n, const float *centroids, const float *basis, const float *lscale,
+                                                           uint8_t *codes)
+{
+    const uint64_t pos = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pos >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t l = sorted_lists[pos];
+    f32x4 r = reinterpret_cast<const f32x4 *>(corpus + (uint64_t)ids[pos] * 256)[lane];
+    r -= reinterpret_cast<const f32x4 *>(centroids + (size_t)l * 256)[lane];
+    const f32x4 *B = reinterpret_cast<const f32x4 *>(basis + (size_t)l * LP_DIMS * 256);
+    uint32_t mine = 0;
+#pragma unroll 4
+    for (int k = 0; k < LP_DIMS; ++k) {
+        const f32x4 b = B[k * 64 + lane];
+        const float y = wave_sum(r.x * b.x + r.y * b.y + r.z * b.z + r.w * b.w);
+        const float c = fminf(fmaxf(rintf(y / lscale[(size_t)l * LP_DIMS + k]), -127.0f), 127.0f);
+        if (lane == k) mine = (uint32_t)(uint8_t)(int8_t)(int)c;
+    }
+    if (lane < LP_DIMS) codes[pos * PQ_M + lane] = (uint8_t)mine;
+}
+
+// w[pair][k] = scale_l[k] * (Q_l[k] . q) for every (query, probed list) pair; one wave per pair
+__global__ void __launch_bounds__(256) lpca_project_kernel(const float *queries, const uint32_t *probe_list, uint64_t n_pairs,
+                                                            uint32_t nprobe, const float *basis, const float *lscale, float *w)
+{
+    const uint64_t pair = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pair >= n_pairs) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t l = probe_list[pair];
+    const f32x4 q = reinterpret_cast<const f32x4 *>(queries + (pair / nprobe) * 256)[lane];
+    const f32x4 *B = reinterpret_cast<const f32x4 *>(basis + (size_t)l * LP_DIMS * 256);
+    float mine = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < LP_DIMS; ++k) {
+        const f32x4 b = B[k * 64 + lane];
+        const float y = wave_sum(q.x * b.x + q.y * b.y + q.z * b.z + q.w * b.w);
+        if (lane == k) mine = y * lscale[(size_t)l * LP_DIMS + k];
+    }
+    if (lane < LP_DIMS) w[pair * LP_DIMS + lane] = mine;
+}
+
 // ------------------------------------------------------------------ query: ADC scan
 struct AdcParams {
     const float *queries;
-    const float *lut;          // [nq][32][256]
+    const float *lut;          // [nq][32][256]  (kind 0)
+    const float *lw;           // [nq][nprobe][32] per-pair weights of the per-list PCA codes (kind 1), or nullptr
     const uint32_t *probe_list;
     const float *probe_dot;
     uint32_t nprobe;
@@ -470,8 +660,20 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         }
     }
 
-    const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(p.lut + (size_t)qi * PQ_M * PQ_K);
-    for (int e = threadIdx.x; e < PQ_M * PQ_K / 4; e += ADC_THREADS) reinterpret_cast<f32x4 *>(s_lut)[e] = lsrc[e];
+    if (p.lw == nullptr) {
+        const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(p.lut + (size_t)qi * PQ_M * PQ_K);
+        for (int e = threadIdx.x; e < PQ_M * PQ_K / 4; e += ADC_THREADS) reinterpret_cast<f32x4 *>(s_lut)[e] = lsrc[e];
+    }
+    // kind 1: the 32 weights of this (query, list) pair, block-uniform (scalar loads)
+    float lw[PQ_M];
+    if (p.lw != nullptr) {
+        const float *src = p.lw + ((size_t)qi * p.nprobe + pi) * PQ_M;
+#pragma unroll
+        for (int k = 0; k < PQ_M; ++k) lw[k] = src[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < PQ_M; ++k) lw[k] = 0.0f;
+    }
     const f32x4 qv = reinterpret_cast<const f32x4 *>(p.queries + (size_t)qi * 256)[lane];
     const float a2 = wave_sum(qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w);
     const bool qz = a2 == 0.0f;
@@ -522,12 +724,22 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
                 const uint4 c1 = reinterpret_cast<const uint4 *>(p.codes + i * PQ_M)[1];
                 const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                 float acc = base;
+                if (p.lw != nullptr) {   // block-uniform branch: signed bytes times the pair's weights
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    acc += s_lut[(4 * u + 0) * PQ_K + (w[u] & 0xFF)];
-                    acc += s_lut[(4 * u + 1) * PQ_K + ((w[u] >> 8) & 0xFF)];
-                    acc += s_lut[(4 * u + 2) * PQ_K + ((w[u] >> 16) & 0xFF)];
-                    acc += s_lut[(4 * u + 3) * PQ_K + (w[u] >> 24)];
+                    for (int u = 0; u < 8; ++u) {
+                        acc += lw[4 * u + 0] * (float)(int8_t)(w[u] & 0xFF);
+                        acc += lw[4 * u + 1] * (float)(int8_t)((w[u] >> 8) & 0xFF);
+                        acc += lw[4 * u + 2] * (float)(int8_t)((w[u] >> 16) & 0xFF);
+                        acc += lw[4 * u + 3] * (float)(int8_t)(w[u] >> 24);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc += s_lut[(4 * u + 0) * PQ_K + (w[u] & 0xFF)];
+                        acc += s_lut[(4 * u + 1) * PQ_K + ((w[u] >> 8) & 0xFF)];
+                        acc += s_lut[(4 * u + 2) * PQ_K + ((w[u] >> 16) & 0xFF)];
+                        acc += s_lut[(4 * u + 3) * PQ_K + (w[u] >> 24)];
+                    }
                 }
                 const float d = fmaxf(1.0f - acc * rq, 0.0f);  // rows are unit-norm (model2vec output), zero rows score ~0
                 if (acc == acc) {                                // a NaN score never becomes a candidate
@@ -681,6 +893,9 @@ struct smt_ivfpq {
     uint64_t *d_offsets = nullptr;  // [nlist+1]
     uint8_t *d_i8 = nullptr;        // [N][256] int8 rows, list order (refinement stage; nullptr = off)
     float *d_i8_scale = nullptr;    // [N]
+    uint32_t kind = 0;              // 0: global residual codebooks (dsub 8); 1: per-list PCA basis + 8-bit scalar codes
+    float *d_basis = nullptr;       // kind 1: [nlist][32][256]
+    float *d_lscale = nullptr;      // kind 1: [nlist][32]
     uint64_t max_list = 0;          // longest inverted list (segments per probed list at query time)
     double build_ms[4] = {0, 0, 0, 0};  // coarse train, assign all, pq train, encode+lists
 };
@@ -710,6 +925,8 @@ int dev_alloc(DevBuf &b, size_t bytes)
 }
 
 constexpr size_t PQ_SMEM = (size_t)PQ_K * 16 * PQ_DSUB * 4;
+
+constexpr size_t LPCA_SMEM = (size_t)(LP_DIMS * 256 + LP_TILE * LP_RSTRIDE + LP_TILE * 33 + LP_DIMS + 4 + LP_DIMS) * 4 + 64;
 
 size_t assign_smem(uint32_t nlist) { return (size_t)2 * QT_F4 * 16 + (size_t)nlist * 4 + 64; }
 
@@ -766,7 +983,7 @@ void smt_ivfpq_destroy(smt_ivfpq *ix)
     if (!ix) return;
     if (ix->corpus) { (void)hipSetDevice(ix->corpus->ctx->device); (void)hipStreamSynchronize(ix->corpus->ctx->stream); }
     for (void *p : {(void *)ix->d_centroids, (void *)ix->d_cnorm_half, (void *)ix->d_codebooks, (void *)ix->d_codes, (void *)ix->d_ids,
-                    (void *)ix->d_offsets, (void *)ix->d_i8, (void *)ix->d_i8_scale})
+                    (void *)ix->d_offsets, (void *)ix->d_i8, (void *)ix->d_i8_scale, (void *)ix->d_basis, (void *)ix->d_lscale})
         if (p) (void)hipFree(p);
     delete ix;
 }
@@ -779,7 +996,9 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     IVF_HIP(hipSetDevice(ctx->device));
     { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     const uint64_t N = corpus->rows;
-    SMT_REQUIRE(prm->m == PQ_M && prm->nbits == 8, "this build supports m = 32 sub-quantisers of 8 bits (dsub = 8)");
+    SMT_REQUIRE(prm->m == PQ_M && prm->nbits == 8, "this build supports m = 32 sub-quantisers of 8 bits");
+    SMT_REQUIRE(prm->local_pca <= 1, "local_pca must be 0 or 1");
+    const bool lpca = prm->local_pca == 1;
     SMT_REQUIRE(prm->nlist >= 32 && prm->nlist <= PROBE_MAX_LISTS && prm->nlist % 32 == 0, "nlist must be a multiple of 32 in [32, 4096]");
     SMT_REQUIRE(N >= (uint64_t)prm->nlist && N < 0xFFFFFFFFull, "corpus needs at least nlist rows");
     const uint32_t nlist = prm->nlist;
@@ -794,6 +1013,11 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     ix->corpus = corpus;
     ix->n_rows = N;
     ix->nlist = nlist;
+    ix->kind = lpca ? 1u : 0u;
+    if (lpca) {
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_basis), (size_t)nlist * LP_DIMS * 256 * 4));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_lscale), (size_t)nlist * LP_DIMS * 4));
+    }
     IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_centroids), (size_t)nlist * 256 * 4));
     IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_cnorm_half), (size_t)nlist * 4));
     IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codebooks), (size_t)PQ_M * PQ_K * PQ_DSUB * 4));
@@ -824,7 +1048,8 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     }
     IVF_HIP(hipEventRecord(ev[1], ctx->stream));
 
-    // ---- product quantiser on the sample's residuals
+    // ---- product quantiser on the sample's residuals (kind 0; kind 1 trains per-list bases after the lists exist)
+    if (!lpca) {
     if ((rc = run_assign(ctx, corpus->d_rows, S, stride, N, ix, b_assign.as<uint32_t>()))) return rc;
     hipLaunchKernelGGL(pq_init_kernel, dim3((PQ_M * PQ_K * PQ_DSUB + 255) / 256), dim3(256), 0, ctx->stream, corpus->d_rows, stride, S,
                        b_assign.as<uint32_t>(), ix->d_centroids, ix->d_codebooks);
@@ -847,6 +1072,7 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
         hipLaunchKernelGGL(pq_finalize_kernel, dim3((PQ_M * PQ_K * PQ_DSUB + 255) / 256), dim3(256), 0, ctx->stream,
                            b_sums.as<long long>(), b_counts.as<unsigned int>(), ix->d_codebooks);
     }
+    }
     IVF_HIP(hipEventRecord(ev[2], ctx->stream));
 
     // ---- assign every row, sort rows by list, encode in list order
@@ -864,7 +1090,19 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
                                       ix->d_ids, N, 0, 32, ctx->stream));
     hipLaunchKernelGGL(list_offsets_kernel, dim3((nlist + 1 + 255) / 256), dim3(256), 0, ctx->stream, b_sorted_lists.as<uint32_t>(), N, nlist,
                        ix->d_offsets);
-    {
+    if (lpca) {
+        // per-list PCA bases (subspace iteration over each list's residuals), then the 8-bit codes in list order
+        if (!(ctx->attr_done & ATTR_IVF_LPCA)) {
+            IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lpca_train_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+            ctx->attr_done |= ATTR_IVF_LPCA;
+        }
+        const uint32_t pca_iters = std::max<uint32_t>(4u, std::min<uint32_t>(iters, 8u));
+        hipLaunchKernelGGL(lpca_train_kernel, dim3(nlist), dim3(256), LPCA_SMEM, ctx->stream, corpus->d_rows, ix->d_ids, ix->d_offsets,
+                           ix->d_centroids, pca_iters, ix->d_basis, ix->d_lscale);
+        hipLaunchKernelGGL(lpca_encode_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
+                           b_sorted_lists.as<uint32_t>(), N, ix->d_centroids, ix->d_basis, ix->d_lscale, ix->d_codes);
+    } else {
         PqParams q;
         q.rows = corpus->d_rows;
         q.order = ix->d_ids;
@@ -906,7 +1144,8 @@ int smt_ivfpq_info(const smt_ivfpq *ix, uint64_t *n_rows, uint32_t *nlist, uint6
     if (nlist) *nlist = ix->nlist;
     if (index_bytes)
         *index_bytes = (uint64_t)ix->n_rows * (PQ_M + 4) + (uint64_t)ix->nlist * 256 * 4 + (uint64_t)PQ_M * PQ_K * PQ_DSUB * 4 +
-                       (uint64_t)(ix->nlist + 1) * 8 + (ix->d_i8 ? (uint64_t)ix->n_rows * 260 : 0);
+                       (uint64_t)(ix->nlist + 1) * 8 + (ix->d_i8 ? (uint64_t)ix->n_rows * 260 : 0) +
+                       (ix->kind == 1 ? (uint64_t)ix->nlist * LP_DIMS * 257 * 4 : 0);
     if (build_ms4) for (int i = 0; i < 4; ++i) build_ms4[i] = ix->build_ms[i];
     return SMT_OK;
 }
@@ -929,7 +1168,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
                              uint64_t **d_or_out, size_t *out_bytes_contig)
 {
     smt_ctx *ctx = ix->corpus->ctx;
-    SMT_REQUIRE(ix->corpus->rows == ix->n_rows, "the corpus changed after the index was built");
+    SMT_REQUIRE(ix->corpus->rows >= ix->n_rows, "the corpus shrank after the index was built: rebuild");
     SMT_REQUIRE(nprobe >= 1 && nprobe <= ix->nlist && nprobe <= 512, "nprobe must be in [1, min(nlist, 512)]");
     SMT_REQUIRE(top_k <= 56, "top_k must be <= 56 for the IVF-PQ path");
     if (rerank == 0) rerank = 512;
@@ -961,7 +1200,8 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     const size_t o_od = o_or + b_or, b_od = b_or;
     const size_t o_oc = o_od + b_od, b_oc = al((size_t)nq * 8);
     const size_t o_sc = o_oc + b_oc, b_sc = al((size_t)nq * ix->nlist * 4);
-    int rc = smt::ensure_scratch(ctx, o_sc + b_sc);
+    const size_t o_lw = o_sc + b_sc, b_lw = ix->kind == 1 ? al((size_t)nq * nprobe * PQ_M * 4) : 0;
+    int rc = smt::ensure_scratch(ctx, o_lw + b_lw);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(ctx->d_scratch);
     const float *d_q = queries;
@@ -987,11 +1227,18 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     hipLaunchKernelGGL(ivf_score_kernel, dim3(ix->nlist / QT_ROWS), dim3(GEMM_THREADS), (size_t)QT_F4 * 16 + 64, ctx->stream, d_q, nq,
                        ix->d_centroids, ix->d_cnorm_half, ix->nlist, d_scores);
     hipLaunchKernelGGL(ivf_probe_select_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, pp, d_scores, nq);
-    hipLaunchKernelGGL(ivf_lut_kernel, dim3(nq, PQ_M), dim3(PQ_K), 0, ctx->stream, d_q, ix->d_codebooks, reinterpret_cast<float *>(base + o_lut));
+    if (ix->kind == 1) {
+        const uint64_t n_pairs = (uint64_t)nq * nprobe;
+        hipLaunchKernelGGL(lpca_project_kernel, dim3((unsigned)((n_pairs * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_q, pp.probe_list,
+                           n_pairs, nprobe, ix->d_basis, ix->d_lscale, reinterpret_cast<float *>(base + o_lw));
+    } else {
+        hipLaunchKernelGGL(ivf_lut_kernel, dim3(nq, PQ_M), dim3(PQ_K), 0, ctx->stream, d_q, ix->d_codebooks, reinterpret_cast<float *>(base + o_lut));
+    }
     prof_end(ctx, "ivf_probe");
     AdcParams ap;
     ap.queries = d_q;
     ap.lut = reinterpret_cast<float *>(base + o_lut);
+    ap.lw = ix->kind == 1 ? reinterpret_cast<const float *>(base + o_lw) : nullptr;
     ap.probe_list = pp.probe_list;
     ap.probe_dot = pp.probe_dot;
     ap.nprobe = nprobe;
@@ -1127,6 +1374,36 @@ bool read_dev(FILE *f, void *d, size_t bytes, hipStream_t st, std::vector<char> 
 }  // namespace
 
 namespace smt {
+// smt_ivfpq_append: merge n_new already-encoded rows (sorted by list) into the inverted lists.
+// grid = nlist blocks: block l copies its old segment to its new place and appends its new rows behind it.
+__global__ void __launch_bounds__(256) ivf_merge_lists_kernel(const uint64_t *old_off, const uint64_t *new_off, const uint32_t *old_ids,
+                                                               const uint8_t *old_codes, const uint32_t *new_ids, const uint8_t *new_codes,
+                                                               uint32_t *out_ids, uint8_t *out_codes, uint64_t *out_off, uint32_t nlist)
+{
+    const uint32_t l = blockIdx.x;
+    const uint64_t ob = old_off[l], on = old_off[l + 1] - ob;
+    const uint64_t nb = new_off[l], nn = new_off[l + 1] - nb;
+    const uint64_t dst = ob + nb;                 // rows of earlier lists: old ones + new ones
+    for (uint64_t i = threadIdx.x; i < on; i += blockDim.x) out_ids[dst + i] = old_ids[ob + i];
+    for (uint64_t i = threadIdx.x; i < nn; i += blockDim.x) out_ids[dst + on + i] = new_ids[nb + i];
+    const uint4 *oc = reinterpret_cast<const uint4 *>(old_codes + ob * PQ_M);
+    const uint4 *nc = reinterpret_cast<const uint4 *>(new_codes + nb * PQ_M);
+    uint4 *dc = reinterpret_cast<uint4 *>(out_codes + dst * PQ_M);
+    for (uint64_t i = threadIdx.x; i < on * 2; i += blockDim.x) dc[i] = oc[i];
+    for (uint64_t i = threadIdx.x; i < nn * 2; i += blockDim.x) dc[on * 2 + i] = nc[i];
+    if (threadIdx.x == 0) {
+        out_off[l] = dst;
+        if (l + 1 == nlist) out_off[nlist] = old_off[nlist] + new_off[nlist];
+    }
+}
+__global__ void iota_from_kernel(uint32_t *v, uint64_t n, uint32_t first)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = first + (uint32_t)i;
+}
+}  // namespace smt
+
+namespace smt {
 __global__ void count_ids_out_of_range_kernel(const uint32_t *ids, uint64_t n, uint32_t n_rows, unsigned int *bad)
 {
     unsigned int mine = 0;
@@ -1137,6 +1414,85 @@ __global__ void count_ids_out_of_range_kernel(const uint32_t *ids, uint64_t n, u
 }  // namespace smt
 
 extern "C" {
+
+int smt_ivfpq_append(smt_ivfpq *ix, uint64_t *n_added)
+{
+    SMT_REQUIRE(ix != nullptr, "index");
+    smt_corpus *corpus = ix->corpus;
+    smt_ctx *ctx = corpus->ctx;
+    if (n_added) *n_added = 0;
+    SMT_REQUIRE(corpus->rows >= ix->n_rows, "the corpus shrank since the index was built: rebuild");
+    const uint64_t n_old = ix->n_rows, n_new = corpus->rows - n_old, N = corpus->rows;
+    if (n_new == 0) return SMT_OK;
+    if (ix->d_i8) { smt::set_error("an index with the int8 refinement copy cannot be extended: rebuild"); return SMT_E_UNSUPPORTED; }
+    SMT_REQUIRE(N < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
+    IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
+    const uint32_t nlist = ix->nlist;
+    DevBuf b_assign, b_sorted, b_iota, b_ids, b_temp, b_codes, b_noff;
+    int rc;
+    if ((rc = dev_alloc(b_assign, n_new * 4)) || (rc = dev_alloc(b_sorted, n_new * 4)) || (rc = dev_alloc(b_iota, n_new * 4)) ||
+        (rc = dev_alloc(b_ids, n_new * 4)) || (rc = dev_alloc(b_codes, n_new * PQ_M)) || (rc = dev_alloc(b_noff, (size_t)(nlist + 1) * 8)))
+        return rc;
+    // nearest centroid of every new row (the MFMA assignment kernel of the build), then the new rows in list order
+    const float *new_rows = corpus->d_rows + (size_t)n_old * 256;
+    if ((rc = run_assign(ctx, new_rows, n_new, 1, n_new, ix, b_assign.as<uint32_t>()))) return rc;
+    hipLaunchKernelGGL(iota_from_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, ctx->stream, b_iota.as<uint32_t>(), n_new,
+                       (uint32_t)n_old);
+    size_t temp_bytes = 0;
+    IVF_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, b_assign.as<uint32_t>(), b_sorted.as<uint32_t>(), b_iota.as<uint32_t>(),
+                                      b_ids.as<uint32_t>(), n_new, 0, 32, ctx->stream));
+    if ((rc = dev_alloc(b_temp, temp_bytes))) return rc;
+    IVF_HIP(rocprim::radix_sort_pairs(b_temp.p, temp_bytes, b_assign.as<uint32_t>(), b_sorted.as<uint32_t>(), b_iota.as<uint32_t>(),
+                                      b_ids.as<uint32_t>(), n_new, 0, 32, ctx->stream));
+    hipLaunchKernelGGL(list_offsets_kernel, dim3((nlist + 1 + 255) / 256), dim3(256), 0, ctx->stream, b_sorted.as<uint32_t>(), n_new, nlist,
+                       b_noff.as<uint64_t>());
+    // encode with the EXISTING quantisers (no retraining: that is what makes this incremental)
+    if (ix->kind == 1) {
+        hipLaunchKernelGGL(lpca_encode_kernel, dim3((unsigned)((n_new * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows,
+                           b_ids.as<uint32_t>(), b_sorted.as<uint32_t>(), n_new, ix->d_centroids, ix->d_basis, ix->d_lscale,
+                           b_codes.as<uint8_t>());
+    } else {
+        PqParams q;
+        q.rows = corpus->d_rows;
+        q.order = b_ids.as<uint32_t>();
+        q.row_stride = 1;
+        q.assign = b_sorted.as<uint32_t>();
+        q.centroids = ix->d_centroids;
+        q.codebooks = ix->d_codebooks;
+        q.n_points = n_new;
+        q.sums = nullptr;
+        q.counts = nullptr;
+        q.codes = b_codes.as<uint8_t>();
+        hipLaunchKernelGGL(pq_assign_kernel, dim3((unsigned)std::min<uint64_t>((n_new + 15) / 16, (uint64_t)ctx->num_cus)), dim3(256),
+                           PQ_SMEM, ctx->stream, q);
+    }
+    // merged lists: list l = its old rows, then its new rows (row order inside a list stays ascending)
+    uint32_t *ids2 = nullptr;
+    uint8_t *codes2 = nullptr;
+    uint64_t *off2 = nullptr;
+    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ids2), (size_t)N * 4));
+    if (hipMalloc(reinterpret_cast<void **>(&codes2), (size_t)N * PQ_M) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&off2), (size_t)(nlist + 1) * 8) != hipSuccess) {
+        (void)hipFree(ids2); if (codes2) (void)hipFree(codes2);
+        smt::set_error("out of device memory while extending the index");
+        return SMT_E_NOMEM;
+    }
+    hipLaunchKernelGGL(ivf_merge_lists_kernel, dim3(nlist), dim3(256), 0, ctx->stream, ix->d_offsets, b_noff.as<uint64_t>(), ix->d_ids,
+                       ix->d_codes, b_ids.as<uint32_t>(), b_codes.as<uint8_t>(), ids2, codes2, off2, nlist);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(ids2); (void)hipFree(codes2); (void)hipFree(off2);
+        smt::set_error("extending the index: %s", hipGetErrorString(e));
+        return SMT_E_HIP;
+    }
+    (void)hipFree(ix->d_ids); (void)hipFree(ix->d_codes); (void)hipFree(ix->d_offsets);
+    ix->d_ids = ids2; ix->d_codes = codes2; ix->d_offsets = off2;
+    ix->n_rows = N;
+    if (n_added) *n_added = n_new;
+    return compute_max_list(ix);
+}
 
 int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
 {
@@ -1156,6 +1512,7 @@ int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
     h.dim = 256;
     h.n_rows = ix->n_rows;
     h.pad[0] = ix->d_i8 ? 1 : 0;  // 1 = built with the int8 refinement copy (never stored: load re-derives it from the corpus)
+    h.pad[1] = (uint8_t)ix->kind; // 1 = per-list PCA bases + scalar codes follow the codes
     std::vector<char> buf;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     ok = ok && write_dev(f, ix->d_centroids, (size_t)ix->nlist * 256 * 4, ctx->stream, buf);
@@ -1164,6 +1521,10 @@ int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
     ok = ok && write_dev(f, ix->d_offsets, (size_t)(ix->nlist + 1) * 8, ctx->stream, buf);
     ok = ok && write_dev(f, ix->d_ids, (size_t)ix->n_rows * 4, ctx->stream, buf);
     ok = ok && write_dev(f, ix->d_codes, (size_t)ix->n_rows * PQ_M, ctx->stream, buf);
+    if (ix->kind == 1) {
+        ok = ok && write_dev(f, ix->d_basis, (size_t)ix->nlist * LP_DIMS * 256 * 4, ctx->stream, buf);
+        ok = ok && write_dev(f, ix->d_lscale, (size_t)ix->nlist * LP_DIMS * 4, ctx->stream, buf);
+    }
     if (fclose(f) != 0) ok = false;
     if (!ok) { smt::set_error("short write to '%s'", path); return SMT_E_IO; }
     return SMT_OK;
@@ -1188,7 +1549,7 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
         smt::set_error("'%s': unsupported index geometry (nlist %u, m %u, nbits %u, dim %u)", path, h.nlist, h.m, h.nbits, h.dim);
         return SMT_E_UNSUPPORTED;
     }
-    if (h.n_rows != corpus->rows) {
+    if (h.n_rows > corpus->rows) {  // (fewer is fine: the index covers a prefix, smt_ivfpq_append takes in the rest)
         smt::set_error("'%s' indexes %llu rows but the corpus holds %llu: rebuild", path, (unsigned long long)h.n_rows,
                        (unsigned long long)corpus->rows);
         return SMT_E_INVALID;
@@ -1213,6 +1574,14 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     ok = ok && read_dev(f, ix->d_offsets, (size_t)(h.nlist + 1) * 8, ctx->stream, buf);
     ok = ok && read_dev(f, ix->d_ids, N * 4, ctx->stream, buf);
     ok = ok && read_dev(f, ix->d_codes, N * PQ_M, ctx->stream, buf);
+    ix->kind = h.pad[1];
+    if (ix->kind > 1) { smt::set_error("'%s': unknown index kind %u", path, ix->kind); return SMT_E_IO; }
+    if (ok && ix->kind == 1) {
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_basis), (size_t)h.nlist * LP_DIMS * 256 * 4));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_lscale), (size_t)h.nlist * LP_DIMS * 4));
+        ok = ok && read_dev(f, ix->d_basis, (size_t)h.nlist * LP_DIMS * 256 * 4, ctx->stream, buf);
+        ok = ok && read_dev(f, ix->d_lscale, (size_t)h.nlist * LP_DIMS * 4, ctx->stream, buf);
+    }
     if (!ok) { smt::set_error("'%s' is truncated or unreadable", path); return SMT_E_IO; }
     // the list table must be consistent with the row count, or the ADC kernel would read out of bounds
     std::vector<uint64_t> offs((size_t)h.nlist + 1);

@@ -84,3 +84,34 @@ def clustered_rows_torch(n, n_centers, latent, seed, device, spread=0.35, noise=
         xs += (noise / 16.0) * torch.randn(e - b, 256, device=device, generator=g)
         x[b:e] = xs / xs.norm(dim=1, keepdim=True)
     return x
+
+
+def clustered_model_torch(n_centers, latent, seed, device):
+    """The generative model behind clustered_rows_torch, kept so that QUERIES can be drawn from it independently of
+    the corpus rows (fresh latent draws of random topics -- not perturbed corpus rows)."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    centers = torch.randn(n_centers, 256, device=device, generator=g)
+    centers /= centers.norm(dim=1, keepdim=True)
+    basis = torch.randn(n_centers, latent, 256, device=device, generator=g) / 16.0
+    return dict(centers=centers, basis=basis, latent=latent, device=device)
+
+
+def clustered_sample_torch(model, n, seed, spread=0.35, noise=0.01):
+    import torch
+
+    g = torch.Generator(device=model["device"])
+    g.manual_seed(seed)
+    centers, basis, latent = model["centers"], model["basis"], model["latent"]
+    which = torch.randint(0, centers.shape[0], (n,), device=model["device"], generator=g)
+    x = torch.empty(n, 256, device=model["device"])
+    step = 500_000
+    for b in range(0, n, step):
+        e = min(n, b + step)
+        z = torch.randn(e - b, 1, latent, device=model["device"], generator=g) * (spread / latent ** 0.5)
+        xs = centers[which[b:e]] + torch.bmm(z, basis[which[b:e]]).squeeze(1)
+        xs += (noise / 16.0) * torch.randn(e - b, 256, device=model["device"], generator=g)
+        x[b:e] = xs / xs.norm(dim=1, keepdim=True)
+    return x

@@ -219,7 +219,9 @@ def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, ca
 
     out2 = host.search_with_workspace(model, query, files, workspace_name="t1", n_lines=1, top_k=3)
     assert capfd.readouterr().err == "" and out2 == out                              # unchanged -> nothing re-embedded
-    assert "Documents: 2" in host.workspace_status(model.ctx, "t1") and "Index: Yes (HNSW)" in host.workspace_status(model.ctx, "t1")
+    # (the reference prints a hard-coded "Index: Yes (HNSW)" although it scans exactly; here a small workspace says
+    # what it does -- the exact scan -- and a large one names its IVF index, see test_workspace_index_lifecycle)
+    assert "Documents: 2" in host.workspace_status(model.ctx, "t1") and "Index: No" in host.workspace_status(model.ctx, "t1")
     assert json.loads(host.workspace_status(model.ctx, "t1", json=True))["total_documents"] == 2
 
     # workspace mode: top_k applies even with a threshold (store.rs:543)
@@ -291,6 +293,60 @@ def test_workspace_survives_a_damaged_store(model, model_dir, prose_files, tmp_p
     assert json.loads(host.workspace_status(model.ctx, "dmg", json=True))["total_documents"] == 2
     live = len(la) + len(lb) + 1
     assert (emb.stat().st_size - 32) // 1024 <= 4096 + 2 * live   # bounded (compaction threshold: 4096 dead rows or half)
+
+
+def test_workspace_index_lifecycle(model, tmp_path, monkeypatch, capfd):
+    """The IVF index of a large workspace: built by the first whole-workspace search above the
+    row threshold, persisted beside the vectors, reloaded by the next process, extended incrementally when a file is
+    added, bypassed for path subsets -- and `workspace status` names it.  With every list probed and more re-scored
+    rows than a list holds the approximate path returns exactly what the exact scan returns."""
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    files = []
+    for i in range(6):
+        f = tmp_path / f"big{i}.txt"
+        f.write_text("\n".join(synth.pseudo_prose(1000, vocab_size=V - 1, seed=100 + i)) + "\n")
+        files.append(str(f))
+    query = synth.pseudo_prose(1, vocab_size=V - 1, seed=103)[0]
+    host.workspace_use(None, "big")
+    root = tmp_path / ".semtools" / "workspaces" / "big"
+    monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "1000000000")                 # exact scan: the truth
+    exact = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
+    assert not (root / "line_index.ivf").exists()
+    assert "Index: No" in host.workspace_status(model.ctx, "big")
+    monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "4000")
+    monkeypatch.setenv("SEMTOOLS_INDEX_NPROBE", "512")
+    capfd.readouterr()
+    got = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
+    assert got == exact
+    ivf = root / "line_index.ivf"
+    assert ivf.exists() and not (root / "line_index.ivf.tmp").exists()
+    assert "Index: Yes (IVF_PQ)" in host.workspace_status(model.ctx, "big")
+    stamp = ivf.stat().st_mtime_ns
+    assert host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5) == exact
+    assert ivf.stat().st_mtime_ns == stamp                                       # reloaded, not rebuilt
+    # a path subset is answered by the exact range-filtered scan
+    sub = host.search_with_workspace(model, query, files[:2], workspace_name="big", n_lines=0, top_k=5)
+    monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "1000000000")
+    assert sub == host.search_with_workspace(model, query, files[:2], workspace_name="big", n_lines=0, top_k=5)
+    # a new file: its rows are inserted into the existing lists (the index file is rewritten, not retrained)
+    f = tmp_path / "big6.txt"
+    f.write_text("\n".join(synth.pseudo_prose(800, vocab_size=V - 1, seed=106)) + "\n")
+    files.append(str(f))
+    exact7 = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
+    monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "4000")
+    size_before = ivf.stat().st_size
+    got7 = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
+    assert got7 == exact7
+    assert ivf.stat().st_size == size_before + 800 * 36                         # 32 B code + 4 B row id per new row
+    # an edited file leaves dead rows behind: they never surface
+    (tmp_path / "big0.txt").write_text("\n".join(synth.pseudo_prose(900, vocab_size=V - 1, seed=100)) + "\n")
+    os.utime(tmp_path / "big0.txt", (1_950_000_000, 1_950_000_000))
+    got8 = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
+    monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "1000000000")
+    assert got8 == host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
 
 
 def test_resident_session_and_serve_mode(model, model_dir, prose_files):

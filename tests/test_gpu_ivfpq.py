@@ -222,3 +222,62 @@ def test_long_lists_are_scanned_in_segments(gpu_ctx):
     assert hit / 640 > 0.85, hit / 640
     ix.close()
     c.close()
+
+
+def test_per_list_pca_codes(gpu_ctx, tmp_path):
+    """Index kind 1 (per-list PCA basis + 8-bit scalar codes): better recall than the global codebooks at a small
+    re-score depth on data whose topics do not coincide with the lists; exact (row, distance) pairs; deterministic
+    build; save / load round trip."""
+    import semtools_amd as smt
+
+    x, _ = clustered(80000, 900, seed=4)                       # 900 topics over 256 lists
+    rng = np.random.default_rng(6)
+    qs, _ = clustered(64, 900, seed=4)                         # (same topic model: seed) ...
+    qs = qs[rng.permutation(64)] + 0.0 * qs                     # ... rows of a FRESH draw, not corpus rows
+    c = smt.Corpus(gpu_ctx)
+    c.append(x)
+    exact = c.search(qs, top_k=10)
+    ix0 = smt.IvfPq(c, nlist=256, train_iters=8)
+    ix1 = smt.IvfPq(c, nlist=256, train_iters=8, local_pca=True)
+    r0 = recall(ix0.search(qs, top_k=10, nprobe=16, rerank=32), exact)
+    got = ix1.search(qs, top_k=10, nprobe=16, rerank=32)
+    r1 = recall(got, exact)
+    assert r1 >= 0.9 and r1 >= r0, (r0, r1)
+    for (rows, dist), q in zip(got, qs):                       # every returned pair is exact
+        ref = np.array([orc.cosine(q, x[int(r)], accurate=True) for r in rows])
+        assert np.array_equal(dist, ref) and (np.diff(dist) >= 0).all()
+    ix1b = smt.IvfPq(c, nlist=256, train_iters=8, local_pca=True)
+    again = ix1b.search(qs, top_k=10, nprobe=16, rerank=32)
+    assert all(a[0].tolist() == b[0].tolist() for a, b in zip(got, again))          # deterministic build
+    path = tmp_path / "lpca.ivf"
+    ix1.save(path)
+    ix1c = smt.IvfPq.load(c, path)
+    loaded = ix1c.search(qs, top_k=10, nprobe=16, rerank=32)
+    assert all(a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1]) for a, b in zip(got, loaded))
+    assert ix1c.info()["index_bytes"] == ix1.info()["index_bytes"] > ix0.info()["index_bytes"]
+    for i in (ix0, ix1, ix1b, ix1c):
+        i.close()
+    c.close()
+
+
+@pytest.mark.parametrize("local_pca", [False, True])
+def test_incremental_append_equals_a_rebuild_on_the_same_quantisers(gpu_ctx, local_pca):
+    """smt_ivfpq_append: rows added after the build are searchable, the old rows keep their codes, and the merged
+    lists partition every row exactly once."""
+    import semtools_amd as smt
+
+    x, _ = clustered(50000, 300, seed=9)
+    c = smt.Corpus(gpu_ctx)
+    c.append(x[:40000])
+    ix = smt.IvfPq(c, nlist=128, train_iters=6, local_pca=local_pca)
+    c.append(x[40000:])
+    assert ix.append() == 10000 and ix.append() == 0
+    assert ix.info()["rows"] == 50000 and int(ix.list_sizes().sum()) == 50000
+    rng = np.random.default_rng(3)
+    qs = x[rng.choice(np.arange(40000, 50000), 32, replace=False)]          # queries that ARE new rows
+    got = ix.search(qs, top_k=5, nprobe=128, rerank=512)
+    exact = c.search(qs, top_k=5)
+    assert recall(got, exact) >= 0.99
+    for (rows, dist), (er, ed) in zip(got, exact):
+        assert rows[0] == er[0] and dist[0] == ed[0]                          # each query finds itself (a new row)
+    ix.close(); c.close()
