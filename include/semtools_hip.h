@@ -91,6 +91,11 @@ int smt_prof_read(smt_ctx *ctx, const char *kernel, uint64_t *launches, double *
  * model's config flag (true for potion-multilingual-128M). */
 int smt_model_create(smt_ctx *ctx, const float *table_host, uint64_t V, uint32_t D,
                      int normalize, smt_model **out);
+/* Stream an f32 table [V x D] that sits at `byte_offset` of a file (the `embeddings` tensor of model.safetensors)
+ * straight into HBM through two pinned buffers: the file read of chunk j+1 overlaps the PCIe copy of chunk j, and no
+ * pageable staging copy of the whole table (512 MB for potion-multilingual-128M) is ever made. */
+int smt_model_create_from_file(smt_ctx *ctx, const char *path, uint64_t byte_offset, uint64_t V, uint32_t D,
+                               int normalize, smt_model **out);
 /* adopt a table already in device memory (not copied, not freed) */
 int smt_model_create_from_device(smt_ctx *ctx, const float *table_dev, uint64_t V, uint32_t D,
                                  int normalize, smt_model **out);

@@ -80,6 +80,10 @@ int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json, 
 int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);
 
 void smt_host_free(char *text);
+/* Wall-clock phases of this process so far as one JSON object (malloc'd): model_load, read_tokenize_embed_files,
+ * embed_query, store_open_corpus_load, change_detection, embed_and_persist_changed_files, scan_select, ... -- what the
+ * CLI prints to stderr under SEMTOOLS_TIMING=1. */
+char *smt_host_timing_json(void);
 
 /* Formatting primitives of the output layer, exported for tests: mode 0 = Rust `{}` of an f64,
  * 1 = Rust `{}` of an f32 (value is narrowed first), 2 = serde_json f64.  Returns malloc'd text. */

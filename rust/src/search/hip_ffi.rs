@@ -61,6 +61,15 @@ extern "C" {
         normalize: c_int,
         out: *mut *mut SmtModel,
     ) -> c_int;
+    pub fn smt_model_create_from_file(
+        ctx: *mut SmtCtx,
+        path: *const c_char,
+        byte_offset: u64,
+        V: u64,
+        D: u32,
+        normalize: c_int,
+        out: *mut *mut SmtModel,
+    ) -> c_int;
     pub fn smt_model_create_from_device(
         ctx: *mut SmtCtx,
         table_dev: *const f32,

@@ -20,7 +20,7 @@ DIM = 256
 EXPORTS = [
     "smt_ctx_create", "smt_ctx_create_on_stream", "smt_ctx_aux_stream", "smt_ctx_destroy", "smt_ctx_synchronize", "smt_last_error", "smt_version",
     "smt_device_count", "smt_prof_enable", "smt_prof_reset", "smt_prof_read",
-    "smt_model_create", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
+    "smt_model_create", "smt_model_create_from_file", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
     "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
     "smt_corpus_save", "smt_corpus_load", "smt_corpus_append_to_file", "smt_search", "smt_search_topk_device", "smt_merge_topk",
@@ -38,7 +38,7 @@ HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
     "smt_host_search_files", "smt_host_search_content", "smt_host_search_workspace", "smt_host_session_open",
     "smt_host_session_search", "smt_host_session_lines", "smt_host_session_close", "smt_host_workspace_use",
-    "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_free", "smt_host_format_float",
+    "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_free", "smt_host_timing_json", "smt_host_format_float",
     "smt_host_split_lines", "smt_host_to_lowercase",
 ]
 TOKENIZE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64,
@@ -106,6 +106,7 @@ def lib():
     L.smt_prof_reset.argtypes = [vp]
     L.smt_prof_read.argtypes = [vp, C.c_char_p, P(u64), P(f64)]
     L.smt_model_create.argtypes = [vp, vp, u64, u32, i32, P(vp)]
+    L.smt_model_create_from_file.argtypes = [vp, C.c_char_p, u64, u64, u32, i32, P(vp)]
     L.smt_model_create_from_device.argtypes = [vp, vp, u64, u32, i32, P(vp)]
     L.smt_model_destroy.argtypes = [vp]
     L.smt_model_destroy.restype = None
@@ -199,6 +200,8 @@ def lib():
     L.smt_host_workspace_prune.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_free.argtypes = [vp]
     L.smt_host_free.restype = None
+    L.smt_host_timing_json.argtypes = []
+    L.smt_host_timing_json.restype = vp
     L.smt_host_format_float.argtypes = [f64, i32]
     L.smt_host_format_float.restype = vp
     L.smt_host_split_lines.argtypes = [C.c_char_p]

@@ -732,6 +732,47 @@ int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
     return SMT_OK;
 }
 
+int smt_model_create_from_file(smt_ctx *ctx, const char *path, uint64_t byte_offset, uint64_t V, uint32_t D, int normalize,
+                               smt_model **out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(out && path, "null argument");
+    *out = nullptr;
+    if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
+    SMT_REQUIRE(V > 0, "empty table");
+    if ((rc = bind_device(ctx))) return rc;
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    if (fseeko(f, (off_t)byte_offset, SEEK_SET) != 0) { fclose(f); set_error("seek in '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    smt_model *m = new (std::nothrow) smt_model();
+    if (!m) { fclose(f); set_error("out of host memory"); return SMT_E_NOMEM; }
+    m->ctx = ctx; m->V = V; m->D = D; m->normalize = normalize ? 1 : 0; m->owned = true;
+    const size_t row_bytes = (size_t)D * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_table), (size_t)V * row_bytes);
+    if (e != hipSuccess) { fclose(f); delete m; set_error("hipMalloc for the embedding table: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
+    auto bail = [&](int code) { fclose(f); (void)hipStreamSynchronize(ctx->stream); (void)hipFree(m->d_table); delete m; return code; };
+    const size_t chunk = io_chunk_rows(V);
+    PinnedPair pp;
+    if ((rc = pp.init(chunk * row_bytes))) return bail(rc);
+    int j = 0;
+    for (uint64_t r = 0; r < V; r += chunk, j ^= 1) {
+        const size_t n = (size_t)std::min<uint64_t>(chunk, V - r);
+        if ((rc = pp.wait(j))) return bail(rc);
+        if (fread(pp.buf[j], row_bytes, n, f) != n) { set_error("'%s' is truncated", path); return bail(SMT_E_IO); }
+        e = hipMemcpyAsync(m->d_table + (size_t)r * D, pp.buf[j], n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
+        if (e != hipSuccess) { set_error("table upload: %s", hipGetErrorString(e)); return bail(SMT_E_HIP); }
+        pp.busy[j] = true;
+    }
+    fclose(f);
+    e = hipStreamSynchronize(ctx->stream);
+    pp.busy[0] = pp.busy[1] = false;
+    if (e != hipSuccess) { (void)hipFree(m->d_table); delete m; set_error("table upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+    *out = m;
+    return SMT_OK;
+}
+
 /* ---------------------------------------------------------------- embed ---- */
 
 int smt_embed_device(smt_model *model, const uint32_t *ids_dev, const uint64_t *offsets_dev, uint64_t n_lines,

@@ -212,7 +212,13 @@ int main(int argc, char **argv)
     }
     if (rc != SMT_OK) return die(smt_last_error());
     fputs(text, stdout);
+    fflush(stdout);
     smt_host_free(text);
+    if (const char *t = getenv("SEMTOOLS_TIMING"); t && *t == '1') {  // where the wall time of this invocation went
+        char *phases = smt_host_timing_json();
+        fprintf(stderr, "{\"timing_ms\": %s}\n", phases ? phases : "{}");
+        smt_host_free(phases);
+    }
     smt_host_model_destroy(model);
     smt_ctx_destroy(ctx);
     return 0;

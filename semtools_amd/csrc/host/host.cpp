@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <fstream>
@@ -309,7 +310,39 @@ StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const flo
     check(smt_model_create(ctx, table, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
 }
 
+StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
+                         bool normalize)
+    : ctx_(ctx), tok_(std::move(tok))
+{
+    check(smt_model_create_from_file(ctx, path.c_str(), byte_offset, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
+}
+
 StaticModel::~StaticModel() { smt_model_destroy(model_); }
+
+// ---- phase timer
+namespace {
+std::vector<std::pair<std::string, double>> g_phases;
+std::chrono::steady_clock::time_point g_phase_t0 = std::chrono::steady_clock::now();
+}  // namespace
+void PhaseTimer::mark(const char *phase)
+{
+    const auto now = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - g_phase_t0).count();
+    g_phase_t0 = now;
+    for (auto &p : g_phases)
+        if (p.first == phase) { p.second += ms; return; }
+    g_phases.emplace_back(phase, ms);
+}
+std::string PhaseTimer::json()
+{
+    std::string out = "{";
+    char buf[64];
+    for (size_t i = 0; i < g_phases.size(); ++i) {
+        snprintf(buf, sizeof(buf), "%.3f", g_phases[i].second);
+        out += (i ? ", \"" : "\"") + g_phases[i].first + "\": " + buf;
+    }
+    return out + "}";
+}
 
 // model2vec-rs truncate_str: keep at most max_tokens * median_token_length characters
 static std::string truncate_str(const std::string &s, size_t max_tokens, size_t median_len)
@@ -527,6 +560,7 @@ std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<
 std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,
                                        const StaticModel &model, const SearchConfig &config)
 {
+    PhaseTimer::mark("model_load");
     Embeddings emb(model.ctx());
     std::vector<Document> documents;
     for (auto &f : files) {
@@ -534,8 +568,12 @@ std::vector<SearchResult> search_files(const std::vector<std::string> &files, co
         auto doc = create_document_from_content(f, content, model, config.ignore_case, emb);
         if (doc) documents.push_back(std::move(*doc));
     }
+    PhaseTimer::mark("read_tokenize_embed_files");
     const std::vector<float> query_embedding = model.encode_single(query);
-    return search_documents(documents, emb, query_embedding, config);
+    PhaseTimer::mark("embed_query");
+    auto res = search_documents(documents, emb, query_embedding, config);
+    PhaseTimer::mark("scan_select");
+    return res;
 }
 
 std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::string> &files, const std::string &query,
@@ -543,9 +581,12 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
                                                          const std::optional<std::string> &workspace_name)
 {
     using namespace workspace;
+    PhaseTimer::mark("model_load");
     const std::vector<float> query_embedding = model.encode_single(query);
+    PhaseTimer::mark("embed_query");
     Workspace ws = Workspace::open(workspace_name);
     auto store = Store::open(ws.config.root_dir, model.ctx());
+    PhaseTimer::mark("store_open_corpus_load");
     {
         const char *min_rows = getenv("SEMTOOLS_INDEX_MIN_ROWS"), *nprobe = getenv("SEMTOOLS_INDEX_NPROBE");
         store->set_index_policy(ws.config.oversample_factor, min_rows ? strtoull(min_rows, nullptr, 10) : 2'000'000ull,
@@ -555,6 +596,7 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
     // Step 1: changed / new / unchanged (mod.rs:158)
     const std::vector<DocumentState> doc_states = store->analyze_document_states(files);
 
+    PhaseTimer::mark("change_detection");
     // Step 2+3: embed new/changed documents straight into the resident store
     size_t n_lines_upserted = 0;
     std::vector<DocMeta> docs_to_upsert;
@@ -579,10 +621,13 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
         store->upsert_document_metadata(docs_to_upsert);
     }
 
+    PhaseTimer::mark("embed_and_persist_changed_files");
     // Step 4 (mod.rs:211-213)
     std::optional<float> max_distance;
     if (config.max_distance) max_distance = (float)*config.max_distance;
-    return store->search_line_embeddings(query_embedding, files, config.top_k, max_distance);
+    auto ranked = store->search_line_embeddings(query_embedding, files, config.top_k, max_distance);
+    PhaseTimer::mark("scan_select");
+    return ranked;
 }
 
 }  // namespace search

@@ -58,10 +58,20 @@ namespace search {
 constexpr const char *MODEL_NAME = "minishlab/potion-multilingual-128M";  // src/search/mod.rs:16
 
 // model2vec_rs::model::StaticModel
+// Wall-clock phases of one CLI invocation (SEMTOOLS_TIMING=1 prints them to stderr as one JSON line): where the
+// time of `semtools search` goes when the scan itself takes 0.15 ms.
+struct PhaseTimer {
+    static void mark(const char *phase);   // closes the running phase under `phase`
+    static std::string json();             // {"phase": ms, ...} in order of first appearance
+};
+
 class StaticModel {
 public:
     // table: [V x 256] f32 host array (the `embeddings` tensor), uploaded once.
     StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize);
+    // the f32 table sits at `byte_offset` of `path` (model.safetensors): streamed to HBM through pinned buffers
+    StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
+                bool normalize);
     ~StaticModel();
     StaticModel(const StaticModel &) = delete;
 

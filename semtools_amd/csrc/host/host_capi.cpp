@@ -96,6 +96,26 @@ std::vector<float> read_safetensors_embeddings(const std::string &path, uint64_t
     return out;
 }
 
+// dtype / shape / byte offset of the `embeddings` tensor (no data read)
+bool safetensors_f32_span(const std::string &path, uint64_t &V, uint64_t &byte_offset)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error("cannot open " + path);
+    uint64_t hlen = 0;
+    f.read(reinterpret_cast<char *>(&hlen), 8);
+    if (!f || hlen > (1ull << 30)) throw Error("bad safetensors header in " + path);
+    std::string hdr(hlen, '\0');
+    f.read(&hdr[0], (std::streamsize)hlen);
+    const json::Value h = json::parse(hdr);
+    const json::Value *t = h.get("embeddings");
+    if (!t) throw Error("tensor 'embeddings' not found in " + path);
+    const auto &shape = t->get("shape")->arr;
+    if (shape.size() != 2 || shape[1].as_u64() != SMT_DIM) throw Error("'embeddings' must be [V, 256]");
+    V = shape[0].as_u64();
+    byte_offset = 8 + hlen + t->get("data_offsets")->arr[0].as_u64();
+    return t->get("dtype")->s == "F32";
+}
+
 }  // namespace
 
 extern "C" {
@@ -132,14 +152,19 @@ int smt_host_model_create(smt_ctx *ctx, const float *table, uint64_t V, int norm
     } catch (const std::exception &e) { return fail(e); }
 }
 
+char *smt_host_timing_json(void) { return dup_text(search::PhaseTimer::json()); }
+
 int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
 {
     if (!ctx || !dir || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out = nullptr;
     try {
         const std::string d(dir);
-        uint64_t V = 0;
-        const std::vector<float> table = read_safetensors_embeddings(d + "/model.safetensors", V);
+        uint64_t V = 0, table_offset = 0;
+        // F32 tables (what model2vec ships) stream file -> pinned -> HBM; F16 / I8 tables are widened on the host first
+        const bool stream_f32 = safetensors_f32_span(d + "/model.safetensors", V, table_offset);
+        std::vector<float> table;
+        if (!stream_f32) table = read_safetensors_embeddings(d + "/model.safetensors", V);
         bool normalize = true;
         std::string unk = "[UNK]";
         try {
@@ -150,7 +175,8 @@ int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
         auto tok = make_vocab_tokenizer(d + "/vocab.txt", unk);
         if (tok->vocab_size() > V) throw Error("vocab.txt has more tokens than the embedding table has rows");
         auto *h = new smt_host_model();
-        h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), table.data(), V, normalize);
+        if (stream_f32) h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), d + "/model.safetensors", table_offset, V, normalize);
+        else h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), table.data(), V, normalize);
         *out = h;
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }

@@ -31,7 +31,7 @@ def load_static_model(ctx, model_dir):
     else:
         unk_id = tok.token_to_id(unk_token) if unk_token else None
     vocab = tok.get_vocab()
-    lens = sorted(len(t) for t in vocab)                                                   # model2vec: median token length
+    lens = sorted(len(t.encode("utf-8")) for t in vocab)                                   # model2vec: median of tk.len() -- BYTES
     median_len = max(1, lens[len(lens) // 2]) if lens else 5
 
     def encode(text):
