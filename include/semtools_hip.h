@@ -322,6 +322,21 @@ int smt_sharded_search(smt_sharded_corpus *corpus, const float *queries, uint32_
 int smt_sharded_search_topk_device(smt_sharded_corpus *corpus, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
                                    uint64_t *const *out_packed);
 
+/* IVF index over a sharded corpus: every rank indexes ITS rows.  shared_centroids != 0 makes the build data-parallel
+ * (SURVEY.md 8(e)): the coarse k-means runs on every rank's sample of its own rows and the fixed-point centroid
+ * sums + counts are summed over the ranks after every accumulation (ncclAllReduce on the ranks' streams), so all
+ * ranks end with the SAME nlist centroids -- "nlist lists over the whole corpus", each list spread over the shards --
+ * while quantisers and codes are fitted locally.  shared_centroids == 0: independent per-shard indexes (own centroids,
+ * no collective in the build).  Search: per-shard smt_ivfpq_search with global rows -> the same all-gather + merge as
+ * smt_sharded_search.  Exact distances, approximate membership; top_k <= 56. */
+typedef struct smt_sharded_ivfpq smt_sharded_ivfpq;
+int smt_sharded_ivfpq_build(smt_sharded_corpus *corpus, const smt_ivfpq_params *params, int shared_centroids,
+                            smt_sharded_ivfpq **out);
+void smt_sharded_ivfpq_destroy(smt_sharded_ivfpq *index);
+smt_ivfpq *smt_sharded_ivfpq_shard(smt_sharded_ivfpq *index, int local_index); /* smt_ivfpq_info etc.; NULL if out of range */
+int smt_sharded_ivfpq_search(smt_sharded_ivfpq *index, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe,
+                             uint32_t rerank, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap);
+
 /* Exactness bookkeeping.  The f32 scan nominates top_k + 8 rows per list and the select stage PROVES per query
  * that no other row can belong to the exact answer (the k-th exact distance lies more than the f32 error bound
  * below the worst nominated f32 distance).  When the proof fails -- more than 8 near-ties around the k-th place --

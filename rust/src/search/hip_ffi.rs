@@ -8,7 +8,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 macro_rules! opaque { ($($name:ident),*) => { $( #[repr(C)] pub struct $name { _private: [u8; 0] } )* } }
-opaque!(SmtCtx, SmtModel, SmtCorpus, SmtIvfpq, SmtGroup, SmtShardedCorpus);
+opaque!(SmtCtx, SmtModel, SmtCorpus, SmtIvfpq, SmtGroup, SmtShardedCorpus, SmtShardedIvfpq);
 
 /// half-open range of corpus rows [begin, end)
 #[repr(C)]
@@ -293,6 +293,26 @@ extern "C" {
         nq: u32,
         top_k: u32,
         out_packed: *const *mut u64,
+    ) -> c_int;
+    pub fn smt_sharded_ivfpq_build(
+        corpus: *mut SmtShardedCorpus,
+        params: *const SmtIvfpqParams,
+        shared_centroids: c_int,
+        out: *mut *mut SmtShardedIvfpq,
+    ) -> c_int;
+    pub fn smt_sharded_ivfpq_destroy(index: *mut SmtShardedIvfpq);
+    pub fn smt_sharded_ivfpq_shard(index: *mut SmtShardedIvfpq, local_index: c_int) -> *mut SmtIvfpq;
+    pub fn smt_sharded_ivfpq_search(
+        index: *mut SmtShardedIvfpq,
+        queries: *const f32,
+        nq: u32,
+        top_k: u32,
+        nprobe: u32,
+        rerank: u32,
+        out_rows: *mut u64,
+        out_dist: *mut f64,
+        out_counts: *mut u64,
+        out_cap: u64,
     ) -> c_int;
     pub fn smt_ctx_uncertain_count(ctx: *mut SmtCtx, count: *mut u64, reset: c_int) -> c_int;
     pub fn smt_ctx_aux_stream(ctx: *mut SmtCtx, stream_out: *mut *mut c_void) -> c_int;

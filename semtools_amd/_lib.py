@@ -32,6 +32,7 @@ EXPORTS = [
     "smt_sharded_corpus_from_host", "smt_sharded_corpus_from_device", "smt_sharded_corpus_load", "smt_sharded_corpus_save",
     "smt_sharded_corpus_destroy", "smt_sharded_corpus_rows", "smt_sharded_corpus_rank_rows", "smt_sharded_corpus_shard",
     "smt_sharded_corpus_append_host", "smt_sharded_search", "smt_sharded_search_topk_device",
+    "smt_sharded_ivfpq_build", "smt_sharded_ivfpq_destroy", "smt_sharded_ivfpq_shard", "smt_sharded_ivfpq_search",
 ]
 UNIQUE_ID_BYTES = 128
 HOST_EXPORTS = [
@@ -179,6 +180,12 @@ def lib():
     L.smt_sharded_corpus_append_host.argtypes = [vp, vp, u64, P(u64)]
     L.smt_sharded_search.argtypes = [vp, vp, u32, u32, f64, i32, vp, u32, vp, vp, vp, u64]
     L.smt_sharded_search_topk_device.argtypes = [vp, P(vp), u32, u32, P(vp)]
+    L.smt_sharded_ivfpq_build.argtypes = [vp, P(SmtIvfPqParams), i32, P(vp)]
+    L.smt_sharded_ivfpq_destroy.argtypes = [vp]
+    L.smt_sharded_ivfpq_destroy.restype = None
+    L.smt_sharded_ivfpq_shard.argtypes = [vp, i32]
+    L.smt_sharded_ivfpq_shard.restype = vp
+    L.smt_sharded_ivfpq_search.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, u64]
     # ---- host layer (include/semtools_host.h)
     cpp = P(C.c_char_p)
     L.smt_host_model_create.argtypes = [vp, vp, u64, i32, i32, C.c_char_p, C.c_char_p, TOKENIZE_CB, vp, u32, u32, P(vp)]

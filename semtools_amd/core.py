@@ -466,6 +466,45 @@ class ShardedCorpus:
         L.check(L.lib().smt_sharded_search_topk_device(self._h, qp, int(nq), int(top_k), op))
 
 
+class ShardedIvfPq:
+    """IVF index over a ShardedCorpus (smt_sharded_ivfpq): every rank indexes its rows; shared_centroids=True runs
+    the coarse k-means data-parallel with an all-reduce of the centroid sums, so all ranks share one set of lists."""
+
+    def __init__(self, sharded_corpus, nlist=4096, train_iters=10, local_pca=True, shared_centroids=True):
+        self.corpus = sharded_corpus
+        self._h = C.c_void_p()
+        prm = L.SmtIvfPqParams(int(nlist), 32, 8, int(train_iters), 0, 0, 1 if local_pca else 0)
+        L.check(L.lib().smt_sharded_ivfpq_build(sharded_corpus._h, C.byref(prm), int(bool(shared_centroids)), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_sharded_ivfpq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_list_sizes(self, local_index, nlist):
+        h = L.lib().smt_sharded_ivfpq_shard(self._h, int(local_index))
+        out = np.empty(int(nlist), dtype=np.uint64)
+        L.check(L.lib().smt_ivfpq_list_sizes(C.c_void_p(h), L.np_ptr(out)))
+        return out
+
+    def search(self, queries, top_k=10, nprobe=16, rerank=128):
+        q = _f32c(queries).reshape(-1, L.DIM)
+        nq = q.shape[0]
+        cap = max(int(top_k), 1)
+        out_rows = np.empty((nq, cap), dtype=np.uint64)
+        out_dist = np.empty((nq, cap), dtype=np.float64)
+        counts = np.zeros(nq, dtype=np.uint64)
+        L.check(L.lib().smt_sharded_ivfpq_search(self._h, L.np_ptr(q), nq, int(top_k), int(nprobe), int(rerank),
+                                                 L.np_ptr(out_rows), L.np_ptr(out_dist), L.np_ptr(counts), cap))
+        return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
+
+
 def merge_topk(rows, dist, k_out):
     """Host merge of per-shard sorted top-k lists laid out [n_lists][nq][k_in]."""
     rows = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -254,6 +254,22 @@ int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *que
                              std::vector<uint32_t> &rows_out, std::vector<double> &dist_out, float *next_d32 = nullptr
                              /* f32 distance of the best row NOT among the candidates (+inf if none) */);
 
+// IVF index as one rank of a shared-centroid build / packed search (ivfpq_kernels.hip <-> group.cpp)
+struct IvfBuildShare {
+    uint32_t rank = 0, n_ranks = 1;
+    // sum `sums` (n_sums int64, 2^-32 fixed point) and `counts` (n_counts u32) over the ranks, in place, enqueued on
+    // the context's stream (ncclAllReduce), or synchronously for the copy transport
+    int (*allreduce)(void *user, long long *sums_dev, size_t n_sums, unsigned int *counts_dev, size_t n_counts) = nullptr;
+    void *user = nullptr;
+};
+}  // namespace smt
+struct smt_ivfpq;
+struct smt_ivfpq_params;
+namespace smt {
+int ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, const IvfBuildShare *share, smt_ivfpq **out);
+int ivfpq_search_packed(smt_ivfpq *ix, const float *queries_dev, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
+                        uint64_t row_base, uint64_t *packed_dev);
+
 // K1
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
                  const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out);

@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "common.h"
@@ -111,6 +113,20 @@ struct smt_group {
     bool copies = false;
     std::vector<hipEvent_t> ev_ready;   // [n_local] rank j's send buffer is complete
     std::vector<hipEvent_t> ev_done;    // [n_local] rank i has finished reading everybody's send buffer
+    // copy-transport all-reduce (shared-centroid IVF builds run one host thread per local rank): a thread barrier
+    // and the ranks' buffer addresses
+    std::mutex ar_mu;
+    std::condition_variable ar_cv;
+    int ar_waiting = 0;
+    uint64_t ar_generation = 0;
+    std::vector<const long long *> ar_sums;
+    std::vector<const unsigned int *> ar_counts;
+};
+
+struct smt_sharded_ivfpq {
+    smt_sharded_corpus *corpus = nullptr;
+    std::vector<smt_ivfpq *> shard;     // [n_local]
+    int shared_centroids = 0;
 };
 
 struct smt_sharded_corpus {
@@ -270,6 +286,8 @@ static int group_make_contexts(smt_group *g, const int *devices, int n)
     g->ctx.assign(n, nullptr);
     g->comm.assign(n, nullptr);
     g->buf.assign(n, GroupBuf());
+    g->ar_sums.assign(n, nullptr);
+    g->ar_counts.assign(n, nullptr);
     for (int i = 0; i < n; ++i) {
         int rc = smt_ctx_create(devices[i], &g->ctx[i]);
         if (rc) return rc;
@@ -406,6 +424,83 @@ static int local_host_search(smt_sharded_corpus *sc, const float *queries, uint3
     }
     for (int i = 0; i < g->n_local; ++i)
         if (rcs[i]) { set_error("shard %d: %s", g->first_rank + i, errs[i].c_str()); return rcs[i]; }
+    return SMT_OK;
+}
+
+// ---------------------------------------------------------------- all-reduce for shared-centroid IVF builds
+__global__ void sum_ranks_i64_kernel(const long long *const *ptrs, int n_ranks, size_t n, long long *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long acc = 0;
+    for (int r = 0; r < n_ranks; ++r) acc += ptrs[r][i];
+    out[i] = acc;
+}
+__global__ void sum_ranks_u32_kernel(const unsigned int *const *ptrs, int n_ranks, size_t n, unsigned int *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned int acc = 0;
+    for (int r = 0; r < n_ranks; ++r) acc += ptrs[r][i];
+    out[i] = acc;
+}
+
+static void thread_barrier(smt_group *g)
+{
+    std::unique_lock<std::mutex> lk(g->ar_mu);
+    const uint64_t gen = g->ar_generation;
+    if (++g->ar_waiting == g->n_local) {
+        g->ar_waiting = 0;
+        ++g->ar_generation;
+        g->ar_cv.notify_all();
+    } else {
+        g->ar_cv.wait(lk, [&] { return g->ar_generation != gen; });
+    }
+}
+
+struct ShareCtx {
+    smt_group *g;
+    int local;
+};
+
+// IvfBuildShare::allreduce for one local rank (called from that rank's host thread)
+static int group_allreduce_sums(void *user, long long *sums, size_t n_sums, unsigned int *counts, size_t n_counts)
+{
+    ShareCtx *sc = static_cast<ShareCtx *>(user);
+    smt_group *g = sc->g;
+    const int i = sc->local;
+    smt_ctx *c = g->ctx[i];
+    if (!g->copies) {
+        SMT_NCCL_CHECK(g_rccl.AllReduce(sums, sums, n_sums, ncclInt64, ncclSum, g->comm[i], c->stream));
+        SMT_NCCL_CHECK(g_rccl.AllReduce(counts, counts, n_counts, ncclUint32, ncclSum, g->comm[i], c->stream));
+        return SMT_OK;
+    }
+    // copy transport: every rank lives in this process (one thread each): meet, sum everybody's buffer, meet, copy back
+    const size_t b_sums = ((n_sums * 8 + 255) & ~(size_t)255), b_cnt = ((n_counts * 4 + 255) & ~(size_t)255);
+    const size_t b_ptr = (((size_t)g->n_local * 16 + 255) & ~(size_t)255);
+    int rc = ensure_dev(g, i, b_sums + b_cnt + b_ptr + 64);
+    SMT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> lk(g->ar_mu);
+        g->ar_sums[i] = sums;
+        g->ar_counts[i] = counts;
+    }
+    thread_barrier(g);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(g->buf[i].dev);
+    long long *t_sums = reinterpret_cast<long long *>(base);
+    unsigned int *t_cnt = reinterpret_cast<unsigned int *>(base + b_sums);
+    const long long **d_ps = reinterpret_cast<const long long **>(base + b_sums + b_cnt);
+    const unsigned int **d_pc = reinterpret_cast<const unsigned int **>(base + b_sums + b_cnt + (size_t)g->n_local * 8);
+    SMT_HIP_CHECK(hipMemcpyAsync(d_ps, g->ar_sums.data(), (size_t)g->n_local * 8, hipMemcpyHostToDevice, c->stream));
+    SMT_HIP_CHECK(hipMemcpyAsync(d_pc, g->ar_counts.data(), (size_t)g->n_local * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(sum_ranks_i64_kernel, dim3((unsigned)((n_sums + 255) / 256)), dim3(256), 0, c->stream, d_ps, g->n_local, n_sums, t_sums);
+    hipLaunchKernelGGL(sum_ranks_u32_kernel, dim3((unsigned)((n_counts + 255) / 256)), dim3(256), 0, c->stream, d_pc, g->n_local, n_counts, t_cnt);
+    SMT_HIP_CHECK(hipGetLastError());
+    SMT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    thread_barrier(g);   // nobody overwrites its buffer before everybody has read it
+    SMT_HIP_CHECK(hipMemcpyAsync(sums, t_sums, n_sums * 8, hipMemcpyDeviceToDevice, c->stream));
+    SMT_HIP_CHECK(hipMemcpyAsync(counts, t_cnt, n_counts * 4, hipMemcpyDeviceToDevice, c->stream));
     return SMT_OK;
 }
 
@@ -892,6 +987,113 @@ int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *q
         if (rc) return rc;
     }
     return SMT_OK;
+}
+
+/* ------------------------------------------------------------ sharded IVF ---- */
+
+int smt_sharded_ivfpq_build(smt_sharded_corpus *sc, const smt_ivfpq_params *params, int shared_centroids, smt_sharded_ivfpq **out)
+{
+    SMT_REQUIRE(sc && params && out, "null argument");
+    *out = nullptr;
+    smt_group *g = sc->group;
+    for (int r = 0; r < g->n_ranks; ++r)  // checked on EVERY rank's size: a rank bailing out alone would leave the others in the all-reduce
+        SMT_REQUIRE(sc->rank_rows[r] >= params->nlist, "every shard needs at least nlist rows");
+    smt_sharded_ivfpq *six = new (std::nothrow) smt_sharded_ivfpq();
+    if (!six) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    six->corpus = sc;
+    six->shared_centroids = shared_centroids ? 1 : 0;
+    six->shard.assign(g->n_local, nullptr);
+    std::vector<int> rcs(g->n_local, SMT_OK);
+    std::vector<std::string> errs(g->n_local);
+    std::vector<ShareCtx> sctx(g->n_local);
+    // one host thread per local rank: the all-reduce inside the k-means loop needs every rank in it at once
+    auto work = [&](int i) {
+        IvfBuildShare share;
+        share.rank = (uint32_t)(g->first_rank + i);
+        share.n_ranks = (uint32_t)g->n_ranks;
+        share.allreduce = group_allreduce_sums;
+        sctx[i] = ShareCtx{g, i};
+        share.user = &sctx[i];
+        rcs[i] = ivfpq_build_shared(sc->shard[i], params, shared_centroids ? &share : nullptr, &six->shard[i]);
+        if (rcs[i]) errs[i] = smt_last_error();
+    };
+    if (g->n_local == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < g->n_local; ++i) th.emplace_back(work, i);
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < g->n_local; ++i)
+        if (rcs[i]) {
+            set_error("shard %d: %s", g->first_rank + i, errs[i].c_str());
+            const int rc = rcs[i];
+            smt_sharded_ivfpq_destroy(six);
+            return rc;
+        }
+    *out = six;
+    return SMT_OK;
+}
+
+void smt_sharded_ivfpq_destroy(smt_sharded_ivfpq *six)
+{
+    if (!six) return;
+    for (smt_ivfpq *ix : six->shard) smt_ivfpq_destroy(ix);
+    delete six;
+}
+
+smt_ivfpq *smt_sharded_ivfpq_shard(smt_sharded_ivfpq *six, int local_index)
+{
+    if (!six || local_index < 0 || local_index >= (int)six->shard.size()) return nullptr;
+    return six->shard[local_index];
+}
+
+int smt_sharded_ivfpq_search(smt_sharded_ivfpq *six, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
+                             uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
+{
+    SMT_REQUIRE(six != nullptr, "index");
+    SMT_REQUIRE(nq == 0 || (queries && out_rows && out_dist && out_counts), "null argument");
+    SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
+    smt_sharded_corpus *sc = six->corpus;
+    smt_group *g = sc->group;
+    SMT_REQUIRE((uint64_t)g->n_ranks * top_k <= 8192, "device merge handles up to 8192 candidates per query");
+    if (nq == 0) return SMT_OK;
+    const size_t list_words = (size_t)nq * 2 * top_k;
+    const size_t q_bytes = ((size_t)nq * SMT_DIM * 4 + 255) & ~(size_t)255;
+    const size_t loc_off = q_bytes, gath_off = loc_off + ((list_words * 8 + 255) & ~(size_t)255);
+    const size_t out_off = gath_off + (((size_t)g->n_ranks * list_words * 8 + 255) & ~(size_t)255);
+    int rc;
+    for (int i = 0; i < g->n_local; ++i) {
+        const int r = g->first_rank + i;
+        if ((rc = group_bind(g, i))) return rc;
+        if ((rc = ensure_dev(g, i, out_off + list_words * 8 + 64))) return rc;
+        char *base = reinterpret_cast<char *>(g->buf[i].dev);
+        SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
+        if ((rc = ivfpq_search_packed(six->shard[i], reinterpret_cast<const float *>(base), nq, top_k, nprobe, rerank, sc->rank_base[r],
+                                      reinterpret_cast<uint64_t *>(base + loc_off))))
+            return rc;
+    }
+    if ((rc = allgather_words(g, loc_off, gath_off, list_words))) return rc;
+    if ((rc = group_bind(g, 0))) return rc;
+    char *base0 = reinterpret_cast<char *>(g->buf[0].dev);
+    uint64_t *merged = reinterpret_cast<uint64_t *>(base0 + out_off);
+    if ((rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, reinterpret_cast<const uint64_t *>(base0 + gath_off),
+                                          (uint32_t)g->n_ranks, nq, top_k, top_k, merged, 0)))
+        return rc;
+    if ((rc = ensure_host(g, 0, list_words * 8))) return rc;
+    uint64_t *h = reinterpret_cast<uint64_t *>(g->buf[0].pinned);
+    SMT_HIP_CHECK(hipMemcpyAsync(h, merged, list_words * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    if ((rc = group_sync_all(g))) return rc;
+    std::vector<LocalHits> hits(nq);
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint64_t *rws = h + (size_t)q * 2 * top_k, *bits = rws + top_k;
+        for (uint32_t e = 0; e < top_k && rws[e] != UINT64_MAX; ++e) {
+            double d;
+            memcpy(&d, bits + e, 8);
+            hits[q].rows.push_back(rws[e]);
+            hits[q].dist.push_back(d);
+        }
+    }
+    return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
 }
 
 }  // extern "C"

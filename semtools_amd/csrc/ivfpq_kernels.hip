@@ -183,6 +183,19 @@ __global__ void ivf_finalize_kernel(const long long *sums, const unsigned int *c
     if (n) centroids[i] = (float)((double)sums[i] / FIXED_SCALE / (double)n);  // empty cluster keeps its centroid
 }
 
+// Shared-centroid builds (group.cpp): rank r seeds the lists l with l % n_ranks == r; every other list contributes
+// nothing, so the all-reduce of (sums, counts) followed by ivf_finalize_kernel gives every rank the same start.
+__global__ void ivf_seed_sums_kernel(const float *centroids, uint32_t nlist, uint32_t rank, uint32_t n_ranks, long long *sums,
+                                     unsigned int *counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlist * 256) return;
+    const uint32_t l = i >> 8;
+    const bool mine = l % n_ranks == rank;
+    sums[i] = mine ? __double2ll_rn((double)centroids[i] * FIXED_SCALE) : 0ll;
+    if ((i & 255) == 0) counts[l] = mine ? 1u : 0u;
+}
+
 __global__ void gather_rows_kernel(const float *rows, uint64_t n, uint64_t row_stride, float *out)
 {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -990,6 +1003,18 @@ void smt_ivfpq_destroy(smt_ivfpq *ix)
 
 int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq **out)
 {
+    return smt::ivfpq_build_shared(corpus, prm, nullptr, out);
+}
+
+}  // extern "C"
+
+// The build proper.  `share` (or nullptr) makes it one rank of a data-parallel build over a row-sharded corpus
+// (SURVEY 8e "C2"): after every accumulation of the coarse k-means -- on this rank's sample of ITS rows -- the
+// fixed-point centroid sums and the counts are summed over the ranks (share->allreduce, enqueued on the context's
+// stream: ncclAllReduce), so every rank finalises the SAME centroids and the lists mean the same thing on every
+// shard; rows are then assigned, sorted and encoded locally (per-list PCA bases are fitted to the rank's own rows).
+int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, const smt::IvfBuildShare *share, smt_ivfpq **out)
+{
     SMT_REQUIRE(corpus && prm && out, "null argument");
     *out = nullptr;
     smt_ctx *ctx = corpus->ctx;
@@ -1000,7 +1025,7 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     SMT_REQUIRE(prm->local_pca <= 1, "local_pca must be 0 or 1");
     const bool lpca = prm->local_pca == 1;
     SMT_REQUIRE(prm->nlist >= 32 && prm->nlist <= PROBE_MAX_LISTS && prm->nlist % 32 == 0, "nlist must be a multiple of 32 in [32, 4096]");
-    SMT_REQUIRE(N >= (uint64_t)prm->nlist && N < 0xFFFFFFFFull, "corpus needs at least nlist rows");
+    SMT_REQUIRE(N >= (uint64_t)prm->nlist && N < 0xFFFFFFFFull, "corpus (shard) needs at least nlist rows");
     const uint32_t nlist = prm->nlist;
     const uint32_t iters = prm->train_iters ? prm->train_iters : 10;
     uint64_t S = prm->train_sample ? prm->train_sample : (uint64_t)64 * nlist;
@@ -1037,12 +1062,21 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     if ((rc = dev_alloc(b_assign, (size_t)std::max(S, N) * 4))) return rc;
     if ((rc = dev_alloc(b_sums, (size_t)std::max<uint64_t>((uint64_t)nlist * 256, (uint64_t)PQ_M * PQ_K * PQ_DSUB) * 8))) return rc;
     if ((rc = dev_alloc(b_counts, (size_t)std::max<uint64_t>(nlist, (uint64_t)PQ_M * PQ_K) * 4))) return rc;
+    if (share) {  // the same starting centroids on every rank: each rank seeds the lists it owns (l % n_ranks == rank)
+        hipLaunchKernelGGL(ivf_seed_sums_kernel, dim3((nlist * 256 + 255) / 256), dim3(256), 0, ctx->stream, ix->d_centroids, nlist,
+                           share->rank, share->n_ranks, b_sums.as<long long>(), b_counts.as<unsigned int>());
+        if ((rc = share->allreduce(share->user, b_sums.as<long long>(), (size_t)nlist * 256, b_counts.as<unsigned int>(), nlist))) return rc;
+        hipLaunchKernelGGL(ivf_finalize_kernel, dim3((nlist * 256 + 255) / 256), dim3(256), 0, ctx->stream, b_sums.as<long long>(),
+                           b_counts.as<unsigned int>(), nlist, ix->d_centroids);
+    }
     for (uint32_t it = 0; it < iters; ++it) {
         if ((rc = run_assign(ctx, corpus->d_rows, S, stride, N, ix, b_assign.as<uint32_t>()))) return rc;
         IVF_HIP(hipMemsetAsync(b_sums.p, 0, (size_t)nlist * 256 * 8, ctx->stream));
         IVF_HIP(hipMemsetAsync(b_counts.p, 0, (size_t)nlist * 4, ctx->stream));
         hipLaunchKernelGGL(ivf_accumulate_kernel, dim3((unsigned)((S * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, S,
                            stride, b_assign.as<uint32_t>(), b_sums.as<long long>(), b_counts.as<unsigned int>());
+        if (share && (rc = share->allreduce(share->user, b_sums.as<long long>(), (size_t)nlist * 256, b_counts.as<unsigned int>(), nlist)))
+            return rc;
         hipLaunchKernelGGL(ivf_finalize_kernel, dim3((nlist * 256 + 255) / 256), dim3(256), 0, ctx->stream, b_sums.as<long long>(),
                            b_counts.as<unsigned int>(), nlist, ix->d_centroids);
     }
@@ -1137,6 +1171,8 @@ int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq *
     return SMT_OK;
 }
 
+extern "C" {
+
 int smt_ivfpq_info(const smt_ivfpq *ix, uint64_t *n_rows, uint32_t *nlist, uint64_t *index_bytes, double *build_ms4)
 {
     SMT_REQUIRE(ix != nullptr, "index");
@@ -1165,7 +1201,7 @@ int smt_ivfpq_list_sizes(const smt_ivfpq *ix, uint64_t *sizes_host)
 // buffers d_or [nq][top_k], d_od [nq][top_k], d_oc [nq] (d_oc may be null).
 static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_on_device, uint32_t nq, uint32_t top_k, uint32_t nprobe,
                              uint32_t rerank, uint64_t row_base, uint64_t *d_or_user, double *d_od_user, uint64_t *d_oc_user,
-                             uint64_t **d_or_out, size_t *out_bytes_contig)
+                             uint64_t **d_or_out, size_t *out_bytes_contig, uint64_t out_stride = 0)
 {
     smt_ctx *ctx = ix->corpus->ctx;
     SMT_REQUIRE(ix->corpus->rows >= ix->n_rows, "the corpus shrank after the index was built: rebuild");
@@ -1275,6 +1311,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     sel.out_rows = d_or;
     sel.out_dist = d_od;
     sel.out_counts = d_oc;
+    sel.out_stride = out_stride;
     rc = launch_select(ctx, sel);
     if (rc) return rc;
     if (d_or_out) *d_or_out = d_or;
@@ -1332,6 +1369,18 @@ int smt_ivfpq_search_device(smt_ivfpq *ix, const float *queries_dev, uint32_t nq
 }
 
 }  // extern "C"
+
+// one shard's answer in the packed exchange layout of group.cpp: [nq][2][top_k] words (global rows | f64 bits)
+int smt::ivfpq_search_packed(smt_ivfpq *ix, const float *queries_dev, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
+                             uint64_t row_base, uint64_t *packed_dev)
+{
+    SMT_REQUIRE(ix && queries_dev && packed_dev, "null argument");
+    smt_ctx *ctx = ix->corpus->ctx;
+    IVF_HIP(hipSetDevice(ctx->device));
+    { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
+    return ivfpq_search_core(ix, queries_dev, true, nq, top_k, nprobe, rerank, row_base, packed_dev,
+                             reinterpret_cast<double *>(packed_dev + top_k), nullptr, nullptr, nullptr, (uint64_t)2 * top_k);
+}
 
 // ---------------------------------------------------------------- persistence
 // File = 64-byte little-endian header + the six device arrays in a fixed order.  The index refers to

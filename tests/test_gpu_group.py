@@ -167,3 +167,42 @@ def test_adopted_device_shards_of_unequal_size(plain):
     for kw in (dict(top_k=6), dict(top_k=6, max_distance=0.92), dict(top_k=3, ranges=[(900, 1100)])):
         _same(sc.search(qs, **kw), c.search(qs, **kw))
     sc.close(); g.close()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_ivf_with_shared_centroids(gpu_ctx):
+    """SURVEY 8(e) "C2": data-parallel k-means -- every rank accumulates the centroid sums of ITS sample, the sums are
+    all-reduced, every rank finalises the same centroids.  With shared centroids a list means the same thing on every
+    shard (per-list sizes of two shards correlate); with independent builds it does not.  Both forms search through
+    the same all-gather + merge and return exact (row, distance) pairs."""
+    import semtools_amd as smt
+    from tests.test_gpu_ivfpq import clustered, recall
+
+    x, _ = clustered(90000, 400, seed=12)
+    qs, _ = clustered(48, 400, seed=12)
+    plain = smt.Corpus(gpu_ctx)
+    plain.append(x)
+    exact = plain.search(qs, top_k=10)
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, rows=x)
+    shared = smt.ShardedIvfPq(sc, nlist=128, train_iters=6, shared_centroids=True)
+    indep = smt.ShardedIvfPq(sc, nlist=128, train_iters=6, shared_centroids=False)
+    s0, s1 = shared.shard_list_sizes(0, 128).astype(float), shared.shard_list_sizes(1, 128).astype(float)
+    i0, i1 = indep.shard_list_sizes(0, 128).astype(float), indep.shard_list_sizes(1, 128).astype(float)
+    assert s0.sum() == 30000 and s1.sum() == 30000
+    assert np.corrcoef(s0, s1)[0, 1] > 0.9 > abs(np.corrcoef(i0, i1)[0, 1])
+    for ix in (shared, indep):
+        got = ix.search(qs, top_k=10, nprobe=16, rerank=128)
+        assert recall(got, exact) >= 0.97
+        for (rows, dist), q in zip(got, qs):
+            assert (np.diff(dist) >= 0).all() and len(set(rows.tolist())) == len(rows)
+            ref = 1.0 - x[rows.astype(np.int64)].astype(np.float64) @ q.astype(np.float64)
+            assert np.allclose(dist, ref, atol=1e-6)
+    # one RCCL rank: ncclAllReduce path of the same build
+    g1 = smt.Group([0])
+    sc1 = smt.ShardedCorpus(g1, rows=x)
+    one = smt.ShardedIvfPq(sc1, nlist=128, train_iters=6, shared_centroids=True)
+    assert recall(one.search(qs, top_k=10, nprobe=16, rerank=128), exact) >= 0.97
+    for o in (one, shared, indep):
+        o.close()
+    sc1.close(); g1.close(); sc.close(); g.close(); plain.close()
