@@ -80,6 +80,19 @@ int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json, 
 int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);
 
 void smt_host_free(char *text);
+
+/* A Hugging Face `tokenizer.json`, read natively (no Python): what model2vec-rs loads through the `tokenizers` crate
+ * (call sites src/cmds/search.rs:123-128; encode_batch_fast(.., add_special_tokens = false) inside encode_with_args).
+ * Supported components: BertNormalizer / Lowercase / NFD / StripAccents / Strip / Replace(String) / Sequence;
+ * BertPreTokenizer / WhitespaceSplit / Punctuation / Metaspace / Sequence; WordPiece, Unigram; added (special) tokens.
+ * Anything else fails at load time with a message naming the component.  smt_host_model_from_dir uses it when the model
+ * directory holds a tokenizer.json.  encode: ids of `text` (no special tokens added); SMT_E_TRUNCATED with the true
+ * count in *n_ids when cap is too small. */
+typedef struct smt_host_tokenizer smt_host_tokenizer;
+int smt_host_tokenizer_load(const char *tokenizer_json_path, smt_host_tokenizer **out);
+void smt_host_tokenizer_free(smt_host_tokenizer *tok);
+int smt_host_tokenizer_encode(smt_host_tokenizer *tok, const char *text, uint32_t *ids, uint64_t cap, uint64_t *n_ids);
+int smt_host_tokenizer_info(smt_host_tokenizer *tok, uint64_t *vocab_size, int64_t *unk_id, uint64_t *median_token_bytes);
 /* Wall-clock phases of this process so far as one JSON object (malloc'd): model_load, read_tokenize_embed_files,
  * embed_query, store_open_corpus_load, change_detection, embed_and_persist_changed_files, scan_select, ... -- what the
  * CLI prints to stderr under SEMTOOLS_TIMING=1. */

@@ -48,6 +48,8 @@ public:
 std::unique_ptr<Tokenizer> make_vocab_tokenizer(const std::string &vocab_path, const std::string &unk_token);
 // whitespace words hashed with FNV-1a into [0, vocab_size) -- for synthetic tests
 std::unique_ptr<Tokenizer> make_hash_tokenizer(uint64_t vocab_size);
+// a Hugging Face tokenizer.json, natively (hf_tokenizer.cpp): BertNormalizer / BertPreTokenizer / WordPiece, Metaspace / Unigram, ...
+std::unique_ptr<Tokenizer> make_hf_tokenizer(const std::string &tokenizer_json_path);
 // caller-provided function (e.g. a binding of the real HF tokenizer)
 using TokenizeFn = std::function<void(const std::string &, std::vector<uint32_t> &)>;
 std::unique_ptr<Tokenizer> make_callback_tokenizer(TokenizeFn fn, uint64_t vocab_size, std::optional<uint32_t> unk,

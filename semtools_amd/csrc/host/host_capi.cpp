@@ -154,6 +154,45 @@ int smt_host_model_create(smt_ctx *ctx, const float *table, uint64_t V, int norm
 
 char *smt_host_timing_json(void) { return dup_text(search::PhaseTimer::json()); }
 
+struct smt_host_tokenizer {
+    std::unique_ptr<Tokenizer> t;
+};
+
+int smt_host_tokenizer_load(const char *tokenizer_json_path, smt_host_tokenizer **out)
+{
+    if (!tokenizer_json_path || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    *out = nullptr;
+    try {
+        auto *h = new smt_host_tokenizer();
+        h->t = make_hf_tokenizer(tokenizer_json_path);
+        *out = h;
+        return SMT_OK;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
+void smt_host_tokenizer_free(smt_host_tokenizer *tok) { delete tok; }
+
+int smt_host_tokenizer_encode(smt_host_tokenizer *tok, const char *text, uint32_t *ids, uint64_t cap, uint64_t *n_ids)
+{
+    if (!tok || !text || !n_ids || (cap && !ids)) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    try {
+        std::vector<uint32_t> v;
+        tok->t->encode(text, v);
+        *n_ids = v.size();
+        for (uint64_t i = 0; i < std::min<uint64_t>(cap, v.size()); ++i) ids[i] = v[i];
+        return v.size() > cap ? SMT_E_TRUNCATED : SMT_OK;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
+int smt_host_tokenizer_info(smt_host_tokenizer *tok, uint64_t *vocab_size, int64_t *unk_id, uint64_t *median_token_bytes)
+{
+    if (!tok) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    if (vocab_size) *vocab_size = tok->t->vocab_size();
+    if (unk_id) *unk_id = tok->t->unk_id() ? (int64_t)*tok->t->unk_id() : -1;
+    if (median_token_bytes) *median_token_bytes = tok->t->median_token_length();
+    return SMT_OK;
+}
+
 int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
 {
     if (!ctx || !dir || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
@@ -172,7 +211,14 @@ int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
             if (auto *x = cfg.get("normalize")) normalize = x->b;
             if (auto *x = cfg.get("unk_token")) unk = x->s;
         } catch (const std::exception &) {}
-        auto tok = make_vocab_tokenizer(d + "/vocab.txt", unk);
+        // a real model2vec directory carries tokenizer.json (read natively: hf_tokenizer.cpp); the synthetic test
+        // models carry a plain vocab.txt
+        std::unique_ptr<Tokenizer> tok;
+        {
+            std::ifstream tj(d + "/tokenizer.json");
+            if (tj.good()) tok = make_hf_tokenizer(d + "/tokenizer.json");
+            else tok = make_vocab_tokenizer(d + "/vocab.txt", unk);
+        }
         if (tok->vocab_size() > V) throw Error("vocab.txt has more tokens than the embedding table has rows");
         auto *h = new smt_host_model();
         if (stream_f32) h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), d + "/model.safetensors", table_offset, V, normalize);

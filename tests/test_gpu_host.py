@@ -410,6 +410,16 @@ def test_real_hf_tokenizer_json_plugs_into_the_host_layer(gpu_ctx, tmp_path):
     out = host.search_files(m, corpus_lines[7], [str(f)], n_lines=0, top_k=1)
     assert out.startswith(f"{f}:7::8 (") and float(out.split("(")[1].split(")")[0]) < 1e-9
     m.close()
+    # the same directory WITHOUT Python in the loop: smt_host_model_from_dir reads tokenizer.json natively
+    # (hf_tokenizer.cpp; pinned against the `tokenizers` wheel by tests/test_tokenizer.py) and streams the table
+    m2 = host.StaticModel(gpu_ctx, model_dir=str(d))
+    assert np.array_equal(m2.encode_with_args(sents, 2048), want)
+    assert host.search_files(m2, corpus_lines[7], [str(f)], n_lines=0, top_k=1) == out
+    m2.close()
+    env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(d))
+    cli = subprocess.run([os.path.join(ROOT, "semtools_amd", "bin", "semtools"), "search", corpus_lines[7], str(f), "-n", "0", "--top-k", "1"],
+                         env=env, capture_output=True, text=True)
+    assert cli.returncode == 0 and cli.stdout == out, cli.stderr
 
 
 @pytest.mark.parametrize("dtype", ["float16", "int8"])

@@ -110,6 +110,13 @@ def main():
         tok.save(os.path.join(model_dir, "tokenizer.json"))
         from semtools_amd import hf
 
+        m3 = host.StaticModel(ctx, model_dir=model_dir)     # tokenizer.json present now: read NATIVELY by the C++ host
+        for rep in range(2):
+            t0 = time.perf_counter()
+            host.search_content(m3, pool[17], content, n_lines=0, top_k=3)
+            dt3 = time.perf_counter() - t0
+        pipe["tokenizer_json_native_wordpiece"] = dict(lines=args.ws_lines, seconds=round(dt3, 3), lines_per_s=round(args.ws_lines / dt3))
+        m3.close()
         m2 = hf.load_static_model(ctx, model_dir)
         n2 = min(args.ws_lines, 200_000)
         content2 = "\n".join(pool[i % len(pool)] for i in range(n2)) + "\n"
