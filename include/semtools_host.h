@@ -84,7 +84,7 @@ void smt_host_free(char *text);
 /* A Hugging Face `tokenizer.json`, read natively (no Python): what model2vec-rs loads through the `tokenizers` crate
  * (call sites src/cmds/search.rs:123-128; encode_batch_fast(.., add_special_tokens = false) inside encode_with_args).
  * Supported components: BertNormalizer / Lowercase / NFD / StripAccents / Strip / Replace(String) / Sequence;
- * BertPreTokenizer / WhitespaceSplit / Punctuation / Metaspace / Sequence; WordPiece, Unigram; added (special) tokens.
+ * BertPreTokenizer / Whitespace / WhitespaceSplit / Punctuation / Metaspace / Sequence; WordPiece, Unigram; added (special) tokens.
  * Anything else fails at load time with a message naming the component.  smt_host_model_from_dir uses it when the model
  * directory holds a tokenizer.json.  encode: ids of `text` (no special tokens added); SMT_E_TRUNCATED with the true
  * count in *n_ids when cap is too small. */

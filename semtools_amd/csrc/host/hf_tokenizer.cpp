@@ -6,7 +6,7 @@
 // src/cmds/search.rs:123-128,136,154).  That crate's algorithm is restated here for the component types model2vec
 // models are built from -- anything else fails loudly at load time:
 //   normalizers     BertNormalizer, Lowercase, NFD, StripAccents, Strip, Replace (string pattern), Sequence
-//   pre_tokenizers  BertPreTokenizer, WhitespaceSplit, Punctuation, Metaspace, Sequence
+//   pre_tokenizers  BertPreTokenizer, Whitespace, WhitespaceSplit, Punctuation, Metaspace, Sequence
 //   models          WordPiece (greedy longest match), Unigram (Viterbi, fused unknowns)
 //   added_tokens    matched on the raw text (special / normalized = false) before everything else
 // Pinned, not recalled: tests/test_tokenizer.py drives this file against the `tokenizers` Python wheel -- the same
@@ -55,6 +55,7 @@ bool is_punct_cat(uint32_t c)
 bool is_ascii_punct(uint32_t c) { return (c >= 0x21 && c <= 0x2F) || (c >= 0x3A && c <= 0x40) || (c >= 0x5B && c <= 0x60) || (c >= 0x7B && c <= 0x7E); }
 bool is_bert_punc(uint32_t c) { return is_ascii_punct(c) || is_punct_cat(c); }
 bool is_mn(uint32_t c) { return c >= 0x300 && SMT_IN(CAT_MN, c); }
+bool is_regex_word(uint32_t c) { return c < 0x80 ? (isalnum((int)c) != 0 || c == '_') : SMT_IN(REGEX_WORD, c); }
 bool is_chinese_char(uint32_t c)
 {
     return (c >= 0x4E00 && c <= 0x9FFF) || (c >= 0x3400 && c <= 0x4DBF) || (c >= 0x20000 && c <= 0x2A6DF) || (c >= 0x2A700 && c <= 0x2B73F) ||
@@ -166,7 +167,7 @@ struct Normalizer {
     std::vector<Normalizer> children;
 };
 struct PreTokenizer {
-    enum Kind { Bert, WsSplit, Punct, Metaspace, Seq } kind = Seq;
+    enum Kind { Bert, WsSplit, Whitespace, Punct, Metaspace, Seq } kind = Seq;
     uint32_t replacement = 0x2581;
     int prepend = 0;  // Metaspace: 0 always, 1 first, 2 never
     bool split = true;
@@ -227,6 +228,7 @@ PreTokenizer parse_pre(const json::Value &v)
     const std::string type = need(v, "type").s;
     if (type == "BertPreTokenizer") p.kind = PreTokenizer::Bert;
     else if (type == "WhitespaceSplit") p.kind = PreTokenizer::WsSplit;
+    else if (type == "Whitespace") p.kind = PreTokenizer::Whitespace;
     else if (type == "Punctuation") {
         p.kind = PreTokenizer::Punct;
         const json::Value *b = v.get("behavior");
@@ -244,7 +246,7 @@ PreTokenizer parse_pre(const json::Value &v)
         for (auto &c : need(v, "pretokenizers").arr) p.children.push_back(parse_pre(c));
     } else {
         throw Error("tokenizer.json: pre_tokenizer type '" + type + "' is not supported by the native tokenizer "
-                    "(supported: BertPreTokenizer, WhitespaceSplit, Punctuation, Metaspace, Sequence)");
+                    "(supported: BertPreTokenizer, Whitespace, WhitespaceSplit, Punctuation, Metaspace, Sequence)");
     }
     return p;
 }
@@ -336,6 +338,18 @@ void apply_pre(const PreTokenizer &p, std::vector<U32> &pieces, bool first_secti
                     const size_t b = i;
                     while (i < w.size() && !is_white_space(w[i])) ++i;
                     if (i > b) out.push_back(w.substr(b, i - b));
+                }
+            }
+            break;
+        case PreTokenizer::Whitespace:  // the regex \w+|[^\w\s]+ : runs of word characters, runs of everything else but white space
+            for (auto &w : pieces) {
+                size_t i = 0;
+                while (i < w.size()) {
+                    if (is_white_space(w[i])) { ++i; continue; }
+                    const bool word = is_regex_word(w[i]);
+                    const size_t b = i;
+                    while (i < w.size() && !is_white_space(w[i]) && is_regex_word(w[i]) == word) ++i;
+                    out.push_back(w.substr(b, i - b));
                 }
             }
             break;

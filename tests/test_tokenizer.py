@@ -89,6 +89,14 @@ def test_wordpiece_sequence_components(tmp_path):
     check(tok, tmp_path / "tokenizer.json", seed=2)
 
 
+def test_wordpiece_whitespace_regex_pretokenizer(tmp_path):
+    tok = Tokenizer(models.WordPiece(unk_token="[UNK]"))
+    tok.normalizer = normalizers.Lowercase()
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()          # \\w+|[^\\w\\s]+
+    tok.train_from_iterator(CORPUS, trainers.WordPieceTrainer(vocab_size=300, special_tokens=["[UNK]"]))
+    check(tok, tmp_path / "tokenizer.json", seed=4)
+
+
 @pytest.mark.parametrize("prepend", ["always", "first", "never"])
 def test_unigram_metaspace_pipeline(tmp_path, prepend):
     tok = Tokenizer(models.Unigram())
