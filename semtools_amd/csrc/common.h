@@ -63,6 +63,7 @@ struct Tuning {
     int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel (superseded)
+    int embed_wave_per_line = 0; // K1: 1 = one wave per line (whole-row gathers), 0 = 16 lanes per line (4 lines per wave)
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
     int gemm_ldsrow = 1;        // 1: batches <= 128 queries and range-filtered batches use the LDS-row kernel (64 queries per pass)
     int prof_select = 1;        // 0: do not bracket the select stage with events (2 fewer event records per query)

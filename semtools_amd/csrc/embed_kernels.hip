@@ -139,6 +139,60 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
     }
 }
 
+// ---- variant B: ONE WAVE PER LINE.  Lane l owns dims 4l .. 4l+3, so every gather instruction reads one whole table
+// row -- 1 KiB contiguous, K2-style -- instead of four 256-B pieces of four different rows; 8 tokens in flight.  The
+// per-dimension sums are the same serial f32 chains in token order; the norm's dimension-order chain walks the 64
+// lanes with DPP wave_shr:1 (after step k lane k holds the chain through its own 4 dims), which costs the wave 64 x 5
+// instructions for ONE line where variant A pays them for four -- the price of the coalesced gather.
+constexpr int DPP_WAVE_SHR1_E = 0x138;
+__global__ void __launch_bounds__(256) embed_wave_kernel(EmbedParams p)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const uint64_t line = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
+    if (line >= p.n_lines) return;
+    const uint64_t t0 = p.offsets[line];
+    uint64_t n_tok = p.offsets[line + 1] - t0;
+    if (p.max_tokens != 0 && n_tok > (uint64_t)p.max_tokens) n_tok = p.max_tokens;
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int TU = 8;
+    for (uint64_t t = 0; t < n_tok; t += TU) {
+        float4 r[TU];
+        bool ok[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const bool on = (t + u) < n_tok;                       // wave-uniform
+            const uint64_t id = on ? (uint64_t)p.ids[t0 + t + u] : 0;
+            ok[u] = on && id < p.V;                                // out-of-vocab ids contribute nothing
+            r[u] = reinterpret_cast<const float4 *>(p.table + (ok[u] ? id : 0) * 256)[lane];
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            if ((t + u) < n_tok) {                                 // token order: u ascending; an invalid id adds +0
+                const float4 v = ok[u] ? r[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+            }
+        }
+    }
+    const float cnt = (float)(n_tok > 0 ? n_tok : 1);
+    acc.x = acc.x / cnt; acc.y = acc.y / cnt; acc.z = acc.z / cnt; acc.w = acc.w / cnt;
+    if (p.normalize) {
+        const float s0 = acc.x * acc.x, s1 = acc.y * acc.y, s2 = acc.z * acc.z, s3 = acc.w * acc.w;
+        float s = 0.0f;
+#pragma unroll 16
+        for (int step = 0; step < 64; ++step) {
+            const float in = step == 0 ? 0.0f : dppf<DPP_WAVE_SHR1_E>(s);   // lane l takes lane l-1's running sum
+            s = (((in + s0) + s1) + s2) + s3;
+        }
+        const float ss = __shfl(s, 63);
+        float norm = sqrtf(ss);
+        if (!(norm > 1e-12f)) norm = 1e-12f;
+        acc.x = acc.x / norm; acc.y = acc.y / norm; acc.z = acc.z / norm; acc.w = acc.w / norm;
+    }
+    reinterpret_cast<float4 *>(p.out + line * 256)[lane] = acc;
+}
+
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
                  const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out)
 {
@@ -152,8 +206,17 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     p.max_tokens = max_tokens;
     p.normalize = normalize;
     p.out = out;
-    const int threads = 256;                       // 4 waves = 16 lines per block
-    const uint64_t waves = (n_lines + 3) / 4;
+    const int threads = 256;
+    if (ctx->tune.embed_wave_per_line) {           // 4 waves = 4 lines per block
+        const uint64_t blocks = (n_lines + 3) / 4;
+        SMT_REQUIRE(blocks < (1ull << 31), "too many lines for one embed launch");
+        prof_begin(ctx, "embed");
+        hipLaunchKernelGGL(embed_wave_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, p);
+        prof_end(ctx, "embed");
+        SMT_HIP_CHECK(hipGetLastError());
+        return SMT_OK;
+    }
+    const uint64_t waves = (n_lines + 3) / 4;      // 4 waves = 16 lines per block
     const uint64_t blocks = (waves + 3) / 4;
     SMT_REQUIRE(blocks < (1ull << 31), "too many lines for one embed launch");
     prof_begin(ctx, "embed");

@@ -9,14 +9,17 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def model(gpu_ctx):
+@pytest.fixture(scope="module", params=[0, 1], ids=["16-lanes-per-line", "wave-per-line"])
+def model(gpu_ctx, request):
+    """Both K1 variants (tuning key embed_wave_per_line) must be bit-exact."""
     import semtools_amd as smt
 
     table = synth.table(5000, seed=2)
+    gpu_ctx.set_tuning("embed_wave_per_line", request.param)
     m = smt.Model(gpu_ctx, table, normalize=True)
     yield table, m
     m.close()
+    gpu_ctx.set_tuning("embed_wave_per_line", 0)
 
 
 def test_embed_bit_exact(model):

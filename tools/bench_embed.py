@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--max-tok", type=int, default=32)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--uniform", action="store_true", help="uniform token ids (no hot rows: every gather goes to HBM)")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for smt_set_tuning (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     table = torch.randn(args.vocab, 256, device=dev) * 0.1
@@ -32,6 +33,9 @@ def main():
     out = torch.empty(args.lines, 256, device=dev)
     ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     model = smt.Model(ctx, device_ptr=table.data_ptr(), V=args.vocab, normalize=True)
+    for kv in args.tune:
+        key, val = kv.split("=")
+        ctx.set_tuning(key, int(val))
     ctx.prof_enable(True)
     model.embed_device(d_ids.data_ptr(), d_off.data_ptr(), args.lines, 2048, out.data_ptr())
     ctx.synchronize()
@@ -50,7 +54,7 @@ def main():
     ref = table[torch.from_numpy(ids[int(offsets[i]):int(offsets[i + 1])].astype(np.int64)).to(dev)].sum(0)
     ref = ref / max(int(offsets[i + 1] - offsets[i]), 1)
     ref = ref / ref.norm().clamp_min(1e-12)
-    print(json.dumps(dict(lines=args.lines, tokens=T, vocab=args.vocab, uniform_ids=bool(args.uniform), kernel_ms=round(ker * 1e3, 3),
+    print(json.dumps(dict(tune=args.tune, lines=args.lines, tokens=T, vocab=args.vocab, uniform_ids=bool(args.uniform), kernel_ms=round(ker * 1e3, 3),
                           wall_ms=round(wall * 1e3, 3), lines_per_s=round(args.lines / ker / 1e6, 1),
                           tokens_per_s_G=round(T / ker / 1e9, 2), gather_GBps=round(alg_bytes / ker / 1e9, 1),
                           frac_of_8TBps=round(alg_bytes / ker / 8e12, 3),
