@@ -344,6 +344,13 @@ int smt_sharded_ivfpq_search(smt_sharded_ivfpq *index, const float *queries, uin
  * synchronises), they count such queries here.  reset != 0 clears the counter. */
 int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset);
 
+/* Test hook for the certificate's error bound: the f32 distances the batched kernels NOMINATE candidates with
+ * (f32 MFMA, or bf16 x 3 split products when tuning key gemm_bf16x3 is set -- the default), for nq <= 32 host
+ * queries against rows [first_row, first_row + n_rows) of the corpus; out is a host buffer [n_rows][32].
+ * These values never reach an answer: results carry exact (f64) distances. */
+int smt_debug_batched_scores(smt_corpus *corpus, const float *queries, uint32_t nq, uint64_t first_row, uint32_t n_rows,
+                             float *out);
+
 /* The context's second stream (hipStream_t), created on first use: async selects run on it.  A host that
  * chains more work behind an async select (an RCCL all-gather of its output, the merge of the gathered
  * lists with tuning key merge_on_aux) enqueues it here so that the main stream carries nothing but scans. */
@@ -351,7 +358,9 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
 
 /* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
  *   scan_blocks, scan_threads, scan_unroll (2/4/8/16), scan_nontemporal   K2 launch shape
- *   gemm_blocks, gemm_resident, gemm_qsplit                               K3
+ *   gemm_blocks, gemm_resident, gemm_qsplit, gemm_ldsrow, gemm_dma_nt      K3
+ *   gemm_bf16x3 (1/0)    K3 nominates with bf16 x 3 split products on the bf16 MFMA pipe (default) or with f32 MFMAs;
+ *                        answers are identical either way (exact re-scoring + the exactness certificate)
  *   prof_select (0/1), prof_every (N: HIP events on one launch in N)       profiling cost control
  *   scan_debug_ptr, select_debug_ptr                                       device pointers for phase stamps
  *   async_select (0/1)   smt_search_topk_device with ONE query: the select stage of call i runs on an

@@ -315,6 +315,14 @@ extern "C" {
         out_cap: u64,
     ) -> c_int;
     pub fn smt_ctx_uncertain_count(ctx: *mut SmtCtx, count: *mut u64, reset: c_int) -> c_int;
+    pub fn smt_debug_batched_scores(
+        corpus: *mut SmtCorpus,
+        queries: *const f32,
+        nq: u32,
+        first_row: u64,
+        n_rows: u32,
+        out: *mut f32,
+    ) -> c_int;
     pub fn smt_ctx_aux_stream(ctx: *mut SmtCtx, stream_out: *mut *mut c_void) -> c_int;
     pub fn smt_set_tuning(ctx: *mut SmtCtx, key: *const c_char, value: i64) -> c_int;
     pub fn smt_fnv1a_hash(bytes: *const u8, n: u64) -> u64;

@@ -26,7 +26,7 @@ EXPORTS = [
     "smt_corpus_save", "smt_corpus_load", "smt_corpus_append_to_file", "smt_search", "smt_search_topk_device", "smt_merge_topk",
     "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_search_device", "smt_ivfpq_info", "smt_ivfpq_list_sizes", "smt_ivfpq_save", "smt_ivfpq_load", "smt_ivfpq_append",
     "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
-    "smt_ctx_uncertain_count",
+    "smt_ctx_uncertain_count", "smt_debug_batched_scores",
     "smt_init", "smt_shutdown", "smt_default_group", "smt_group_create", "smt_group_create_logical", "smt_group_unique_id", "smt_group_create_rank",
     "smt_group_destroy", "smt_group_info", "smt_group_ctx", "smt_group_synchronize", "smt_group_barrier",
     "smt_sharded_corpus_from_host", "smt_sharded_corpus_from_device", "smt_sharded_corpus_load", "smt_sharded_corpus_save",
@@ -152,6 +152,7 @@ def lib():
     L.smt_doc_meta_id.argtypes = [C.c_char_p]
     L.smt_doc_meta_id.restype = u64
     L.smt_ctx_uncertain_count.argtypes = [vp, P(u64), i32]
+    L.smt_debug_batched_scores.argtypes = [vp, vp, C.c_uint32, u64, C.c_uint32, vp]
     # ---- groups of GPUs
     L.smt_init.argtypes = [P(i32), i32]
     L.smt_shutdown.argtypes = []

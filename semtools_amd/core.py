@@ -190,6 +190,15 @@ class Corpus:
     def truncate(self, n_rows):
         L.check(L.lib().smt_corpus_truncate(self._h, int(n_rows)))
 
+    def debug_batched_scores(self, queries, first_row=0, n_rows=None):
+        """Test hook (smt_debug_batched_scores): the f32 distances the batched kernels nominate candidates with,
+        float32 [n_rows, nq]."""
+        q = _f32c(queries).reshape(-1, L.DIM)
+        n_rows = self.rows - first_row if n_rows is None else int(n_rows)
+        out = np.empty((n_rows, 32), dtype=np.float32)
+        L.check(L.lib().smt_debug_batched_scores(self._h, L.np_ptr(q), q.shape[0], int(first_row), n_rows, L.np_ptr(out)))
+        return out[:, :q.shape[0]].copy()
+
     def search(self, queries, top_k=3, max_distance=None, mode=L.MODE_DOCUMENTS, ranges=None, row_base=0,
                out_cap=None):
         """Returns a list (one per query) of (rows uint64[n], dist float64[n]).

@@ -314,6 +314,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
     else if (k == "gemm_resident") ctx->tune.gemm_resident = (int)value;
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
+    else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
     else if (k == "gemm_dma_nt") ctx->tune.gemm_dma_nt = (int)value;
     else if (k == "embed_wave_per_line") ctx->tune.embed_wave_per_line = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
@@ -1232,6 +1233,25 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
     rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
     if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
     return rc;
+}
+
+int smt_debug_batched_scores(smt_corpus *corpus, const float *queries, uint32_t nq, uint64_t first_row, uint32_t n_rows,
+                             float *out)
+{
+    SMT_REQUIRE(corpus && queries && out, "null argument");
+    SMT_REQUIRE(first_row + n_rows <= corpus->rows, "row range outside the corpus");
+    smt_ctx *ctx = corpus->ctx;
+    int rc = bind_device(ctx, true);
+    if (rc) return rc;
+    const size_t b_q = (size_t)nq * 256 * 4, b_out = (size_t)n_rows * 32 * 4;
+    if ((rc = ensure_scratch(ctx, b_q + b_out + 256))) return rc;
+    float *d_q = reinterpret_cast<float *>(ctx->d_scratch);
+    float *d_out = reinterpret_cast<float *>(reinterpret_cast<char *>(ctx->d_scratch) + ((b_q + 255) & ~(size_t)255));
+    SMT_HIP_CHECK(hipMemcpyAsync(d_q, queries, b_q, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_gemm_debug_scores(ctx, corpus->d_rows, first_row, n_rows, d_q, nq, d_out))) return rc;
+    SMT_HIP_CHECK(hipMemcpyAsync(out, d_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMT_OK;
 }
 
 int smt_merge_topk(const uint64_t *rows, const double *dist, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,

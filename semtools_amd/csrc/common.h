@@ -65,6 +65,7 @@ struct Tuning {
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel (superseded)
     int embed_wave_per_line = 0; // K1: 1 = one wave per line (whole-row gathers), 0 = 16 lanes per line (4 lines per wave)
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
+    int gemm_bf16x3 = 1;        // 1: K3 nominates candidates with bf16 x 3 split products on the bf16 MFMA pipe (mfma_tile.h); 0: f32 MFMA
     int gemm_ldsrow = 1;        // 1: batches <= 128 queries and range-filtered batches use the LDS-row kernel (64 queries per pass)
     int prof_select = 1;        // 0: do not bracket the select stage with events (2 fewer event records per query)
     int64_t scan_debug_ptr = 0;    // device pointer to (2*waves + blocks) u64 wall_clock64 stamps (profiling only)
@@ -220,6 +221,8 @@ int launch_select(smt_ctx *ctx, const SelectArgs &s);
 // accumulates 256 products sequentially: <= 256 * 2^-24 = 1.5e-5 in the worst case.
 constexpr double F32_ERR_SCAN = 4e-6;
 constexpr double F32_ERR_MFMA = 2e-5;
+// bf16 x 3 split products (mfma_tile.h): 3 * 2^-18 representation + 768 f32 accumulations, doubled
+constexpr double F32_ERR_BF16X3 = 1.2e-4;
 // K2/K3 keep k + 8 <= 64 candidates per list: top_k above this goes to the all-keys path (largek.hip)
 constexpr uint32_t SCAN_MAX_K = 56;
 
@@ -277,5 +280,8 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
 
 // K3: batched queries, f32 MFMA with fused candidate selection.
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);
+// test hook: the nominating f32 distances of the K3 kernels for <= 32 queries (gemm_kernels.hip)
+int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_row, uint32_t n_rows, const float *queries,
+                             uint32_t nq, float *out);
 
 }  // namespace smt

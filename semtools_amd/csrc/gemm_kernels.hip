@@ -57,6 +57,7 @@ struct GemmParams {
     const float *corpus;
     uint64_t n_rows;
     const float *queries;     // [nq][256]
+    const uint32_t *queries_split;  // BF16 kernels: [nqt*32][256] words, the split image written by split_queries_kernel
     uint32_t nq;
     uint32_t nqt;             // ceil(nq / 32)
     uint64_t level_tiles;     // tiles visited by this launch
@@ -96,6 +97,24 @@ __device__ __forceinline__ float score_threshold(float tau, float rq)
     return t - fabsf(t) * 2.4e-7f;
 }
 
+// Split image of the queries for the bf16 x 3 kernels: one 1 KiB row per query (zero rows pad the last tile);
+// K-step m, half h occupy bytes (2m + h) * 32 ..: 16 B of hi (dims 16m + 8h .. + 7 as bf16 pairs) then 16 B of lo --
+// exactly the two B-operand quads lane (j, h) feeds to K-step m, so a staged row is read with two ds_read_b128.
+__global__ void split_queries_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out)
+{
+    const uint32_t q = blockIdx.x * 2 + (threadIdx.x >> 7), pr = threadIdx.x & 127;  // pair pr = dims 2pr, 2pr + 1
+    if (q >= nq_pad) return;
+    uint32_t hi = 0, lo = 0;
+    if (q < nq) {
+        const f32x2 v = reinterpret_cast<const f32x2 *>(queries + (size_t)q * 256)[pr];
+        bf16_split2(v.x, v.y, hi, lo);
+    }
+    uint32_t *row = out + (size_t)q * 256 + (pr >> 2) * 8 + (pr & 3);
+    row[0] = hi;
+    row[4] = lo;
+}
+
+template <bool BF16>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -140,7 +159,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             const uint32_t q = qt * QT_ROWS + r;
             f32x4 *dst = s_q + slot * QT_F4 + r * QT_STRIDE_F4;
             if (q < p.nq) {
-                __builtin_amdgcn_global_load_lds(p.queries + (size_t)q * 256 + lane * 4,
+                const float *src = BF16 ? reinterpret_cast<const float *>(p.queries_split) : p.queries;  // same row size
+                __builtin_amdgcn_global_load_lds(src + (size_t)q * 256 + lane * 4,
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             } else {
                 dst[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};  // padding rows of the last tile
@@ -165,30 +185,54 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
         const bool has = it < p.level_tiles;  // wave-uniform
         const uint64_t row0 = (has ? level_tile(it, p.stride, p.skip16) : 0) * 32;
 
-        // ---- A operand: this wave's 32 corpus rows, register resident
-        f32x4 A[32];
+        // ---- A operand: this wave's 32 corpus rows, register resident (f32: 128 VGPRs; bf16 x 3: 64 hi + 64 lo)
+        f32x4 A[BF16 ? 1 : 32];
+        u32x4 Ah[BF16 ? 16 : 1], Al[BF16 ? 16 : 1];
         unsigned zero16 = 0;   // bit r: tile row acc_row(r, h) is the zero vector
         unsigned valid16 = 0;  // bit r: that row exists
         if (has) {
             const uint64_t my_row = row0 + j;
             const bool row_ok = my_row < p.n_rows;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (row_ok ? my_row : 0) * 256) + h;
             float part = 0.0f;
+            float rb;
+            if constexpr (!BF16) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (row_ok ? my_row : 0) * 256) + h;
 #pragma unroll
-            for (int m = 0; m < 32; ++m) {
-                A[m] = __builtin_nontemporal_load(src + 2 * m);  // unconditional (address clamped above): 32 loads in flight
+                for (int m = 0; m < 32; ++m) {
+                    A[m] = __builtin_nontemporal_load(src + 2 * m);  // unconditional (address clamped above): 32 loads in flight
+                }
+                if (!row_ok) {  // rows past the end of the corpus contribute zeros (one test, not one branch per load)
+#pragma unroll
+                    for (int m = 0; m < 32; ++m) A[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int m = 0; m < 32; ++m)
+                    part += A[m].x * A[m].x + A[m].y * A[m].y + A[m].z * A[m].z + A[m].w * A[m].w;
+                const float b2 = part + __shfl_xor(part, 32);
+                rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);  // row l&31, same in both halves
+#pragma unroll
+                for (int m = 0; m < 32; ++m) A[m] *= rb;  // unit rows: the accumulators are cosines times |q|
+            } else {
+                // lane (j, h): dims 16m + 8h .. + 7 of K-step m = float4 4m + 2h and the next one (32 contiguous bytes)
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (row_ok ? my_row : 0) * 256) + 2 * h;
+                f32x4 R[32];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    R[2 * m] = __builtin_nontemporal_load(src + 4 * m);
+                    R[2 * m + 1] = __builtin_nontemporal_load(src + 4 * m + 1);
+                }
+                if (!row_ok) {
+#pragma unroll
+                    for (int m = 0; m < 32; ++m) R[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int m = 0; m < 32; ++m)
+                    part += R[m].x * R[m].x + R[m].y * R[m].y + R[m].z * R[m].z + R[m].w * R[m].w;
+                const float b2 = part + __shfl_xor(part, 32);
+                rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) bf16_split8(R[2 * m] * rb, R[2 * m + 1] * rb, Ah[m], Al[m]);  // unit rows, split once per tile
             }
-            if (!row_ok) {  // rows past the end of the corpus contribute zeros (one test, not one branch per load)
-#pragma unroll
-                for (int m = 0; m < 32; ++m) A[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int m = 0; m < 32; ++m)
-                part += A[m].x * A[m].x + A[m].y * A[m].y + A[m].z * A[m].z + A[m].w * A[m].w;
-            const float b2 = part + __shfl_xor(part, 32);
-            const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);  // row l&31, same in both halves
-#pragma unroll
-            for (int m = 0; m < 32; ++m) A[m] *= rb;  // unit rows: the accumulators are cosines times |q|
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;  // accumulator reg r <-> tile row i
@@ -202,21 +246,26 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const f32x4 *bq = s_q + slot * QT_F4 + j * QT_STRIDE_F4 + h;
             // lane owns query q = qt*32 + j: its threshold and 1/|q| are fetched now, under the MFMAs
             const uint32_t q = qt * QT_ROWS + j;
             const float thr_q = s_tau[q], rq_q = s_rq[q];
+            if constexpr (!BF16) {
+                const f32x4 *bq = s_q + slot * QT_F4 + j * QT_STRIDE_F4 + h;
 #pragma unroll
-            for (int m = 0; m < 32; ++m) {
-                const f32x4 b = bq[2 * m];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, b.w, acc, 0, 0, 0);
+                for (int m = 0; m < 32; ++m) {
+                    const f32x4 b = bq[2 * m];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, b.w, acc, 0, 0, 0);
+                }
+            } else {
+                const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) acc = mfma_bf16x3(Ah[m], Al[m], bq[4 * m], bq[4 * m + 1], acc);
             }
             append_candidates(acc, zero16, valid16, q, thr_q, rq_q, row0, h, p.cand, p.counts);  // 16 rows x this lane's query
         };
-
         if (resident) {
             if (has)
                 for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t);
@@ -420,7 +469,10 @@ __device__ __forceinline__ void lr_fill_slice(const float *corpus, const uint32_
 }
 
 // AUX: cache-policy bits of the row DMA (0 = default, 2 = nt: the corpus is streamed once)
-template <int NQT, bool FILTERED, int AUX>
+// BF16: bf16 x 3 split products (mfma_tile.h).  The rows still arrive as f32 (LDS-DMA moves bytes); a wave splits the
+// fragments it reads (2.5 VALU instructions per element, next to 3 MFMAs of 32 cycles per 8 elements instead of 8 MFMAs
+// of 64) -- the MFMA pipe drops from 55 % busy to 10 % at 32 queries and the kernel is purely a question of row arrival.
+template <int NQT, bool FILTERED, int AUX, bool BF16>
 __global__ void __launch_bounds__(LR_THREADS) gemm_ldsrow_kernel(GemmParams p)
 {
     using G = LrGeom<NQT>;
@@ -433,19 +485,26 @@ __global__ void __launch_bounds__(LR_THREADS) gemm_ldsrow_kernel(GemmParams p)
     float *scale = reinterpret_cast<float *>(smem_raw + G::SCRATCH_OFF + wave * 128);
 
     // fragment geometry: lane (j, h) reads chunk 2m'+h of row j, stored at position chunk ^ (j & 7)
+    // (BF16: K-step m'' of the slice takes chunks 4m'' + 2h and + 1: fragments 2m'', 2m'' + 1)
     uint32_t foff[8];  // byte offset of fragment m' inside a slice
 #pragma unroll
-    for (int mp = 0; mp < 8; ++mp) foff[mp] = (uint32_t)(j * 256 + (((2 * mp + h) ^ (j & 7)) << 4));
+    for (int mp = 0; mp < 8; ++mp) {
+        const int chunk = BF16 ? 4 * (mp >> 1) + 2 * h + (mp & 1) : 2 * mp + h;
+        foff[mp] = (uint32_t)(j * 256 + ((chunk ^ (j & 7)) << 4));
+    }
 
     // ---- B operand: this lane's query of every tile, K-permuted like the A fragments (dims 8m+4h .. +3 in group m)
-    f32x4 Bq[B_REGS ? 32 : 1];
+    f32x4 Bq[B_REGS && !BF16 ? 32 : 1];
+    u32x4 Bh[B_REGS && BF16 ? 16 : 1], Bl[B_REGS && BF16 ? 16 : 1];
     float thr[NQT], rq[NQT];
     if constexpr (!B_REGS) {
         // queries -> LDS by LDS-DMA, one 1 KiB row per instruction, chunk c of row r at position c ^ (r & 7)
+        // (BF16: the rows of the split image, see split_queries_kernel)
+        const float *qsrc = BF16 ? reinterpret_cast<const float *>(p.queries_split) : p.queries;
         for (int r = wave; r < NQT * QT_ROWS; r += LR_WAVES) {  // wave-uniform
             unsigned char *dst = smem_raw + r * 1024;
             if ((uint32_t)r < p.nq)
-                __builtin_amdgcn_global_load_lds(p.queries + (size_t)r * 256 + ((lane ^ (r & 7)) << 2),
+                __builtin_amdgcn_global_load_lds(qsrc + (size_t)r * 256 + ((lane ^ (r & 7)) << 2),
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             else
                 reinterpret_cast<f32x4 *>(dst)[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -458,7 +517,18 @@ __global__ void __launch_bounds__(LR_THREADS) gemm_ldsrow_kernel(GemmParams p)
         const uint32_t q = t * QT_ROWS + j;
         const bool ok = q < p.nq;
         float part = 0.0f;
-        if constexpr (B_REGS) {
+        if constexpr (BF16) {
+            // the norm always comes from the f32 query; with B in registers the lane also splits its operand quads
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.queries + (size_t)(ok ? q : 0) * 256) + 2 * h;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                f32x4 v0 = src[4 * m], v1 = src[4 * m + 1];
+                if (!ok) v0 = v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                part += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+                part += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+                if constexpr (B_REGS) bf16_split8(v0, v1, Bh[m], Bl[m]);
+            }
+        } else if constexpr (B_REGS) {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(p.queries + (size_t)(ok ? q : 0) * 256) + h;
 #pragma unroll
             for (int m = 0; m < 32; ++m) {
@@ -567,6 +637,30 @@ __global__ void __launch_bounds__(LR_THREADS) gemm_ldsrow_kernel(GemmParams p)
             constexpr int next_slot = G::SLOTS == 2 ? ((s + 1) & 1) : 0;
             wait_lgkm0();                              // the ds_reads of `fr` have returned: its slot is free
             fill(ahead_tile, SAHEAD, slot);
+            if constexpr (BF16) {
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) {       // K-step 4s + mq
+                    const f32x4 a0 = fr[2 * mq], a1 = fr[2 * mq + 1];
+                    part += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
+                    part += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
+                    u32x4 ah, al;
+                    bf16_split8(a0, a1, ah, al);
+#pragma unroll
+                    for (int t = 0; t < NQT; ++t) {
+                        u32x4 bh, bl;
+                        if constexpr (B_REGS) {
+                            bh = Bh[4 * s + mq];
+                            bl = Bl[4 * s + mq];
+                        } else {
+                            const unsigned char *qrow = smem_raw + t * LR_QTILE_BYTES + j * 1024;
+                            const int c = 2 * (2 * (4 * s + mq) + h);  // chunk of the hi quad; lo is the next one
+                            bh = *reinterpret_cast<const u32x4 *>(qrow + ((c ^ (j & 7)) << 4));
+                            bl = *reinterpret_cast<const u32x4 *>(qrow + (((c + 1) ^ (j & 7)) << 4));
+                        }
+                        acc[t] = mfma_bf16x3(ah, al, bh, bl, acc[t]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int mp = 0; mp < 8; ++mp) {
                 const f32x4 a = fr[mp];
@@ -703,6 +797,106 @@ __global__ void fill_f32_kernel(float *p, float v, uint32_t n)
     if (i < n) p[i] = v;
 }
 
+// ---- test hook: the NOMINATING distances themselves (never part of an answer).  One wave per 32-row tile against one
+// tile of <= 32 queries, the same operand preparation and MFMA sequence as gemm_level_kernel; out[row][32] = the f32
+// distance the candidate test sees.  tests/test_gpu_batched.py measures |out - exact| against F32_ERR_MFMA / _BF16X3.
+template <bool BF16>
+__global__ void __launch_bounds__(64) gemm_debug_scores_kernel(const float *corpus, uint64_t first_row, uint32_t n_rows,
+                                                               const float *queries, uint32_t nq, float *out)
+{
+    const int lane = threadIdx.x, h = lane >> 5, j = lane & 31;
+    const uint64_t row = first_row + (uint64_t)blockIdx.x * 32 + j;
+    const bool row_ok = (uint64_t)blockIdx.x * 32 + j < n_rows;
+    const f32x4 *rsrc = reinterpret_cast<const f32x4 *>(corpus + (row_ok ? row : first_row) * 256);
+    const f32x4 *qsrc = reinterpret_cast<const f32x4 *>(queries + (size_t)((uint32_t)j < nq ? j : 0) * 256);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float rpart = 0.0f, qpart = 0.0f;
+    f32x4 R[32], Q[32];
+    // f32: lane (j, h) feeds dims 8m + 4h .. + 3 of group m; bf16: dims 16m + 8h .. + 7 of K-step m
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        const int idx = BF16 ? 4 * (m >> 1) + 2 * h + (m & 1) : 2 * m + h;
+        R[m] = row_ok ? rsrc[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        Q[m] = (uint32_t)j < nq ? qsrc[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rpart += R[m].x * R[m].x + R[m].y * R[m].y + R[m].z * R[m].z + R[m].w * R[m].w;
+        qpart += Q[m].x * Q[m].x + Q[m].y * Q[m].y + Q[m].z * Q[m].z + Q[m].w * Q[m].w;
+    }
+    const float r2 = rpart + __shfl_xor(rpart, 32), q2 = qpart + __shfl_xor(qpart, 32);
+    const float rb = r2 == 0.0f ? 0.0f : __frsqrt_rn(r2), rq = q2 == 0.0f ? 0.0f : __frsqrt_rn(q2);
+    if constexpr (BF16) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            u32x4 ah, al, bh, bl;
+            bf16_split8(R[2 * m] * rb, R[2 * m + 1] * rb, ah, al);
+            bf16_split8(Q[2 * m], Q[2 * m + 1], bh, bl);
+            acc = mfma_bf16x3(ah, al, bh, bl, acc);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const f32x4 a = R[m] * rb, b = Q[m];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t i = blockIdx.x * 32 + acc_row(r, h);
+        if (i < n_rows) out[(size_t)i * 32 + j] = fmaxf(1.0f - acc[r] * rq, 0.0f);
+    }
+}
+
+int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_row, uint32_t n_rows, const float *queries,
+                             uint32_t nq, float *out)
+{
+    if (nq < 1 || nq > 32 || n_rows < 1) { set_error("debug scores: 1..32 queries, >= 1 row"); return SMT_E_INVALID; }
+    const dim3 grid((n_rows + 31) / 32);
+    if (ctx->tune.gemm_bf16x3) hipLaunchKernelGGL(gemm_debug_scores_kernel<true>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    else hipLaunchKernelGGL(gemm_debug_scores_kernel<false>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+template <int NQT, bool FILTERED, int AUX, bool BF16>
+static hipError_t lr_attr()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<NQT, FILTERED, AUX, BF16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <bool BF16>
+static hipError_t lr_set_attr()
+{
+    hipError_t e;
+    if ((e = lr_attr<1, false, 0, BF16>()) != hipSuccess) return e;
+    if ((e = lr_attr<2, false, 0, BF16>()) != hipSuccess) return e;
+    if ((e = lr_attr<1, false, 2, BF16>()) != hipSuccess) return e;
+    if ((e = lr_attr<2, false, 2, BF16>()) != hipSuccess) return e;
+    if ((e = lr_attr<1, true, 0, BF16>()) != hipSuccess) return e;
+    return lr_attr<2, true, 0, BF16>();
+}
+template <int NQT, bool FILTERED, int AUX, bool BF16>
+static void lr_launch(smt_ctx *ctx, int nb, size_t smem, const GemmParams &g)
+{
+    hipLaunchKernelGGL((gemm_ldsrow_kernel<NQT, FILTERED, AUX, BF16>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
+}
+template <bool BF16>
+static void lr_dispatch(smt_ctx *ctx, uint32_t nqt, bool filtered, bool nt, int nb, size_t smem, const GemmParams &g)
+{
+    if (nqt <= 1) {
+        if (filtered) lr_launch<1, true, 0, BF16>(ctx, nb, smem, g);
+        else if (nt) lr_launch<1, false, 2, BF16>(ctx, nb, smem, g);
+        else lr_launch<1, false, 0, BF16>(ctx, nb, smem, g);
+    } else {
+        if (filtered) lr_launch<2, true, 0, BF16>(ctx, nb, smem, g);
+        else if (nt) lr_launch<2, false, 2, BF16>(ctx, nb, smem, g);
+        else lr_launch<2, false, 0, BF16>(ctx, nb, smem, g);
+    }
+}
+
 static size_t gemm_smem_bytes(uint32_t nqt)
 {
     return (size_t)4 * QT_F4 * 16 + (size_t)nqt * QT_ROWS * 4 * 2 + 64;
@@ -742,7 +936,9 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (gemm_smem_bytes(nqt) > 160 * 1024) { set_error("batch too large for one launch"); return SMT_E_UNSUPPORTED; }
 
     if (!(ctx->attr_done & ATTR_GEMM)) {  // per context == per device
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -750,27 +946,20 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, false, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, false, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, false, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, false, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<1, true, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ldsrow_kernel<2, true, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK((lr_set_attr<false>()));
+        SMT_HIP_CHECK((lr_set_attr<true>()));
         ctx->attr_done |= ATTR_GEMM;
     }
 
-    // scratch: cand [nq][CAP] keys | counts [nq] | overflow [nq] | tau [nqt*32]
+    // scratch: cand [nq][CAP] keys | counts [nq] | overflow [nq] | tau [nqt*32] | split queries [nqt*32][1 KiB] | chunk table
+    const bool bf16 = ctx->tune.gemm_bf16x3 != 0;
     const size_t b_cand = (size_t)a.nq * CAND_CAP * sizeof(key_t64);
     const size_t b_cnt = (((size_t)a.nq * 4) + 15) & ~(size_t)15;
     const size_t b_tau = (size_t)nqt * QT_ROWS * 4;
     const uint64_t n_chunks = filtered ? a.n_chunks : 0;
-    const size_t b_head = (b_cand + 2 * b_cnt + b_tau + 255) & ~(size_t)255;
+    const size_t b_split = bf16 ? (size_t)nqt * QT_ROWS * 1024 : 0;
+    const size_t o_split = (b_cand + 2 * b_cnt + b_tau + 255) & ~(size_t)255;
+    const size_t b_head = o_split + b_split;
     int rc = ensure_scratch(ctx, b_head + (size_t)n_chunks * sizeof(uint64_t) + 64);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(ctx->d_scratch);
@@ -779,6 +968,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     unsigned int *overflow = reinterpret_cast<unsigned int *>(base + b_cand + b_cnt);
     float *tau = reinterpret_cast<float *>(base + b_cand + 2 * b_cnt);
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
+    uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
+    if (bf16)
+        hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, a.queries, a.nq,
+                           nqt * QT_ROWS, q_split);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -800,6 +993,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.corpus = a.corpus;
         g.n_rows = a.rows;
         g.queries = a.queries;
+        g.queries_split = bf16 ? q_split : nullptr;
         g.nq = a.nq;
         g.nqt = nqt;
         g.level_tiles = multiples - parents;
@@ -817,15 +1011,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             const size_t smem = nqt <= 1 ? (size_t)LrGeom<1>::SMEM : (size_t)LrGeom<2>::SMEM;
             prof_begin(ctx, "gemm");
             const bool nt = ctx->tune.gemm_dma_nt != 0;
-            if (nqt <= 1) {
-                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<1, true, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-                else if (nt) hipLaunchKernelGGL((gemm_ldsrow_kernel<1, false, 2>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-                else hipLaunchKernelGGL((gemm_ldsrow_kernel<1, false, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-            } else {
-                if (filtered) hipLaunchKernelGGL((gemm_ldsrow_kernel<2, true, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-                else if (nt) hipLaunchKernelGGL((gemm_ldsrow_kernel<2, false, 2>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-                else hipLaunchKernelGGL((gemm_ldsrow_kernel<2, false, 0>), dim3(nb), dim3(LR_THREADS), smem, ctx->stream, g);
-            }
+            if (bf16) lr_dispatch<true>(ctx, nqt, filtered, nt, nb, smem, g);
+            else lr_dispatch<false>(ctx, nqt, filtered, nt, nb, smem, g);
             prof_end(ctx, "gemm");
         } else if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident && !ctx->tune.gemm_ldsrow) {  // first generation, A/B only
             const uint64_t need_blocks = (g.level_tiles + RES_WAVES - 1) / RES_WAVES;
@@ -846,7 +1033,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                 nb = (int)(need_blocks * g.qsplit);
             }
             prof_begin(ctx, "gemm");
-            hipLaunchKernelGGL(gemm_level_kernel, dim3(nb), dim3(GEMM_THREADS), gemm_smem_bytes(nqt), ctx->stream, g);
+            if (bf16) hipLaunchKernelGGL(gemm_level_kernel<true>, dim3(nb), dim3(GEMM_THREADS), gemm_smem_bytes(nqt), ctx->stream, g);
+            else hipLaunchKernelGGL(gemm_level_kernel<false>, dim3(nb), dim3(GEMM_THREADS), gemm_smem_bytes(nqt), ctx->stream, g);
             prof_end(ctx, "gemm");
         }
         LevelSelectParams ls;
@@ -878,7 +1066,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     sel.out_dist = a.out_dist;
     sel.out_counts = a.out_counts;
     sel.out_stride = a.out_stride;
-    sel.f32_err = F32_ERR_MFMA;
+    sel.f32_err = bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
     sel.out_uncertain = a.out_uncertain;
     rc = launch_select(ctx, sel);
     if (rc) return rc;

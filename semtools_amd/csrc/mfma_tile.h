@@ -33,6 +33,52 @@ __device__ __forceinline__ f32x16 mfma_tile_32x32x256(const f32x4 (&A)[32], cons
     return acc;
 }
 
+// ---- bf16 x 3 split products on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16: 16x the f32 MFMA rate).
+// An f32 value x is split into hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): x - hi is exact in f32,
+// so |x - hi - lo| <= 2^-18 |x|.  x . q  ~=  xh.qh + xl.qh + xh.ql  (three MFMAs into ONE f32 accumulator; the
+// products of bf16 pairs are exact in f32).  Dropped: xl.ql and the two residuals, each <= 2^-18 |x||q| summed over
+// the dims (Cauchy-Schwarz) => <= 3 * 2^-18 |x||q| = 1.15e-5 |x||q|; accumulating 768 products in f32 adds at most
+// 768 * 2^-24 * (1 + 2^-8) |x||q| = 4.6e-5 |x||q| with round-to-nearest adds.  common.h: F32_ERR_BF16X3 = 1.2e-4
+// (twice the sum: the MFMA's internal adder tree is not documented to round to nearest).  The scores only NOMINATE
+// candidates; final distances are recomputed exactly (f64) and the certificate of section 5 of DESIGN.md uses this bound.
+// Operand layout: lane (j, h) feeds row / query j with dims 16m + 8h .. + 7 of K-step m (8 bf16 = 4 VGPRs), the same
+// K permutation on both operands.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bf16_pack2(float a, float b)  // v_cvt_pk_bf16_f32: a -> bits 15:0, b -> bits 31:16
+{
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void bf16_split2(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    hi = bf16_pack2(a, b);
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
+    lo = bf16_pack2(a - ah, b - bh);
+}
+// eight consecutive dims (two float4) -> hi and lo operand quads
+__device__ __forceinline__ void bf16_split8(const f32x4 &a, const f32x4 &b, u32x4 &hi, u32x4 &lo)
+{
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    bf16_split2(a.x, a.y, h0, l0);
+    bf16_split2(a.z, a.w, h1, l1);
+    bf16_split2(b.x, b.y, h2, l2);
+    bf16_split2(b.z, b.w, h3, l3);
+    hi = (u32x4){h0, h1, h2, h3};
+    lo = (u32x4){l0, l1, l2, l3};
+}
+// acc += (ah + al) . (bh + bl) without the al.bl term
+__device__ __forceinline__ f32x16 mfma_bf16x3(const u32x4 &ah, const u32x4 &al, const u32x4 &bh, const u32x4 &bl, f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+    return acc;
+}
+
 // accumulator register r of lane (j, h) holds tile row acc_row(r, h) and tile column j
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -1,5 +1,6 @@
-"""GPU parity: K3 batched path (f32 MFMA Q x C^T + fused candidate selection) vs the oracle and
-vs the single-query K2 path.  Same bar: indices exact, distances = oracle f64 values."""
+"""GPU parity: K3 batched path (Q x C^T on the MFMA pipes + fused candidate selection) vs the oracle and
+vs the single-query K2 path.  Same bar: indices exact, distances = oracle f64 values.  Every test runs twice:
+candidates nominated by bf16 x 3 split products (the default) and by f32 MFMAs (tuning key gemm_bf16x3 = 0)."""
 import numpy as np
 import pytest
 
@@ -8,6 +9,13 @@ from tests import synth
 from tests.compare import assert_topk_tie_aware, reference_distances
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=[1, 0], ids=["bf16x3", "f32mfma"])
+def nominate_with(request, gpu_ctx):
+    gpu_ctx.set_tuning("gemm_bf16x3", request.param)
+    yield request.param
+    gpu_ctx.set_tuning("gemm_bf16x3", 1)
 
 
 def _oracle_topk(emb, q, k):
@@ -156,4 +164,35 @@ def test_both_small_batch_kernels_agree(gpu_ctx):
         gpu_ctx.set_tuning("gemm_ldsrow", 1)
     for a, b in zip(new, old):
         assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+    c.close()
+
+
+def test_nominating_distance_error_is_inside_the_certificate_bound(gpu_ctx, nominate_with):
+    """The certificate needs |nominating f32 distance - exact distance| <= the bound compiled into
+    the library: 2e-5 for the f32 MFMA chain, 1.2e-4 for bf16 x 3.  Measured here on the corpora that stress it:
+    isotropic rows, all-positive rows (sum |x_i q_i| = x.q: no cancellation, the largest accumulations), rows with
+    a few dominant components, unnormalised rows and queries."""
+    import semtools_amd as smt
+
+    rng = np.random.default_rng(5)
+    n = 4096
+    iso = synth.unit_rows(n, seed=77, dup_frac=0, zero_frac=0)
+    pos = np.abs(rng.standard_normal((n, 256))).astype(np.float32)
+    spiky = (rng.standard_normal((n, 256)) * np.exp(3.0 * rng.standard_normal((n, 256)))).astype(np.float32)
+    scaled = (rng.standard_normal((n, 256)) * 37.5).astype(np.float32)
+    emb = np.ascontiguousarray(np.concatenate([iso, pos, spiky, scaled]))
+    qs = np.concatenate([synth.unit_query(9, nq=8), np.abs(rng.standard_normal((8, 256))).astype(np.float32),
+                         (rng.standard_normal((8, 256)) * np.exp(3.0 * rng.standard_normal((8, 256)))).astype(np.float32),
+                         (rng.standard_normal((8, 256)) * 1e-3).astype(np.float32)])
+    qs = np.ascontiguousarray(qs, dtype=np.float32)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    got = c.debug_batched_scores(qs).astype(np.float64)                   # [rows, 32]
+    e64, q64 = emb.astype(np.float64), qs.astype(np.float64)
+    cos = (e64 @ q64.T) / (np.linalg.norm(e64, axis=1)[:, None] * np.linalg.norm(q64, axis=1)[None, :])
+    exact = np.maximum(1.0 - cos, 0.0)
+    err = np.abs(got - exact).max()
+    bound = 1.2e-4 if nominate_with else 2e-5
+    print(f"max |nominating - exact| = {err:.3e} (bound {bound:.1e}, {'bf16x3' if nominate_with else 'f32 MFMA'})")
+    assert err < bound / 4, err          # the compiled-in bound is a worst case; observed errors sit far inside it
     c.close()
