@@ -315,6 +315,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_resident") ctx->tune.gemm_resident = (int)value;
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
     else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
+    else if (k == "gemm_rowreg") ctx->tune.gemm_rowreg = (int)value;
     else if (k == "gemm_dma_nt") ctx->tune.gemm_dma_nt = (int)value;
     else if (k == "embed_wave_per_line") ctx->tune.embed_wave_per_line = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;

@@ -65,6 +65,8 @@ struct GemmParams {
     int skip16;               // LEVEL_RATIO (64 or 16) when u skips the multiples of the ratio (they belong to earlier levels), else 0
     uint32_t qsplit;          // gemm_level_kernel: blocks per row-tile group, each sweeping 1/qsplit of the query tiles
     const float *tau;         // [nqt*32] distance thresholds (+inf = take everything, <0 = padding)
+    const float *thr;         // gemm_rowreg_kernel: [nqt*32] score thresholds = score_threshold(tau, rq), kept by level_select_kernel
+    const float *rq;          // gemm_rowreg_kernel: [nqt*32] 1/|q| (0: zero or padding query)
     key_t64 *cand;            // [nq][CAND_CAP]
     unsigned int *counts;     // [nq]
     // range-filtered batches (gemm_ldsrow_kernel<.., true>): the rows to scan are the FILTER_CHUNK-row chunks of the
@@ -241,8 +243,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
             }
         }
 
-        // one (row tile x query tile) product + epilogue; the tile sits in LDS slot `slot`
-        auto tile_product = [&](uint32_t qt, int slot) {
+        // f32 MFMA: one (row tile x query tile) product + epilogue; the tile sits in LDS slot `slot`
+        auto tile_product = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -259,16 +261,71 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, b.z, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, b.w, acc, 0, 0, 0);
                 }
-            } else {
-                const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
-#pragma unroll
-                for (int m = 0; m < 16; ++m) acc = mfma_bf16x3(Ah[m], Al[m], bq[4 * m], bq[4 * m + 1], acc);
             }
             append_candidates(acc, zero16, valid16, q, thr_q, rq_q, row0, h, p.cand, p.counts);  // 16 rows x this lane's query
         };
+        // bf16 x 3: NT (1 or 2) query tiles against the row tile at once.  The B quads are software-pipelined through
+        // registers (LDS latency is ~100 cycles, a K-step of one tile is only 3 MFMAs = 96): prefetch distance 2 K-steps
+        // for one tile, 1 for two; two tiles also interleave their accumulators, so no MFMA waits for its predecessor.
+        auto tile_products_bf16 = [&](auto NTc, uint32_t qt0, int slot0) __attribute__((always_inline)) {
+            constexpr int NT = decltype(NTc)::value;
+            constexpr int D = NT == 1 ? 2 : 1, NB = D + 1;
+            f32x16 acc[NT];
+            const u32x4 *bq[NT];
+            float thr_q[NT], rq_q[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                bq[t] = reinterpret_cast<const u32x4 *>(s_q + (slot0 + t) * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
+            }
+            u32x4 bh[NB][NT], bl[NB][NT];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { bh[d][t] = bq[t][4 * d]; bl[d][t] = bq[t][4 * d + 1]; }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m + D < 16) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { bh[(m + D) % NB][t] = bq[t][4 * (m + D)]; bl[(m + D) % NB][t] = bq[t][4 * (m + D) + 1]; }
+                } else if (m + D == 16) {
+                    // the lane's query constants arrive under the last MFMAs
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { thr_q[t] = s_tau[(qt0 + t) * QT_ROWS + j]; rq_q[t] = s_rq[(qt0 + t) * QT_ROWS + j]; }
+                }
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah[m]), al = __builtin_bit_cast(bf16x8, Al[m]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[m % NB][t]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, bh[m % NB][t]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[m % NB][t]), acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);  // keeps the prefetch distance: hipcc otherwise sinks each read to its use
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                append_candidates(acc[t], zero16, valid16, (qt0 + t) * QT_ROWS + j, thr_q[t], rq_q[t], row0, h, p.cand, p.counts);
+        };
+        using One = std::integral_constant<int, 1>;
+        // tiles [t, t + n) of this block's range sit in consecutive slots from `slot`
+        auto products = [&](uint32_t t, uint32_t n, int slot) __attribute__((always_inline)) {
+            if constexpr (BF16) {
+                // (two tiles at once with interleaved accumulators measured no faster at 1000 queries and slower at
+                // 128 -- the second accumulator and B buffers push the kernel into spills)
+                tile_products_bf16(One{}, qt_lo + t, slot);
+                if (n == 2) tile_products_bf16(One{}, qt_lo + t + 1, slot + 1);
+            } else {
+                tile_product(qt_lo + t, slot);
+                if (n == 2) tile_product(qt_lo + t + 1, slot + 1);
+            }
+        };
         if (resident) {
             if (has)
-                for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t);
+                for (uint32_t t = 0; t < n_qt; t += 2) products(t, t + 1 < n_qt ? 2u : 1u, (int)t);
         } else {
             // streaming: TWO query tiles per barrier (the block's 8 waves meet half as often: the barrier cost
             // 2.6 ms of a 43 ms batch).  While pair P is multiplied, the next pair lands in the other two slots.
@@ -279,8 +336,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
                 const uint32_t nx0 = two ? tn0 : 0u, nx1 = two ? tn1 : 1u;
                 stage_tile(qt_lo + nx0, (cur ^ 1) * 2);      // both DMA batches fly under the two products
                 stage_tile(qt_lo + nx1, (cur ^ 1) * 2 + 1);
-                if (has) tile_product(qt_lo + t, cur * 2);
-                if (has && two) tile_product(qt_lo + t + 1, cur * 2 + 1);
+                if (has) products(t, two ? 2u : 1u, cur * 2);
                 stage_wait();
                 __syncthreads();
                 cur ^= 1;
@@ -293,6 +349,15 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
 __device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned zero16, unsigned valid16, uint32_t q,
                                                   float thr, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts)
 {
+    // almost every (tile, query tile) nominates nothing: one max over the lane's 16 scores (v_max3) and one wave-wide
+    // test skip the per-row work (the per-row compares were 1/4 of a bf16 x 3 tile product)
+    {
+        float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+        mx = fmaxf(mx, acc[15]);
+        if (!__builtin_amdgcn_ballot_w64(rq == 0.0f || mx >= thr)) return;
+    }
     unsigned pass = 0;
     auto dist_of = [&](int r) {
         if (rq == 0.0f) return (zero16 >> r) & 1u ? 0.0f : 1.0f;  // zero query: 0 against a zero row, else 1 (simsimd rules)
@@ -322,6 +387,212 @@ __device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned ze
             }
         }
     }
+}
+
+// ---- bf16 x 3, every unfiltered batch size: row tiles arrive in REGISTERS with coalesced loads and are transposed
+// into the MFMA operand layout through a small wave-private LDS buffer.
+//
+// Why: the MFMA A layout wants lane j <-> row j, and loading a row tile directly in that layout means 32 instructions
+// that each touch 16- or 32-byte pieces of 32 different rows.  Measured on MI355X (tools/micro/row_load_patterns.hip,
+// 8 waves per CU, 10 M rows): such loads deliver 3.2-3.6 TB/s whatever the sweep behind them; instructions that read
+// 128-byte runs (8 lanes per row, 8 rows per instruction) deliver 7.0-7.2 TB/s, also with 192 MFMAs per tile behind
+// them.  So: 32 coalesced loads per tile -> 1/|row| scaling and the bf16 hi/lo split ONCE per tile in that layout ->
+// per 32-dim slice the packed words go through a 2.5 KiB LDS buffer (80-byte row stride: conflict-free b128 reads)
+// and come back as the operand quads Ah/Al[16], which then serve the whole sweep over the query tiles.  The query
+// tiles are the split image (split_queries_kernel) in LDS: resident up to 4 tiles, else streamed in pairs like
+// gemm_level_kernel.  Thresholds and 1/|q| are read from global memory (kept per level by level_select_kernel), so
+// the LDS footprint does not depend on the batch size.
+constexpr int RR_TROW = 80;                       // bytes per row in the transpose buffer (64 used)
+constexpr int RR_TBUF = 32 * RR_TROW;             // per wave
+// Streaming (more than four query tiles): the four slots form a ring of single tiles -- tile n is multiplied while
+// tiles n+1 .. n+3 are in flight or landed (the DMA of n+3 is issued during product n), one barrier per tile.  A
+// distance of one step (the pair scheme of gemm_level_kernel, or two slots per block with two blocks per CU -- both
+// measured) leaves the L2 -> LDS latency of every tile exposed at the barrier: a step is only 1.5-3 k cycles of
+// bf16 MFMAs, no longer the 16 k of the f32 kernel.
+constexpr int RR_THREADS = 512;
+constexpr int RR_WAVES = RR_THREADS / 64;
+constexpr int RR_SLOTS = 4;
+#ifndef SMT_RR_BDIST
+#define SMT_RR_BDIST 2
+#endif
+constexpr int RR_BDIST = SMT_RR_BDIST;            // K-steps between the LDS read of a B quad pair and its MFMAs
+constexpr int RR_SMEM = RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF;
+
+__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *rq_out, float *thr_out)
+{
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq_pad) return;
+    float rq = 0.0f;
+    if (q < nq) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(queries + (size_t)q * 256)[lane];
+        const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+        rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
+    }
+    if (lane == 0) {
+        rq_out[q] = rq;
+        thr_out[q] = score_threshold(q < nq ? __builtin_inff() : -1.0f, rq);  // padding: zero query, tau < 0 -> never passes
+    }
+}
+
+__global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p)
+{
+    constexpr int WAVES = RR_WAVES;
+    constexpr int STAGE_ROWS = QT_ROWS / WAVES;      // rows of a query tile each wave stages: 4
+    constexpr int STAGE_EVERY = 2;                   // one DMA every so many K-steps at the start of a product
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *s_q = reinterpret_cast<f32x4 *>(smem_raw);                  // [4][32][65] float4: query tiles (split image)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    unsigned char *tbuf = smem_raw + RR_SLOTS * QT_F4 * 16 + wave * RR_TBUF;
+    const uint32_t qs = blockIdx.x % p.qsplit;
+    const uint32_t row_block = blockIdx.x / p.qsplit, row_blocks = gridDim.x / p.qsplit;
+    const uint32_t qt_lo = (uint32_t)((uint64_t)qs * p.nqt / p.qsplit);
+    const uint32_t qt_hi = (uint32_t)((uint64_t)(qs + 1) * p.nqt / p.qsplit);
+    const uint32_t n_qt = qt_hi - qt_lo;
+    const bool resident = n_qt <= (uint32_t)RR_SLOTS;
+
+    // row u of this wave's share of query tile qt -> LDS slot (padding rows of the image are zero rows: no branch)
+    auto stage_row = [&](uint32_t qt, int slot, int u) __attribute__((always_inline)) {
+        const int r = wave * STAGE_ROWS + u;  // wave-uniform
+        const uint32_t q = qt * QT_ROWS + r;
+        f32x4 *dst = s_q + slot * QT_F4 + r * QT_STRIDE_F4;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * 256 + lane * 4,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto stage_tile = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < STAGE_ROWS; ++u) stage_row(qt, slot, u);
+    };
+    auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };  // vmcnt(0)
+    {
+        const uint32_t first = resident ? n_qt : 3u;   // streaming: ring positions 0, 1, 2
+        for (uint32_t t = 0; t < first; ++t) stage_tile(qt_lo + t, (int)t);
+        stage_wait();
+    }
+    __syncthreads();
+
+    const uint64_t W = (uint64_t)row_blocks * WAVES;
+    const uint64_t steps = (p.level_tiles + W - 1) / W;  // block-uniform trip count
+    uint64_t it = (uint64_t)row_block * WAVES + wave;
+    uint32_t pos = 0;            // streaming: running ring position (block-uniform); slot = pos & 3
+    uint32_t tq = 0, tq_ahead = 3 % n_qt;   // tile at position pos / pos + 3 (the tile sequence is cyclic over the sweeps)
+    // transpose geometry: this lane WRITES row (8u + lane/8), bytes 8 * (lane%8) of a slice; it READS row j, quads 2mm + h
+    const uint32_t t_wr = (uint32_t)((lane >> 3) * RR_TROW + (lane & 7) * 8);
+    const uint32_t t_rd = (uint32_t)(j * RR_TROW + h * 16);
+
+    for (uint64_t step = 0; step < steps; ++step, it += W) {
+        const bool has = it < p.level_tiles;  // wave-uniform
+        const uint64_t row0 = (has ? level_tile(it, p.stride, p.skip16) : 0) * 32;
+
+        u32x4 Ah[16], Al[16];
+        unsigned zero16 = 0, valid16 = 0;
+        if (has) {
+            // ---- 32 coalesced loads: instruction i = 4s + u covers rows 8u .. 8u+7, dims 32s .. 32s+31 (128 B per row)
+            f32x4 R[32];
+            {
+                const f32x4 *base = reinterpret_cast<const f32x4 *>(p.corpus) + (lane & 7);
+                uint64_t rowv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t r = row0 + 8 * u + (lane >> 3);
+                    rowv[u] = r < p.n_rows ? r : 0;   // rows past the end: any valid address, masked by valid16
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) R[i] = __builtin_nontemporal_load(base + rowv[i & 3] * 64 + 8 * (i >> 2));
+            }
+            // ---- 1/|row| for the four rows this lane holds pieces of (8 lanes per row)
+            float rb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float part = 0.0f;
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    const f32x4 v = R[4 * sl + u];
+                    part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+                part += __shfl_xor(part, 1);
+                part += __shfl_xor(part, 2);
+                part += __shfl_xor(part, 4);
+                rb[u] = part == 0.0f ? 0.0f : __frsqrt_rn(part);
+            }
+            // ---- per slice: scale, split, transpose hi then lo through the wave's buffer
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                uint32_t hi[4][2], lo[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = R[4 * sl + u] * rb[u];
+                    bf16_split2(v.x, v.y, hi[u][0], lo[u][0]);
+                    bf16_split2(v.z, v.w, hi[u][1], lo[u][1]);
+                }
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){hi[u][0], hi[u][1]};
+                Ah[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
+                Ah[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){lo[u][0], lo[u][1]};
+                Al[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
+                Al[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 4 * h;                     // accumulator reg r <-> tile row 8 (r >> 2) + i
+                if (__shfl(rb[r >> 2], 8 * i) == 0.0f) zero16 |= 1u << r;
+                if (row0 + 8 * (r >> 2) + i < p.n_rows) valid16 |= 1u << r;
+            }
+        }
+
+        // one (row tile x query tile) product + epilogue; B quads prefetched one K-step ahead.  While it runs the
+        // wave issues its share of the DMA that brings query tile stage_qt into stage_slot (stage: wave-uniform).
+        auto tile_product = [&](uint32_t qt, int slot, bool stage, uint32_t stage_qt, int stage_slot) __attribute__((always_inline)) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const uint32_t q = qt * QT_ROWS + j;
+            const float thr_q = p.thr[q], rq_q = p.rq[q];   // global (L1/L2 hits), consumed after 48 MFMAs
+            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
+            // B quads run RR_BDIST K-steps ahead of their MFMAs (sched_barrier: hipcc otherwise sinks every read to its
+            // use and each K-step then starts with a full LDS round trip in front of 96 cycles of MFMA)
+            constexpr int NB = RR_BDIST + 1;
+            u32x4 bh[NB], bl[NB];
+#pragma unroll
+            for (int d = 0; d < RR_BDIST; ++d) { bh[d] = bq[4 * d]; bl[d] = bq[4 * d + 1]; }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m + RR_BDIST < 16) { bh[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST)]; bl[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST) + 1]; }
+                if (m % STAGE_EVERY == 0 && m / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, m / STAGE_EVERY);
+                acc = mfma_bf16x3(Ah[m], Al[m], bh[m % NB], bl[m % NB], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            append_candidates(acc, zero16, valid16, q, thr_q, rq_q, row0, h, p.cand, p.counts);
+        };
+
+        if (resident) {
+            if (has)
+                for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t, false, 0, 0);
+        } else {
+            for (uint32_t t = 0; t < n_qt; ++t) {
+                const int slot = (int)(pos & 3), slot_ahead = (int)((pos + 3) & 3);   // slot_ahead was read during step pos - 1
+                if (has) tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
+                else stage_tile(qt_lo + tq_ahead, slot_ahead);
+                // this wave's share of tile pos + 1 has landed: only the 2 x STAGE_ROWS younger DMAs may still fly
+                // (a raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), i.e. it would wait
+                // for the two tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
+                __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                ++pos;
+                tq = tq + 1 == n_qt ? 0 : tq + 1;
+                tq_ahead = tq_ahead + 1 == n_qt ? 0 : tq_ahead + 1;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no LDS-DMA may outlive the block's LDS allocation
 }
 
 // ---- small / medium batches (nq <= 128): every query tile stays in LDS for the whole kernel, so the
@@ -761,6 +1032,8 @@ struct LevelSelectParams {
     float *tau;
     unsigned int *overflow;  // [nq], sticky
     uint32_t kp;
+    float *thr;              // when set: score threshold of the new tau (gemm_rowreg_kernel reads it instead of tau)
+    const float *rq;
 };
 
 __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
@@ -787,7 +1060,9 @@ __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
     if (threadIdx.x < p.kp) buf[threadIdx.x] = s_best[threadIdx.x];
     if (threadIdx.x == 0) {
         p.counts[q] = n < p.kp ? n : p.kp;
-        p.tau[q] = n >= p.kp ? __uint_as_float((unsigned)(s_best[p.kp - 1] >> 32)) : __builtin_inff();
+        const float tau = n >= p.kp ? __uint_as_float((unsigned)(s_best[p.kp - 1] >> 32)) : __builtin_inff();
+        p.tau[q] = tau;
+        if (p.thr) p.thr[q] = score_threshold(tau, p.rq[q]);
     }
 }
 
@@ -914,7 +1189,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     //   8..32 queries 1.84 / 3.1;  64 queries 3.05 / 3.24;  96 queries 4.96 (two passes) / 4.32;  128: 6.04 / 5.48.
     // So: up to 64 queries, and every range-filtered batch (in passes of 64), take the LDS-row kernel; larger batches
     // stream the query tiles through LDS (gemm_level_kernel), one sweep over the corpus for up to 3584 queries.
-    const bool lds_rows = ctx->tune.gemm_ldsrow && (filtered || nqt <= 2);
+    // bf16 x 3 (the default): gemm_rowreg_kernel takes every unfiltered batch; range-filtered batches keep the LDS-row
+    // kernel (its chunk table gathers the rows).  f32 MFMA (gemm_bf16x3 = 0): the round-1/2 routing below.
+    const bool rowreg = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && !filtered;
+    const bool lds_rows = !rowreg && ctx->tune.gemm_ldsrow && (filtered || nqt <= 2);
     if (filtered && !lds_rows) { set_error("range-filtered batches need the LDS-row kernel (tuning key gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
     const uint32_t pass_nq = lds_rows ? 2 * QT_ROWS : GEMM_MAX_NQ;
     if (a.nq > pass_nq) {
@@ -946,6 +1224,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK((lr_set_attr<false>()));
         SMT_HIP_CHECK((lr_set_attr<true>()));
         ctx->attr_done |= ATTR_GEMM;
@@ -958,7 +1238,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const size_t b_tau = (size_t)nqt * QT_ROWS * 4;
     const uint64_t n_chunks = filtered ? a.n_chunks : 0;
     const size_t b_split = bf16 ? (size_t)nqt * QT_ROWS * 1024 : 0;
-    const size_t o_split = (b_cand + 2 * b_cnt + b_tau + 255) & ~(size_t)255;
+    const size_t o_split = (b_cand + 2 * b_cnt + 3 * b_tau + 255) & ~(size_t)255;  // tau | thr | rq
     const size_t b_head = o_split + b_split;
     int rc = ensure_scratch(ctx, b_head + (size_t)n_chunks * sizeof(uint64_t) + 64);
     if (rc) return rc;
@@ -967,11 +1247,15 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     unsigned int *counts = reinterpret_cast<unsigned int *>(base + b_cand);
     unsigned int *overflow = reinterpret_cast<unsigned int *>(base + b_cand + b_cnt);
     float *tau = reinterpret_cast<float *>(base + b_cand + 2 * b_cnt);
+    float *thr = tau + (size_t)nqt * QT_ROWS, *rqv = thr + (size_t)nqt * QT_ROWS;
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
     if (bf16)
         hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, q_split);
+    if (rowreg)
+        hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
+                           nqt * QT_ROWS, rqv, thr);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -1001,11 +1285,23 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.skip16 = lev == 0 ? 0 : LEVEL_RATIO;
         g.qsplit = 1;
         g.tau = tau;
+        g.thr = thr;
+        g.rq = rqv;
         g.cand = cand;
         g.counts = counts;
         g.chunk_table = filtered ? chunk_table : nullptr;
         g.n_chunks = n_chunks;
-        if (g.level_tiles > 0 && lds_rows) {
+        if (g.level_tiles > 0 && rowreg) {
+            const uint64_t need_blocks = (g.level_tiles + RR_WAVES - 1) / RR_WAVES;
+            int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
+            if (ctx->tune.gemm_qsplit && need_blocks < (uint64_t)blocks) {   // small levels: split the query tiles over more blocks
+                g.qsplit = (uint32_t)std::min<uint64_t>(nqt, std::max<uint64_t>(1, (uint64_t)2 * blocks / need_blocks));
+                nb = (int)(need_blocks * g.qsplit);
+            }
+            prof_begin(ctx, "gemm");
+            hipLaunchKernelGGL(gemm_rowreg_kernel, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            prof_end(ctx, "gemm");
+        } else if (g.level_tiles > 0 && lds_rows) {
             const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
             const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
             const size_t smem = nqt <= 1 ? (size_t)LrGeom<1>::SMEM : (size_t)LrGeom<2>::SMEM;
@@ -1043,6 +1339,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         ls.tau = tau;
         ls.overflow = overflow;
         ls.kp = kp;
+        ls.thr = rowreg ? thr : nullptr;
+        ls.rq = rqv;
         prof_begin(ctx, "select");
         hipLaunchKernelGGL(level_select_kernel, dim3(a.nq), dim3(1024), 0, ctx->stream, ls);
         prof_end(ctx, "select");

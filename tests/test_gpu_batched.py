@@ -1,6 +1,7 @@
 """GPU parity: K3 batched path (Q x C^T on the MFMA pipes + fused candidate selection) vs the oracle and
-vs the single-query K2 path.  Same bar: indices exact, distances = oracle f64 values.  Every test runs twice:
-candidates nominated by bf16 x 3 split products (the default) and by f32 MFMAs (tuning key gemm_bf16x3 = 0)."""
+vs the single-query K2 path.  Same bar: indices exact, distances = oracle f64 values.  Every test runs three times:
+candidates nominated by bf16 x 3 split products in the row-register kernel (the default), by bf16 x 3 in the
+round-2 kernels (gemm_rowreg = 0), and by f32 MFMAs (gemm_bf16x3 = 0)."""
 import numpy as np
 import pytest
 
@@ -11,11 +12,14 @@ from tests.compare import assert_topk_tie_aware, reference_distances
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[1, 0], ids=["bf16x3", "f32mfma"])
+@pytest.fixture(autouse=True, params=[(1, 1), (1, 0), (0, 0)], ids=["bf16x3-rowreg", "bf16x3-level", "f32mfma"])
 def nominate_with(request, gpu_ctx):
-    gpu_ctx.set_tuning("gemm_bf16x3", request.param)
-    yield request.param
+    bf16, rowreg = request.param
+    gpu_ctx.set_tuning("gemm_bf16x3", bf16)
+    gpu_ctx.set_tuning("gemm_rowreg", rowreg)
+    yield bf16
     gpu_ctx.set_tuning("gemm_bf16x3", 1)
+    gpu_ctx.set_tuning("gemm_rowreg", 1)
 
 
 def _oracle_topk(emb, q, k):
