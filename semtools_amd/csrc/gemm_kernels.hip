@@ -65,8 +65,8 @@ struct GemmParams {
     int skip16;               // LEVEL_RATIO (64 or 16) when u skips the multiples of the ratio (they belong to earlier levels), else 0
     uint32_t qsplit;          // gemm_level_kernel: blocks per row-tile group, each sweeping 1/qsplit of the query tiles
     const float *tau;         // [nqt*32] distance thresholds (+inf = take everything, <0 = padding)
-    const float *thr;         // gemm_rowreg_kernel: [nqt*32] score thresholds = score_threshold(tau, rq), kept by level_select_kernel
-    const float *rq;          // gemm_rowreg_kernel: [nqt*32] 1/|q| (0: zero or padding query)
+    const float *qconst;      // gemm_rowreg_kernel: [nqt*32][2] = (score threshold = score_threshold(tau, rq), 1/|q|) per query;
+                              // the thresholds are kept by level_select_kernel; padding queries: (-1, 0)
     key_t64 *cand;            // [nq][CAND_CAP]
     unsigned int *counts;     // [nq]
     // range-filtered batches (gemm_ldsrow_kernel<.., true>): the rows to scan are the FILTER_CHUNK-row chunks of the
@@ -416,9 +416,10 @@ constexpr int RR_SLOTS = 4;
 #define SMT_RR_BDIST 2
 #endif
 constexpr int RR_BDIST = SMT_RR_BDIST;            // K-steps between the LDS read of a B quad pair and its MFMAs
-constexpr int RR_SMEM = RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF;
+constexpr int RR_QCONST = QT_ROWS * 8;            // per slot: (score threshold, 1/|q|) of the tile's 32 queries
+constexpr int RR_SMEM = RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF + RR_SLOTS * RR_QCONST;
 
-__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *rq_out, float *thr_out)
+__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst)
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -430,8 +431,8 @@ __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t 
         rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
     }
     if (lane == 0) {
-        rq_out[q] = rq;
-        thr_out[q] = score_threshold(q < nq ? __builtin_inff() : -1.0f, rq);  // padding: zero query, tau < 0 -> never passes
+        qconst[2 * q] = score_threshold(q < nq ? __builtin_inff() : -1.0f, rq);  // padding: zero query, tau < 0 -> never passes
+        qconst[2 * q + 1] = rq;
     }
 }
 
@@ -446,6 +447,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     unsigned char *tbuf = smem_raw + RR_SLOTS * QT_F4 * 16 + wave * RR_TBUF;
+    unsigned char *s_qconst = smem_raw + RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF;   // [4][32] (threshold, 1/|q|)
     const uint32_t qs = blockIdx.x % p.qsplit;
     const uint32_t row_block = blockIdx.x / p.qsplit, row_blocks = gridDim.x / p.qsplit;
     const uint32_t qt_lo = (uint32_t)((uint64_t)qs * p.nqt / p.qsplit);
@@ -461,9 +463,16 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * 256 + lane * 4,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
+    // the tile's 32 (threshold, 1/|q|) pairs: 256 B, one 4-byte DMA.  EVERY wave issues it (same bytes to the same
+    // place) so that all waves count the same number of DMA instructions per tile -- the vmcnt arithmetic below
+    auto stage_consts = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds(p.qconst + (size_t)qt * QT_ROWS * 2 + lane,
+                                         (__attribute__((address_space(3))) void *)(s_qconst + slot * RR_QCONST), 4, 0, 0);
+    };
     auto stage_tile = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < STAGE_ROWS; ++u) stage_row(qt, slot, u);
+        stage_consts(qt, slot);
     };
     auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };  // vmcnt(0)
     {
@@ -554,7 +563,10 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const uint32_t q = qt * QT_ROWS + j;
-            const float thr_q = p.thr[q], rq_q = p.rq[q];   // global (L1/L2 hits), consumed after 48 MFMAs
+            // (from LDS, staged with the tile: a global load here would sit in the same in-order vmcnt queue as the
+            // tile DMAs issued below, and waiting for it would wait for them)
+            const f32x2 qc = *reinterpret_cast<const f32x2 *>(s_qconst + slot * RR_QCONST + j * 8);
+            const float thr_q = qc.x, rq_q = qc.y;
             const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
             // B quads run RR_BDIST K-steps ahead of their MFMAs (sched_barrier: hipcc otherwise sinks every read to its
             // use and each K-step then starts with a full LDS round trip in front of 96 cycles of MFMA)
@@ -566,6 +578,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             for (int m = 0; m < 16; ++m) {
                 if (m + RR_BDIST < 16) { bh[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST)]; bl[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST) + 1]; }
                 if (m % STAGE_EVERY == 0 && m / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, m / STAGE_EVERY);
+                if (m == STAGE_EVERY * STAGE_ROWS && stage) stage_consts(stage_qt, stage_slot);
                 acc = mfma_bf16x3(Ah[m], Al[m], bh[m % NB], bl[m % NB], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -580,10 +593,10 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 const int slot = (int)(pos & 3), slot_ahead = (int)((pos + 3) & 3);   // slot_ahead was read during step pos - 1
                 if (has) tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
                 else stage_tile(qt_lo + tq_ahead, slot_ahead);
-                // this wave's share of tile pos + 1 has landed: only the 2 x STAGE_ROWS younger DMAs may still fly
+                // this wave's share of tile pos + 1 has landed: only the 2 x (STAGE_ROWS + 1) younger DMAs may still fly
                 // (a raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), i.e. it would wait
                 // for the two tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
-                __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+                __builtin_amdgcn_s_waitcnt(0x0F7A);  // vmcnt(10)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 ++pos;
@@ -1032,8 +1045,7 @@ struct LevelSelectParams {
     float *tau;
     unsigned int *overflow;  // [nq], sticky
     uint32_t kp;
-    float *thr;              // when set: score threshold of the new tau (gemm_rowreg_kernel reads it instead of tau)
-    const float *rq;
+    float *qconst;           // when set: [q][2] = (score threshold of the new tau, 1/|q|), what gemm_rowreg_kernel reads
 };
 
 __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
@@ -1062,7 +1074,7 @@ __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
         p.counts[q] = n < p.kp ? n : p.kp;
         const float tau = n >= p.kp ? __uint_as_float((unsigned)(s_best[p.kp - 1] >> 32)) : __builtin_inff();
         p.tau[q] = tau;
-        if (p.thr) p.thr[q] = score_threshold(tau, p.rq[q]);
+        if (p.qconst) p.qconst[2 * q] = score_threshold(tau, p.qconst[2 * q + 1]);
     }
 }
 
@@ -1247,7 +1259,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     unsigned int *counts = reinterpret_cast<unsigned int *>(base + b_cand);
     unsigned int *overflow = reinterpret_cast<unsigned int *>(base + b_cand + b_cnt);
     float *tau = reinterpret_cast<float *>(base + b_cand + 2 * b_cnt);
-    float *thr = tau + (size_t)nqt * QT_ROWS, *rqv = thr + (size_t)nqt * QT_ROWS;
+    float *qconst = tau + (size_t)nqt * QT_ROWS;   // [nqt*32][2]
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
     if (bf16)
@@ -1255,7 +1267,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                            nqt * QT_ROWS, q_split);
     if (rowreg)
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, rqv, thr);
+                           nqt * QT_ROWS, qconst);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -1285,8 +1297,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.skip16 = lev == 0 ? 0 : LEVEL_RATIO;
         g.qsplit = 1;
         g.tau = tau;
-        g.thr = thr;
-        g.rq = rqv;
+        g.qconst = qconst;
         g.cand = cand;
         g.counts = counts;
         g.chunk_table = filtered ? chunk_table : nullptr;
@@ -1339,8 +1350,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         ls.tau = tau;
         ls.overflow = overflow;
         ls.kp = kp;
-        ls.thr = rowreg ? thr : nullptr;
-        ls.rq = rqv;
+        ls.qconst = rowreg ? qconst : nullptr;
         prof_begin(ctx, "select");
         hipLaunchKernelGGL(level_select_kernel, dim3(a.nq), dim3(1024), 0, ctx->stream, ls);
         prof_end(ctx, "select");
