@@ -316,6 +316,8 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
     else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
     else if (k == "gemm_rowreg") ctx->tune.gemm_rowreg = (int)value;
+    else if (k == "gemm_min_nq") ctx->tune.gemm_min_nq = (int)std::max<int64_t>(2, std::min<int64_t>(8, value));
+    else if (k == "gemm_min_rows_small") ctx->tune.gemm_min_rows_small = value < 0 ? 0 : value;
     else if (k == "gemm_dma_nt") ctx->tune.gemm_dma_nt = (int)value;
     else if (k == "embed_wave_per_line") ctx->tune.embed_wave_per_line = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
@@ -897,6 +899,26 @@ static int exact_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *query_d
 
 // The body of smt_search with per-query result vectors instead of caller arrays: group.cpp runs it once per
 // local shard (threshold mode / top_k > 64, whose result sizes are not known up front) and exchanges the lists.
+
+// K2 (scan, <= 4 queries per corpus pass) or K3 (batched, one pass for the whole batch)?  8+ queries always take K3.
+// With the bf16 x 3 row-register kernel a batch costs about 1.15 single-query passes whatever its size, while a K2 pass
+// slows down with every query it carries (per row and query a DPP reduction tree: 10 M rows, 1 / 2 / 4 queries per
+// pass = 1.43 / 2.0 / 3.2 ms).  Measured on MI355X, wall ms per call, K2 | K3:
+//   10 M rows: 2 queries 2.03 | 1.77, 3: 3.54 | 1.84, 4: 3.24 | 1.71, 5: 4.83 | 1.75, 7: 6.71 | 1.77
+//    2 M rows: 2: 0.49 | 0.52, 3: 0.87 | 0.52, 4: 0.75 | 0.53;   1 M rows: 2: 0.27 | 0.36, 3: 0.44 | 0.37, 4: 0.42 | 0.37
+//  300 k rows: 3: 0.17 | 0.25 (K3's fixed cost: five level launches + selects)
+// => K3 from gemm_min_nq (3) queries on shards of gemm_min_rows_small (1 M) rows, from 2 queries on 4 x that.
+static int topk_dispatch(smt_ctx *ctx, const ScanArgs &a)
+{
+    const bool fast_k3 = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && a.n_ranges == 0;
+    const uint64_t small = (uint64_t)ctx->tune.gemm_min_rows_small;
+    const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && a.rows >= small) ||
+                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small);
+    int rc = batched ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
+    if (rc == SMT_E_UNSUPPORTED && batched) rc = launch_scan_topk(ctx, a);
+    return rc;
+}
+
 int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
                       const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out)
 {
@@ -1029,9 +1051,8 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
         a.out_dist = d_odist;
         a.out_counts = d_ocnt;
         a.out_uncertain = d_ocnt + nq;
-        // the MFMA path pays off from 8 queries up (one 32-query tile)
-        rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
-        if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
+        // K2 or K3: topk_dispatch above
+        rc = topk_dispatch(ctx, a);
         if (rc) return rc;
 
         if ((rc = ensure_pinned(ctx, o_rows + o_dist + o_cnt))) return rc;
@@ -1177,8 +1198,7 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     a.out_uncertain = uncertain_dev;
     a.allow_async = async;
     a.out_stride = (uint64_t)2 * k_pad;
-    rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
-    if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
+    rc = topk_dispatch(ctx, a);
     return rc;
 }
 
@@ -1231,8 +1251,7 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
         // nothing to scan: fill with padding through the merge kernel on zero lists
         return launch_merge_topk(ctx, out_rows_dev, out_dist_dev, 0, nq, 1, top_k, out_rows_dev, out_dist_dev);
     }
-    rc = (nq >= 8) ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
-    if (rc == SMT_E_UNSUPPORTED && nq >= 8) rc = launch_scan_topk(ctx, a);
+    rc = topk_dispatch(ctx, a);
     return rc;
 }
 

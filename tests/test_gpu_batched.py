@@ -17,6 +17,7 @@ def nominate_with(request, gpu_ctx):
     bf16, rowreg = request.param
     gpu_ctx.set_tuning("gemm_bf16x3", bf16)
     gpu_ctx.set_tuning("gemm_rowreg", rowreg)
+    gpu_ctx._rowreg_mode = bool(rowreg)
     yield bf16
     gpu_ctx.set_tuning("gemm_bf16x3", 1)
     gpu_ctx.set_tuning("gemm_rowreg", 1)
@@ -200,3 +201,37 @@ def test_nominating_distance_error_is_inside_the_certificate_bound(gpu_ctx, nomi
     print(f"max |nominating - exact| = {err:.3e} (bound {bound:.1e}, {'bf16x3' if nominate_with else 'f32 MFMA'})")
     assert err < bound / 4, err          # the compiled-in bound is a worst case; observed errors sit far inside it
     c.close()
+
+
+@pytest.mark.parametrize("nq", [2, 3, 5, 7])
+def test_two_to_seven_queries_take_the_batched_path_on_large_shards(gpu_ctx, nq, nominate_with):
+    """A K2 pass slows down with every query it carries; with the row-register kernel one K3 pass is cheaper from
+    3 queries on 1 M rows, from 2 on 4 M (topk_dispatch, tuning keys gemm_min_nq / gemm_min_rows_small).  Forced
+    here on a small corpus: same answers, and the batched kernels really ran."""
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(30000, seed=41)
+    qs = synth.unit_query(90 + nq, nq=nq)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    via_k2 = c.search(qs, top_k=7)
+    gpu_ctx.set_tuning("gemm_min_rows_small", 0)
+    gpu_ctx.set_tuning("gemm_min_nq", 2)
+    try:
+        gpu_ctx.prof_enable(True)
+        gpu_ctx.prof_reset()
+        via_k3 = c.search(qs, top_k=7)
+        launches, _ = gpu_ctx.prof_read("gemm")
+        gpu_ctx.prof_enable(False)
+    finally:
+        gpu_ctx.set_tuning("gemm_min_rows_small", 1_000_000)
+        gpu_ctx.set_tuning("gemm_min_nq", 3)
+    if nominate_with and gpu_ctx_is_rowreg(gpu_ctx):
+        assert launches > 0            # really went through K3
+    for a, b in zip(via_k2, via_k3):
+        assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+    c.close()
+
+
+def gpu_ctx_is_rowreg(ctx):
+    return getattr(ctx, "_rowreg_mode", True)

@@ -70,7 +70,7 @@ def main():
             n_g, ms_g = ctx.prof_read("gemm")
             n_s, ms_s = ctx.prof_read("select")
             ctx.prof_enable(False)
-            gemm_ms = ms_g / args.reps
+            gemm_ms = ms_g / args.reps if n_g else wall * 1e3   # (no K3 launch: the batch went through K2 passes)
             same = int(((k2_rows == out_rows).all(dim=1) & (k2_dist == out_dist).all(dim=1)).sum().item())
             passes = -(-nq // 64) if (variant == 1 and nq <= 128) else 1
             r = dict(rows=args.rows, nq=nq, gemm_ldsrow=variant, wall_ms=round(wall * 1e3, 3), gemm_ms=round(gemm_ms, 3),
