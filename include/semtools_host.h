@@ -78,6 +78,12 @@ void smt_host_session_close(smt_host_session *session);
 int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json, char **out_text);
 int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);
 int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json, char **out_text);
+/* No reference counterpart.  The workspace keeps the token ids it pooled for every stored line
+ * (line_tokens.log, written by the workspace search; SEMTOOLS_TOKEN_CACHE=0 disables it).  This call re-creates every
+ * stored vector from those ids with `model` -- a new embedding table behind the same tokenizer -- on the GPU, without
+ * reading or tokenising the source files; document metadata is untouched.  Documents without cached tokens are listed
+ * and nothing is changed.  A model with a different tokenizer is refused. */
+int smt_host_workspace_reembed(smt_host_model *model, const char *name_or_null, int json, char **out_text);
 
 void smt_host_free(char *text);
 

@@ -39,7 +39,7 @@ HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
     "smt_host_search_files", "smt_host_search_content", "smt_host_search_workspace", "smt_host_session_open",
     "smt_host_session_search", "smt_host_session_lines", "smt_host_session_close", "smt_host_workspace_use",
-    "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_free", "smt_host_timing_json", "smt_host_tokenizer_load", "smt_host_tokenizer_free",
+    "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_workspace_reembed", "smt_host_free", "smt_host_timing_json", "smt_host_tokenizer_load", "smt_host_tokenizer_free",
     "smt_host_tokenizer_encode", "smt_host_tokenizer_info", "smt_host_format_float",
     "smt_host_split_lines", "smt_host_to_lowercase",
 ]
@@ -207,6 +207,7 @@ def lib():
     L.smt_host_workspace_use.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_workspace_status.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_workspace_prune.argtypes = [vp, C.c_char_p, i32, P(vp)]
+    L.smt_host_workspace_reembed.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_free.argtypes = [vp]
     L.smt_host_free.restype = None
     L.smt_host_tokenizer_load.argtypes = [C.c_char_p, P(vp)]

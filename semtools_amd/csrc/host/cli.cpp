@@ -40,7 +40,9 @@ static int usage()
             "  workspace  Manage semtools workspaces\n\n"
             "semtools search <QUERY> [FILES]... [-n, --n-lines <N>] [--top-k <K>] [-m, --max-distance <D>]\n"
             "                [-i, --ignore-case] [-j, --json] [-w, --workspace <NAME>]\n"
-            "semtools workspace [-j, --json] use <NAME> | status [NAME] | prune [NAME]\n"
+            "semtools workspace [-j, --json] use <NAME> | status [NAME] | prune [NAME] | reembed [NAME]\n"
+            "               (reembed is not in the reference: re-creates the stored vectors from cached token ids with\n"
+            "                the model in $SEMTOOLS_MODEL_DIR -- a new table, same tokenizer -- without reading the files)\n"
             "semtools serve <FILES>... [-n N] [--top-k K] [-m D] [-i] [-j] [--batch B]\n"
             "               (resident mode, not in the reference: files embedded once, one query per stdin line;\n"
             "                each answer is what `semtools search <query> <FILES>` prints, preceded by `### <query>`)\n");
@@ -72,6 +74,16 @@ int main(int argc, char **argv)
             if (pos.size() < 2) return usage();
             if (json && !need_ctx()) return 1;
             rc = smt_host_workspace_use(ctx, pos[1].c_str(), json, &text);
+        } else if (pos[0] == "reembed") {
+            // not in the reference: re-create the stored vectors from the cached token ids with the model in
+            // $SEMTOOLS_MODEL_DIR (a new embedding table behind the same tokenizer), no source file is read
+            if (!need_ctx()) return 1;
+            const char *model_dir = getenv("SEMTOOLS_MODEL_DIR");
+            if (!model_dir) return die("SEMTOOLS_MODEL_DIR is not set (directory with model.safetensors + vocab.txt)");
+            smt_host_model *model = nullptr;
+            if (smt_host_model_from_dir(ctx, model_dir, &model) != SMT_OK) return die(smt_last_error());
+            rc = smt_host_workspace_reembed(model, pos.size() > 1 ? pos[1].c_str() : nullptr, json, &text);
+            smt_host_model_destroy(model);
         } else if (pos[0] == "status" || pos[0] == "prune") {
             if (!need_ctx()) return 1;
             const char *nm = pos.size() > 1 ? pos[1].c_str() : nullptr;

@@ -423,7 +423,7 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
 }
 
 uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
-                                  size_t batch_size, smt_corpus *corpus) const
+                                  size_t batch_size, smt_corpus *corpus, TokenCsr *sink) const
 {
     // Double-buffered pipeline: while the GPU gathers/pools batch i (H2D of the ids + K1),
     // the host threads already tokenise batch i+1.  Batches are appended in order, so rows == line order.
@@ -448,9 +448,35 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
         if (next.joinable()) next.join();
         if (next_failed) std::rethrow_exception(next_failed);
         check(rc, "encode_into");
+        if (sink) {  // (tokenize_batch already dropped unk ids and truncated: these are exactly the ids that were pooled)
+            sink->ids.insert(sink->ids.end(), slots[cur].ids.begin(), slots[cur].ids.end());
+            for (size_t i = 0; i + 1 < slots[cur].offsets.size(); ++i)
+                sink->lens.push_back((uint32_t)(slots[cur].offsets[i + 1] - slots[cur].offsets[i]));
+        }
         cur ^= 1;
     }
     return first;
+}
+
+void StaticModel::embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_corpus *corpus) const
+{
+    check(smt_embed(model_, ids, offsets, n_lines, 0, nullptr, corpus, nullptr), "embed_tokens_into");
+}
+
+uint64_t StaticModel::tokenizer_fingerprint() const
+{
+    // FNV-1a over: vocab size, unk id, median token length, and the ids of a probe text that exercises casing,
+    // accents, digits, punctuation and an unknown-looking word
+    uint64_t hsh = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { hsh ^= (v >> (8 * i)) & 0xFF; hsh *= 0x100000001b3ull; } };
+    mix(tok_->vocab_size());
+    mix(tok_->unk_id() ? (uint64_t)*tok_->unk_id() + 1 : 0);
+    mix(tok_->median_token_length());
+    std::vector<uint32_t> ids;
+    tok_->encode("The quick brown fox, jumping over 12 lazy dogs: caf\xc3\xa9 na\xc3\xaf" "ve Stra\xc3\x9f" "e _foo-bar_ w17 zqxjkv!", ids);
+    mix(ids.size());
+    for (uint32_t id : ids) mix(id);
+    return hsh ? hsh : 1;
 }
 
 std::vector<float> StaticModel::encode_single(const std::string &sentence) const
@@ -833,7 +859,11 @@ void Store::delete_line_embeddings(const std::vector<std::string> &paths)
     if (paths.empty()) return;
     for (auto &p : paths) {
         auto it = extents_.find(p);
-        if (it != extents_.end()) { dead_rows_ += it->second.n_rows; extents_.erase(it); }
+        if (it != extents_.end()) {
+            dead_rows_ += it->second.n_rows;
+            extents_.erase(it);
+            token_log_append(p, nullptr, 0);   // tombstone (no-op without a log)
+        }
     }
     compact_if_sparse();
     flush_line_embeddings();
@@ -885,17 +915,159 @@ void Store::upsert_line_embeddings(const std::vector<LineEmbedding> &line_embedd
         dead_rows_ += old_n;
         extents_[kv.first] = Extent{first, new_n};
     }
+    for (auto &kv : by_path) token_log_append(kv.first, nullptr, 0);   // vectors from outside: no tokens are known for them
     compact_if_sparse();
     flush_line_embeddings();
 }
+
+static bool token_cache_enabled();
 
 void Store::upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
                                   const search::StaticModel &model)
 {
     auto it = extents_.find(path);
     if (it != extents_.end()) dead_rows_ += it->second.n_rows;  // the whole old document is replaced (no stale tail)
-    const uint64_t first = model.encode_into(lines_for_embedding, 2048, 16384, corpus_);
+    const bool cache = token_cache_enabled();
+    search::TokenCsr tokens;
+    const uint64_t first = model.encode_into(lines_for_embedding, 2048, 16384, corpus_, cache ? &tokens : nullptr);
     extents_[path] = Extent{first, (uint64_t)lines_for_embedding.size()};
+    if (cache) token_log_append(path, &tokens, model.tokenizer_fingerprint());
+}
+
+// ---- token cache: <dir>/line_tokens.log
+//   header  : "SMTTOK01", u64 tokenizer fingerprint, u64 reserved
+//   record  : u32 'TOKD', u32 path bytes, u32 n_lines (0xFFFFFFFF = tombstone), u32 reserved, u64 n_ids,
+//             path, u32 lens[n_lines], u32 ids[n_ids]
+// Append-only; the latest record of a path wins; a torn tail record is ignored by the reader.
+static bool token_cache_enabled()
+{
+    const char *e = getenv("SEMTOOLS_TOKEN_CACHE");
+    return !(e && e[0] == '0');
+}
+static constexpr uint32_t TOK_TAG = 0x444B4F54u, TOK_TOMBSTONE = 0xFFFFFFFFu;
+
+void Store::token_log_append(const std::string &path, const search::TokenCsr *tokens, uint64_t fingerprint) const
+{
+    const std::string log = dir_ + "/line_tokens.log";
+    if (token_log_fingerprint_ == 0 && path_exists(log)) {
+        FILE *f = fopen(log.c_str(), "rb");
+        char magic[8];
+        uint64_t fp = 0;
+        if (f && fread(magic, 1, 8, f) == 8 && memcmp(magic, "SMTTOK01", 8) == 0 && fread(&fp, 8, 1, f) == 1) token_log_fingerprint_ = fp;
+        if (f) fclose(f);
+    }
+    if (!tokens && token_log_fingerprint_ == 0) return;  // tombstone into a log that does not exist: nothing to cancel
+    if (tokens && fingerprint == 0) return;
+    const bool fresh = tokens && token_log_fingerprint_ != fingerprint;   // no log yet, or tokens of ANOTHER tokenizer: start over
+    FILE *f = fopen(log.c_str(), fresh ? "wb" : "ab");
+    if (!f) throw Error("cannot open " + log + ": " + strerror(errno));
+    bool ok = true;
+    if (fresh) {
+        const uint64_t zero = 0;
+        ok = fwrite("SMTTOK01", 1, 8, f) == 8 && fwrite(&fingerprint, 8, 1, f) == 1 && fwrite(&zero, 8, 1, f) == 1;
+        token_log_fingerprint_ = fingerprint;
+    }
+    const uint32_t head[4] = {TOK_TAG, (uint32_t)path.size(), tokens ? (uint32_t)tokens->lens.size() : TOK_TOMBSTONE, 0};
+    const uint64_t n_ids = tokens ? tokens->ids.size() : 0;
+    ok = ok && fwrite(head, 4, 4, f) == 4 && fwrite(&n_ids, 8, 1, f) == 1 && fwrite(path.data(), 1, path.size(), f) == path.size();
+    if (tokens && !tokens->lens.empty()) ok = ok && fwrite(tokens->lens.data(), 4, tokens->lens.size(), f) == tokens->lens.size();
+    if (n_ids) ok = ok && fwrite(tokens->ids.data(), 4, n_ids, f) == n_ids;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) throw Error("short write to " + log);
+}
+
+Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &model)
+{
+    ReembedReport rep;
+    const std::string log = dir_ + "/line_tokens.log";
+    std::map<std::string, search::TokenCsr> cache;
+    uint64_t log_fp = 0;
+    if (FILE *f = fopen(log.c_str(), "rb")) {
+        char magic[8];
+        uint64_t reserved = 0;
+        if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "SMTTOK01", 8) == 0 && fread(&log_fp, 8, 1, f) == 1 && fread(&reserved, 8, 1, f) == 1) {
+            for (;;) {
+                uint32_t head[4];
+                uint64_t n_ids = 0;
+                if (fread(head, 4, 4, f) != 4 || head[0] != TOK_TAG || fread(&n_ids, 8, 1, f) != 1) break;
+                std::string path(head[1], '\0');
+                if (head[1] && fread(&path[0], 1, head[1], f) != head[1]) break;
+                if (head[2] == TOK_TOMBSTONE) { cache.erase(path); continue; }
+                search::TokenCsr t;
+                t.lens.resize(head[2]);
+                t.ids.resize(n_ids);
+                if (head[2] && fread(t.lens.data(), 4, head[2], f) != head[2]) break;   // torn tail: ignore it
+                if (n_ids && fread(t.ids.data(), 4, n_ids, f) != n_ids) break;
+                cache[path] = std::move(t);
+            }
+        }
+        fclose(f);
+    }
+    if (log_fp != 0 && log_fp != model.tokenizer_fingerprint())
+        throw Error("the cached tokens were produced by a different tokenizer than this model's; re-embed from the source files");
+    // every live document needs a record that matches its extent
+    std::vector<std::pair<uint64_t, std::string>> order;
+    for (auto &kv : extents_) {
+        auto it = cache.find(kv.first);
+        uint64_t sum = 0;
+        if (it != cache.end()) for (uint32_t l : it->second.lens) sum += l;
+        if (it == cache.end() || it->second.lens.size() != kv.second.n_rows || sum != it->second.ids.size()) rep.missing.push_back(kv.first);
+        order.emplace_back(kv.second.first_row, kv.first);
+    }
+    if (!rep.missing.empty()) return rep;   // nothing changed
+    std::sort(order.begin(), order.end());
+    const uint64_t live = smt_corpus_rows(corpus_) - dead_rows_;
+    smt_corpus *fresh = nullptr;
+    check(smt_corpus_create(ctx_, SMT_DIM, live, &fresh), "reembed");
+    try {
+        // batches of about 16384 lines, like encode_with_args' batch size
+        std::vector<uint32_t> ids;
+        std::vector<uint64_t> offsets(1, 0);
+        auto flush = [&]() {
+            if (offsets.size() > 1) model.embed_tokens_into(ids.data(), offsets.data(), offsets.size() - 1, fresh);
+            ids.clear();
+            offsets.assign(1, 0);
+        };
+        for (auto &o : order) {
+            const search::TokenCsr &t = cache[o.second];
+            Extent &x = extents_[o.second];
+            x.first_row = smt_corpus_rows(fresh) + (offsets.size() - 1);
+            ids.insert(ids.end(), t.ids.begin(), t.ids.end());
+            for (uint32_t l : t.lens) offsets.push_back(offsets.back() + l);
+            rep.documents += 1;
+            rep.lines += t.lens.size();
+            rep.tokens += t.ids.size();
+            if (offsets.size() > 16384) flush();
+        }
+        flush();
+    } catch (...) { smt_corpus_destroy(fresh); throw; }
+    smt_corpus_destroy(corpus_);
+    corpus_ = fresh;
+    dead_rows_ = 0;
+    rows_on_disk_valid_ = false;
+    if (index_) { smt_ivfpq_destroy(index_); index_ = nullptr; }
+    if (index_on_disk_) { (void)remove((dir_ + "/line_index.ivf").c_str()); index_on_disk_ = false; }
+    flush_line_embeddings();
+    // rewrite the log with one record per live document (drops superseded records and tombstones)
+    const std::string tmp = log + ".tmp";
+    {
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) throw Error("cannot open " + tmp + ": " + strerror(errno));
+        const uint64_t fp = model.tokenizer_fingerprint(), zero = 0;
+        bool ok = fwrite("SMTTOK01", 1, 8, f) == 8 && fwrite(&fp, 8, 1, f) == 1 && fwrite(&zero, 8, 1, f) == 1;
+        for (auto &o : order) {
+            const search::TokenCsr &t = cache[o.second];
+            const uint32_t head[4] = {TOK_TAG, (uint32_t)o.second.size(), (uint32_t)t.lens.size(), 0};
+            const uint64_t n_ids = t.ids.size();
+            ok = ok && fwrite(head, 4, 4, f) == 4 && fwrite(&n_ids, 8, 1, f) == 1 && fwrite(o.second.data(), 1, o.second.size(), f) == o.second.size();
+            if (!t.lens.empty()) ok = ok && fwrite(t.lens.data(), 4, t.lens.size(), f) == t.lens.size();
+            if (n_ids) ok = ok && fwrite(t.ids.data(), 4, n_ids, f) == n_ids;
+        }
+        ok = (fclose(f) == 0) && ok;
+        if (!ok || rename(tmp.c_str(), log.c_str()) != 0) throw Error("cannot rewrite " + log);
+        token_log_fingerprint_ = fp;
+    }
+    return rep;
 }
 
 void Store::compact_if_sparse()

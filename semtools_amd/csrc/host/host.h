@@ -67,6 +67,14 @@ struct PhaseTimer {
     static std::string json();             // {"phase": ms, ...} in order of first appearance
 };
 
+// The token ids StaticModel pooled for a run of lines (unk ids dropped, truncated to max_length): lens[i] ids per line.
+// The workspace keeps them (line_tokens.log) so that a new embedding table for the same tokenizer can re-embed the
+// whole store on the GPU without reading or tokenising a single source file.
+struct TokenCsr {
+    std::vector<uint32_t> ids;
+    std::vector<uint32_t> lens;
+};
+
 class StaticModel {
 public:
     // table: [V x 256] f32 host array (the `embeddings` tensor), uploaded once.
@@ -81,8 +89,13 @@ public:
     std::vector<std::vector<float>> encode_with_args(const std::vector<std::string> &sentences,
                                                      std::optional<size_t> max_length, size_t batch_size) const;
     // same, but the rows are appended to `corpus` (resident); returns the first new row
+    // (sink, if given, receives the pooled token ids of every sentence in order)
     uint64_t encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
-                         size_t batch_size, smt_corpus *corpus) const;
+                         size_t batch_size, smt_corpus *corpus, TokenCsr *sink = nullptr) const;
+    // pool step only: n_lines lines given as token CSR (already filtered / truncated) appended to `corpus`
+    void embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_corpus *corpus) const;
+    // identifies the tokenizer (vocab size, unk id, ids of a fixed probe text): cached tokens are only valid for it
+    uint64_t tokenizer_fingerprint() const;
     // encode_single(text) = encode(&[text]) -> max_length 512, batch 1024
     std::vector<float> encode_single(const std::string &sentence) const;
 
@@ -247,6 +260,16 @@ public:
     // Rows of replaced / deleted documents stay behind until they exceed half the matrix; then live extents are
     // rewritten back to back (row order preserved).  Called after every batch of upserts and deletes.
     void compact_if_sparse();
+    // Token cache.  upsert_document_lines appends the pooled token ids of every document it embeds to
+    // <dir>/line_tokens.log (append-only records, the latest record of a path wins, deletions write tombstones;
+    // SEMTOOLS_TOKEN_CACHE=0 turns it off).  reembed_from_token_cache re-creates every stored vector from those ids
+    // with `model` -- a new embedding table behind the SAME tokenizer (fingerprint checked) -- on the GPU, in row
+    // order, without touching the source files; documents without a usable record are reported and nothing changes.
+    struct ReembedReport {
+        uint64_t documents = 0, lines = 0, tokens = 0;
+        std::vector<std::string> missing;   // documents whose tokens are not cached (re-embed them from their files)
+    };
+    ReembedReport reembed_from_token_cache(const search::StaticModel &model);
     // Approximate index policy.  Whole-workspace searches (the path subset covers every stored document) over at
     // least `min_rows` rows go through an IVF index with per-list PCA codes (smt_ivfpq_*, local_pca = 1) that lives
     // beside the vectors (`line_index.ivf`), is extended incrementally when rows are appended and rebuilt when rows
@@ -275,6 +298,8 @@ private:
     mutable bool index_on_disk_ = false;
     mutable uint64_t index_built_rows_ = 0;      // corpus rows when the quantisers were trained
     size_t oversample_factor_ = 3;
+    void token_log_append(const std::string &path, const search::TokenCsr *tokens, uint64_t fingerprint) const;  // null = tombstone
+    mutable uint64_t token_log_fingerprint_ = 0;   // fingerprint in the log's header (0 = not read yet / no log)
     uint64_t index_min_rows_ = 2'000'000;
     uint32_t index_nprobe_ = 16;
 };

@@ -385,6 +385,40 @@ int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json_o
     } catch (const std::exception &e) { return fail(e); }
 }
 
+int smt_host_workspace_reembed(smt_host_model *model, const char *name_or_null, int json_out, char **out_text)
+{
+    if (!model || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    *out_text = nullptr;
+    try {
+        std::optional<std::string> nm;
+        if (name_or_null) nm = name_or_null;
+        try { workspace::Workspace::active(nm); } catch (const Error &) { throw Error("No active workspace"); }
+        const auto ws = workspace::Workspace::open(nm);
+        auto store = workspace::Store::open(ws.config.root_dir, model->m->ctx());
+        const auto rep = store->reembed_from_token_cache(*model->m);
+        std::string out;
+        if (json_out) {
+            json::Value o = json::Value::object();
+            o.set("documents_reembedded", json::Value::uint(rep.documents));
+            o.set("lines_reembedded", json::Value::uint(rep.lines));
+            o.set("tokens_pooled", json::Value::uint(rep.tokens));
+            json::Value miss = json::Value::array();
+            for (auto &p : rep.missing) miss.arr.push_back(json::Value::str(p));
+            o.set("documents_without_cached_tokens", std::move(miss));
+            out = json::to_string_pretty(o) + "\n";
+        } else if (!rep.missing.empty()) {
+            out = "No cached tokens for " + std::to_string(rep.missing.size()) + " documents (nothing was changed):\n";
+            for (auto &p : rep.missing) out += "  - " + p + "\n";
+            out += "Search them once with this model to re-embed them from their files.\n";
+        } else {
+            out = "Re-embedded " + std::to_string(rep.lines) + " lines of " + std::to_string(rep.documents) +
+                  " documents from cached tokens (" + std::to_string(rep.tokens) + " tokens).\n";
+        }
+        *out_text = dup_text(out);
+        return SMT_OK;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
 int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json_out, char **out_text)
 {
     if (!ctx || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }

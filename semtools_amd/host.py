@@ -156,6 +156,13 @@ def workspace_prune(ctx, name=None, json=False):
     return _take_text(out)
 
 
+def workspace_reembed(model, name=None, json=False):
+    """Re-create every stored vector of the workspace from its cached token ids with `model` (smt_host_workspace_reembed)."""
+    out = C.c_void_p()
+    L.check(L.lib().smt_host_workspace_reembed(model._h, name.encode() if name else None, int(json), C.byref(out)))
+    return _take_text(out)
+
+
 def format_float(value, mode):
     return _take_text(L.lib().smt_host_format_float(float(value), int(mode)))
 

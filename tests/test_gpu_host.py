@@ -252,6 +252,86 @@ def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, ca
     assert all(h[0] == str(b) for h in parse(out5)) and len(parse(out5)) == 5
 
 
+def test_workspace_reembed_from_cached_tokens(gpu_ctx, model, model_dir, prose_files, tmp_path, monkeypatch, capfd):
+    """the workspace keeps the token ids it pooled (line_tokens.log); a new embedding table behind the
+    same tokenizer re-embeds the store on the GPU without reading a source file.  Vectors = the oracle's for the new
+    table, bit for bit; a different tokenizer is refused; a store without cached tokens is left alone."""
+    import semtools_amd as smt
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    la, lb = prose_files[1][1][:15], prose_files[0][1][495:505] + prose_files[0][1][598:603]   # incl. an empty and an all-unk line
+    a.write_text("\n".join(la) + "\n")
+    b.write_text("\n".join(lb) + "\n")
+    files = [str(a), str(b)]
+    host.workspace_use(None, "tk")
+    host.search_with_workspace(model, la[2], files, workspace_name="tk", n_lines=0, top_k=3)
+    # replace a (its first record in the log is superseded)
+    la = la[:9] + ["w5 w6 w7 w5"]
+    a.write_text("\n".join(la) + "\n")
+    os.utime(a, (1_900_000_000, 1_900_000_000))
+    host.search_with_workspace(model, la[2], files, workspace_name="tk", n_lines=0, top_k=3)
+    capfd.readouterr()
+    root = tmp_path / ".semtools" / "workspaces" / "tk"
+    assert (root / "line_tokens.log").exists()
+
+    table2 = synth.table(V, seed=77)                                   # "the next version of the model": same tokenizer
+    model2 = host.StaticModel(gpu_ctx, table=table2, tokenizer=("vocab", model_dir[0] / "vocab.txt", "[UNK]"))
+    try:
+        a.rename(tmp_path / "a.away")                                   # no source file is needed ...
+        b.rename(tmp_path / "b.away")
+        txt = host.workspace_reembed(model2, "tk")
+        assert txt == f"Re-embedded {len(la) + len(lb)} lines of 2 documents from cached tokens ({sum(len(tok(l)) for l in la + lb)} tokens).\n"
+        (tmp_path / "a.away").rename(a)
+        (tmp_path / "b.away").rename(b)
+        os.utime(a, (1_900_000_000, 1_900_000_000))
+        c = smt.Corpus.load(gpu_ctx, str(root / "line_embeddings.f32"))
+        got = c.read_rows(0, c.rows)
+        c.close()
+        rows = json.loads((root / "line_rows.json").read_text())["extents"]
+        ext = {e["path"]: (e["first_row"], e["n_rows"]) for e in rows}
+        assert ext[str(a)][1] == len(la) and ext[str(b)][1] == len(lb) and len(got) == len(la) + len(lb)   # compacted: live rows only
+        for path, lines in ((str(a), la), (str(b), lb)):
+            f0, n = ext[path]
+            assert np.array_equal(got[f0:f0 + n], oracle_embed(table2, lines, 2048)), path
+        # ... and the next search with the new model finds everything unchanged (nothing re-embedded) and uses the new vectors
+        out = host.search_with_workspace(model2, lb[3], files, workspace_name="tk", n_lines=0, top_k=2)
+        assert capfd.readouterr().err == ""
+        assert out.split("\n")[0].startswith(f"{b}:3::4 (")
+        js = json.loads(host.workspace_reembed(model2, "tk", json=True))
+        assert js["documents_reembedded"] == 2 and js["documents_without_cached_tokens"] == []
+
+        # the CLI form (model from $SEMTOOLS_MODEL_DIR: back to the first table)
+        env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]))
+        r = subprocess.run([CLI, "workspace", "reembed", "tk"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith(f"Re-embedded {len(la) + len(lb)} lines of 2 documents"), r.stderr
+        ext = {e["path"]: e["first_row"] for e in json.loads((root / "line_rows.json").read_text())["extents"]}
+        c = smt.Corpus.load(gpu_ctx, str(root / "line_embeddings.f32"))
+        assert np.array_equal(c.read_rows(ext[str(a)], len(la)), oracle_embed(model_dir[1], la, 2048))
+        c.close()
+
+        # a model with another tokenizer is refused
+        other = host.StaticModel(gpu_ctx, table=table2, tokenizer="hash")
+        with pytest.raises(Exception, match="different tokenizer"):
+            host.workspace_reembed(other, "tk")
+        other.close()
+
+        # a workspace filled with the cache turned off: reported, untouched
+        monkeypatch.setenv("SEMTOOLS_TOKEN_CACHE", "0")
+        host.workspace_use(None, "nocache")
+        host.search_with_workspace(model, la[2], files, workspace_name="nocache", n_lines=0, top_k=3)
+        monkeypatch.delenv("SEMTOOLS_TOKEN_CACHE")
+        root2 = tmp_path / ".semtools" / "workspaces" / "nocache"
+        before = (root2 / "line_embeddings.f32").read_bytes()
+        txt = host.workspace_reembed(model2, "nocache")
+        assert txt.startswith("No cached tokens for 2 documents (nothing was changed):") and f"  - {a}\n" in txt
+        assert (root2 / "line_embeddings.f32").read_bytes() == before
+    finally:
+        model2.close()
+
+
 def test_workspace_survives_a_damaged_store(model, model_dir, prose_files, tmp_path, monkeypatch, capfd):
     """Crash consistency: a truncated line_embeddings.f32, or metadata whose line rows are gone, must
     lead to a re-embed -- not to a dead workspace, and not to documents that silently drop out of the search."""
