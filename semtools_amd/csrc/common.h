@@ -65,6 +65,7 @@ struct Tuning {
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel (superseded)
     int embed_wave_per_line = 0; // K1: 1 = one wave per line (whole-row gathers), 0 = 16 lanes per line (4 lines per wave)
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
+    int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
     int gemm_min_nq = 3;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
     int64_t gemm_min_rows_small = 1000000;   // (2 queries: 4 x this; api.cpp topk_dispatch)
     int gemm_rowreg = 1;        // 1: with gemm_bf16x3, unfiltered batches use gemm_rowreg_kernel (coalesced row loads + LDS transpose)

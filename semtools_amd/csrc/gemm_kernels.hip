@@ -1194,7 +1194,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (a.k_out + 8 > 64 || a.k_out < 1) { set_error("batched path: top_k must be in [1, 56]"); return SMT_E_UNSUPPORTED; }
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const bool filtered = a.n_ranges != 0;
-    const uint32_t kp = a.k_out + 8;
+    const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)ctx->tune.guard_band);  // see candidates_per_list (scan_kernels.hip)
     const uint32_t nqt = (a.nq + QT_ROWS - 1) / QT_ROWS;
     const uint64_t ostride = a.out_stride ? a.out_stride : a.k_out;
     // Which kernel (measured on MI355X, 10 M rows, ms per batch: LDS-row kernel / gemm_level_kernel):

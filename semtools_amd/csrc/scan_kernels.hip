@@ -818,12 +818,14 @@ __global__ void merge_topk_kernel(const uint64_t *rows, const double *dist, uint
 }
 
 // ------------------------------------------------------------------ launchers
-static inline uint32_t candidates_per_list(uint32_t k_out)
+static inline uint32_t candidates_per_list(const smt_ctx *ctx, uint32_t k_out)
 {
     // guard band: 8 extra f32 candidates so that f32-vs-f64 rank flips at the k-th boundary do not drop a true
     // top-k row; the select stage PROVES per query that the band was wide enough (SelectArgs::f32_err) and flags
-    // the query otherwise.  k_out <= SCAN_MAX_K = 56, so the band never shrinks.
-    return k_out + 8;
+    // the query otherwise.  k_out <= SCAN_MAX_K = 56, so the band never shrinks below 8; tuning key guard_band widens
+    // it (lists hold at most 64 keys) for corpora with many near-duplicate lines -- every proof that succeeds saves
+    // the exhaustive re-answer, at the price of a longer select (256 lists x k' keys).
+    return std::min<uint32_t>(64, k_out + (uint32_t)ctx->tune.guard_band);
 }
 
 template <int NQ, int U>
@@ -903,7 +905,7 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
     SMT_REQUIRE(a.k_out >= 1 && a.k_out <= SCAN_MAX_K, "top_k for the scan path must be in [1, 56]");
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const bool filtered = a.n_ranges > 0;
-    const uint32_t kp = candidates_per_list(a.k_out);
+    const uint32_t kp = candidates_per_list(ctx, a.k_out);
     int blocks = ctx->tune.scan_blocks > 0 ? ctx->tune.scan_blocks : ctx->num_cus;
     if (blocks > SEL_MAX_LISTS) blocks = SEL_MAX_LISTS;
     const int threads = ctx->tune.scan_threads;

@@ -131,6 +131,19 @@ def test_device_entry_point_counts_what_it_cannot_prove(gpu_ctx):
     c.search_topk_device(qd.data_ptr(), 1, 10, 0, o_rows.data_ptr(), o_dist.data_ptr())
     gpu_ctx.synchronize()
     assert gpu_ctx.uncertain_count() == 1                      # 40 near-ties around the 10th place: no certificate
+    # a wider guard band (tuning key guard_band: 10 + 54 = all 64 list slots) holds the whole cluster: proved exact
+    gpu_ctx.set_tuning("guard_band", 54)
+    try:
+        exp_rows, exp_dist = _oracle_topk(emb, q, 10)
+        c.search_topk_device(qd.data_ptr(), 1, 10, 0, o_rows.data_ptr(), o_dist.data_ptr())
+        gpu_ctx.synchronize()
+        assert gpu_ctx.uncertain_count() == 0
+        assert o_rows.cpu().tolist() == exp_rows and np.array_equal(o_dist.cpu().numpy(), exp_dist)
+        qs = np.stack([q] * 9)                                 # ... through K3 as well
+        got = c.search(qs, top_k=10)
+        assert all(g[0].tolist() == exp_rows for g in got)
+    finally:
+        gpu_ctx.set_tuning("guard_band", 8)
     easy = torch.from_numpy(synth.unit_query(3)[0]).cuda()
     torch.cuda.synchronize()
     c.search_topk_device(easy.data_ptr(), 1, 10, 0, o_rows.data_ptr(), o_dist.data_ptr())
