@@ -359,6 +359,8 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
 /* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
  *   scan_blocks, scan_threads, scan_unroll (2/4/8/16), scan_nontemporal   K2 launch shape
  *   gemm_blocks, gemm_resident, gemm_qsplit, gemm_ldsrow, gemm_dma_nt      K3
+ *   fallback_batch_min_rows   two or more uncertain queries of one call on a shard of at least this many rows (100 000)
+ *                        are re-answered by ONE batched threshold pass instead of one exhaustive scan each
  *   guard_band (8..56)   the scans nominate min(64, top_k + guard_band) rows per list; the exactness proof tolerates that
  *                        many near-ties around the k-th place before a query has to be re-answered exhaustively
  *   gemm_min_nq, gemm_min_rows_small   from this many queries (default 3; 8+ always) on shards of this many rows (1 M)

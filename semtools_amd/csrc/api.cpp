@@ -316,6 +316,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
     else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
     else if (k == "gemm_rowreg") ctx->tune.gemm_rowreg = (int)value;
+    else if (k == "fallback_batch_min_rows") ctx->tune.fallback_batch_min_rows = value < 0 ? 0 : value;
     else if (k == "guard_band") ctx->tune.guard_band = (int)std::max<int64_t>(8, std::min<int64_t>(56, value));
     else if (k == "gemm_min_nq") ctx->tune.gemm_min_nq = (int)std::max<int64_t>(2, std::min<int64_t>(8, value));
     else if (k == "gemm_min_rows_small") ctx->tune.gemm_min_rows_small = value < 0 ? 0 : value;
@@ -898,6 +899,83 @@ static int exact_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *query_d
     return SMT_OK;
 }
 
+// The same re-answer for MANY queries of one call at once.  One sweep of the batched kernel collects, per query, every
+// row whose nominating distance is <= bound + F32_ERR_BF16X3 (a superset of the rows with exact distance <= bound);
+// they are re-scored exactly, ordered (distance, row) and cut at k -- what exact_fallback does with one K4 scan per
+// query.  Queries whose band holds more rows than a candidate buffer (2048) come back in `left` for the K4 route.
+static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queries_dev, const std::vector<uint32_t> &redo,
+                            const std::vector<double> &bounds, uint32_t k_eff, bool ws_thr, float thr_score, uint64_t row_base,
+                            std::vector<LocalHits> &out, std::vector<uint32_t> &left)
+{
+    const uint32_t n = (uint32_t)redo.size();
+    float *d_qc = nullptr;   // compact copies of the uncertain queries + their f32 thresholds (rare path: plain hipMalloc)
+    SMT_HIP_CHECK(hipMalloc(&d_qc, (size_t)n * (SMT_DIM + 1) * sizeof(float)));
+    struct Free { float *p; ~Free() { (void)hipFree(p); } } guard{d_qc};
+    float *d_tau = d_qc + (size_t)n * SMT_DIM;
+    std::vector<float> tau(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        SMT_HIP_CHECK(hipMemcpyAsync(d_qc + (size_t)i * SMT_DIM, queries_dev + (size_t)redo[i] * SMT_DIM, SMT_DIM * sizeof(float),
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+        tau[i] = std::nextafter((float)(bounds[i] + F32_ERR_BF16X3), std::numeric_limits<float>::infinity());
+    }
+    SMT_HIP_CHECK(hipMemcpyAsync(d_tau, tau.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const key_t64 *d_cand = nullptr;
+    const unsigned int *d_cnt = nullptr;
+    uint32_t stride = 0;
+    int rc = launch_gemm_threshold(ctx, corpus->d_rows, corpus->rows, d_qc, n, d_tau, &d_cand, &d_cnt, &stride);
+    if (rc) return rc;
+    std::vector<unsigned int> cnt(n);
+    std::vector<key_t64> keys((size_t)n * stride);
+    SMT_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, n * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipMemcpyAsync(keys.data(), d_cand, keys.size() * sizeof(key_t64), hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // exact distances of every collected row (the scratch that held the candidates is free again)
+    std::vector<uint32_t> rows;
+    std::vector<uint64_t> first(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        first[i] = rows.size();
+        if (cnt[i] > stride) continue;   // overflow: K4
+        for (uint32_t c = 0; c < cnt[i]; ++c) rows.push_back((uint32_t)(keys[(size_t)i * stride + c] & 0xFFFFFFFFull));
+    }
+    first[n] = rows.size();
+    std::vector<double> dist(rows.size());
+    if (!rows.empty()) {
+        const size_t b_rows = (rows.size() * sizeof(uint32_t) + 255) & ~(size_t)255;
+        if ((rc = ensure_scratch(ctx, b_rows + rows.size() * sizeof(double)))) return rc;
+        uint32_t *d_rows = reinterpret_cast<uint32_t *>(ctx->d_scratch);
+        double *d_dist = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_scratch) + b_rows);
+        SMT_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t m = (cnt[i] > stride) ? 0 : first[i + 1] - first[i];
+            if (m && (rc = launch_rescore_rows(ctx, corpus->d_rows, d_qc + (size_t)i * SMT_DIM, d_rows + first[i], m, d_dist + first[i]))) return rc;
+        }
+        SMT_HIP_CHECK(hipMemcpyAsync(dist.data(), d_dist, rows.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (cnt[i] > stride) { left.push_back(redo[i]); continue; }
+        std::vector<uint64_t> order;
+        for (uint64_t c = first[i]; c < first[i + 1]; ++c) {
+            if (!(dist[c] <= bounds[i])) continue;                                   // (also drops NaN)
+            if (ws_thr && !((1.0 - dist[c]) > (double)thr_score)) continue;         // store.rs:502-503
+            order.push_back(c);
+        }
+        std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+            if (dist[x] != dist[y]) return dist[x] < dist[y];
+            return rows[x] < rows[y];
+        });
+        LocalHits &o = out[redo[i]];
+        o.rows.clear();
+        o.dist.clear();
+        for (uint64_t c : order) {
+            if (o.rows.size() >= k_eff) break;
+            o.rows.push_back(row_base + rows[c]);
+            o.dist.push_back(dist[c]);
+        }
+    }
+    return SMT_OK;
+}
+
 // The body of smt_search with per-query result vectors instead of caller arrays: group.cpp runs it once per
 // local shard (threshold mode / top_k > 64, whose result sizes are not known up front) and exchanges the lists.
 
@@ -1070,12 +1148,24 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
             if (h_cnt[nq + q]) redo.push_back(q);  // (h_pinned is reused by the fallback: copy everything out first)
         }
         // queries whose f32 nomination could not be proven sufficient (a cluster of near-ties around the k-th
-        // place that is wider than the guard band): answer them exhaustively
+        // place that is wider than the guard band): answer them exhaustively -- several of them with ONE batched
+        // threshold pass over the shard (batched_fallback), the rest (and whatever overflows there) one K4 scan each
+        const bool ws_thr = a.ws_threshold != 0;
+        auto bound_of = [&](uint32_t q) {
+            return out[q].rows.size() == k_eff ? out[q].dist.back() : 1.0 - (double)a.ws_thr_score;
+        };
+        if (nr == 0 && redo.size() >= 2 && ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg &&
+            corpus->rows >= (uint64_t)ctx->tune.fallback_batch_min_rows) {
+            std::vector<double> bounds;
+            for (uint32_t q : redo) bounds.push_back(bound_of(q));
+            std::vector<uint32_t> left;
+            rc = batched_fallback(ctx, corpus, d_q, redo, bounds, k_eff, ws_thr, a.ws_thr_score, row_base, out, left);
+            if (rc) return rc;
+            redo.swap(left);
+        }
         for (uint32_t q : redo) {
-            const bool ws_thr = a.ws_threshold != 0;
-            const double bound = out[q].rows.size() == k_eff ? out[q].dist.back() : 1.0 - (double)a.ws_thr_score;
             rc = exact_fallback(ctx, corpus, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr, nr ? d_cp : nullptr, nr, n_virtual,
-                                n_chunks, bound, k_eff, ws_thr, a.ws_thr_score, row_base, out[q]);
+                                n_chunks, bound_of(q), k_eff, ws_thr, a.ws_thr_score, row_base, out[q]);
             if (rc) return rc;
         }
         return SMT_OK;

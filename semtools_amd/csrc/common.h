@@ -65,6 +65,7 @@ struct Tuning {
     int gemm_resident = 1;      // 1: batches <= 128 queries use the resident-query, double-buffered-row kernel (superseded)
     int embed_wave_per_line = 0; // K1: 1 = one wave per line (whole-row gathers), 0 = 16 lanes per line (4 lines per wave)
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
+    int64_t fallback_batch_min_rows = 100000;   // >= 2 uncertain queries of a call on a shard this large are re-answered by ONE batched threshold pass
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
     int gemm_min_nq = 3;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
     int64_t gemm_min_rows_small = 1000000;   // (2 queries: 4 x this; api.cpp topk_dispatch)
@@ -284,6 +285,9 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
 
 // K3: batched queries, f32 MFMA with fused candidate selection.
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);
+// batched threshold pass (gemm_kernels.hip): rows with nominating distance <= tau[q], per query, in scratch buffers
+int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const float *queries, uint32_t nq,
+                          const float *tau, const key_t64 **cand_out, const unsigned int **counts_out, uint32_t *cand_stride);
 // test hook: the nominating f32 distances of the K3 kernels for <= 32 queries (gemm_kernels.hip)
 int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_row, uint32_t n_rows, const float *queries,
                              uint32_t nq, float *out);

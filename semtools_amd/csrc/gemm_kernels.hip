@@ -1189,6 +1189,28 @@ static size_t gemm_smem_bytes(uint32_t nqt)
     return (size_t)4 * QT_F4 * 16 + (size_t)nqt * QT_ROWS * 4 * 2 + 64;
 }
 
+static int ensure_gemm_attrs(smt_ctx *ctx)
+{
+    if (!(ctx->attr_done & ATTR_GEMM)) {  // per context == per device
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK((lr_set_attr<false>()));
+        SMT_HIP_CHECK((lr_set_attr<true>()));
+        ctx->attr_done |= ATTR_GEMM;
+    }
+    return SMT_OK;
+}
+
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
 {
     if (a.k_out + 8 > 64 || a.k_out < 1) { set_error("batched path: top_k must be in [1, 56]"); return SMT_E_UNSUPPORTED; }
@@ -1225,23 +1247,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     }
     if (gemm_smem_bytes(nqt) > 160 * 1024) { set_error("batch too large for one launch"); return SMT_E_UNSUPPORTED; }
 
-    if (!(ctx->attr_done & ATTR_GEMM)) {  // per context == per device
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK((lr_set_attr<false>()));
-        SMT_HIP_CHECK((lr_set_attr<true>()));
-        ctx->attr_done |= ATTR_GEMM;
-    }
+    if (int rc_attr = ensure_gemm_attrs(ctx)) return rc_attr;
 
     // scratch: cand [nq][CAP] keys | counts [nq] | overflow [nq] | tau [nqt*32] | split queries [nqt*32][1 KiB] | chunk table
     const bool bf16 = ctx->tune.gemm_bf16x3 != 0;
@@ -1394,6 +1400,66 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         one.out_uncertain = a.out_uncertain ? a.out_uncertain + q : nullptr;
         if ((rc = launch_scan_topk(ctx, one))) return rc;
     }
+    return SMT_OK;
+}
+
+__global__ void set_qconst_thresholds_kernel(float *qconst, const float *tau, uint32_t nq)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) qconst[2 * q] = score_threshold(tau[q], qconst[2 * q + 1]);
+}
+
+// ---- batched threshold pass: the exhaustive re-answer of MANY uncertain queries in one sweep (api.cpp).  Every row
+// whose nominating distance is <= tau[q] lands in query q's candidate buffer: gemm_rowreg_kernel over all tiles as a
+// single level with preset thresholds.  A query with more than CAND_CAP such rows reports count > CAND_CAP (the caller
+// re-answers it with the streaming K4 scan).  Buffers live in the context's scratch until the next launch.
+int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const float *queries, uint32_t nq,
+                          const float *tau, const key_t64 **cand_out, const unsigned int **counts_out, uint32_t *cand_stride)
+{
+    SMT_REQUIRE(nq >= 1 && rows >= 1 && rows < 0xFFFFFFFFull, "threshold pass: bad sizes");
+    if (int rc_attr = ensure_gemm_attrs(ctx)) return rc_attr;
+    const uint32_t nqt = (nq + QT_ROWS - 1) / QT_ROWS;
+    const size_t b_cand = (size_t)nq * CAND_CAP * sizeof(key_t64);
+    const size_t b_cnt = (((size_t)nq * 4) + 255) & ~(size_t)255;
+    const size_t b_qc = (((size_t)nqt * QT_ROWS * 8) + 255) & ~(size_t)255;
+    const size_t b_split = (size_t)nqt * QT_ROWS * 1024;
+    int rc = ensure_scratch(ctx, b_cand + b_cnt + b_qc + b_split + 256);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(ctx->d_scratch);
+    key_t64 *cand = reinterpret_cast<key_t64 *>(base);
+    unsigned int *counts = reinterpret_cast<unsigned int *>(base + b_cand);
+    float *qconst = reinterpret_cast<float *>(base + b_cand + b_cnt);
+    uint32_t *q_split = reinterpret_cast<uint32_t *>(base + b_cand + b_cnt + b_qc);
+    SMT_HIP_CHECK(hipMemsetAsync(counts, 0, b_cnt, ctx->stream));
+    hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, q_split);
+    hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, qconst);
+    hipLaunchKernelGGL(set_qconst_thresholds_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, qconst, tau, nq);
+    GemmParams g;
+    g.corpus = corpus;
+    g.n_rows = rows;
+    g.queries = queries;
+    g.queries_split = q_split;
+    g.nq = nq;
+    g.nqt = nqt;
+    g.level_tiles = (rows + 31) / 32;
+    g.stride = 1;
+    g.skip16 = 0;
+    g.qsplit = 1;
+    g.tau = nullptr;
+    g.qconst = qconst;
+    g.cand = cand;
+    g.counts = counts;
+    g.chunk_table = nullptr;
+    g.n_chunks = 0;
+    const int blocks = ctx->tune.gemm_blocks > 0 ? ctx->tune.gemm_blocks : ctx->num_cus;
+    const int nb = (int)std::min<uint64_t>((uint64_t)blocks, (g.level_tiles + RR_WAVES - 1) / RR_WAVES);
+    prof_begin(ctx, "gemm_thr");
+    hipLaunchKernelGGL(gemm_rowreg_kernel, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+    prof_end(ctx, "gemm_thr");
+    SMT_HIP_CHECK(hipGetLastError());
+    *cand_out = cand;
+    *counts_out = counts;
+    *cand_stride = CAND_CAP;
     return SMT_OK;
 }
 

@@ -152,6 +152,53 @@ def test_device_entry_point_counts_what_it_cannot_prove(gpu_ctx):
     c.close()
 
 
+def test_many_uncertain_queries_are_reanswered_by_one_batched_pass(gpu_ctx):
+    """A batch whose queries ALL sit on near-tie clusters: instead of one exhaustive K4 scan per query the host entry
+    point runs ONE batched threshold pass (api.cpp batched_fallback) -- same answers as the oracle, and the pass is
+    visible to the profiler as exactly one `gemm_thr` launch.  A band wider than a candidate buffer overflows into
+    the per-query route."""
+    import semtools_amd as smt
+
+    rng = np.random.default_rng(9)
+    emb = synth.unit_rows(6000, seed=31, dup_frac=0.0, zero_frac=0.0)
+    queries, spots = [], rng.permutation(6000)
+    at = 0
+    for c in range(10):                                           # ten queries, each with its own 30-row near-tie cluster
+        q = _unit(rng.standard_normal(256))
+        v = _unit(q + 0.8 * _unit(rng.standard_normal(256)))
+        for i in range(30):
+            row = v.copy() if i % 2 else (v * np.float32(0.5 + 0.1 * i)).astype(np.float32)
+            if i % 4 == 1:
+                idx = rng.choice(256, size=5, replace=False)
+                row[idx] = np.nextafter(row[idx], np.float32(np.inf), dtype=np.float32)
+            emb[spots[at]] = row
+            at += 1
+        queries.append(q)
+    big_q = _unit(rng.standard_normal(256))                       # one query whose cluster (2500 copies) overflows a buffer
+    big_v = _unit(big_q + 0.7 * _unit(rng.standard_normal(256)))
+    emb = np.concatenate([emb, np.tile(big_v, (2500, 1))]).astype(np.float32)
+    queries.append(big_q)
+    queries += list(synth.unit_query(71, nq=3))                   # and three ordinary ones
+    qs = np.ascontiguousarray(np.stack(queries), dtype=np.float32)
+    c = smt.Corpus(gpu_ctx)
+    c.append(np.ascontiguousarray(emb))
+    gpu_ctx.set_tuning("fallback_batch_min_rows", 0)
+    try:
+        gpu_ctx.prof_enable(True)
+        gpu_ctx.prof_reset()
+        got = c.search(qs, top_k=10)
+        launches, _ = gpu_ctx.prof_read("gemm_thr")
+        gpu_ctx.prof_enable(False)
+    finally:
+        gpu_ctx.set_tuning("fallback_batch_min_rows", 100000)
+    assert launches == 1
+    for i in range(len(qs)):
+        exp_rows, exp_dist = _oracle_topk(emb, qs[i], 10)
+        assert got[i][0].tolist() == exp_rows, i
+        assert np.array_equal(got[i][1], exp_dist), i
+    c.close()
+
+
 def test_sharded_search_redoes_uncertain_queries(gpu_ctx):
     import semtools_amd as smt
 
