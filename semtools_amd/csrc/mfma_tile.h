@@ -34,13 +34,15 @@ __device__ __forceinline__ f32x16 mfma_tile_32x32x256(const f32x4 (&A)[32], cons
 }
 
 // ---- bf16 x 3 split products on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16: 16x the f32 MFMA rate).
-// An f32 value x is split into hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): x - hi is exact in f32,
-// so |x - hi - lo| <= 2^-18 |x|.  x . q  ~=  xh.qh + xl.qh + xh.ql  (three MFMAs into ONE f32 accumulator; the
-// products of bf16 pairs are exact in f32).  Dropped: xl.ql and the two residuals, each <= 2^-18 |x||q| summed over
-// the dims (Cauchy-Schwarz) => <= 3 * 2^-18 |x||q| = 1.15e-5 |x||q|; accumulating 768 products in f32 adds at most
-// 768 * 2^-24 * (1 + 2^-8) |x||q| = 4.6e-5 |x||q| with round-to-nearest adds.  common.h: F32_ERR_BF16X3 = 1.2e-4
-// (twice the sum: the MFMA's internal adder tree is not documented to round to nearest).  The scores only NOMINATE
-// candidates; final distances are recomputed exactly (f64) and the certificate of section 5 of DESIGN.md uses this bound.
+// An f32 value x is split into hi = bf16(x) (round to nearest even: 8 significant bits, |x - hi| <= 2^-8 |x|) and
+// lo = bf16(x - hi): x - hi is exact in f32, so |x - hi - lo| <= 2^-16 |x|.  x . q  ~=  xh.qh + xl.qh + xh.ql  (three
+// MFMAs into ONE f32 accumulator; the products of bf16 pairs are exact in f32).  Dropped: xl.ql (<= 2^-8 * 2^-8) and
+// the two residual terms, each <= 2^-16 sum |x_i q_i| <= 2^-16 |x||q| (Cauchy-Schwarz) => <= 3 * 2^-16 |x||q| =
+// 4.6e-5 |x||q|; accumulating 768 products in f32 adds at most 768 * 2^-24 * (1 + 2^-7) |x||q| = 4.6e-5 |x||q| with
+// round-to-nearest adds.  common.h: F32_ERR_BF16X3 = 1.5e-4 (the accumulation part counted twice: the MFMA's internal
+// adder tree is not documented to round to nearest).  Measured maximum on adversarial rows: 1.0e-5.  The scores only
+// NOMINATE candidates; final distances are recomputed exactly (f64) and the certificate of section 5 of DESIGN.md uses
+// this bound.
 // Operand layout: lane (j, h) feeds row / query j with dims 16m + 8h .. + 7 of K-step m (8 bf16 = 4 VGPRs), the same
 // K permutation on both operands.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

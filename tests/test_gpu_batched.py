@@ -174,7 +174,7 @@ def test_both_small_batch_kernels_agree(gpu_ctx):
 
 def test_nominating_distance_error_is_inside_the_certificate_bound(gpu_ctx, nominate_with):
     """The certificate needs |nominating f32 distance - exact distance| <= the bound compiled into
-    the library: 2e-5 for the f32 MFMA chain, 1.2e-4 for bf16 x 3.  Measured here on the corpora that stress it:
+    the library: 2e-5 for the f32 MFMA chain, 1.5e-4 for bf16 x 3.  Measured here on the corpora that stress it:
     isotropic rows, all-positive rows (sum |x_i q_i| = x.q: no cancellation, the largest accumulations), rows with
     a few dominant components, unnormalised rows and queries."""
     import semtools_amd as smt
@@ -197,7 +197,7 @@ def test_nominating_distance_error_is_inside_the_certificate_bound(gpu_ctx, nomi
     cos = (e64 @ q64.T) / (np.linalg.norm(e64, axis=1)[:, None] * np.linalg.norm(q64, axis=1)[None, :])
     exact = np.maximum(1.0 - cos, 0.0)
     err = np.abs(got - exact).max()
-    bound = 1.2e-4 if nominate_with else 2e-5
+    bound = 1.5e-4 if nominate_with else 2e-5
     print(f"max |nominating - exact| = {err:.3e} (bound {bound:.1e}, {'bf16x3' if nominate_with else 'f32 MFMA'})")
     assert err < bound / 4, err          # the compiled-in bound is a worst case; observed errors sit far inside it
     c.close()
