@@ -608,99 +608,11 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no LDS-DMA may outlive the block's LDS allocation
 }
 
-// ---- small / medium batches (nq <= 128): every query tile stays in LDS for the whole kernel, so the
-// block needs NO barrier in its main loop, and each wave (one per SIMD, 512 registers) double-buffers its
-// corpus row tile: the 32 loads of tile i+1 are in flight while tile i is multiplied.  With one or two
-// query tiles there are only 128-256 MFMAs (4-8 us) per 32 KiB of corpus, i.e. this regime is bound by
-// how fast rows arrive, and the K3 main kernel (row tile loaded, then used) leaves that latency exposed.
-constexpr int RES_THREADS = 256;
-constexpr int RES_WAVES = RES_THREADS / 64;
-
-template <int NQT>
-__global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    f32x4 *s_q = reinterpret_cast<f32x4 *>(smem_raw);            // [NQT][32][65] float4
-    float *s_tau = reinterpret_cast<float *>(s_q + NQT * QT_F4); // [NQT*32]
-    float *s_rq = s_tau + NQT * QT_ROWS;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    for (uint32_t q = wave; q < NQT * QT_ROWS; q += RES_WAVES) {
-        float rq = 0.0f;
-        if (q < p.nq) {
-            const f32x4 v = reinterpret_cast<const f32x4 *>(p.queries + (size_t)q * 256)[lane];
-            const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-            rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
-        }
-        if (lane == 0) {
-            s_rq[q] = rq;
-            s_tau[q] = score_threshold(q < p.nq ? p.tau[q] : -1.0f, rq);
-        }
-    }
-    for (int idx = threadIdx.x; idx < NQT * QT_ROWS * 64; idx += RES_THREADS) {
-        const uint32_t q = idx >> 6;
-        s_q[(idx >> 6) * QT_STRIDE_F4 + (idx & 63)] =
-            q < p.nq ? reinterpret_cast<const f32x4 *>(p.queries + (size_t)q * 256)[idx & 63] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-
-    const uint64_t W = (uint64_t)gridDim.x * RES_WAVES;
-    const uint64_t first = (uint64_t)blockIdx.x * RES_WAVES + wave;
-
-    auto issue = [&](uint64_t it, f32x4 (&A)[32]) {
-        const uint64_t my_row = level_tile(it, p.stride, p.skip16) * 32 + j;
-        const bool row_ok = my_row < p.n_rows;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.corpus + (row_ok ? my_row : 0) * 256) + h;
-#pragma unroll
-        for (int m = 0; m < 32; ++m) A[m] = __builtin_nontemporal_load(src + 2 * m);  // unconditional, address clamped
-        if (!row_ok) {
-#pragma unroll
-            for (int m = 0; m < 32; ++m) A[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto compute = [&](uint64_t it, f32x4 (&A)[32]) {
-        const uint64_t row0 = level_tile(it, p.stride, p.skip16) * 32;
-        float part = 0.0f;
-#pragma unroll
-        for (int m = 0; m < 32; ++m) part += A[m].x * A[m].x + A[m].y * A[m].y + A[m].z * A[m].z + A[m].w * A[m].w;
-        const float b2 = part + __shfl_xor(part, 32);
-        const float rb = b2 == 0.0f ? 0.0f : __frsqrt_rn(b2);
-#pragma unroll
-        for (int m = 0; m < 32; ++m) A[m] *= rb;  // unit rows (see score_threshold)
-        unsigned zero16 = 0, valid16 = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (__shfl(rb, acc_row(r, h)) == 0.0f) zero16 |= 1u << r;
-            if (row0 + acc_row(r, h) < p.n_rows) valid16 |= 1u << r;
-        }
-#pragma unroll 1
-        for (int qt = 0; qt < NQT; ++qt) {  // not unrolled: one accumulator set and one B stream live at a time
-            const f32x16 acc = mfma_tile_32x32x256(A, s_q + qt * QT_F4 + j * QT_STRIDE_F4 + h);
-            const uint32_t q = qt * QT_ROWS + j;
-            append_candidates(acc, zero16, valid16, q, s_tau[q], s_rq[q], row0, h, p.cand, p.counts);
-        }
-    };
-
-    f32x4 A0[32], A1[32];
-    uint64_t it = first;
-    if (it < p.level_tiles) issue(it, A0);
-    while (it < p.level_tiles) {
-        if (it + W < p.level_tiles) issue(it + W, A1);      // next tile in flight while this one is multiplied
-        compute(it, A0);
-        it += W;
-        if (it >= p.level_tiles) break;
-        if (it + W < p.level_tiles) issue(it + W, A0);
-        compute(it, A1);
-        it += W;
-    }
-}
-
-// ---- small / medium batches, second generation (nq <= 64 per pass): ROW TILES LAND IN LDS BY LDS-DMA.
-// The resident kernel above pulls its 32-row tile straight into registers with fragment-shaped loads: one wave
-// instruction touches 32 B of 32 different rows, every 128-B line is requested four times and the vector L1 thrashes
-// (32 queries x 10 M rows: 3.0 ms against an HBM bound of 1.28 ms).  Here
+// ---- small / medium batches on f32 MFMAs and every range-filtered batch (nq <= 64 per pass): ROW TILES LAND IN LDS
+// BY LDS-DMA.  (The first-generation kernel of this regime, removed since, pulled its 32-row tile straight into
+// registers with fragment-shaped loads: one wave instruction touches 32 B of 32 different rows -- 32 queries x 10 M
+// rows took 3.0 ms against an HBM bound of 1.28 ms.  gemm_rowreg_kernel above is the third answer to the same
+// problem and the default for unfiltered batches.)  Here
 //   * the corpus streams through a per-wave LDS ring of 8 KiB K-SLICES (32 rows x 64 dims) filled by
 //     global_load_lds_dwordx4: one instruction moves 4 rows x 256 contiguous bytes, no staging registers, no ds_write;
 //   * A fragments are read from the ring with ds_read_b128 (one read feeds 4 x NQT MFMAs); a slot is refilled the
@@ -713,7 +625,7 @@ __global__ void __launch_bounds__(RES_THREADS, 1) gemm_resident_kernel(GemmParam
 //     MFMA time + everything else, back to back (ablations on MI355X, 32 queries x 10 M rows: MFMAs alone 1.04 ms,
 //     LDS reads + address work alone 0.63 ms, together 1.68 ms; epilogue +0.25 ms; DMA waits +0.25 ms) -- a lone
 //     wave issues in order, so its own LDS waits, norm FMAs and epilogue stall its MFMA stream; the second wave of
-//     the SIMD fills those holes (the gemm_level_kernel below already worked that way);
+//     the SIMD fills those holes (gemm_level_kernel already worked that way);
 //   * no barrier anywhere: every wave runs its own pipeline (s_waitcnt vmcnt(N) covers the issuing wave's LDS-DMA).
 // LDS image: rows are 256 B apart inside a slice (no padding: LDS-DMA writes lane-linear), so the 16-B chunk c of
 // row i is stored at position c ^ (i & 7): the swizzle is applied to the SOURCE address of the DMA and to the
@@ -1196,12 +1108,6 @@ static int ensure_gemm_attrs(smt_ctx *ctx)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_resident_kernel<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK((lr_set_attr<false>()));
@@ -1326,15 +1232,6 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             const bool nt = ctx->tune.gemm_dma_nt != 0;
             if (bf16) lr_dispatch<true>(ctx, nqt, filtered, nt, nb, smem, g);
             else lr_dispatch<false>(ctx, nqt, filtered, nt, nb, smem, g);
-            prof_end(ctx, "gemm");
-        } else if (g.level_tiles > 0 && nqt <= 4 && ctx->tune.gemm_resident && !ctx->tune.gemm_ldsrow) {  // first generation, A/B only
-            const uint64_t need_blocks = (g.level_tiles + RES_WAVES - 1) / RES_WAVES;
-            const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
-            const size_t smem = (size_t)(nqt <= 1 ? 1 : nqt <= 2 ? 2 : 4) * (QT_F4 * 16 + QT_ROWS * 8) + 64;
-            prof_begin(ctx, "gemm");
-            if (nqt <= 1) hipLaunchKernelGGL(gemm_resident_kernel<1>, dim3(nb), dim3(RES_THREADS), smem, ctx->stream, g);
-            else if (nqt <= 2) hipLaunchKernelGGL(gemm_resident_kernel<2>, dim3(nb), dim3(RES_THREADS), smem, ctx->stream, g);
-            else hipLaunchKernelGGL(gemm_resident_kernel<4>, dim3(nb), dim3(RES_THREADS), smem, ctx->stream, g);
             prof_end(ctx, "gemm");
         } else if (g.level_tiles > 0) {
             const uint64_t need_blocks = (g.level_tiles + GEMM_WAVES - 1) / GEMM_WAVES;

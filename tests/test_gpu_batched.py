@@ -153,8 +153,9 @@ def test_batched_with_row_ranges_reaches_the_mfma_path(gpu_ctx, nq):
     c.close()
 
 
-def test_both_small_batch_kernels_agree(gpu_ctx):
-    """The first-generation resident-query kernel stays selectable (tuning key gemm_ldsrow = 0) for A/B runs."""
+def test_level_kernel_and_lds_row_kernel_agree(gpu_ctx):
+    """In the non-row-register modes up to 64 queries take the LDS-row kernel; gemm_ldsrow = 0 sends them through
+    gemm_level_kernel instead (A/B runs).  Same answers."""
     import semtools_amd as smt
 
     emb = synth.unit_rows(40000, seed=23)

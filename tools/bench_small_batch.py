@@ -1,7 +1,7 @@
-"""K3 small / medium batches (8..128 queries x N rows): per batch size the wall time, the summed "gemm" kernel time
-(HIP events), the HBM and MFMA roofline fractions, and an all-queries check against the single-query K2 path on the
-device.  --variants runs the LDS-row kernel (gemm_ldsrow=1) beside the first-generation resident-query kernel
-(gemm_ldsrow=0) inside ONE process (boxes differ by more than small deltas)."""
+"""K3 batches (2..1000+ queries x N rows): per batch size the wall time, the summed "gemm" kernel time (HIP events),
+the HBM fraction of one corpus pass, the algorithmic flop rate over the f32-MFMA peak, and an all-queries check against
+the single-query K2 path on the device.  --tune key=value selects the mode (gemm_bf16x3, gemm_rowreg, ...); runs that
+are to be compared belong in ONE gpurun call (boxes differ by more than small deltas)."""
 import argparse
 import json
 import os
@@ -20,8 +20,8 @@ def main():
     ap.add_argument("--nq", type=int, nargs="+", default=[8, 16, 32, 64, 128])
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--variants", type=int, nargs="+", default=[1, 0, 2],
-                    help="1 = LDS-row kernel, 0 = first-generation resident-query kernel, 2 = gemm_level_kernel")
+    ap.add_argument("--variants", type=int, nargs="+", default=[1],
+                    help="1 = default routing, 2 = gemm_level_kernel instead of the LDS-row kernel (f32 / gemm_rowreg=0 modes)")
     ap.add_argument("--ranges", action="store_true", help="also time a range-filtered batch (two ranges, 90 %% of the rows)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--tune", action="append", default=[], help="key=value for smt_set_tuning (repeatable)")
@@ -53,9 +53,10 @@ def main():
             corpus.search_topk_device(q[i:i + n].data_ptr(), n, args.k, 0, k2_rows[i:i + n].data_ptr(), k2_dist[i:i + n].data_ptr())
         ctx.synchronize()
         for variant in args.variants:
-            ctx.set_tuning("gemm_ldsrow", 1 if variant in (1, 3) else 0)  # 1 = default routing (LDS-row kernel up to 64 queries,
-            ctx.set_tuning("gemm_resident", 0 if variant == 2 else 1)     # level kernel above), 0 = first-generation resident-query
-                                                                          # kernel, 2 = gemm_level_kernel for every size
+            # 1 = default routing; 2 = (with --tune gemm_rowreg=0 or gemm_bf16x3=0) gemm_level_kernel for every size
+            # instead of the LDS-row kernel up to 64 queries.  (Variant 0, the first-generation resident-query
+            # kernel, is gone; profiles/r02_k3_small_batch*.json hold its numbers.)
+            ctx.set_tuning("gemm_ldsrow", 0 if variant == 2 else 1)
             out_rows = torch.empty(nq, args.k, dtype=torch.int64, device=dev)
             out_dist = torch.empty(nq, args.k, dtype=torch.float64, device=dev)
             ctx.prof_enable(True)
@@ -82,7 +83,6 @@ def main():
             print(json.dumps(r), flush=True)
         if args.ranges:
             ctx.set_tuning("gemm_ldsrow", 1)
-            ctx.set_tuning("gemm_resident", 1)
             cut = args.rows // 20
             rng = [(cut, args.rows // 2), (args.rows // 2 + cut, args.rows)]
             qh = q.cpu().numpy()
