@@ -17,6 +17,7 @@
 #include <unordered_map>
 
 #include "host.h"
+#include "flat_vocab.h"
 #include "json.h"
 #include "unicode_lower.h"
 
@@ -421,51 +422,80 @@ class HfTokenizer : public Tokenizer {
 public:
     explicit HfTokenizer(const std::string &path)
     {
-        const json::Value root = json::parse(read_to_string(path));
+        // The vocabulary (500 k entries in potion-multilingual) stays out of the DOM -- 150 B per entry as json::Values,
+        // most of the load time -- and is read straight into the lookup table while the parser passes over it.
+        const std::string text = read_to_string(path);
+        std::vector<size_t> lens;
+        bool vocab_is_array = false, vocab_seen = false;
+        double min_score = 0.0;
+        json::Parser parser(text);
+        parser.read_member("vocab", 2, [&](json::Parser &p) {     // root object -> "model" -> "vocab"
+            vocab_seen = true;
+            vocab_.reserve_bytes(text.size() / 2);
+            lens.reserve(text.size() / 24);
+            if (p.accept('{')) {                                   // WordPiece (and BPE, refused below): {"piece": id, ...}
+                if (p.accept('}')) return;
+                for (;;) {
+                    const std::string piece = p.string();
+                    p.expect(':');
+                    const uint32_t id = (uint32_t)p.number_f64();
+                    size_ = std::max<uint64_t>(size_, (uint64_t)id + 1);
+                    lens.push_back(piece.size());
+                    vocab_.add(piece, id);
+                    if (p.accept(',')) continue;
+                    p.expect('}');
+                    return;
+                }
+            }
+            vocab_is_array = true;                                 // Unigram: [["piece", score], ...]
+            p.expect('[');
+            if (p.accept(']')) return;
+            uint32_t id = 0;
+            for (;;) {
+                p.expect('[');
+                const std::string piece = p.string();
+                p.expect(',');
+                const double sc = p.number_f64();
+                if (!p.accept(']')) throw Error("tokenizer.json: malformed Unigram vocab entry");
+                scores_.push_back(sc);
+                max_piece_bytes_ = std::max(max_piece_bytes_, piece.size());
+                lens.push_back(piece.size());
+                if (id == 0 || sc < min_score) min_score = sc;
+                vocab_.add(piece, id);                             // (a repeated piece: the later id wins, like the crate's HashMap insert)
+                ++id;
+                if (p.accept(',')) continue;
+                p.expect(']');
+                return;
+            }
+        });
+        const json::Value root = parser.parse();
+        if (!vocab_seen) throw Error("tokenizer.json: model.vocab is missing");
+        vocab_.build();
         if (const json::Value *n = root.get("normalizer"); n && n->kind == json::Value::Object) { norm_ = parse_normalizer(*n); has_norm_ = true; }
         if (const json::Value *p = root.get("pre_tokenizer"); p && p->kind == json::Value::Object) { pre_ = parse_pre(*p); has_pre_ = true; }
         const json::Value &model = need(root, "model");
         const json::Value *type = model.get("type");
-        const json::Value &vocab = need(model, "vocab");
-        std::string kind = type ? type->s : (vocab.kind == json::Value::Array ? "Unigram" : "WordPiece");
-        std::vector<size_t> lens;
+        const std::string kind = type ? type->s : (vocab_is_array ? "Unigram" : "WordPiece");
         if (kind == "WordPiece") {
+            if (vocab_is_array) throw Error("tokenizer.json: a WordPiece vocabulary must be an object");
             wordpiece_ = true;
             prefix_ = model.get("continuing_subword_prefix") ? model.get("continuing_subword_prefix")->s : "##";
             max_chars_ = model.get("max_input_chars_per_word") ? (size_t)model.get("max_input_chars_per_word")->as_u64() : 100;
-            for (auto &kv : vocab.obj) {
-                const uint32_t id = (uint32_t)kv.second.as_u64();
-                vocab_.emplace(kv.first, id);
-                size_ = std::max<uint64_t>(size_, (uint64_t)id + 1);
-                lens.push_back(kv.first.size());
-            }
             const std::string unk = model.get("unk_token") ? model.get("unk_token")->s : "[UNK]";
-            auto it = vocab_.find(unk);
-            if (it == vocab_.end()) throw Error("tokenizer.json: WordPiece unk_token '" + unk + "' is not in the vocabulary");
-            unk_ = it->second;
+            const int64_t unk_id = vocab_.find(unk);
+            if (unk_id < 0) throw Error("tokenizer.json: WordPiece unk_token '" + unk + "' is not in the vocabulary");
+            unk_ = (uint32_t)unk_id;
         } else if (kind == "Unigram") {
+            if (!vocab_is_array) throw Error("tokenizer.json: a Unigram vocabulary must be an array of [piece, score]");
             if (flag(model, "byte_fallback", false)) throw Error("tokenizer.json: Unigram byte_fallback is not supported by the native tokenizer");
-            double min_score = 0.0;
-            bool any = false;
-            uint32_t id = 0;
-            for (auto &e : vocab.arr) {
-                if (e.arr.size() != 2) throw Error("tokenizer.json: malformed Unigram vocab entry");
-                const double sc = e.arr[1].kind == json::Value::Float ? e.arr[1].f : (double)e.arr[1].as_i64();
-                vocab_[e.arr[0].s] = id;                  // (a repeated piece: the later id wins, like the crate's HashMap insert)
-                scores_.push_back(sc);
-                max_piece_bytes_ = std::max(max_piece_bytes_, e.arr[0].s.size());
-                lens.push_back(e.arr[0].s.size());
-                if (!any || sc < min_score) { min_score = sc; any = true; }
-                ++id;
-            }
-            size_ = id;
+            size_ = scores_.size();
             if (const json::Value *u = model.get("unk_id"); u && u->kind != json::Value::Null) unk_ = (uint32_t)u->as_u64();
             unk_score_ = min_score - 10.0;  // K_UNK_PENALTY
         } else {
             throw Error("tokenizer.json: model type '" + kind + "' is not supported by the native tokenizer (WordPiece, Unigram)");
         }
-        if (!lens.empty()) {  // model2vec-rs: median of tk.len() over the vocabulary (bytes)
-            std::sort(lens.begin(), lens.end());
+        if (!lens.empty()) {  // model2vec-rs: median of tk.len() over the vocabulary (bytes): the upper median of the sorted lengths
+            std::nth_element(lens.begin(), lens.begin() + lens.size() / 2, lens.end());
             median_ = std::max<size_t>(1, lens[lens.size() / 2]);
         }
         if (const json::Value *added = root.get("added_tokens"))
@@ -553,8 +583,8 @@ private:
                 cand.clear();
                 if (start > 0) cand = prefix_;
                 cand.append(bytes, off[start], off[end] - off[start]);
-                auto it = vocab_.find(cand);
-                if (it != vocab_.end()) { sub.push_back(it->second); found = true; break; }
+                const int64_t hit = vocab_.find(cand);
+                if (hit >= 0) { sub.push_back((uint32_t)hit); found = true; break; }
                 --end;
             }
             if (!found) { ids.push_back(*unk_); return; }
@@ -578,15 +608,13 @@ private:
             const size_t mblen = c0 < 0x80 ? 1 : (c0 >> 5) == 0x6 ? 2 : (c0 >> 4) == 0xE ? 3 : 4;
             const double here = best[at].score;
             bool single = false;
-            std::string key;
             for (size_t len = 1; at + len <= n && len <= max_piece_bytes_; ++len) {
                 if (at + len < n && ((unsigned char)s[at + len] & 0xC0) == 0x80) continue;  // not a character boundary
-                key.assign(s, at, len);
-                auto it = vocab_.find(key);
-                if (it == vocab_.end()) continue;
+                const int64_t hit = vocab_.find(s.data() + at, len);
+                if (hit < 0) continue;
                 Node &t = best[at + len];
-                const double cand = scores_[it->second] + here;
-                if (!t.set || cand > t.score) { t.score = cand; t.from = at; t.id = it->second; t.unk = false; t.set = true; }
+                const double cand = scores_[(size_t)hit] + here;
+                if (!t.set || cand > t.score) { t.score = cand; t.from = at; t.id = (uint32_t)hit; t.unk = false; t.set = true; }
                 if (len == mblen) single = true;
             }
             if (!single) {
@@ -610,7 +638,7 @@ private:
     Normalizer norm_;
     PreTokenizer pre_;
     bool has_norm_ = false, has_pre_ = false, wordpiece_ = false;
-    std::unordered_map<std::string, uint32_t> vocab_;
+    FlatVocab vocab_;
     std::vector<double> scores_;
     std::string prefix_ = "##";
     size_t max_chars_ = 100, max_piece_bytes_ = 0, median_ = 5;

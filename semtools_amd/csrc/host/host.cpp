@@ -4,6 +4,7 @@
 #include "host.h"
 #include "unicode_lower.h"
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -19,6 +20,7 @@
 #include <sstream>
 #include <thread>
 
+#include "flat_vocab.h"
 #include "fmt.h"
 #include "json.h"
 
@@ -163,11 +165,28 @@ std::string to_lowercase(const std::string &s)
 
 std::string read_to_string(const std::string &path)
 {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw Error(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + "): " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
+    // one read into a string sized from fstat (an ostringstream << rdbuf() copies a 30 MB tokenizer.json twice)
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + "): " + path);
+    struct stat st;
+    std::string out;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) out.resize((size_t)st.st_size);
+    size_t got = 0;
+    for (;;) {
+        if (got == out.size()) out.resize(out.size() < 4096 ? 65536 : out.size() * 2);   // unknown size (pipe) or a file that grew
+        const ssize_t n = read(fd, &out[got], out.size() - got);
+        if (n < 0) {
+            if (errno == EINTR) continue;
+            const int e = errno;
+            close(fd);
+            throw Error(std::string(strerror(e)) + " (os error " + std::to_string(e) + "): " + path);
+        }
+        if (n == 0) break;
+        got += (size_t)n;
+    }
+    close(fd);
+    out.resize(got);
+    return out;
 }
 
 static void write_file_atomic(const std::string &path, const std::string &data)
@@ -215,23 +234,30 @@ class VocabTokenizer : public Tokenizer {
 public:
     VocabTokenizer(const std::string &path, const std::string &unk_token)
     {
-        std::ifstream f(path);
-        if (!f) throw Error("cannot open vocab file " + path);
-        std::string line;
+        const std::string text = read_to_string(path);   // one token per line, id = line index
         std::vector<size_t> lens;
+        vocab_.reserve_bytes(text.size());
+        lens.reserve(text.size() / 8);
         uint32_t id = 0;
-        while (std::getline(f, line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            vocab_.emplace(line, id++);
-            lens.push_back(line.size());  // model2vec-rs takes the median of tk.len(): BYTES, not characters
+        std::string line;
+        for (size_t at = 0; at < text.size();) {
+            const void *nl = memchr(text.data() + at, '\n', text.size() - at);
+            size_t end = nl ? (size_t)((const char *)nl - text.data()) : text.size();
+            size_t len = end - at;
+            if (len && text[at + len - 1] == '\r') --len;
+            line.assign(text, at, len);
+            vocab_.add(line, id++);                       // (a repeated token: the later id wins)
+            lens.push_back(len);                          // model2vec-rs takes the median of tk.len(): BYTES, not characters
+            at = end + 1;
         }
+        vocab_.build();
         size_ = id;
         if (!unk_token.empty()) {
-            auto it = vocab_.find(unk_token);
-            if (it != vocab_.end()) unk_ = it->second;
+            const int64_t u = vocab_.find(unk_token);
+            if (u >= 0) unk_ = (uint32_t)u;
         }
         if (!lens.empty()) {  // model2vec: median length of the vocabulary's tokens
-            std::sort(lens.begin(), lens.end());
+            std::nth_element(lens.begin(), lens.begin() + lens.size() / 2, lens.end());
             median_ = std::max<size_t>(1, lens[lens.size() / 2]);
         }
     }
@@ -240,8 +266,8 @@ public:
         std::vector<std::pair<size_t, size_t>> spans;
         split_whitespace(text, spans);
         for (auto &sp : spans) {
-            auto it = vocab_.find(text.substr(sp.first, sp.second));
-            if (it != vocab_.end()) ids.push_back(it->second);
+            const int64_t hit = vocab_.find(text.data() + sp.first, sp.second);
+            if (hit >= 0) ids.push_back((uint32_t)hit);
             else if (unk_) ids.push_back(*unk_);
         }
     }
@@ -250,7 +276,7 @@ public:
     uint64_t vocab_size() const override { return size_; }
 
 private:
-    std::unordered_map<std::string, uint32_t> vocab_;
+    FlatVocab vocab_;
     std::optional<uint32_t> unk_;
     size_t median_ = 5;
     uint64_t size_ = 0;
@@ -314,10 +340,86 @@ StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std
                          bool normalize)
     : ctx_(ctx), tok_(std::move(tok))
 {
-    check(smt_model_create_from_file(ctx, path.c_str(), byte_offset, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
+    const char *eager = getenv("SEMTOOLS_EAGER_MODEL");
+    if (eager && eager[0] == '1') {
+        check(smt_model_create_from_file(ctx, path.c_str(), byte_offset, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
+        return;
+    }
+    lazy_path_ = path;
+    lazy_offset_ = byte_offset;
+    lazy_V_ = V;
+    lazy_normalize_ = normalize;
+    lazy_fd_ = open(path.c_str(), O_RDONLY);
+    if (lazy_fd_ < 0) throw Error("cannot open " + path + ": " + strerror(errno));
 }
 
-StaticModel::~StaticModel() { smt_model_destroy(model_); }
+StaticModel::~StaticModel()
+{
+    if (model_) smt_model_destroy(model_);
+    if (lazy_fd_ >= 0) close(lazy_fd_);
+}
+
+smt_model *StaticModel::full_model() const
+{
+    if (!model_) {
+        check(smt_model_create_from_file(ctx_, lazy_path_.c_str(), lazy_offset_, lazy_V_, SMT_DIM, lazy_normalize_ ? 1 : 0, &model_),
+              "StaticModel (full table upload)");
+        PhaseTimer::mark("model_table_upload");
+    }
+    return model_;
+}
+
+void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<uint64_t> &offsets, uint64_t n_lines, float *out_host,
+                            smt_corpus *corpus) const
+{
+    if (model_ || lazy_fd_ < 0) {
+        check(smt_embed(model_, ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
+        return;
+    }
+    // ---- lazy: which rows does this batch touch?
+    if (lazy_slot_.size() != lazy_V_) lazy_slot_.assign(lazy_V_, 0);
+    std::vector<uint32_t> uniq;
+    for (uint32_t id : ids) {
+        if (id >= lazy_V_) throw Error("token id outside the embedding table");
+        if (!lazy_slot_[id]) { lazy_slot_[id] = 1; uniq.push_back(id); }
+    }
+    if ((uint64_t)uniq.size() * 16 > lazy_V_) {   // a sizeable part of the table: upload all of it, once
+        for (uint32_t id : uniq) lazy_slot_[id] = 0;
+        check(smt_embed(full_model(), ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
+        return;
+    }
+    std::sort(uniq.begin(), uniq.end());          // file order: neighbouring rows share pages
+    for (size_t s = 0; s < uniq.size(); ++s) lazy_slot_[uniq[s]] = (uint32_t)s + 1;
+    std::vector<float> compact(std::max<size_t>(uniq.size(), 1) * SMT_DIM, 0.0f);
+    {
+        const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)8, uniq.size() / 512}));
+        std::vector<std::exception_ptr> failed(n_threads);
+        auto work = [&](size_t t) {
+            try {
+                for (size_t s = uniq.size() * t / n_threads; s < uniq.size() * (t + 1) / n_threads; ++s) {
+                    const off_t at = (off_t)(lazy_offset_ + (uint64_t)uniq[s] * SMT_DIM * sizeof(float));
+                    if (pread(lazy_fd_, &compact[s * SMT_DIM], SMT_DIM * sizeof(float), at) != (ssize_t)(SMT_DIM * sizeof(float)))
+                        throw Error("short read from " + lazy_path_);
+                }
+            } catch (...) { failed[t] = std::current_exception(); }
+        };
+        if (n_threads == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (auto &f : failed) if (f) { for (uint32_t id : uniq) lazy_slot_[id] = 0; std::rethrow_exception(f); }
+    }
+    std::vector<uint32_t> remapped(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) remapped[i] = lazy_slot_[ids[i]] - 1;
+    for (uint32_t id : uniq) lazy_slot_[id] = 0;
+    smt_model *tmp = nullptr;
+    check(smt_model_create(ctx_, compact.data(), std::max<size_t>(uniq.size(), 1), SMT_DIM, lazy_normalize_ ? 1 : 0, &tmp), "embed (compact table)");
+    const int rc = smt_embed(tmp, remapped.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr);
+    smt_model_destroy(tmp);
+    check(rc, "embed (compact table)");
+}
 
 // ---- phase timer
 namespace {
@@ -415,8 +517,7 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
         const size_t e = std::min(sentences.size(), b + batch_size);
         tokenize_batch(sentences, b, e, max_length, ids, offsets);
         buf.resize((e - b) * SMT_DIM);
-        check(smt_embed(model_, ids.data(), offsets.data(), e - b, max_length ? (uint32_t)*max_length : 0, buf.data(),
-                        nullptr, nullptr), "encode_with_args");
+        embed_csr(ids, offsets, e - b, buf.data(), nullptr);   // (tokenize_batch already truncated to max_length)
         for (size_t i = 0; i < e - b; ++i) out.emplace_back(buf.begin() + i * SMT_DIM, buf.begin() + (i + 1) * SMT_DIM);
     }
     return out;
@@ -433,6 +534,7 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
     Slot slots[2];
     const size_t n = sentences.size();
     if (n == 0) return first;
+    if (!model_ && n > 32768) full_model();   // lazy mode: a large job wants the whole table, decide before the pipeline starts
     auto tokenize = [&](size_t b, Slot &s) { tokenize_batch(sentences, b, std::min(n, b + batch_size), max_length, s.ids, s.offsets); };
     tokenize(0, slots[0]);
     int cur = 0;
@@ -443,11 +545,11 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
         if (e < n) next = std::thread([&, e, cur]() {
             try { tokenize(e, slots[cur ^ 1]); } catch (...) { next_failed = std::current_exception(); }
         });
-        const int rc = smt_embed(model_, slots[cur].ids.data(), slots[cur].offsets.data(), e - b,
-                                 max_length ? (uint32_t)*max_length : 0, nullptr, corpus, nullptr);
+        std::exception_ptr embed_failed;
+        try { embed_csr(slots[cur].ids, slots[cur].offsets, e - b, nullptr, corpus); } catch (...) { embed_failed = std::current_exception(); }
         if (next.joinable()) next.join();
+        if (embed_failed) std::rethrow_exception(embed_failed);
         if (next_failed) std::rethrow_exception(next_failed);
-        check(rc, "encode_into");
         if (sink) {  // (tokenize_batch already dropped unk ids and truncated: these are exactly the ids that were pooled)
             sink->ids.insert(sink->ids.end(), slots[cur].ids.begin(), slots[cur].ids.end());
             for (size_t i = 0; i + 1 < slots[cur].offsets.size(); ++i)
@@ -460,7 +562,7 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
 
 void StaticModel::embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_corpus *corpus) const
 {
-    check(smt_embed(model_, ids, offsets, n_lines, 0, nullptr, corpus, nullptr), "embed_tokens_into");
+    check(smt_embed(full_model(), ids, offsets, n_lines, 0, nullptr, corpus, nullptr), "embed_tokens_into");
 }
 
 uint64_t StaticModel::tokenizer_fingerprint() const

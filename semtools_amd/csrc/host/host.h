@@ -79,7 +79,13 @@ class StaticModel {
 public:
     // table: [V x 256] f32 host array (the `embeddings` tensor), uploaded once.
     StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize);
-    // the f32 table sits at `byte_offset` of `path` (model.safetensors): streamed to HBM through pinned buffers
+    // the f32 table sits at `byte_offset` of `path` (model.safetensors).  LAZY: nothing is uploaded until an embed call
+    // shows what it needs.  A one-shot CLI run (c1: 1000 lines; a warm workspace search: the query alone) touches a few
+    // thousand of the 500 k rows: those rows are read from the file (pread, a few MB), uploaded as a compact table
+    // with remapped ids, pooled and dropped -- same values, same order, bit-identical embeddings -- instead of
+    // streaming 512 MB through pinned buffers first (0.2-0.3 s, most of the CLI's wall time).  A call with more than
+    // 32768 lines, or whose ids cover more than 1/16 of the table, uploads the whole table once (and for good).
+    // SEMTOOLS_EAGER_MODEL=1 restores the eager upload.
     StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
                 bool normalize);
     ~StaticModel();
@@ -106,9 +112,19 @@ private:
     void tokenize_batch(const std::vector<std::string> &sentences, size_t begin, size_t end,
                         std::optional<size_t> max_length, std::vector<uint32_t> &ids,
                         std::vector<uint64_t> &offsets) const;
+    // one batch of token CSR -> rows (host buffer and / or appended to a corpus) through the full or a compact table
+    void embed_csr(const std::vector<uint32_t> &ids, const std::vector<uint64_t> &offsets, uint64_t n_lines, float *out_host,
+                   smt_corpus *corpus) const;
+    smt_model *full_model() const;   // uploads the whole table on first use (lazy mode)
     smt_ctx *ctx_;
     std::unique_ptr<Tokenizer> tok_;
-    smt_model *model_ = nullptr;
+    mutable smt_model *model_ = nullptr;
+    // lazy mode (file-backed f32 table not uploaded yet)
+    std::string lazy_path_;
+    uint64_t lazy_offset_ = 0, lazy_V_ = 0;
+    bool lazy_normalize_ = true;
+    int lazy_fd_ = -1;
+    mutable std::vector<uint32_t> lazy_slot_;   // id -> compact slot + 1 (0 = unseen), reset after every call
 };
 
 // src/search/mod.rs:18-22.  `embeddings: Vec<Vec<f32>>` became a row range of the resident corpus.

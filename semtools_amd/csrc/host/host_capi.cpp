@@ -199,6 +199,7 @@ int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
     *out = nullptr;
     try {
         const std::string d(dir);
+        search::PhaseTimer::mark("process_start_and_hip_context");   // (everything before the model directory is touched)
         uint64_t V = 0, table_offset = 0;
         // F32 tables (what model2vec ships) stream file -> pinned -> HBM; F16 / I8 tables are widened on the host first
         const bool stream_f32 = safetensors_f32_span(d + "/model.safetensors", V, table_offset);
@@ -220,6 +221,7 @@ int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
             else tok = make_vocab_tokenizer(d + "/vocab.txt", unk);
         }
         if (tok->vocab_size() > V) throw Error("vocab.txt has more tokens than the embedding table has rows");
+        search::PhaseTimer::mark("tokenizer_load");
         auto *h = new smt_host_model();
         if (stream_f32) h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), d + "/model.safetensors", table_offset, V, normalize);
         else h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), table.data(), V, normalize);

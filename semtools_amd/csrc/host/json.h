@@ -1,9 +1,11 @@
 // json.h -- minimal JSON value + parser + serde_json-style pretty writer (2-space indent,
 // insertion-ordered objects), enough for workspace config / metadata files and CLI output.
 #pragma once
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -94,36 +96,97 @@ public:
         if (p_ != t_.size()) throw std::runtime_error("trailing characters in JSON");
         return v;
     }
+    // Large members can be left out of the DOM: the value of `key` in an object at nesting depth `depth` (root = 1)
+    // is skipped -- a Null stays in its place -- and its byte span in the text is reported, for a purpose-built scan
+    // (hf_tokenizer.cpp: a 500 k-entry vocabulary costs 150 B per entry as Values).
+    void skip_member(const std::string &key, int depth) { skip_key_ = key; skip_depth_ = depth; }
+    bool skipped(size_t &begin, size_t &end) const { begin = skip_begin_; end = skip_end_; return skip_end_ > skip_begin_; }
+    // ... or consumed on the spot by `reader` (which must leave the parser just behind the value): one pass over the text
+    void read_member(const std::string &key, int depth, std::function<void(Parser &)> reader)
+    {
+        skip_key_ = key;
+        skip_depth_ = depth;
+        reader_ = std::move(reader);
+    }
+    // low-level access for such scans
+    void seek(size_t pos) { p_ = pos; }
+    size_t pos() const { return p_; }
+
+    void ws() { while (p_ < t_.size() && (t_[p_] == ' ' || t_[p_] == '\n' || t_[p_] == '\r' || t_[p_] == '\t')) ++p_; }
+    char peek() { ws(); if (p_ >= t_.size()) throw std::runtime_error("unexpected end of JSON"); return t_[p_]; }
+    void expect(char c) { if (peek() != c) throw std::runtime_error(std::string("expected '") + c + "' in JSON"); ++p_; }
+    bool accept(char c) { if (peek() == c) { ++p_; return true; } return false; }
+    double number_f64()
+    {
+        ws();
+        double v = 0.0;   // std::from_chars: correctly rounded like strtod / serde_json, several times faster (no locale)
+        const char *b = t_.data() + p_ + (p_ < t_.size() && t_[p_] == '+' ? 1 : 0);
+        const auto r = std::from_chars(b, t_.data() + t_.size(), v);
+        if (r.ec != std::errc() || r.ptr == b) throw std::runtime_error("invalid JSON number");
+        p_ = (size_t)(r.ptr - t_.data());
+        return v;
+    }
+    void skip_value()   // brackets matched outside strings
+    {
+        const char c = peek();
+        if (c == '"') { (void)string(); return; }
+        if (c != '{' && c != '[') { (void)number_or_literal(); return; }
+        int depth = 0;
+        while (p_ < t_.size()) {
+            const char x = t_[p_];
+            if (x == '"') { (void)string(); continue; }
+            if (x == '{' || x == '[') ++depth;
+            else if (x == '}' || x == ']') { if (--depth == 0) { ++p_; return; } }
+            ++p_;
+        }
+        throw std::runtime_error("unterminated JSON value");
+    }
 
 private:
     const std::string &t_;
     size_t p_ = 0;
-    void ws() { while (p_ < t_.size() && (t_[p_] == ' ' || t_[p_] == '\n' || t_[p_] == '\r' || t_[p_] == '\t')) ++p_; }
-    char peek() { ws(); if (p_ >= t_.size()) throw std::runtime_error("unexpected end of JSON"); return t_[p_]; }
-    void expect(char c) { if (peek() != c) throw std::runtime_error(std::string("expected '") + c + "' in JSON"); ++p_; }
+    std::string skip_key_;
+    int skip_depth_ = -1, depth_ = 0;
+    size_t skip_begin_ = 0, skip_end_ = 0;
+    std::function<void(Parser &)> reader_;
+    Value number_or_literal()
+    {
+        if (t_.compare(p_, 4, "true") == 0) { p_ += 4; Value v; v.kind = Value::Bool; v.b = true; return v; }
+        if (t_.compare(p_, 5, "false") == 0) { p_ += 5; Value v; v.kind = Value::Bool; v.b = false; return v; }
+        if (t_.compare(p_, 4, "null") == 0) { p_ += 4; return Value(); }
+        return number();
+    }
     Value value()
     {
         const char c = peek();
         if (c == '{') return object();
         if (c == '[') return array();
         if (c == '"') return Value::str(string());
-        if (t_.compare(p_, 4, "true") == 0) { p_ += 4; Value v; v.kind = Value::Bool; v.b = true; return v; }
-        if (t_.compare(p_, 5, "false") == 0) { p_ += 5; Value v; v.kind = Value::Bool; v.b = false; return v; }
-        if (t_.compare(p_, 4, "null") == 0) { p_ += 4; return Value(); }
-        return number();
+        return number_or_literal();
     }
     Value object()
     {
         Value v = Value::object();
         expect('{');
         if (peek() == '}') { ++p_; return v; }
+        ++depth_;
         for (;;) {
             ws();
             std::string k = string();
             expect(':');
-            v.obj.emplace_back(std::move(k), value());
+            if (depth_ == skip_depth_ && k == skip_key_ && skip_end_ == 0) {
+                ws();
+                skip_begin_ = p_;
+                if (reader_) reader_(*this);
+                else skip_value();
+                skip_end_ = p_;
+                v.obj.emplace_back(std::move(k), Value());
+            } else {
+                v.obj.emplace_back(std::move(k), value());
+            }
             if (peek() == ',') { ++p_; continue; }
             expect('}');
+            --depth_;
             return v;
         }
     }
@@ -139,6 +202,7 @@ private:
             return v;
         }
     }
+public:
     static void put_utf8(std::string &o, unsigned cp)
     {
         if (cp < 0x80) o.push_back((char)cp);
@@ -152,6 +216,10 @@ private:
         ++p_;
         std::string o;
         while (p_ < t_.size() && t_[p_] != '"') {
+            // bulk-copy the run up to the next quote or backslash
+            size_t e = p_;
+            while (e < t_.size() && t_[e] != '"' && t_[e] != '\\') ++e;
+            if (e > p_) { o.append(t_, p_, e - p_); p_ = e; continue; }
             char c = t_[p_++];
             if (c != '\\') { o.push_back(c); continue; }
             if (p_ >= t_.size()) break;
@@ -180,6 +248,7 @@ private:
         ++p_;
         return o;
     }
+private:
     Value number()
     {
         const size_t s = p_;

@@ -171,6 +171,29 @@ def test_callback_tokenizer_plugs_in(gpu_ctx, model_dir):
     m.close()
 
 
+def test_lazy_table_gives_the_same_embeddings_as_the_full_upload(gpu_ctx, model_dir, monkeypatch):
+    """A file-backed model uploads nothing until an embed call shows what it needs: small calls pool from a compact
+    table of just the rows they touch, a large call (> 32768 lines, or ids covering > 1/16 of the table) uploads the
+    whole table once.  All three routes -- compact, full after lazy, eager -- give bit-identical rows."""
+    from semtools_amd import host
+
+    lines = synth.pseudo_prose(40000, vocab_size=V - 1, seed=5)
+    lazy = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
+    small = lazy.encode_with_args(lines[:300], 2048)                       # compact table (300 lines touch < V/16 ids)
+    assert np.array_equal(small, oracle_embed(model_dir[1], lines[:300], 2048))
+    q = lazy.encode_with_args([lines[7]], 512)                              # one line: a handful of rows
+    assert np.array_equal(q[0], small[7])
+    big = lazy.encode_with_args(lines, 2048)                                # covers most of the vocabulary: full upload
+    after = lazy.encode_with_args(lines[:300], 2048)                        # ... which later small calls then use
+    lazy.close()
+    monkeypatch.setenv("SEMTOOLS_EAGER_MODEL", "1")
+    eager = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
+    monkeypatch.delenv("SEMTOOLS_EAGER_MODEL")
+    ref = eager.encode_with_args(lines, 2048)
+    eager.close()
+    assert np.array_equal(big, ref) and np.array_equal(after, ref[:300]) and np.array_equal(small, ref[:300])
+
+
 def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, capfd):
     """search_with_workspace (src/search/mod.rs:146-216): first run embeds and persists, second run reuses,
     a modified file is re-embedded, prune drops deleted files, status/stats keep the reference's text."""

@@ -117,6 +117,14 @@ def main():
             dt3 = time.perf_counter() - t0
         pipe["tokenizer_json_native_wordpiece"] = dict(lines=args.ws_lines, seconds=round(dt3, 3), lines_per_s=round(args.ws_lines / dt3))
         m3.close()
+        # the CLI with that model directory (tokenizer.json read natively at every start): c1 and the warm workspace again
+        runs = [run_cli(["search", pool[17], c1, "--top-k", "3", "-n", "3"], env) for _ in range(args.reps)]
+        best = min(runs, key=lambda r: r[0])
+        result["cases"]["c1_1k_lines_tokenizer_json"] = dict(wall_s=round(best[0], 4), phases_ms=best[1], first_line=best[2].split("\n")[0])
+        runs = [run_cli(["search", pool[4242], *files, "--top-k", "3", "-n", "1"], dict(env, SEMTOOLS_WORKSPACE="bench")) for _ in range(args.reps)]
+        best = min(runs, key=lambda r: r[0])
+        result["cases"]["workspace_warm_tokenizer_json"] = dict(lines=per * args.ws_files, wall_s=round(best[0], 3), phases_ms=best[1])
+        print(json.dumps({k: result["cases"][k] for k in ("c1_1k_lines_tokenizer_json", "workspace_warm_tokenizer_json")}), flush=True)
         m2 = hf.load_static_model(ctx, model_dir)
         n2 = min(args.ws_lines, 200_000)
         content2 = "\n".join(pool[i % len(pool)] for i in range(n2)) + "\n"
