@@ -530,6 +530,13 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
     // the host threads already tokenise batch i+1.  Batches are appended in order, so rows == line order.
     const uint64_t first = smt_corpus_rows(corpus);
     if (batch_size == 0) batch_size = 1;
+    // The reference's 16384-line batches are an allocation bound of its own pipeline; rows do not depend on how the lines
+    // are batched.  Here a batch is what one round of tokenizer threads chews on, so it must be large enough to amortise
+    // starting them: SEMTOOLS_EMBED_BATCH overrides (default: the caller's value, at least 65536).
+    {
+        static const size_t env_batch = [] { const char *e = getenv("SEMTOOLS_EMBED_BATCH"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();
+        batch_size = env_batch ? env_batch : std::max<size_t>(batch_size, 65536);
+    }
     struct Slot { std::vector<uint32_t> ids; std::vector<uint64_t> offsets; };
     Slot slots[2];
     const size_t n = sentences.size();
@@ -596,6 +603,7 @@ std::optional<Document> create_document_from_content(const std::string &filename
 {
     std::vector<std::string> lines = lines_of(content);
     if (lines.empty()) return std::nullopt;  // mod.rs:57-59
+    PhaseTimer::mark("split_lines");
     Document doc;
     doc.filename = filename;
     if (ignore_case) {
@@ -606,6 +614,7 @@ std::optional<Document> create_document_from_content(const std::string &filename
     } else {
         doc.first_row = model.encode_into(lines, 2048, 16384, emb.corpus());
     }
+    PhaseTimer::mark("tokenize_and_embed");
     doc.lines = std::move(lines);
     return doc;
 }
