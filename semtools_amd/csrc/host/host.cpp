@@ -383,7 +383,9 @@ void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<
         if (id >= lazy_V_) throw Error("token id outside the embedding table");
         if (!lazy_slot_[id]) { lazy_slot_[id] = 1; uniq.push_back(id); }
     }
-    if ((uint64_t)uniq.size() * 16 > lazy_V_) {   // a sizeable part of the table: upload all of it, once
+    // a sizeable part of the table, or the 65th small call of this process (`semtools search` over hundreds of files embeds
+    // them one by one; each compact table costs a device allocation and an upload): upload all of it, once
+    if ((uint64_t)uniq.size() * 16 > lazy_V_ || ++lazy_calls_ > 64) {
         for (uint32_t id : uniq) lazy_slot_[id] = 0;
         check(smt_embed(full_model(), ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
         return;
@@ -749,7 +751,7 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
     }
     if (n_lines_upserted) {
         fprintf(stderr, "Updating workspace with %zu lines from new/changed docs...\n", n_lines_upserted);  // mod.rs:194-197
-        for (auto &p : pending) store->upsert_document_lines(p.first, p.second, model);
+        store->upsert_documents_lines(pending, model);
         store->compact_if_sparse();  // every re-embedded document left its old rows behind: bound the dead rows
         store->flush_line_embeddings();
     }
@@ -885,6 +887,7 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
 
 Store::~Store()
 {
+    if (token_log_file_) fclose(token_log_file_);
     if (index_) smt_ivfpq_destroy(index_);  // (before the corpus it points into)
     smt_corpus_destroy(corpus_);
 }
@@ -1033,6 +1036,41 @@ void Store::upsert_line_embeddings(const std::vector<LineEmbedding> &line_embedd
 
 static bool token_cache_enabled();
 
+void Store::upsert_documents_lines(std::vector<std::pair<std::string, std::vector<std::string>>> &docs, const search::StaticModel &model)
+{
+    if (docs.empty()) return;
+    if (docs.size() == 1) { upsert_document_lines(docs[0].first, docs[0].second, model); return; }
+    size_t total = 0;
+    for (auto &d : docs) total += d.second.size();
+    std::vector<std::string> all;
+    all.reserve(total);
+    for (auto &d : docs) {
+        auto it = extents_.find(d.first);
+        if (it != extents_.end()) dead_rows_ += it->second.n_rows;  // the whole old document is replaced (no stale tail)
+        for (auto &l : d.second) all.push_back(std::move(l));
+    }
+    const bool cache = token_cache_enabled();
+    search::TokenCsr tokens;
+    uint64_t row = model.encode_into(all, 2048, 16384, corpus_, cache ? &tokens : nullptr);
+    const uint64_t fingerprint = cache ? model.tokenizer_fingerprint() : 0;
+    size_t line = 0, id_at = 0;
+    for (auto &d : docs) {
+        const size_t n = d.second.size();
+        extents_[d.first] = Extent{row, (uint64_t)n};
+        if (cache) {
+            search::TokenCsr one;
+            one.lens.assign(tokens.lens.begin() + line, tokens.lens.begin() + line + n);
+            size_t n_ids = 0;
+            for (uint32_t l : one.lens) n_ids += l;
+            one.ids.assign(tokens.ids.begin() + id_at, tokens.ids.begin() + id_at + n_ids);
+            token_log_append(d.first, &one, fingerprint);
+            id_at += n_ids;
+        }
+        row += n;
+        line += n;
+    }
+}
+
 void Store::upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
                                   const search::StaticModel &model)
 {
@@ -1070,7 +1108,11 @@ void Store::token_log_append(const std::string &path, const search::TokenCsr *to
     if (!tokens && token_log_fingerprint_ == 0) return;  // tombstone into a log that does not exist: nothing to cancel
     if (tokens && fingerprint == 0) return;
     const bool fresh = tokens && token_log_fingerprint_ != fingerprint;   // no log yet, or tokens of ANOTHER tokenizer: start over
-    FILE *f = fopen(log.c_str(), fresh ? "wb" : "ab");
+    // the stream stays open over a series of appends (a repository is thousands of small files) and is closed -- i.e.
+    // flushed -- by token_log_close(), which flush_line_embeddings and the destructor call
+    if (fresh && token_log_file_) { fclose(token_log_file_); token_log_file_ = nullptr; }
+    if (!token_log_file_) token_log_file_ = fopen(log.c_str(), fresh ? "wb" : "ab");
+    FILE *f = token_log_file_;
     if (!f) throw Error("cannot open " + log + ": " + strerror(errno));
     bool ok = true;
     if (fresh) {
@@ -1083,13 +1125,21 @@ void Store::token_log_append(const std::string &path, const search::TokenCsr *to
     ok = ok && fwrite(head, 4, 4, f) == 4 && fwrite(&n_ids, 8, 1, f) == 1 && fwrite(path.data(), 1, path.size(), f) == path.size();
     if (tokens && !tokens->lens.empty()) ok = ok && fwrite(tokens->lens.data(), 4, tokens->lens.size(), f) == tokens->lens.size();
     if (n_ids) ok = ok && fwrite(tokens->ids.data(), 4, n_ids, f) == n_ids;
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) throw Error("short write to " + log);
+    if (!ok) { token_log_close(); throw Error("short write to " + log); }
+}
+
+void Store::token_log_close() const
+{
+    if (!token_log_file_) return;
+    const bool ok = fclose(token_log_file_) == 0;
+    token_log_file_ = nullptr;
+    if (!ok) throw Error("short write to " + dir_ + "/line_tokens.log");
 }
 
 Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &model)
 {
     ReembedReport rep;
+    token_log_close();
     const std::string log = dir_ + "/line_tokens.log";
     std::map<std::string, search::TokenCsr> cache;
     uint64_t log_fp = 0;
@@ -1354,6 +1404,7 @@ void Store::flush_documents() const
 
 void Store::flush_line_embeddings() const
 {
+    token_log_close();
     // vectors first, then the extent table that references them (a crash in between leaves extra
     // rows that no extent points at -- harmless; the reverse order could reference missing rows)
     const std::string emb = dir_ + "/line_embeddings.f32";

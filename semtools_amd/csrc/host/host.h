@@ -9,6 +9,7 @@
 // reference's own host code and call the C ABI as INTEGRATION.md shows.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <functional>
 #include <map>
 #include <memory>
@@ -125,6 +126,7 @@ private:
     bool lazy_normalize_ = true;
     int lazy_fd_ = -1;
     mutable std::vector<uint32_t> lazy_slot_;   // id -> compact slot + 1 (0 = unseen), reset after every call
+    mutable uint32_t lazy_calls_ = 0;           // compact-table calls so far: a long series of small calls gets the full table too
 };
 
 // src/search/mod.rs:18-22.  `embeddings: Vec<Vec<f32>>` became a row range of the resident corpus.
@@ -263,6 +265,9 @@ public:
     // ... and the resident form used by search_with_workspace: embed straight into the store's corpus
     void upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
                                const search::StaticModel &model);
+    // the same for a batch of documents through ONE embedding pipeline run (tokenise || H2D || K1 across document
+    // borders; one round of tokenizer threads per 65536 lines instead of one per file)
+    void upsert_documents_lines(std::vector<std::pair<std::string, std::vector<std::string>>> &docs, const search::StaticModel &model);
     WorkspaceStats get_stats() const;
     std::vector<std::string> get_all_document_paths() const;
     std::vector<RankedLine> search_line_embeddings(const std::vector<float> &query_vec,
@@ -315,6 +320,8 @@ private:
     mutable uint64_t index_built_rows_ = 0;      // corpus rows when the quantisers were trained
     size_t oversample_factor_ = 3;
     void token_log_append(const std::string &path, const search::TokenCsr *tokens, uint64_t fingerprint) const;  // null = tombstone
+    void token_log_close() const;
+    mutable FILE *token_log_file_ = nullptr;       // open while a series of appends is under way
     mutable uint64_t token_log_fingerprint_ = 0;   // fingerprint in the log's header (0 = not read yet / no log)
     uint64_t index_min_rows_ = 2'000'000;
     uint32_t index_nprobe_ = 16;

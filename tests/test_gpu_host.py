@@ -194,6 +194,41 @@ def test_lazy_table_gives_the_same_embeddings_as_the_full_upload(gpu_ctx, model_
     assert np.array_equal(big, ref) and np.array_equal(after, ref[:300]) and np.array_equal(small, ref[:300])
 
 
+def test_many_small_files_plain_and_workspace(gpu_ctx, model_dir, tmp_path, monkeypatch, capfd):
+    """A repository is hundreds of small files.  `search_files` embeds them one by one (the lazy model switches from
+    compact tables to the full table after 64 calls); the workspace embeds all changed files through ONE pipeline run
+    and logs one token record per file.  Same answers as the oracle either way, and the token cache re-embeds them."""
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    pool = synth.pseudo_prose(400, vocab_size=V - 1, seed=19)
+    docs = []
+    for i in range(90):
+        lines = pool[4 * i: 4 * i + 1 + i % 4]
+        f = tmp_path / f"src_{i:03d}.txt"
+        f.write_text("\n".join(lines) + "\n")
+        docs.append((str(f), lines))
+    files = [p for p, _ in docs]
+    query = docs[71][1][0]
+    fresh = host.StaticModel(gpu_ctx, model_dir=model_dir[0])          # lazy: 90 small calls cross the 64-call switch
+    try:
+        want = expected_results(model_dir[1], docs, query, 0, 5)
+        assert host.search_files(fresh, query, files, n_lines=0, top_k=5) == refimpl.print_search_results(want)
+        host.workspace_use(None, "many")
+        out = host.search_with_workspace(fresh, query, files, workspace_name="many", n_lines=0, top_k=5)
+        assert f"Updating workspace with {sum(len(l) for _, l in docs)} lines" in capfd.readouterr().err
+        assert out.split("\n")[0].startswith(f"{files[71]}:0::1 (")
+        root = tmp_path / ".semtools" / "workspaces" / "many"
+        log = (root / "line_tokens.log").read_bytes()
+        assert log.count(b"TOKD") == 90                                # one record per file
+        txt = host.workspace_reembed(fresh, "many")
+        assert txt.startswith(f"Re-embedded {sum(len(l) for _, l in docs)} lines of 90 documents")
+        assert host.search_with_workspace(fresh, query, files, workspace_name="many", n_lines=0, top_k=5) == out
+    finally:
+        fresh.close()
+
+
 def test_workspace_flow(model, model_dir, prose_files, tmp_path, monkeypatch, capfd):
     """search_with_workspace (src/search/mod.rs:146-216): first run embeds and persists, second run reuses,
     a modified file is re-embedded, prune drops deleted files, status/stats keep the reference's text."""
