@@ -702,12 +702,27 @@ std::vector<SearchResult> search_files(const std::vector<std::string> &files, co
     PhaseTimer::mark("model_load");
     Embeddings emb(model.ctx());
     std::vector<Document> documents;
+    // mod.rs:128-134 reads and embeds file by file; the rows do not depend on how the lines are batched, so all files
+    // are read first (the first error still aborts before anything is printed) and embedded in ONE pipeline run
+    // (tokenise || H2D || K1 across file borders instead of a round of threads and a K1 launch per file)
+    std::vector<std::string> all;
     for (auto &f : files) {
         const std::string content = read_to_string(f);  // `?`: first error aborts (mod.rs:130)
-        auto doc = create_document_from_content(f, content, model, config.ignore_case, emb);
-        if (doc) documents.push_back(std::move(*doc));
+        std::vector<std::string> lines = lines_of(content);
+        if (lines.empty()) continue;                     // create_document_from_content -> None (mod.rs:57-59)
+        Document doc;
+        doc.filename = f;
+        doc.first_row = all.size();
+        for (auto &l : lines) all.push_back(config.ignore_case ? to_lowercase(l) : l);   // mod.rs:61-67: embed the lowered copy
+        doc.lines = std::move(lines);
+        documents.push_back(std::move(doc));
     }
-    PhaseTimer::mark("read_tokenize_embed_files");
+    PhaseTimer::mark("split_lines");
+    if (!all.empty()) {
+        const uint64_t first = model.encode_into(all, 2048, 16384, emb.corpus());     // mod.rs:69
+        for (auto &d : documents) d.first_row += first;
+    }
+    PhaseTimer::mark("tokenize_and_embed");
     const std::vector<float> query_embedding = model.encode_single(query);
     PhaseTimer::mark("embed_query");
     auto res = search_documents(documents, emb, query_embedding, config);

@@ -195,9 +195,9 @@ def test_lazy_table_gives_the_same_embeddings_as_the_full_upload(gpu_ctx, model_
 
 
 def test_many_small_files_plain_and_workspace(gpu_ctx, model_dir, tmp_path, monkeypatch, capfd):
-    """A repository is hundreds of small files.  `search_files` embeds them one by one (the lazy model switches from
-    compact tables to the full table after 64 calls); the workspace embeds all changed files through ONE pipeline run
-    and logs one token record per file.  Same answers as the oracle either way, and the token cache re-embeds them."""
+    """A repository is hundreds of small files.  `search_files` and the workspace embed all of them through ONE pipeline
+    run (the workspace logs one token record per file); a long series of separate small embed calls makes the lazy
+    model switch from compact tables to the full table (after 64).  Same answers as the oracle on every route."""
     from semtools_amd import host
 
     monkeypatch.setenv("HOME", str(tmp_path))
@@ -211,8 +211,10 @@ def test_many_small_files_plain_and_workspace(gpu_ctx, model_dir, tmp_path, monk
         docs.append((str(f), lines))
     files = [p for p, _ in docs]
     query = docs[71][1][0]
-    fresh = host.StaticModel(gpu_ctx, model_dir=model_dir[0])          # lazy: 90 small calls cross the 64-call switch
+    fresh = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
     try:
+        for i in range(70):                                             # lazy: 70 small calls cross the 64-call switch
+            assert np.array_equal(fresh.encode_with_args(docs[i][1], 2048), oracle_embed(model_dir[1], docs[i][1], 2048)), i
         want = expected_results(model_dir[1], docs, query, 0, 5)
         assert host.search_files(fresh, query, files, n_lines=0, top_k=5) == refimpl.print_search_results(want)
         host.workspace_use(None, "many")
