@@ -500,6 +500,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     ctx.prof_enable(False)
     gemm_s = ms_g / reps * 1e-3
     flops = 2.0 * nq * rows * 256
+    issued = 2.0 if (nq >= 128 and rows <= (1 << 25)) else 3.0   # gemm_kernels.hip launch_gemm_topk: the auto rule of gemm_nominate
     ok = True
     for i in range(min(3, nq)):  # independent fp64 check of a few queries
         ref = 1.0 - (x.double() @ q[i].double())
@@ -523,11 +524,13 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         "metric": "queries/sec at 10M-chunk corpus (batched)", "value": nq / wall, "unit": "queries/s",
         "ms_per_batch": wall * 1e3, "rows_scanned_per_s": nq * rows / wall,
         "config": {"workload": f"c3: {nq} batched queries x {rows} chunks (D=256, f32), top-{k}, one MI355X"},
-        # three bf16 MFMAs (hi.hi, lo.hi, hi.lo) per product of the score matrix: the kernel issues 3 x the algorithmic
-        # flops on the bf16 pipe (dense peak 2.5 PF); the same batch on f32 MFMAs is bounded by 157.3 TF
-        "roofline": {"kernel": "gemm_rowreg_kernel (K3, bf16 x 3)", "bound": "mfma", "achieved": 3.0 * flops / gemm_s / 1e12,
-                     "peak": 2500.0, "unit": "TFLOP/s", "frac": 3.0 * flops / gemm_s / 2500e12, "traffic": None,
-                     "algorithmic_flops_per_batch": flops, "issued_bf16_flops_per_batch": 3.0 * flops,
+        # The score matrix only nominates candidates.  From 128 queries on (shards <= 32 M rows) the library's default is
+        # f16 x 2: one fp16 operand per row, hi + lo per query = 2 x the algorithmic flops on the 16-bit MFMA pipe (dense
+        # peak 2.5 PF); smaller batches / larger shards use bf16 x 3 (3 x).  The same batch on f32 MFMAs is bounded by 157.3 TF.
+        "roofline": {"kernel": f"gemm_rowreg_kernel (K3, {'f16 x 2' if issued == 2.0 else 'bf16 x 3'})", "bound": "mfma",
+                     "achieved": issued * flops / gemm_s / 1e12,
+                     "peak": 2500.0, "unit": "TFLOP/s", "frac": issued * flops / gemm_s / 2500e12, "traffic": None,
+                     "algorithmic_flops_per_batch": flops, "issued_16bit_mfma_flops_per_batch": issued * flops,
                      "algorithmic_rate_over_f32_mfma_peak": flops / gemm_s / 157.3e12,
                      "gemm_ms_per_batch": gemm_s * 1e3, "gemm_launches_per_batch": n_g // reps},
         "checks": {"torch_fp64_topk_match": ok, "k2_path_agreement": f"{n_same}/{nq}",

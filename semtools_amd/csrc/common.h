@@ -68,6 +68,7 @@ struct Tuning {
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
     int gemm_min_nq = 3;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
     int64_t gemm_min_rows_small = 1000000;   // (2 queries: 4 x this; api.cpp topk_dispatch)
+    int gemm_nominate = 0;      // gemm_rowreg_kernel: 0 auto (f16 x 2 from 128 queries on shards <= 32 M rows), 1 bf16 x 3, 2 f16 x 2
     int gemm_rowreg = 1;        // 1: with gemm_bf16x3, unfiltered batches use gemm_rowreg_kernel (coalesced row loads + LDS transpose)
     int gemm_bf16x3 = 1;        // 1: K3 nominates candidates with bf16 x 3 split products on the bf16 MFMA pipe (mfma_tile.h); 0: f32 MFMA
     int gemm_ldsrow = 1;        // 1: batches <= 128 queries and range-filtered batches use the LDS-row kernel (64 queries per pass)
@@ -228,6 +229,8 @@ constexpr double F32_ERR_MFMA = 2e-5;
 // bf16 x 3 split products (mfma_tile.h): 3 * 2^-16 representation (4.6e-5) + 768 f32 accumulations (4.6e-5 with
 // round-to-nearest adds, counted twice: the MFMA adder tree is not documented to round to nearest) = 1.4e-4
 constexpr double F32_ERR_BF16X3 = 1.5e-4;
+// f16 x 2 (mfma_tile.h): one fp16 operand for the rows (2^-11 = 4.9e-4) + 512 accumulations counted twice (6e-5)
+constexpr double F32_ERR_F16X2 = 6e-4;
 // K2/K3 keep k + 8 <= 64 candidates per list: top_k above this goes to the all-keys path (largek.hip)
 constexpr uint32_t SCAN_MAX_K = 56;
 

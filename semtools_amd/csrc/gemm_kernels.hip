@@ -419,7 +419,27 @@ constexpr int RR_BDIST = SMT_RR_BDIST;            // K-steps between the LDS rea
 constexpr int RR_QCONST = QT_ROWS * 8;            // per slot: (score threshold, 1/|q|) of the tile's 32 queries
 constexpr int RR_SMEM = RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF + RR_SLOTS * RR_QCONST;
 
-__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst)
+// The f16 x 2 image of the queries (same row layout: K-step m, half h -> 16 B of hi, 16 B of lo): the UNIT query times
+// 2^8, split into two fp16 parts.  One wave per query (the norm is needed first).
+__global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out)
+{
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq_pad) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq) v = reinterpret_cast<const f32x4 *>(queries + (size_t)q * 256)[lane];
+    const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    const float s = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2) * F16X2_QUERY_SCALE;
+    uint32_t h0, l0, h1, l1;
+    f16_split2(v.x * s, v.y * s, h0, l0);   // pairs 2 lane, 2 lane + 1  (dims 4 lane .. 4 lane + 3)
+    f16_split2(v.z * s, v.w * s, h1, l1);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint32_t *row = out + (size_t)q * 256 + (lane >> 1) * 8 + 2 * (lane & 1);   // pair pr -> word (pr >> 2) * 8 + (pr & 3)
+    *reinterpret_cast<u32x2 *>(row) = (u32x2){h0, h1};
+    *reinterpret_cast<u32x2 *>(row + 4) = (u32x2){l0, l1};
+}
+
+__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst, int f16x2)
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -430,12 +450,16 @@ __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t 
         const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
         rq = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2);
     }
+    if (f16x2 && rq != 0.0f) rq = F16X2_INV_SCALE;   // the f16 x 2 operands are unit vectors times 2^10 and 2^8
     if (lane == 0) {
         qconst[2 * q] = score_threshold(q < nq ? __builtin_inff() : -1.0f, rq);  // padding: zero query, tau < 0 -> never passes
         qconst[2 * q + 1] = rq;
     }
 }
 
+// F16X2: f16 x 2 nomination (mfma_tile.h) instead of bf16 x 3 -- the rows carry ONE fp16 operand (64 VGPRs), the
+// transpose moves half the words, a K-step is two MFMAs.
+template <bool F16X2>
 __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p)
 {
     constexpr int WAVES = RR_WAVES;
@@ -495,7 +519,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
         const bool has = it < p.level_tiles;  // wave-uniform
         const uint64_t row0 = (has ? level_tile(it, p.stride, p.skip16) : 0) * 32;
 
-        u32x4 Ah[16], Al[16];
+        u32x4 Ah[16], Al[F16X2 ? 1 : 16];
         unsigned zero16 = 0, valid16 = 0;
         if (has) {
             // ---- 32 coalesced loads: instruction i = 4s + u covers rows 8u .. 8u+7, dims 32s .. 32s+31 (128 B per row)
@@ -527,26 +551,36 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 rb[u] = part == 0.0f ? 0.0f : __frsqrt_rn(part);
             }
             // ---- per slice: scale, split, transpose hi then lo through the wave's buffer
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) {
-                uint32_t hi[4][2], lo[4][2];
+                if constexpr (F16X2) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 v = R[4 * sl + u] * rb[u];
-                    bf16_split2(v.x, v.y, hi[u][0], lo[u][0]);
-                    bf16_split2(v.z, v.w, hi[u][1], lo[u][1]);
+                    for (int u = 0; u < 4; ++u) {
+                        const f32x4 v = R[4 * sl + u] * (rb[u] * F16X2_ROW_SCALE);
+                        *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){f16_pack2(v.x, v.y), f16_pack2(v.z, v.w)};
+                    }
+                    Ah[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
+                    Ah[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
+                } else {
+                    uint32_t hi[4][2], lo[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const f32x4 v = R[4 * sl + u] * rb[u];
+                        bf16_split2(v.x, v.y, hi[u][0], lo[u][0]);
+                        bf16_split2(v.z, v.w, hi[u][1], lo[u][1]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){hi[u][0], hi[u][1]};
+                    Ah[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
+                    Ah[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){lo[u][0], lo[u][1]};
+                    Al[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
+                    Al[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
                 }
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){hi[u][0], hi[u][1]};
-                Ah[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
-                Ah[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){lo[u][0], lo[u][1]};
-                Al[2 * sl] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
-                Al[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -579,7 +613,8 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 if (m + RR_BDIST < 16) { bh[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST)]; bl[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST) + 1]; }
                 if (m % STAGE_EVERY == 0 && m / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, m / STAGE_EVERY);
                 if (m == STAGE_EVERY * STAGE_ROWS && stage) stage_consts(stage_qt, stage_slot);
-                acc = mfma_bf16x3(Ah[m], Al[m], bh[m % NB], bl[m % NB], acc);
+                if constexpr (F16X2) acc = mfma_f16x2(Ah[m], bh[m % NB], bl[m % NB], acc);
+                else acc = mfma_bf16x3(Ah[m], Al[m], bh[m % NB], bl[m % NB], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
             append_candidates(acc, zero16, valid16, q, thr_q, rq_q, row0, h, p.cand, p.counts);
@@ -999,7 +1034,7 @@ __global__ void fill_f32_kernel(float *p, float v, uint32_t n)
 // ---- test hook: the NOMINATING distances themselves (never part of an answer).  One wave per 32-row tile against one
 // tile of <= 32 queries, the same operand preparation and MFMA sequence as gemm_level_kernel; out[row][32] = the f32
 // distance the candidate test sees.  tests/test_gpu_batched.py measures |out - exact| against F32_ERR_MFMA / _BF16X3.
-template <bool BF16>
+template <int MODE>   // 0 f32 MFMA, 1 bf16 x 3, 2 f16 x 2
 __global__ void __launch_bounds__(64) gemm_debug_scores_kernel(const float *corpus, uint64_t first_row, uint32_t n_rows,
                                                                const float *queries, uint32_t nq, float *out)
 {
@@ -1016,15 +1051,31 @@ __global__ void __launch_bounds__(64) gemm_debug_scores_kernel(const float *corp
     // f32: lane (j, h) feeds dims 8m + 4h .. + 3 of group m; bf16: dims 16m + 8h .. + 7 of K-step m
 #pragma unroll
     for (int m = 0; m < 32; ++m) {
-        const int idx = BF16 ? 4 * (m >> 1) + 2 * h + (m & 1) : 2 * m + h;
+        const int idx = MODE ? 4 * (m >> 1) + 2 * h + (m & 1) : 2 * m + h;
         R[m] = row_ok ? rsrc[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
         Q[m] = (uint32_t)j < nq ? qsrc[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
         rpart += R[m].x * R[m].x + R[m].y * R[m].y + R[m].z * R[m].z + R[m].w * R[m].w;
         qpart += Q[m].x * Q[m].x + Q[m].y * Q[m].y + Q[m].z * Q[m].z + Q[m].w * Q[m].w;
     }
     const float r2 = rpart + __shfl_xor(rpart, 32), q2 = qpart + __shfl_xor(qpart, 32);
-    const float rb = r2 == 0.0f ? 0.0f : __frsqrt_rn(r2), rq = q2 == 0.0f ? 0.0f : __frsqrt_rn(q2);
-    if constexpr (BF16) {
+    const float rb = r2 == 0.0f ? 0.0f : __frsqrt_rn(r2);
+    float rq = q2 == 0.0f ? 0.0f : __frsqrt_rn(q2);
+    if constexpr (MODE == 2) {
+        const float qs = rq * F16X2_QUERY_SCALE;   // unit query x 2^8, unit row x 2^10 (as split_queries_f16_kernel / gemm_rowreg_kernel<true>)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const f32x4 r0 = R[2 * m] * (rb * F16X2_ROW_SCALE), r1 = R[2 * m + 1] * (rb * F16X2_ROW_SCALE);
+            const f32x4 q0 = Q[2 * m] * qs, q1 = Q[2 * m + 1] * qs;
+            const u32x4 a = {f16_pack2(r0.x, r0.y), f16_pack2(r0.z, r0.w), f16_pack2(r1.x, r1.y), f16_pack2(r1.z, r1.w)};
+            uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+            f16_split2(q0.x, q0.y, h0, l0);
+            f16_split2(q0.z, q0.w, h1, l1);
+            f16_split2(q1.x, q1.y, h2, l2);
+            f16_split2(q1.z, q1.w, h3, l3);
+            acc = mfma_f16x2(a, (u32x4){h0, h1, h2, h3}, (u32x4){l0, l1, l2, l3}, acc);
+        }
+        if (rq != 0.0f) rq = F16X2_INV_SCALE;
+    } else if constexpr (MODE == 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             u32x4 ah, al, bh, bl;
@@ -1054,8 +1105,9 @@ int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_r
 {
     if (nq < 1 || nq > 32 || n_rows < 1) { set_error("debug scores: 1..32 queries, >= 1 row"); return SMT_E_INVALID; }
     const dim3 grid((n_rows + 31) / 32);
-    if (ctx->tune.gemm_bf16x3) hipLaunchKernelGGL(gemm_debug_scores_kernel<true>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
-    else hipLaunchKernelGGL(gemm_debug_scores_kernel<false>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    if (ctx->tune.gemm_bf16x3 && ctx->tune.gemm_nominate == 2) hipLaunchKernelGGL(gemm_debug_scores_kernel<2>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    else if (ctx->tune.gemm_bf16x3) hipLaunchKernelGGL(gemm_debug_scores_kernel<1>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    else hipLaunchKernelGGL(gemm_debug_scores_kernel<0>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }
@@ -1108,7 +1160,9 @@ static int ensure_gemm_attrs(smt_ctx *ctx)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK((lr_set_attr<false>()));
         SMT_HIP_CHECK((lr_set_attr<true>()));
@@ -1122,7 +1176,6 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (a.k_out + 8 > 64 || a.k_out < 1) { set_error("batched path: top_k must be in [1, 56]"); return SMT_E_UNSUPPORTED; }
     SMT_REQUIRE(a.rows < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     const bool filtered = a.n_ranges != 0;
-    const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)ctx->tune.guard_band);  // see candidates_per_list (scan_kernels.hip)
     const uint32_t nqt = (a.nq + QT_ROWS - 1) / QT_ROWS;
     const uint64_t ostride = a.out_stride ? a.out_stride : a.k_out;
     // Which kernel (measured on MI355X, 10 M rows, ms per batch: LDS-row kernel / gemm_level_kernel):
@@ -1132,6 +1185,14 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // bf16 x 3 (the default): gemm_rowreg_kernel takes every unfiltered batch; range-filtered batches keep the LDS-row
     // kernel (its chunk table gathers the rows).  f32 MFMA (gemm_bf16x3 = 0): the round-1/2 routing below.
     const bool rowreg = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && !filtered;
+    // How gemm_rowreg_kernel nominates (tuning key gemm_nominate: 0 auto, 1 bf16 x 3, 2 f16 x 2).  f16 x 2 issues a third
+    // fewer MFMAs -- what large batches are bound by -- for a four times wider certificate band (6e-4 against 1.5e-4):
+    // auto takes it from 128 queries up on shards of at most 32 M rows (the rank spacing of the distances shrinks with
+    // the shard; at 10 M random rows the k-th and k+8-th distances are ~8e-3 apart).  Small batches are HBM-bound: bf16 x 3.
+    const bool f16x2 = rowreg && (ctx->tune.gemm_nominate == 2 ||
+                                  (ctx->tune.gemm_nominate == 0 && nqt >= 4 && a.rows <= (1ull << 25)));
+    // guard band, see candidates_per_list (scan_kernels.hip); the wider certificate band of f16 x 2 gets a band of at least 16
+    const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)std::max(ctx->tune.guard_band, f16x2 ? 16 : 8));
     const bool lds_rows = !rowreg && ctx->tune.gemm_ldsrow && (filtered || nqt <= 2);
     if (filtered && !lds_rows) { set_error("range-filtered batches need the LDS-row kernel (tuning key gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
     const uint32_t pass_nq = lds_rows ? 2 * QT_ROWS : GEMM_MAX_NQ;
@@ -1174,12 +1235,15 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     float *qconst = tau + (size_t)nqt * QT_ROWS;   // [nqt*32][2]
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
-    if (bf16)
+    if (f16x2)
+        hipLaunchKernelGGL(split_queries_f16_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
+                           nqt * QT_ROWS, q_split);
+    else if (bf16)
         hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, q_split);
     if (rowreg)
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, qconst);
+                           nqt * QT_ROWS, qconst, f16x2 ? 1 : 0);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -1222,7 +1286,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                 nb = (int)(need_blocks * g.qsplit);
             }
             prof_begin(ctx, "gemm");
-            hipLaunchKernelGGL(gemm_rowreg_kernel, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<true>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            else hipLaunchKernelGGL(gemm_rowreg_kernel<false>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
             prof_end(ctx, "gemm");
         } else if (g.level_tiles > 0 && lds_rows) {
             const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
@@ -1277,7 +1342,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     sel.out_dist = a.out_dist;
     sel.out_counts = a.out_counts;
     sel.out_stride = a.out_stride;
-    sel.f32_err = bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
+    sel.f32_err = f16x2 ? F32_ERR_F16X2 : bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
     sel.out_uncertain = a.out_uncertain;
     rc = launch_select(ctx, sel);
     if (rc) return rc;
@@ -1329,7 +1394,7 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + b_cand + b_cnt + b_qc);
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, b_cnt, ctx->stream));
     hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, q_split);
-    hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, qconst);
+    hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, qconst, 0);
     hipLaunchKernelGGL(set_qconst_thresholds_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, qconst, tau, nq);
     GemmParams g;
     g.corpus = corpus;
@@ -1350,8 +1415,8 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     g.n_chunks = 0;
     const int blocks = ctx->tune.gemm_blocks > 0 ? ctx->tune.gemm_blocks : ctx->num_cus;
     const int nb = (int)std::min<uint64_t>((uint64_t)blocks, (g.level_tiles + RR_WAVES - 1) / RR_WAVES);
-    prof_begin(ctx, "gemm_thr");
-    hipLaunchKernelGGL(gemm_rowreg_kernel, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+    prof_begin(ctx, "gemm_thr");   // (always bf16 x 3: the tighter band collects fewer rows)
+    hipLaunchKernelGGL(gemm_rowreg_kernel<false>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
     prof_end(ctx, "gemm_thr");
     SMT_HIP_CHECK(hipGetLastError());
     *cand_out = cand;

@@ -81,6 +81,38 @@ __device__ __forceinline__ f32x16 mfma_bf16x3(const u32x4 &ah, const u32x4 &al, 
     return acc;
 }
 
+// ---- f16 x 2: one fp16 operand for the rows, hi + lo fp16 for the queries -- TWO MFMAs per 16 dims instead of three.
+// fp16 keeps 11 significant bits: a row element rounds with relative error <= 2^-11, so the score is off by at most
+// 2^-11 |x||q| = 4.9e-4 (the query, hi + lo, carries 22 bits: its residual is noise next to that); 512 f32 accumulations
+// add <= 3e-5 (counted twice: 6e-5).  common.h: F32_ERR_F16X2 = 6e-4, four times the bf16 x 3 bound -- the price of a
+// third fewer MFMAs, which is what the part's power budget is spent on in large batches.  Scaling keeps everything away
+// from fp16's subnormals: unit rows are multiplied by 2^10, unit queries by 2^8 (an element would have to be below
+// 6e-8 resp. 2.4e-7 to be flushed); the accumulator then holds 2^18 cos, which the query's constant 1/|q| := 2^-18 undoes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16X2_ROW_SCALE = 1024.0f, F16X2_QUERY_SCALE = 256.0f, F16X2_INV_SCALE = 1.0f / (1024.0f * 256.0f);
+
+__device__ __forceinline__ uint32_t f16_pack2(float a, float b)  // v_cvt_pk_f16_f32 (round to nearest even)
+{
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void f16_split2(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = f16_pack2(a - hf.x, b - hf.y);
+}
+// acc += a . (bh + bl)
+__device__ __forceinline__ f32x16 mfma_f16x2(const u32x4 &a, const u32x4 &bh, const u32x4 &bl, f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bl), acc, 0, 0, 0);
+    return acc;
+}
+
 // accumulator register r of lane (j, h) holds tile row acc_row(r, h) and tile column j
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
