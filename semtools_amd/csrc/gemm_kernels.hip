@@ -1,7 +1,19 @@
-// gemm_kernels.hip -- K3: batched queries.  S = C x Q^T on the f32 MFMA pipe
-// (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak on MI355X) with the top-k
-// candidate selection fused into the epilogue -- the nq x N score matrix
-// (40 GB at 1k x 10M) is never materialised.
+// gemm_kernels.hip -- K3: batched queries.  S = C x Q^T on the MFMA pipes with the top-k candidate selection fused
+// into the epilogue -- the nq x N score matrix (40 GB at 1k x 10M) is never materialised.  The scores only NOMINATE
+// candidates (k + guard per query); answers are re-scored exactly in f64 and proved complete by the select stage.
+//
+// Kernels in this file, and who runs when (launch_gemm_topk):
+//   gemm_rowreg_kernel<F16X2>   DEFAULT for every unfiltered batch.  Row tiles arrive with coalesced loads, are split
+//                               into 16-bit operands once and transposed through LDS; bf16 x 3 products below 128
+//                               queries, f16 x 2 from there (tuning key gemm_nominate).  DESIGN.md 4.3c.
+//   gemm_ldsrow_kernel<..>      range-filtered batches (chunk table), <= 64 queries per pass; f32 or bf16 x 3 MFMAs.
+//   gemm_level_kernel<BF16>     the round-1 corpus-stationary kernel: f32 MFMAs (v_mfma_f32_32x32x2_f32, exact f32,
+//                               157 TF peak) when gemm_bf16x3 = 0, or bf16 x 3 when gemm_rowreg = 0.  The level scheme,
+//                               the epilogue and the candidate buffers described below are shared by all three.
+//   level_select_kernel, split_queries_*_kernel, query_consts_kernel: per-level / per-batch helpers.
+//   launch_gemm_threshold       one sweep with preset thresholds: the batched exhaustive re-answer (api.cpp).
+//
+// The f32 design (gemm_level_kernel):
 //
 // No reference counterpart: the reference answers one query per process with a
 // scalar loop (src/search/mod.rs:84-86).  Contract = same results as the K2
