@@ -904,9 +904,10 @@ static int exact_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *query_d
 // row whose nominating distance is <= bound + F32_ERR_BF16X3 (a superset of the rows with exact distance <= bound);
 // they are re-scored exactly, ordered (distance, row) and cut at k -- what exact_fallback does with one K4 scan per
 // query.  Queries whose band holds more rows than a candidate buffer (2048) come back in `left` for the K4 route.
+// The same sweep answers threshold searches of several queries at once (`strict`: distance < bound, every hit: k_eff = all).
 static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queries_dev, const std::vector<uint32_t> &redo,
-                            const std::vector<double> &bounds, uint32_t k_eff, bool ws_thr, float thr_score, uint64_t row_base,
-                            std::vector<LocalHits> &out, std::vector<uint32_t> &left)
+                            const std::vector<double> &bounds, uint64_t k_eff, bool ws_thr, float thr_score, uint64_t row_base,
+                            std::vector<LocalHits> &out, std::vector<uint32_t> &left, bool strict = false)
 {
     const uint32_t n = (uint32_t)redo.size();
     float *d_qc = nullptr;   // compact copies of the uncertain queries + their f32 thresholds (rare path: plain hipMalloc)
@@ -957,7 +958,7 @@ static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queri
         if (cnt[i] > stride) { left.push_back(redo[i]); continue; }
         std::vector<uint64_t> order;
         for (uint64_t c = first[i]; c < first[i + 1]; ++c) {
-            if (!(dist[c] <= bounds[i])) continue;                                   // (also drops NaN)
+            if (strict ? !(dist[c] < bounds[i]) : !(dist[c] <= bounds[i])) continue;   // (also drops NaN)
             if (ws_thr && !((1.0 - dist[c]) > (double)thr_score)) continue;         // store.rs:502-503
             order.push_back(c);
         }
@@ -1173,7 +1174,19 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     }
 
     // ---------------- all rows with distance < max_distance (mod.rs:88-89,115-116)
-    for (uint32_t q = 0; q < nq; ++q) {
+    // several queries on a large unfiltered shard: ONE sweep of the batched kernel collects every query's hits (up to a
+    // candidate buffer, 2048 rows, each); a query with more hits than that takes the streaming K4 scan below
+    std::vector<uint32_t> todo(nq);
+    for (uint32_t q = 0; q < nq; ++q) todo[q] = q;
+    if (nr == 0 && nq >= 2 && ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && max_distance <= 2.5 &&
+        corpus->rows >= (uint64_t)ctx->tune.fallback_batch_min_rows) {
+        std::vector<double> bounds(nq, max_distance);
+        std::vector<uint32_t> left;
+        rc = batched_fallback(ctx, corpus, d_q, todo, bounds, ~0ull, false, 0.f, row_base, out, left, /*strict=*/true);
+        if (rc) return rc;
+        todo.swap(left);
+    }
+    for (uint32_t q : todo) {
         ThresholdQuery t;
         t.corpus = corpus->d_rows;
         t.rows = corpus->rows;

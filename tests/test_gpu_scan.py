@@ -127,6 +127,29 @@ def test_threshold_mode_returns_all_under_max_distance(corpus20k):
         assert (dist < thr).all()
 
 
+def test_threshold_mode_several_queries_take_one_batched_sweep(corpus20k):
+    """Several threshold queries on one unfiltered shard are answered by ONE sweep of the batched kernel (api.cpp,
+    batched_fallback with strict = true); a query with more hits than a candidate buffer (2048 rows) still takes the
+    streaming K4 scan.  Same hit lists as the oracle for both kinds."""
+    emb, c = corpus20k
+    qs = synth.unit_query(31, nq=6)
+    c.ctx.set_tuning("fallback_batch_min_rows", 0)
+    try:
+        for thr in (0.82, 0.88, 0.97):                       # ~10, ~300, ~6000 hits per query: the last one overflows
+            c.ctx.prof_enable(True)
+            c.ctx.prof_reset()
+            got = c.search(qs, top_k=3, max_distance=thr)
+            launches, _ = c.ctx.prof_read("gemm_thr")
+            c.ctx.prof_enable(False)
+            assert launches == 1
+            for i in range(len(qs)):
+                res = orc.search_documents(emb, [len(emb)], qs[i], n_lines=0, top_k=3, max_distance=thr, accurate=True)
+                assert got[i][0].tolist() == [r["match_line"] for r in res], (thr, i)
+                assert np.array_equal(got[i][1], np.array([r["distance"] for r in res]))
+    finally:
+        c.ctx.set_tuning("fallback_batch_min_rows", 100000)
+
+
 def test_threshold_truncation_reports_true_count(corpus20k):
     import ctypes as C
     from semtools_amd import _lib as L
