@@ -244,3 +244,33 @@ def test_two_to_seven_queries_take_the_batched_path_on_large_shards(gpu_ctx, nq,
 
 def gpu_ctx_is_rowreg(ctx):
     return getattr(ctx, "_rowreg_mode", True)
+
+
+def test_random_shapes_against_the_oracle(gpu_ctx, nominate_with):
+    """Seeded random (rows, queries, k) triples -- ragged tile counts, single-tile corpora, batches that stream query
+    tiles, planted duplicate / zero rows -- all through K3 (forced from 2 queries on): indices and distances = oracle."""
+    import semtools_amd as smt
+
+    rng = np.random.default_rng(20260923)
+    gpu_ctx.set_tuning("gemm_min_rows_small", 0)
+    gpu_ctx.set_tuning("gemm_min_nq", 2)
+    try:
+        for case in range(10):
+            n_rows = int(rng.choice([1, 31, 33, 1000, 4095, 4096, 4097, 20001, 65537])) if case < 9 else 150000
+            nq = int(rng.choice([2, 3, 9, 31, 32, 33, 64, 129, 161, 260]))
+            k = int(rng.integers(1, min(56, n_rows) + 1))
+            emb = synth.unit_rows(n_rows, seed=1000 + case, dup_frac=0.02, zero_frac=0.002)
+            qs = synth.unit_query(2000 + case, nq=nq)
+            if case % 3 == 0:
+                qs[0] = 0.0                                        # a zero query rides along
+            c = smt.Corpus(gpu_ctx)
+            c.append(emb)
+            got = c.search(qs, top_k=k)
+            for i in sorted(set([0, 1, nq // 2, nq - 1])):
+                orows, odist = _oracle_topk(emb, qs[i], k)
+                assert got[i][0].tolist() == orows, (case, n_rows, nq, k, i)
+                assert np.array_equal(got[i][1], np.array(odist)), (case, n_rows, nq, k, i)
+            c.close()
+    finally:
+        gpu_ctx.set_tuning("gemm_min_rows_small", 1_000_000)
+        gpu_ctx.set_tuning("gemm_min_nq", 3)
