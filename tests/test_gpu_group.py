@@ -94,6 +94,9 @@ def test_logical_shards_equal_the_unsharded_search(plain, n_shards):
         _same(sc.search(qs, **kw), c.search(qs, **kw))
     qb = synth.unit_query(5, nq=12)
     _same(sc.search(qb, top_k=10), c.search(qb, top_k=10))
+    ql = synth.unit_query(6, nq=140)                     # 128+ queries: the f16 x 2 nomination inside every shard, lists merged
+    _same(sc.search(ql, top_k=7), c.search(ql, top_k=7))
+    _same(sc.search(ql[:5], max_distance=0.88), c.search(ql[:5], max_distance=0.88))   # several threshold queries per shard
     # rows appended later extend the last rank's range
     extra = synth.unit_rows(700, seed=77)
     first = sc.append(extra)
