@@ -34,7 +34,7 @@ def _oracle_topk(emb, q, k):
 
 
 @pytest.mark.parametrize("n_rows,nq,k", [(20000, 8, 5), (20000, 33, 10), (4097, 64, 3), (50000, 100, 10),
-                                          (1000, 9, 24), (31, 8, 4), (70000, 40, 1)])
+                                          (1000, 9, 24), (31, 8, 4), (70000, 40, 1), (30001, 200, 10), (5000, 300, 3)])
 def test_batched_matches_oracle(gpu_ctx, n_rows, nq, k):
     import semtools_amd as smt
 
