@@ -288,6 +288,8 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
 
 // K3: batched queries, f32 MFMA with fused candidate selection.
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);
+// bf16 hi / lo split image (mfma_tile.h layout) of n rows of 256 f32, padded with zero rows to n_pad (gemm_kernels.hip)
+int launch_split_rows_bf16(smt_ctx *ctx, const float *rows, uint32_t n, uint32_t n_pad, uint32_t *out);
 // batched threshold pass (gemm_kernels.hip): rows with nominating distance <= tau[q], per query, in scratch buffers
 int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const float *queries, uint32_t nq,
                           const float *tau, const key_t64 **cand_out, const unsigned int **counts_out, uint32_t *cand_stride);

@@ -1383,6 +1383,14 @@ __global__ void set_qconst_thresholds_kernel(float *qconst, const float *tau, ui
     if (q < nq) qconst[2 * q] = score_threshold(tau[q], qconst[2 * q + 1]);
 }
 
+// split image of n rows of 256 f32 (queries, k-means centroids) for the bf16 x 3 kernels of other translation units
+int launch_split_rows_bf16(smt_ctx *ctx, const float *rows, uint32_t n, uint32_t n_pad, uint32_t *out)
+{
+    hipLaunchKernelGGL(split_queries_kernel, dim3((n_pad + 1) / 2), dim3(256), 0, ctx->stream, rows, n, n_pad, out);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
 // ---- batched threshold pass: the exhaustive re-answer of MANY uncertain queries in one sweep (api.cpp).  Every row
 // whose nominating distance is <= tau[q] lands in query q's candidate buffer: gemm_rowreg_kernel over all tiles as a
 // single level with preset thresholds.  A query with more than CAND_CAP such rows reports count > CAND_CAP (the caller

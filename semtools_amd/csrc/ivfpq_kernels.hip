@@ -51,12 +51,15 @@ struct AssignParams {
     uint64_t n_points;        // points to assign
     uint64_t row_stride;      // point i = corpus row i * row_stride  (training sample: stride > 1)
     uint64_t n_rows_total;    // bound for reads
-    const float *centroids;   // [nlist][256]
+    const float *centroids;   // [nlist][256]  (BF16: the bf16 hi / lo split image of the centroids, same row size)
     const float *cnorm_half;  // [nlist] 0.5 * |c|^2
     uint32_t nlist;           // multiple of 32
     uint32_t *assign;         // [n_points]
 };
 
+// BF16: x . c from bf16 x 3 split products (mfma_tile.h; 16 x the f32 MFMA rate, error <= 1.5e-4 |x||c|): an assignment
+// can only differ from the f32 one between two centroids that are equally good to that precision.
+template <bool BF16>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) ivf_assign_kernel(AssignParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -99,13 +102,27 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) ivf_assign_kernel(AssignParam
     for (uint64_t step = 0; step < steps; ++step, it += W) {
         const bool has = it < n_tiles;
         const uint64_t p0 = (has ? it : 0) * 32;
-        f32x4 A[32];
+        f32x4 A[BF16 ? 1 : 32];
+        u32x4 Ah[BF16 ? 16 : 1], Al[BF16 ? 16 : 1];
         if (has) {
             const uint64_t pt = p0 + j;
             const bool ok = pt < p.n_points;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.rows + (ok ? pt * p.row_stride : 0) * 256) + h;
+            if constexpr (BF16) {
+                // lane (j, h): dims 16m + 8h .. + 7 of K-step m
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.rows + (ok ? pt * p.row_stride : 0) * 256) + 2 * h;
+                f32x4 R[32];
 #pragma unroll
-            for (int m = 0; m < 32; ++m) A[m] = ok ? src[2 * m] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < 16; ++m) {
+                    R[2 * m] = ok ? src[4 * m] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    R[2 * m + 1] = ok ? src[4 * m + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int m = 0; m < 16; ++m) bf16_split8(R[2 * m], R[2 * m + 1], Ah[m], Al[m]);
+            } else {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.rows + (ok ? pt * p.row_stride : 0) * 256) + h;
+#pragma unroll
+                for (int m = 0; m < 32; ++m) A[m] = ok ? src[2 * m] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
         unsigned long long best[16];
 #pragma unroll
@@ -116,7 +133,16 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) ivf_assign_kernel(AssignParam
             const uint32_t ct_next = (ct + 1 == nct) ? 0 : ct + 1;
             stage_load(ct_next, nxt);
             if (has) {
-                const f32x16 acc = mfma_tile_32x32x256(A, s_c + cur * QT_F4 + j * QT_STRIDE_F4 + h);
+                f32x16 acc;
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_c + cur * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) acc = mfma_bf16x3(Ah[m], Al[m], bq[4 * m], bq[4 * m + 1], acc);
+                } else {
+                    acc = mfma_tile_32x32x256(A, s_c + cur * QT_F4 + j * QT_STRIDE_F4 + h);
+                }
                 const uint32_t cid = ct * QT_ROWS + j;
                 const float cn = s_cn[cid];
 #pragma unroll
@@ -947,7 +973,9 @@ int run_assign(smt_ctx *ctx, const float *rows, uint64_t n_points, uint64_t stri
                uint32_t *d_assign)
 {
     if (!(ctx->attr_done & ATTR_IVF_ASSIGN)) {  // per context == per device
-        IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_assign_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ivf_assign_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
         IVF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
@@ -966,7 +994,17 @@ int run_assign(smt_ctx *ctx, const float *rows, uint64_t n_points, uint64_t stri
     a.assign = d_assign;
     const uint64_t tiles = (n_points + 31) / 32;
     const int blocks = (int)std::min<uint64_t>((uint64_t)ctx->num_cus, (tiles + GEMM_WAVES - 1) / GEMM_WAVES);
-    hipLaunchKernelGGL(ivf_assign_kernel, dim3(blocks), dim3(GEMM_THREADS), assign_smem(ix->nlist), ctx->stream, a);
+    if (ctx->tune.gemm_bf16x3) {
+        // the centroids' split image lives in the context's scratch for the duration of this launch
+        int rc = smt::ensure_scratch(ctx, (size_t)ix->nlist * 1024);
+        if (rc) return rc;
+        uint32_t *split = reinterpret_cast<uint32_t *>(ctx->d_scratch);
+        if ((rc = smt::launch_split_rows_bf16(ctx, ix->d_centroids, ix->nlist, ix->nlist, split))) return rc;
+        a.centroids = reinterpret_cast<const float *>(split);
+        hipLaunchKernelGGL(ivf_assign_kernel<true>, dim3(blocks), dim3(GEMM_THREADS), assign_smem(ix->nlist), ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(ivf_assign_kernel<false>, dim3(blocks), dim3(GEMM_THREADS), assign_smem(ix->nlist), ctx->stream, a);
+    }
     IVF_HIP(hipGetLastError());
     return SMT_OK;
 }
