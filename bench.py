@@ -359,8 +359,21 @@ def main():
             }
         except Exception as exc:
             result["cpu_baseline"] = {"error": repr(exc)}
+    # The JSON line must be the LAST thing on stdout.  RCCL prints a version banner through C stdio when a communicator is
+    # created; redirected to a file, that text sits in libc's buffer until exit and would land BEHIND the line.  Flush C
+    # stdio first, then print and flush the line.
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        dist.barrier()          # every rank's banner is out before rank 0 writes the line
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.write(json.dumps(result) + "\n")
+        sys.stdout.flush()
     if exchange:
         dist.destroy_process_group()
 
