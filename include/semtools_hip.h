@@ -275,6 +275,10 @@ int smt_group_create(const int *devices, int n_dev, smt_group **out);
  * ranks on one GPU): lets a single-GPU box run the whole sharded path -- the GPU tests do -- and splits a
  * corpus into independently growable shards.  smt_group_info reports rccl_ranks = 0 for such a group. */
 int smt_group_create_logical(int device, int n_shards, smt_group **out);
+/* A ONE-rank group around an existing context (which the caller keeps and destroys after the group): every smt_sharded_*
+ * entry point then forwards to its single-GPU counterpart on that context -- no RCCL is loaded, nothing is exchanged.
+ * It lets a host layer written against the sharded API serve the default single-GPU case at single-GPU cost. */
+int smt_group_from_ctx(smt_ctx *ctx, smt_group **out);
 int smt_group_unique_id(void *id_out /* SMT_UNIQUE_ID_BYTES */);
 int smt_group_create_rank(int device, int rank, int n_ranks, const void *unique_id, smt_group **out);
 void smt_group_destroy(smt_group *group);
@@ -286,25 +290,59 @@ smt_ctx *smt_group_ctx(smt_group *group, int local_index);
 int smt_group_synchronize(smt_group *group); /* every local stream, async pipelines drained */
 int smt_group_barrier(smt_group *group);     /* + an all-gather across the ranks */
 
-/* A corpus row-sharded over the group by contiguous ranges, rows_per_rank = ceil(N / n_ranks) (SURVEY.md 8(e):
- * a document's lines and the path-subset ranges stay ranges).  Global row = position in the whole corpus.
+/* A corpus row-sharded over the group.  Global row = position in the whole corpus = INSERTION ORDER (the reference's tie
+ * order: document, then line -- src/search/mod.rs:84-85,107-111).  A corpus made in one go is cut into contiguous ranges,
+ * rows_per_rank = ceil(N / n_ranks) (a document's lines and the path-subset ranges stay ranges).  A corpus
+ * that GROWS (the workspace store: src/workspace/store.rs:402-434 appends, never rewrites) deals every append over the
+ * ranks -- the emptier shards are filled first, a handful of rows goes to one shard -- so that all GPUs keep equal shares;
+ * the numbering is then a list of pieces (smt_sharded_corpus_layout).  Inside a shard local order == global order.
+ *   create       empty corpus (rows arrive through smt_sharded_embed / append_host)
  *   from_host    `rows` is the WHOLE matrix [total_rows x D]; every process uploads the slices of its local ranks.
  *   from_device  adopt one resident buffer per LOCAL device (not copied, not freed); the ranks' sizes are
  *                exchanged with one all-gather.
- *   load / save  the smt_corpus_save file format; every rank streams its own slice of the file.
- *   append_host  global rows are insertion order, so new rows extend the LAST rank's range.
- *   shard        the smt_corpus behind local device i (+ its first global row and row count), e.g. as the
- *                `append_to` target of smt_embed with a model created on smt_group_ctx(group, i). */
+ *   load / save / append_to_file   the smt_corpus_save file format (rows in global order -- a file written by N GPUs
+ *                loads on one, and back); every rank streams its own pieces.  load cuts the file into ceil(N / n_ranks)
+ *                ranges; load_layout restores a recorded piece list (piece k = piece_rows[k] consecutive global rows on
+ *                rank piece_rank[k]), e.g. so that per-shard index files stay valid.  A failing rank reports through the
+ *                collective: every process returns the error.
+ *   layout       the piece list in global order; returns the piece count (call with cap 0 to size the arrays).
+ *   append_host  n_rows new global rows, dealt to the ranks as described above; every process passes the same rows.
+ *   read_rows / write_rows   rows by global position <-> host (single-process groups: the one caller sees the matrix).
+ *   shard        the smt_corpus behind local device i and its row count; row_base (may be NULL) is only defined -- and
+ *                only accepted -- while the corpus is one range per rank.  Do not append to a shard directly. */
+int smt_sharded_corpus_create(smt_group *group, uint32_t D, smt_sharded_corpus **out);
 int smt_sharded_corpus_from_host(smt_group *group, const float *rows, uint64_t total_rows, uint32_t D, smt_sharded_corpus **out);
 int smt_sharded_corpus_from_device(smt_group *group, const float *const *shard_rows_dev, const uint64_t *shard_rows,
                                    uint32_t D, smt_sharded_corpus **out);
 int smt_sharded_corpus_load(smt_group *group, const char *path, smt_sharded_corpus **out);
+int smt_sharded_corpus_load_layout(smt_group *group, const char *path, const uint64_t *piece_rows, const uint32_t *piece_rank,
+                                   uint64_t n_pieces, smt_sharded_corpus **out);
+uint64_t smt_sharded_corpus_layout(const smt_sharded_corpus *corpus, uint64_t *piece_rows, uint32_t *piece_rank, uint64_t cap);
 int smt_sharded_corpus_save(smt_sharded_corpus *corpus, const char *path);
+int smt_sharded_corpus_append_to_file(smt_sharded_corpus *corpus, const char *path, uint64_t rows_on_disk);
 void smt_sharded_corpus_destroy(smt_sharded_corpus *corpus);
 uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *corpus);
 int smt_sharded_corpus_rank_rows(const smt_sharded_corpus *corpus, uint64_t *rows_per_rank /* [n_ranks] */);
 int smt_sharded_corpus_shard(smt_sharded_corpus *corpus, int local_index, smt_corpus **shard, uint64_t *row_base, uint64_t *rows);
 int smt_sharded_corpus_append_host(smt_sharded_corpus *corpus, const float *rows, uint64_t n_rows, uint64_t *first_row);
+int smt_sharded_corpus_read_rows(smt_sharded_corpus *corpus, uint64_t first_row, uint64_t n_rows, float *out_host);
+int smt_sharded_corpus_write_rows(smt_sharded_corpus *corpus, uint64_t first_row, const float *rows, uint64_t n_rows);
+
+/* The embedding table replicated on every device of the group, and K1 sharded by line ("K1 shards by
+ * line with a replicated table", no collective): the device half of StaticModel::from_pretrained / encode_with_args
+ * (call sites src/search/mod.rs:69,138,153; src/cmds/search.rs:123-128,136,154) for a caller that owns N GPUs.
+ * smt_sharded_embed = smt_embed's arguments and results: the lines are dealt to the ranks in contiguous blocks, block r is
+ * pooled on rank r from its copy of the table (one host thread per device) and, with `append_to`, appended to rank r's
+ * shard; the blocks in rank order become the new global rows, so global row == line order and *first_row = the first of
+ * them.  Every row is bit-identical to smt_embed's (same kernel, same table).  out_host receives [n_lines x D] (in a
+ * multi-process group: the blocks of the local ranks only).  If any rank fails, no shard keeps rows of the call. */
+typedef struct smt_sharded_model smt_sharded_model;
+int smt_sharded_model_create(smt_group *group, const float *table_host, uint64_t V, uint32_t D, int normalize, smt_sharded_model **out);
+int smt_sharded_model_create_from_file(smt_group *group, const char *path, uint64_t byte_offset, uint64_t V, uint32_t D,
+                                       int normalize, smt_sharded_model **out);
+void smt_sharded_model_destroy(smt_sharded_model *model);
+int smt_sharded_embed(smt_sharded_model *model, const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens,
+                      float *out_host, smt_sharded_corpus *append_to, uint64_t *first_row);
 
 /* smt_search over the sharded corpus: same arguments and semantics (ranges and returned rows are GLOBAL), same
  * result as smt_search on the unsharded matrix.  top_k <= 56 without "all under threshold": per-device scan +
@@ -336,6 +374,14 @@ void smt_sharded_ivfpq_destroy(smt_sharded_ivfpq *index);
 smt_ivfpq *smt_sharded_ivfpq_shard(smt_sharded_ivfpq *index, int local_index); /* smt_ivfpq_info etc.; NULL if out of range */
 int smt_sharded_ivfpq_search(smt_sharded_ivfpq *index, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe,
                              uint32_t rerank, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap);
+/* Life cycle, shard by shard (smt_ivfpq_save / _load / _append / _info on every local rank).  A one-rank group uses `path`
+ * itself; otherwise rank r's part is `<path>.r<r>of<n_ranks>` -- the files name LOCAL rows by position, so they are valid
+ * for the layout they were built on (persist it with smt_sharded_corpus_layout, restore it with _load_layout).
+ * info: rows covered and index bytes summed over the local ranks, the largest nlist. */
+int smt_sharded_ivfpq_save(smt_sharded_ivfpq *index, const char *path);
+int smt_sharded_ivfpq_load(smt_sharded_corpus *corpus, const char *path, smt_sharded_ivfpq **out);
+int smt_sharded_ivfpq_append(smt_sharded_ivfpq *index, uint64_t *n_added);
+int smt_sharded_ivfpq_info(const smt_sharded_ivfpq *index, uint64_t *rows_covered, uint32_t *nlist, uint64_t *index_bytes);
 
 /* Exactness bookkeeping.  The f32 scan nominates top_k + 8 rows per list and the select stage PROVES per query
  * that no other row can belong to the exact answer (the k-th exact distance lies more than the f32 error bound

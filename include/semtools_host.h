@@ -87,6 +87,26 @@ int smt_host_workspace_reembed(smt_host_model *model, const char *name_or_null, 
 
 void smt_host_free(char *text);
 
+/* ---- the host layer on SEVERAL GPUs.  The caller is one process (src/bin/semtools.rs:134-135 runs the search from one
+ * task); it hands the layer an smt_group instead of a context and everything above runs sharded: the embedding table is
+ * replicated per GPU (smt_sharded_model), lines are pooled by all GPUs at once (smt_sharded_embed), the Documents' /
+ * workspace store's matrix is an smt_sharded_corpus whose rows are dealt over the GPUs as they arrive, searches end in
+ * ONE all-gather of per-shard top-k lists, the optional index is built with shared centroids.  Output bytes are the same
+ * as on one GPU (the global row order is insertion order either way).  The `smt_ctx *` forms above are these with a
+ * one-rank group (smt_group_from_ctx).  The group must outlive the model / calls.
+ *   smt_host_group_from_spec   "0,1,2,3" = those GPUs (RCCL), "all" = every visible GPU, "<d>:<n>" = n logical shards on
+ *                              GPU d (one-GPU test rigs), "<d>" = GPU d alone.  The CLI reads $SEMTOOLS_DEVICES with it.
+ * The workspace store records how its rows were dealt over the GPUs (line_rows.json "shards"); the vector file itself
+ * holds the rows in global order, so a store written by N GPUs opens on one, and back. */
+int smt_host_group_from_spec(const char *spec, smt_group **out);
+int smt_host_model_create_group(smt_group *group, const float *table, uint64_t V, int normalize, int tok_kind,
+                                const char *vocab_path, const char *unk_token, smt_tokenize_cb cb, void *user,
+                                uint32_t unk_id, uint32_t median_len, smt_host_model **out);
+int smt_host_model_from_dir_group(smt_group *group, const char *dir, smt_host_model **out);
+int smt_host_workspace_use_group(smt_group *group, const char *name, int json, char **out_text);
+int smt_host_workspace_status_group(smt_group *group, const char *name_or_null, int json, char **out_text);
+int smt_host_workspace_prune_group(smt_group *group, const char *name_or_null, int json, char **out_text);
+
 /* A Hugging Face `tokenizer.json`, read natively (no Python): what model2vec-rs loads through the `tokenizers` crate
  * (call sites src/cmds/search.rs:123-128; encode_batch_fast(.., add_special_tokens = false) inside encode_with_args).
  * Supported components: BertNormalizer / Lowercase / NFD / StripAccents / Strip / Replace(String) / Sequence;

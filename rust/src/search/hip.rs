@@ -16,11 +16,16 @@ use std::fs::read_to_string;
 use std::ptr;
 use tokenizers::Tokenizer;
 
-/// Handles that live as long as the process: one GPU context, the model table, the corpus of this invocation.
+/// Handles that live as long as the process: the GPUs this process owns (an `smt_group`: one GPU by default, every
+/// GPU of the node when `devices` lists them -- the reference runs the whole search from ONE task,
+/// src/bin/semtools.rs:134-135, and that one caller drives them all), the model table replicated on each of them,
+/// and the corpus of this invocation, its rows dealt over the GPUs as they are embedded.  With one device every
+/// `smt_sharded_*` call below IS its single-GPU counterpart (`smt_group_from_ctx`).
 pub struct GpuSearch {
-    ctx: *mut SmtCtx,
-    model: *mut SmtModel,
-    corpus: *mut SmtCorpus,
+    ctx: *mut SmtCtx,                 // only for the one-GPU form (the group borrows it)
+    group: *mut SmtGroup,
+    model: *mut SmtShardedModel,
+    corpus: *mut SmtShardedCorpus,
     tokenizer: Tokenizer,
     unk_id: Option<u32>,
     median_token_len: usize,
@@ -36,15 +41,21 @@ pub struct GpuDocument {
 impl GpuSearch {
     /// `table`: the model's `embeddings` tensor [vocab x 256] as f32 (what `StaticModel::from_pretrained` loads,
     /// call sites src/cmds/search.rs:123-128); it is uploaded once.
-    pub fn new(device: i32, table: &[f32], vocab: usize, normalize: bool, tokenizer: Tokenizer, unk_id: Option<u32>,
+    /// `devices`: the GPU ordinals to use, e.g. from `SEMTOOLS_DEVICES=0,1,2,3` (one entry = today's single GPU).
+    pub fn new(devices: &[i32], table: &[f32], vocab: usize, normalize: bool, tokenizer: Tokenizer, unk_id: Option<u32>,
                median_token_len: usize) -> Result<Self> {
-        let (mut ctx, mut model, mut corpus) = (ptr::null_mut(), ptr::null_mut(), ptr::null_mut());
+        let (mut ctx, mut group, mut model, mut corpus) = (ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut());
         unsafe {
-            check(smt_ctx_create(device, &mut ctx))?;
-            check(smt_model_create(ctx, table.as_ptr(), vocab as u64, SMT_DIM, normalize as i32, &mut model))?;
-            check(smt_corpus_create(ctx, SMT_DIM, 0, &mut corpus))?;
+            if devices.len() == 1 {
+                check(smt_ctx_create(devices[0], &mut ctx))?;
+                check(smt_group_from_ctx(ctx, &mut group))?;                 // no RCCL, nothing exchanged
+            } else {
+                check(smt_group_create(devices.as_ptr(), devices.len() as i32, &mut group))?;   // ncclCommInitAll
+            }
+            check(smt_sharded_model_create(group, table.as_ptr(), vocab as u64, SMT_DIM, normalize as i32, &mut model))?;
+            check(smt_sharded_corpus_create(group, SMT_DIM, &mut corpus))?;
         }
-        Ok(Self { ctx, model, corpus, tokenizer, unk_id, median_token_len })
+        Ok(Self { ctx, group, model, corpus, tokenizer, unk_id, median_token_len })
     }
 
     /// model2vec-rs' front half of `encode_with_args`: char pre-truncation, `encode_batch_fast(.., false)`, unk
@@ -69,8 +80,8 @@ impl GpuSearch {
     pub fn encode_single(&self, query: &str) -> Result<Vec<f32>> {
         let (ids, offsets) = self.tokenize(&[query.to_string()], 512)?;
         let mut out = vec![0f32; SMT_DIM as usize];
-        check(unsafe { smt_embed(self.model, ids.as_ptr(), offsets.as_ptr(), 1, 512, out.as_mut_ptr(), ptr::null_mut(),
-                                 ptr::null_mut()) })?;
+        check(unsafe { smt_sharded_embed(self.model, ids.as_ptr(), offsets.as_ptr(), 1, 512, out.as_mut_ptr(), ptr::null_mut(),
+                                         ptr::null_mut()) })?;
         Ok(out)
     }
 
@@ -87,8 +98,10 @@ impl GpuSearch {
         for batch in for_embedding.chunks(16384) {            // encode_with_args(.., Some(2048), 16384)
             let (ids, offsets) = self.tokenize(batch, 2048)?;
             let mut first = 0u64;
-            check(unsafe { smt_embed(self.model, ids.as_ptr(), offsets.as_ptr(), batch.len() as u64, 2048,
-                                     ptr::null_mut(), self.corpus, &mut first) })?;
+            // lines are dealt to the GPUs in contiguous blocks, pooled by all of them at once and appended to their
+            // shards; `first` is the first of the new GLOBAL rows (global row == line order)
+            check(unsafe { smt_sharded_embed(self.model, ids.as_ptr(), offsets.as_ptr(), batch.len() as u64, 2048,
+                                             ptr::null_mut(), self.corpus, &mut first) })?;
             if batch.as_ptr() == for_embedding.as_ptr() {
                 first_row = first;
             }
@@ -99,7 +112,7 @@ impl GpuSearch {
     /// `search_documents` (mod.rs:77-120).  `documents` must be the documents embedded into this corpus, in order.
     pub fn search_documents(&self, documents: &[GpuDocument], query_embedding: &[f32], config: &SearchConfig)
         -> Result<Vec<SearchResult>> {
-        let total = unsafe { smt_corpus_rows(self.corpus) };
+        let total = unsafe { smt_sharded_corpus_rows(self.corpus) };
         if total == 0 {
             return Ok(Vec::new());
         }
@@ -110,9 +123,10 @@ impl GpuSearch {
         loop {
             rows.resize(cap as usize, 0u64);
             dist.resize(cap as usize, 0f64);
-            let rc = unsafe { smt_search(self.corpus, query_embedding.as_ptr(), 1, config.top_k as u32,
-                                         config.max_distance.unwrap_or(f64::NAN), SMT_MODE_DOCUMENTS, ptr::null(), 0, 0,
-                                         rows.as_mut_ptr(), dist.as_mut_ptr(), &mut n, cap) };
+            // per-GPU scan + select, ONE all-gather of the per-shard top-k lists, merge: rows come back global
+            let rc = unsafe { smt_sharded_search(self.corpus, query_embedding.as_ptr(), 1, config.top_k as u32,
+                                                 config.max_distance.unwrap_or(f64::NAN), SMT_MODE_DOCUMENTS, ptr::null(), 0,
+                                                 rows.as_mut_ptr(), dist.as_mut_ptr(), &mut n, cap) };
             if rc == SMT_E_TRUNCATED {
                 cap = n;
                 continue;
@@ -150,20 +164,23 @@ impl GpuSearch {
     /// Rows of a document just embedded, for `search_with_workspace` (mod.rs:168-181: one LineEmbedding per line).
     pub fn read_rows(&self, first_row: u64, n: usize) -> Result<Vec<f32>> {
         let mut out = vec![0f32; n * SMT_DIM as usize];
-        check(unsafe { smt_corpus_read_rows(self.corpus, first_row, n as u64, out.as_mut_ptr()) })?;
+        check(unsafe { smt_sharded_corpus_read_rows(self.corpus, first_row, n as u64, out.as_mut_ptr()) })?;
         Ok(out)
     }
 
-    pub fn ctx(&self) -> *mut SmtCtx { self.ctx }
-    pub fn model(&self) -> *mut SmtModel { self.model }
+    pub fn group(&self) -> *mut SmtGroup { self.group }
+    pub fn model(&self) -> *mut SmtShardedModel { self.model }
 }
 
 impl Drop for GpuSearch {
     fn drop(&mut self) {
         unsafe {
-            smt_corpus_destroy(self.corpus);
-            smt_model_destroy(self.model);
-            smt_ctx_destroy(self.ctx);
+            smt_sharded_corpus_destroy(self.corpus);
+            smt_sharded_model_destroy(self.model);
+            smt_group_destroy(self.group);
+            if !self.ctx.is_null() {
+                smt_ctx_destroy(self.ctx);                              // (after the group that borrowed it)
+            }
         }
     }
 }
@@ -181,7 +198,7 @@ pub fn search_with_workspace(gpu: &mut GpuSearch, files: &[String], query: &str,
     let query_embedding = gpu.encode_single(query)?;
     let ws = Workspace::open(workspace_name)?;
     let store = Store::open(&ws.config.root_dir)?;                       // document metadata stays where it is
-    let mut lines = HipLineStore::open(gpu.ctx(), &ws.config.root_dir)?; // replaces line_embeddings.qdrant
+    let mut lines = HipLineStore::open(gpu.group(), &ws.config.root_dir)?; // replaces line_embeddings.qdrant
     let doc_states = store.analyze_document_states(files)?;              // mod.rs:158 (store.rs:549-611)
     let (mut n_lines, mut docs_to_upsert) = (0usize, Vec::new());
     for state in &doc_states {

@@ -8,7 +8,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 macro_rules! opaque { ($($name:ident),*) => { $( #[repr(C)] pub struct $name { _private: [u8; 0] } )* } }
-opaque!(SmtCtx, SmtModel, SmtCorpus, SmtIvfpq, SmtGroup, SmtShardedCorpus, SmtShardedIvfpq);
+opaque!(SmtCtx, SmtModel, SmtCorpus, SmtIvfpq, SmtGroup, SmtShardedCorpus, SmtShardedIvfpq, SmtShardedModel);
 
 /// half-open range of corpus rows [begin, end)
 #[repr(C)]
@@ -217,6 +217,7 @@ extern "C" {
     pub fn smt_default_group() -> *mut SmtGroup;
     pub fn smt_group_create(devices: *const c_int, n_dev: c_int, out: *mut *mut SmtGroup) -> c_int;
     pub fn smt_group_create_logical(device: c_int, n_shards: c_int, out: *mut *mut SmtGroup) -> c_int;
+    pub fn smt_group_from_ctx(ctx: *mut SmtCtx, out: *mut *mut SmtGroup) -> c_int;
     pub fn smt_group_unique_id(id_out: *mut c_void) -> c_int;
     pub fn smt_group_create_rank(
         device: c_int,
@@ -237,6 +238,7 @@ extern "C" {
     pub fn smt_group_ctx(group: *mut SmtGroup, local_index: c_int) -> *mut SmtCtx;
     pub fn smt_group_synchronize(group: *mut SmtGroup) -> c_int;
     pub fn smt_group_barrier(group: *mut SmtGroup) -> c_int;
+    pub fn smt_sharded_corpus_create(group: *mut SmtGroup, D: u32, out: *mut *mut SmtShardedCorpus) -> c_int;
     pub fn smt_sharded_corpus_from_host(
         group: *mut SmtGroup,
         rows: *const f32,
@@ -256,7 +258,26 @@ extern "C" {
         path: *const c_char,
         out: *mut *mut SmtShardedCorpus,
     ) -> c_int;
+    pub fn smt_sharded_corpus_load_layout(
+        group: *mut SmtGroup,
+        path: *const c_char,
+        piece_rows: *const u64,
+        piece_rank: *const u32,
+        n_pieces: u64,
+        out: *mut *mut SmtShardedCorpus,
+    ) -> c_int;
+    pub fn smt_sharded_corpus_layout(
+        corpus: *const SmtShardedCorpus,
+        piece_rows: *mut u64,
+        piece_rank: *mut u32,
+        cap: u64,
+    ) -> u64;
     pub fn smt_sharded_corpus_save(corpus: *mut SmtShardedCorpus, path: *const c_char) -> c_int;
+    pub fn smt_sharded_corpus_append_to_file(
+        corpus: *mut SmtShardedCorpus,
+        path: *const c_char,
+        rows_on_disk: u64,
+    ) -> c_int;
     pub fn smt_sharded_corpus_destroy(corpus: *mut SmtShardedCorpus);
     pub fn smt_sharded_corpus_rows(corpus: *const SmtShardedCorpus) -> u64;
     pub fn smt_sharded_corpus_rank_rows(corpus: *const SmtShardedCorpus, rows_per_rank: *mut u64) -> c_int;
@@ -271,6 +292,46 @@ extern "C" {
         corpus: *mut SmtShardedCorpus,
         rows: *const f32,
         n_rows: u64,
+        first_row: *mut u64,
+    ) -> c_int;
+    pub fn smt_sharded_corpus_read_rows(
+        corpus: *mut SmtShardedCorpus,
+        first_row: u64,
+        n_rows: u64,
+        out_host: *mut f32,
+    ) -> c_int;
+    pub fn smt_sharded_corpus_write_rows(
+        corpus: *mut SmtShardedCorpus,
+        first_row: u64,
+        rows: *const f32,
+        n_rows: u64,
+    ) -> c_int;
+    pub fn smt_sharded_model_create(
+        group: *mut SmtGroup,
+        table_host: *const f32,
+        V: u64,
+        D: u32,
+        normalize: c_int,
+        out: *mut *mut SmtShardedModel,
+    ) -> c_int;
+    pub fn smt_sharded_model_create_from_file(
+        group: *mut SmtGroup,
+        path: *const c_char,
+        byte_offset: u64,
+        V: u64,
+        D: u32,
+        normalize: c_int,
+        out: *mut *mut SmtShardedModel,
+    ) -> c_int;
+    pub fn smt_sharded_model_destroy(model: *mut SmtShardedModel);
+    pub fn smt_sharded_embed(
+        model: *mut SmtShardedModel,
+        ids: *const u32,
+        offsets: *const u64,
+        n_lines: u64,
+        max_tokens: u32,
+        out_host: *mut f32,
+        append_to: *mut SmtShardedCorpus,
         first_row: *mut u64,
     ) -> c_int;
     pub fn smt_sharded_search(
@@ -313,6 +374,19 @@ extern "C" {
         out_dist: *mut f64,
         out_counts: *mut u64,
         out_cap: u64,
+    ) -> c_int;
+    pub fn smt_sharded_ivfpq_save(index: *mut SmtShardedIvfpq, path: *const c_char) -> c_int;
+    pub fn smt_sharded_ivfpq_load(
+        corpus: *mut SmtShardedCorpus,
+        path: *const c_char,
+        out: *mut *mut SmtShardedIvfpq,
+    ) -> c_int;
+    pub fn smt_sharded_ivfpq_append(index: *mut SmtShardedIvfpq, n_added: *mut u64) -> c_int;
+    pub fn smt_sharded_ivfpq_info(
+        index: *const SmtShardedIvfpq,
+        rows_covered: *mut u64,
+        nlist: *mut u32,
+        index_bytes: *mut u64,
     ) -> c_int;
     pub fn smt_ctx_uncertain_count(ctx: *mut SmtCtx, count: *mut u64, reset: c_int) -> c_int;
     pub fn smt_debug_batched_scores(

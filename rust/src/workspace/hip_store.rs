@@ -2,8 +2,12 @@
 //! `upsert_line_embeddings` (:402-434), `search_line_embeddings` (:481-546), `delete_line_embeddings`,
 //! `count_line_embeddings`.  UNCOMPILED here -- see rust/README.md.
 //!
-//! Storage: one flat corpus file `line_embeddings.f32` (smt_corpus_save format) + `line_rows.json`
-//! (path -> first_row, n_lines).  A document's lines are contiguous rows, so the reference's payload filter
+//! Storage: one flat corpus file `line_embeddings.f32` (smt_corpus_save format, rows in global = insertion order
+//! whatever the number of GPUs that wrote it) + `line_rows.json` (path -> first_row, n_lines; and how the rows were
+//! dealt over the GPUs, so that a group of the same size gets the same shards back).  The matrix lives in an
+//! `smt_sharded_corpus` on the caller's `smt_group`: every upsert is pooled by all GPUs at once and its rows are dealt
+//! over them; every search is a per-GPU scan + one all-gather + merge.  With a one-GPU group these are the single-GPU
+//! calls.  A document's lines are contiguous GLOBAL rows, so the reference's payload filter
 //! `path IN subset` (:507-515) becomes a sorted list of row ranges, and a re-embedded document simply gets a fresh
 //! extent (the reference's stale-tail-rows quirk of upsert-only storage is not reproduced).
 use crate::search::hip_ffi::*;
@@ -20,51 +24,84 @@ struct Extent {
     n_lines: u64,
 }
 
+/// `line_rows.json`
+#[derive(Default, serde::Serialize, serde::Deserialize)]
+struct RowsFile {
+    extents: BTreeMap<String, Extent>,
+    /// (rows, rank) per piece of the global row numbering, in global order, and the group size it was dealt over
+    #[serde(default)]
+    n_ranks: i32,
+    #[serde(default)]
+    pieces: Vec<(u64, u32)>,
+}
+
 pub struct HipLineStore {
-    corpus: *mut SmtCorpus,
+    group: *mut SmtGroup,
+    corpus: *mut SmtShardedCorpus,
     extents: BTreeMap<String, Extent>,
     dir: PathBuf,
     rows_on_disk: u64,
 }
 
 impl HipLineStore {
-    pub fn open(ctx: *mut SmtCtx, root_dir: &str) -> Result<Self> {
+    pub fn open(group: *mut SmtGroup, root_dir: &str) -> Result<Self> {
         let dir = Path::new(root_dir).to_path_buf();
         let file = dir.join("line_embeddings.f32");
         let mut corpus = ptr::null_mut();
-        let mut extents = BTreeMap::new();
+        let mut table = RowsFile::default();
         if file.exists() {
             let c = CString::new(file.to_string_lossy().as_bytes())?;
-            check(unsafe { smt_corpus_load(ctx, c.as_ptr(), &mut corpus) })?;
             if let Ok(text) = std::fs::read_to_string(dir.join("line_rows.json")) {
-                extents = serde_json::from_str(&text)?;
+                table = serde_json::from_str(&text)?;
             }
+            let mut n_ranks = 0i32;
+            check(unsafe { smt_group_info(group, &mut n_ranks, ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut()) })?;
+            // the same number of GPUs as the run that wrote the store: every shard gets its rows back; otherwise the
+            // matrix is cut into ceil(N / n_ranks) ranges (the file is in global row order either way)
+            let mut rc = SMT_E_INVALID;
+            if n_ranks > 1 && table.n_ranks == n_ranks && !table.pieces.is_empty() {
+                let rows: Vec<u64> = table.pieces.iter().map(|p| p.0).collect();
+                let rank: Vec<u32> = table.pieces.iter().map(|p| p.1).collect();
+                rc = unsafe { smt_sharded_corpus_load_layout(group, c.as_ptr(), rows.as_ptr(), rank.as_ptr(), rows.len() as u64, &mut corpus) };
+            }
+            if rc == SMT_E_INVALID {
+                rc = unsafe { smt_sharded_corpus_load(group, c.as_ptr(), &mut corpus) };
+            }
+            check(rc)?;
         } else {
-            check(unsafe { smt_corpus_create(ctx, SMT_DIM, 0, &mut corpus) })?;
+            check(unsafe { smt_sharded_corpus_create(group, SMT_DIM, &mut corpus) })?;
         }
-        let rows_on_disk = if file.exists() { unsafe { smt_corpus_rows(corpus) } } else { 0 };
-        Ok(Self { corpus, extents, dir, rows_on_disk })
+        let rows_on_disk = if file.exists() { unsafe { smt_sharded_corpus_rows(corpus) } } else { 0 };
+        Ok(Self { group, corpus, extents: table.extents, dir, rows_on_disk })
     }
 
-    /// `upsert_line_embeddings` for one document: its lines are pooled on the GPU straight into fresh corpus rows.
-    pub fn upsert_document(&mut self, model: *mut SmtModel, path: &str, ids: &[u32], offsets: &[u64]) -> Result<()> {
+    /// `upsert_line_embeddings` for one document: its lines are pooled on the GPUs straight into fresh corpus rows
+    /// (`first` = the first of the new global rows; the document's lines stay contiguous in the global numbering).
+    pub fn upsert_document(&mut self, model: *mut SmtShardedModel, path: &str, ids: &[u32], offsets: &[u64]) -> Result<()> {
         let n = (offsets.len() - 1) as u64;
         let mut first = 0u64;
-        check(unsafe { smt_embed(model, ids.as_ptr(), offsets.as_ptr(), n, 2048, ptr::null_mut(), self.corpus, &mut first) })?;
+        check(unsafe { smt_sharded_embed(model, ids.as_ptr(), offsets.as_ptr(), n, 2048, ptr::null_mut(), self.corpus, &mut first) })?;
         self.extents.insert(path.to_string(), Extent { first_row: first, n_lines: n });
         Ok(())
     }
 
-    /// `flush_line_embeddings`: append the new rows to the file (O(new rows)), then the row table.
+    /// `flush_line_embeddings`: append the new rows to the file (O(new rows): every GPU writes its own pieces), then
+    /// the row table with the layout.
     pub fn flush(&mut self) -> Result<()> {
         let file = CString::new(self.dir.join("line_embeddings.f32").to_string_lossy().as_bytes())?;
         if self.rows_on_disk == 0 {
-            check(unsafe { smt_corpus_save(self.corpus, file.as_ptr()) })?;
+            check(unsafe { smt_sharded_corpus_save(self.corpus, file.as_ptr()) })?;
         } else {
-            check(unsafe { smt_corpus_append_to_file(self.corpus, file.as_ptr(), self.rows_on_disk) })?;
+            check(unsafe { smt_sharded_corpus_append_to_file(self.corpus, file.as_ptr(), self.rows_on_disk) })?;
         }
-        self.rows_on_disk = unsafe { smt_corpus_rows(self.corpus) };
-        std::fs::write(self.dir.join("line_rows.json"), serde_json::to_string(&self.extents)?)?;
+        self.rows_on_disk = unsafe { smt_sharded_corpus_rows(self.corpus) };
+        let mut n_ranks = 0i32;
+        check(unsafe { smt_group_info(self.group, &mut n_ranks, ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut()) })?;
+        let n = unsafe { smt_sharded_corpus_layout(self.corpus, ptr::null_mut(), ptr::null_mut(), 0) } as usize;
+        let (mut rows, mut rank) = (vec![0u64; n], vec![0u32; n]);
+        unsafe { smt_sharded_corpus_layout(self.corpus, rows.as_mut_ptr(), rank.as_mut_ptr(), n as u64) };
+        let table = RowsFile { extents: self.extents.clone(), n_ranks, pieces: rows.into_iter().zip(rank).collect() };
+        std::fs::write(self.dir.join("line_rows.json"), serde_json::to_string(&table)?)?;
         Ok(())
     }
 
@@ -95,10 +132,11 @@ impl HipLineStore {
         }
         let ranges: Vec<SmtRange> = owners.iter().map(|(r, _)| *r).collect();
         let (mut rows, mut dist, mut n) = (vec![0u64; top_k], vec![0f64; top_k], 0u64);
-        check(unsafe { smt_search(self.corpus, query_vec.as_ptr(), 1, top_k as u32,
-                                  max_distance.map(|d| d as f64).unwrap_or(f64::NAN), SMT_MODE_WORKSPACE,
-                                  ranges.as_ptr(), ranges.len() as u32, 0, rows.as_mut_ptr(), dist.as_mut_ptr(), &mut n,
-                                  top_k as u64) })?;
+        // global ranges in, global rows out: the library cuts the ranges along the shards' pieces
+        check(unsafe { smt_sharded_search(self.corpus, query_vec.as_ptr(), 1, top_k as u32,
+                                          max_distance.map(|d| d as f64).unwrap_or(f64::NAN), SMT_MODE_WORKSPACE,
+                                          ranges.as_ptr(), ranges.len() as u32, rows.as_mut_ptr(), dist.as_mut_ptr(), &mut n,
+                                          top_k as u64) })?;
         Ok((0..n as usize).map(|i| {
             let j = owners.partition_point(|(r, _)| r.end <= rows[i]);
             let (r, path) = owners[j];
@@ -109,6 +147,6 @@ impl HipLineStore {
 
 impl Drop for HipLineStore {
     fn drop(&mut self) {
-        unsafe { smt_corpus_destroy(self.corpus) };
+        unsafe { smt_sharded_corpus_destroy(self.corpus) };
     }
 }

@@ -33,6 +33,10 @@ EXPORTS = [
     "smt_sharded_corpus_destroy", "smt_sharded_corpus_rows", "smt_sharded_corpus_rank_rows", "smt_sharded_corpus_shard",
     "smt_sharded_corpus_append_host", "smt_sharded_search", "smt_sharded_search_topk_device",
     "smt_sharded_ivfpq_build", "smt_sharded_ivfpq_destroy", "smt_sharded_ivfpq_shard", "smt_sharded_ivfpq_search",
+    "smt_group_from_ctx", "smt_sharded_corpus_create", "smt_sharded_corpus_load_layout", "smt_sharded_corpus_layout",
+    "smt_sharded_corpus_append_to_file", "smt_sharded_corpus_read_rows", "smt_sharded_corpus_write_rows",
+    "smt_sharded_model_create", "smt_sharded_model_create_from_file", "smt_sharded_model_destroy", "smt_sharded_embed",
+    "smt_sharded_ivfpq_save", "smt_sharded_ivfpq_load", "smt_sharded_ivfpq_append", "smt_sharded_ivfpq_info",
 ]
 UNIQUE_ID_BYTES = 128
 HOST_EXPORTS = [
@@ -42,6 +46,8 @@ HOST_EXPORTS = [
     "smt_host_workspace_status", "smt_host_workspace_prune", "smt_host_workspace_reembed", "smt_host_free", "smt_host_timing_json", "smt_host_tokenizer_load", "smt_host_tokenizer_free",
     "smt_host_tokenizer_encode", "smt_host_tokenizer_info", "smt_host_format_float",
     "smt_host_split_lines", "smt_host_to_lowercase",
+    "smt_host_group_from_spec", "smt_host_model_create_group", "smt_host_model_from_dir_group",
+    "smt_host_workspace_use_group", "smt_host_workspace_status_group", "smt_host_workspace_prune_group",
 ]
 TOKENIZE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64,
                           C.POINTER(C.c_uint64))
@@ -188,8 +194,31 @@ def lib():
     L.smt_sharded_ivfpq_shard.argtypes = [vp, i32]
     L.smt_sharded_ivfpq_shard.restype = vp
     L.smt_sharded_ivfpq_search.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, u64]
+    L.smt_group_from_ctx.argtypes = [vp, P(vp)]
+    L.smt_sharded_corpus_create.argtypes = [vp, u32, P(vp)]
+    L.smt_sharded_corpus_load_layout.argtypes = [vp, C.c_char_p, vp, vp, u64, P(vp)]
+    L.smt_sharded_corpus_layout.argtypes = [vp, vp, vp, u64]
+    L.smt_sharded_corpus_layout.restype = u64
+    L.smt_sharded_corpus_append_to_file.argtypes = [vp, C.c_char_p, u64]
+    L.smt_sharded_corpus_read_rows.argtypes = [vp, u64, u64, vp]
+    L.smt_sharded_corpus_write_rows.argtypes = [vp, u64, vp, u64]
+    L.smt_sharded_model_create.argtypes = [vp, vp, u64, u32, i32, P(vp)]
+    L.smt_sharded_model_create_from_file.argtypes = [vp, C.c_char_p, u64, u64, u32, i32, P(vp)]
+    L.smt_sharded_model_destroy.argtypes = [vp]
+    L.smt_sharded_model_destroy.restype = None
+    L.smt_sharded_embed.argtypes = [vp, vp, vp, u64, u32, vp, vp, P(u64)]
+    L.smt_sharded_ivfpq_save.argtypes = [vp, C.c_char_p]
+    L.smt_sharded_ivfpq_load.argtypes = [vp, C.c_char_p, P(vp)]
+    L.smt_sharded_ivfpq_append.argtypes = [vp, P(u64)]
+    L.smt_sharded_ivfpq_info.argtypes = [vp, P(u64), P(u32), P(u64)]
     # ---- host layer (include/semtools_host.h)
     cpp = P(C.c_char_p)
+    L.smt_host_group_from_spec.argtypes = [C.c_char_p, P(vp)]
+    L.smt_host_model_create_group.argtypes = [vp, vp, u64, i32, i32, C.c_char_p, C.c_char_p, TOKENIZE_CB, vp, u32, u32, P(vp)]
+    L.smt_host_model_from_dir_group.argtypes = [vp, C.c_char_p, P(vp)]
+    L.smt_host_workspace_use_group.argtypes = [vp, C.c_char_p, i32, P(vp)]
+    L.smt_host_workspace_status_group.argtypes = [vp, C.c_char_p, i32, P(vp)]
+    L.smt_host_workspace_prune_group.argtypes = [vp, C.c_char_p, i32, P(vp)]
     L.smt_host_model_create.argtypes = [vp, vp, u64, i32, i32, C.c_char_p, C.c_char_p, TOKENIZE_CB, vp, u32, u32, P(vp)]
     L.smt_host_model_from_dir.argtypes = [vp, C.c_char_p, P(vp)]
     L.smt_host_model_destroy.argtypes = [vp]

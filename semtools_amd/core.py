@@ -342,6 +342,22 @@ class Group:
         L.check(L.lib().smt_group_create_logical(int(device), int(n_shards), C.byref(h)))
         return cls(_handle=h)
 
+    @classmethod
+    def from_ctx(cls, ctx):
+        """A one-rank group around an existing Context: every sharded call forwards to its single-GPU counterpart."""
+        h = C.c_void_p()
+        L.check(L.lib().smt_group_from_ctx(ctx._h, C.byref(h)))
+        g = cls(_handle=h)
+        g._keep = ctx   # the context must outlive the group
+        return g
+
+    @classmethod
+    def from_spec(cls, spec):
+        """"0,1,2" / "all" / "<device>:<logical shards>" / "<device>" -- what the CLI reads from $SEMTOOLS_DEVICES."""
+        h = C.c_void_p()
+        L.check(L.lib().smt_host_group_from_spec(str(spec).encode(), C.byref(h)))
+        return cls(_handle=h)
+
     @staticmethod
     def unique_id():
         buf = (C.c_ubyte * L.UNIQUE_ID_BYTES)()
@@ -389,14 +405,55 @@ class Group:
             pass
 
 
-class ShardedCorpus:
-    """Corpus row-sharded over a Group by contiguous ranges, ceil(N / n_ranks) rows per rank (smt_sharded_corpus).
-    search() has Corpus.search's arguments and returns the same answer as the unsharded matrix would."""
+class ShardedModel:
+    """The embedding table replicated on every GPU of a Group; embed() = Model.embed with the lines dealt over the ranks."""
 
-    def __init__(self, group, rows=None, device_ptrs=None, shard_rows=None, path=None):
+    def __init__(self, group, table, normalize=True):
         self.group = group
         self._h = C.c_void_p()
-        if path is not None:
+        table = _f32c(table).reshape(-1, L.DIM)
+        self.V = table.shape[0]
+        L.check(L.lib().smt_sharded_model_create(group._h, L.np_ptr(table), self.V, L.DIM, int(normalize), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().smt_sharded_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def embed(self, ids, offsets, max_tokens=2048, append_to=None, want_host=True):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.empty((n, L.DIM), dtype=np.float32) if want_host else None
+        first = C.c_uint64(0)
+        L.check(L.lib().smt_sharded_embed(self._h, L.np_ptr(ids) if len(ids) else None, L.np_ptr(offsets), n, int(max_tokens),
+                                          L.np_ptr(out) if out is not None else None,
+                                          append_to._h if append_to is not None else None, C.byref(first)))
+        return out, int(first.value)
+
+
+class ShardedCorpus:
+    """Corpus row-sharded over a Group (smt_sharded_corpus): cut into ceil(N / n_ranks)-row ranges when made in one go,
+    dealt over the ranks append by append when it grows.  Global row == insertion order either way.
+    search() has Corpus.search's arguments and returns the same answer as the unsharded matrix would."""
+
+    def __init__(self, group, rows=None, device_ptrs=None, shard_rows=None, path=None, layout=None, empty=False):
+        self.group = group
+        self._h = C.c_void_p()
+        if empty:
+            L.check(L.lib().smt_sharded_corpus_create(group._h, L.DIM, C.byref(self._h)))
+        elif path is not None and layout is not None:
+            pr = np.ascontiguousarray([p[0] for p in layout], dtype=np.uint64)
+            rk = np.ascontiguousarray([p[1] for p in layout], dtype=np.uint32)
+            L.check(L.lib().smt_sharded_corpus_load_layout(group._h, str(path).encode(), L.np_ptr(pr), L.np_ptr(rk), len(pr),
+                                                           C.byref(self._h)))
+        elif path is not None:
             L.check(L.lib().smt_sharded_corpus_load(group._h, str(path).encode(), C.byref(self._h)))
         elif device_ptrs is not None:
             n = len(device_ptrs)
@@ -413,6 +470,25 @@ class ShardedCorpus:
 
     def save(self, path):
         L.check(L.lib().smt_sharded_corpus_save(self._h, str(path).encode()))
+
+    def append_to_file(self, path, rows_on_disk):
+        L.check(L.lib().smt_sharded_corpus_append_to_file(self._h, str(path).encode(), int(rows_on_disk)))
+
+    def layout(self):
+        """[(rows, rank), ...] in global row order."""
+        n = int(L.lib().smt_sharded_corpus_layout(self._h, None, None, 0))
+        pr, rk = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint32)
+        L.lib().smt_sharded_corpus_layout(self._h, L.np_ptr(pr), L.np_ptr(rk), n)
+        return [(int(pr[i]), int(rk[i])) for i in range(n)]
+
+    def read_rows(self, first_row, n_rows):
+        out = np.empty((int(n_rows), L.DIM), dtype=np.float32)
+        L.check(L.lib().smt_sharded_corpus_read_rows(self._h, int(first_row), int(n_rows), L.np_ptr(out)))
+        return out
+
+    def write_rows(self, first_row, rows):
+        rows = _f32c(rows).reshape(-1, L.DIM)
+        L.check(L.lib().smt_sharded_corpus_write_rows(self._h, int(first_row), L.np_ptr(rows), rows.shape[0]))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -434,11 +510,13 @@ class ShardedCorpus:
         L.check(L.lib().smt_sharded_corpus_rank_rows(self._h, L.np_ptr(out)))
         return out
 
-    def shard(self, local_index=0):
-        """(Corpus view of local device i's shard, its first global row, its row count)."""
+    def shard(self, local_index=0, want_base=True):
+        """(Corpus view of local device i's shard, its first global row, its row count).  A corpus that grew by dealt
+        appends has no single base per shard: pass want_base=False (the base comes back as None)."""
         h, base, n = C.c_void_p(), C.c_uint64(), C.c_uint64()
-        L.check(L.lib().smt_sharded_corpus_shard(self._h, int(local_index), C.byref(h), C.byref(base), C.byref(n)))
-        return Corpus(self.group.ctx(local_index), _handle=h, _borrowed=True), int(base.value), int(n.value)
+        L.check(L.lib().smt_sharded_corpus_shard(self._h, int(local_index), C.byref(h), C.byref(base) if want_base else None,
+                                                 C.byref(n)))
+        return Corpus(self.group.ctx(local_index), _handle=h, _borrowed=True), int(base.value) if want_base else None, int(n.value)
 
     def append(self, rows):
         rows = _f32c(rows).reshape(-1, L.DIM)
@@ -479,11 +557,31 @@ class ShardedIvfPq:
     """IVF index over a ShardedCorpus (smt_sharded_ivfpq): every rank indexes its rows; shared_centroids=True runs
     the coarse k-means data-parallel with an all-reduce of the centroid sums, so all ranks share one set of lists."""
 
-    def __init__(self, sharded_corpus, nlist=4096, train_iters=10, local_pca=True, shared_centroids=True):
+    def __init__(self, sharded_corpus, nlist=4096, train_iters=10, local_pca=True, shared_centroids=True, _path=None):
         self.corpus = sharded_corpus
         self._h = C.c_void_p()
+        if _path is not None:
+            L.check(L.lib().smt_sharded_ivfpq_load(sharded_corpus._h, str(_path).encode(), C.byref(self._h)))
+            return
         prm = L.SmtIvfPqParams(int(nlist), 32, 8, int(train_iters), 0, 0, 1 if local_pca else 0)
         L.check(L.lib().smt_sharded_ivfpq_build(sharded_corpus._h, C.byref(prm), int(bool(shared_centroids)), C.byref(self._h)))
+
+    @classmethod
+    def load(cls, sharded_corpus, path):
+        return cls(sharded_corpus, _path=path)
+
+    def save(self, path):
+        L.check(L.lib().smt_sharded_ivfpq_save(self._h, str(path).encode()))
+
+    def append(self):
+        n = C.c_uint64(0)
+        L.check(L.lib().smt_sharded_ivfpq_append(self._h, C.byref(n)))
+        return int(n.value)
+
+    def info(self):
+        rows, nlist, nbytes = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        L.check(L.lib().smt_sharded_ivfpq_info(self._h, C.byref(rows), C.byref(nlist), C.byref(nbytes)))
+        return dict(rows=int(rows.value), nlist=int(nlist.value), index_bytes=int(nbytes.value))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -633,26 +633,34 @@ int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows)
     return SMT_OK;
 }
 
-// Write every row of `c` into the (existing) corpus file at row position file_first_row.
-int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row)
+// Write runs of rows of `c` into the (existing) corpus file: run j = local rows [local_first, local_first + n_rows) at file
+// row position file_first_row.  One open / fsync for all runs; the D2H of chunk j+1 flies while chunk j is written.
+int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_t n_runs)
 {
     smt_ctx *ctx = c->ctx;
     int rc = bind_device(ctx);
     if (rc) return rc;
-    if (c->rows == 0) return SMT_OK;
+    uint64_t total = 0, longest = 0;
+    for (size_t j = 0; j < n_runs; ++j) {
+        SMT_REQUIRE(runs[j].local_first + runs[j].n_rows <= c->rows, "run extends past the shard");
+        total += runs[j].n_rows;
+        longest = std::max(longest, runs[j].n_rows);
+    }
+    if (total == 0) return SMT_OK;
+    const size_t chunk = io_chunk_rows(longest);
+    struct Chunk { uint64_t local, n, file_row; };
+    std::vector<Chunk> chunks;
+    for (size_t j = 0; j < n_runs; ++j)
+        for (uint64_t r = 0; r < runs[j].n_rows; r += chunk)
+            chunks.push_back({runs[j].local_first + r, std::min<uint64_t>(chunk, runs[j].n_rows - r), runs[j].file_first_row + r});
     FILE *f = fopen(path, "r+b");
     if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
     const size_t row_bytes = (size_t)c->dim * sizeof(float);
-    if (fseeko(f, (off_t)(sizeof(CorpusFileHeader) + file_first_row * row_bytes), SEEK_SET) != 0) {
-        fclose(f); set_error("seek in '%s': %s", path, strerror(errno)); return SMT_E_IO;
-    }
-    const size_t chunk = io_chunk_rows(c->rows);
     PinnedPair pp;
     if ((rc = pp.init(chunk * row_bytes))) { fclose(f); return rc; }
-    // D2H of chunk j+1 flies while chunk j is written
-    auto issue = [&](uint64_t r, int j) -> int {
-        const size_t n = (size_t)std::min<uint64_t>(chunk, c->rows - r);
-        hipError_t e = hipMemcpyAsync(pp.buf[j], c->d_rows + (size_t)r * c->dim, n * row_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    auto issue = [&](size_t k, int j) -> int {
+        hipError_t e = hipMemcpyAsync(pp.buf[j], c->d_rows + (size_t)chunks[k].local * c->dim, (size_t)chunks[k].n * row_bytes,
+                                      hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
         if (e != hipSuccess) { set_error("corpus download: %s", hipGetErrorString(e)); return SMT_E_HIP; }
         pp.busy[j] = true;
@@ -661,15 +669,57 @@ int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row)
     if ((rc = issue(0, 0))) { fclose(f); return rc; }
     int j = 0;
     bool ok = true;
-    for (uint64_t r = 0; r < c->rows && ok; r += chunk, j ^= 1) {
-        if (r + chunk < c->rows && (rc = issue(r + chunk, j ^ 1))) { fclose(f); return rc; }
+    uint64_t file_at = UINT64_MAX;
+    for (size_t k = 0; k < chunks.size() && ok; ++k, j ^= 1) {
+        if (k + 1 < chunks.size() && (rc = issue(k + 1, j ^ 1))) { fclose(f); return rc; }
         if ((rc = pp.wait(j))) { fclose(f); return rc; }
-        const size_t n = (size_t)std::min<uint64_t>(chunk, c->rows - r);
-        ok = fwrite(pp.buf[j], row_bytes, n, f) == n;
+        if (file_at != chunks[k].file_row)
+            ok = fseeko(f, (off_t)(sizeof(CorpusFileHeader) + chunks[k].file_row * row_bytes), SEEK_SET) == 0;
+        ok = ok && fwrite(pp.buf[j], row_bytes, (size_t)chunks[k].n, f) == (size_t)chunks[k].n;
+        file_at = chunks[k].file_row + chunks[k].n;
     }
     ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
     if (fclose(f) != 0) ok = false;
     if (!ok) { set_error("short write to '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    return SMT_OK;
+}
+
+// Write every row of `c` into the (existing) corpus file at row position file_first_row.
+int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row)
+{
+    const FileRun run{0, c->rows, file_first_row};
+    return corpus_save_runs(c, path, &run, 1);
+}
+
+// Header of an existing corpus file: check it describes `dim`-wide rows and holds exactly `expect_rows`; then (new_rows !=
+// expect_rows) grow the file to new_rows WITHOUT touching the header -- corpus_file_commit writes it last, so a crash in
+// between leaves the old, consistent prefix.
+int corpus_file_extend(const char *path, uint32_t dim, uint64_t expect_rows, uint64_t new_rows)
+{
+    FILE *f = fopen(path, "r+b");
+    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
+    CorpusFileHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTCORP1", 8) != 0 || h.dim != dim || h.rows != expect_rows) {
+        fclose(f);
+        set_error("'%s' does not hold exactly the first %llu rows of this corpus", path, (unsigned long long)expect_rows);
+        return SMT_E_IO;
+    }
+    bool ok = ftruncate(fileno(f), (off_t)(sizeof(h) + new_rows * (uint64_t)dim * sizeof(float))) == 0;
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("cannot grow '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    return SMT_OK;
+}
+
+int corpus_file_commit(const char *path, uint64_t rows)
+{
+    FILE *f = fopen(path, "r+b");
+    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
+    CorpusFileHeader h;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "SMTCORP1", 8) == 0;
+    h.rows = rows;
+    ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1 && fflush(f) == 0 && fsync(fileno(f)) == 0;
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("cannot update the header of '%s': %s", path, strerror(errno)); return SMT_E_IO; }
     return SMT_OK;
 }
 

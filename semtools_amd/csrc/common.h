@@ -250,6 +250,10 @@ int corpus_file_info(const char *path, uint64_t *rows, uint32_t *dim);
 int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint64_t n_rows);
 int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows);
 int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row);
+struct FileRun { uint64_t local_first, n_rows, file_first_row; };
+int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_t n_runs);
+int corpus_file_extend(const char *path, uint32_t dim, uint64_t expect_rows, uint64_t new_rows);
+int corpus_file_commit(const char *path, uint64_t rows);
 int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *packed, uint32_t n_lists, uint32_t nq,
                                 uint32_t k_in, uint32_t k_out, uint64_t *out_packed, uint64_t list_stride_words = 0);
 
@@ -272,6 +276,9 @@ struct IvfBuildShare {
     // sum `sums` (n_sums int64, 2^-32 fixed point) and `counts` (n_counts u32) over the ranks, in place, enqueued on
     // the context's stream (ncclAllReduce), or synchronously for the copy transport
     int (*allreduce)(void *user, long long *sums_dev, size_t n_sums, unsigned int *counts_dev, size_t n_counts) = nullptr;
+    // every rank reports the status of its set-up (allocations) and gets back the first failure of ANY rank: called once,
+    // before the first allreduce, so that no rank enters a collective the others will never reach
+    int (*agree)(void *user, int rc) = nullptr;
     void *user = nullptr;
 };
 }  // namespace smt

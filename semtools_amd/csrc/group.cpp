@@ -18,7 +18,6 @@
 // RCCL is loaded lazily (dlopen) when the first group is created: single-GPU users -- the `semtools search` CLI
 // -- never pay for mapping it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -27,7 +26,9 @@
 #include <mutex>
 #include <thread>
 
-#include "common.h"
+#include <functional>
+
+#include "group.h"
 
 namespace smt {
 
@@ -92,62 +93,17 @@ static int load_rccl()
 
 using namespace smt;
 
-// One exchange workspace per local device, grown on demand.
-struct GroupBuf {
-    void *dev = nullptr;
-    size_t dev_bytes = 0;
-    void *pinned = nullptr;
-    size_t pinned_bytes = 0;
-};
-
-struct smt_group {
-    int n_ranks = 0;
-    int n_local = 0;
-    int first_rank = 0;              // local device i is rank first_rank + i
-    std::vector<smt_ctx *> ctx;      // [n_local], owned
-    std::vector<ncclComm_t> comm;    // [n_local]
-    std::vector<GroupBuf> buf;       // [n_local]
-    int rccl_version = 0;
-    // Copy transport (smt_group_create_logical): every rank is a context of THIS process, possibly several on one
-    // device; the all-gather is n x n device copies ordered by events instead of an RCCL collective.
-    bool copies = false;
-    std::vector<hipEvent_t> ev_ready;   // [n_local] rank j's send buffer is complete
-    std::vector<hipEvent_t> ev_done;    // [n_local] rank i has finished reading everybody's send buffer
-    // copy-transport all-reduce (shared-centroid IVF builds run one host thread per local rank): a thread barrier
-    // and the ranks' buffer addresses
-    std::mutex ar_mu;
-    std::condition_variable ar_cv;
-    int ar_waiting = 0;
-    uint64_t ar_generation = 0;
-    std::vector<const long long *> ar_sums;
-    std::vector<const unsigned int *> ar_counts;
-};
-
-struct smt_sharded_ivfpq {
-    smt_sharded_corpus *corpus = nullptr;
-    std::vector<smt_ivfpq *> shard;     // [n_local]
-    int shared_centroids = 0;
-};
-
-struct smt_sharded_corpus {
-    smt_group *group = nullptr;
-    uint32_t dim = SMT_DIM;
-    std::vector<smt_corpus *> shard;   // [n_local], owned handles (rows themselves may be adopted device memory)
-    std::vector<uint64_t> rank_rows;   // [n_ranks]
-    std::vector<uint64_t> rank_base;   // [n_ranks + 1] exclusive prefix
-};
-
 namespace smt {
 
 static smt_group *g_default_group = nullptr;
 
-static int group_bind(smt_group *g, int i)
+int group_bind(smt_group *g, int i)
 {
     SMT_HIP_CHECK(hipSetDevice(g->ctx[i]->device));
     return SMT_OK;
 }
 
-static int ensure_dev(smt_group *g, int i, size_t bytes)
+int ensure_dev(smt_group *g, int i, size_t bytes)
 {
     GroupBuf &b = g->buf[i];
     if (bytes <= b.dev_bytes) return SMT_OK;
@@ -165,7 +121,7 @@ static int ensure_dev(smt_group *g, int i, size_t bytes)
     return SMT_OK;
 }
 
-static int ensure_host(smt_group *g, int i, size_t bytes)
+int ensure_host(smt_group *g, int i, size_t bytes)
 {
     GroupBuf &b = g->buf[i];
     if (bytes <= b.pinned_bytes) return SMT_OK;
@@ -181,7 +137,7 @@ static int ensure_host(smt_group *g, int i, size_t bytes)
 
 // All-gather `words` u64 per rank: send_off/recv_off are BYTE offsets into each local device's exchange buffer.
 // The streams are the contexts' main streams, or their aux streams where on_aux[i] (async select pipeline).
-static int allgather_words(smt_group *g, size_t send_off, size_t recv_off, size_t words, const std::vector<char> *on_aux = nullptr)
+int allgather_words(smt_group *g, size_t send_off, size_t recv_off, size_t words, const std::vector<char> *on_aux)
 {
     if (g->copies) {
         auto stream_of = [&](int i) { return (on_aux && (*on_aux)[i]) ? g->ctx[i]->aux_stream : g->ctx[i]->stream; };
@@ -224,7 +180,7 @@ static int allgather_words(smt_group *g, size_t send_off, size_t recv_off, size_
     return SMT_OK;
 }
 
-static int group_sync_all(smt_group *g)
+int group_sync_all(smt_group *g)
 {
     for (int i = 0; i < g->n_local; ++i) {
         int rc = group_bind(g, i);
@@ -236,7 +192,7 @@ static int group_sync_all(smt_group *g)
 }
 
 // A barrier across ranks that also proves the communicator works: all-gather one word per rank.
-static int group_barrier(smt_group *g)
+int group_barrier(smt_group *g)
 {
     const size_t words = 1;
     for (int i = 0; i < g->n_local; ++i) {
@@ -261,6 +217,55 @@ static int group_barrier(smt_group *g)
     return SMT_OK;
 }
 
+int group_agree(smt_group *g, int rc)
+{
+    if (g->n_local == g->n_ranks) return rc;   // every rank is in this process: nothing to agree on
+    const std::string mine = rc ? smt_last_error() : "";
+    for (int i = 0; i < g->n_local; ++i) {
+        int rc2 = group_bind(g, i);
+        if (!rc2) rc2 = ensure_dev(g, i, (size_t)(1 + g->n_ranks) * 8 + 64);
+        if (rc2) return rc2;   // (no way left to tell the others: HIP itself is failing)
+        const uint64_t word = (uint64_t)(uint32_t)(rc < 0 ? -rc : rc);
+        SMT_HIP_CHECK(hipMemcpyAsync(g->buf[i].dev, &word, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    int rc2 = allgather_words(g, 0, 8, 1);
+    if (rc2) return rc2;
+    if ((rc2 = group_bind(g, 0))) return rc2;
+    std::vector<uint64_t> got(g->n_ranks);
+    SMT_HIP_CHECK(hipMemcpyAsync(got.data(), reinterpret_cast<char *>(g->buf[0].dev) + 8, (size_t)g->n_ranks * 8, hipMemcpyDeviceToHost,
+                                 g->ctx[0]->stream));
+    if ((rc2 = group_sync_all(g))) return rc2;
+    if (rc) { set_error("%s", mine.c_str()); return rc; }
+    for (int r = 0; r < g->n_ranks; ++r)
+        if (got[r]) { set_error("rank %d failed with status -%llu; this rank gives up with it", r, (unsigned long long)got[r]); return -(int)got[r]; }
+    return SMT_OK;
+}
+
+int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool threads)
+{
+    std::vector<int> rcs(g->n_local, SMT_OK);
+    std::vector<std::string> errs(g->n_local);
+    auto run = [&](int i) {
+        rcs[i] = work(i);
+        if (rcs[i]) errs[i] = smt_last_error();   // (thread-local: carry it back to the caller's thread)
+    };
+    if (g->n_local == 1 || !threads) {
+        for (int i = 0; i < g->n_local; ++i) run(i);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < g->n_local; ++i) th.emplace_back(run, i);
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < g->n_local; ++i)
+        if (rcs[i]) {
+            if (g->n_ranks > 1) set_error("shard %d: %s", g->first_rank + i, errs[i].c_str());
+            else set_error("%s", errs[i].c_str());
+            return rcs[i];
+        }
+    return SMT_OK;
+}
+
 static void group_free(smt_group *g)
 {
     if (!g) return;
@@ -276,7 +281,7 @@ static void group_free(smt_group *g)
             if (g->buf[i].dev) (void)hipFree(g->buf[i].dev);
             if (g->buf[i].pinned) (void)hipHostFree(g->buf[i].pinned);
         }
-        smt_ctx_destroy(g->ctx[i]);
+        if (!g->borrowed) smt_ctx_destroy(g->ctx[i]);
     }
     delete g;
 }
@@ -293,16 +298,6 @@ static int group_make_contexts(smt_group *g, const int *devices, int n)
         if (rc) return rc;
     }
     return SMT_OK;
-}
-
-// Global ranges -> the part inside [base, base + rows), in local row numbers.
-static void localize_ranges(const smt_range *ranges, uint32_t n, uint64_t base, uint64_t rows, std::vector<smt_range> &out)
-{
-    out.clear();
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t b = std::max(ranges[i].begin, base), e = std::min(ranges[i].end, base + rows);
-        if (e > b) out.push_back(smt_range{b - base, e - base});
-    }
 }
 
 static int validate_global_ranges(const smt_range *ranges, uint32_t n, uint64_t rows)
@@ -409,12 +404,17 @@ static int local_host_search(smt_sharded_corpus *sc, const float *queries, uint3
         const int r = g->first_rank + i;
         std::vector<smt_range> lr;
         if (n_ranges) {
-            localize_ranges(ranges, n_ranges, sc->rank_base[r], sc->rank_rows[r], lr);
+            layout_localize(sc, r, ranges, n_ranges, lr);
             if (lr.empty()) return;  // the filter leaves this shard nothing
         }
+        // a shard cut as ONE range returns global rows by adding its base; a shard of several pieces returns local rows
+        // (already in global order: pieces ascend in both numberings) which are mapped piece by piece
         rcs[i] = search_local_host(sc->shard[i], queries, nq, top_k, max_distance, mode, lr.empty() ? nullptr : lr.data(),
-                                   (uint32_t)lr.size(), sc->rank_base[r], local[i]);
-        if (rcs[i]) errs[i] = smt_last_error();
+                                   (uint32_t)lr.size(), sc->contiguous ? sc->rank_base[r] : 0, local[i]);
+        if (rcs[i]) { errs[i] = smt_last_error(); return; }
+        if (!sc->contiguous)
+            for (LocalHits &h : local[i])
+                for (uint64_t &row : h.rows) row = layout_to_global(sc, r, row);
     };
     if (g->n_local == 1) work(0);
     else {
@@ -475,32 +475,64 @@ static int group_allreduce_sums(void *user, long long *sums, size_t n_sums, unsi
         SMT_NCCL_CHECK(g_rccl.AllReduce(counts, counts, n_counts, ncclUint32, ncclSum, g->comm[i], c->stream));
         return SMT_OK;
     }
-    // copy transport: every rank lives in this process (one thread each): meet, sum everybody's buffer, meet, copy back
+    // copy transport: every rank lives in this process (one thread each): meet, sum everybody's buffer, meet, copy back.
+    // A rank whose HIP calls fail still passes BOTH barriers (its siblings would wait for it forever) and then reports.
     const size_t b_sums = ((n_sums * 8 + 255) & ~(size_t)255), b_cnt = ((n_counts * 4 + 255) & ~(size_t)255);
     const size_t b_ptr = (((size_t)g->n_local * 16 + 255) & ~(size_t)255);
     int rc = ensure_dev(g, i, b_sums + b_cnt + b_ptr + 64);
-    SMT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) { set_error("%s: %s", what, hipGetErrorString(e)); rc = SMT_E_HIP; }
+    };
+    hip_ok(hipStreamSynchronize(c->stream), "all-reduce (sync)");
     {
         std::lock_guard<std::mutex> lk(g->ar_mu);
         g->ar_sums[i] = sums;
         g->ar_counts[i] = counts;
     }
     thread_barrier(g);
-    if (rc) return rc;
-    char *base = reinterpret_cast<char *>(g->buf[i].dev);
-    long long *t_sums = reinterpret_cast<long long *>(base);
-    unsigned int *t_cnt = reinterpret_cast<unsigned int *>(base + b_sums);
-    const long long **d_ps = reinterpret_cast<const long long **>(base + b_sums + b_cnt);
-    const unsigned int **d_pc = reinterpret_cast<const unsigned int **>(base + b_sums + b_cnt + (size_t)g->n_local * 8);
-    SMT_HIP_CHECK(hipMemcpyAsync(d_ps, g->ar_sums.data(), (size_t)g->n_local * 8, hipMemcpyHostToDevice, c->stream));
-    SMT_HIP_CHECK(hipMemcpyAsync(d_pc, g->ar_counts.data(), (size_t)g->n_local * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(sum_ranks_i64_kernel, dim3((unsigned)((n_sums + 255) / 256)), dim3(256), 0, c->stream, d_ps, g->n_local, n_sums, t_sums);
-    hipLaunchKernelGGL(sum_ranks_u32_kernel, dim3((unsigned)((n_counts + 255) / 256)), dim3(256), 0, c->stream, d_pc, g->n_local, n_counts, t_cnt);
-    SMT_HIP_CHECK(hipGetLastError());
-    SMT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    long long *t_sums = nullptr;
+    unsigned int *t_cnt = nullptr;
+    if (!rc) {
+        char *base = reinterpret_cast<char *>(g->buf[i].dev);
+        t_sums = reinterpret_cast<long long *>(base);
+        t_cnt = reinterpret_cast<unsigned int *>(base + b_sums);
+        const long long **d_ps = reinterpret_cast<const long long **>(base + b_sums + b_cnt);
+        const unsigned int **d_pc = reinterpret_cast<const unsigned int **>(base + b_sums + b_cnt + (size_t)g->n_local * 8);
+        hip_ok(hipMemcpyAsync(d_ps, g->ar_sums.data(), (size_t)g->n_local * 8, hipMemcpyHostToDevice, c->stream), "all-reduce (pointers)");
+        hip_ok(hipMemcpyAsync(d_pc, g->ar_counts.data(), (size_t)g->n_local * 8, hipMemcpyHostToDevice, c->stream), "all-reduce (pointers)");
+        if (!rc) {
+            hipLaunchKernelGGL(sum_ranks_i64_kernel, dim3((unsigned)((n_sums + 255) / 256)), dim3(256), 0, c->stream, d_ps, g->n_local, n_sums, t_sums);
+            hipLaunchKernelGGL(sum_ranks_u32_kernel, dim3((unsigned)((n_counts + 255) / 256)), dim3(256), 0, c->stream, d_pc, g->n_local, n_counts, t_cnt);
+            hip_ok(hipGetLastError(), "all-reduce (sum kernels)");
+        }
+        hip_ok(hipStreamSynchronize(c->stream), "all-reduce (sum)");
+    }
     thread_barrier(g);   // nobody overwrites its buffer before everybody has read it
+    if (rc) return rc;
     SMT_HIP_CHECK(hipMemcpyAsync(sums, t_sums, n_sums * 8, hipMemcpyDeviceToDevice, c->stream));
     SMT_HIP_CHECK(hipMemcpyAsync(counts, t_cnt, n_counts * 4, hipMemcpyDeviceToDevice, c->stream));
+    return SMT_OK;
+}
+
+// IvfBuildShare::agree: the ranks meet and share a status before the first collective of a build, so that a rank whose
+// set-up failed (out of memory ...) takes the others with it instead of leaving them in the all-reduce.
+static int group_share_agree(void *user, int rc)
+{
+    ShareCtx *sc = static_cast<ShareCtx *>(user);
+    smt_group *g = sc->g;
+    if (g->n_local == 1) return group_agree(g, rc);
+    const std::string mine = rc ? smt_last_error() : "";
+    {
+        std::lock_guard<std::mutex> lk(g->ar_mu);
+        if (rc && !g->ar_failed) g->ar_failed = rc;
+    }
+    thread_barrier(g);
+    const int all = g->ar_failed;
+    thread_barrier(g);             // everybody has read the verdict ...
+    if (sc->local == 0) g->ar_failed = 0;   // ... before it is cleared for the next build
+    thread_barrier(g);
+    if (rc) { set_error("%s", mine.c_str()); return rc; }
+    if (all) { set_error("another shard of the group failed to set up its index build"); return all; }
     return SMT_OK;
 }
 
@@ -553,6 +585,31 @@ int smt_group_create_logical(int device, int n_shards, smt_group **out)
         if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); group_free(g); return SMT_E_HIP; }
     }
     if ((rc = group_barrier(g))) { group_free(g); return rc; }
+    *out = g;
+    return SMT_OK;
+}
+
+int smt_group_from_ctx(smt_ctx *ctx, smt_group **out)
+{
+    SMT_REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    smt_group *g = new (std::nothrow) smt_group();
+    if (!g) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    g->n_ranks = g->n_local = 1;
+    g->first_rank = 0;
+    g->copies = true;      // no communicator: a one-rank group never exchanges anything
+    g->borrowed = true;    // the caller keeps (and later destroys) the context
+    g->ctx.assign(1, ctx);
+    g->comm.assign(1, nullptr);
+    g->buf.assign(1, GroupBuf());
+    g->ar_sums.assign(1, nullptr);
+    g->ar_counts.assign(1, nullptr);
+    g->ev_ready.assign(1, nullptr);
+    g->ev_done.assign(1, nullptr);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_ready[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_done[0], hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); group_free(g); return SMT_E_HIP; }
     *out = g;
     return SMT_OK;
 }
@@ -666,190 +723,6 @@ int smt_shutdown(void)
 
 smt_group *smt_default_group(void) { return g_default_group; }
 
-/* --------------------------------------------------------- sharded corpus ---- */
-
-static int sharded_set_rows(smt_sharded_corpus *sc, const std::vector<uint64_t> &rank_rows)
-{
-    sc->rank_rows = rank_rows;
-    sc->rank_base.assign(rank_rows.size() + 1, 0);
-    for (size_t r = 0; r < rank_rows.size(); ++r) sc->rank_base[r + 1] = sc->rank_base[r] + rank_rows[r];
-    return SMT_OK;
-}
-
-// rows_per_rank = ceil(N / n_ranks): SURVEY 8(e)
-static void partition_rows(uint64_t total, int n_ranks, std::vector<uint64_t> &rank_rows)
-{
-    const uint64_t per = n_ranks > 0 ? (total + (uint64_t)n_ranks - 1) / (uint64_t)n_ranks : 0;
-    rank_rows.assign(n_ranks, 0);
-    for (int r = 0; r < n_ranks; ++r) {
-        const uint64_t b = std::min<uint64_t>((uint64_t)r * per, total), e = std::min<uint64_t>((uint64_t)(r + 1) * per, total);
-        rank_rows[r] = e - b;
-    }
-}
-
-void smt_sharded_corpus_destroy(smt_sharded_corpus *sc)
-{
-    if (!sc) return;
-    for (smt_corpus *c : sc->shard) smt_corpus_destroy(c);
-    delete sc;
-}
-
-int smt_sharded_corpus_from_host(smt_group *group, const float *rows, uint64_t total_rows, uint32_t D, smt_sharded_corpus **out)
-{
-    SMT_REQUIRE(group && out, "null argument");
-    *out = nullptr;
-    SMT_REQUIRE(rows || total_rows == 0, "rows");
-    if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
-    smt_sharded_corpus *sc = new (std::nothrow) smt_sharded_corpus();
-    if (!sc) { set_error("out of host memory"); return SMT_E_NOMEM; }
-    sc->group = group;
-    std::vector<uint64_t> rr;
-    partition_rows(total_rows, group->n_ranks, rr);
-    sharded_set_rows(sc, rr);
-    sc->shard.assign(group->n_local, nullptr);
-    for (int i = 0; i < group->n_local; ++i) {
-        const int r = group->first_rank + i;
-        int rc = smt_corpus_create(group->ctx[i], D, sc->rank_rows[r], &sc->shard[i]);
-        if (!rc && sc->rank_rows[r])
-            rc = smt_corpus_append_host(sc->shard[i], rows + (size_t)sc->rank_base[r] * D, sc->rank_rows[r], nullptr);
-        if (rc) { smt_sharded_corpus_destroy(sc); return rc; }
-    }
-    *out = sc;
-    return SMT_OK;
-}
-
-int smt_sharded_corpus_from_device(smt_group *group, const float *const *shard_rows_dev, const uint64_t *shard_rows, uint32_t D,
-                                   smt_sharded_corpus **out)
-{
-    SMT_REQUIRE(group && out && shard_rows_dev && shard_rows, "null argument");
-    *out = nullptr;
-    if (D != SMT_DIM) { set_error("embedding dim %u unsupported", D); return SMT_E_UNSUPPORTED; }
-    smt_sharded_corpus *sc = new (std::nothrow) smt_sharded_corpus();
-    if (!sc) { set_error("out of host memory"); return SMT_E_NOMEM; }
-    sc->group = group;
-    sc->shard.assign(group->n_local, nullptr);
-    int rc = SMT_OK;
-    for (int i = 0; i < group->n_local && !rc; ++i)
-        rc = smt_corpus_from_device(group->ctx[i], shard_rows_dev[i], shard_rows[i], D, &sc->shard[i]);
-    // every rank's row count (the bases of the global row numbering): one all-gather of a word per rank
-    for (int i = 0; i < group->n_local && !rc; ++i) {
-        if ((rc = group_bind(group, i))) break;
-        if ((rc = ensure_dev(group, i, (size_t)(1 + group->n_ranks) * 8 + 64))) break;
-        hipError_t e = hipMemcpyAsync(group->buf[i].dev, &shard_rows[i], 8, hipMemcpyHostToDevice, group->ctx[i]->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(group->ctx[i]->stream);
-        if (e != hipSuccess) { set_error("shard size upload: %s", hipGetErrorString(e)); rc = SMT_E_HIP; }
-    }
-    if (!rc) rc = allgather_words(group, 0, 8, 1);
-    std::vector<uint64_t> rr(group->n_ranks, 0);
-    if (!rc && !(rc = group_bind(group, 0))) {
-        hipError_t e = hipMemcpyAsync(rr.data(), reinterpret_cast<char *>(group->buf[0].dev) + 8, (size_t)group->n_ranks * 8,
-                                      hipMemcpyDeviceToHost, group->ctx[0]->stream);
-        if (e != hipSuccess) { set_error("shard size download: %s", hipGetErrorString(e)); rc = SMT_E_HIP; }
-    }
-    if (!rc) rc = group_sync_all(group);
-    if (rc) { smt_sharded_corpus_destroy(sc); return rc; }
-    sharded_set_rows(sc, rr);
-    *out = sc;
-    return SMT_OK;
-}
-
-int smt_sharded_corpus_load(smt_group *group, const char *path, smt_sharded_corpus **out)
-{
-    SMT_REQUIRE(group && path && out, "null argument");
-    *out = nullptr;
-    uint64_t total = 0;
-    uint32_t dim = 0;
-    int rc = corpus_file_info(path, &total, &dim);
-    if (rc) return rc;
-    if (dim != SMT_DIM) { set_error("'%s' holds %u-dimensional rows; kernels are specialised for 256", path, dim); return SMT_E_UNSUPPORTED; }
-    smt_sharded_corpus *sc = new (std::nothrow) smt_sharded_corpus();
-    if (!sc) { set_error("out of host memory"); return SMT_E_NOMEM; }
-    sc->group = group;
-    std::vector<uint64_t> rr;
-    partition_rows(total, group->n_ranks, rr);
-    sharded_set_rows(sc, rr);
-    sc->shard.assign(group->n_local, nullptr);
-    // every local rank streams ITS slice of the file (pinned double buffers), one host thread per device
-    std::vector<int> rcs(group->n_local, SMT_OK);
-    std::vector<std::string> errs(group->n_local);
-    auto work = [&](int i) {
-        const int r = group->first_rank + i;
-        rcs[i] = smt_corpus_create(group->ctx[i], dim, sc->rank_rows[r], &sc->shard[i]);
-        if (!rcs[i]) rcs[i] = corpus_load_slice(sc->shard[i], path, sc->rank_base[r], sc->rank_rows[r]);
-        if (rcs[i]) errs[i] = smt_last_error();
-    };
-    if (group->n_local == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < group->n_local; ++i) th.emplace_back(work, i);
-        for (auto &t : th) t.join();
-    }
-    for (int i = 0; i < group->n_local; ++i)
-        if (rcs[i]) { set_error("shard %d: %s", group->first_rank + i, errs[i].c_str()); rc = rcs[i]; smt_sharded_corpus_destroy(sc); return rc; }
-    *out = sc;
-    return SMT_OK;
-}
-
-int smt_sharded_corpus_save(smt_sharded_corpus *sc, const char *path)
-{
-    SMT_REQUIRE(sc && path, "null argument");
-    smt_group *g = sc->group;
-    const uint64_t total = sc->rank_base[g->n_ranks];
-    const std::string tmp = std::string(path) + ".tmp";
-    int rc = SMT_OK;
-    if (g->first_rank == 0) rc = corpus_file_begin(tmp.c_str(), sc->dim, total);  // header + final size
-    int rc2 = smt_group_barrier(g);  // the file exists before any other process opens it
-    if (rc) return rc;
-    if (rc2) return rc2;
-    for (int i = 0; i < g->n_local && !rc; ++i) {
-        const int r = g->first_rank + i;
-        rc = corpus_save_slice(sc->shard[i], tmp.c_str(), sc->rank_base[r]);
-    }
-    rc2 = smt_group_barrier(g);      // every slice is on disk before the rename publishes the file
-    if (rc) return rc;
-    if (rc2) return rc2;
-    if (g->first_rank == 0 && rename(tmp.c_str(), path) != 0) { set_error("rename '%s' -> '%s': %s", tmp.c_str(), path, strerror(errno)); return SMT_E_IO; }
-    return smt_group_barrier(g);
-}
-
-uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *sc) { return sc ? sc->rank_base[sc->group->n_ranks] : 0; }
-
-int smt_sharded_corpus_shard(smt_sharded_corpus *sc, int local_index, smt_corpus **shard, uint64_t *row_base, uint64_t *rows)
-{
-    SMT_REQUIRE(sc != nullptr, "corpus");
-    SMT_REQUIRE(local_index >= 0 && local_index < sc->group->n_local, "local index");
-    const int r = sc->group->first_rank + local_index;
-    if (shard) *shard = sc->shard[local_index];
-    if (row_base) *row_base = sc->rank_base[r];
-    if (rows) *rows = sc->rank_rows[r];
-    return SMT_OK;
-}
-
-int smt_sharded_corpus_rank_rows(const smt_sharded_corpus *sc, uint64_t *rows_per_rank)
-{
-    SMT_REQUIRE(sc && rows_per_rank, "null argument");
-    for (int r = 0; r < sc->group->n_ranks; ++r) rows_per_rank[r] = sc->rank_rows[r];
-    return SMT_OK;
-}
-
-int smt_sharded_corpus_append_host(smt_sharded_corpus *sc, const float *rows, uint64_t n_rows, uint64_t *first_row)
-{
-    SMT_REQUIRE(sc != nullptr && (rows || n_rows == 0), "null argument");
-    smt_group *g = sc->group;
-    const int last = g->n_ranks - 1;
-    if (first_row) *first_row = sc->rank_base[g->n_ranks];
-    if (n_rows == 0) return SMT_OK;
-    // global row numbers are insertion order, so new rows can only extend the LAST rank's range
-    const int li = last - g->first_rank;
-    if (li >= 0 && li < g->n_local) {
-        int rc = smt_corpus_append_host(sc->shard[li], rows, n_rows, nullptr);
-        if (rc) return rc;
-    }
-    std::vector<uint64_t> rr = sc->rank_rows;
-    rr[last] += n_rows;
-    return sharded_set_rows(sc, rr);
-}
-
 /* ----------------------------------------------------------------- search ---- */
 
 int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
@@ -862,8 +735,10 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
     SMT_REQUIRE(n_ranges == 0 || ranges != nullptr, "ranges");
     smt_group *g = sc->group;
     if (nq == 0) return SMT_OK;
+    if (g->n_ranks == 1)   // one shard: the single-GPU call, nothing to exchange
+        return smt_search(sc->shard[0], queries, nq, top_k, max_distance, mode, ranges, n_ranges, 0, out_rows, out_dist, out_counts, out_cap);
     for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
-    const uint64_t total = sc->rank_base[g->n_ranks];
+    const uint64_t total = sc->total();
     int rc;
     if (n_ranges && (rc = validate_global_ranges(ranges, n_ranges, total))) return rc;
     uint64_t n_virtual = total;
@@ -882,7 +757,10 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
     std::vector<uint32_t> redo;  // queries answered through the host-list exchange
     if (device_exchange) {
         // ---- per-shard scan + select -> packed lists -> ONE all-gather -> device merge
-        const size_t list_words = (size_t)nq * 2 * K, rank_words = list_words + nq;  // + one "uncertain" word per query
+        // per rank: the lists, one "uncertain" word per query, one STATUS word -- a rank whose local stage failed still
+        // takes part in the all-gather and says so there, so that every process returns the error together (a rank
+        // that simply left would strand the others inside the collective)
+        const size_t list_words = (size_t)nq * 2 * K, rank_words = list_words + nq + 1;
         const size_t q_bytes = ((size_t)nq * SMT_DIM * 4 + 255) & ~(size_t)255;
         const size_t loc_off = q_bytes;
         const size_t gath_off = loc_off + ((rank_words * 8 + 255) & ~(size_t)255);
@@ -890,37 +768,52 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
         const size_t dev_bytes = out_off + list_words * 8 + 64;
         const int ws = (mode == SMT_MODE_WORKSPACE && has_thr) ? 1 : 0;
         const float thr_score = 1.0f - (float)max_distance;  // store.rs:502-503
+        int local_rc = SMT_OK;
+        std::string local_err;
         for (int i = 0; i < g->n_local; ++i) {
             const int r = g->first_rank + i;
             if ((rc = group_bind(g, i))) return rc;
-            if ((rc = ensure_dev(g, i, dev_bytes))) return rc;
+            if ((rc = ensure_dev(g, i, dev_bytes))) return rc;   // (no exchange buffer: nothing to report through)
             char *base = reinterpret_cast<char *>(g->buf[i].dev);
-            SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
-            std::vector<smt_range> lr;
-            if (n_ranges) localize_ranges(ranges, n_ranges, sc->rank_base[r], sc->rank_rows[r], lr);
             uint64_t *loc = reinterpret_cast<uint64_t *>(base + loc_off);
-            rc = search_topk_packed_local(sc->shard[i], reinterpret_cast<const float *>(base), nq, K, ws, thr_score, lr.data(),
-                                          (uint32_t)lr.size(), n_ranges != 0, sc->rank_base[r], loc, loc + list_words, false);
-            if (rc) return rc;
+            const int stage_rc = [&]() -> int {
+                SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
+                std::vector<smt_range> lr;
+                if (n_ranges) layout_localize(sc, r, ranges, n_ranges, lr);
+                int rc2 = search_topk_packed_local(sc->shard[i], reinterpret_cast<const float *>(base), nq, K, ws, thr_score, lr.data(),
+                                                   (uint32_t)lr.size(), n_ranges != 0, sc->contiguous ? sc->rank_base[r] : 0, loc,
+                                                   loc + list_words, false);
+                if (!rc2 && !sc->contiguous) rc2 = layout_translate_packed(sc, i, g->ctx[i]->stream, loc, nq, K);
+                return rc2;
+            }();
+            if (stage_rc && !local_rc) { local_rc = stage_rc; local_err = smt_last_error(); }
+            const uint64_t status = (uint64_t)(uint32_t)(stage_rc < 0 ? -stage_rc : stage_rc);
+            SMT_HIP_CHECK(hipMemcpyAsync(loc + list_words + nq, &status, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
+            SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));   // (`status` is a stack word)
         }
         if ((rc = allgather_words(g, loc_off, gath_off, rank_words))) return rc;
         // the caller is one host thread and needs ONE copy of the answer: merge on local device 0
         if ((rc = group_bind(g, 0))) return rc;
         char *base0 = reinterpret_cast<char *>(g->buf[0].dev);
         uint64_t *gath = reinterpret_cast<uint64_t *>(base0 + gath_off), *merged = reinterpret_cast<uint64_t *>(base0 + out_off);
-        if ((rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, gath, (uint32_t)g->n_ranks, nq, K, K, merged, rank_words)))
+        if (!local_rc && (rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, gath, (uint32_t)g->n_ranks, nq, K, K, merged, rank_words)))
             return rc;
-        const size_t flag_words = (size_t)g->n_ranks * nq;
+        const size_t flag_words = (size_t)g->n_ranks * (nq + 1);
         if ((rc = ensure_host(g, 0, (list_words + flag_words) * 8))) return rc;
         uint64_t *h = reinterpret_cast<uint64_t *>(g->buf[0].pinned);
-        SMT_HIP_CHECK(hipMemcpyAsync(h, merged, list_words * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-        for (int r = 0; r < g->n_ranks; ++r)  // every rank's flags: all processes take the same fallback decision
-            SMT_HIP_CHECK(hipMemcpyAsync(h + list_words + (size_t)r * nq, gath + (size_t)r * rank_words + list_words, (size_t)nq * 8,
+        if (!local_rc) SMT_HIP_CHECK(hipMemcpyAsync(h, merged, list_words * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        for (int r = 0; r < g->n_ranks; ++r)  // every rank's flags + status: all processes take the same decisions
+            SMT_HIP_CHECK(hipMemcpyAsync(h + list_words + (size_t)r * (nq + 1), gath + (size_t)r * rank_words + list_words, (size_t)(nq + 1) * 8,
                                          hipMemcpyDeviceToHost, g->ctx[0]->stream));
         if ((rc = group_sync_all(g))) return rc;
+        if (local_rc) { set_error("%s", local_err.c_str()); return local_rc; }
+        for (int r = 0; r < g->n_ranks; ++r) {
+            const uint64_t st = h[list_words + (size_t)r * (nq + 1) + nq];
+            if (st) { set_error("rank %d failed with status -%llu; this rank gives up with it", r, (unsigned long long)st); return -(int)st; }
+        }
         for (uint32_t q = 0; q < nq; ++q) {
             bool uncertain = false;
-            for (int r = 0; r < g->n_ranks; ++r) uncertain |= h[list_words + (size_t)r * nq + q] != 0;
+            for (int r = 0; r < g->n_ranks; ++r) uncertain |= h[list_words + (size_t)r * (nq + 1) + q] != 0;
             if (uncertain) { redo.push_back(q); continue; }
             const uint64_t *rws = h + (size_t)q * 2 * K, *bits = rws + K;
             for (uint32_t e = 0; e < K && rws[e] != UINT64_MAX; ++e) {
@@ -939,7 +832,8 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
         std::vector<float> sub((size_t)redo.size() * SMT_DIM);
         for (size_t j = 0; j < redo.size(); ++j) memcpy(&sub[j * SMT_DIM], queries + (size_t)redo[j] * SMT_DIM, SMT_DIM * 4);
         std::vector<std::vector<LocalHits>> local;
-        if ((rc = local_host_search(sc, sub.data(), (uint32_t)redo.size(), top_k, max_distance, mode, ranges, n_ranges, local))) return rc;
+        rc = local_host_search(sc, sub.data(), (uint32_t)redo.size(), top_k, max_distance, mode, ranges, n_ranges, local);
+        if ((rc = group_agree(g, rc))) return rc;   // (a rank whose shard search failed must not leave the others in the exchange)
         std::vector<LocalHits> merged;
         if ((rc = exchange_host_lists(g, local, (uint32_t)redo.size(), all_under_threshold ? UINT64_MAX : (uint64_t)top_k, merged)))
             return rc;
@@ -970,9 +864,12 @@ int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *q
         // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select);
         // the all-gather and the merge then follow it there, and the main stream carries nothing but scans
         const bool async = c->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k;
-        rc = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false, sc->rank_base[r],
-                                      reinterpret_cast<uint64_t *>(g->buf[i].dev), nullptr, async);
+        rc = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false,
+                                      sc->contiguous ? sc->rank_base[r] : 0, reinterpret_cast<uint64_t *>(g->buf[i].dev), nullptr, async);
         if (rc) return rc;
+        if (!sc->contiguous && (rc = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream,
+                                                             reinterpret_cast<uint64_t *>(g->buf[i].dev), nq, top_k)))
+            return rc;
         on_aux[i] = async ? 1 : 0;
         if (async) c->async_pending = true;
     }
@@ -1012,6 +909,7 @@ int smt_sharded_ivfpq_build(smt_sharded_corpus *sc, const smt_ivfpq_params *para
         share.rank = (uint32_t)(g->first_rank + i);
         share.n_ranks = (uint32_t)g->n_ranks;
         share.allreduce = group_allreduce_sums;
+        share.agree = group_share_agree;
         sctx[i] = ShareCtx{g, i};
         share.user = &sctx[i];
         rcs[i] = ivfpq_build_shared(sc->shard[i], params, shared_centroids ? &share : nullptr, &six->shard[i]);
@@ -1057,6 +955,7 @@ int smt_sharded_ivfpq_search(smt_sharded_ivfpq *six, const float *queries, uint3
     smt_group *g = sc->group;
     SMT_REQUIRE((uint64_t)g->n_ranks * top_k <= 8192, "device merge handles up to 8192 candidates per query");
     if (nq == 0) return SMT_OK;
+    if (g->n_ranks == 1) return smt_ivfpq_search(six->shard[0], queries, nq, top_k, nprobe, rerank, 0, out_rows, out_dist, out_counts, out_cap);
     const size_t list_words = (size_t)nq * 2 * top_k;
     const size_t q_bytes = ((size_t)nq * SMT_DIM * 4 + 255) & ~(size_t)255;
     const size_t loc_off = q_bytes, gath_off = loc_off + ((list_words * 8 + 255) & ~(size_t)255);
@@ -1068,8 +967,10 @@ int smt_sharded_ivfpq_search(smt_sharded_ivfpq *six, const float *queries, uint3
         if ((rc = ensure_dev(g, i, out_off + list_words * 8 + 64))) return rc;
         char *base = reinterpret_cast<char *>(g->buf[i].dev);
         SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
-        if ((rc = ivfpq_search_packed(six->shard[i], reinterpret_cast<const float *>(base), nq, top_k, nprobe, rerank, sc->rank_base[r],
-                                      reinterpret_cast<uint64_t *>(base + loc_off))))
+        if ((rc = ivfpq_search_packed(six->shard[i], reinterpret_cast<const float *>(base), nq, top_k, nprobe, rerank,
+                                      sc->contiguous ? sc->rank_base[r] : 0, reinterpret_cast<uint64_t *>(base + loc_off))))
+            return rc;
+        if (!sc->contiguous && (rc = layout_translate_packed(sc, i, g->ctx[i]->stream, reinterpret_cast<uint64_t *>(base + loc_off), nq, top_k)))
             return rc;
     }
     if ((rc = allgather_words(g, loc_off, gath_off, list_words))) return rc;

@@ -55,11 +55,15 @@ int main(int argc, char **argv)
     const std::string cmd = argv[1];
     std::vector<std::string> args(argv + 2, argv + argc);
 
-    smt_ctx *ctx = nullptr;
+    // The GPUs this process owns.  $SEMTOOLS_DEVICES = "0,1,2,3" | "all" | "<device>:<logical shards>" runs the whole
+    // path sharded over them (table replicated, lines and rows dealt over the GPUs, one all-gather per search); unset, it is
+    // one GPU ($SEMTOOLS_DEVICE, default 0).  Output bytes do not depend on it.
+    smt_group *group = nullptr;
     auto need_ctx = [&]() -> bool {
-        if (ctx) return true;
-        const char *dev = getenv("SEMTOOLS_DEVICE");
-        if (smt_ctx_create(dev ? atoi(dev) : 0, &ctx) != SMT_OK) { die(smt_last_error()); return false; }
+        if (group) return true;
+        const char *devs = getenv("SEMTOOLS_DEVICES"), *dev = getenv("SEMTOOLS_DEVICE");
+        const std::string spec = (devs && *devs) ? devs : (dev && *dev) ? dev : "0";
+        if (smt_host_group_from_spec(spec.c_str(), &group) != SMT_OK) { die(smt_last_error()); return false; }
         return true;
     };
 
@@ -73,7 +77,7 @@ int main(int argc, char **argv)
         if (pos[0] == "use") {
             if (pos.size() < 2) return usage();
             if (json && !need_ctx()) return 1;
-            rc = smt_host_workspace_use(ctx, pos[1].c_str(), json, &text);
+            rc = smt_host_workspace_use_group(group, pos[1].c_str(), json, &text);
         } else if (pos[0] == "reembed") {
             // not in the reference: re-create the stored vectors from the cached token ids with the model in
             // $SEMTOOLS_MODEL_DIR (a new embedding table behind the same tokenizer), no source file is read
@@ -81,18 +85,18 @@ int main(int argc, char **argv)
             const char *model_dir = getenv("SEMTOOLS_MODEL_DIR");
             if (!model_dir) return die("SEMTOOLS_MODEL_DIR is not set (directory with model.safetensors + vocab.txt)");
             smt_host_model *model = nullptr;
-            if (smt_host_model_from_dir(ctx, model_dir, &model) != SMT_OK) return die(smt_last_error());
+            if (smt_host_model_from_dir_group(group, model_dir, &model) != SMT_OK) return die(smt_last_error());
             rc = smt_host_workspace_reembed(model, pos.size() > 1 ? pos[1].c_str() : nullptr, json, &text);
             smt_host_model_destroy(model);
         } else if (pos[0] == "status" || pos[0] == "prune") {
             if (!need_ctx()) return 1;
             const char *nm = pos.size() > 1 ? pos[1].c_str() : nullptr;
-            rc = pos[0] == "status" ? smt_host_workspace_status(ctx, nm, json, &text) : smt_host_workspace_prune(ctx, nm, json, &text);
+            rc = pos[0] == "status" ? smt_host_workspace_status_group(group, nm, json, &text) : smt_host_workspace_prune_group(group, nm, json, &text);
         } else return usage();
         if (rc != SMT_OK) return die(smt_last_error());
         fputs(text, stdout);
         smt_host_free(text);
-        smt_ctx_destroy(ctx);
+        smt_group_destroy(group);
         return 0;
     }
     if (cmd == "serve") {
@@ -119,7 +123,7 @@ int main(int argc, char **argv)
         const char *model_dir = getenv("SEMTOOLS_MODEL_DIR");
         if (!model_dir) return die("SEMTOOLS_MODEL_DIR is not set (directory with model.safetensors + vocab.txt)");
         smt_host_model *model = nullptr;
-        if (smt_host_model_from_dir(ctx, model_dir, &model) != SMT_OK) return die(smt_last_error());
+        if (smt_host_model_from_dir_group(group, model_dir, &model) != SMT_OK) return die(smt_last_error());
         std::vector<const char *> fp;
         for (auto &f : files) fp.push_back(f.c_str());
         smt_host_session *session = nullptr;
@@ -153,7 +157,7 @@ int main(int argc, char **argv)
         if (flush_batch()) return 1;
         smt_host_session_close(session);
         smt_host_model_destroy(model);
-        smt_ctx_destroy(ctx);
+        smt_group_destroy(group);
         return 0;
     }
     if (cmd != "search") return usage();
@@ -186,7 +190,7 @@ int main(int argc, char **argv)
     const char *model_dir = getenv("SEMTOOLS_MODEL_DIR");
     if (!model_dir) return die("SEMTOOLS_MODEL_DIR is not set (directory with model.safetensors + vocab.txt)");
     smt_host_model *model = nullptr;
-    if (smt_host_model_from_dir(ctx, model_dir, &model) != SMT_OK) return die(smt_last_error());
+    if (smt_host_model_from_dir_group(group, model_dir, &model) != SMT_OK) return die(smt_last_error());
 
     const int is_tty = isatty(STDOUT_FILENO);
     char *text = nullptr;
@@ -232,6 +236,6 @@ int main(int argc, char **argv)
         smt_host_free(phases);
     }
     smt_host_model_destroy(model);
-    smt_ctx_destroy(ctx);
+    smt_group_destroy(group);
     return 0;
 }

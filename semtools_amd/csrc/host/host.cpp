@@ -330,19 +330,19 @@ std::unique_ptr<Tokenizer> make_callback_tokenizer(TokenizeFn fn, uint64_t vocab
 // ================================================================== search
 namespace search {
 
-StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize)
-    : ctx_(ctx), tok_(std::move(tok))
+StaticModel::StaticModel(smt_group *group, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize)
+    : group_(group), tok_(std::move(tok))
 {
-    check(smt_model_create(ctx, table, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
+    check(smt_sharded_model_create(group, table, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
 }
 
-StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
+StaticModel::StaticModel(smt_group *group, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
                          bool normalize)
-    : ctx_(ctx), tok_(std::move(tok))
+    : group_(group), tok_(std::move(tok))
 {
     const char *eager = getenv("SEMTOOLS_EAGER_MODEL");
     if (eager && eager[0] == '1') {
-        check(smt_model_create_from_file(ctx, path.c_str(), byte_offset, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
+        check(smt_sharded_model_create_from_file(group, path.c_str(), byte_offset, V, SMT_DIM, normalize ? 1 : 0, &model_), "StaticModel");
         return;
     }
     lazy_path_ = path;
@@ -355,14 +355,14 @@ StaticModel::StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std
 
 StaticModel::~StaticModel()
 {
-    if (model_) smt_model_destroy(model_);
+    if (model_) smt_sharded_model_destroy(model_);
     if (lazy_fd_ >= 0) close(lazy_fd_);
 }
 
-smt_model *StaticModel::full_model() const
+smt_sharded_model *StaticModel::full_model() const
 {
     if (!model_) {
-        check(smt_model_create_from_file(ctx_, lazy_path_.c_str(), lazy_offset_, lazy_V_, SMT_DIM, lazy_normalize_ ? 1 : 0, &model_),
+        check(smt_sharded_model_create_from_file(group_, lazy_path_.c_str(), lazy_offset_, lazy_V_, SMT_DIM, lazy_normalize_ ? 1 : 0, &model_),
               "StaticModel (full table upload)");
         PhaseTimer::mark("model_table_upload");
     }
@@ -370,10 +370,10 @@ smt_model *StaticModel::full_model() const
 }
 
 void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<uint64_t> &offsets, uint64_t n_lines, float *out_host,
-                            smt_corpus *corpus) const
+                            smt_sharded_corpus *corpus) const
 {
     if (model_ || lazy_fd_ < 0) {
-        check(smt_embed(model_, ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
+        check(smt_sharded_embed(model_, ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
         return;
     }
     // ---- lazy: which rows does this batch touch?
@@ -387,7 +387,7 @@ void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<
     // them one by one; each compact table costs a device allocation and an upload): upload all of it, once
     if ((uint64_t)uniq.size() * 16 > lazy_V_ || ++lazy_calls_ > 64) {
         for (uint32_t id : uniq) lazy_slot_[id] = 0;
-        check(smt_embed(full_model(), ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
+        check(smt_sharded_embed(full_model(), ids.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr), "embed");
         return;
     }
     std::sort(uniq.begin(), uniq.end());          // file order: neighbouring rows share pages
@@ -416,10 +416,10 @@ void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<
     std::vector<uint32_t> remapped(ids.size());
     for (size_t i = 0; i < ids.size(); ++i) remapped[i] = lazy_slot_[ids[i]] - 1;
     for (uint32_t id : uniq) lazy_slot_[id] = 0;
-    smt_model *tmp = nullptr;
-    check(smt_model_create(ctx_, compact.data(), std::max<size_t>(uniq.size(), 1), SMT_DIM, lazy_normalize_ ? 1 : 0, &tmp), "embed (compact table)");
-    const int rc = smt_embed(tmp, remapped.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr);
-    smt_model_destroy(tmp);
+    smt_sharded_model *tmp = nullptr;   // (a few MB: replicated like the full table)
+    check(smt_sharded_model_create(group_, compact.data(), std::max<size_t>(uniq.size(), 1), SMT_DIM, lazy_normalize_ ? 1 : 0, &tmp), "embed (compact table)");
+    const int rc = smt_sharded_embed(tmp, remapped.data(), offsets.data(), n_lines, 0, out_host, corpus, nullptr);
+    smt_sharded_model_destroy(tmp);
     check(rc, "embed (compact table)");
 }
 
@@ -526,11 +526,11 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
 }
 
 uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
-                                  size_t batch_size, smt_corpus *corpus, TokenCsr *sink) const
+                                  size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink) const
 {
     // Double-buffered pipeline: while the GPU gathers/pools batch i (H2D of the ids + K1),
     // the host threads already tokenise batch i+1.  Batches are appended in order, so rows == line order.
-    const uint64_t first = smt_corpus_rows(corpus);
+    const uint64_t first = smt_sharded_corpus_rows(corpus);
     if (batch_size == 0) batch_size = 1;
     // The reference's 16384-line batches are an allocation bound of its own pipeline; rows do not depend on how the lines
     // are batched.  Here a batch is what one round of tokenizer threads chews on, so it must be large enough to amortise
@@ -569,9 +569,9 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
     return first;
 }
 
-void StaticModel::embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_corpus *corpus) const
+void StaticModel::embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_sharded_corpus *corpus) const
 {
-    check(smt_embed(full_model(), ids, offsets, n_lines, 0, nullptr, corpus, nullptr), "embed_tokens_into");
+    check(smt_sharded_embed(full_model(), ids, offsets, n_lines, 0, nullptr, corpus, nullptr), "embed_tokens_into");
 }
 
 uint64_t StaticModel::tokenizer_fingerprint() const
@@ -596,9 +596,9 @@ std::vector<float> StaticModel::encode_single(const std::string &sentence) const
     return encode_with_args({sentence}, 512, 1024).at(0);
 }
 
-Embeddings::Embeddings(smt_ctx *ctx) { check(smt_corpus_create(ctx, SMT_DIM, 0, &corpus_), "Embeddings"); }
-Embeddings::~Embeddings() { smt_corpus_destroy(corpus_); }
-uint64_t Embeddings::rows() const { return smt_corpus_rows(corpus_); }
+Embeddings::Embeddings(smt_group *group) { check(smt_sharded_corpus_create(group, SMT_DIM, &corpus_), "Embeddings"); }
+Embeddings::~Embeddings() { smt_sharded_corpus_destroy(corpus_); }
+uint64_t Embeddings::rows() const { return smt_sharded_corpus_rows(corpus_); }
 
 std::optional<Document> create_document_from_content(const std::string &filename, const std::string &content,
                                                      const StaticModel &model, bool ignore_case, Embeddings &emb)
@@ -666,9 +666,9 @@ std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<
     for (;;) {
         rows.resize(cap * nq);
         dist.resize(cap * nq);
-        const int rc = smt_search(emb.corpus(), qflat.data(), (uint32_t)nq, (uint32_t)std::min<size_t>(config.top_k, 0xFFFFFFFFu),
-                                  all_hits ? *config.max_distance : NAN, SMT_MODE_DOCUMENTS, whole ? nullptr : ranges.data(),
-                                  whole ? 0 : (uint32_t)ranges.size(), 0, rows.data(), dist.data(), counts.data(), cap);
+        const int rc = smt_sharded_search(emb.corpus(), qflat.data(), (uint32_t)nq, (uint32_t)std::min<size_t>(config.top_k, 0xFFFFFFFFu),
+                                          all_hits ? *config.max_distance : NAN, SMT_MODE_DOCUMENTS, whole ? nullptr : ranges.data(),
+                                          whole ? 0 : (uint32_t)ranges.size(), rows.data(), dist.data(), counts.data(), cap);
         if (rc == SMT_E_TRUNCATED) { cap = *std::max_element(counts.begin(), counts.end()); continue; }
         check(rc, "search_documents");
         break;
@@ -700,7 +700,7 @@ std::vector<SearchResult> search_files(const std::vector<std::string> &files, co
                                        const StaticModel &model, const SearchConfig &config)
 {
     PhaseTimer::mark("model_load");
-    Embeddings emb(model.ctx());
+    Embeddings emb(model.group());
     std::vector<Document> documents;
     // mod.rs:128-134 reads and embeds file by file; the rows do not depend on how the lines are batched, so all files
     // are read first (the first error still aborts before anything is printed) and embedded in ONE pipeline run
@@ -739,12 +739,14 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
     const std::vector<float> query_embedding = model.encode_single(query);
     PhaseTimer::mark("embed_query");
     Workspace ws = Workspace::open(workspace_name);
-    auto store = Store::open(ws.config.root_dir, model.ctx());
+    auto store = Store::open(ws.config.root_dir, model.group());
     PhaseTimer::mark("store_open_corpus_load");
     {
+        // the approximate index is OPT-IN: the reference's store always searches exactly (store.rs:619,632)
         const char *min_rows = getenv("SEMTOOLS_INDEX_MIN_ROWS"), *nprobe = getenv("SEMTOOLS_INDEX_NPROBE");
-        store->set_index_policy(ws.config.oversample_factor, min_rows ? strtoull(min_rows, nullptr, 10) : 2'000'000ull,
-                                nprobe ? (uint32_t)strtoul(nprobe, nullptr, 10) : 16u);
+        uint64_t min = ws.config.approximate_index_min_rows ? ws.config.approximate_index_min_rows : UINT64_MAX;
+        if (min_rows) { min = strtoull(min_rows, nullptr, 10); if (min == 0) min = UINT64_MAX; }
+        store->set_index_policy(ws.config.oversample_factor, min, nprobe ? (uint32_t)strtoul(nprobe, nullptr, 10) : 16u);
     }
 
     // Step 1: changed / new / unchanged (mod.rs:158)
@@ -820,6 +822,7 @@ Workspace Workspace::open(const std::optional<std::string> &workspace_name)
         if (auto *x = v.get("root_dir")) ws.config.root_dir = x->s;
         if (auto *x = v.get("in_batch_size")) ws.config.in_batch_size = (size_t)x->as_u64();
         if (auto *x = v.get("oversample_factor")) ws.config.oversample_factor = (size_t)x->as_u64();
+        if (auto *x = v.get("approximate_index_min_rows")) ws.config.approximate_index_min_rows = x->as_u64();
     } catch (const std::exception &) {
         ws.config = WorkspaceConfig();  // unreadable / invalid config -> defaults (mod.rs:36-40)
     }
@@ -837,17 +840,20 @@ void Workspace::save() const
     v.set("root_dir", json::Value::str(config.root_dir));
     v.set("in_batch_size", json::Value::uint(config.in_batch_size));
     v.set("oversample_factor", json::Value::uint(config.oversample_factor));
+    if (config.approximate_index_min_rows) v.set("approximate_index_min_rows", json::Value::uint(config.approximate_index_min_rows));
     write_file_atomic(path, json::to_string_pretty(v));
 }
 
 uint64_t DocMeta::id() const { return smt_doc_meta_id(path.c_str()); }
 uint64_t LineEmbedding::id() const { return smt_line_embedding_id(path.c_str(), line_number); }
 
-std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ctx)
+std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_group *group)
 {
     std::unique_ptr<Store> s(new Store());
     s->dir_ = workspace_dir;
-    s->ctx_ = ctx;
+    s->group_ = group;
+    int n_ranks = 1;
+    check(smt_group_info(group, &n_ranks, nullptr, nullptr, nullptr, nullptr), "Store::open");
     mkdir_p(workspace_dir);
     const std::string docs = workspace_dir + "/documents.json";
     const std::string rows = workspace_dir + "/line_rows.json";
@@ -866,12 +872,33 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
         }
     }
     bool corpus_ok = false;
+    json::Value rows_json;
+    bool have_rows_json = false;
+    if (path_exists(rows)) {
+        try { rows_json = json::parse(read_to_string(rows)); have_rows_json = true; } catch (const std::exception &) {}
+    }
+    // how the rows were dealt over the GPUs when the store was written (see flush_line_embeddings): restored when this
+    // group has as many ranks, so that shards -- and the per-shard index files -- are what they were
+    std::vector<uint64_t> piece_rows;
+    std::vector<uint32_t> piece_rank;
+    if (have_rows_json && n_ranks > 1)
+        if (auto *sh = rows_json.get("shards"))
+            if (auto *nr = sh->get("n_ranks"); nr && nr->as_u64() == (uint64_t)n_ranks)
+                if (auto *pc = sh->get("pieces"))
+                    for (auto &e : pc->arr)
+                        if (e.arr.size() == 2) { piece_rows.push_back(e.arr[0].as_u64()); piece_rank.push_back((uint32_t)e.arr[1].as_u64()); }
+    bool layout_restored = false;
     if (path_exists(emb)) {
         // A truncated / foreign file must not brick the workspace: start from an empty store, every document then
         // counts as Changed (no extent, see analyze_document_states) and is re-embedded by the next search.
-        const int rc = smt_corpus_load(ctx, emb.c_str(), &s->corpus_);
+        int rc = SMT_E_INVALID;
+        if (!piece_rows.empty()) {
+            rc = smt_sharded_corpus_load_layout(group, emb.c_str(), piece_rows.data(), piece_rank.data(), piece_rows.size(), &s->corpus_);
+            layout_restored = rc == SMT_OK;
+        }
+        if (rc == SMT_E_INVALID) rc = smt_sharded_corpus_load(group, emb.c_str(), &s->corpus_);   // (stale layout: cut evenly)
         if (rc == SMT_OK) {
-            s->rows_on_disk_ = smt_corpus_rows(s->corpus_);
+            s->rows_on_disk_ = smt_sharded_corpus_rows(s->corpus_);
             s->rows_on_disk_valid_ = true;
             corpus_ok = true;
         } else if (rc != SMT_E_IO) {
@@ -880,10 +907,11 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
             fprintf(stderr, "warning: %s is unreadable (%s); the workspace will be re-embedded\n", emb.c_str(), smt_last_error());
         }
     }
-    if (!corpus_ok) check(smt_corpus_create(ctx, SMT_DIM, 0, &s->corpus_), "Store::open");
-    s->index_on_disk_ = corpus_ok && path_exists(workspace_dir + "/line_index.ivf");
-    if (corpus_ok && path_exists(rows)) {
-        const json::Value v = json::parse(read_to_string(rows));
+    if (!corpus_ok) check(smt_sharded_corpus_create(group, SMT_DIM, &s->corpus_), "Store::open");
+    // the index files name LOCAL rows by position: only valid on the layout they were built on
+    s->index_on_disk_ = corpus_ok && (n_ranks == 1 || layout_restored) && path_exists(s->index_file(0));
+    if (corpus_ok && have_rows_json) {
+        const json::Value &v = rows_json;
         uint64_t live = 0;
         if (auto *arr = v.get("extents"))
             for (auto &e : arr->arr) {
@@ -891,11 +919,11 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
                 x.first_row = e.get("first_row")->as_u64();
                 x.n_rows = e.get("n_rows")->as_u64();
                 // torn write: drop the extent; analyze_document_states reports a document without one as Changed
-                if (x.first_row + x.n_rows > smt_corpus_rows(s->corpus_)) continue;
+                if (x.first_row + x.n_rows > smt_sharded_corpus_rows(s->corpus_)) continue;
                 s->extents_[e.get("path")->s] = x;
                 live += x.n_rows;
             }
-        s->dead_rows_ = smt_corpus_rows(s->corpus_) - live;
+        s->dead_rows_ = smt_sharded_corpus_rows(s->corpus_) - live;
     }
     return s;
 }
@@ -903,8 +931,30 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_ctx *ct
 Store::~Store()
 {
     if (token_log_file_) fclose(token_log_file_);
-    if (index_) smt_ivfpq_destroy(index_);  // (before the corpus it points into)
-    smt_corpus_destroy(corpus_);
+    if (index_) smt_sharded_ivfpq_destroy(index_);  // (before the corpus it points into)
+    smt_sharded_corpus_destroy(corpus_);
+}
+
+// rank r's part of the index: `line_index.ivf` on one GPU, `line_index.ivf.r<r>of<n>` on several (smt_sharded_ivfpq_save)
+std::string Store::index_file(int rank) const
+{
+    int n_ranks = 1;
+    (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
+    const std::string base = dir_ + "/line_index.ivf";
+    return n_ranks == 1 ? base : base + ".r" + std::to_string(rank) + "of" + std::to_string(n_ranks);
+}
+
+// The index points into corpus_ and names its rows by position: it goes BEFORE the corpus is destroyed or its rows move
+// (smt_ivfpq_destroy reads index->corpus->ctx: the other order is a use-after-free).
+void Store::drop_index()
+{
+    if (index_) { smt_sharded_ivfpq_destroy(index_); index_ = nullptr; }
+    if (index_on_disk_) {
+        int n_ranks = 1;
+        (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
+        for (int r = 0; r < n_ranks; ++r) (void)remove(index_file(r).c_str());
+        index_on_disk_ = false;
+    }
 }
 
 void Store::set_index_policy(size_t oversample_factor, uint64_t min_rows, uint32_t nprobe)
@@ -918,21 +968,23 @@ void Store::set_index_policy(size_t oversample_factor, uint64_t min_rows, uint32
 // (re)build it.  Returns false when no usable index exists (then the caller scans exactly).
 bool Store::ensure_index() const
 {
-    const uint64_t rows = smt_corpus_rows(corpus_);
+    const uint64_t rows = smt_sharded_corpus_rows(corpus_);
     const std::string file = dir_ + "/line_index.ivf";
+    int n_ranks = 1;
+    (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
     bool changed = false;
     if (!index_ && index_on_disk_) {
-        if (smt_ivfpq_load(corpus_, file.c_str(), &index_) != SMT_OK) index_ = nullptr;  // stale / corrupt: rebuild below
-        if (index_) { uint64_t n = 0; smt_ivfpq_info(index_, &n, nullptr, nullptr, nullptr); index_built_rows_ = n; }
+        if (smt_sharded_ivfpq_load(corpus_, file.c_str(), &index_) != SMT_OK) index_ = nullptr;  // stale / corrupt: rebuild below
+        if (index_) { uint64_t n = 0; smt_sharded_ivfpq_info(index_, &n, nullptr, nullptr); index_built_rows_ = n; }
     }
     if (index_) {
         uint64_t covered = 0;
-        smt_ivfpq_info(index_, &covered, nullptr, nullptr, nullptr);
+        smt_sharded_ivfpq_info(index_, &covered, nullptr, nullptr);
         if (covered < rows) {
             // the corpus only grew: incremental insert with the existing quantisers -- until it has doubled
             uint64_t added = 0;
-            if (rows > 2 * std::max<uint64_t>(index_built_rows_, 1) || smt_ivfpq_append(index_, &added) != SMT_OK) {
-                smt_ivfpq_destroy(index_);
+            if (rows > 2 * std::max<uint64_t>(index_built_rows_, 1) || smt_sharded_ivfpq_append(index_, &added) != SMT_OK) {
+                smt_sharded_ivfpq_destroy(index_);
                 index_ = nullptr;
             } else {
                 changed = true;
@@ -942,22 +994,25 @@ bool Store::ensure_index() const
     if (!index_) {
         smt_ivfpq_params prm;
         memset(&prm, 0, sizeof(prm));
-        // ~ sqrt(N) lists (a multiple of 32 in [32, 4096]): 10 M rows -> 4096 lists of ~2.4 k rows
-        uint64_t nlist = (uint64_t)std::sqrt((double)rows) * 4 / 3;
+        // ~ sqrt(N) lists per shard (a multiple of 32 in [32, 4096]): 10 M rows -> 4096 lists of ~2.4 k rows
+        std::vector<uint64_t> per_rank((size_t)n_ranks, 0);
+        (void)smt_sharded_corpus_rank_rows(corpus_, per_rank.data());
+        const uint64_t smallest = *std::min_element(per_rank.begin(), per_rank.end());
+        uint64_t nlist = (uint64_t)std::sqrt((double)(rows / (uint64_t)n_ranks)) * 4 / 3;
         nlist = std::min<uint64_t>(4096, std::max<uint64_t>(32, nlist / 32 * 32));
         prm.nlist = (uint32_t)nlist;
         prm.m = 32;
         prm.nbits = 8;
         prm.train_iters = 10;
         prm.local_pca = 1;
-        if (rows < nlist || smt_ivfpq_build(corpus_, &prm, &index_) != SMT_OK) { index_ = nullptr; return false; }
+        // several GPUs: ONE set of nlist lists over the whole corpus (centroid sums all-reduced in the k-means), each list
+        // spread over the shards; quantisers and codes are fitted per shard
+        if (smallest < nlist || smt_sharded_ivfpq_build(corpus_, &prm, n_ranks > 1 ? 1 : 0, &index_) != SMT_OK) { index_ = nullptr; return false; }
         index_built_rows_ = rows;
         changed = true;
     }
-    if (changed) {  // persist beside the vectors: write a sibling, then rename
-        const std::string tmp = file + ".tmp";
-        if (smt_ivfpq_save(index_, tmp.c_str()) == SMT_OK && rename(tmp.c_str(), file.c_str()) == 0) index_on_disk_ = true;
-        else (void)remove(tmp.c_str());
+    if (changed) {  // persist beside the vectors (a sibling first, then rename: smt_sharded_ivfpq_save)
+        if (smt_sharded_ivfpq_save(index_, file.c_str()) == SMT_OK) index_on_disk_ = true;
     }
     return true;
 }
@@ -1029,18 +1084,19 @@ void Store::upsert_line_embeddings(const std::vector<LineEmbedding> &line_embedd
         const uint64_t old_n = it != extents_.end() ? it->second.n_rows : 0;
         if (it != extents_.end() && max_line < old_n) {  // in-place replacement
             for (auto *le : kv.second)
-                check(smt_corpus_write_rows(corpus_, it->second.first_row + (uint64_t)le->line_number, le->embedding.data(), 1),
+                check(smt_sharded_corpus_write_rows(corpus_, it->second.first_row + (uint64_t)le->line_number, le->embedding.data(), 1),
                       "upsert_line_embeddings");
             rows_on_disk_valid_ = false;  // rows already on disk changed: the next flush rewrites the file
+            drop_index();                 // ... and the index's codes of those rows are stale
             continue;
         }
         const uint64_t new_n = std::max(old_n, max_line + 1);
         std::vector<float> rows((size_t)new_n * LINE_EMBEDDING_SIZE, 0.0f);
-        if (old_n) check(smt_corpus_read_rows(corpus_, it->second.first_row, old_n, rows.data()), "upsert_line_embeddings");
+        if (old_n) check(smt_sharded_corpus_read_rows(corpus_, it->second.first_row, old_n, rows.data()), "upsert_line_embeddings");
         for (auto *le : kv.second)
             std::copy(le->embedding.begin(), le->embedding.end(), rows.begin() + (size_t)le->line_number * LINE_EMBEDDING_SIZE);
         uint64_t first = 0;
-        check(smt_corpus_append_host(corpus_, rows.data(), new_n, &first), "upsert_line_embeddings");
+        check(smt_sharded_corpus_append_host(corpus_, rows.data(), new_n, &first), "upsert_line_embeddings");
         dead_rows_ += old_n;
         extents_[kv.first] = Extent{first, new_n};
     }
@@ -1161,11 +1217,17 @@ Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &
     if (FILE *f = fopen(log.c_str(), "rb")) {
         char magic[8];
         uint64_t reserved = 0;
+        // record sizes come from the file: bound every one of them by what is left of it before allocating
+        uint64_t file_size = 0;
+        { struct stat st; if (fstat(fileno(f), &st) == 0) file_size = (uint64_t)st.st_size; }
         if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "SMTTOK01", 8) == 0 && fread(&log_fp, 8, 1, f) == 1 && fread(&reserved, 8, 1, f) == 1) {
             for (;;) {
                 uint32_t head[4];
                 uint64_t n_ids = 0;
                 if (fread(head, 4, 4, f) != 4 || head[0] != TOK_TAG || fread(&n_ids, 8, 1, f) != 1) break;
+                const uint64_t at = (uint64_t)ftello(f), left = file_size > at ? file_size - at : 0;
+                const uint64_t n_lens = head[2] == TOK_TOMBSTONE ? 0 : head[2];
+                if (head[1] > left || n_lens > (left - head[1]) / 4 || n_ids > (left - head[1] - n_lens * 4) / 4) break;   // torn / corrupt tail
                 std::string path(head[1], '\0');
                 if (head[1] && fread(&path[0], 1, head[1], f) != head[1]) break;
                 if (head[2] == TOK_TOMBSTONE) { cache.erase(path); continue; }
@@ -1192,9 +1254,11 @@ Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &
     }
     if (!rep.missing.empty()) return rep;   // nothing changed
     std::sort(order.begin(), order.end());
-    const uint64_t live = smt_corpus_rows(corpus_) - dead_rows_;
-    smt_corpus *fresh = nullptr;
-    check(smt_corpus_create(ctx_, SMT_DIM, live, &fresh), "reembed");
+    smt_sharded_corpus *fresh = nullptr;
+    check(smt_sharded_corpus_create(group_, SMT_DIM, &fresh), "reembed");
+    // the new extents are collected aside and swapped in only once the fresh corpus is complete: if an embed call fails
+    // half way, extents_ still describes the corpus that is still there
+    std::map<std::string, Extent> fresh_extents;
     try {
         // batches of about 16384 lines, like encode_with_args' batch size
         std::vector<uint32_t> ids;
@@ -1206,8 +1270,7 @@ Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &
         };
         for (auto &o : order) {
             const search::TokenCsr &t = cache[o.second];
-            Extent &x = extents_[o.second];
-            x.first_row = smt_corpus_rows(fresh) + (offsets.size() - 1);
+            fresh_extents[o.second] = Extent{smt_sharded_corpus_rows(fresh) + (offsets.size() - 1), extents_[o.second].n_rows};
             ids.insert(ids.end(), t.ids.begin(), t.ids.end());
             for (uint32_t l : t.lens) offsets.push_back(offsets.back() + l);
             rep.documents += 1;
@@ -1216,13 +1279,13 @@ Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &
             if (offsets.size() > 16384) flush();
         }
         flush();
-    } catch (...) { smt_corpus_destroy(fresh); throw; }
-    smt_corpus_destroy(corpus_);
+    } catch (...) { smt_sharded_corpus_destroy(fresh); throw; }
+    drop_index();                            // (before the corpus it points into goes away)
+    smt_sharded_corpus_destroy(corpus_);
     corpus_ = fresh;
+    extents_.swap(fresh_extents);
     dead_rows_ = 0;
     rows_on_disk_valid_ = false;
-    if (index_) { smt_ivfpq_destroy(index_); index_ = nullptr; }
-    if (index_on_disk_) { (void)remove((dir_ + "/line_index.ivf").c_str()); index_on_disk_ = false; }
     flush_line_embeddings();
     // rewrite the log with one record per live document (drops superseded records and tombstones)
     const std::string tmp = log + ".tmp";
@@ -1248,29 +1311,44 @@ Store::ReembedReport Store::reembed_from_token_cache(const search::StaticModel &
 
 void Store::compact_if_sparse()
 {
-    const uint64_t total = smt_corpus_rows(corpus_);
+    const uint64_t total = smt_sharded_corpus_rows(corpus_);
     if (dead_rows_ < 4096 || dead_rows_ * 2 < total) return;
     // rewrite live extents back to back (row order of surviving documents is preserved)
     std::vector<std::pair<uint64_t, std::string>> order;
     for (auto &kv : extents_) order.emplace_back(kv.second.first_row, kv.first);
     std::sort(order.begin(), order.end());
-    smt_corpus *fresh = nullptr;
-    check(smt_corpus_create(ctx_, SMT_DIM, total - dead_rows_, &fresh), "compact");
-    std::vector<float> buf;
-    for (auto &o : order) {
-        Extent &x = extents_[o.second];
-        buf.resize((size_t)x.n_rows * LINE_EMBEDDING_SIZE);
-        check(smt_corpus_read_rows(corpus_, x.first_row, x.n_rows, buf.data()), "compact");
-        uint64_t first = 0;
-        check(smt_corpus_append_host(fresh, buf.data(), x.n_rows, &first), "compact");
-        x.first_row = first;
-    }
-    smt_corpus_destroy(corpus_);
+    smt_sharded_corpus *fresh = nullptr;
+    check(smt_sharded_corpus_create(group_, SMT_DIM, &fresh), "compact");
+    std::map<std::string, Extent> fresh_extents;
+    try {
+        // extents travel in runs of up to 64 Ki rows: one read / one dealt append per run, not per document
+        std::vector<float> buf;
+        std::vector<std::pair<const std::string *, uint64_t>> run;   // (path, offset inside the run)
+        uint64_t run_rows = 0;
+        auto flush = [&]() {
+            if (!run_rows) return;
+            uint64_t first = 0;
+            check(smt_sharded_corpus_append_host(fresh, buf.data(), run_rows, &first), "compact");
+            for (auto &r : run) fresh_extents[*r.first] = Extent{first + r.second, extents_[*r.first].n_rows};
+            run.clear();
+            run_rows = 0;
+        };
+        for (auto &o : order) {
+            const Extent &x = extents_[o.second];
+            if (run_rows && run_rows + x.n_rows > 65536) flush();
+            buf.resize((size_t)(run_rows + x.n_rows) * LINE_EMBEDDING_SIZE);
+            check(smt_sharded_corpus_read_rows(corpus_, x.first_row, x.n_rows, buf.data() + (size_t)run_rows * LINE_EMBEDDING_SIZE), "compact");
+            run.emplace_back(&o.second, run_rows);
+            run_rows += x.n_rows;
+        }
+        flush();
+    } catch (...) { smt_sharded_corpus_destroy(fresh); throw; }
+    drop_index();                            // the index names rows by position and points into corpus_: it goes first
+    smt_sharded_corpus_destroy(corpus_);
     corpus_ = fresh;
+    extents_.swap(fresh_extents);
     dead_rows_ = 0;
     rows_on_disk_valid_ = false;  // rows moved: the file must be rewritten
-    if (index_) { smt_ivfpq_destroy(index_); index_ = nullptr; }  // ... and the index names rows by position
-    if (index_on_disk_) { (void)remove((dir_ + "/line_index.ivf").c_str()); index_on_disk_ = false; }
 }
 
 WorkspaceStats Store::get_stats() const
@@ -1320,32 +1398,35 @@ std::vector<RankedLine> Store::search_line_embeddings(const std::vector<float> &
     // ---- approximate path: whole-workspace search over a large store (see set_index_policy)
     uint64_t ranged = 0;
     for (auto &r : ranges) ranged += r.end - r.begin;
-    if (smt_corpus_rows(corpus_) >= index_min_rows_ && top_k <= 24 && ranged == count_line_embeddings() && ensure_index()) {
+    if (smt_sharded_corpus_rows(corpus_) >= index_min_rows_ && top_k <= 24 && ranged == count_line_embeddings() && ensure_index()) {
         const uint32_t fetch = (uint32_t)std::min<size_t>(56, 2 * top_k + 8);  // head-room for dead rows and the threshold
         const uint32_t rerank = (uint32_t)std::min<size_t>(512, std::max<size_t>(64, 2 * top_k * oversample_factor_));
         std::vector<uint64_t> c_rows(fetch);
         std::vector<double> c_dist(fetch);
         uint64_t c_n = 0;
         uint32_t n_lists = 0;
-        check(smt_ivfpq_info(index_, nullptr, &n_lists, nullptr, nullptr), "search_line_embeddings (index)");
-        check(smt_ivfpq_search(index_, query_vec.data(), 1, fetch, std::min<uint32_t>(std::min<uint32_t>(index_nprobe_, n_lists), 512),
-                               rerank, 0, c_rows.data(), c_dist.data(), &c_n, fetch), "search_line_embeddings (index)");
+        check(smt_sharded_ivfpq_info(index_, nullptr, &n_lists, nullptr), "search_line_embeddings (index)");
+        check(smt_sharded_ivfpq_search(index_, query_vec.data(), 1, fetch, std::min<uint32_t>(std::min<uint32_t>(index_nprobe_, n_lists), 512),
+                                       rerank, c_rows.data(), c_dist.data(), &c_n, fetch), "search_line_embeddings (index)");
         const float thr_score = max_distance ? 1.0f - *max_distance : 0.0f;
+        bool cut_by_threshold = false;
         for (uint64_t i = 0; i < c_n && n < top_k; ++i) {
             auto it = std::upper_bound(segs.begin(), segs.end(), c_rows[i], [](uint64_t r, const Seg &s) { return r < s.first; });
             if (it == segs.begin() || c_rows[i] >= (it - 1)->first + (it - 1)->n) continue;       // a dead row (replaced document)
-            if (max_distance && !((1.0 - c_dist[i]) > (double)thr_score)) continue;               // store.rs:502-503
+            if (max_distance && !((1.0 - c_dist[i]) > (double)thr_score)) { cut_by_threshold = true; break; }   // store.rs:502-503 (sorted: the rest fails too)
             rows[n] = c_rows[i];
             dist[n] = c_dist[i];
             ++n;
         }
-        // fewer than top_k survivors although the index returned a full list: dead rows crowded it -> scan exactly
-        answered = n == top_k || c_n < fetch;
+        // A short list is only an answer when the THRESHOLD cut it (the candidates are sorted by exact distance, so
+        // nothing behind the cut passes either).  Otherwise -- dead rows crowded the list, the probed lists held fewer
+        // than top_k rows -- the exact scan answers.
+        answered = n == top_k || cut_by_threshold;
         if (!answered) n = 0;
     }
     if (!answered)
-        check(smt_search(corpus_, query_vec.data(), 1, k, max_distance ? (double)*max_distance : NAN, SMT_MODE_WORKSPACE,
-                         ranges.data(), (uint32_t)ranges.size(), 0, rows.data(), dist.data(), &n, top_k),
+        check(smt_sharded_search(corpus_, query_vec.data(), 1, k, max_distance ? (double)*max_distance : NAN, SMT_MODE_WORKSPACE,
+                                 ranges.data(), (uint32_t)ranges.size(), rows.data(), dist.data(), &n, top_k),
               "search_line_embeddings");
     for (uint64_t i = 0; i < n; ++i) {
         auto it = std::upper_bound(segs.begin(), segs.end(), rows[i], [](uint64_t r, const Seg &s) { return r < s.first; });
@@ -1423,11 +1504,11 @@ void Store::flush_line_embeddings() const
     // vectors first, then the extent table that references them (a crash in between leaves extra
     // rows that no extent points at -- harmless; the reverse order could reference missing rows)
     const std::string emb = dir_ + "/line_embeddings.f32";
-    const uint64_t rows = smt_corpus_rows(corpus_);
+    const uint64_t rows = smt_sharded_corpus_rows(corpus_);
     if (rows_on_disk_valid_ && rows >= rows_on_disk_ && path_exists(emb)) {
-        if (rows > rows_on_disk_) check(smt_corpus_append_to_file(corpus_, emb.c_str(), rows_on_disk_), "flush_line_embeddings");
+        if (rows > rows_on_disk_) check(smt_sharded_corpus_append_to_file(corpus_, emb.c_str(), rows_on_disk_), "flush_line_embeddings");
     } else {
-        check(smt_corpus_save(corpus_, emb.c_str()), "flush_line_embeddings");  // first flush or after a compaction
+        check(smt_sharded_corpus_save(corpus_, emb.c_str()), "flush_line_embeddings");  // first flush or after a compaction
     }
     rows_on_disk_ = rows;
     rows_on_disk_valid_ = true;
@@ -1441,6 +1522,25 @@ void Store::flush_line_embeddings() const
         arr.arr.push_back(std::move(e));
     }
     root.set("extents", std::move(arr));
+    int n_ranks = 1;
+    (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
+    if (n_ranks > 1) {   // how the rows are dealt over the GPUs: [rows, rank] per piece, in global row order (see Store::open)
+        const uint64_t n_pieces = smt_sharded_corpus_layout(corpus_, nullptr, nullptr, 0);
+        std::vector<uint64_t> piece_rows(n_pieces);
+        std::vector<uint32_t> piece_rank(n_pieces);
+        (void)smt_sharded_corpus_layout(corpus_, piece_rows.data(), piece_rank.data(), n_pieces);
+        json::Value pieces = json::Value::array();
+        for (uint64_t k = 0; k < n_pieces; ++k) {
+            json::Value pc = json::Value::array();
+            pc.arr.push_back(json::Value::uint(piece_rows[k]));
+            pc.arr.push_back(json::Value::uint(piece_rank[k]));
+            pieces.arr.push_back(std::move(pc));
+        }
+        json::Value sh = json::Value::object();
+        sh.set("n_ranks", json::Value::uint((uint64_t)n_ranks));
+        sh.set("pieces", std::move(pieces));
+        root.set("shards", std::move(sh));
+    }
     write_file_atomic(dir_ + "/line_rows.json", json::to_string_pretty(root));
 }
 

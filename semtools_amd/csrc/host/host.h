@@ -4,6 +4,11 @@
 // callers of libsemtools_hip (embeddings never live on the host: a Document
 // records which corpus rows are its lines).
 //
+// Everything here runs on an smt_group -- the GPUs the one calling process owns (src/bin/semtools.rs:134-135 is one
+// synchronous task): the embedding table is replicated per GPU, every matrix of line embeddings is an
+// smt_sharded_corpus whose rows are dealt over the GPUs, searches end in the all-gather + merge of group.cpp.  The
+// default group has ONE rank (smt_group_from_ctx), for which every smt_sharded_* call IS its single-GPU counterpart.
+//
 // The reference is Rust; no Rust toolchain exists here, so this C++ layer is
 // what the CLI replica and the tests drive.  A Rust maintainer would keep the
 // reference's own host code and call the C ABI as INTEGRATION.md shows.
@@ -78,8 +83,8 @@ struct TokenCsr {
 
 class StaticModel {
 public:
-    // table: [V x 256] f32 host array (the `embeddings` tensor), uploaded once.
-    StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize);
+    // table: [V x 256] f32 host array (the `embeddings` tensor), uploaded once (to every GPU of the group).
+    StaticModel(smt_group *group, std::unique_ptr<Tokenizer> tok, const float *table, uint64_t V, bool normalize);
     // the f32 table sits at `byte_offset` of `path` (model.safetensors).  LAZY: nothing is uploaded until an embed call
     // shows what it needs.  A one-shot CLI run (c1: 1000 lines; a warm workspace search: the query alone) touches a few
     // thousand of the 500 k rows: those rows are read from the file (pread, a few MB), uploaded as a compact table
@@ -87,7 +92,7 @@ public:
     // streaming 512 MB through pinned buffers first (0.2-0.3 s, most of the CLI's wall time).  A call with more than
     // 32768 lines, or whose ids cover more than 1/16 of the table, uploads the whole table once (and for good).
     // SEMTOOLS_EAGER_MODEL=1 restores the eager upload.
-    StaticModel(smt_ctx *ctx, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
+    StaticModel(smt_group *group, std::unique_ptr<Tokenizer> tok, const std::string &path, uint64_t byte_offset, uint64_t V,
                 bool normalize);
     ~StaticModel();
     StaticModel(const StaticModel &) = delete;
@@ -98,15 +103,15 @@ public:
     // same, but the rows are appended to `corpus` (resident); returns the first new row
     // (sink, if given, receives the pooled token ids of every sentence in order)
     uint64_t encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
-                         size_t batch_size, smt_corpus *corpus, TokenCsr *sink = nullptr) const;
+                         size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr) const;
     // pool step only: n_lines lines given as token CSR (already filtered / truncated) appended to `corpus`
-    void embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_corpus *corpus) const;
+    void embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_sharded_corpus *corpus) const;
     // identifies the tokenizer (vocab size, unk id, ids of a fixed probe text): cached tokens are only valid for it
     uint64_t tokenizer_fingerprint() const;
     // encode_single(text) = encode(&[text]) -> max_length 512, batch 1024
     std::vector<float> encode_single(const std::string &sentence) const;
 
-    smt_ctx *ctx() const { return ctx_; }
+    smt_group *group() const { return group_; }
     const Tokenizer &tokenizer() const { return *tok_; }
 
 private:
@@ -115,11 +120,11 @@ private:
                         std::vector<uint64_t> &offsets) const;
     // one batch of token CSR -> rows (host buffer and / or appended to a corpus) through the full or a compact table
     void embed_csr(const std::vector<uint32_t> &ids, const std::vector<uint64_t> &offsets, uint64_t n_lines, float *out_host,
-                   smt_corpus *corpus) const;
-    smt_model *full_model() const;   // uploads the whole table on first use (lazy mode)
-    smt_ctx *ctx_;
+                   smt_sharded_corpus *corpus) const;
+    smt_sharded_model *full_model() const;   // uploads the whole table on first use (lazy mode)
+    smt_group *group_;
     std::unique_ptr<Tokenizer> tok_;
-    mutable smt_model *model_ = nullptr;
+    mutable smt_sharded_model *model_ = nullptr;
     // lazy mode (file-backed f32 table not uploaded yet)
     std::string lazy_path_;
     uint64_t lazy_offset_ = 0, lazy_V_ = 0;
@@ -155,14 +160,14 @@ struct SearchResult {  // src/search/mod.rs:40-47
 // The resident embedding matrix that a set of Documents points into.
 class Embeddings {
 public:
-    explicit Embeddings(smt_ctx *ctx);
+    explicit Embeddings(smt_group *group);
     ~Embeddings();
     Embeddings(const Embeddings &) = delete;
-    smt_corpus *corpus() const { return corpus_; }
+    smt_sharded_corpus *corpus() const { return corpus_; }
     uint64_t rows() const;
 
 private:
-    smt_corpus *corpus_ = nullptr;
+    smt_sharded_corpus *corpus_ = nullptr;
 };
 
 // src/search/mod.rs:49-75: None for empty content; original lines kept; lower-cased copy embedded
@@ -195,6 +200,9 @@ struct WorkspaceConfig {  // src/workspace/mod.rs:8-26
     std::string root_dir;
     size_t in_batch_size = 5000;
     size_t oversample_factor = 3;
+    // not in the reference (ignored by it: serde skips unknown keys): opt into the approximate index for whole-workspace
+    // searches over at least this many lines (0 = never; SEMTOOLS_INDEX_MIN_ROWS overrides)
+    uint64_t approximate_index_min_rows = 0;
 };
 
 struct Workspace {  // src/workspace/mod.rs:28-101
@@ -249,10 +257,13 @@ struct WorkspaceStats {  // src/workspace/store.rs:98-103
 // Storage wrapper (src/workspace/store.rs:105-647).  The two Qdrant shards became:
 //   <dir>/documents.json      doc metadata (path, size_bytes, mtime, _version)
 //   <dir>/line_rows.bin       per document: path + (first_row, n_rows)  [lines of a doc are contiguous rows]
-//   <dir>/line_embeddings.f32 the resident corpus matrix (smt_corpus_save format)
+//   <dir>/line_embeddings.f32 the resident corpus matrix (smt_corpus_save format, rows in global order whatever the
+//                             number of GPUs that wrote it)
+// line_rows.json also records how the rows were dealt over the GPUs ("shards"); a store opened by a group of the same
+// size restores that layout (per-shard index files stay valid), any other group re-cuts the matrix evenly.
 class Store {
 public:
-    static std::unique_ptr<Store> open(const std::string &workspace_dir, smt_ctx *ctx);
+    static std::unique_ptr<Store> open(const std::string &workspace_dir, smt_group *group);
     ~Store();
 
     std::unordered_map<std::string, DocMeta> get_existing_docs(const std::vector<std::string> &paths) const;
@@ -291,14 +302,16 @@ public:
         std::vector<std::string> missing;   // documents whose tokens are not cached (re-embed them from their files)
     };
     ReembedReport reembed_from_token_cache(const search::StaticModel &model);
-    // Approximate index policy.  Whole-workspace searches (the path subset covers every stored document) over at
-    // least `min_rows` rows go through an IVF index with per-list PCA codes (smt_ivfpq_*, local_pca = 1) that lives
+    // Approximate index policy -- OPT-IN (min_rows = UINT64_MAX, the default, never uses it: the reference's store always
+    // searches with `exact: true`, src/workspace/store.rs:619,632).  When enabled (SEMTOOLS_INDEX_MIN_ROWS, or
+    // "approximate_index_min_rows" in the workspace's config.json), whole-workspace searches (the path subset covers
+    // every stored document) over at least `min_rows` rows go through an IVF index with per-list PCA codes (local_pca = 1) that lives
     // beside the vectors (`line_index.ivf`), is extended incrementally when rows are appended and rebuilt when rows
     // move (compaction) or the corpus has doubled.  oversample_factor (WorkspaceConfig, src/workspace/mod.rs:13,22 --
     // vestigial in the reference, whose store scans exactly) sets the re-score depth: 2 * top_k * oversample_factor
     // ADC candidates per probed list (at least 64) are re-scored against the full-precision rows.  Every returned
     // distance is exact; only membership is approximate.  Searches over a path subset, top_k > 24, or smaller
-    // stores use the exact scan.
+    // stores use the exact scan, and so does a search to which the index returns fewer than top_k live rows.
     void set_index_policy(size_t oversample_factor, uint64_t min_rows, uint32_t nprobe);
     bool has_index() const { return index_ != nullptr || index_on_disk_; }
 
@@ -306,8 +319,10 @@ private:
     Store() = default;
     struct Extent { uint64_t first_row = 0; uint64_t n_rows = 0; };
     std::string dir_;
-    smt_ctx *ctx_ = nullptr;
-    smt_corpus *corpus_ = nullptr;
+    smt_group *group_ = nullptr;
+    smt_sharded_corpus *corpus_ = nullptr;
+    void drop_index();                           // index_ (points into corpus_) and its files: rows are about to move
+    std::string index_file(int rank) const;
     std::map<std::string, DocMeta> docs_;        // documents shard
     std::map<std::string, Extent> extents_;      // path -> rows holding its lines (line i = first_row + i)
     uint64_t dead_rows_ = 0;                     // rows of deleted/replaced documents awaiting compaction
@@ -315,7 +330,7 @@ private:
     mutable bool rows_on_disk_valid_ = false;
     // approximate index (built / extended lazily by the first search that qualifies)
     bool ensure_index() const;
-    mutable smt_ivfpq *index_ = nullptr;
+    mutable smt_sharded_ivfpq *index_ = nullptr;
     mutable bool index_on_disk_ = false;
     mutable uint64_t index_built_rows_ = 0;      // corpus rows when the quantisers were trained
     size_t oversample_factor_ = 3;
@@ -323,7 +338,7 @@ private:
     void token_log_close() const;
     mutable FILE *token_log_file_ = nullptr;       // open while a series of appends is under way
     mutable uint64_t token_log_fingerprint_ = 0;   // fingerprint in the log's header (0 = not read yet / no log)
-    uint64_t index_min_rows_ = 2'000'000;
+    uint64_t index_min_rows_ = UINT64_MAX;   // opt-in (see set_index_policy)
     uint32_t index_nprobe_ = 16;
 };
 

@@ -13,7 +13,25 @@
 
 using namespace semtools;
 
+// The host layer runs on a group (host.h).  Entry points that take an smt_ctx wrap it in a one-rank group, for which
+// every sharded call is its single-GPU counterpart.
+struct GroupRef {
+    smt_group *g = nullptr;
+    bool owned = false;   // a one-rank group made around the caller's context (the context itself stays the caller's)
+    GroupRef() = default;
+    GroupRef(const GroupRef &) = delete;
+    GroupRef &operator=(const GroupRef &) = delete;
+    ~GroupRef() { if (owned && g) smt_group_destroy(g); }
+    void wrap(smt_ctx *ctx)
+    {
+        if (smt_group_from_ctx(ctx, &g) != SMT_OK) throw semtools::Error(smt_last_error());
+        owned = true;
+    }
+    void use(smt_group *group) { g = group; owned = false; }
+};
+
 struct smt_host_model {
+    GroupRef group;                          // (declared first: destroyed after the model that lives on it)
     std::unique_ptr<search::StaticModel> m;
 };
 
@@ -120,11 +138,11 @@ bool safetensors_f32_span(const std::string &path, uint64_t &V, uint64_t &byte_o
 
 extern "C" {
 
-int smt_host_model_create(smt_ctx *ctx, const float *table, uint64_t V, int normalize, int tok_kind, const char *vocab_path,
-                          const char *unk_token, smt_tokenize_cb cb, void *user, uint32_t unk_id, uint32_t median_len,
-                          smt_host_model **out)
+static int host_model_create(smt_ctx *ctx, smt_group *group, const float *table, uint64_t V, int normalize, int tok_kind,
+                             const char *vocab_path, const char *unk_token, smt_tokenize_cb cb, void *user, uint32_t unk_id,
+                             uint32_t median_len, smt_host_model **out)
 {
-    if (!ctx || !table || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    if ((!ctx && !group) || !table || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out = nullptr;
     try {
         std::unique_ptr<Tokenizer> tok;
@@ -145,11 +163,61 @@ int smt_host_model_create(smt_ctx *ctx, const float *table, uint64_t V, int norm
             tok = make_callback_tokenizer(std::move(fn), V, unk_id == UINT32_MAX ? std::nullopt : std::optional<uint32_t>(unk_id),
                                           median_len ? median_len : 5);
         } else { smt::set_error("unknown tokenizer kind %d", tok_kind); return SMT_E_INVALID; }
-        auto *h = new smt_host_model();
-        h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), table, V, normalize != 0);
-        *out = h;
+        std::unique_ptr<smt_host_model> h(new smt_host_model());
+        if (group) h->group.use(group); else h->group.wrap(ctx);
+        h->m = std::make_unique<search::StaticModel>(h->group.g, std::move(tok), table, V, normalize != 0);
+        *out = h.release();
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
+}
+
+int smt_host_model_create(smt_ctx *ctx, const float *table, uint64_t V, int normalize, int tok_kind, const char *vocab_path,
+                          const char *unk_token, smt_tokenize_cb cb, void *user, uint32_t unk_id, uint32_t median_len,
+                          smt_host_model **out)
+{
+    return host_model_create(ctx, nullptr, table, V, normalize, tok_kind, vocab_path, unk_token, cb, user, unk_id, median_len, out);
+}
+
+int smt_host_model_create_group(smt_group *group, const float *table, uint64_t V, int normalize, int tok_kind, const char *vocab_path,
+                                const char *unk_token, smt_tokenize_cb cb, void *user, uint32_t unk_id, uint32_t median_len,
+                                smt_host_model **out)
+{
+    return host_model_create(nullptr, group, table, V, normalize, tok_kind, vocab_path, unk_token, cb, user, unk_id, median_len, out);
+}
+
+// "0,1,2" = those GPUs (RCCL between them); "all" = every visible GPU; "<d>:<n>" = n logical shards on GPU d (a test rig
+// with one GPU: device copies stand in for RCCL); "<d>" = GPU d alone.
+int smt_host_group_from_spec(const char *spec, smt_group **out)
+{
+    if (!spec || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    *out = nullptr;
+    const std::string s(spec);
+    if (s == "all") {
+        const int n = smt_device_count();
+        if (n <= 0) { if (n == 0) smt::set_error("no HIP device visible: libsemtools_hip has no CPU fallback"); return SMT_E_HIP; }
+        if (n == 1) return smt_group_create_logical(0, 1, out);
+        std::vector<int> devs;
+        for (int i = 0; i < n; ++i) devs.push_back(i);
+        return smt_group_create(devs.data(), n, out);
+    }
+    const size_t colon = s.find(':');
+    char *end = nullptr;
+    if (colon != std::string::npos) {
+        const long dev = strtol(s.c_str(), &end, 10);
+        const long n = strtol(s.c_str() + colon + 1, nullptr, 10);
+        if (end != s.c_str() + colon || dev < 0 || n < 1) { smt::set_error("device spec '%s': expected <device>:<shards>", spec); return SMT_E_INVALID; }
+        return smt_group_create_logical((int)dev, (int)n, out);
+    }
+    std::vector<int> devs;
+    for (const char *p = s.c_str(); *p;) {
+        const long d = strtol(p, &end, 10);
+        if (end == p || d < 0 || (*end && *end != ',')) { smt::set_error("device spec '%s': expected a comma-separated list of GPU ordinals", spec); return SMT_E_INVALID; }
+        devs.push_back((int)d);
+        p = *end ? end + 1 : end;
+    }
+    if (devs.empty()) { smt::set_error("device spec is empty"); return SMT_E_INVALID; }
+    if (devs.size() == 1) return smt_group_create_logical(devs[0], 1, out);   // one GPU: no communicator needed
+    return smt_group_create(devs.data(), (int)devs.size(), out);
 }
 
 char *smt_host_timing_json(void) { return dup_text(search::PhaseTimer::json()); }
@@ -193,9 +261,9 @@ int smt_host_tokenizer_info(smt_host_tokenizer *tok, uint64_t *vocab_size, int64
     return SMT_OK;
 }
 
-int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
+static int host_model_from_dir(smt_ctx *ctx, smt_group *group, const char *dir, smt_host_model **out)
 {
-    if (!ctx || !dir || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    if ((!ctx && !group) || !dir || !out) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out = nullptr;
     try {
         const std::string d(dir);
@@ -222,13 +290,17 @@ int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out)
         }
         if (tok->vocab_size() > V) throw Error("vocab.txt has more tokens than the embedding table has rows");
         search::PhaseTimer::mark("tokenizer_load");
-        auto *h = new smt_host_model();
-        if (stream_f32) h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), d + "/model.safetensors", table_offset, V, normalize);
-        else h->m = std::make_unique<search::StaticModel>(ctx, std::move(tok), table.data(), V, normalize);
-        *out = h;
+        std::unique_ptr<smt_host_model> h(new smt_host_model());
+        if (group) h->group.use(group); else h->group.wrap(ctx);
+        if (stream_f32) h->m = std::make_unique<search::StaticModel>(h->group.g, std::move(tok), d + "/model.safetensors", table_offset, V, normalize);
+        else h->m = std::make_unique<search::StaticModel>(h->group.g, std::move(tok), table.data(), V, normalize);
+        *out = h.release();
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
 }
+
+int smt_host_model_from_dir(smt_ctx *ctx, const char *dir, smt_host_model **out) { return host_model_from_dir(ctx, nullptr, dir, out); }
+int smt_host_model_from_dir_group(smt_group *group, const char *dir, smt_host_model **out) { return host_model_from_dir(nullptr, group, dir, out); }
 
 void smt_host_model_destroy(smt_host_model *model) { delete model; }
 
@@ -265,7 +337,7 @@ int smt_host_search_content(smt_host_model *model, const char *query, const char
     try {
         const auto cfg = make_config(n_lines, top_k, max_distance, ignore_case);
         const std::string q = ignore_case ? to_lowercase(query) : std::string(query);
-        search::Embeddings emb(model->m->ctx());
+        search::Embeddings emb(model->m->group());
         std::vector<search::Document> docs;
         auto doc = search::create_document_from_content(filename ? filename : "<stdin>", content, *model->m, ignore_case != 0, emb);
         if (doc) docs.push_back(std::move(*doc));
@@ -301,7 +373,7 @@ int smt_host_session_open(smt_host_model *model, const char *const *files, uint6
         std::unique_ptr<smt_host_session> s(new smt_host_session());
         s->model = model;
         s->ignore_case = ignore_case != 0;
-        s->emb = std::make_unique<search::Embeddings>(model->m->ctx());
+        s->emb = std::make_unique<search::Embeddings>(model->m->group());
         for (uint64_t i = 0; i < n_files; ++i) {
             const std::string content = read_to_string(files[i]);
             auto doc = search::create_document_from_content(files[i], content, *model->m, s->ignore_case, *s->emb);
@@ -332,11 +404,13 @@ int smt_host_session_search(smt_host_session *s, const char *const *queries, uin
 uint64_t smt_host_session_lines(const smt_host_session *s) { return s ? s->emb->rows() : 0; }
 void smt_host_session_close(smt_host_session *s) { delete s; }
 
-int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json_out, char **out_text)
+static int host_workspace_use(smt_ctx *ctx, smt_group *group, const char *name, int json_out, char **out_text)
 {
     if (!name || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out_text = nullptr;
     try {
+        GroupRef gr;
+        if (group) gr.use(group); else if (ctx) gr.wrap(ctx);
         workspace::Workspace ws;
         ws.config.name = name;
         ws.config.root_dir = workspace::Workspace::root_path(name);
@@ -344,7 +418,7 @@ int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json_out, char **
         std::string out;
         if (json_out) {
             size_t total = 0;
-            if (ctx) { try { total = workspace::Store::open(ws.config.root_dir, ctx)->get_stats().total_documents; } catch (const std::exception &) {} }
+            if (gr.g) { try { total = workspace::Store::open(ws.config.root_dir, gr.g)->get_stats().total_documents; } catch (const std::exception &) {} }
             json::Value o = json::Value::object();  // WorkspaceOutput (src/json_mode.rs:41-46)
             o.set("name", json::Value::str(ws.config.name));
             o.set("root_dir", json::Value::str(ws.config.root_dir));
@@ -360,16 +434,21 @@ int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json_out, char **
     } catch (const std::exception &e) { return fail(e); }
 }
 
-int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json_out, char **out_text)
+int smt_host_workspace_use(smt_ctx *ctx, const char *name, int json_out, char **out_text) { return host_workspace_use(ctx, nullptr, name, json_out, out_text); }
+int smt_host_workspace_use_group(smt_group *group, const char *name, int json_out, char **out_text) { return host_workspace_use(nullptr, group, name, json_out, out_text); }
+
+static int host_workspace_status(smt_ctx *ctx, smt_group *group, const char *name_or_null, int json_out, char **out_text)
 {
-    if (!ctx || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    if ((!ctx && !group) || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out_text = nullptr;
     try {
+        GroupRef gr;
+        if (group) gr.use(group); else gr.wrap(ctx);
         std::optional<std::string> nm;
         if (name_or_null) nm = name_or_null;
         try { workspace::Workspace::active(nm); } catch (const Error &) { throw Error("No active workspace"); }
         const auto ws = workspace::Workspace::open(nm);
-        const auto stats = workspace::Store::open(ws.config.root_dir, ctx)->get_stats();
+        const auto stats = workspace::Store::open(ws.config.root_dir, gr.g)->get_stats();
         std::string out;
         if (json_out) {
             json::Value o = json::Value::object();
@@ -387,6 +466,9 @@ int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json_o
     } catch (const std::exception &e) { return fail(e); }
 }
 
+int smt_host_workspace_status(smt_ctx *ctx, const char *name_or_null, int json_out, char **out_text) { return host_workspace_status(ctx, nullptr, name_or_null, json_out, out_text); }
+int smt_host_workspace_status_group(smt_group *group, const char *name_or_null, int json_out, char **out_text) { return host_workspace_status(nullptr, group, name_or_null, json_out, out_text); }
+
 int smt_host_workspace_reembed(smt_host_model *model, const char *name_or_null, int json_out, char **out_text)
 {
     if (!model || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
@@ -396,7 +478,7 @@ int smt_host_workspace_reembed(smt_host_model *model, const char *name_or_null, 
         if (name_or_null) nm = name_or_null;
         try { workspace::Workspace::active(nm); } catch (const Error &) { throw Error("No active workspace"); }
         const auto ws = workspace::Workspace::open(nm);
-        auto store = workspace::Store::open(ws.config.root_dir, model->m->ctx());
+        auto store = workspace::Store::open(ws.config.root_dir, model->m->group());
         const auto rep = store->reembed_from_token_cache(*model->m);
         std::string out;
         if (json_out) {
@@ -421,16 +503,18 @@ int smt_host_workspace_reembed(smt_host_model *model, const char *name_or_null, 
     } catch (const std::exception &e) { return fail(e); }
 }
 
-int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json_out, char **out_text)
+static int host_workspace_prune(smt_ctx *ctx, smt_group *group, const char *name_or_null, int json_out, char **out_text)
 {
-    if (!ctx || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
+    if ((!ctx && !group) || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out_text = nullptr;
     try {
+        GroupRef gr;
+        if (group) gr.use(group); else gr.wrap(ctx);
         std::optional<std::string> nm;
         if (name_or_null) nm = name_or_null;
         try { workspace::Workspace::active(nm); } catch (const Error &) { throw Error("No active workspace"); }
         const auto ws = workspace::Workspace::open(nm);
-        auto store = workspace::Store::open(ws.config.root_dir, ctx);
+        auto store = workspace::Store::open(ws.config.root_dir, gr.g);
         const auto all_paths = store->get_all_document_paths();
         std::vector<std::string> missing;
         for (auto &p : all_paths) if (access(p.c_str(), F_OK) != 0) missing.push_back(p);  // Path::exists()
@@ -453,6 +537,9 @@ int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json_ou
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
 }
+
+int smt_host_workspace_prune(smt_ctx *ctx, const char *name_or_null, int json_out, char **out_text) { return host_workspace_prune(ctx, nullptr, name_or_null, json_out, out_text); }
+int smt_host_workspace_prune_group(smt_group *group, const char *name_or_null, int json_out, char **out_text) { return host_workspace_prune(nullptr, group, name_or_null, json_out, out_text); }
 
 void smt_host_free(char *text) { free(text); }
 

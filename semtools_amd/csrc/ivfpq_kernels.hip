@@ -1077,29 +1077,35 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
     ix->n_rows = N;
     ix->nlist = nlist;
     ix->kind = lpca ? 1u : 0u;
-    if (lpca) {
-        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_basis), (size_t)nlist * LP_DIMS * 256 * 4));
-        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_lscale), (size_t)nlist * LP_DIMS * 4));
-    }
-    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_centroids), (size_t)nlist * 256 * 4));
-    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_cnorm_half), (size_t)nlist * 4));
-    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codebooks), (size_t)PQ_M * PQ_K * PQ_DSUB * 4));
-    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codes), (size_t)N * PQ_M));
-    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_ids), (size_t)N * 4));
-    IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_offsets), (size_t)(nlist + 1) * 8));
-
-    hipEvent_t ev[5];
-    for (auto &e : ev) IVF_HIP(hipEventCreate(&e));
+    // ---- set-up: every allocation of the coarse stage.  In a shared build the ranks then AGREE on its outcome, so that a
+    // rank that ran out of memory takes the others with it instead of leaving them inside the first all-reduce.
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf b_assign, b_sums, b_counts;
+    int rc = [&]() -> int {
+        if (lpca) {
+            IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_basis), (size_t)nlist * LP_DIMS * 256 * 4));
+            IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_lscale), (size_t)nlist * LP_DIMS * 4));
+        }
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_centroids), (size_t)nlist * 256 * 4));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_cnorm_half), (size_t)nlist * 4));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codebooks), (size_t)PQ_M * PQ_K * PQ_DSUB * 4));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_codes), (size_t)N * PQ_M));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_ids), (size_t)N * 4));
+        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_offsets), (size_t)(nlist + 1) * 8));
+        for (auto &e : ev) IVF_HIP(hipEventCreate(&e));
+        int rc2;
+        if ((rc2 = dev_alloc(b_assign, (size_t)std::max(S, N) * 4))) return rc2;
+        if ((rc2 = dev_alloc(b_sums, (size_t)std::max<uint64_t>((uint64_t)nlist * 256, (uint64_t)PQ_M * PQ_K * PQ_DSUB) * 8))) return rc2;
+        if ((rc2 = dev_alloc(b_counts, (size_t)std::max<uint64_t>(nlist, (uint64_t)PQ_M * PQ_K) * 4))) return rc2;
+        return SMT_OK;
+    }();
+    if (share && share->agree) rc = share->agree(share->user, rc);
+    if (rc) return rc;
     IVF_HIP(hipEventRecord(ev[0], ctx->stream));
 
     // ---- coarse k-means on the sample.  init: nlist evenly spaced sample points
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nlist * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows,
                        (uint64_t)nlist, stride * (S / nlist), ix->d_centroids);
-    DevBuf b_assign, b_sums, b_counts;
-    int rc;
-    if ((rc = dev_alloc(b_assign, (size_t)std::max(S, N) * 4))) return rc;
-    if ((rc = dev_alloc(b_sums, (size_t)std::max<uint64_t>((uint64_t)nlist * 256, (uint64_t)PQ_M * PQ_K * PQ_DSUB) * 8))) return rc;
-    if ((rc = dev_alloc(b_counts, (size_t)std::max<uint64_t>(nlist, (uint64_t)PQ_M * PQ_K) * 4))) return rc;
     if (share) {  // the same starting centroids on every rank: each rank seeds the lists it owns (l % n_ranks == rank)
         hipLaunchKernelGGL(ivf_seed_sums_kernel, dim3((nlist * 256 + 255) / 256), dim3(256), 0, ctx->stream, ix->d_centroids, nlist,
                            share->rank, share->n_ranks, b_sums.as<long long>(), b_counts.as<unsigned int>());

@@ -31,12 +31,16 @@ class StaticModel:
     Python callable text -> list of ids (e.g. tokenizers.Tokenizer(...).encode(t, add_special_tokens=False).ids)."""
 
     def __init__(self, ctx, table=None, tokenizer="hash", normalize=True, unk_id=None, median_len=5, model_dir=None):
+        """ctx: a core.Context (one GPU) or a core.Group (the host layer then runs sharded over its GPUs)."""
+        from .core import Group
         self.ctx = ctx
+        on_group = isinstance(ctx, Group)
         self._h = C.c_void_p()
         self._cb = L.TOKENIZE_CB()
         lib = L.lib()
         if model_dir is not None:
-            L.check(lib.smt_host_model_from_dir(ctx._h, str(model_dir).encode(), C.byref(self._h)))
+            fn = lib.smt_host_model_from_dir_group if on_group else lib.smt_host_model_from_dir
+            L.check(fn(ctx._h, str(model_dir).encode(), C.byref(self._h)))
             return
         table = np.ascontiguousarray(table, dtype=np.float32)
         kind, vocab, unk = 0, None, None
@@ -56,9 +60,9 @@ class StaticModel:
                     return 1
 
             self._cb = L.TOKENIZE_CB(_cb)
-        L.check(lib.smt_host_model_create(ctx._h, L.np_ptr(table), table.shape[0], int(normalize), kind, vocab, unk,
-                                          self._cb, None, 0xFFFFFFFF if unk_id is None else int(unk_id),
-                                          int(median_len), C.byref(self._h)))
+        fn = lib.smt_host_model_create_group if on_group else lib.smt_host_model_create
+        L.check(fn(ctx._h, L.np_ptr(table), table.shape[0], int(normalize), kind, vocab, unk,
+                   self._cb, None, 0xFFFFFFFF if unk_id is None else int(unk_id), int(median_len), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -138,21 +142,27 @@ class Session:
             pass
 
 
+def _ws_fn(ctx, name):
+    """ctx may be a core.Context or a core.Group: the *_group twin of the entry point for the latter."""
+    from .core import Group
+    return getattr(L.lib(), name + "_group" if isinstance(ctx, Group) else name)
+
+
 def workspace_use(ctx, name, json=False):
     out = C.c_void_p()
-    L.check(L.lib().smt_host_workspace_use(ctx._h if ctx is not None else None, name.encode(), int(json), C.byref(out)))
+    L.check(_ws_fn(ctx, "smt_host_workspace_use")(ctx._h if ctx is not None else None, name.encode(), int(json), C.byref(out)))
     return _take_text(out)
 
 
 def workspace_status(ctx, name=None, json=False):
     out = C.c_void_p()
-    L.check(L.lib().smt_host_workspace_status(ctx._h, name.encode() if name else None, int(json), C.byref(out)))
+    L.check(_ws_fn(ctx, "smt_host_workspace_status")(ctx._h, name.encode() if name else None, int(json), C.byref(out)))
     return _take_text(out)
 
 
 def workspace_prune(ctx, name=None, json=False):
     out = C.c_void_p()
-    L.check(L.lib().smt_host_workspace_prune(ctx._h, name.encode() if name else None, int(json), C.byref(out)))
+    L.check(_ws_fn(ctx, "smt_host_workspace_prune")(ctx._h, name.encode() if name else None, int(json), C.byref(out)))
     return _take_text(out)
 
 

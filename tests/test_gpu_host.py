@@ -31,13 +31,24 @@ def model_dir(tmp_path_factory):
     return d, table
 
 
-@pytest.fixture(scope="module")
-def model(gpu_ctx, model_dir):
+@pytest.fixture(scope="module", params=["one_gpu", "three_shards"])
+def model(request, gpu_ctx, model_dir):
+    """The host layer on one GPU, and on a group of three shards (VERDICT r2 row e': table replicated, lines and rows
+    dealt over the shards, searches merged after one all-gather).  Every test that takes `model` runs both ways and
+    compares with the SAME expected bytes, so sharded output == single-GPU output == the reference's format."""
+    import semtools_amd as smt
     from semtools_amd import host
 
-    m = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
+    group = None
+    if request.param == "three_shards":
+        group = smt.Group.logical(0, 3)       # (a 1-GPU box: device copies stand in for RCCL between the three ranks)
+    m = host.StaticModel(group if group is not None else gpu_ctx, model_dir=model_dir[0])
+    m.n_shards = 3 if group is not None else 1
+    m.devices_env = {"SEMTOOLS_DEVICES": "0:3"} if group is not None else {}
     yield m
     m.close()
+    if group is not None:
+        group.close()
 
 
 def tok(text):
@@ -94,10 +105,16 @@ def test_c1_search_one_query_over_1k_lines_text_and_json(model, model_dir, prose
     assert host.search_files(model, query, [docs[0][0]], is_tty=True) == refimpl.print_search_results(want, is_tty=True)
 
 
-def test_cli_binary_matches_reference_format(model_dir, prose_files):
+@pytest.mark.parametrize("devices", [None, "0:3", "0"])
+def test_cli_binary_matches_reference_format(model_dir, prose_files, devices):
+    """`semtools search` on one GPU (default), on three shards ($SEMTOOLS_DEVICES: table replicated, lines dealt over the
+    shards, one all-gather per search) and on an explicit one-GPU list: the same bytes."""
     table = model_dir[1]
     env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]))
     env.pop("SEMTOOLS_WORKSPACE", None)
+    env.pop("SEMTOOLS_DEVICES", None)
+    if devices:
+        env["SEMTOOLS_DEVICES"] = devices
     files = [p for p, _ in prose_files]
     query = prose_files[1][1][5]
     want = expected_results(table, prose_files, query, 2, 4)
@@ -125,6 +142,45 @@ def test_cli_binary_matches_reference_format(model_dir, prose_files):
     r = subprocess.run([CLI, "search", query, files[0], "/nonexistent/file.txt"], capture_output=True, text=True, env=env,
                        stdin=subprocess.DEVNULL)
     assert r.returncode == 1 and r.stdout == ""
+    # a malformed device list is an error, not a silent single GPU
+    r = subprocess.run([CLI, "search", query, files[0]], capture_output=True, text=True, env=dict(env, SEMTOOLS_DEVICES="0;1"),
+                       stdin=subprocess.DEVNULL)
+    assert r.returncode == 1 and "device spec" in r.stderr
+
+
+def test_cli_workspace_is_interchangeable_between_one_gpu_and_three_shards(model_dir, prose_files, tmp_path):
+    """A workspace filled by a 3-shard run is searched by a 1-GPU run and extended by it, then searched by 3 shards again
+    (the vector file holds global row order; line_rows.json records how 3 shards dealt the rows and a group of another size
+    re-cuts them): every run prints the same bytes."""
+    env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]), HOME=str(tmp_path))
+    env.pop("SEMTOOLS_WORKSPACE", None)
+    env.pop("SEMTOOLS_DEVICES", None)
+    three = dict(env, SEMTOOLS_DEVICES="0:3")
+    files = [p for p, _ in prose_files]
+    query = prose_files[0][1][250]
+
+    def run(e, fs, *extra):
+        r = subprocess.run([CLI, "search", query, *fs, "-w", "mix", "-n", "1", "--top-k", "5", *extra], capture_output=True, text=True,
+                           env=e, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0, r.stderr
+        return r.stdout, r.stderr
+
+    assert subprocess.run([CLI, "workspace", "use", "mix"], env=env, capture_output=True).returncode == 0
+    first, err = run(three, files[:1])
+    assert "Updating workspace with 1000 lines" in err
+    rows = json.loads((tmp_path / ".semtools/workspaces/mix/line_rows.json").read_text())
+    assert rows["shards"]["n_ranks"] == 3 and sum(p[0] for p in rows["shards"]["pieces"]) == 1000
+    again, err = run(env, files[:1])                                    # one GPU reads what three wrote
+    assert again == first and "Updating" not in err
+    both, err = run(env, files)                                         # ... and appends a document
+    assert "Updating workspace with 37 lines" in err
+    both3, err = run(three, files)                                      # three shards read what one wrote
+    assert both3 == both and "Updating" not in err
+    js1, _ = run(env, files, "--json")
+    js3, _ = run(three, files, "--json")
+    assert js1 == js3 and json.loads(js1)["results"][0]["match_line_number"] == 250
+    st = subprocess.run([CLI, "workspace", "status", "mix"], env=three, capture_output=True, text=True)
+    assert st.returncode == 0 and "Documents: 2" in st.stdout
 
 
 def test_context_window_clamps_at_file_boundaries(model, model_dir, tmp_path):
@@ -454,19 +510,20 @@ def test_workspace_index_lifecycle(model, tmp_path, monkeypatch, capfd):
     root = tmp_path / ".semtools" / "workspaces" / "big"
     monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "1000000000")                 # exact scan: the truth
     exact = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
-    assert not (root / "line_index.ivf").exists()
+    n = model.n_shards
+    parts = [root / ("line_index.ivf" if n == 1 else f"line_index.ivf.r{r}of{n}") for r in range(n)]
+    assert not any(p.exists() for p in parts)
     assert "Index: No" in host.workspace_status(model.ctx, "big")
     monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "4000")
     monkeypatch.setenv("SEMTOOLS_INDEX_NPROBE", "512")
     capfd.readouterr()
     got = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
     assert got == exact
-    ivf = root / "line_index.ivf"
-    assert ivf.exists() and not (root / "line_index.ivf.tmp").exists()
+    assert all(p.exists() for p in parts) and not list(root.glob("line_index.ivf*.tmp"))
     assert "Index: Yes (IVF_PQ)" in host.workspace_status(model.ctx, "big")
-    stamp = ivf.stat().st_mtime_ns
+    stamp = [p.stat().st_mtime_ns for p in parts]
     assert host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5) == exact
-    assert ivf.stat().st_mtime_ns == stamp                                       # reloaded, not rebuilt
+    assert [p.stat().st_mtime_ns for p in parts] == stamp                        # reloaded, not rebuilt
     # a path subset is answered by the exact range-filtered scan
     sub = host.search_with_workspace(model, query, files[:2], workspace_name="big", n_lines=0, top_k=5)
     monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "1000000000")
@@ -477,10 +534,10 @@ def test_workspace_index_lifecycle(model, tmp_path, monkeypatch, capfd):
     files.append(str(f))
     exact7 = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
     monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "4000")
-    size_before = ivf.stat().st_size
+    size_before = sum(p.stat().st_size for p in parts)
     got7 = host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
     assert got7 == exact7
-    assert ivf.stat().st_size == size_before + 800 * 36                         # 32 B code + 4 B row id per new row
+    assert sum(p.stat().st_size for p in parts) == size_before + 800 * 36       # 32 B code + 4 B row id per new row
     # an edited file leaves dead rows behind: they never surface
     (tmp_path / "big0.txt").write_text("\n".join(synth.pseudo_prose(900, vocab_size=V - 1, seed=100)) + "\n")
     os.utime(tmp_path / "big0.txt", (1_950_000_000, 1_950_000_000))
@@ -507,7 +564,7 @@ def test_resident_session_and_serve_mode(model, model_dir, prose_files):
     js = s.search(queries[:9], n_lines=1, top_k=2, json=True)
     assert js[4] == host.search_files(model, queries[4], files, n_lines=1, top_k=2, json=True)
     s.close()
-    env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]))
+    env = dict(os.environ, SEMTOOLS_MODEL_DIR=str(model_dir[0]), **model.devices_env)
     r = subprocess.run([CLI, "serve", *files, "-n", "2", "--top-k", "4", "--batch", "16"], input="\n".join(queries) + "\n",
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr

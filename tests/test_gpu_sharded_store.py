@@ -1,0 +1,198 @@
+"""GPU: what the host layer needs from a group of GPUs (csrc/sharded.cpp; VERDICT r2 row e') -- a corpus that GROWS while
+staying balanced over the shards (appends are dealt over the ranks, the global row numbering is insertion order), the
+embedding table replicated per device with K1 sharded by line, the single-GPU file format written and read by any number
+of shards, and the per-shard index life cycle.  Contract everywhere: what a group of N shards returns == what one GPU
+returns on the same inputs (which the other GPU tests pin to the oracle), rows and f64 distances bit for bit.
+
+Runs on a 1-GPU box through logical groups (N ranks on one device, device copies in place of RCCL) and the one-rank
+pass-through group (smt_group_from_ctx)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+V = 3000
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for (gr, gd), (wr, wd) in zip(got, want):
+        assert gr.tolist() == wr.tolist()
+        assert np.array_equal(gd, wd)
+
+
+@pytest.fixture(scope="module")
+def table():
+    return synth.table(V, seed=2)
+
+
+def _lines(n, seed, min_tok=0, max_tok=24):
+    return synth.token_lines(n, V=V, seed=seed, min_tok=min_tok, max_tok=max_tok)
+
+
+CASES = [
+    dict(top_k=7),
+    dict(top_k=56),
+    dict(top_k=7, max_distance=0.93),                                   # A6: all rows under the threshold
+    dict(top_k=4, max_distance=0.95, mode=1),                           # A10: score threshold, then top-k
+    dict(top_k=100),                                                    # all-keys path per shard
+    dict(top_k=5, ranges=[(10, 50), (2999, 3001), (4000, 5200)]),       # path subsets crossing pieces and shards
+    dict(top_k=3, ranges=[(5290, 5300)]),
+    dict(top_k=9, max_distance=0.9, ranges=[(100, 4100)]),
+]
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 5])
+def test_sharded_embed_and_search_on_a_corpus_that_grows(gpu_ctx, table, n_shards):
+    """Five embed calls of very different sizes into an empty sharded corpus: every row is the oracle's bit for bit, global
+    rows are line order, the shards stay balanced, and every search mode answers exactly like one GPU."""
+    import semtools_amd as smt
+
+    g = smt.Group.from_ctx(gpu_ctx) if n_shards == 1 else smt.Group.logical(0, n_shards)
+    model = smt.ShardedModel(g, table)
+    sc = smt.ShardedCorpus(g, empty=True)
+    plain_model = smt.Model(gpu_ctx, table)
+    plain = smt.Corpus(gpu_ctx)
+    all_rows = []
+    for call, n in enumerate([2500, 7, 1800, 1, 992]):                  # 5300 rows; 7 and 1 go to ONE (the emptiest) shard
+        ids, offsets = _lines(n, seed=10 + call)
+        emb, first = model.embed(ids, offsets, append_to=sc)
+        assert first == sum(len(r) for r in all_rows)
+        assert np.array_equal(emb, orc.embed_lines(table, ids, offsets, True, 2048)), call     # bit-exact, whatever the split
+        plain_model.embed(ids, offsets, append_to=plain, want_host=False)
+        all_rows.append(emb)
+    emb = np.concatenate(all_rows)
+    assert sc.rows == plain.rows == 5300
+    rr = sc.rank_rows()
+    assert int(rr.sum()) == 5300 and int(rr.max()) - int(rr.min()) <= 8, rr          # dealt: the shards stay level
+    layout = sc.layout()
+    assert sum(n for n, _ in layout) == 5300 and all(0 <= r < n_shards for _, r in layout)
+    if n_shards > 1:
+        assert len(layout) > n_shards                                    # several pieces per shard: not one range per rank
+    assert np.array_equal(sc.read_rows(0, 5300), emb)                    # global row == line order
+    assert np.array_equal(sc.read_rows(2490, 30), emb[2490:2520])        # (a window crossing calls and pieces)
+    # query embeds (no corpus): few lines -> rank 0 alone; many lines -> equal blocks over the ranks
+    ids, offsets = _lines(3000, seed=99)
+    qe, _ = model.embed(ids, offsets, max_tokens=512)
+    assert np.array_equal(qe, orc.embed_lines(table, ids, offsets, True, 512))
+    qs = np.concatenate([emb[[17, 2503, 4400]], synth.unit_query(4, nq=1)])
+    for kw in CASES:
+        _same(sc.search(qs, **kw), plain.search(qs, **kw))
+    qb = np.concatenate([emb[100:108], synth.unit_query(5, nq=4)])       # >= 8 queries: the MFMA path inside every shard
+    _same(sc.search(qb, top_k=10), plain.search(qb, top_k=10))
+    # in-place replacement by global position (Store::upsert_line_embeddings' host form)
+    new = synth.unit_rows(40, seed=8)
+    sc.write_rows(2480, new)
+    plain.write_rows(2480, new)
+    assert np.array_equal(sc.read_rows(2470, 60), plain.read_rows(2470, 60))
+    _same(sc.search(new[:2], top_k=3), plain.search(new[:2], top_k=3))
+    for x in (sc, model, plain, plain_model, g):
+        x.close()
+
+
+def test_ties_across_pieces_come_back_in_insertion_order(gpu_ctx):
+    """The reference's stable sort keeps equal distances in (document, line) order (src/search/mod.rs:107-111).  Duplicate
+    rows spread over every shard and piece must come back by GLOBAL row, not by shard."""
+    import semtools_amd as smt
+
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, empty=True)
+    base = synth.unit_rows(900, seed=21)
+    dup = base[5].copy()
+    want_rows = []
+    total = 0
+    for n in (300, 250, 200, 150):                                       # four appends -> up to 12 pieces
+        rows = base[total:total + n].copy()
+        rows[[3, n // 2, n - 1]] = dup
+        want_rows += [total + 3, total + n // 2, total + n - 1]
+        sc.append(rows)
+        total += n
+    (got_rows, got_dist), = sc.search(dup, top_k=12)
+    assert got_rows.tolist() == sorted(want_rows) and np.all(got_dist == got_dist[0])
+    (thr_rows, _), = sc.search(dup, top_k=0, max_distance=1e-6)           # threshold mode: host-list exchange
+    assert thr_rows.tolist() == sorted(want_rows)
+    sc.close()
+    g.close()
+
+
+def test_file_written_by_n_shards_reads_on_m(gpu_ctx, table, tmp_path):
+    """line_embeddings.f32 holds the rows in global order whatever wrote it: 3 shards write (save, then an incremental
+    append_to_file), 1 / 2 / 3 shards read -- evenly re-cut, or with the recorded layout restored piece for piece."""
+    import semtools_amd as smt
+
+    g3 = smt.Group.logical(0, 3)
+    model = smt.ShardedModel(g3, table)
+    sc = smt.ShardedCorpus(g3, empty=True)
+    ids, offsets = _lines(2000, seed=31)
+    e1, _ = model.embed(ids, offsets, append_to=sc)
+    path = tmp_path / "rows.f32"
+    sc.save(path)
+    ids2, offsets2 = _lines(777, seed=32)
+    e2, first = model.embed(ids2, offsets2, append_to=sc)
+    assert first == 2000
+    sc.append_to_file(path, 2000)                                        # only the new pieces travel
+    emb = np.concatenate([e1, e2])
+    layout = sc.layout()
+    one = smt.Corpus.load(gpu_ctx, str(path))
+    assert one.rows == 2777 and np.array_equal(one.read_rows(0, 2777), emb)
+    q = np.concatenate([emb[[5, 2100]], synth.unit_query(7, nq=1)])
+    want = one.search(q, top_k=9)
+    for n in (2, 3):
+        g = smt.Group.logical(0, n)
+        even = smt.ShardedCorpus.load(g, path)
+        assert even.rank_rows().tolist() == [min(-(-2777 // n), 2777 - r * -(-2777 // n)) for r in range(n)]
+        assert np.array_equal(even.read_rows(0, 2777), emb)
+        _same(even.search(q, top_k=9), want)
+        even.close()
+        g.close()
+    back = smt.ShardedCorpus(g3, path=path, layout=layout)               # what Store::open does with line_rows.json's "shards"
+    assert back.layout() == layout and back.rank_rows().tolist() == sc.rank_rows().tolist()
+    for i in range(3):                                                   # shard for shard the same local rows
+        a, _, n = sc.shard(i, want_base=False)
+        b, _, m = back.shard(i, want_base=False)
+        assert n == m and np.array_equal(a.read_rows(0, n), b.read_rows(0, m))
+    _same(back.search(q, top_k=9), want)
+    with pytest.raises(Exception, match="layout describes"):
+        smt.ShardedCorpus(g3, path=path, layout=layout[:-1])
+    for x in (back, one, sc, model, g3):
+        x.close()
+
+
+def test_sharded_index_life_cycle_on_a_dealt_corpus(gpu_ctx, tmp_path):
+    """Build (shared centroids) -> save -> load on the restored layout -> append: with every list probed and more re-scored
+    rows than a list holds, the sharded index answers exactly like the exact sharded scan; per-shard files are named
+    <path>.r<rank>of<n>."""
+    import semtools_amd as smt
+
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, empty=True)
+    rows = synth.unit_rows(9000, seed=41)
+    sc.append(rows[:5000])
+    sc.append(rows[5000:9000])
+    q = np.concatenate([rows[[11, 6000]], synth.unit_query(9, nq=2)])
+    want = sc.search(q, top_k=8)
+    ix = smt.ShardedIvfPq(sc, nlist=32, shared_centroids=True)
+    _same(ix.search(q, top_k=8, nprobe=32, rerank=512), want)
+    assert ix.info()["rows"] == 9000
+    path = tmp_path / "line_index.ivf"
+    ix.save(path)
+    assert sorted(p.name for p in tmp_path.iterdir()) == [f"line_index.ivf.r{r}of3" for r in range(3)]
+    ix.close()
+    corpus_file = tmp_path / "rows.f32"
+    sc.save(corpus_file)
+    layout = sc.layout()
+    sc.close()
+    sc = smt.ShardedCorpus(g, path=corpus_file, layout=layout)          # "the next process"
+    ix = smt.ShardedIvfPq.load(sc, path)
+    _same(ix.search(q, top_k=8, nprobe=32, rerank=512), want)
+    more = synth.unit_rows(1500, seed=42)
+    sc.append(more)
+    assert ix.append() == 1500 and ix.info()["rows"] == 10500
+    q2 = np.concatenate([q, more[[3, 1400]]])
+    _same(ix.search(q2, top_k=8, nprobe=32, rerank=512), sc.search(q2, top_k=8))
+    ix.close()
+    sc.close()
+    g.close()

@@ -22,7 +22,7 @@ PRELUDE = '''//! FFI declarations for libsemtools_hip.so -- GENERATED from inclu
 use std::os::raw::{c_char, c_int, c_void};
 
 macro_rules! opaque { ($($name:ident),*) => { $( #[repr(C)] pub struct $name { _private: [u8; 0] } )* } }
-opaque!(SmtCtx, SmtModel, SmtCorpus, SmtIvfpq, SmtGroup, SmtShardedCorpus, SmtShardedIvfpq);
+opaque!(SmtCtx, SmtModel, SmtCorpus, SmtIvfpq, SmtGroup, SmtShardedCorpus, SmtShardedIvfpq, SmtShardedModel);
 
 /// half-open range of corpus rows [begin, end)
 #[repr(C)]
