@@ -212,6 +212,104 @@ def test_nominating_distance_error_is_inside_the_certificate_bound(gpu_ctx, nomi
     c.close()
 
 
+def _bf16_rne(x):
+    """f32 -> bf16 (round to nearest even) -> f32, as v_cvt_pk_bf16_f32 does"""
+    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    b = (b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000
+    return b.astype(np.uint32).view(np.float32)
+
+
+def _worst_case_rows_f16x2(rng, n_rows):
+    """Unit rows whose elements x 2^10 sit EXACTLY on fp16 rounding midpoints, in two binades so that the row has unit norm
+    to within 2^-14: the kernel's normalisation then shifts every element off its midpoint in the SAME direction and all
+    256 roundings go the same way.  With a query of matching signs the rounding errors add up instead of cancelling:
+    |error| = sum |delta_i q_i| -- the situation F32_ERR_F16X2 = 2^-11 (+ accumulation) is the bound for."""
+    rows = np.zeros((n_rows, 256), dtype=np.float64)
+    for r in range(n_rows):
+        i = int(rng.integers(0, 4))
+        j = 3 * (2 * i + 1) + (0 if r % 2 else -1)          # (2j + 1) = 6 (2i + 1) -+ 1: the norm is off by 2^-14 only
+        a = 2.0 ** -3 * (1 + (2 * i + 1) * 2.0 ** -11)       # 48 elements just above 2^-3: midpoint of the fp16 grid after x 2^10
+        b = 2.0 ** -4 * (1 - (2 * j + 1) * 2.0 ** -12)       # 64 elements just below 2^-4
+        pos = rng.permutation(256)
+        sign = rng.choice([-1.0, 1.0], size=256)
+        rows[r, pos[:48]] = a * sign[pos[:48]]
+        rows[r, pos[48:112]] = b * sign[pos[48:112]]
+    return rows
+
+
+def _worst_case_rows_bf16x3(rng, n_rows):
+    """Unit rows (to within f32 rounding: one free element absorbs the rest of the norm) whose elements carry the bit
+    pattern that maximises what bf16 x 3 drops: x = hi + lo + r with lo ~ 2^-8 |x| (the residual just below half a bf16
+    ulp, so hi rounds DOWN) and r = 0.75 * 2^-17 |x| of the same sign (lo rounds down too).  With q = x the dropped terms
+    lo.lo + 2 r.x are all positive: error ~ 2^-15 |x||q| = 3.1e-5, the worst this scheme can do -- against a bound of 1.5e-4."""
+    rows = np.zeros((n_rows, 256), dtype=np.float64)
+    frac = 2.0 ** -8 - 2.0 ** -16 + 0.75 * 2.0 ** -17       # bits below the 7 fraction bits of hi
+    for r in range(n_rows):
+        while True:
+            n = 62
+            t = rng.integers(0, 3, size=n)                   # the top 7 fraction bits are free: they tune the norm
+            mags = 2.0 ** -3 * (1 + t * 2.0 ** -7 + frac)
+            rest = 1.0 - float((mags ** 2).sum())
+            if 2.0 ** -8 < rest < 2.0 ** -5:
+                break
+        pos = rng.permutation(256)
+        sign = rng.choice([-1.0, 1.0], size=256)
+        rows[r, pos[:n]] = mags * sign[pos[:n]]
+        rows[r, pos[n]] = np.sqrt(rest) * sign[pos[n]]       # the free element
+    return rows
+
+
+def test_constructed_worst_case_rows_stay_inside_the_certificate_bound(gpu_ctx, nominate_with):
+    """the certificate's bounds were only ever checked on random corpora.  Here the rows are BUILT to make
+    every rounding of the nominating arithmetic err in the same direction (see the two generators), at unit norm and scaled
+    by powers of two and by 3.7 / 1e-3 (non-unit norms: the kernels normalise), and the queries are the rows themselves and
+    sign-matched vectors of other magnitudes.  Asserted: |nominating - exact| <= the compiled-in bound in every mode, the
+    construction really is adversarial in the mode it targets (several times the random-corpus maximum), and searches over
+    these rows still return exactly the oracle's answer."""
+    import semtools_amd as smt
+
+    rng = np.random.default_rng(2024)
+    f16x2 = getattr(gpu_ctx, "_f16x2_mode", False)
+    bound = 6e-4 if f16x2 else 1.5e-4 if nominate_with else 2e-5
+    base16 = _worst_case_rows_f16x2(rng, 256)
+    base_bf = _worst_case_rows_bf16x3(rng, 256)
+    scales = np.array([1.0, 2.0 ** 5, 2.0 ** -7, 3.7, 1e-3])
+    rows64 = np.concatenate([base16 * s for s in scales] + [base_bf * s for s in scales])
+    emb = np.ascontiguousarray(rows64.astype(np.float32))
+    # queries: 8 adversarial rows of each kind (cos = 1 with their own row), 8 sign-matched vectors per kind (cos ~ 0.95)
+    qs = [base16[:8], base_bf[:8]]
+    for base in (base16, base_bf):
+        mag = np.where(base[8:16] != 0, 0.5 + rng.random((8, 256)), 0.0)
+        qs.append(np.sign(base[8:16]) * mag / 16.0)
+    qs = np.ascontiguousarray(np.concatenate(qs).astype(np.float32))
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    got = c.debug_batched_scores(qs).astype(np.float64)                   # [rows, 32]
+    e64, q64 = emb.astype(np.float64), qs.astype(np.float64)
+    cos = (e64 @ q64.T) / (np.linalg.norm(e64, axis=1)[:, None] * np.linalg.norm(q64, axis=1)[None, :])
+    exact = np.maximum(1.0 - cos, 0.0)
+    err = np.abs(got - exact)
+    # the pairs the construction aims at: row i of a power-of-two-scaled block against "its" query
+    n = 256
+    own16 = max(err[blk * n + i, i] for blk in range(3) for i in range(8))                 # f16 rows x their own rows as queries
+    own_bf = max(err[(5 + blk) * n + i, 8 + i] for blk in range(3) for i in range(8))
+    matched16 = max(err[blk * n + 8 + i, 16 + i] for blk in range(3) for i in range(8))
+    print(f"max |nominating - exact| = {err.max():.3e} (bound {bound:.1e}); f16-midpoint rows vs own query {own16:.3e}, "
+          f"vs sign-matched query {matched16:.3e}; bf16-residual rows vs own query {own_bf:.3e}")
+    assert err.max() <= bound, (err.max(), bound)
+    if f16x2:
+        assert own16 > 3.0e-4 and matched16 > 2.0e-4          # ~ 0.85 * 2^-11: adversarial indeed (random corpora: 2.3e-4 at most)
+    elif nominate_with:
+        assert own_bf > 2.0e-5                                 # ~ 2^-15 (random corpora: 1.0e-5 at most)
+    # ... and the answers over these rows are still exact: indices and f64 distances of the oracle
+    got_search = c.search(qs[[0, 9, 17, 25]], top_k=12)
+    for (r, d), qi in zip(got_search, (0, 9, 17, 25)):
+        orows, odist = _oracle_topk(emb, qs[qi], 12)
+        assert r.tolist() == orows
+        np.testing.assert_allclose(d, odist, rtol=0, atol=1e-12)
+    c.close()
+
+
 @pytest.mark.parametrize("nq", [2, 3, 5, 7])
 def test_two_to_seven_queries_take_the_batched_path_on_large_shards(gpu_ctx, nq, nominate_with):
     """A K2 pass slows down with every query it carries; with the row-register kernel one K3 pass is cheaper from

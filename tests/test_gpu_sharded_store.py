@@ -102,7 +102,7 @@ def test_ties_across_pieces_come_back_in_insertion_order(gpu_ctx):
     sc = smt.ShardedCorpus(g, empty=True)
     base = synth.unit_rows(900, seed=21)
     dup = base[5].copy()
-    want_rows = []
+    want_rows = [5]                                                      # (the original sits in the first append)
     total = 0
     for n in (300, 250, 200, 150):                                       # four appends -> up to 12 pieces
         rows = base[total:total + n].copy()
@@ -110,7 +110,7 @@ def test_ties_across_pieces_come_back_in_insertion_order(gpu_ctx):
         want_rows += [total + 3, total + n // 2, total + n - 1]
         sc.append(rows)
         total += n
-    (got_rows, got_dist), = sc.search(dup, top_k=12)
+    (got_rows, got_dist), = sc.search(dup, top_k=13)
     assert got_rows.tolist() == sorted(want_rows) and np.all(got_dist == got_dist[0])
     (thr_rows, _), = sc.search(dup, top_k=0, max_distance=1e-6)           # threshold mode: host-list exchange
     assert thr_rows.tolist() == sorted(want_rows)

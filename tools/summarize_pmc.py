@@ -31,6 +31,7 @@ def main():
                 else:
                     e[c + "_avg"] = sum(vals) / len(vals)
                     e[c + "_max"] = max(vals)
+                    e[c + "_min"] = min(vals)
                     if c == "FETCH_SIZE":
                         e["hbm_bytes_avg_corrected_x2"] = 2048.0 * sum(vals) / len(vals)
                         e["hbm_bytes_max_corrected_x2"] = 2048.0 * max(vals)
