@@ -233,3 +233,96 @@ def test_fair_cpu_scan_agrees_with_restatement():
     ref = orc.search_documents(emb, [5000], q, 0, 10)
     assert rows.tolist() == [r["match_line"] for r in ref]
     assert np.allclose(dist, [r["distance"] for r in ref], rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the REAL reference's outputs (oracle/_ref recipe)
+# tests/golden/ref_*.npz are written by oracle/_ref/collect.py from a run of the real reference (semtools v3.0.0 +
+# model2vec-rs 0.1.3 + simsimd 6.5.1 + qdrant-edge) on the committed synthetic inputs.  The round's container cannot produce
+# them (no cargo, no network): until somebody runs the recipe these tests SKIP with "parity unpinned", and DESIGN.md section 6
+# says the same.  Once the fixtures exist they are the anchor every other parity test inherits from.
+UNPINNED = ("parity unpinned: tests/golden/{} has not been generated -- run the recipe in oracle/_ref/README.md "
+            "(needs cargo + crates.io); the oracle is checked against its numpy twin and the reference's behavioural tests only")
+
+
+def _ref_fixture(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        print(UNPINNED.format(name))
+        pytest.skip(UNPINNED.format(name))
+    return np.load(path, allow_pickle=True)
+
+
+def test_reference_model2vec_embeddings_match_the_oracle_bit_for_bit():
+    """model2vec-rs 0.1.3: from_pretrained + encode_with_args(.., Some(2048 / 512 / 4), ..) + encode_single on 400 lines
+    (empty, all-unknown, 3000 tokens) vs orc_embed_lines on the ids the SAME tokenizer.json gives (tokenizers wheel = the crate
+    model2vec-rs uses; add_special_tokens = false, unk ids dropped, truncated to the cap)."""
+    import json
+
+    ref = _ref_fixture("ref_embed.npz")
+    from tokenizers import Tokenizer, models, pre_tokenizers
+
+    V = int(ref["V"])
+    table = synth.table(V, seed=int(ref["table_seed"]))
+    vocab = {f"w{i}": i for i in range(V - 1)}
+    vocab["[UNK]"] = V - 1
+    tok = Tokenizer(models.WordLevel(vocab=vocab, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+
+    def csr(texts, cap):
+        ids, offsets = [], [0]
+        for t in texts:
+            # model2vec-rs truncates the STRING to cap * median token length characters first, then encodes, drops unk, truncates
+            got = [i for i in tok.encode(t, add_special_tokens=False).ids if i != V - 1][:cap]
+            ids += got
+            offsets.append(len(ids))
+        return np.array(ids, np.uint32), np.array(offsets, np.uint64)
+
+    lines, queries = [str(x) for x in ref["lines"]], [str(x) for x in ref["queries"]]
+    for key, cap in (("emb_2048", 2048), ("emb_512", 512), ("emb_4", 4)):
+        ids, offsets = csr(lines, cap)
+        mine = orc.embed_lines(table, ids, offsets, True, cap)
+        assert np.array_equal(mine, ref[key]), (key, float(np.abs(mine - ref[key]).max()))
+    ids, offsets = csr(queries, 512)
+    assert np.array_equal(orc.embed_lines(table, ids, offsets, True, 512), ref["emb_single"])
+    print("pinned against", json.loads(str(ref["versions"])))
+
+
+def test_reference_simsimd_cosine_and_search_documents_match_the_oracle():
+    """simsimd 6.5.1 cosine on 3 x 600 pairs (duplicates, zero rows): <= 1e-5 to both oracle forms, zero rules exact;
+    semtools v3.0.0 search_documents: indices / windows exact, distances <= 1e-5."""
+    import json
+
+    ref = _ref_fixture("ref_search.npz")
+    corpus, qs, cos = ref["corpus"], ref["queries"], ref["simsimd_cosine"]
+    for qi in range(len(qs)):
+        for r in range(len(corpus)):
+            for acc in (False, True):
+                assert abs(orc.cosine(qs[qi], corpus[r], accurate=acc) - cos[qi, r]) <= 1e-5, (qi, r, acc)
+        zero = np.nonzero(~corpus.any(axis=1))[0]
+        assert len(zero) and all(cos[qi, z] == 1.0 for z in zero)          # ab == 0 -> distance 1
+    split = 400
+    for case in json.loads(str(ref["search_documents"])):
+        res = orc.search_documents(corpus, [split, len(corpus) - split], qs[case["query"]], n_lines=case["n_lines"],
+                                   top_k=case["top_k"], max_distance=case["max_distance"], accurate=True)
+        hits = case["hits"]
+        assert [(f"doc{r['doc']}", r["match_line"], r["start"], r["end"]) for r in res] == \
+               [(h["filename"], h["match_line"], h["start"], h["end"]) for h in hits], case
+        assert np.allclose([r["distance"] for r in res], [h["distance"] for h in hits], rtol=0, atol=1e-5)
+
+
+def test_reference_store_search_matches_the_oracle():
+    """semtools v3.0.0 Store::search_line_embeddings (qdrant-edge) incl. the reference's own known-answer vectors."""
+    import json
+
+    ref = _ref_fixture("ref_store.npz")
+    rows, qs = ref["store_rows"], ref["queries"]
+    names = ["doc1", "doc2", "doc3"]
+    path = np.array([0, 1, 1] + [2] * (len(rows) - 3), np.uint32)
+    line = np.array([0, 0, 1] + list(range(len(rows) - 3)), np.int32)
+    probes = {"q_0.1": np.full(256, 0.1, np.float32), "row10": rows[10], "vecq0": qs[0]}
+    for case in json.loads(str(ref["store_search"])):
+        subset = np.array([names.index(p) for p in case["subset"]], np.uint32)
+        res = orc.search_line_embeddings(rows, path, line, probes[case["query"]], subset, case["top_k"], case["max_distance"])
+        hits = case["hits"]
+        assert [(names[r["path_id"]], r["line_number"]) for r in res] == [(h["path"], h["line_number"]) for h in hits], case
+        assert np.allclose([r["distance"] for r in res], [h["distance"] for h in hits], rtol=0, atol=1e-5)
