@@ -148,6 +148,38 @@ int main()
                 printf("    \"plus1_minus1_plus_0.75ulp\": \"%a\", \"small_product_survives_large_cancelling_pair\": %s,\n", r, r == c + ulp ? "true" : "false");
             }
         }
+        // How far below the accumulator's ulp does the instruction still SEE a product?  p0 = 0.5 ulp (a tie: stays at c, even
+        // mantissa) + p1 = 2^-j ulp: seen -> above the tie -> c + ulp; dropped -> c.  Negative twin on an odd accumulator
+        // (tie -> c + 2 ulp if p1 is dropped, c + ulp if seen).  The largest j that is still seen = guard bits of the adder.
+        {
+            int seen_pos = 0, seen_neg = 0;
+            for (int j = 1; j <= 40; ++j) {
+                std::vector<float> a(K, 0.0f), b(K, 0.0f);
+                a[0] = 0.5f; b[0] = ulp;
+                a[1] = 1.0f; b[1] = ldexpf(ulp, -j);
+                if (kind == 2) {   // keep both fp16 operands normal: split the exponent over a and b
+                    a[0] = 0.5f * ldexpf(1.0f, -10); b[0] = ldexpf(1.0f, -13);
+                    a[1] = ldexpf(1.0f, -12 - j / 2); b[1] = ldexpf(1.0f, -11 - (j - j / 2));
+                    if (-12 - j / 2 < -14 || -11 - (j - j / 2) < -14) break;
+                }
+                if (run(kind, a, b, c, &r)) return 1;
+                if (r == c + ulp) seen_pos = j;
+                a[1] = -a[1];
+                if (run(kind, a, b, c + ulp, &r)) return 1;
+                if (r == c + ulp) seen_neg = j;
+            }
+            printf("    \"tie_breaker_seen_down_to_2^-j_ulp\": {\"positive\": %d, \"negative\": %d},\n", seen_pos, seen_neg);
+        }
+        // K - 1 products of 2^-j ulp each next to p0 = 0.5 ulp - (K - 1) 2^-j ulp ... simpler: many tiny products, do they add up?
+        // p0 = 0.25 ulp, 15 x p = 1/32 ulp (sum 0.25 + 0.469 = 0.719 ulp > tie) -> c + ulp only if the tiny ones are summed
+        if (K > 2) {
+            std::vector<float> a(K, 0.0f), b(K, 0.0f);
+            a[0] = 0.25f; b[0] = ulp;
+            for (int k = 1; k < K; ++k) { a[k] = 0.03125f; b[k] = ulp; }
+            if (kind == 2) { a[0] = 0.25f * ldexpf(1.0f, -10); b[0] = ldexpf(1.0f, -13); for (int k = 1; k < K; ++k) { a[k] = ldexpf(1.0f, -14); b[k] = ldexpf(1.0f, -14); } }
+            if (run(kind, a, b, c, &r)) return 1;
+            printf("    \"0.25ulp_plus_15_x_1_32ulp\": \"%a\", \"tiny_products_of_one_instruction_add_up\": %s,\n", r, r == c + ulp ? "true" : "false");
+        }
         // empirical: 256-dim dots of positive values, chained exactly like the kernels do
         {
             std::mt19937 rng(1234 + kind);
