@@ -609,7 +609,10 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     ctx.prof_enable(False)
     gemm_s = ms_g / reps * 1e-3
     flops = 2.0 * nq * rows * 256
-    issued = 2.0 if (nq >= 128 and rows <= (1 << 25)) else 3.0   # gemm_kernels.hip launch_gemm_topk: the auto rule of gemm_nominate
+    # gemm_kernels.hip launch_gemm_topk, the auto rule of gemm_nominate: MFMAs issued per algorithmic multiply-add
+    small_shard = rows <= (1 << 25)
+    issued = 1.0 if (nq >= 256 and small_shard and k + 24 <= 64) else 2.0 if (nq >= 128 and small_shard) else 3.0
+    mode_name = {1.0: "f16 x 1", 2.0: "f16 x 2", 3.0: "bf16 x 3"}[issued]
     ok = True
     for i in range(min(3, nq)):  # independent fp64 check of a few queries
         ref = 1.0 - (x.double() @ q[i].double())
@@ -660,10 +663,12 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         "metric": "queries/sec at 10M-chunk corpus (batched)", "value": nq / wall, "unit": "queries/s",
         "ms_per_batch": wall * 1e3, "rows_scanned_per_s": nq * rows / wall,
         "config": {"workload": f"c3: {nq} batched queries x {rows} chunks (D=256, f32), top-{k}, one MI355X"},
-        # The score matrix only nominates candidates.  From 128 queries on (shards <= 32 M rows) the library's default is
-        # f16 x 2: one fp16 operand per row, hi + lo per query = 2 x the algorithmic flops on the 16-bit MFMA pipe (dense
-        # peak 2.5 PF); smaller batches / larger shards use bf16 x 3 (3 x).  The same batch on f32 MFMAs is bounded by 157.3 TF.
-        "roofline": {"kernel": f"gemm_rowreg_kernel (K3, {'f16 x 2' if issued == 2.0 else 'bf16 x 3'})", "bound": "mfma",
+        # The score matrix only nominates candidates.  On shards <= 32 M rows the library's default is f16 x 1 from 256 queries
+        # (one fp16 operand per row and per query = 1 x the algorithmic flops on the 16-bit MFMA pipe, dense peak 2.5 PF), f16 x 2
+        # from 128 (hi + lo per query: 2 x); smaller batches / larger shards use bf16 x 3 (3 x).  `frac` is ISSUED MFMA flops over
+        # the 16-bit peak -- a mode that issues fewer MFMAs for the same answers finishes sooner at a LOWER fraction; queries/s is
+        # the figure of merit.  The same batch on f32 MFMAs (roofline_f32_mfma) is bounded by 157.3 TF.
+        "roofline": {"kernel": f"gemm_rowreg_kernel (K3, {mode_name})", "bound": "mfma",
                      "achieved": issued * flops / gemm_s / 1e12,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": issued * flops / gemm_s / 2500e12, "traffic": traffic,
                      "traffic_source": traffic_source, "algorithmic_bytes_per_batch": rows * ROW_BYTES,

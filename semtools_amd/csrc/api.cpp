@@ -316,7 +316,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
     else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
     else if (k == "gemm_rowreg") ctx->tune.gemm_rowreg = (int)value;
-    else if (k == "gemm_nominate") ctx->tune.gemm_nominate = (value == 1 || value == 2) ? (int)value : 0;
+    else if (k == "gemm_nominate") ctx->tune.gemm_nominate = (value >= 1 && value <= 3) ? (int)value : 0;
     else if (k == "fallback_batch_min_rows") ctx->tune.fallback_batch_min_rows = value < 0 ? 0 : value;
     else if (k == "guard_band") ctx->tune.guard_band = (int)std::max<int64_t>(8, std::min<int64_t>(56, value));
     else if (k == "gemm_min_nq") ctx->tune.gemm_min_nq = (int)std::max<int64_t>(2, std::min<int64_t>(8, value));

@@ -68,7 +68,7 @@ struct Tuning {
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
     int gemm_min_nq = 3;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
     int64_t gemm_min_rows_small = 1000000;   // (2 queries: 4 x this; api.cpp topk_dispatch)
-    int gemm_nominate = 0;      // gemm_rowreg_kernel: 0 auto (f16 x 2 from 128 queries on shards <= 32 M rows), 1 bf16 x 3, 2 f16 x 2
+    int gemm_nominate = 0;      // gemm_rowreg_kernel: 0 auto (shards <= 32 M rows: f16 x 2 from 128 queries, f16 x 1 from 256), 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1
     int gemm_rowreg = 1;        // 1: with gemm_bf16x3, unfiltered batches use gemm_rowreg_kernel (coalesced row loads + LDS transpose)
     int gemm_bf16x3 = 1;        // 1: K3 nominates candidates with bf16 x 3 split products on the bf16 MFMA pipe (mfma_tile.h); 0: f32 MFMA
     int gemm_ldsrow = 1;        // 1: batches <= 128 queries and range-filtered batches use the LDS-row kernel (64 queries per pass)
@@ -221,16 +221,24 @@ struct SelectArgs {
 };
 int launch_select(smt_ctx *ctx, const SelectArgs &s);
 
-// |f32 scan distance - exact distance| bounds used for the certificate: K2/K4 reduce 4 FMAs per lane + an 8-step
-// tree (<= 12 roundings of terms whose absolute sum is <= 1, plus two rsqrt/multiplies): < 1e-6; the MFMA path
-// accumulates 256 products sequentially: <= 256 * 2^-24 = 1.5e-5 in the worst case.
+// |f32 scan distance - exact distance| bounds used for the certificate.  What an MFMA does to its accumulator was MEASURED
+// on gfx950 (tools/micro/mfma_rounding.hip, profiles/r03_mfma_rounding.json): v_mfma_f32_32x32x2_f32 is a chain of fused
+// multiply-adds, each rounded to nearest-even; the 16-bit 32x32x16 MFMAs form their 16 products exactly, align them with the
+// accumulator keeping 5 bits below its ulp, and round the sum ONCE to nearest-even -- at most 2 ulp of the accumulator per
+// instruction (measured on positive 256-dim dots: 2 ulp in total over 16 instructions).
+//   K2/K4: 4 FMAs per lane + an 8-step tree (<= 12 roundings of terms whose absolute sum is <= 1, plus two rsqrt/multiplies): < 1e-6.
+//   f32 MFMA: 256 products accumulated one by one, each add rounded to nearest: <= 256 * 2^-24 = 1.5e-5.
 constexpr double F32_ERR_SCAN = 4e-6;
 constexpr double F32_ERR_MFMA = 2e-5;
-// bf16 x 3 split products (mfma_tile.h): 3 * 2^-16 representation (4.6e-5) + 768 f32 accumulations (4.6e-5 with
-// round-to-nearest adds, counted twice: the MFMA adder tree is not documented to round to nearest) = 1.4e-4
-constexpr double F32_ERR_BF16X3 = 1.5e-4;
-// f16 x 2 (mfma_tile.h): one fp16 operand for the rows (2^-11 = 4.9e-4) + 512 accumulations counted twice (6e-5)
-constexpr double F32_ERR_F16X2 = 6e-4;
+// bf16 x 3 split products (mfma_tile.h): representation 3 * 2^-16 |x||q| (4.6e-5: the dropped lo.lo term and the two
+// residuals, each <= 2^-16 sum |x_i q_i|) + 48 instructions x 2 ulp (1.1e-5) + the f32 scaling by 1/|x|, 1/|q| (< 1e-6)
+// = 5.8e-5.  Constructed worst case (tests/test_gpu_batched.py): 2.6e-5; random corpora: 1.0e-5.
+constexpr double F32_ERR_BF16X3 = 7e-5;
+// f16 x 2: ONE fp16 operand for the rows: 2^-11 sum |x_i q_i| <= 4.88e-4 (the query, hi + lo, carries 22 bits) + 32
+// instructions x 2 ulp (7.6e-6) + scaling = 4.97e-4.  Constructed worst case: 3.7e-4; random corpora: 2.3e-4.
+constexpr double F32_ERR_F16X2 = 5.2e-4;
+// f16 x 1: the query is a single fp16 operand too: 2 x 2^-11 (+ 2^-22) = 9.77e-4 + 16 instructions x 2 ulp (3.8e-6) = 9.8e-4.
+constexpr double F32_ERR_F16X1 = 1.0e-3;
 // K2/K3 keep k + 8 <= 64 candidates per list: top_k above this goes to the all-keys path (largek.hip)
 constexpr uint32_t SCAN_MAX_K = 56;
 

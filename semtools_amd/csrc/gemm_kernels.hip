@@ -469,11 +469,16 @@ __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t 
     }
 }
 
-// F16X2: f16 x 2 nomination (mfma_tile.h) instead of bf16 x 3 -- the rows carry ONE fp16 operand (64 VGPRs), the
-// transpose moves half the words, a K-step is two MFMAs.
-template <bool F16X2>
+// MODE 0: bf16 x 3.  MODE 1: f16 x 2 nomination (mfma_tile.h) -- the rows carry ONE fp16 operand (64 VGPRs), the transpose
+// moves half the words, a K-step is two MFMAs (row x query-hi, row x query-lo).  MODE 2: f16 x 1 -- the query's lo part is
+// dropped too: ONE MFMA and ONE B quad per K-step, half the MFMA and half the LDS operand traffic of f16 x 2 for a
+// certificate band of 2^-10 instead of 2^-11 (common.h F32_ERR_F16X1): the large-batch mode, where the MFMA pipe -- at the
+// clock the part sustains under this load -- is the bound and the only lever left is fewer MFMAs per useful flop.
+template <int MODE>
 __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p)
 {
+    constexpr bool F16X2 = MODE >= 1;     // fp16 row operand (MODE 1 and 2)
+    constexpr bool F16X1 = MODE == 2;     // ... and a single fp16 query operand
     constexpr int WAVES = RR_WAVES;
     constexpr int STAGE_ROWS = QT_ROWS / WAVES;      // rows of a query tile each wave stages: 4
     constexpr int STAGE_EVERY = 2;                   // one DMA every so many K-steps at the start of a product
@@ -537,7 +542,10 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             // ---- 32 coalesced loads: instruction i = 4s + u covers rows 8u .. 8u+7, dims 32s .. 32s+31 (128 B per row)
             f32x4 R[32];
             {
-                const f32x4 *base = reinterpret_cast<const f32x4 *>(p.corpus) + (lane & 7);
+                // (rebuilt per tile from the SGPR base: as a loop invariant it was the one value hipcc spilled across the sweep)
+                uint32_t l7 = (uint32_t)lane & 7u;
+                asm volatile("" : "+v"(l7));
+                const f32x4 *base = reinterpret_cast<const f32x4 *>(p.corpus) + l7;
                 uint64_t rowv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -594,11 +602,17 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                     Al[2 * sl + 1] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
                 }
             }
+            // accumulator reg r = 4u + c <-> tile row 8u + i, i = c + 4h; row 8u + i's scale sits in lanes 8i .. 8i + 7 of rb[u]:
+            // one ballot per u instead of sixteen LDS permutes (whose hoisted lane indices were what spilled at 256 VGPRs)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 4 * h;                     // accumulator reg r <-> tile row 8 (r >> 2) + i
-                if (__shfl(rb[r >> 2], 8 * i) == 0.0f) zero16 |= 1u << r;
-                if (row0 + 8 * (r >> 2) + i < p.n_rows) valid16 |= 1u << r;
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long zm = __ballot(rb[u] == 0.0f);
+                const uint32_t w = h ? (uint32_t)(zm >> 32) : (uint32_t)zm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    zero16 |= ((w >> (8 * c)) & 1u) << (4 * u + c);
+                    if (row0 + 8 * u + c + 4 * h < p.n_rows) valid16 |= 1u << (4 * u + c);
+                }
             }
         }
 
@@ -616,16 +630,24 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
             // B quads run RR_BDIST K-steps ahead of their MFMAs (sched_barrier: hipcc otherwise sinks every read to its
             // use and each K-step then starts with a full LDS round trip in front of 96 cycles of MFMA)
-            constexpr int NB = RR_BDIST + 1;
-            u32x4 bh[NB], bl[NB];
+            // (bf16 x 3 holds 128 operand VGPRs: one K-step of distance keeps it at 256 registers WITHOUT spilling -- with two
+            // it spilled three into scratch inside this loop; measured equal otherwise)
+            constexpr int BD = MODE == 0 ? 1 : RR_BDIST;
+            constexpr int NB = BD + 1;
+            u32x4 bh[NB], bl[F16X1 ? 1 : NB];
 #pragma unroll
-            for (int d = 0; d < RR_BDIST; ++d) { bh[d] = bq[4 * d]; bl[d] = bq[4 * d + 1]; }
+            for (int d = 0; d < BD; ++d) { bh[d] = bq[4 * d]; if constexpr (!F16X1) bl[d] = bq[4 * d + 1]; }
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                if (m + RR_BDIST < 16) { bh[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST)]; bl[(m + RR_BDIST) % NB] = bq[4 * (m + RR_BDIST) + 1]; }
+                if (m + BD < 16) {
+                    bh[(m + BD) % NB] = bq[4 * (m + BD)];
+                    if constexpr (!F16X1) bl[(m + BD) % NB] = bq[4 * (m + BD) + 1];
+                }
                 if (m % STAGE_EVERY == 0 && m / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, m / STAGE_EVERY);
                 if (m == STAGE_EVERY * STAGE_ROWS && stage) stage_consts(stage_qt, stage_slot);
-                if constexpr (F16X2) acc = mfma_f16x2(Ah[m], bh[m % NB], bl[m % NB], acc);
+                if constexpr (F16X1)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[m]), __builtin_bit_cast(f16x8, bh[m % NB]), acc, 0, 0, 0);
+                else if constexpr (F16X2) acc = mfma_f16x2(Ah[m], bh[m % NB], bl[m % NB], acc);
                 else acc = mfma_bf16x3(Ah[m], Al[m], bh[m % NB], bl[m % NB], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1046,7 +1068,7 @@ __global__ void fill_f32_kernel(float *p, float v, uint32_t n)
 // ---- test hook: the NOMINATING distances themselves (never part of an answer).  One wave per 32-row tile against one
 // tile of <= 32 queries, the same operand preparation and MFMA sequence as gemm_level_kernel; out[row][32] = the f32
 // distance the candidate test sees.  tests/test_gpu_batched.py measures |out - exact| against F32_ERR_MFMA / _BF16X3.
-template <int MODE>   // 0 f32 MFMA, 1 bf16 x 3, 2 f16 x 2
+template <int MODE>   // 0 f32 MFMA, 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1
 __global__ void __launch_bounds__(64) gemm_debug_scores_kernel(const float *corpus, uint64_t first_row, uint32_t n_rows,
                                                                const float *queries, uint32_t nq, float *out)
 {
@@ -1072,7 +1094,7 @@ __global__ void __launch_bounds__(64) gemm_debug_scores_kernel(const float *corp
     const float r2 = rpart + __shfl_xor(rpart, 32), q2 = qpart + __shfl_xor(qpart, 32);
     const float rb = r2 == 0.0f ? 0.0f : __frsqrt_rn(r2);
     float rq = q2 == 0.0f ? 0.0f : __frsqrt_rn(q2);
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
         const float qs = rq * F16X2_QUERY_SCALE;   // unit query x 2^8, unit row x 2^10 (as split_queries_f16_kernel / gemm_rowreg_kernel<true>)
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
@@ -1084,7 +1106,9 @@ __global__ void __launch_bounds__(64) gemm_debug_scores_kernel(const float *corp
             f16_split2(q0.z, q0.w, h1, l1);
             f16_split2(q1.x, q1.y, h2, l2);
             f16_split2(q1.z, q1.w, h3, l3);
-            acc = mfma_f16x2(a, (u32x4){h0, h1, h2, h3}, (u32x4){l0, l1, l2, l3}, acc);
+            if constexpr (MODE == 3)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3}), acc, 0, 0, 0);
+            else acc = mfma_f16x2(a, (u32x4){h0, h1, h2, h3}, (u32x4){l0, l1, l2, l3}, acc);
         }
         if (rq != 0.0f) rq = F16X2_INV_SCALE;
     } else if constexpr (MODE == 1) {
@@ -1117,7 +1141,8 @@ int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_r
 {
     if (nq < 1 || nq > 32 || n_rows < 1) { set_error("debug scores: 1..32 queries, >= 1 row"); return SMT_E_INVALID; }
     const dim3 grid((n_rows + 31) / 32);
-    if (ctx->tune.gemm_bf16x3 && ctx->tune.gemm_nominate == 2) hipLaunchKernelGGL(gemm_debug_scores_kernel<2>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    if (ctx->tune.gemm_bf16x3 && ctx->tune.gemm_nominate == 3) hipLaunchKernelGGL(gemm_debug_scores_kernel<3>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
+    else if (ctx->tune.gemm_bf16x3 && ctx->tune.gemm_nominate == 2) hipLaunchKernelGGL(gemm_debug_scores_kernel<2>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
     else if (ctx->tune.gemm_bf16x3) hipLaunchKernelGGL(gemm_debug_scores_kernel<1>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
     else hipLaunchKernelGGL(gemm_debug_scores_kernel<0>, grid, dim3(64), 0, ctx->stream, corpus, first_row, n_rows, queries, nq, out);
     SMT_HIP_CHECK(hipGetLastError());
@@ -1172,9 +1197,11 @@ static int ensure_gemm_attrs(smt_ctx *ctx)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_level_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<false>),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<true>),
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK((lr_set_attr<false>()));
         SMT_HIP_CHECK((lr_set_attr<true>()));
@@ -1197,14 +1224,17 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // bf16 x 3 (the default): gemm_rowreg_kernel takes every unfiltered batch; range-filtered batches keep the LDS-row
     // kernel (its chunk table gathers the rows).  f32 MFMA (gemm_bf16x3 = 0): the round-1/2 routing below.
     const bool rowreg = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && !filtered;
-    // How gemm_rowreg_kernel nominates (tuning key gemm_nominate: 0 auto, 1 bf16 x 3, 2 f16 x 2).  f16 x 2 issues a third
-    // fewer MFMAs -- what large batches are bound by -- for a four times wider certificate band (6e-4 against 1.5e-4):
-    // auto takes it from 128 queries up on shards of at most 32 M rows (the rank spacing of the distances shrinks with
-    // the shard; at 10 M random rows the k-th and k+8-th distances are ~8e-3 apart).  Small batches are HBM-bound: bf16 x 3.
-    const bool f16x2 = rowreg && (ctx->tune.gemm_nominate == 2 ||
-                                  (ctx->tune.gemm_nominate == 0 && nqt >= 4 && a.rows <= (1ull << 25)));
-    // guard band, see candidates_per_list (scan_kernels.hip); the wider certificate band of f16 x 2 gets a band of at least 16
-    const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)std::max(ctx->tune.guard_band, f16x2 ? 16 : 8));
+    // How gemm_rowreg_kernel nominates (tuning key gemm_nominate: 0 auto, 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1).  The fp16 modes
+    // issue 2/3 resp. 1/3 of the MFMAs of bf16 x 3 -- what large batches are bound by -- for a wider certificate band
+    // (5.2e-4 / 1.0e-3 against 7e-5): auto takes f16 x 2 from 128 queries and f16 x 1 from 256 queries on shards of at most
+    // 32 M rows (the rank spacing of the distances shrinks with the shard; at 10 M random rows the k-th and k+8-th distances
+    // are ~8e-3 apart), provided the lists have room for the wider guard band.  Small batches are HBM-bound: bf16 x 3.
+    const bool auto_fp16 = rowreg && ctx->tune.gemm_nominate == 0 && a.rows <= (1ull << 25);
+    const bool f16x1 = rowreg && (ctx->tune.gemm_nominate == 3 || (auto_fp16 && nqt >= 8 && a.k_out + 24 <= 64));
+    const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && nqt >= 4));
+    // guard band, see candidates_per_list (scan_kernels.hip): the wider the certificate band, the more rows are nominated
+    // (the proof needs the k-th exact distance to lie 2 x the band below the worst nominated one): 8 / 16 / 24
+    const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)std::max(ctx->tune.guard_band, f16x1 ? 24 : f16x2 ? 16 : 8));
     const bool lds_rows = !rowreg && ctx->tune.gemm_ldsrow && (filtered || nqt <= 2);
     if (filtered && !lds_rows) { set_error("range-filtered batches need the LDS-row kernel (tuning key gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
     const uint32_t pass_nq = lds_rows ? 2 * QT_ROWS : GEMM_MAX_NQ;
@@ -1247,7 +1277,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     float *qconst = tau + (size_t)nqt * QT_ROWS;   // [nqt*32][2]
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
-    if (f16x2)
+    if (f16x2 || f16x1)   // (f16 x 1 reads only the hi halves of the same image)
         hipLaunchKernelGGL(split_queries_f16_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, q_split);
     else if (bf16)
@@ -1255,7 +1285,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                            nqt * QT_ROWS, q_split);
     if (rowreg)
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, qconst, f16x2 ? 1 : 0);
+                           nqt * QT_ROWS, qconst, (f16x2 || f16x1) ? 1 : 0);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -1298,8 +1328,9 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                 nb = (int)(need_blocks * g.qsplit);
             }
             prof_begin(ctx, "gemm");
-            if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<true>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
-            else hipLaunchKernelGGL(gemm_rowreg_kernel<false>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            if (f16x1) hipLaunchKernelGGL(gemm_rowreg_kernel<2>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            else if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<1>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            else hipLaunchKernelGGL(gemm_rowreg_kernel<0>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
             prof_end(ctx, "gemm");
         } else if (g.level_tiles > 0 && lds_rows) {
             const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
@@ -1354,7 +1385,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     sel.out_dist = a.out_dist;
     sel.out_counts = a.out_counts;
     sel.out_stride = a.out_stride;
-    sel.f32_err = f16x2 ? F32_ERR_F16X2 : bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
+    sel.f32_err = f16x1 ? F32_ERR_F16X1 : f16x2 ? F32_ERR_F16X2 : bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
     sel.out_uncertain = a.out_uncertain;
     rc = launch_select(ctx, sel);
     if (rc) return rc;

@@ -452,19 +452,20 @@ __global__ void ivf_lut_kernel(const float *queries, const float *codebooks, flo
 // int8 copy of the rows in LIST order: x ~= scale * q, scale = max|x| / 127 (one wave per row)
 __global__ void quantize_rows_kernel(const float *rows, const uint32_t *ids, uint64_t n, uint8_t *out, float *scale)
 {
-    const uint64_t pos = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (pos >= n) return;
     const int lane = threadIdx.x & 63;
-    const f32x4 v = reinterpret_cast<const f32x4 *>(rows + (uint64_t)ids[pos] * 256)[lane];
-    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);   // grid-stride: a launch holds < 2^32 work-items
+    for (uint64_t pos = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pos < n; pos += n_waves) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(rows + (uint64_t)ids[pos] * 256)[lane];
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    const float sc = m > 0.0f ? m / 127.0f : 1.0f;
-    const float inv = 1.0f / sc;
-    const uint32_t b0 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.x * inv), b1 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.y * inv);
-    const uint32_t b2 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.z * inv), b3 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.w * inv);
-    reinterpret_cast<uint32_t *>(out + pos * 256)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-    if (lane == 0) scale[pos] = sc;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float sc = m > 0.0f ? m / 127.0f : 1.0f;
+        const float inv = 1.0f / sc;
+        const uint32_t b0 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.x * inv), b1 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.y * inv);
+        const uint32_t b2 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.z * inv), b3 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.w * inv);
+        reinterpret_cast<uint32_t *>(out + pos * 256)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        if (lane == 0) scale[pos] = sc;
+    }
 }
 
 // ------------------------------------------------------------------ per-list PCA codes (index kind 1)
@@ -613,27 +614,32 @@ __global__ void __launch_bounds__(256) lpca_train_kernel(const float *corpus, co
     }
 }
 
-// one wave per row (list order): code_k = clamp(round(Q_l[k] . (x - c_l) / scale_l[k]))
+// one wave per row (list order): code_k = clamp(round(Q_l[k] . (x - c_l) / scale_l[k])).  Grid-stride over the rows: a launch
+// carries at most 2^32 - 1 work-items per dimension (the AQL packet's grid size is a u32 count of work-items), and 64 lanes
+// per row pass that at 67 M rows -- the first version launched n * 64 threads and, at config c5's 100 M rows, silently
+// encoded the first third of them only (recall 0.35; profiles/r03_ivf_sweep_100M_20k_topics.json has before and after).
+constexpr unsigned LPCA_ENCODE_MAX_BLOCKS = 1u << 20;   // x 4 waves: rows per pass of the grid
 __global__ void __launch_bounds__(256) lpca_encode_kernel(const float *corpus, const uint32_t *ids, const uint32_t *sorted_lists,
                                                            uint64_t n, const float *centroids, const float *basis, const float *lscale,
                                                            uint8_t *codes)
 {
-    const uint64_t pos = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (pos >= n) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t l = sorted_lists[pos];
-    f32x4 r = reinterpret_cast<const f32x4 *>(corpus + (uint64_t)ids[pos] * 256)[lane];
-    r -= reinterpret_cast<const f32x4 *>(centroids + (size_t)l * 256)[lane];
-    const f32x4 *B = reinterpret_cast<const f32x4 *>(basis + (size_t)l * LP_DIMS * 256);
-    uint32_t mine = 0;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t pos = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pos < n; pos += n_waves) {
+        const uint32_t l = sorted_lists[pos];
+        f32x4 r = reinterpret_cast<const f32x4 *>(corpus + (uint64_t)ids[pos] * 256)[lane];
+        r -= reinterpret_cast<const f32x4 *>(centroids + (size_t)l * 256)[lane];
+        const f32x4 *B = reinterpret_cast<const f32x4 *>(basis + (size_t)l * LP_DIMS * 256);
+        uint32_t mine = 0;
 #pragma unroll 4
-    for (int k = 0; k < LP_DIMS; ++k) {
-        const f32x4 b = B[k * 64 + lane];
-        const float y = wave_sum(r.x * b.x + r.y * b.y + r.z * b.z + r.w * b.w);
-        const float c = fminf(fmaxf(rintf(y / lscale[(size_t)l * LP_DIMS + k]), -127.0f), 127.0f);
-        if (lane == k) mine = (uint32_t)(uint8_t)(int8_t)(int)c;
+        for (int k = 0; k < LP_DIMS; ++k) {
+            const f32x4 b = B[k * 64 + lane];
+            const float y = wave_sum(r.x * b.x + r.y * b.y + r.z * b.z + r.w * b.w);
+            const float c = fminf(fmaxf(rintf(y / lscale[(size_t)l * LP_DIMS + k]), -127.0f), 127.0f);
+            if (lane == k) mine = (uint32_t)(uint8_t)(int8_t)(int)c;
+        }
+        if (lane < LP_DIMS) codes[pos * PQ_M + lane] = (uint8_t)mine;
     }
-    if (lane < LP_DIMS) codes[pos * PQ_M + lane] = (uint8_t)mine;
 }
 
 // w[pair][k] = scale_l[k] * (Q_l[k] . q) for every (query, probed list) pair; one wave per pair
@@ -1178,7 +1184,7 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
         const uint32_t pca_iters = std::max<uint32_t>(4u, std::min<uint32_t>(iters, 8u));
         hipLaunchKernelGGL(lpca_train_kernel, dim3(nlist), dim3(256), LPCA_SMEM, ctx->stream, corpus->d_rows, ix->d_ids, ix->d_offsets,
                            ix->d_centroids, pca_iters, ix->d_basis, ix->d_lscale);
-        hipLaunchKernelGGL(lpca_encode_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
+        hipLaunchKernelGGL(lpca_encode_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, LPCA_ENCODE_MAX_BLOCKS)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
                            b_sorted_lists.as<uint32_t>(), N, ix->d_centroids, ix->d_basis, ix->d_lscale, ix->d_codes);
     } else {
         PqParams q;
@@ -1199,7 +1205,7 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
     if (prm->refine == 1) {  // opt-in: keep an int8 copy of the rows (256 B + 4 B per row) for the refinement stage
         IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), (size_t)N * 256));
         IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), (size_t)N * 4));
-        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
+        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, 1u << 20)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
                            N, ix->d_i8, ix->d_i8_scale);
     }
     IVF_HIP(hipEventRecord(ev[4], ctx->stream));
@@ -1542,7 +1548,7 @@ int smt_ivfpq_append(smt_ivfpq *ix, uint64_t *n_added)
                        b_noff.as<uint64_t>());
     // encode with the EXISTING quantisers (no retraining: that is what makes this incremental)
     if (ix->kind == 1) {
-        hipLaunchKernelGGL(lpca_encode_kernel, dim3((unsigned)((n_new * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows,
+        hipLaunchKernelGGL(lpca_encode_kernel, dim3((unsigned)std::min<uint64_t>((n_new + 3) / 4, LPCA_ENCODE_MAX_BLOCKS)), dim3(256), 0, ctx->stream, corpus->d_rows,
                            b_ids.as<uint32_t>(), b_sorted.as<uint32_t>(), n_new, ix->d_centroids, ix->d_basis, ix->d_lscale,
                            b_codes.as<uint8_t>());
     } else {
@@ -1701,7 +1707,7 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     if (h.pad[0] == 1 && N > 0) {  // the int8 refinement copy is a function of (corpus, ids): re-derive it
         IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), N * 256));
         IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), N * 4));
-        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
+        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, 1u << 20)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
                            (uint64_t)N, ix->d_i8, ix->d_i8_scale);
         IVF_HIP(hipGetLastError());
         IVF_HIP(hipStreamSynchronize(ctx->stream));
