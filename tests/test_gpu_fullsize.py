@@ -156,3 +156,34 @@ def test_c2_spec_corpus_duplicates_zero_rows_k_sweep_and_threshold(gpu_ctx):
         assert int(rt.astype(np.int64).sum()) == int(torch.nonzero(inside).sum())
         assert not bool(inside[zero].any()) and not (set(zero.cpu().tolist()) & set(rt.tolist()))
     c.close()
+
+
+def test_ivf_index_encodes_every_row_of_a_seventy_million_row_shard(gpu_ctx):
+    """Regression (round 3): the per-list PCA encoder launched rows x 64 work-items -- more than a dispatch can carry
+    (2^32 - 1) from 67 M rows on -- and at config c5's 100 M rows silently left two thirds of the codes unwritten
+    (recall 0.35 whatever nprobe and re-score depth).  70 M rows: a query planted in the LAST million rows must be found."""
+    import torch
+    import semtools_amd as smt
+
+    rows = 70_000_000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    centres = torch.randn(512, 256, device=dev, generator=g)
+    x = torch.empty((rows, 256), device=dev)
+    for b in range(0, rows, 2_000_000):
+        e = min(rows, b + 2_000_000)
+        c = centres[torch.randint(0, 512, (e - b,), device=dev, generator=g)] + 0.35 * torch.randn(e - b, 256, device=dev, generator=g)
+        x[b:e] = c / c.norm(dim=1, keepdim=True)
+    probes = torch.tensor([5, 20_000_000, 44_000_000, 67_200_000, 69_000_000, rows - 1], device=dev)
+    q = x[probes] + 0.01 * torch.randn(len(probes), 256, device=dev, generator=g)
+    torch.cuda.synchronize()
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=rows)
+    ix = smt.IvfPq(c, nlist=1024, train_iters=4, local_pca=True)
+    got = ix.search(q.cpu().numpy(), top_k=5, nprobe=4, rerank=64)
+    exact = c.search(q.cpu().numpy(), top_k=5)
+    for i, p in enumerate(probes.tolist()):
+        assert got[i][0][0] == p == exact[i][0][0], (i, got[i][0][:3], exact[i][0][:3])
+        assert len(set(got[i][0].tolist()) & set(exact[i][0].tolist())) >= 4
+    ix.close()
+    c.close()
