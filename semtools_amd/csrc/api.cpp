@@ -322,7 +322,6 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_min_nq") ctx->tune.gemm_min_nq = (int)std::max<int64_t>(2, std::min<int64_t>(8, value));
     else if (k == "gemm_min_rows_small") ctx->tune.gemm_min_rows_small = value < 0 ? 0 : value;
     else if (k == "gemm_dma_nt") ctx->tune.gemm_dma_nt = (int)value;
-    else if (k == "embed_wave_per_line") ctx->tune.embed_wave_per_line = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
     else if (k == "prof_every") ctx->tune.prof_every = (int)value;
     else if (k == "merge_on_aux") {

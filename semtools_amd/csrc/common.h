@@ -62,7 +62,6 @@ struct Tuning {
     int merge_on_aux = 0;       // 1: smt_merge_topk_packed_device runs on the aux stream (behind the async select it consumes)
     int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks
-    int embed_wave_per_line = 0; // K1: 1 = one wave per line (whole-row gathers), 0 = 16 lanes per line (4 lines per wave)
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
     int64_t fallback_batch_min_rows = 100000;   // >= 2 uncertain queries of a call on a shard this large are re-answered by ONE batched threshold pass
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)

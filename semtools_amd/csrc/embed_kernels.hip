@@ -9,13 +9,19 @@
 // the output is bit-identical to the oracle (oracle/semtools_oracle.c
 // orc_pool_ids), not merely close.
 //
-// Mapping: 16 lanes (one DPP row) own one line, 4 lines per wave.  Lane a of a
-// row group owns dims {64c + 4a .. 64c + 4a + 3 : c = 0..3}: every gather
-// instruction reads 16 lanes x 16 B = 256 contiguous bytes of a table row
-// (4 instructions cover the 1 KiB row), and each lane's 16 accumulators are
-// independent per-dimension chains, so token order is preserved trivially.
-// The norm's dimension-order chain runs around the row group with DPP
-// row_ror:1 (64 steps x 4 adds), all 4 lines of the wave in parallel.
+// Mapping: 16 lanes (one DPP row) form a GROUP; lane a of a group owns dims {64c + 4a .. 64c + 4a + 3 : c = 0..3}:
+// every gather instruction reads 16 lanes x 16 B = 256 contiguous bytes of a table row (4 instructions cover the
+// 1 KiB row; tools/micro/gather_patterns.hip: this shape pulls random 1 KiB rows at 6.9 TB/s, the streaming ceiling of
+// the part, also with the row number loaded from memory first), and each lane's 16 accumulators are independent
+// per-dimension chains, so token order is preserved trivially.  The norm's dimension-order chain runs around the
+// group with DPP row_ror:1 (64 steps x 4 adds).
+//
+// Work: a group owns a CONTIGUOUS RUN of lines and walks it on its own -- the four groups of a wave share an
+// instruction stream but not a position: each step a group gathers the next 4 tokens of ITS current line, and a
+// group whose line is complete finalises it (mean, norm, store) and moves on while the others keep gathering.  The
+// first version gave a wave four lines and iterated to the longest of them: with ragged lines (0..32 tokens) a third of
+// the gather slots sat idle and the kernel stopped at 5.3 TB/s on uniform ids (0.76 of what the probe shows the part
+// delivers for this access pattern).
 #include "common.h"
 
 namespace smt {
@@ -38,40 +44,42 @@ struct EmbedParams {
     uint32_t max_tokens;
     int normalize;
     float *out;
+    uint64_t lines_per_group;   // a group of 16 lanes walks lines [g * lines_per_group, ...)
 };
 
 __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
 {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
-    const int a = lane & 15;        // position inside the row group
-    const int g = lane >> 4;        // which of the wave's 4 lines
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t line = wave_global * 4 + g;
-    const bool live = line < p.n_lines;
+    const int a = lane & 15;        // position inside the group
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    uint64_t line = group * p.lines_per_group;
+    const uint64_t line_end = min(p.n_lines, line + p.lines_per_group);
+    bool active = line < line_end;                       // group-uniform
 
-    uint64_t t0 = 0, n_tok = 0;
-    if (live) {
-        t0 = p.offsets[line];
-        n_tok = p.offsets[line + 1] - t0;
-        if (p.max_tokens != 0 && n_tok > (uint64_t)p.max_tokens) n_tok = p.max_tokens;
+    // token range of the current line [t, t_end) (max_tokens applied), its token count, and the NEXT line's end (read one
+    // line ahead: a group that moves on must not wait for a dependent offsets load)
+    uint64_t t = 0, t_end = 0, o_end = 0, o_next = 0;
+    if (active) {
+        t = p.offsets[line];
+        o_end = p.offsets[line + 1];
+        o_next = line + 1 < line_end ? p.offsets[line + 2] : o_end;
+        t_end = o_end;
+        if (p.max_tokens != 0 && t_end - t > (uint64_t)p.max_tokens) t_end = t + p.max_tokens;
     }
-    // the wave iterates to the longest of its 4 lines
-    uint64_t n_max = n_tok;
-    n_max = max(n_max, (uint64_t)__shfl_xor((unsigned long long)n_max, 16));
-    n_max = max(n_max, (uint64_t)__shfl_xor((unsigned long long)n_max, 32));
+    uint64_t n_tok = t_end - t;
 
     float4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    constexpr int TU = 4;  // tokens in flight per line
-    for (uint64_t t = 0; t < n_max; t += TU) {
+    constexpr int TU = 4;  // tokens in flight per group
+    while (__any(active)) {
         float4 r[TU][4];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const bool on = (t + u) < n_tok;
-            uint64_t id = on ? (uint64_t)p.ids[t0 + t + u] : 0;
+            const bool on = active && (t + u) < t_end;
+            uint64_t id = on ? (uint64_t)p.ids[t + u] : 0;
             const bool ok = on && id < p.V;  // out-of-vocab ids contribute nothing
             const float4 *row = reinterpret_cast<const float4 *>(p.table + (ok ? id : 0) * 256);
 #pragma unroll
@@ -81,7 +89,7 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
         }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            if ((t + u) < n_tok) {  // token order: u ascending
+            if (active && (t + u) < t_end) {  // token order: u ascending
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     acc[c].x = acc[c].x + r[u][c].x;
@@ -91,106 +99,63 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
                 }
             }
         }
-    }
-
-    const float cnt = (float)(n_tok > 0 ? n_tok : 1);
+        t += TU;
+        if (active && t >= t_end) {
+            // ---- this group's line is complete (the other groups of the wave sit this block out): mean, norm, store
+            const float cnt = (float)(n_tok > 0 ? n_tok : 1);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        acc[c].x = acc[c].x / cnt; acc[c].y = acc[c].y / cnt;
-        acc[c].z = acc[c].z / cnt; acc[c].w = acc[c].w / cnt;
-    }
-
-    if (p.normalize) {
-        // ss = (((0 + v0^2) + v1^2) + ... + v255^2), dimension order.
-        // step s = 16*c + a': the true chain value sits in lane a' of the group;
-        // every lane runs the same instruction stream, only lane a' matters.
-        float sq[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            sq[c][0] = acc[c].x * acc[c].x; sq[c][1] = acc[c].y * acc[c].y;
-            sq[c][2] = acc[c].z * acc[c].z; sq[c][3] = acc[c].w * acc[c].w;
-        }
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int step = 0; step < 16; ++step) {
-                // take the running sum from the previous lane of the row (lane 15 -> lane 0 wraps
-                // into the next 64-dim chunk); at the very first step everyone holds 0.
-                const float in = (c == 0 && step == 0) ? 0.0f : dppf<DPP_ROW_ROR1>(s);
-                s = (((in + sq[c][0]) + sq[c][1]) + sq[c][2]) + sq[c][3];
+            for (int c = 0; c < 4; ++c) {
+                acc[c].x = acc[c].x / cnt; acc[c].y = acc[c].y / cnt;
+                acc[c].z = acc[c].z / cnt; acc[c].w = acc[c].w / cnt;
             }
-        }
-        // after 64 steps the full chain value is in lane 15 of each row group
-        const float ss = __shfl(s, (lane & 48) | 15);
-        float norm = sqrtf(ss);
-        if (!(norm > 1e-12f)) norm = 1e-12f;
+            if (p.normalize) {
+                // ss = (((0 + v0^2) + v1^2) + ... + v255^2), dimension order.
+                // step s = 16*c + a': the true chain value sits in lane a' of the group;
+                // every lane runs the same instruction stream, only lane a' matters.
+                float sq[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            acc[c].x = acc[c].x / norm; acc[c].y = acc[c].y / norm;
-            acc[c].z = acc[c].z / norm; acc[c].w = acc[c].w / norm;
-        }
-    }
-
-    if (live) {
-        float4 *o = reinterpret_cast<float4 *>(p.out + line * 256);
+                for (int c = 0; c < 4; ++c) {
+                    sq[c][0] = acc[c].x * acc[c].x; sq[c][1] = acc[c].y * acc[c].y;
+                    sq[c][2] = acc[c].z * acc[c].z; sq[c][3] = acc[c].w * acc[c].w;
+                }
+                float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[c * 16 + a] = acc[c];
-    }
-}
-
-// ---- variant B: ONE WAVE PER LINE.  Lane l owns dims 4l .. 4l+3, so every gather instruction reads one whole table
-// row -- 1 KiB contiguous, K2-style -- instead of four 256-B pieces of four different rows; 8 tokens in flight.  The
-// per-dimension sums are the same serial f32 chains in token order; the norm's dimension-order chain walks the 64
-// lanes with DPP wave_shr:1 (after step k lane k holds the chain through its own 4 dims), which costs the wave 64 x 5
-// instructions for ONE line where variant A pays them for four -- the price of the coalesced gather.
-constexpr int DPP_WAVE_SHR1_E = 0x138;
-__global__ void __launch_bounds__(256) embed_wave_kernel(EmbedParams p)
-{
-#pragma clang fp contract(off)
-    const int lane = threadIdx.x & 63;
-    const uint64_t line = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
-    if (line >= p.n_lines) return;
-    const uint64_t t0 = p.offsets[line];
-    uint64_t n_tok = p.offsets[line + 1] - t0;
-    if (p.max_tokens != 0 && n_tok > (uint64_t)p.max_tokens) n_tok = p.max_tokens;
-
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int TU = 8;
-    for (uint64_t t = 0; t < n_tok; t += TU) {
-        float4 r[TU];
-        bool ok[TU];
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const bool on = (t + u) < n_tok;                       // wave-uniform
-            const uint64_t id = on ? (uint64_t)p.ids[t0 + t + u] : 0;
-            ok[u] = on && id < p.V;                                // out-of-vocab ids contribute nothing
-            r[u] = reinterpret_cast<const float4 *>(p.table + (ok[u] ? id : 0) * 256)[lane];
-        }
+                    for (int step = 0; step < 16; ++step) {
+                        // take the running sum from the previous lane of the row (lane 15 -> lane 0 wraps
+                        // into the next 64-dim chunk); at the very first step everyone holds 0.
+                        const float in = (c == 0 && step == 0) ? 0.0f : dppf<DPP_ROW_ROR1>(s);
+                        s = (((in + sq[c][0]) + sq[c][1]) + sq[c][2]) + sq[c][3];
+                    }
+                }
+                // after 64 steps the full chain value is in lane 15 of each group
+                const float ss = __shfl(s, (lane & 48) | 15);
+                float norm = sqrtf(ss);
+                if (!(norm > 1e-12f)) norm = 1e-12f;
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            if ((t + u) < n_tok) {                                 // token order: u ascending; an invalid id adds +0
-                const float4 v = ok[u] ? r[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+                for (int c = 0; c < 4; ++c) {
+                    acc[c].x = acc[c].x / norm; acc[c].y = acc[c].y / norm;
+                    acc[c].z = acc[c].z / norm; acc[c].w = acc[c].w / norm;
+                }
             }
+            float4 *o = reinterpret_cast<float4 *>(p.out + line * 256);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                o[c * 16 + a] = acc[c];
+                acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // ---- next line of the run
+            ++line;
+            active = line < line_end;
+            t = o_end;
+            o_end = o_next;
+            if (line + 1 < line_end) o_next = p.offsets[line + 2];
+            t_end = o_end;
+            if (p.max_tokens != 0 && t_end - t > (uint64_t)p.max_tokens) t_end = t + p.max_tokens;
+            n_tok = t_end - t;
         }
     }
-    const float cnt = (float)(n_tok > 0 ? n_tok : 1);
-    acc.x = acc.x / cnt; acc.y = acc.y / cnt; acc.z = acc.z / cnt; acc.w = acc.w / cnt;
-    if (p.normalize) {
-        const float s0 = acc.x * acc.x, s1 = acc.y * acc.y, s2 = acc.z * acc.z, s3 = acc.w * acc.w;
-        float s = 0.0f;
-#pragma unroll 16
-        for (int step = 0; step < 64; ++step) {
-            const float in = step == 0 ? 0.0f : dppf<DPP_WAVE_SHR1_E>(s);   // lane l takes lane l-1's running sum
-            s = (((in + s0) + s1) + s2) + s3;
-        }
-        const float ss = __shfl(s, 63);
-        float norm = sqrtf(ss);
-        if (!(norm > 1e-12f)) norm = 1e-12f;
-        acc.x = acc.x / norm; acc.y = acc.y / norm; acc.z = acc.z / norm; acc.w = acc.w / norm;
-    }
-    reinterpret_cast<float4 *>(p.out + line * 256)[lane] = acc;
 }
 
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
@@ -206,21 +171,15 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     p.max_tokens = max_tokens;
     p.normalize = normalize;
     p.out = out;
-    const int threads = 256;
-    if (ctx->tune.embed_wave_per_line) {           // 4 waves = 4 lines per block
-        const uint64_t blocks = (n_lines + 3) / 4;
-        SMT_REQUIRE(blocks < (1ull << 31), "too many lines for one embed launch");
-        prof_begin(ctx, "embed");
-        hipLaunchKernelGGL(embed_wave_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, p);
-        prof_end(ctx, "embed");
-        SMT_HIP_CHECK(hipGetLastError());
-        return SMT_OK;
-    }
-    const uint64_t waves = (n_lines + 3) / 4;      // 4 waves = 16 lines per block
-    const uint64_t blocks = (waves + 3) / 4;
-    SMT_REQUIRE(blocks < (1ull << 31), "too many lines for one embed launch");
+    // a run of lines per group: enough groups to fill the chip (16 waves x 4 groups per CU), runs long enough that ragged
+    // lines average out inside a run (a group with 100 lines of 0..32 tokens ends within ~5 % of its neighbours)
+    const uint64_t want_groups = (uint64_t)std::max(ctx->num_cus, 1) * 64;
+    p.lines_per_group = std::max<uint64_t>(1, (n_lines + want_groups - 1) / want_groups);
+    const uint64_t groups = (n_lines + p.lines_per_group - 1) / p.lines_per_group;
+    const uint64_t blocks = (groups + 15) / 16;    // 256 threads = 16 groups
+    SMT_REQUIRE(blocks < (1ull << 24), "too many lines for one embed launch");
     prof_begin(ctx, "embed");
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, p);
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
     prof_end(ctx, "embed");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;

@@ -9,17 +9,35 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["16-lanes-per-line", "wave-per-line"])
-def model(gpu_ctx, request):
-    """Both K1 variants (tuning key embed_wave_per_line) must be bit-exact."""
+@pytest.fixture(scope="module")
+def model(gpu_ctx):
     import semtools_amd as smt
 
     table = synth.table(5000, seed=2)
-    gpu_ctx.set_tuning("embed_wave_per_line", request.param)
     m = smt.Model(gpu_ctx, table, normalize=True)
     yield table, m
     m.close()
-    gpu_ctx.set_tuning("embed_wave_per_line", 0)
+
+
+def test_embed_runs_of_lines_per_group_bit_exact(model):
+    """More lines than the chip has lane groups: every group then walks a RUN of consecutive lines on its own (the four
+    groups of a wave at different lines, finishing at different steps).  300 k ragged lines incl. empty ones, lines longer
+    than the cap and a stretch of empty lines: bit-exact, with and without truncation."""
+    table, m = model
+    rng = np.random.default_rng(11)
+    n = 300_000
+    lens = rng.integers(0, 33, size=n)
+    lens[rng.integers(0, n, size=200)] = rng.integers(100, 700, size=200)      # long lines scattered about
+    lens[1000:1040] = 0                                                         # a stretch of empty lines
+    lens[-1] = 0
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    ids = rng.integers(0, 5000, size=int(offsets[-1])).astype(np.uint32)
+    for cap in (2048, 16):
+        got, _ = m.embed(ids, offsets, max_tokens=cap)
+        ref = orc.embed_lines(table, ids, offsets, normalize=True, max_tokens=cap)
+        assert np.array_equal(got, ref), f"cap {cap}: max |diff| {np.abs(got - ref).max()}"
+        assert not got[lens == 0].any()
 
 
 def test_embed_bit_exact(model):
