@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
             const float4 *row = reinterpret_cast<const float4 *>(p.table + (ok ? id : 0) * 256);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                // (plain loads, not nontemporal: natural text is Zipf-distributed and its hot rows must stay in L2 / MALL --
+                // measured with the nt policy: Zipf ids 3.50 -> 4.59 ms, uniform ids 5.97 -> 6.27 ms)
                 r[u][c] = ok ? row[c * 16 + a] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
