@@ -211,10 +211,7 @@ typedef struct smt_ivfpq_params {
     uint32_t nbits;        /* 8                                                           */
     uint32_t train_iters;  /* k-means iterations for both quantisers (0 = 10)            */
     uint64_t train_sample; /* training rows, evenly spaced (0 = 64 * nlist)              */
-    uint32_t refine;       /* 0 = off: 36 B/row index, every ADC candidate is re-scored;      */
-                           /* 1 = keep an int8 copy of the rows (+260 B/row) and prune the    */
-                           /* ADC shortlist with it before the full-precision re-score        */
-                           /* (same recall, ~6 % faster queries: measured, rarely worth it)   */
+    uint32_t reserved;     /* must be 0 (was `refine`: an int8 refinement stage, measured +6 % for a 7x larger index, removed) */
     uint32_t local_pca;    /* 0 = one global residual codebook set (8 dims x 256 codes per sub-quantiser);    */
                            /* 1 = per-list PCA: every list gets its own orthonormal basis of its 32 principal */
                            /* residual directions and one 8-bit scalar quantiser per direction (still 32 B    */

@@ -26,7 +26,7 @@ pub struct SmtIvfpqParams {
     pub nbits: u32,
     pub train_iters: u32,
     pub train_sample: u64,
-    pub refine: u32,
+    pub reserved: u32,
     pub local_pca: u32,
 }
 

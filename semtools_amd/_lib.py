@@ -59,7 +59,7 @@ class SmtRange(C.Structure):
 
 class SmtIvfPqParams(C.Structure):
     _fields_ = [("nlist", C.c_uint32), ("m", C.c_uint32), ("nbits", C.c_uint32), ("train_iters", C.c_uint32),
-                ("train_sample", C.c_uint64), ("refine", C.c_uint32), ("local_pca", C.c_uint32)]
+                ("train_sample", C.c_uint64), ("reserved", C.c_uint32), ("local_pca", C.c_uint32)]
 
 
 class SmtError(RuntimeError):

@@ -240,13 +240,13 @@ class Corpus:
 class IvfPq:
     """IVF-PQ index over a resident Corpus (smt_ivfpq).  Approximate top-k membership, exact distances."""
 
-    def __init__(self, corpus, nlist=4096, train_iters=10, train_sample=0, refine=False, local_pca=False, _path=None):
+    def __init__(self, corpus, nlist=4096, train_iters=10, train_sample=0, local_pca=False, _path=None):
         self.corpus = corpus
         self._h = C.c_void_p()
         if _path is not None:
             L.check(L.lib().smt_ivfpq_load(corpus._h, str(_path).encode(), C.byref(self._h)))
             return
-        prm = L.SmtIvfPqParams(int(nlist), 32, 8, int(train_iters), int(train_sample), 1 if refine else 0, 1 if local_pca else 0)
+        prm = L.SmtIvfPqParams(int(nlist), 32, 8, int(train_iters), int(train_sample), 0, 1 if local_pca else 0)
         L.check(L.lib().smt_ivfpq_build(corpus._h, C.byref(prm), C.byref(self._h)))
 
     def close(self):

@@ -118,13 +118,13 @@ void prof_end(smt_ctx *ctx, const char *name)
     e.used += 2;
 }
 
-static int check_ctx(const smt_ctx *ctx)
+int check_ctx(const smt_ctx *ctx)
 {
     if (!ctx) { set_error("null context"); return SMT_E_INVALID; }
     return SMT_OK;
 }
 
-static int bind_device(smt_ctx *ctx, bool drain = true)
+int bind_device(smt_ctx *ctx, bool drain)
 {
     SMT_HIP_CHECK(hipSetDevice(ctx->device));
     return drain ? drain_async(ctx) : SMT_OK;
@@ -142,6 +142,27 @@ static uint64_t fnv1a(const uint8_t *b, uint64_t n)
     uint64_t h = 0xcbf29ce484222325ull;
     for (uint64_t i = 0; i < n; ++i) { h ^= (uint64_t)b[i]; h *= 0x100000001b3ull; }
     return h;
+}
+
+int corpus_reserve(smt_corpus *c, uint64_t rows_needed)
+{
+    if (rows_needed <= c->capacity) return SMT_OK;
+    if (!c->owned) { set_error("corpus adopted from device memory cannot grow"); return SMT_E_NOMEM; }
+    uint64_t cap = std::max<uint64_t>(c->capacity * 2, rows_needed);
+    cap = std::max<uint64_t>(cap, 1024);
+    float *nd = nullptr;
+    const size_t bytes = (size_t)cap * c->dim * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&nd), bytes);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) for corpus rows: %s", bytes, hipGetErrorString(e)); return SMT_E_NOMEM; }
+    if (c->rows) {
+        e = hipMemcpyAsync(nd, c->d_rows, (size_t)c->rows * c->dim * sizeof(float), hipMemcpyDeviceToDevice, c->ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(nd); set_error("corpus grow copy: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+    }
+    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    if (c->d_rows) (void)hipFree(c->d_rows);
+    c->d_rows = nd;
+    c->capacity = cap;
+    return SMT_OK;
 }
 
 }  // namespace smt
@@ -394,27 +415,6 @@ void smt_model_destroy(smt_model *model)
 
 /* --------------------------------------------------------------- corpus ---- */
 
-static int corpus_reserve(smt_corpus *c, uint64_t rows_needed)
-{
-    if (rows_needed <= c->capacity) return SMT_OK;
-    if (!c->owned) { set_error("corpus adopted from device memory cannot grow"); return SMT_E_NOMEM; }
-    uint64_t cap = std::max<uint64_t>(c->capacity * 2, rows_needed);
-    cap = std::max<uint64_t>(cap, 1024);
-    float *nd = nullptr;
-    const size_t bytes = (size_t)cap * c->dim * sizeof(float);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&nd), bytes);
-    if (e != hipSuccess) { set_error("hipMalloc(%zu) for corpus rows: %s", bytes, hipGetErrorString(e)); return SMT_E_NOMEM; }
-    if (c->rows) {
-        e = hipMemcpyAsync(nd, c->d_rows, (size_t)c->rows * c->dim * sizeof(float), hipMemcpyDeviceToDevice, c->ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(nd); set_error("corpus grow copy: %s", hipGetErrorString(e)); return SMT_E_HIP; }
-    }
-    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
-    if (c->d_rows) (void)hipFree(c->d_rows);
-    c->d_rows = nd;
-    c->capacity = cap;
-    return SMT_OK;
-}
-
 int smt_corpus_create(smt_ctx *ctx, uint32_t D, uint64_t capacity_rows, smt_corpus **out)
 {
     int rc = check_ctx(ctx);
@@ -510,323 +510,6 @@ int smt_corpus_truncate(smt_corpus *c, uint64_t n_rows)
     SMT_REQUIRE(c != nullptr, "corpus");
     SMT_REQUIRE(n_rows <= c->rows, "cannot truncate to more rows than stored");
     c->rows = n_rows;
-    return SMT_OK;
-}
-
-struct CorpusFileHeader {  // 32 bytes, little endian
-    char magic[8];         // "SMTCORP1"
-    uint32_t dim;
-    uint32_t reserved;
-    uint64_t rows;
-    uint64_t reserved2;
-};
-
-}  // extern "C"
-
-namespace smt {
-
-// Two pinned staging buffers + one event each: the file transfer of chunk j+1 overlaps the PCIe transfer of
-// chunk j (the first version read 64 K-row chunks into a pageable vector and copied them synchronously).
-struct PinnedPair {
-    void *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    bool busy[2] = {false, false};
-    size_t bytes = 0;
-    int init(size_t want)
-    {
-        bytes = want;
-        for (int i = 0; i < 2; ++i) {
-            SMT_HIP_CHECK(hipHostMalloc(&buf[i], bytes, hipHostMallocDefault));
-            SMT_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-        }
-        return SMT_OK;
-    }
-    int wait(int i)
-    {
-        if (busy[i]) { SMT_HIP_CHECK(hipEventSynchronize(ev[i])); busy[i] = false; }
-        return SMT_OK;
-    }
-    ~PinnedPair()
-    {
-        for (int i = 0; i < 2; ++i) {
-            if (ev[i]) { if (busy[i]) (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
-            if (buf[i]) (void)hipHostFree(buf[i]);
-        }
-    }
-};
-
-static size_t io_chunk_rows(uint64_t n_rows)
-{
-    // 32 MiB chunks for big files, two chunks for small ones (a 1 k-line corpus must not pin 64 MiB)
-    const uint64_t big = 32768;
-    return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(big, (n_rows + 1) / 2));
-}
-
-int corpus_file_info(const char *path, uint64_t *rows, uint32_t *dim)
-{
-    FILE *f = fopen(path, "rb");
-    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    CorpusFileHeader h;
-    const bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "SMTCORP1", 8) == 0;
-    bool sized = false;
-    if (ok && fseek(f, 0, SEEK_END) == 0) {
-        const long long sz = ftello(f);
-        sized = sz >= 0 && (uint64_t)sz >= sizeof(h) + h.rows * (uint64_t)h.dim * sizeof(float);
-    }
-    fclose(f);
-    if (!ok) { set_error("'%s' is not a corpus file", path); return SMT_E_IO; }
-    if (!sized) { set_error("'%s' is truncated", path); return SMT_E_IO; }
-    *rows = h.rows;
-    *dim = h.dim;
-    return SMT_OK;
-}
-
-// Append rows [first_row, first_row + n_rows) of the corpus file to `c`.
-int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint64_t n_rows)
-{
-    if (n_rows == 0) return SMT_OK;
-    smt_ctx *ctx = c->ctx;
-    int rc = bind_device(ctx);
-    if (rc) return rc;
-    if ((rc = corpus_reserve(c, c->rows + n_rows))) return rc;
-    FILE *f = fopen(path, "rb");
-    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    const size_t row_bytes = (size_t)c->dim * sizeof(float);
-    if (fseeko(f, (off_t)(sizeof(CorpusFileHeader) + first_row * row_bytes), SEEK_SET) != 0) {
-        fclose(f); set_error("seek in '%s': %s", path, strerror(errno)); return SMT_E_IO;
-    }
-    const size_t chunk = io_chunk_rows(n_rows);
-    PinnedPair pp;
-    if ((rc = pp.init(chunk * row_bytes))) { fclose(f); return rc; }
-    int j = 0;
-    for (uint64_t r = 0; r < n_rows; r += chunk, j ^= 1) {
-        const size_t n = (size_t)std::min<uint64_t>(chunk, n_rows - r);
-        if ((rc = pp.wait(j))) { fclose(f); return rc; }
-        if (fread(pp.buf[j], row_bytes, n, f) != n) { fclose(f); set_error("'%s' is truncated", path); return SMT_E_IO; }
-        hipError_t e = hipMemcpyAsync(c->d_rows + (size_t)(c->rows + r) * c->dim, pp.buf[j], n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
-        if (e != hipSuccess) { fclose(f); set_error("corpus upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
-        pp.busy[j] = true;
-    }
-    fclose(f);
-    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    pp.busy[0] = pp.busy[1] = false;
-    c->rows += n_rows;
-    return SMT_OK;
-}
-
-// Create `path` with a header announcing total_rows and its final size (slices are then written in place).
-int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows)
-{
-    FILE *f = fopen(path, "wb");
-    if (!f) { set_error("cannot open '%s' for writing: %s", path, strerror(errno)); return SMT_E_IO; }
-    CorpusFileHeader h;
-    memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SMTCORP1", 8);
-    h.dim = dim;
-    h.rows = total_rows;
-    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
-    ok = ok && fflush(f) == 0 && ftruncate(fileno(f), (off_t)(sizeof(h) + total_rows * (uint64_t)dim * sizeof(float))) == 0;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("cannot write '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    return SMT_OK;
-}
-
-// Write runs of rows of `c` into the (existing) corpus file: run j = local rows [local_first, local_first + n_rows) at file
-// row position file_first_row.  One open / fsync for all runs; the D2H of chunk j+1 flies while chunk j is written.
-int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_t n_runs)
-{
-    smt_ctx *ctx = c->ctx;
-    int rc = bind_device(ctx);
-    if (rc) return rc;
-    uint64_t total = 0, longest = 0;
-    for (size_t j = 0; j < n_runs; ++j) {
-        SMT_REQUIRE(runs[j].local_first + runs[j].n_rows <= c->rows, "run extends past the shard");
-        total += runs[j].n_rows;
-        longest = std::max(longest, runs[j].n_rows);
-    }
-    if (total == 0) return SMT_OK;
-    const size_t chunk = io_chunk_rows(longest);
-    struct Chunk { uint64_t local, n, file_row; };
-    std::vector<Chunk> chunks;
-    for (size_t j = 0; j < n_runs; ++j)
-        for (uint64_t r = 0; r < runs[j].n_rows; r += chunk)
-            chunks.push_back({runs[j].local_first + r, std::min<uint64_t>(chunk, runs[j].n_rows - r), runs[j].file_first_row + r});
-    FILE *f = fopen(path, "r+b");
-    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
-    const size_t row_bytes = (size_t)c->dim * sizeof(float);
-    PinnedPair pp;
-    if ((rc = pp.init(chunk * row_bytes))) { fclose(f); return rc; }
-    auto issue = [&](size_t k, int j) -> int {
-        hipError_t e = hipMemcpyAsync(pp.buf[j], c->d_rows + (size_t)chunks[k].local * c->dim, (size_t)chunks[k].n * row_bytes,
-                                      hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
-        if (e != hipSuccess) { set_error("corpus download: %s", hipGetErrorString(e)); return SMT_E_HIP; }
-        pp.busy[j] = true;
-        return SMT_OK;
-    };
-    if ((rc = issue(0, 0))) { fclose(f); return rc; }
-    int j = 0;
-    bool ok = true;
-    uint64_t file_at = UINT64_MAX;
-    for (size_t k = 0; k < chunks.size() && ok; ++k, j ^= 1) {
-        if (k + 1 < chunks.size() && (rc = issue(k + 1, j ^ 1))) { fclose(f); return rc; }
-        if ((rc = pp.wait(j))) { fclose(f); return rc; }
-        if (file_at != chunks[k].file_row)
-            ok = fseeko(f, (off_t)(sizeof(CorpusFileHeader) + chunks[k].file_row * row_bytes), SEEK_SET) == 0;
-        ok = ok && fwrite(pp.buf[j], row_bytes, (size_t)chunks[k].n, f) == (size_t)chunks[k].n;
-        file_at = chunks[k].file_row + chunks[k].n;
-    }
-    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("short write to '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    return SMT_OK;
-}
-
-// Write every row of `c` into the (existing) corpus file at row position file_first_row.
-int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row)
-{
-    const FileRun run{0, c->rows, file_first_row};
-    return corpus_save_runs(c, path, &run, 1);
-}
-
-// Header of an existing corpus file: check it describes `dim`-wide rows and holds exactly `expect_rows`; then (new_rows !=
-// expect_rows) grow the file to new_rows WITHOUT touching the header -- corpus_file_commit writes it last, so a crash in
-// between leaves the old, consistent prefix.
-int corpus_file_extend(const char *path, uint32_t dim, uint64_t expect_rows, uint64_t new_rows)
-{
-    FILE *f = fopen(path, "r+b");
-    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
-    CorpusFileHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTCORP1", 8) != 0 || h.dim != dim || h.rows != expect_rows) {
-        fclose(f);
-        set_error("'%s' does not hold exactly the first %llu rows of this corpus", path, (unsigned long long)expect_rows);
-        return SMT_E_IO;
-    }
-    bool ok = ftruncate(fileno(f), (off_t)(sizeof(h) + new_rows * (uint64_t)dim * sizeof(float))) == 0;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("cannot grow '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    return SMT_OK;
-}
-
-int corpus_file_commit(const char *path, uint64_t rows)
-{
-    FILE *f = fopen(path, "r+b");
-    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
-    CorpusFileHeader h;
-    bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "SMTCORP1", 8) == 0;
-    h.rows = rows;
-    ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1 && fflush(f) == 0 && fsync(fileno(f)) == 0;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("cannot update the header of '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    return SMT_OK;
-}
-
-}  // namespace smt
-
-extern "C" {
-
-int smt_corpus_save(smt_corpus *c, const char *path)
-{
-    SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
-    // never rewrite the live file in place: a crash or ENOSPC half way would leave a truncated corpus that
-    // every later workspace command rejects.  Write a sibling, fsync, rename.
-    const std::string tmp = std::string(path) + ".tmp";
-    int rc = corpus_file_begin(tmp.c_str(), c->dim, c->rows);
-    if (!rc) rc = corpus_save_slice(c, tmp.c_str(), 0);
-    if (rc) { (void)remove(tmp.c_str()); return rc; }
-    if (rename(tmp.c_str(), path) != 0) {
-        set_error("rename '%s' -> '%s': %s", tmp.c_str(), path, strerror(errno));
-        (void)remove(tmp.c_str());
-        return SMT_E_IO;
-    }
-    return SMT_OK;
-}
-
-int smt_corpus_append_to_file(smt_corpus *c, const char *path, uint64_t rows_on_disk)
-{
-    SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
-    SMT_REQUIRE(rows_on_disk <= c->rows, "file holds more rows than the corpus");
-    int rc = bind_device(c->ctx);
-    if (rc) return rc;
-    FILE *f = fopen(path, "r+b");
-    if (!f) { set_error("cannot open '%s' for update: %s", path, strerror(errno)); return SMT_E_IO; }
-    CorpusFileHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMTCORP1", 8) != 0 || h.dim != c->dim || h.rows != rows_on_disk) {
-        fclose(f);
-        set_error("'%s' does not hold exactly the first %llu rows of this corpus", path, (unsigned long long)rows_on_disk);
-        return SMT_E_IO;
-    }
-    bool ok = fseek(f, (long)(sizeof(h) + (size_t)rows_on_disk * c->dim * sizeof(float)), SEEK_SET) == 0;
-    const uint64_t chunk_rows = 65536;
-    std::vector<float> buf((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(c->rows - rows_on_disk, 1)) * c->dim);
-    for (uint64_t r = rows_on_disk; ok && r < c->rows; r += chunk_rows) {
-        const uint64_t n = std::min(chunk_rows, c->rows - r);
-        rc = smt_corpus_read_rows(c, r, n, buf.data());
-        if (rc) { fclose(f); return rc; }
-        ok = fwrite(buf.data(), sizeof(float), (size_t)n * c->dim, f) == (size_t)n * c->dim;
-    }
-    h.rows = c->rows;  // header last: a crash before this point leaves the old, consistent prefix
-    ok = ok && fflush(f) == 0 && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("short write to '%s'", path); return SMT_E_IO; }
-    return SMT_OK;
-}
-
-int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
-{
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
-    SMT_REQUIRE(path && out, "null argument");
-    *out = nullptr;
-    uint64_t rows = 0;
-    uint32_t dim = 0;
-    if ((rc = corpus_file_info(path, &rows, &dim))) return rc;
-    smt_corpus *c = nullptr;
-    if ((rc = smt_corpus_create(ctx, dim, rows, &c))) return rc;
-    if ((rc = corpus_load_slice(c, path, 0, rows))) { smt_corpus_destroy(c); return rc; }
-    *out = c;
-    return SMT_OK;
-}
-
-int smt_model_create_from_file(smt_ctx *ctx, const char *path, uint64_t byte_offset, uint64_t V, uint32_t D, int normalize,
-                               smt_model **out)
-{
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
-    SMT_REQUIRE(out && path, "null argument");
-    *out = nullptr;
-    if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
-    SMT_REQUIRE(V > 0, "empty table");
-    if ((rc = bind_device(ctx))) return rc;
-    FILE *f = fopen(path, "rb");
-    if (!f) { set_error("cannot open '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    if (fseeko(f, (off_t)byte_offset, SEEK_SET) != 0) { fclose(f); set_error("seek in '%s': %s", path, strerror(errno)); return SMT_E_IO; }
-    smt_model *m = new (std::nothrow) smt_model();
-    if (!m) { fclose(f); set_error("out of host memory"); return SMT_E_NOMEM; }
-    m->ctx = ctx; m->V = V; m->D = D; m->normalize = normalize ? 1 : 0; m->owned = true;
-    const size_t row_bytes = (size_t)D * sizeof(float);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_table), (size_t)V * row_bytes);
-    if (e != hipSuccess) { fclose(f); delete m; set_error("hipMalloc for the embedding table: %s", hipGetErrorString(e)); return SMT_E_NOMEM; }
-    auto bail = [&](int code) { fclose(f); (void)hipStreamSynchronize(ctx->stream); (void)hipFree(m->d_table); delete m; return code; };
-    const size_t chunk = io_chunk_rows(V);
-    PinnedPair pp;
-    if ((rc = pp.init(chunk * row_bytes))) return bail(rc);
-    int j = 0;
-    for (uint64_t r = 0; r < V; r += chunk, j ^= 1) {
-        const size_t n = (size_t)std::min<uint64_t>(chunk, V - r);
-        if ((rc = pp.wait(j))) return bail(rc);
-        if (fread(pp.buf[j], row_bytes, n, f) != n) { set_error("'%s' is truncated", path); return bail(SMT_E_IO); }
-        e = hipMemcpyAsync(m->d_table + (size_t)r * D, pp.buf[j], n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
-        if (e != hipSuccess) { set_error("table upload: %s", hipGetErrorString(e)); return bail(SMT_E_HIP); }
-        pp.busy[j] = true;
-    }
-    fclose(f);
-    e = hipStreamSynchronize(ctx->stream);
-    pp.busy[0] = pp.busy[1] = false;
-    if (e != hipSuccess) { (void)hipFree(m->d_table); delete m; set_error("table upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
-    *out = m;
     return SMT_OK;
 }
 

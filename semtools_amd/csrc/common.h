@@ -126,6 +126,9 @@ struct smt_model {
 
 namespace smt {
 
+int check_ctx(const smt_ctx *ctx);
+int bind_device(smt_ctx *ctx, bool drain = true);   // hipSetDevice + (drain) wait for async selects
+int corpus_reserve(smt_corpus *c, uint64_t rows_needed);
 int ensure_scratch(smt_ctx *ctx, size_t bytes);
 int ensure_pinned(smt_ctx *ctx, size_t bytes);
 int ensure_stage(smt_ctx *ctx, size_t bytes);

@@ -449,25 +449,6 @@ __global__ void ivf_lut_kernel(const float *queries, const float *codebooks, flo
     lut[((size_t)qi * PQ_M + s) * PQ_K + code] = acc;
 }
 
-// int8 copy of the rows in LIST order: x ~= scale * q, scale = max|x| / 127 (one wave per row)
-__global__ void quantize_rows_kernel(const float *rows, const uint32_t *ids, uint64_t n, uint8_t *out, float *scale)
-{
-    const int lane = threadIdx.x & 63;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);   // grid-stride: a launch holds < 2^32 work-items
-    for (uint64_t pos = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pos < n; pos += n_waves) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(rows + (uint64_t)ids[pos] * 256)[lane];
-        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        const float sc = m > 0.0f ? m / 127.0f : 1.0f;
-        const float inv = 1.0f / sc;
-        const uint32_t b0 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.x * inv), b1 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.y * inv);
-        const uint32_t b2 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.z * inv), b3 = (uint32_t)(uint8_t)(int8_t)__float2int_rn(v.w * inv);
-        reinterpret_cast<uint32_t *>(out + pos * 256)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        if (lane == 0) scale[pos] = sc;
-    }
-}
-
 // ------------------------------------------------------------------ per-list PCA codes (index kind 1)
 // A global residual codebook (8 dims x 256 codes per sub-quantiser, above) spends its bits on all 256 coordinates
 // of a residual alike: 25 % relative distortion per sub-vector, which on clustered data ranks the rows INSIDE a
@@ -681,9 +662,6 @@ struct AdcParams {
     const uint8_t *codes;      // [N][32] in list order
     const uint32_t *ids;       // [N] corpus row of each code
     const float *corpus;       // full-precision rows for the in-kernel re-score
-    const uint8_t *i8;         // [N][256] int8 rows in LIST order (same index as codes), or nullptr
-    const float *i8_scale;     // [N] row = scale * int8
-    uint32_t refine_keep;      // per wave: ADC shortlist -> this many by the int8 dot product -> full-precision re-score
     uint32_t n_seg;            // blocks per (query, probed list): a list is cut into segments of seg_len codes, each
     uint32_t seg_len;          //   with its own shortlist -- the re-scored fraction of a LONG list stays what it is for a short one
     uint32_t shortlist;        // ADC candidates kept per WAVE (<= 64); 4 or 8 waves per (query, list segment)
@@ -850,43 +828,11 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         lr = mine != KEY_PAD ? (uint32_t)(mine & 0xFFFFFFFFull) : 0xFFFFFFFFu;
     }
 
-    // ---- stage 1.5 (opt-in, smt_ivfpq_params.refine): int8 refinement.  A full-precision re-score reads 1 KiB per
-    // candidate; the int8 copy of a row is 256 B and ranks the shortlist well enough (same recall) that only
-    // `refine_keep` candidates per wave go on to stage 2.  Measured: the kernel is bound by the shortlist
-    // maintenance of stage 1, not by the re-score reads -- 8x fewer full-precision reads buy 6 % (0.875 -> 0.82 ms
-    // per 1000 queries), which does not pay for 260 B/row of index, hence off by default.
+    // (An int8 refinement stage between the two -- a 260 B/row copy of the rows ranking the shortlist so that only a few
+    // candidates need their 1 KiB row -- was built in round 1, measured at +6 % queries/s for a 7x larger index, kept opt-in
+    // for two rounds and removed in round 3.)
     const int n_short = __popcll(__ballot(lr != 0xFFFFFFFFu));  // the set sits in lanes 0..n_short-1
     unsigned long long go = n_short >= 64 ? ~0ull : ((1ull << n_short) - 1ull);  // lanes whose candidate is re-scored
-    if (p.i8 != nullptr && n_short > (int)p.refine_keep) {
-        float rd = __builtin_inff();  // lane i: refined distance of shortlist entry i
-        for (int i0 = 0; i0 < n_short; i0 += 4) {
-            uint32_t w[4];
-            float sc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u < n_short ? i0 + u : n_short - 1;
-                const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)lr, i);
-                w[u] = reinterpret_cast<const uint32_t *>(p.i8 + (uint64_t)pos * 256)[lane];  // 256 B per row, coalesced
-                sc[u] = p.i8_scale[pos];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float x0 = (float)(int8_t)(w[u] & 0xFF), x1 = (float)(int8_t)((w[u] >> 8) & 0xFF);
-                const float x2 = (float)(int8_t)((w[u] >> 16) & 0xFF), x3 = (float)(int8_t)(w[u] >> 24);
-                const float dot = wave_sum(x0 * qv.x + x1 * qv.y + x2 * qv.z + x3 * qv.w) * sc[u];
-                if (lane == i0 + u) rd = fmaxf(1.0f - dot * rq, 0.0f);
-            }
-        }
-        // rank of my candidate among the wave's (refined distance, position): keep the refine_keep best
-        const unsigned long long mykey = ((unsigned long long)__float_as_uint(rd) << 32) | lr;
-        int rank = 0;
-        for (int i = 0; i < n_short; ++i) {
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), i);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mykey, i);
-            rank += ((((unsigned long long)hi << 32) | lo) < mykey) ? 1 : 0;
-        }
-        go = __ballot(lane < n_short && rank < (int)p.refine_keep);
-    }
 
     // ---- stage 2: re-score the survivors with the full-precision rows (coalesced 1 KiB loads, f32),
     //      keep the kp best; the select stage then recomputes those exactly in f64
@@ -943,8 +889,6 @@ struct smt_ivfpq {
     uint8_t *d_codes = nullptr;     // [N][32] list order
     uint32_t *d_ids = nullptr;      // [N]
     uint64_t *d_offsets = nullptr;  // [nlist+1]
-    uint8_t *d_i8 = nullptr;        // [N][256] int8 rows, list order (refinement stage; nullptr = off)
-    float *d_i8_scale = nullptr;    // [N]
     uint32_t kind = 0;              // 0: global residual codebooks (dsub 8); 1: per-list PCA basis + 8-bit scalar codes
     float *d_basis = nullptr;       // kind 1: [nlist][32][256]
     float *d_lscale = nullptr;      // kind 1: [nlist][32]
@@ -1047,7 +991,7 @@ void smt_ivfpq_destroy(smt_ivfpq *ix)
     if (!ix) return;
     if (ix->corpus) { (void)hipSetDevice(ix->corpus->ctx->device); (void)hipStreamSynchronize(ix->corpus->ctx->stream); }
     for (void *p : {(void *)ix->d_centroids, (void *)ix->d_cnorm_half, (void *)ix->d_codebooks, (void *)ix->d_codes, (void *)ix->d_ids,
-                    (void *)ix->d_offsets, (void *)ix->d_i8, (void *)ix->d_i8_scale, (void *)ix->d_basis, (void *)ix->d_lscale})
+                    (void *)ix->d_offsets, (void *)ix->d_basis, (void *)ix->d_lscale})
         if (p) (void)hipFree(p);
     delete ix;
 }
@@ -1074,6 +1018,7 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
     const uint64_t N = corpus->rows;
     SMT_REQUIRE(prm->m == PQ_M && prm->nbits == 8, "this build supports m = 32 sub-quantisers of 8 bits");
     SMT_REQUIRE(prm->local_pca <= 1, "local_pca must be 0 or 1");
+    SMT_REQUIRE(prm->reserved == 0, "smt_ivfpq_params.reserved must be 0 (it was `refine`, the int8 refinement stage removed in round 3)");
     const bool lpca = prm->local_pca == 1;
     SMT_REQUIRE(prm->nlist >= 32 && prm->nlist <= PROBE_MAX_LISTS && prm->nlist % 32 == 0, "nlist must be a multiple of 32 in [32, 4096]");
     SMT_REQUIRE(N >= (uint64_t)prm->nlist && N < 0xFFFFFFFFull, "corpus (shard) needs at least nlist rows");
@@ -1209,12 +1154,6 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
                            PQ_SMEM, ctx->stream, q);
     }
     hipLaunchKernelGGL(cnorm_half_kernel, dim3((nlist + 3) / 4), dim3(256), 0, ctx->stream, ix->d_centroids, nlist, ix->d_cnorm_half);
-    if (prm->refine == 1) {  // opt-in: keep an int8 copy of the rows (256 B + 4 B per row) for the refinement stage
-        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), (size_t)N * 256));
-        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), (size_t)N * 4));
-        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, 1u << 20)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
-                           N, ix->d_i8, ix->d_i8_scale);
-    }
     IVF_HIP(hipEventRecord(ev[4], ctx->stream));
     IVF_HIP(hipGetLastError());
     IVF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1237,7 +1176,7 @@ int smt_ivfpq_info(const smt_ivfpq *ix, uint64_t *n_rows, uint32_t *nlist, uint6
     if (nlist) *nlist = ix->nlist;
     if (index_bytes)
         *index_bytes = (uint64_t)ix->n_rows * (PQ_M + 4) + (uint64_t)ix->nlist * 256 * 4 + (uint64_t)PQ_M * PQ_K * PQ_DSUB * 4 +
-                       (uint64_t)(ix->nlist + 1) * 8 + (ix->d_i8 ? (uint64_t)ix->n_rows * 260 : 0) +
+                       (uint64_t)(ix->nlist + 1) * 8 +
                        (ix->kind == 1 ? (uint64_t)ix->nlist * LP_DIMS * 257 * 4 : 0);
     if (build_ms4) for (int i = 0; i < 4; ++i) build_ms4[i] = ix->build_ms[i];
     return SMT_OK;
@@ -1339,9 +1278,6 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     ap.codes = ix->d_codes;
     ap.ids = ix->d_ids;
     ap.corpus = ix->corpus->d_rows;
-    ap.i8 = ix->d_i8;
-    ap.i8_scale = ix->d_i8_scale;
-    ap.refine_keep = std::max<uint32_t>(8u, (kp + adc_waves - 1) / adc_waves);
     ap.n_seg = n_seg;
     ap.seg_len = seg_len ? seg_len : 512;
     ap.shortlist = shortlist;
@@ -1530,7 +1466,6 @@ int smt_ivfpq_append(smt_ivfpq *ix, uint64_t *n_added)
     SMT_REQUIRE(corpus->rows >= ix->n_rows, "the corpus shrank since the index was built: rebuild");
     const uint64_t n_old = ix->n_rows, n_new = corpus->rows - n_old, N = corpus->rows;
     if (n_new == 0) return SMT_OK;
-    if (ix->d_i8) { smt::set_error("an index with the int8 refinement copy cannot be extended: rebuild"); return SMT_E_UNSUPPORTED; }
     SMT_REQUIRE(N < 0xFFFFFFFFull, "a shard holds fewer than 2^32-1 rows");
     IVF_HIP(hipSetDevice(ctx->device));
     { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
@@ -1617,7 +1552,7 @@ int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
     h.nbits = 8;
     h.dim = 256;
     h.n_rows = ix->n_rows;
-    h.pad[0] = ix->d_i8 ? 1 : 0;  // 1 = built with the int8 refinement copy (never stored: load re-derives it from the corpus)
+    h.pad[0] = 0;  // (1 marked an index built with the int8 refinement copy, removed in round 3: load refuses such files)
     h.pad[1] = (uint8_t)ix->kind; // 1 = per-list PCA bases + scalar codes follow the codes
     std::vector<char> buf;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
@@ -1689,14 +1624,14 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
         ok = ok && read_dev(f, ix->d_lscale, (size_t)h.nlist * LP_DIMS * 4, ctx->stream, buf);
     }
     if (!ok) { smt::set_error("'%s' is truncated or unreadable", path); return SMT_E_IO; }
+    if (h.pad[0] == 1) { smt::set_error("'%s' was built with the int8 refinement stage (removed): rebuild the index", path); return SMT_E_INVALID; }
     // the list table must be consistent with the row count, or the ADC kernel would read out of bounds
     std::vector<uint64_t> offs((size_t)h.nlist + 1);
     IVF_HIP(hipMemcpy(offs.data(), ix->d_offsets, offs.size() * 8, hipMemcpyDeviceToHost));
     bool sane = offs[0] == 0 && offs[h.nlist] == h.n_rows;
     for (uint32_t l = 0; sane && l < h.nlist; ++l) sane = offs[l] <= offs[l + 1];
     if (!sane) { smt::set_error("'%s': corrupt list offsets", path); return SMT_E_IO; }
-    // ... and every stored row id must name a row of THIS corpus: the re-score and the int8 refinement gather
-    // corpus rows by id (a stale or corrupt file would otherwise read out of bounds)
+    // ... and every stored row id must name a row of THIS corpus: the re-score gathers corpus rows by id (a stale or corrupt file would otherwise read out of bounds)
     if (N > 0) {
         int rc_s = smt::ensure_scratch(ctx, 64);
         if (rc_s) return rc_s;
@@ -1711,14 +1646,6 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     }
     ix->max_list = 0;
     for (uint32_t l = 0; l < h.nlist; ++l) ix->max_list = std::max<uint64_t>(ix->max_list, offs[l + 1] - offs[l]);
-    if (h.pad[0] == 1 && N > 0) {  // the int8 refinement copy is a function of (corpus, ids): re-derive it
-        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), N * 256));
-        IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8_scale), N * 4));
-        hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, 1u << 20)), dim3(256), 0, ctx->stream, corpus->d_rows, ix->d_ids,
-                           (uint64_t)N, ix->d_i8, ix->d_i8_scale);
-        IVF_HIP(hipGetLastError());
-        IVF_HIP(hipStreamSynchronize(ctx->stream));
-    }
     *out = guard.release();
     return SMT_OK;
 }

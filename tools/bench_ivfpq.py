@@ -14,7 +14,6 @@ def main():
     ap.add_argument("--nlist", type=int, default=4096)
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--refine", action="store_true", help="build with the int8 refinement copy (+260 B/row)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     x = synth.clustered_rows_torch(args.rows, 4096, 8, 11, dev)
@@ -26,7 +25,7 @@ def main():
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=args.rows)
     qh = q.cpu().numpy()
     t0 = time.perf_counter()
-    ix = smt.IvfPq(corpus, nlist=args.nlist, train_iters=10, refine=args.refine)
+    ix = smt.IvfPq(corpus, nlist=args.nlist, train_iters=10)
     build_s = time.perf_counter() - t0
     info = ix.info()
     sizes = ix.list_sizes()
