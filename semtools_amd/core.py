@@ -100,7 +100,10 @@ class Model:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            L.lib().smt_model_destroy(self._h)
+            # a handle that outlived its Context (an error path, garbage collection at interpreter exit) is dropped, not
+            # destroyed: smt_model_destroy would read the freed context (the C ABI's rule is children first)
+            if getattr(getattr(self, "ctx", None), "_h", None):
+                L.lib().smt_model_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -155,7 +158,7 @@ class Corpus:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            if not getattr(self, "_borrowed", False):
+            if not getattr(self, "_borrowed", False) and getattr(getattr(self, "ctx", None), "_h", None):   # (see Model.close)
                 L.lib().smt_corpus_destroy(self._h)
             self._h = None
 

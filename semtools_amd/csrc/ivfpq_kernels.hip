@@ -881,6 +881,7 @@ using namespace smt;
 
 struct smt_ivfpq {
     smt_corpus *corpus = nullptr;
+    int device = -1;                // the corpus' GPU (recorded so that destroy never has to look at the corpus)
     uint64_t n_rows = 0;
     uint32_t nlist = 0;
     float *d_centroids = nullptr;   // [nlist][256]
@@ -989,7 +990,11 @@ extern "C" {
 void smt_ivfpq_destroy(smt_ivfpq *ix)
 {
     if (!ix) return;
-    if (ix->corpus) { (void)hipSetDevice(ix->corpus->ctx->device); (void)hipStreamSynchronize(ix->corpus->ctx->stream); }
+    // The index is documented to be destroyed BEFORE its corpus, but a caller that gets the order wrong (a garbage
+    // collector at interpreter exit, an error path) must not turn that into a use-after-free: nothing here touches the
+    // corpus or its context -- the device ordinal was recorded at build / load time, and hipDeviceSynchronize covers
+    // whatever stream the index's last kernels ran on.
+    if (ix->device >= 0) { (void)hipSetDevice(ix->device); (void)hipDeviceSynchronize(); }
     for (void *p : {(void *)ix->d_centroids, (void *)ix->d_cnorm_half, (void *)ix->d_codebooks, (void *)ix->d_codes, (void *)ix->d_ids,
                     (void *)ix->d_offsets, (void *)ix->d_basis, (void *)ix->d_lscale})
         if (p) (void)hipFree(p);
@@ -1032,6 +1037,7 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
     if (!ix) { smt::set_error("out of host memory"); return SMT_E_NOMEM; }
     std::unique_ptr<smt_ivfpq, void (*)(smt_ivfpq *)> guard(ix, smt_ivfpq_destroy);
     ix->corpus = corpus;
+    ix->device = corpus->ctx->device;
     ix->n_rows = N;
     ix->nlist = nlist;
     ix->kind = lpca ? 1u : 0u;
@@ -1599,6 +1605,7 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     if (!ix) { smt::set_error("out of host memory"); return SMT_E_NOMEM; }
     std::unique_ptr<smt_ivfpq, void (*)(smt_ivfpq *)> guard(ix, smt_ivfpq_destroy);
     ix->corpus = corpus;
+    ix->device = corpus->ctx->device;
     ix->n_rows = h.n_rows;
     ix->nlist = h.nlist;
     const size_t N = (size_t)h.n_rows;
