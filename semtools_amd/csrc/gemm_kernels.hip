@@ -429,7 +429,22 @@ constexpr int RR_SLOTS = 4;
 #endif
 constexpr int RR_BDIST = SMT_RR_BDIST;            // K-steps between the LDS read of a B quad pair and its MFMAs
 constexpr int RR_QCONST = QT_ROWS * 8;            // per slot: (score threshold, 1/|q|) of the tile's 32 queries
-constexpr int RR_SMEM = RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF + RR_SLOTS * RR_QCONST;
+// Per nomination mode: how a query tile lies in LDS and how deep the ring is.  bf16 x 3 / f16 x 2 read a hi and a lo
+// quad per (K-step, half): 1 KiB per query (65-float4 rows), four slots.  f16 x 1 reads the hi quads only: its image is
+// COMPACT -- 512 B per query, 33-float4 rows (132 words: the same 4-bank step per lane as 260) -- so EIGHT slots fit
+// the same LDS: batches of up to 256 queries stay resident (no ring, no barrier), and a streamed batch has seven tiles
+// in flight or landed instead of three (a ring step is 16 MFMAs per wave now, half of f16 x 2's: three steps no longer
+// cover the L2 -> LDS latency of a tile).
+template <int MODE>
+struct RrGeom {
+    static constexpr int SLOTS = MODE == 2 ? 8 : RR_SLOTS;
+    static constexpr int ROW_F4 = MODE == 2 ? 33 : QT_STRIDE_F4;     // float4 per query row in LDS
+    static constexpr int SLOT_F4 = QT_ROWS * ROW_F4;                  // float4 per slot
+    static constexpr int QUERY_WORDS = MODE == 2 ? 128 : 256;         // words per query in the global split image
+    static constexpr int AHEAD = SLOTS - 1;                           // ring: tile pos + AHEAD is staged during product pos
+    static constexpr int SMEM = SLOTS * SLOT_F4 * 16 + RR_WAVES * RR_TBUF + SLOTS * RR_QCONST;
+};
+constexpr int RR_SMEM = RrGeom<0>::SMEM;
 
 // The f16 x 2 image of the queries (same row layout: K-step m, half h -> 16 B of hi, 16 B of lo): the UNIT query times
 // 2^8, split into two fp16 parts.  One wave per query (the norm is needed first).
@@ -449,6 +464,21 @@ __global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint
     uint32_t *row = out + (size_t)q * 256 + (lane >> 1) * 8 + 2 * (lane & 1);   // pair pr -> word (pr >> 2) * 8 + (pr & 3)
     *reinterpret_cast<u32x2 *>(row) = (u32x2){h0, h1};
     *reinterpret_cast<u32x2 *>(row + 4) = (u32x2){l0, l1};
+}
+
+// The f16 x 1 image: the hi halves only, 512 B per query -- (K-step m, half h) -> 16 B at word 8 m + 4 h.
+__global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out)
+{
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq_pad) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq) v = reinterpret_cast<const f32x4 *>(queries + (size_t)q * 256)[lane];
+    const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    const float s = a2 == 0.0f ? 0.0f : __frsqrt_rn(a2) * F16X2_QUERY_SCALE;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    // lane holds dims 4 lane .. 4 lane + 3 = pairs 2 lane, 2 lane + 1 -> words 2 lane, 2 lane + 1 of the 128
+    *reinterpret_cast<u32x2 *>(out + (size_t)q * 128 + 2 * lane) = (u32x2){f16_pack2(v.x * s, v.y * s), f16_pack2(v.z * s, v.w * s)};
 }
 
 __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst, int f16x2)
@@ -479,6 +509,11 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
 {
     constexpr bool F16X2 = MODE >= 1;     // fp16 row operand (MODE 1 and 2)
     constexpr bool F16X1 = MODE == 2;     // ... and a single fp16 query operand
+    // (plain constants, not RrGeom<MODE>::X inside the lambdas below: hipcc 7.2 silently drops the HOST-side instantiation of a
+    // kernel template whose always_inline lambda names a dependent type alias of the enclosing function -- the stub stays a
+    // declaration and the library fails to link)
+    constexpr int SLOTS = RrGeom<MODE>::SLOTS, ROW_F4 = RrGeom<MODE>::ROW_F4, SLOT_F4 = RrGeom<MODE>::SLOT_F4;
+    constexpr int QUERY_WORDS = RrGeom<MODE>::QUERY_WORDS, AHEAD = RrGeom<MODE>::AHEAD;
     constexpr int WAVES = RR_WAVES;
     constexpr int STAGE_ROWS = QT_ROWS / WAVES;      // rows of a query tile each wave stages: 4
     constexpr int STAGE_EVERY = 2;                   // one DMA every so many K-steps at the start of a product
@@ -487,22 +522,28 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    unsigned char *tbuf = smem_raw + RR_SLOTS * QT_F4 * 16 + wave * RR_TBUF;
-    unsigned char *s_qconst = smem_raw + RR_SLOTS * QT_F4 * 16 + RR_WAVES * RR_TBUF;   // [4][32] (threshold, 1/|q|)
+    unsigned char *tbuf = smem_raw + SLOTS * SLOT_F4 * 16 + wave * RR_TBUF;
+    unsigned char *s_qconst = smem_raw + SLOTS * SLOT_F4 * 16 + RR_WAVES * RR_TBUF;   // [slots][32] (threshold, 1/|q|)
     const uint32_t qs = blockIdx.x % p.qsplit;
     const uint32_t row_block = blockIdx.x / p.qsplit, row_blocks = gridDim.x / p.qsplit;
     const uint32_t qt_lo = (uint32_t)((uint64_t)qs * p.nqt / p.qsplit);
     const uint32_t qt_hi = (uint32_t)((uint64_t)(qs + 1) * p.nqt / p.qsplit);
     const uint32_t n_qt = qt_hi - qt_lo;
-    const bool resident = n_qt <= (uint32_t)RR_SLOTS;
+    const bool resident = n_qt <= (uint32_t)SLOTS;
 
     // row u of this wave's share of query tile qt -> LDS slot (padding rows of the image are zero rows: no branch)
     auto stage_row = [&](uint32_t qt, int slot, int u) __attribute__((always_inline)) {
         const int r = wave * STAGE_ROWS + u;  // wave-uniform
         const uint32_t q = qt * QT_ROWS + r;
-        f32x4 *dst = s_q + slot * QT_F4 + r * QT_STRIDE_F4;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * 256 + lane * 4,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        f32x4 *dst = s_q + slot * SLOT_F4 + r * ROW_F4;
+        if constexpr (F16X1) {   // 512 B per query: the lower half of the wave carries it (every wave still issues ONE instruction)
+            if (lane < 32)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * QUERY_WORDS + lane * 4,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * QUERY_WORDS + lane * 4,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
     };
     // the tile's 32 (threshold, 1/|q|) pairs: 256 B, one 4-byte DMA.  EVERY wave issues it (same bytes to the same
     // place) so that all waves count the same number of DMA instructions per tile -- the vmcnt arithmetic below
@@ -517,7 +558,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     };
     auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };  // vmcnt(0)
     {
-        const uint32_t first = resident ? n_qt : 3u;   // streaming: ring positions 0, 1, 2
+        const uint32_t first = resident ? n_qt : (uint32_t)AHEAD;   // streaming: ring positions 0 .. AHEAD - 1
         for (uint32_t t = 0; t < first; ++t) stage_tile(qt_lo + t, (int)t);
         stage_wait();
     }
@@ -526,8 +567,8 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     const uint64_t W = (uint64_t)row_blocks * WAVES;
     const uint64_t steps = (p.level_tiles + W - 1) / W;  // block-uniform trip count
     uint64_t it = (uint64_t)row_block * WAVES + wave;
-    uint32_t pos = 0;            // streaming: running ring position (block-uniform); slot = pos & 3
-    uint32_t tq = 0, tq_ahead = 3 % n_qt;   // tile at position pos / pos + 3 (the tile sequence is cyclic over the sweeps)
+    uint32_t pos = 0;            // streaming: running ring position (block-uniform); slot = pos & (SLOTS - 1)
+    uint32_t tq = 0, tq_ahead = (uint32_t)AHEAD % n_qt;   // tile at position pos / pos + AHEAD (the tile sequence is cyclic over the sweeps)
     // transpose geometry: this lane WRITES row (8u + lane/8), bytes 8 * (lane%8) of a slice; it READS row j, quads 2mm + h
     const uint32_t t_wr = (uint32_t)((lane >> 3) * RR_TROW + (lane & 7) * 8);
     const uint32_t t_rd = (uint32_t)(j * RR_TROW + h * 16);
@@ -627,7 +668,9 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             // tile DMAs issued below, and waiting for it would wait for them)
             const f32x2 qc = *reinterpret_cast<const f32x2 *>(s_qconst + slot * RR_QCONST + j * 8);
             const float thr_q = qc.x, rq_q = qc.y;
-            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * QT_F4 + j * QT_STRIDE_F4) + 2 * h;
+            // quad of (K-step m, half h): [hi, lo] pairs at 4 m + 2 h (+ 1) in the 1 KiB image; hi only at 2 m + h in the compact one
+            constexpr int QS = F16X1 ? 2 : 4;   // quads per K-step in a query row
+            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * SLOT_F4 + j * ROW_F4) + (F16X1 ? h : 2 * h);
             // B quads run RR_BDIST K-steps ahead of their MFMAs (sched_barrier: hipcc otherwise sinks every read to its
             // use and each K-step then starts with a full LDS round trip in front of 96 cycles of MFMA)
             // (bf16 x 3 holds 128 operand VGPRs: one K-step of distance keeps it at 256 registers WITHOUT spilling -- with two
@@ -636,12 +679,12 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             constexpr int NB = BD + 1;
             u32x4 bh[NB], bl[F16X1 ? 1 : NB];
 #pragma unroll
-            for (int d = 0; d < BD; ++d) { bh[d] = bq[4 * d]; if constexpr (!F16X1) bl[d] = bq[4 * d + 1]; }
+            for (int d = 0; d < BD; ++d) { bh[d] = bq[QS * d]; if constexpr (!F16X1) bl[d] = bq[QS * d + 1]; }
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m + BD < 16) {
-                    bh[(m + BD) % NB] = bq[4 * (m + BD)];
-                    if constexpr (!F16X1) bl[(m + BD) % NB] = bq[4 * (m + BD) + 1];
+                    bh[(m + BD) % NB] = bq[QS * (m + BD)];
+                    if constexpr (!F16X1) bl[(m + BD) % NB] = bq[QS * (m + BD) + 1];
                 }
                 if (m % STAGE_EVERY == 0 && m / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, m / STAGE_EVERY);
                 if (m == STAGE_EVERY * STAGE_ROWS && stage) stage_consts(stage_qt, stage_slot);
@@ -659,13 +702,15 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t, false, 0, 0);
         } else {
             for (uint32_t t = 0; t < n_qt; ++t) {
-                const int slot = (int)(pos & 3), slot_ahead = (int)((pos + 3) & 3);   // slot_ahead was read during step pos - 1
+                const int slot = (int)(pos & (SLOTS - 1)), slot_ahead = (int)((pos + AHEAD) & (SLOTS - 1));   // slot_ahead was read during step pos - 1
                 if (has) tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
                 else stage_tile(qt_lo + tq_ahead, slot_ahead);
-                // this wave's share of tile pos + 1 has landed: only the 2 x (STAGE_ROWS + 1) younger DMAs may still fly
+                // this wave's share of tile pos + 1 has landed: only the (SLOTS - 2) x (STAGE_ROWS + 1) younger DMAs may still fly
                 // (a raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), i.e. it would wait
-                // for the two tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
-                __builtin_amdgcn_s_waitcnt(0x0F7A);  // vmcnt(10)
+                // for the tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
+                constexpr int FLY = (SLOTS - 2) * (STAGE_ROWS + 1);               // 10 (four slots) / 30 (eight)
+                static_assert(FLY < 64, "vmcnt is a 6-bit counter");
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (FLY & 15) | ((FLY >> 4) << 14));  // vmcnt(FLY), expcnt / lgkmcnt unconstrained
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 ++pos;
@@ -1277,7 +1322,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     float *qconst = tau + (size_t)nqt * QT_ROWS;   // [nqt*32][2]
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
-    if (f16x2 || f16x1)   // (f16 x 1 reads only the hi halves of the same image)
+    if (f16x1)
+        hipLaunchKernelGGL(split_queries_f16x1_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
+                           nqt * QT_ROWS, q_split);
+    else if (f16x2)
         hipLaunchKernelGGL(split_queries_f16_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, q_split);
     else if (bf16)
@@ -1328,9 +1376,9 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                 nb = (int)(need_blocks * g.qsplit);
             }
             prof_begin(ctx, "gemm");
-            if (f16x1) hipLaunchKernelGGL(gemm_rowreg_kernel<2>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
-            else if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<1>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
-            else hipLaunchKernelGGL(gemm_rowreg_kernel<0>, dim3(nb), dim3(RR_THREADS), (size_t)RR_SMEM, ctx->stream, g);
+            if (f16x1) hipLaunchKernelGGL(gemm_rowreg_kernel<2>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<2>::SMEM, ctx->stream, g);
+            else if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<1>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<1>::SMEM, ctx->stream, g);
+            else hipLaunchKernelGGL(gemm_rowreg_kernel<0>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<0>::SMEM, ctx->stream, g);
             prof_end(ctx, "gemm");
         } else if (g.level_tiles > 0 && lds_rows) {
             const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
