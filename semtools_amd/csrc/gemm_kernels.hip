@@ -435,13 +435,22 @@ constexpr int RR_QCONST = QT_ROWS * 8;            // per slot: (score threshold,
 // the same LDS: batches of up to 256 queries stay resident (no ring, no barrier), and a streamed batch has seven tiles
 // in flight or landed instead of three (a ring step is 16 MFMAs per wave now, half of f16 x 2's: three steps no longer
 // cover the L2 -> LDS latency of a tile).
+#ifndef SMT_RR_GT
+#define SMT_RR_GT 2
+#endif
 template <int MODE>
 struct RrGeom {
     static constexpr int SLOTS = MODE == 2 ? 8 : RR_SLOTS;
     static constexpr int ROW_F4 = MODE == 2 ? 33 : QT_STRIDE_F4;     // float4 per query row in LDS
     static constexpr int SLOT_F4 = QT_ROWS * ROW_F4;                  // float4 per slot
     static constexpr int QUERY_WORDS = MODE == 2 ? 128 : 256;         // words per query in the global split image
-    static constexpr int AHEAD = SLOTS - 1;                           // ring: tile pos + AHEAD is staged during product pos
+    // The ring advances in GROUPS of GT tiles: one block-wide barrier per group instead of per tile (between barriers the
+    // eight waves run free -- the barrier is what kept them in lock step, row phases included).  Tile pos + AHEAD is staged
+    // during product pos into the slot that tile pos + AHEAD - SLOTS used: that one must belong to an EARLIER group than
+    // pos (every wave is past it), hence AHEAD = SLOTS - GT; at a group border the tiles of the next group were staged at
+    // least AHEAD - GT + 1 products ago.
+    static constexpr int GT = MODE == 2 ? SMT_RR_GT : 1;
+    static constexpr int AHEAD = SLOTS - GT;
     static constexpr int SMEM = SLOTS * SLOT_F4 * 16 + RR_WAVES * RR_TBUF + SLOTS * RR_QCONST;
 };
 constexpr int RR_SMEM = RrGeom<0>::SMEM;
@@ -513,7 +522,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     // kernel template whose always_inline lambda names a dependent type alias of the enclosing function -- the stub stays a
     // declaration and the library fails to link)
     constexpr int SLOTS = RrGeom<MODE>::SLOTS, ROW_F4 = RrGeom<MODE>::ROW_F4, SLOT_F4 = RrGeom<MODE>::SLOT_F4;
-    constexpr int QUERY_WORDS = RrGeom<MODE>::QUERY_WORDS, AHEAD = RrGeom<MODE>::AHEAD;
+    constexpr int QUERY_WORDS = RrGeom<MODE>::QUERY_WORDS, AHEAD = RrGeom<MODE>::AHEAD, GT = RrGeom<MODE>::GT;
     constexpr int WAVES = RR_WAVES;
     constexpr int STAGE_ROWS = QT_ROWS / WAVES;      // rows of a query tile each wave stages: 4
     constexpr int STAGE_EVERY = 2;                   // one DMA every so many K-steps at the start of a product
@@ -708,10 +717,14 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 // this wave's share of tile pos + 1 has landed: only the (SLOTS - 2) x (STAGE_ROWS + 1) younger DMAs may still fly
                 // (a raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), i.e. it would wait
                 // for the tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
-                constexpr int FLY = (SLOTS - 2) * (STAGE_ROWS + 1);               // 10 (four slots) / 30 (eight)
-                static_assert(FLY < 64, "vmcnt is a 6-bit counter");
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (FLY & 15) | ((FLY >> 4) << 14));  // vmcnt(FLY), expcnt / lgkmcnt unconstrained
-                __builtin_amdgcn_s_barrier();
+                // At the border in front of position pos + 1 the tiles pos + 1 .. pos + GT must have landed; the younger ones,
+                // pos + GT + 1 .. pos + AHEAD, may still fly.
+                constexpr int FLY = (AHEAD - GT) * (STAGE_ROWS + 1);               // 10 (four slots, GT 1) / 20 (eight, GT 2)
+                static_assert(FLY >= 0 && FLY < 64, "vmcnt is a 6-bit counter");
+                if ((pos + 1) % GT == 0) {   // block-uniform
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | (FLY & 15) | ((FLY >> 4) << 14));  // vmcnt(FLY), expcnt / lgkmcnt unconstrained
+                    __builtin_amdgcn_s_barrier();
+                }
                 asm volatile("" ::: "memory");
                 ++pos;
                 tq = tq + 1 == n_qt ? 0 : tq + 1;
