@@ -133,6 +133,16 @@ int smt_corpus_write_rows(smt_corpus *corpus, uint64_t first_row, const float *r
                           uint64_t n_rows);
 int smt_corpus_read_rows(smt_corpus *corpus, uint64_t first_row, uint64_t n_rows, float *out_host);
 int smt_corpus_truncate(smt_corpus *corpus, uint64_t n_rows);
+/* The fp16 OPERAND IMAGE of a corpus: what the batched nomination modes multiply with (unit rows x 2^10 as fp16 in MFMA operand
+ * order, 512 B per row beside the 1 KiB of f32), so that a batch of >= 8 queries reads half the bytes per row and converts
+ * nothing.  Derived data only: nominations come from it, every returned distance is re-scored from the f32 rows, results are
+ * identical with and without it.  A corpus whose memory the library owns builds and maintains it by itself (first batch of
+ * >= 8 queries over >= 64 Ki rows; appends, writes and truncation are tracked; tuning key corpus_image = 0 turns that off).
+ * smt_corpus_prepack(corpus, 1) builds it NOW from the rows as they are -- the way to have one for a corpus adopted with
+ * smt_corpus_from_device, whose caller then answers for calling it again after changing rows; (corpus, 0) drops it and keeps the
+ * corpus without one.  No reference counterpart (the reference scores Vec<Vec<f32>> rows one by one, src/search/mod.rs:84-119). */
+int smt_corpus_prepack(smt_corpus *corpus, int enable);
+uint64_t smt_corpus_image_bytes(const smt_corpus *corpus);
 uint64_t smt_corpus_rows(const smt_corpus *corpus);
 uint32_t smt_corpus_dim(const smt_corpus *corpus);
 /* flat little-endian file: 32-byte header + rows*D f32 */

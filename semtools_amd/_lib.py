@@ -23,6 +23,7 @@ EXPORTS = [
     "smt_model_create", "smt_model_create_from_file", "smt_model_create_from_device", "smt_model_destroy", "smt_embed", "smt_embed_device",
     "smt_corpus_create", "smt_corpus_from_device", "smt_corpus_destroy", "smt_corpus_append_host",
     "smt_corpus_write_rows", "smt_corpus_read_rows", "smt_corpus_truncate", "smt_corpus_rows", "smt_corpus_dim",
+    "smt_corpus_prepack", "smt_corpus_image_bytes",
     "smt_corpus_save", "smt_corpus_load", "smt_corpus_append_to_file", "smt_search", "smt_search_topk_device", "smt_merge_topk",
     "smt_merge_topk_device", "smt_merge_topk_packed_device", "smt_ivfpq_build", "smt_ivfpq_destroy", "smt_ivfpq_search", "smt_ivfpq_search_device", "smt_ivfpq_info", "smt_ivfpq_list_sizes", "smt_ivfpq_save", "smt_ivfpq_load", "smt_ivfpq_append",
     "smt_set_tuning", "smt_fnv1a_hash", "smt_line_embedding_id", "smt_doc_meta_id",
@@ -126,6 +127,9 @@ def lib():
     L.smt_corpus_destroy.restype = None
     L.smt_corpus_append_host.argtypes = [vp, vp, u64, P(u64)]
     L.smt_corpus_write_rows.argtypes = [vp, u64, vp, u64]
+    L.smt_corpus_prepack.argtypes = [vp, C.c_int]
+    L.smt_corpus_image_bytes.argtypes = [vp]
+    L.smt_corpus_image_bytes.restype = u64
     L.smt_corpus_read_rows.argtypes = [vp, u64, u64, vp]
     L.smt_corpus_truncate.argtypes = [vp, u64]
     L.smt_corpus_rows.argtypes = [vp]

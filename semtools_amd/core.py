@@ -193,6 +193,15 @@ class Corpus:
     def truncate(self, n_rows):
         L.check(L.lib().smt_corpus_truncate(self._h, int(n_rows)))
 
+    def prepack(self, enable=True):
+        """smt_corpus_prepack: build (or drop) the fp16 operand image the batched searches read -- half the bytes per row.  For a
+        corpus adopted from device memory this is the only way to get one; call it again after changing rows."""
+        L.check(L.lib().smt_corpus_prepack(self._h, 1 if enable else 0))
+
+    @property
+    def image_bytes(self):
+        return int(L.lib().smt_corpus_image_bytes(self._h))
+
     def debug_batched_scores(self, queries, first_row=0, n_rows=None):
         """Test hook (smt_debug_batched_scores): the f32 distances the batched kernels nominate candidates with,
         float32 [n_rows, nq]."""

@@ -165,6 +165,63 @@ int corpus_reserve(smt_corpus *c, uint64_t rows_needed)
     return SMT_OK;
 }
 
+void corpus_image_drop(smt_corpus *c)
+{
+    if (c->image) (void)hipFree(c->image);
+    if (c->image_zero) (void)hipFree(c->image_zero);
+    c->image = nullptr;
+    c->image_zero = nullptr;
+    c->image_cap_tiles = 0;
+    c->image_rows = 0;
+}
+
+// Policy: an image is kept for a corpus whose memory this library owns (every change of a row goes through this file) from the
+// first batch of >= 8 queries over >= 64 Ki rows on (tuning key corpus_image), and for any corpus it was asked for
+// (smt_corpus_prepack: the caller of smt_corpus_from_device then answers for the rows not changing behind the image).
+// It costs half the corpus again in HBM; when that allocation fails the corpus goes on without one.
+int corpus_image_sync(smt_corpus *c, uint32_t nq, const void **image, const uint32_t **image_zero)
+{
+    *image = nullptr;
+    *image_zero = nullptr;
+    if (c->image_mode < 0) return SMT_OK;
+    if (c->image_mode == 0 && !(c->owned && c->ctx->tune.corpus_image != 0 && (c->image || (nq >= 8 && c->rows >= 65536)))) return SMT_OK;
+    if (c->rows == 0) return SMT_OK;
+    const uint64_t tiles = (c->rows + 31) / 32;
+    if (tiles > c->image_cap_tiles) {
+        const uint64_t cap = std::max<uint64_t>(tiles, c->image ? c->image_cap_tiles + c->image_cap_tiles / 2 : (c->capacity + 31) / 32);
+        void *ni = nullptr;
+        uint32_t *nz = nullptr;
+        if (hipMalloc(&ni, (size_t)cap * 16384) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&nz), (size_t)cap * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ni) (void)hipFree(ni);
+            corpus_image_drop(c);
+            c->image_mode = -1;   // no room beside the rows: this corpus is searched from its f32 rows
+            return SMT_OK;
+        }
+        const uint64_t keep = c->image ? c->image_rows / 32 : 0;   // whole tiles that stay valid
+        if (keep) {
+            SMT_HIP_CHECK(hipMemcpyAsync(ni, c->image, (size_t)keep * 16384, hipMemcpyDeviceToDevice, c->ctx->stream));
+            SMT_HIP_CHECK(hipMemcpyAsync(nz, c->image_zero, (size_t)keep * 4, hipMemcpyDeviceToDevice, c->ctx->stream));
+            SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+        }
+        const uint64_t had = c->image_rows;
+        corpus_image_drop(c);
+        c->image = ni;
+        c->image_zero = nz;
+        c->image_cap_tiles = cap;
+        c->image_rows = keep * 32 <= had ? keep * 32 : 0;
+    }
+    if (c->image_rows < c->rows) {
+        const uint64_t first = c->image_rows / 32;   // a partly filled last tile is packed again
+        const int rc = launch_pack_image(c->ctx, c->d_rows, c->rows, first, tiles - first, c->image, c->image_zero);
+        if (rc) return rc;
+        c->image_rows = c->rows;
+    }
+    *image = c->image;
+    *image_zero = c->image_zero;
+    return SMT_OK;
+}
+
 }  // namespace smt
 
 using namespace smt;
@@ -344,6 +401,10 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_min_rows_small") ctx->tune.gemm_min_rows_small = value < 0 ? 0 : value;
     else if (k == "gemm_dma_nt") ctx->tune.gemm_dma_nt = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
+    else if (k == "gemm_buffered") ctx->tune.gemm_buffered = (int)value;
+    else if (k == "gemm_split_last") ctx->tune.gemm_split_last = (int)value;
+    else if (k == "gemm_image") ctx->tune.gemm_image = (int)value;
+    else if (k == "corpus_image") ctx->tune.corpus_image = (int)value;
     else if (k == "prof_every") ctx->tune.prof_every = (int)value;
     else if (k == "merge_on_aux") {
         int rc2 = drain_async(ctx);
@@ -457,6 +518,7 @@ void smt_corpus_destroy(smt_corpus *corpus)
     (void)hipStreamSynchronize(corpus->ctx->stream);
     (void)drain_async(corpus->ctx);  // an async select may still be rescoring rows of this corpus
     if (corpus->owned && corpus->d_rows) (void)hipFree(corpus->d_rows);
+    corpus_image_drop(corpus);
     delete corpus;
 }
 
@@ -489,8 +551,31 @@ int smt_corpus_write_rows(smt_corpus *c, uint64_t first_row, const float *rows, 
     SMT_HIP_CHECK(hipMemcpyAsync(c->d_rows + (size_t)first_row * c->dim, rows, (size_t)n_rows * c->dim * sizeof(float),
                                  hipMemcpyHostToDevice, c->ctx->stream));
     SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    c->image_rows = std::min<uint64_t>(c->image_rows, first_row / 32 * 32);   // the operand image is packed again from this tile on
     return SMT_OK;
 }
+
+int smt_corpus_prepack(smt_corpus *c, int enable)
+{
+    SMT_REQUIRE(c != nullptr, "corpus");
+    int rc = bind_device(c->ctx);
+    if (rc) return rc;
+    if (!enable) {
+        SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+        corpus_image_drop(c);
+        c->image_mode = -1;
+        return SMT_OK;
+    }
+    c->image_mode = 1;
+    c->image_rows = 0;   // "the rows are what they are NOW": an adopted corpus may have changed since the last call
+    const void *img;
+    const uint32_t *zero;
+    if ((rc = corpus_image_sync(c, 0, &img, &zero))) return rc;
+    if (c->rows && !img) { set_error("no room for the operand image (%llu bytes)", (unsigned long long)((c->rows + 31) / 32 * 16384)); return SMT_E_NOMEM; }
+    return SMT_OK;
+}
+
+uint64_t smt_corpus_image_bytes(const smt_corpus *c) { return c && c->image ? c->image_cap_tiles * (16384 + 4) : 0; }
 
 int smt_corpus_read_rows(smt_corpus *c, uint64_t first_row, uint64_t n_rows, float *out_host)
 {
@@ -510,6 +595,7 @@ int smt_corpus_truncate(smt_corpus *c, uint64_t n_rows)
     SMT_REQUIRE(c != nullptr, "corpus");
     SMT_REQUIRE(n_rows <= c->rows, "cannot truncate to more rows than stored");
     c->rows = n_rows;
+    c->image_rows = std::min<uint64_t>(c->image_rows, n_rows / 32 * 32);   // rows appended later land in tiles the image packs again
     return SMT_OK;
 }
 
@@ -721,12 +807,15 @@ static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queri
 //    2 M rows: 2: 0.49 | 0.52, 3: 0.87 | 0.52, 4: 0.75 | 0.53;   1 M rows: 2: 0.27 | 0.36, 3: 0.44 | 0.37, 4: 0.42 | 0.37
 //  300 k rows: 3: 0.17 | 0.25 (K3's fixed cost: five level launches + selects)
 // => K3 from gemm_min_nq (3) queries on shards of gemm_min_rows_small (1 M) rows, from 2 queries on 4 x that.
-static int topk_dispatch(smt_ctx *ctx, const ScanArgs &a)
+static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
 {
     const bool fast_k3 = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && a.n_ranges == 0;
     const uint64_t small = (uint64_t)ctx->tune.gemm_min_rows_small;
     const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && a.rows >= small) ||
                          (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small);
+    if (batched && a.n_ranges == 0 && corpus->d_rows == a.corpus && corpus->rows == a.rows) {
+        if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
+    }
     int rc = batched ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
     if (rc == SMT_E_UNSUPPORTED && batched) rc = launch_scan_topk(ctx, a);
     return rc;
@@ -865,7 +954,7 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
         a.out_counts = d_ocnt;
         a.out_uncertain = d_ocnt + nq;
         // K2 or K3: topk_dispatch above
-        rc = topk_dispatch(ctx, a);
+        rc = topk_dispatch(ctx, corpus, a);
         if (rc) return rc;
 
         if ((rc = ensure_pinned(ctx, o_rows + o_dist + o_cnt))) return rc;
@@ -1035,7 +1124,7 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     a.out_uncertain = uncertain_dev;
     a.allow_async = async;
     a.out_stride = (uint64_t)2 * k_pad;
-    rc = topk_dispatch(ctx, a);
+    rc = topk_dispatch(ctx, corpus, a);
     return rc;
 }
 
@@ -1088,7 +1177,7 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
         // nothing to scan: fill with padding through the merge kernel on zero lists
         return launch_merge_topk(ctx, out_rows_dev, out_dist_dev, 0, nq, 1, top_k, out_rows_dev, out_dist_dev);
     }
-    rc = topk_dispatch(ctx, a);
+    rc = topk_dispatch(ctx, corpus, a);
     return rc;
 }
 

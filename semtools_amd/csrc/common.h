@@ -61,6 +61,10 @@ struct Tuning {
     int prof_every = 1;         // HIP events bracket one launch in N (an event pair costs ~6 us of stream time)
     int merge_on_aux = 0;       // 1: smt_merge_topk_packed_device runs on the aux stream (behind the async select it consumes)
     int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
+    int gemm_image = 1;         // 1: batched searches read the corpus' fp16 operand image when it has one (0: A/B only)
+    int corpus_image = 1;       // 1: a corpus this library owns builds its operand image at the first batch of >= 8 queries (>= 64 Ki rows)
+    int gemm_split_last = 1;    // 1: a streamed K3 sweep runs its last level in two parts with a select pass in between (0: A/B only)
+    int gemm_buffered = 1;      // 1: gemm_rowreg_kernel nominations go through the wave's LDS buffer (0: straight to the lists; A/B only)
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
     int64_t fallback_batch_min_rows = 100000;   // >= 2 uncertain queries of a call on a shard this large are re-answered by ONE batched threshold pass
@@ -113,6 +117,15 @@ struct smt_corpus {
     uint64_t capacity = 0;
     uint32_t dim = 0;
     bool owned = true;
+    // fp16 OPERAND IMAGE (gemm_kernels.hip: pack_image_kernel): what the batched fp16 nomination modes multiply with, kept
+    // beside the f32 rows -- 512 B per row, 16 KiB per 32-row tile -- so that a batch reads half the bytes and converts nothing.
+    // Derived data: the f32 rows stay the truth (every returned distance is re-scored from them).  image_rows = the rows the
+    // image describes; appends grow `rows` past it, smt_corpus_write_rows pulls it back: corpus_image_sync packs what is missing.
+    void *image = nullptr;
+    uint32_t *image_zero = nullptr;
+    uint64_t image_cap_tiles = 0;
+    uint64_t image_rows = 0;
+    int image_mode = 0;          // 0: by policy (tuning key corpus_image; owned corpora only), 1: requested (smt_corpus_prepack), -1: refused
 };
 
 struct smt_model {
@@ -129,6 +142,11 @@ namespace smt {
 int check_ctx(const smt_ctx *ctx);
 int bind_device(smt_ctx *ctx, bool drain = true);   // hipSetDevice + (drain) wait for async selects
 int corpus_reserve(smt_corpus *c, uint64_t rows_needed);
+// the image up to date for a batch of nq queries, or left alone (policy, memory): sets *image / *image_zero (nullptr = none)
+int corpus_image_sync(smt_corpus *c, uint32_t nq, const void **image, const uint32_t **image_zero);
+void corpus_image_drop(smt_corpus *c);
+int launch_pack_image(smt_ctx *ctx, const float *corpus, uint64_t n_rows, uint64_t first_tile, uint64_t n_tiles, void *image,
+                      uint32_t *image_zero);
 int ensure_scratch(smt_ctx *ctx, size_t bytes);
 int ensure_pinned(smt_ctx *ctx, size_t bytes);
 int ensure_stage(smt_ctx *ctx, size_t bytes);
@@ -167,6 +185,8 @@ struct ScanArgs {
                                         // contain the exact top-k (see SelectArgs::f32_err); the host API then
                                         // re-answers that query exhaustively
     bool allow_async = false; // the caller does not read the outputs on the main stream before smt_ctx_synchronize
+    const void *image = nullptr;          // the corpus' fp16 operand image covering all `rows` (smt_corpus::image), or nullptr
+    const uint32_t *image_zero = nullptr;
     uint64_t out_stride = 0;  // words between the output lists of consecutive queries (0 = k_out); the packed
                               // [nq][2][k] exchange layout of group.cpp uses 2*k with out_dist = out_rows + k
 };

@@ -72,7 +72,8 @@ struct GemmParams {
     const uint32_t *queries_split;  // BF16 kernels: [nqt*32][256] words, the split image written by split_queries_kernel
     uint32_t nq;
     uint32_t nqt;             // ceil(nq / 32)
-    uint64_t level_tiles;     // tiles visited by this launch
+    uint64_t level_tiles;     // tiles of the level: this launch visits [tile_begin, level_tiles) (gemm_rowreg_kernel; the others start at 0)
+    uint64_t tile_begin;
     uint64_t stride;          // visited tile = stride * u(i)
     int skip16;               // LEVEL_RATIO (64 or 16) when u skips the multiples of the ratio (they belong to earlier levels), else 0
     uint32_t qsplit;          // gemm_level_kernel: blocks per row-tile group, each sweeping 1/qsplit of the query tiles
@@ -85,6 +86,10 @@ struct GemmParams {
     // chunk table (scan_kernels.hip: row0 | valid rows << 32); a "tile" is then 8 consecutive chunks
     const uint64_t *chunk_table;
     uint64_t n_chunks;
+    const void *image;            // gemm_rowreg_kernel<MODE, true>: the corpus' fp16 operand image (16 KiB per 32-row tile) ...
+    const uint32_t *image_zero;   // ... and per tile the mask of its zero rows
+    int buffered;                 // gemm_rowreg_kernel: nominations go through the wave's LDS buffer (every level but the first)
+    unsigned long long *stamps;   // trace builds only (SMT_RR_EXP & 256, tools/exp_k3_trace.sh): s_memtime stamps of one block
 };
 
 __device__ __forceinline__ uint64_t level_tile(uint64_t i, uint64_t stride, int skip16)
@@ -358,8 +363,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_level_kernel(GemmParams 
 }
 
 // ---- shared epilogue: lane (j, h) owns query q and the 16 rows acc_row(r, h) of the tile at row0
-__device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned zero16, unsigned valid16, uint32_t q,
-                                                  float thr, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts)
+// which of the lane's 16 scores are nominations (bit r <-> accumulator register r); 0 in every lane when the tile has none
+__device__ __forceinline__ float nomination_dist(const f32x16 &acc, int r, unsigned zero16, float rq)
+{
+    if (rq == 0.0f) return (zero16 >> r) & 1u ? 0.0f : 1.0f;  // zero query: 0 against a zero row, else 1 (simsimd rules)
+    return fmaxf(1.0f - acc[r] * rq, 0.0f);                    // a zero row has acc == 0 -> 1
+}
+__device__ __forceinline__ unsigned nomination_mask(const f32x16 &acc, unsigned zero16, unsigned valid16, float thr, float rq)
 {
     // almost every (tile, query tile) nominates nothing: one max over the lane's 16 scores (v_max3) and one wave-wide
     // test skip the per-row work (the per-row compares were 1/4 of a bf16 x 3 tile product)
@@ -368,13 +378,9 @@ __device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned ze
 #pragma unroll
         for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
         mx = fmaxf(mx, acc[15]);
-        if (!__builtin_amdgcn_ballot_w64(rq == 0.0f || mx >= thr)) return;
+        if (!__builtin_amdgcn_ballot_w64(rq == 0.0f || mx >= thr)) return 0;
     }
     unsigned pass = 0;
-    auto dist_of = [&](int r) {
-        if (rq == 0.0f) return (zero16 >> r) & 1u ? 0.0f : 1.0f;  // zero query: 0 against a zero row, else 1 (simsimd rules)
-        return fmaxf(1.0f - acc[r] * rq, 0.0f);                    // a zero row has acc == 0 -> 1
-    };
     if (rq != 0.0f) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -382,23 +388,45 @@ __device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned ze
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (dist_of(r) <= thr) pass |= 1u << r;
+            if (nomination_dist(acc, r, zero16, rq) <= thr) pass |= 1u << r;
     }
-    pass &= valid16;
-    if (__builtin_amdgcn_ballot_w64(pass != 0)) {
-        if (pass) {
-            const unsigned base = atomicAdd(&counts[q], (unsigned)__popc(pass));  // one slot grab per lane per tile
-            key_t64 *dst = cand + (size_t)q * CAND_CAP;
-            unsigned slot = base;
+    return pass & valid16;
+}
+// acc[r] for a per-lane r: a select chain (a dynamically indexed register array would live in scratch)
+__device__ __forceinline__ float acc_select(const f32x16 &acc, int r)
+{
+    float a = acc[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (pass & (1u << r)) {
-                    if (slot < CAND_CAP) dst[slot] = make_key(dist_of(r), (uint32_t)(row0 + acc_row(r, h)));
-                    ++slot;
-                }
-            }
+    for (int rr = 1; rr < 16; ++rr) a = r == rr ? acc[rr] : a;
+    return a;
+}
+// The nominations of a tile are walked lowest-bit-first in a wave-uniform loop: one trip as a rule (a lane rarely holds two).
+// (The obvious form -- sixteen "if (pass & bit)" blocks -- is sixteen exec-masked regions with a taken branch around each:
+// measured ~1150 cycles per nominating product at 1000 x 10 M, during which the other seven waves stood at the ring barrier.)
+// straight to the per-query lists: one slot grab per lane per tile
+__device__ __forceinline__ void append_direct(const f32x16 &acc, unsigned pass, unsigned zero16, uint32_t q, float rq, uint64_t row0, int h,
+                                              key_t64 *cand, unsigned int *counts)
+{
+    unsigned slot = 0;
+    if (pass) slot = atomicAdd(&counts[q], (unsigned)__popc(pass));
+    key_t64 *dst = cand + (size_t)q * CAND_CAP;
+    unsigned todo = pass;
+    while (__builtin_amdgcn_ballot_w64(todo != 0)) {
+        const int r = todo ? __builtin_ctz(todo) : 0;
+        const float a = acc_select(acc, r);
+        if (todo) {
+            const float d = rq == 0.0f ? ((zero16 >> r) & 1u ? 0.0f : 1.0f) : fmaxf(1.0f - a * rq, 0.0f);
+            if (slot < CAND_CAP) dst[slot] = make_key(d, (uint32_t)(row0 + acc_row(r, h)));
+            ++slot;
+            todo &= todo - 1;
         }
     }
+}
+__device__ __forceinline__ void append_candidates(const f32x16 &acc, unsigned zero16, unsigned valid16, uint32_t q,
+                                                  float thr, float rq, uint64_t row0, int h, key_t64 *cand, unsigned int *counts)
+{
+    const unsigned pass = nomination_mask(acc, zero16, valid16, thr, rq);
+    if (__builtin_amdgcn_ballot_w64(pass != 0)) append_direct(acc, pass, zero16, q, rq, row0, h, cand, counts);
 }
 
 // ---- bf16 x 3, every unfiltered batch size: row tiles arrive in REGISTERS with coalesced loads and are transposed
@@ -429,6 +457,15 @@ constexpr int RR_SLOTS = 4;
 #endif
 constexpr int RR_BDIST = SMT_RR_BDIST;            // K-steps between the LDS read of a B quad pair and its MFMAs
 constexpr int RR_QCONST = QT_ROWS * 8;            // per slot: (score threshold, 1/|q|) of the tile's 32 queries
+// NOMINATIONS GO THROUGH LDS.  During a sweep the wave's transpose buffer is idle; it holds the nominations of the sweep --
+// RR_CB_CAP (key, query) pairs, allocated with ballot / readlane arithmetic (no atomic, no memory wait) -- and the wave flushes
+// them to the per-query lists (one returning atomic per pair, then a store) at the START OF THE NEXT ROW PHASE, behind the 32 row
+// loads it has to wait for anyway.  Before (wave timeline, tools/trace_k3.py, 1000 x 10 M): the main level admits ~16 (k + 24)
+// rows per query (its thresholds come from a 1/16 sample), 6 % of the products nominate something, and the direct path --
+// global_atomic_add with return, s_waitcnt vmcnt(0), then a vmcnt(0) in front of every store; vmcnt is in-order, so each of these
+// also waits for the query-tile DMAs in flight -- held its wave for ~2000 cycles while the other seven waited at the ring's
+// barrier: 63 % of the barriers had such a straggler, the barrier period was 5200 cycles instead of 4350.
+constexpr int RR_CB_CAP = 208;                    // 208 x 8 B keys + 208 x 4 B queries = 2496 B <= RR_TBUF
 // Per nomination mode: how a query tile lies in LDS and how deep the ring is.  bf16 x 3 / f16 x 2 read a hi and a lo
 // quad per (K-step, half): 1 KiB per query (65-float4 rows), four slots.  f16 x 1 reads the hi quads only: its image is
 // COMPACT -- 512 B per query, 33-float4 rows (132 words: the same 4-bank step per lane as 260) -- so EIGHT slots fit
@@ -449,8 +486,12 @@ struct RrGeom {
     // during product pos into the slot that tile pos + AHEAD - SLOTS used: that one must belong to an EARLIER group than
     // pos (every wave is past it), hence AHEAD = SLOTS - GT; at a group border the tiles of the next group were staged at
     // least AHEAD - GT + 1 products ago.
+    // STAGGERED SWEEP: the waves 4 .. 7 of a block (the second wave of each SIMD) run half a product behind the waves 0 .. 3 --
+    // during position pos they finish product pos - 1 (K-steps 8 .. 15, epilogue) and start product pos (K-steps 0 .. 7) -- so a
+    // slot is read for one position longer than its own: one slot less ahead.
     static constexpr int GT = MODE == 2 ? SMT_RR_GT : 1;
-    static constexpr int AHEAD = SLOTS - GT;
+    static constexpr bool STAGGER = MODE != 0;   // (bf16 x 3 has no registers for an accumulator that lives across positions)
+    static constexpr int AHEAD = SLOTS - GT - (STAGGER ? 1 : 0);
     static constexpr int SMEM = SLOTS * SLOT_F4 * 16 + RR_WAVES * RR_TBUF + SLOTS * RR_QCONST;
 };
 constexpr int RR_SMEM = RrGeom<0>::SMEM;
@@ -513,9 +554,194 @@ __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t 
 // dropped too: ONE MFMA and ONE B quad per K-step, half the MFMA and half the LDS operand traffic of f16 x 2 for a
 // certificate band of 2^-10 instead of 2^-11 (common.h F32_ERR_F16X1): the large-batch mode, where the MFMA pipe -- at the
 // clock the part sustains under this load -- is the bound and the only lever left is fewer MFMAs per useful flop.
-template <int MODE>
+#if defined(SMT_RR_EXP) && (SMT_RR_EXP & 256)
+#define CB_STAMP(id) do { if (dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) dbg[dbg_n] = (t_ << 8) | (unsigned)(id); ++dbg_n; } } while (0)
+#define CB_DBG_PARAMS , unsigned long long *dbg, int &dbg_n
+#else
+#define CB_STAMP(id) do { } while (0)
+#define CB_DBG_PARAMS
+#endif
+// the wave's nomination buffer (its transpose buffer, idle during a sweep): keys at cb, queries behind them; n_buf is wave-uniform
+__device__ __forceinline__ void append_candidates_lds(const f32x16 &acc, unsigned zero16, unsigned valid16, uint32_t q, float thr, float rq,
+                                                      uint64_t row0, int h, int lane, unsigned char *cb, uint32_t &n_buf,
+                                                      key_t64 *cand, unsigned int *counts CB_DBG_PARAMS)
+{
+    // Every VALU instruction of an epilogue competes with the MFMA stream of the SIMD's other wave (~12 cycles apiece there), and
+    // while it runs the block's other waves may be standing at the ring barrier.  So, in order of frequency:
+    //  (1) nothing to nominate (~90 % of the products at 1000 x 10 M): eight v_max3, one compare, one branch;
+    //  (2) nominations of nonzero queries in a full tile: one v_cmp per accumulator register, its lane mask in SGPRs -- scalar
+    //      tests skip the registers without a nomination; a register with some: slot = count + mbcnt, two LDS writes;
+    //  (3) zero queries with a reachable threshold, tiles that hang over the end of the corpus: the general mask, bit by bit.
+    const bool zq = rq == 0.0f;    // a zero query's slot carries tau itself (score_threshold): padding has tau < 0
+    {
+        float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+        mx = fmaxf(mx, acc[15]);
+        if (!__builtin_amdgcn_ballot_w64(zq ? thr >= 0.0f : mx >= thr)) return;
+    }
+    CB_STAMP(11);
+    key_t64 *keys = reinterpret_cast<key_t64 *>(cb);
+    uint32_t *qs = reinterpret_cast<uint32_t *>(cb + RR_CB_CAP * 8);
+    if (__builtin_amdgcn_ballot_w64((zq && thr >= 0.0f) || valid16 != 0xffffu)) {
+        unsigned pass = 0;
+        if (!zq) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (acc[r] >= thr) pass |= 1u << r;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nomination_dist(acc, r, zero16, rq) <= thr) pass |= 1u << r;
+        }
+        pass &= valid16;
+        const unsigned long long lanes = __builtin_amdgcn_ballot_w64(pass != 0);
+        if (!lanes) return;
+        const uint32_t mine = (uint32_t)__popc(pass);
+        uint32_t slot = 0, run = n_buf;
+        for (unsigned long long m = lanes; m; m &= m - 1) {
+            const int l = __builtin_ctzll(m);
+            if (lane == l) slot = run;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)mine, l);
+        }
+        if (run > (uint32_t)RR_CB_CAP) {   // wave-uniform: no room: this tile goes straight to the lists
+            append_direct(acc, pass, zero16, q, rq, row0, h, cand, counts);
+            return;
+        }
+        n_buf = run;
+        unsigned todo = pass;
+        while (__builtin_amdgcn_ballot_w64(todo != 0)) {
+            const int r = todo ? __builtin_ctz(todo) : 0;
+            const float a = acc_select(acc, r);
+            if (todo) {
+                const float d = zq ? ((zero16 >> r) & 1u ? 0.0f : 1.0f) : fmaxf(1.0f - a * rq, 0.0f);
+                keys[slot] = make_key(d, (uint32_t)(row0 + acc_row(r, h)));
+                qs[slot] = q;
+                ++slot;
+                todo &= todo - 1;
+            }
+        }
+        return;
+    }
+    const unsigned long long nonzero_q = __builtin_amdgcn_ballot_w64(!zq);
+    const uint32_t lo = (uint32_t)lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned long long mr = __builtin_amdgcn_ballot_w64(acc[r] >= thr) & nonzero_q;
+        if (__builtin_expect(mr != 0, 0)) {
+            const uint32_t n = (uint32_t)__builtin_popcountll(mr);
+            const bool mine = (mr >> lo) & 1ull;
+            const key_t64 key = make_key(fmaxf(1.0f - acc[r] * rq, 0.0f), (uint32_t)(row0 + acc_row(r, h)));
+            if (n_buf + n <= (uint32_t)RR_CB_CAP) {
+                if (mine) {
+                    const uint32_t slot = n_buf + __builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0u));
+                    keys[slot] = key;
+                    qs[slot] = q;
+                }
+                n_buf += n;
+            } else if (mine) {   // no room (a loose threshold): straight to the list
+                const unsigned slot = atomicAdd(&counts[q], 1u);
+                if (slot < CAND_CAP) cand[(size_t)q * CAND_CAP + slot] = key;
+            }
+        }
+    }
+    CB_STAMP(13);
+}
+__device__ __forceinline__ void flush_candidates_lds(int lane, const unsigned char *cb, uint32_t &n_buf, key_t64 *cand, unsigned int *counts)
+{
+    const key_t64 *keys = reinterpret_cast<const key_t64 *>(cb);
+    const uint32_t *qs = reinterpret_cast<const uint32_t *>(cb + RR_CB_CAP * 8);
+    for (uint32_t i = (uint32_t)lane; i < n_buf; i += 64) {
+        const uint32_t q = qs[i];
+        const unsigned slot = atomicAdd(&counts[q], 1u);
+        if (slot < CAND_CAP) cand[(size_t)q * CAND_CAP + slot] = keys[i];
+    }
+    n_buf = 0;
+}
+
+// THE CORPUS' fp16 OPERAND IMAGE (smt_corpus::image, api.cpp): per 32-row tile the sixteen operand quads gemm_rowreg_kernel's fp16
+// modes build in their row phase -- unit row x 2^10, fp16, quad (K-step m, lane l = 32 h + j) at 16 (64 m + l) bytes of the
+// tile's 16 KiB -- written ONCE per row by this kernel with the same arithmetic in the same order (the tests compare the
+// nominations of both forms bit for bit), plus the tile's zero-row mask.  One wave per tile.
+__global__ void __launch_bounds__(256) pack_image_kernel(const float *corpus, uint64_t n_rows, uint64_t first_tile, uint64_t n_tiles,
+                                                         uint32_t *image, uint32_t *image_zero)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[4 * RR_TBUF];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + wave;
+    if (t >= n_tiles) return;
+    const uint64_t tile = first_tile + t, row0 = tile * 32;
+    unsigned char *tbuf = s_t + wave * RR_TBUF;
+    const uint32_t t_wr = (uint32_t)((lane >> 3) * RR_TROW + (lane & 7) * 8);
+    const uint32_t t_rd = (uint32_t)(j * RR_TROW + h * 16);
+    f32x4 R[32];
+    {
+        const f32x4 *base = reinterpret_cast<const f32x4 *>(corpus) + (lane & 7);
+        uint64_t rowv[4];
+        bool inside[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t r = row0 + 8 * u + (lane >> 3);
+            inside[u] = r < n_rows;
+            rowv[u] = inside[u] ? r : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            R[i] = __builtin_nontemporal_load(base + rowv[i & 3] * 64 + 8 * (i >> 2));
+            if (!inside[i & 3]) R[i] = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows past the end: zero rows (masked by valid16 in the sweep)
+        }
+    }
+    float rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float part = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const f32x4 v = R[4 * sl + u];
+            part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        rb[u] = part == 0.0f ? 0.0f : __frsqrt_rn(part);
+    }
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x4 *out = reinterpret_cast<u32x4 *>(image) + tile * 1024 + lane;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 v = R[4 * sl + u] * (rb[u] * F16X2_ROW_SCALE);
+            *reinterpret_cast<u32x2 *>(tbuf + t_wr + u * 8 * RR_TROW) = (u32x2){f16_pack2(v.x, v.y), f16_pack2(v.z, v.w)};
+        }
+        out[(2 * sl) * 64] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd);
+        out[(2 * sl + 1) * 64] = *reinterpret_cast<const u32x4 *>(tbuf + t_rd + 32);
+    }
+    uint32_t zm = 0;   // bit 8u + i: tile row 8u + i (its 1/|row| sits in lanes 8i .. 8i + 7 of rb[u])
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned long long z = __ballot(rb[u] == 0.0f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zm |= (uint32_t)((z >> (8 * i)) & 1ull) << (8 * u + i);
+    }
+    if (lane == 0) image_zero[tile] = zm;
+}
+
+#ifndef SMT_RR_EXP
+#define SMT_RR_EXP 0
+#endif
+#if (SMT_RR_EXP & 256)
+// wave timeline of block 40, second step, main level (level_tiles large): (s_memtime << 8) | id, 1024 stamps per wave
+#define RR_STAMP(id) do { if (tracing && n_stamp < 1024) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (lane == 0) p.stamps[wave * 1024 + n_stamp] = (t_ << 8) | (unsigned)(id); ++n_stamp; } } while (0)
+#else
+#define RR_STAMP(id) do { } while (0)
+#endif
+template <int MODE, bool IMG = false>
 __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p)
 {
+    static_assert(!IMG || MODE >= 1, "the operand image holds fp16 rows");
     constexpr bool F16X2 = MODE >= 1;     // fp16 row operand (MODE 1 and 2)
     constexpr bool F16X1 = MODE == 2;     // ... and a single fp16 query operand
     // (plain constants, not RrGeom<MODE>::X inside the lambdas below: hipcc 7.2 silently drops the HOST-side instantiation of a
@@ -574,21 +800,58 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     __syncthreads();
 
     const uint64_t W = (uint64_t)row_blocks * WAVES;
-    const uint64_t steps = (p.level_tiles + W - 1) / W;  // block-uniform trip count
-    uint64_t it = (uint64_t)row_block * WAVES + wave;
+    const uint64_t steps = (p.level_tiles - p.tile_begin + W - 1) / W;  // block-uniform trip count
+    uint64_t it = p.tile_begin + (uint64_t)row_block * WAVES + wave;
     uint32_t pos = 0;            // streaming: running ring position (block-uniform); slot = pos & (SLOTS - 1)
     uint32_t tq = 0, tq_ahead = (uint32_t)AHEAD % n_qt;   // tile at position pos / pos + AHEAD (the tile sequence is cyclic over the sweeps)
     // transpose geometry: this lane WRITES row (8u + lane/8), bytes 8 * (lane%8) of a slice; it READS row j, quads 2mm + h
     const uint32_t t_wr = (uint32_t)((lane >> 3) * RR_TROW + (lane & 7) * 8);
     const uint32_t t_rd = (uint32_t)(j * RR_TROW + h * 16);
 
+#if (SMT_RR_EXP & 8)
+    u32x4 Ah[16], Al[F16X2 ? 1 : 16];
+    unsigned zero16 = 0, valid16 = 0;
+#endif
+#if (SMT_RR_EXP & 256)
+    int n_stamp = 0;
+#endif
+    uint32_t n_buf = 0;          // nominations waiting in this wave's LDS buffer (wave-uniform)
     for (uint64_t step = 0; step < steps; ++step, it += W) {
         const bool has = it < p.level_tiles;  // wave-uniform
         const uint64_t row0 = (has ? level_tile(it, p.stride, p.skip16) : 0) * 32;
+#if (SMT_RR_EXP & 256)
+        const bool tracing = p.stamps != nullptr && blockIdx.x == 40 && step == 1 && p.level_tiles > 100000;
+#endif
+        RR_STAMP(1);   // step start
 
+#if !(SMT_RR_EXP & 8)
         u32x4 Ah[16], Al[F16X2 ? 1 : 16];
         unsigned zero16 = 0, valid16 = 0;
-        if (has) {
+#endif
+        if constexpr (IMG) {
+            // ---- the operands are READY in the corpus' fp16 image (corpus_image.hip wrote them with the arithmetic of the branch
+            // below): 16 loads of 1 KiB, quad m of lane l at 16 (64 m + l) in the tile's 16 KiB -- half the bytes of the f32 rows,
+            // no norms, no conversion, no transpose
+            if (has) {
+                const uint64_t tile = row0 >> 5;
+                const u32x4 *img = reinterpret_cast<const u32x4 *>(p.image) + tile * 1024 + lane;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) Ah[m] = __builtin_nontemporal_load(img + m * 64);
+                RR_STAMP(2);
+                if (n_buf) flush_candidates_lds(lane, tbuf, n_buf, p.cand, p.counts);
+                const uint32_t zm = p.image_zero[tile] >> (4 * h);   // bit 8u + c: tile row 8u + c + 4h
+                zero16 = 0;
+                valid16 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        zero16 |= ((zm >> (8 * u + c)) & 1u) << (4 * u + c);
+                        if (row0 + 8 * u + c + 4 * h < p.n_rows) valid16 |= 1u << (4 * u + c);
+                    }
+            }
+        } else
+        if (has && (!(SMT_RR_EXP & 8) || step == 0)) {
             // ---- 32 coalesced loads: instruction i = 4s + u covers rows 8u .. 8u+7, dims 32s .. 32s+31 (128 B per row)
             f32x4 R[32];
             {
@@ -605,6 +868,9 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
 #pragma unroll
                 for (int i = 0; i < 32; ++i) R[i] = __builtin_nontemporal_load(base + rowv[i & 3] * 64 + 8 * (i >> 2));
             }
+            RR_STAMP(2);   // row loads issued
+            // the previous sweep's nominations leave the transpose buffer now: the atomics' round trip hides behind the row loads
+            if (n_buf) flush_candidates_lds(lane, tbuf, n_buf, p.cand, p.counts);
             // ---- 1/|row| for the four rows this lane holds pieces of (8 lanes per row)
             float rb[4];
 #pragma unroll
@@ -620,6 +886,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 part += __shfl_xor(part, 4);
                 rb[u] = part == 0.0f ? 0.0f : __frsqrt_rn(part);
             }
+            RR_STAMP(3);   // rows arrived, norms done
             // ---- per slice: scale, split, transpose hi then lo through the wave's buffer
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -666,72 +933,166 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             }
         }
 
-        // one (row tile x query tile) product + epilogue; B quads prefetched one K-step ahead.  While it runs the
-        // wave issues its share of the DMA that brings query tile stage_qt into stage_slot (stage: wave-uniform).
+        RR_STAMP(4);   // operands converted
+        // K-steps M0 .. M1 - 1 of one (row tile x query tile) product.  While it runs the wave issues its share of the DMA
+        // that brings query tile stage_qt into stage_slot (stage: wave-uniform): one row every second K-step, then the constants.
+        auto product_part = [&](f32x16 &acc, int slot, const int M0, const int M1, bool stage, uint32_t stage_qt, int stage_slot) __attribute__((always_inline)) {
+            // quad of (K-step m, half h): [hi, lo] pairs at 4 m + 2 h (+ 1) in the 1 KiB image; hi only at 2 m + h in the compact one
+            constexpr int QS = F16X1 ? 2 : 4;   // quads per K-step in a query row
+            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * SLOT_F4 + j * ROW_F4) + (F16X1 ? h : 2 * h);
+            const int M_CONSTS = M0 + (M1 - M0 > STAGE_EVERY * STAGE_ROWS ? STAGE_EVERY * STAGE_ROWS : M1 - M0 - 1);
+            if constexpr (F16X1) {
+                // B quads arrive in GROUPS of four K-steps, double-buffered: wait for group g (an explicit lgkmcnt(0)), THEN
+                // issue the four reads of group g + 1, THEN run the four MFMAs of group g -- the reads fly under 128 cycles of
+                // this wave's MFMAs and no MFMA waits for a read issued an instruction earlier (hipcc guards a read issued
+                // one or two K-steps ahead, as below for the other modes, with lgkmcnt(0) at every second MFMA).
+                constexpr int BG = 4;
+                u32x4 B[2][BG];
+#pragma unroll
+                for (int d = 0; d < BG; ++d) B[0][d] = bq[QS * (M0 + d)];
+#pragma unroll
+                for (int g = 0; g < (M1 - M0) / BG; ++g) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt unconstrained: group g is in registers
+                    if (g + 1 < (M1 - M0) / BG) {
+#pragma unroll
+                        for (int d = 0; d < BG; ++d) B[(g + 1) & 1][d] = bq[QS * (M0 + BG * (g + 1) + d)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int d = 0; d < BG; ++d) {
+                        const int m = M0 + BG * g + d;
+                        if ((m - M0) % STAGE_EVERY == 0 && (m - M0) / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, (m - M0) / STAGE_EVERY);
+                        if (m == M_CONSTS && stage) stage_consts(stage_qt, stage_slot);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[m]), __builtin_bit_cast(f16x8, B[g & 1][d]), acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // B quads run RR_BDIST K-steps ahead of their MFMAs (sched_barrier: hipcc otherwise sinks every read to its
+                // use and each K-step then starts with a full LDS round trip in front of 96 cycles of MFMA)
+                // (bf16 x 3 holds 128 operand VGPRs: one K-step of distance keeps it at 256 registers WITHOUT spilling -- with two
+                // it spilled three into scratch inside this loop; measured equal otherwise)
+                constexpr int BD = MODE == 0 ? 1 : RR_BDIST;
+                constexpr int NB = BD + 1;
+                u32x4 bh[NB], bl[NB];
+#pragma unroll
+                for (int d = 0; d < BD; ++d) { bh[d] = bq[QS * (M0 + d)]; bl[d] = bq[QS * (M0 + d) + 1]; }
+#pragma unroll
+                for (int m = M0; m < M1; ++m) {
+                    if (m + BD < M1) {
+                        bh[(m - M0 + BD) % NB] = bq[QS * (m + BD)];
+                        bl[(m - M0 + BD) % NB] = bq[QS * (m + BD) + 1];
+                    }
+                    if ((m - M0) % STAGE_EVERY == 0 && (m - M0) / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, (m - M0) / STAGE_EVERY);
+                    if (m == M_CONSTS && stage) stage_consts(stage_qt, stage_slot);
+                    if constexpr (F16X2) acc = mfma_f16x2(Ah[m], bh[(m - M0) % NB], bl[(m - M0) % NB], acc);
+                    else acc = mfma_bf16x3(Ah[m], Al[m], bh[(m - M0) % NB], bl[(m - M0) % NB], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        auto product_epilogue = [&](const f32x16 &acc, uint32_t qt, int slot) __attribute__((always_inline)) {
+            // (thresholds from LDS, staged with the tile: a global load here would sit in the same in-order vmcnt queue as the
+            // tile DMAs, and waiting for it would wait for them)
+            const f32x2 qc = *reinterpret_cast<const f32x2 *>(s_qconst + slot * RR_QCONST + j * 8);
+#if (SMT_RR_EXP & 1)
+            if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.678f)
+#endif
+            {
+#if (SMT_RR_EXP & 256)
+                if (p.buffered) append_candidates_lds(acc, zero16, valid16, qt * QT_ROWS + j, qc.x, qc.y, row0, h, lane, tbuf, n_buf, p.cand, p.counts,
+                                                      tracing && n_stamp < 1000 ? p.stamps + wave * 1024 : nullptr, n_stamp);
+#else
+                if (p.buffered) append_candidates_lds(acc, zero16, valid16, qt * QT_ROWS + j, qc.x, qc.y, row0, h, lane, tbuf, n_buf, p.cand, p.counts);
+#endif
+                else append_candidates(acc, zero16, valid16, qt * QT_ROWS + j, qc.x, qc.y, row0, h, p.cand, p.counts);
+            }
+        };
         auto tile_product = [&](uint32_t qt, int slot, bool stage, uint32_t stage_qt, int stage_slot) __attribute__((always_inline)) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const uint32_t q = qt * QT_ROWS + j;
-            // (from LDS, staged with the tile: a global load here would sit in the same in-order vmcnt queue as the
-            // tile DMAs issued below, and waiting for it would wait for them)
-            const f32x2 qc = *reinterpret_cast<const f32x2 *>(s_qconst + slot * RR_QCONST + j * 8);
-            const float thr_q = qc.x, rq_q = qc.y;
-            // quad of (K-step m, half h): [hi, lo] pairs at 4 m + 2 h (+ 1) in the 1 KiB image; hi only at 2 m + h in the compact one
-            constexpr int QS = F16X1 ? 2 : 4;   // quads per K-step in a query row
-            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * SLOT_F4 + j * ROW_F4) + (F16X1 ? h : 2 * h);
-            // B quads run RR_BDIST K-steps ahead of their MFMAs (sched_barrier: hipcc otherwise sinks every read to its
-            // use and each K-step then starts with a full LDS round trip in front of 96 cycles of MFMA)
-            // (bf16 x 3 holds 128 operand VGPRs: one K-step of distance keeps it at 256 registers WITHOUT spilling -- with two
-            // it spilled three into scratch inside this loop; measured equal otherwise)
-            constexpr int BD = MODE == 0 ? 1 : RR_BDIST;
-            constexpr int NB = BD + 1;
-            u32x4 bh[NB], bl[F16X1 ? 1 : NB];
-#pragma unroll
-            for (int d = 0; d < BD; ++d) { bh[d] = bq[QS * d]; if constexpr (!F16X1) bl[d] = bq[QS * d + 1]; }
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                if (m + BD < 16) {
-                    bh[(m + BD) % NB] = bq[QS * (m + BD)];
-                    if constexpr (!F16X1) bl[(m + BD) % NB] = bq[QS * (m + BD) + 1];
-                }
-                if (m % STAGE_EVERY == 0 && m / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, m / STAGE_EVERY);
-                if (m == STAGE_EVERY * STAGE_ROWS && stage) stage_consts(stage_qt, stage_slot);
-                if constexpr (F16X1)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[m]), __builtin_bit_cast(f16x8, bh[m % NB]), acc, 0, 0, 0);
-                else if constexpr (F16X2) acc = mfma_f16x2(Ah[m], bh[m % NB], bl[m % NB], acc);
-                else acc = mfma_bf16x3(Ah[m], Al[m], bh[m % NB], bl[m % NB], acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            append_candidates(acc, zero16, valid16, q, thr_q, rq_q, row0, h, p.cand, p.counts);
+            RR_STAMP(5);   // product start
+            product_part(acc, slot, 0, 16, stage, stage_qt, stage_slot);
+            RR_STAMP(6);   // MFMAs issued
+            product_epilogue(acc, qt, slot);
+            RR_STAMP(7);   // epilogue done
         };
 
         if (resident) {
             if (has)
                 for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t, false, 0, 0);
         } else {
+            // waves 0 .. 3: one whole product per position.  Waves 4 .. 7 (the second wave of each SIMD): half a product behind --
+            // their epilogue (and the wait for the last MFMA in front of it) falls into the middle of the other wave's product
+            // and the other way round.  In lock step (both waves of a SIMD released by the same barrier, same instruction
+            // stream) the MFMA pipe sat idle through two epilogues per position: ablation at 1000 x 10 M, epilogue compiled
+            // out: 7.2 -> 6.0 ms.
+#if (SMT_RR_EXP & 32)
+            const bool late = false;
+#elif (SMT_RR_EXP & 64)
+            const bool late = wave & 1;
+#elif (SMT_RR_EXP & 128)
+            const bool late = (wave >> 1) & 1;
+#else
+            const bool late = RrGeom<MODE>::STAGGER && wave >= WAVES / 2;     // wave-uniform
+#endif
+            f32x16 acc;
+            uint32_t qt_prev = 0;
+            int slot_prev = 0;
             for (uint32_t t = 0; t < n_qt; ++t) {
-                const int slot = (int)(pos & (SLOTS - 1)), slot_ahead = (int)((pos + AHEAD) & (SLOTS - 1));   // slot_ahead was read during step pos - 1
-                if (has) tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
-                else stage_tile(qt_lo + tq_ahead, slot_ahead);
-                // this wave's share of tile pos + 1 has landed: only the (SLOTS - 2) x (STAGE_ROWS + 1) younger DMAs may still fly
+                const int slot = (int)(pos & (SLOTS - 1)), slot_ahead = (int)((pos + AHEAD) & (SLOTS - 1));
+#if (SMT_RR_EXP & 2)
+                if (has) tile_product(qt_lo + tq, slot, false, qt_lo + tq_ahead, slot_ahead);
+#else
+                if (has) {
+                    if (!late) {
+                        tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
+                    } else {
+                        RR_STAMP(5);
+                        if (t != 0) {
+                            product_part(acc, slot_prev, 8, 16, false, 0, 0);
+                            RR_STAMP(6);
+                            product_epilogue(acc, qt_prev, slot_prev);
+                            RR_STAMP(7);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                        product_part(acc, slot, 0, 8, true, qt_lo + tq_ahead, slot_ahead);
+                        RR_STAMP(10);  // (late waves) first half of the next product issued
+                        qt_prev = qt_lo + tq;
+                        slot_prev = slot;
+                    }
+                } else {
+                    stage_tile(qt_lo + tq_ahead, slot_ahead);
+                }
+#endif
+                // this wave's share of the next group's tiles has landed: only the younger DMAs may still fly
                 // (a raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), i.e. it would wait
                 // for the tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
                 // At the border in front of position pos + 1 the tiles pos + 1 .. pos + GT must have landed; the younger ones,
                 // pos + GT + 1 .. pos + AHEAD, may still fly.
-                constexpr int FLY = (AHEAD - GT) * (STAGE_ROWS + 1);               // 10 (four slots, GT 1) / 20 (eight, GT 2)
+                constexpr int FLY = (AHEAD - GT) * (STAGE_ROWS + 1);               // 5 (four slots, GT 1) / 15 (eight, GT 2)
                 static_assert(FLY >= 0 && FLY < 64, "vmcnt is a 6-bit counter");
-                if ((pos + 1) % GT == 0) {   // block-uniform
+                if ((pos + 1) % GT == 0 && !(SMT_RR_EXP & 4)) {   // block-uniform
                     __builtin_amdgcn_s_waitcnt(0x0F70 | (FLY & 15) | ((FLY >> 4) << 14));  // vmcnt(FLY), expcnt / lgkmcnt unconstrained
+                    RR_STAMP(8);   // own DMAs landed
                     __builtin_amdgcn_s_barrier();
+                    RR_STAMP(9);   // barrier passed
                 }
                 asm volatile("" ::: "memory");
                 ++pos;
                 tq = tq + 1 == n_qt ? 0 : tq + 1;
                 tq_ahead = tq_ahead + 1 == n_qt ? 0 : tq_ahead + 1;
             }
+            if (has && late) {   // the second half of the sweep's last product (its slot is not restaged before every wave passed
+                                 // the next group border: AHEAD = SLOTS - GT - 1)
+                product_part(acc, slot_prev, 8, 16, false, 0, 0);
+                product_epilogue(acc, qt_prev, slot_prev);
+            }
         }
     }
+    if (n_buf) flush_candidates_lds(lane, tbuf, n_buf, p.cand, p.counts);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no LDS-DMA may outlive the block's LDS allocation
 }
 
@@ -1261,6 +1622,10 @@ static int ensure_gemm_attrs(smt_ctx *ctx)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rowreg_kernel<2, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK((lr_set_attr<false>()));
         SMT_HIP_CHECK((lr_set_attr<true>()));
         ctx->attr_done |= ATTR_GEMM;
@@ -1288,8 +1653,12 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // 32 M rows (the rank spacing of the distances shrinks with the shard; at 10 M random rows the k-th and k+8-th distances
     // are ~8e-3 apart), provided the lists have room for the wider guard band.  Small batches are HBM-bound: bf16 x 3.
     const bool auto_fp16 = rowreg && ctx->tune.gemm_nominate == 0 && a.rows <= (1ull << 25);
+    // With the corpus' fp16 operand image at hand (ScanArgs::image) the fp16 modes read HALF the bytes per row and skip the row
+    // phase: f16 x 2 then also takes the batches below 128 queries, which are HBM-bound.
+    const bool have_image = a.image != nullptr && rowreg && ctx->tune.gemm_image != 0;
     const bool f16x1 = rowreg && (ctx->tune.gemm_nominate == 3 || (auto_fp16 && nqt >= 8 && a.k_out + 24 <= 64));
-    const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && nqt >= 4));
+    const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && (nqt >= 4 || (have_image && a.k_out + 16 <= 64))));
+    const bool use_image = have_image && (f16x1 || f16x2);
     // guard band, see candidates_per_list (scan_kernels.hip): the wider the certificate band, the more rows are nominated
     // (the proof needs the k-th exact distance to lie 2 x the band below the worst nominated one): 8 / 16 / 24
     const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)std::max(ctx->tune.guard_band, f16x1 ? 24 : f16x2 ? 16 : 8));
@@ -1372,6 +1741,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.nq = a.nq;
         g.nqt = nqt;
         g.level_tiles = multiples - parents;
+        g.tile_begin = 0;
         g.stride = stride;
         g.skip16 = lev == 0 ? 0 : LEVEL_RATIO;
         g.qsplit = 1;
@@ -1380,6 +1750,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.cand = cand;
         g.counts = counts;
         g.chunk_table = filtered ? chunk_table : nullptr;
+        g.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
+        g.buffered = lev > 0 && ctx->tune.gemm_buffered != 0;
+        g.image = use_image ? a.image : nullptr;
+        g.image_zero = use_image ? a.image_zero : nullptr;
         g.n_chunks = n_chunks;
         if (g.level_tiles > 0 && rowreg) {
             const uint64_t need_blocks = (g.level_tiles + RR_WAVES - 1) / RR_WAVES;
@@ -1388,11 +1762,39 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                 g.qsplit = (uint32_t)std::min<uint64_t>(nqt, std::max<uint64_t>(1, (uint64_t)2 * blocks / need_blocks));
                 nb = (int)(need_blocks * g.qsplit);
             }
-            prof_begin(ctx, "gemm");
-            if (f16x1) hipLaunchKernelGGL(gemm_rowreg_kernel<2>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<2>::SMEM, ctx->stream, g);
-            else if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<1>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<1>::SMEM, ctx->stream, g);
-            else hipLaunchKernelGGL(gemm_rowreg_kernel<0>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<0>::SMEM, ctx->stream, g);
-            prof_end(ctx, "gemm");
+            // THE LAST LEVEL IN TWO PARTS when it is MFMA-bound (a streamed sweep): its thresholds come from a 1/ratio sample and
+            // admit ~ratio x k' rows per query -- 12 % of the (row tile, query tile) products of a 1000 x 10 M batch nominate
+            // something, and a nominating wave holds its block's other seven at the ring barrier (wave timeline: 63 % of the
+            // barriers had such a straggler).  After the first eighth of the level a select pass tightens the thresholds to what
+            // 18 % of the rows know (~3 x fewer nominations for the remaining 7/8); it costs one more launch and select pass.
+            const uint64_t level_end = g.level_tiles;
+            uint64_t part_end = level_end;
+            if (ctx->tune.gemm_split_last && lev == L - 1 && lev > 0 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
+                level_end >= (uint64_t)64 * blocks * RR_WAVES)
+                part_end = (level_end / 8 + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
+            for (;;) {
+                g.level_tiles = part_end;
+                prof_begin(ctx, "gemm");
+                if (f16x1 && use_image) hipLaunchKernelGGL((gemm_rowreg_kernel<2, true>), dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<2>::SMEM, ctx->stream, g);
+                else if (f16x2 && use_image) hipLaunchKernelGGL((gemm_rowreg_kernel<1, true>), dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<1>::SMEM, ctx->stream, g);
+                else if (f16x1) hipLaunchKernelGGL(gemm_rowreg_kernel<2>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<2>::SMEM, ctx->stream, g);
+                else if (f16x2) hipLaunchKernelGGL(gemm_rowreg_kernel<1>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<1>::SMEM, ctx->stream, g);
+                else hipLaunchKernelGGL(gemm_rowreg_kernel<0>, dim3(nb), dim3(RR_THREADS), (size_t)RrGeom<0>::SMEM, ctx->stream, g);
+                prof_end(ctx, "gemm");
+                if (part_end == level_end) break;
+                LevelSelectParams mid;
+                mid.cand = cand;
+                mid.counts = counts;
+                mid.tau = tau;
+                mid.overflow = overflow;
+                mid.kp = kp;
+                mid.qconst = qconst;
+                prof_begin(ctx, "select");
+                hipLaunchKernelGGL(level_select_kernel, dim3(a.nq), dim3(1024), 0, ctx->stream, mid);
+                prof_end(ctx, "select");
+                g.tile_begin = part_end;
+                part_end = level_end;
+            }
         } else if (g.level_tiles > 0 && lds_rows) {
             const uint64_t need_blocks = (g.level_tiles + LR_WAVES - 1) / LR_WAVES;
             const int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
@@ -1524,6 +1926,11 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     g.cand = cand;
     g.counts = counts;
     g.chunk_table = nullptr;
+    g.stamps = nullptr;
+    g.buffered = 0;
+    g.image = nullptr;
+    g.image_zero = nullptr;
+    g.tile_begin = 0;
     g.n_chunks = 0;
     const int blocks = ctx->tune.gemm_blocks > 0 ? ctx->tune.gemm_blocks : ctx->num_cus;
     const int nb = (int)std::min<uint64_t>((uint64_t)blocks, (g.level_tiles + RR_WAVES - 1) / RR_WAVES);
@@ -1534,6 +1941,18 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     *cand_out = cand;
     *counts_out = counts;
     *cand_stride = CAND_CAP;
+    return SMT_OK;
+}
+
+int launch_pack_image(smt_ctx *ctx, const float *corpus, uint64_t n_rows, uint64_t first_tile, uint64_t n_tiles, void *image,
+                      uint32_t *image_zero)
+{
+    if (n_tiles == 0) return SMT_OK;
+    prof_begin(ctx, "pack_image");
+    hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, ctx->stream, corpus, n_rows, first_tile,
+                       n_tiles, reinterpret_cast<uint32_t *>(image), image_zero);
+    prof_end(ctx, "pack_image");
+    SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }
 

@@ -1,0 +1,115 @@
+"""The fp16 operand image of a corpus (smt_corpus_prepack, include/semtools_hip.h): derived data -- a batched search returns the
+same rows and the same f64 distances with it and without it; appends, writes and truncation keep it current."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _unit(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, 256)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def _topk64(rows, q, k):
+    d = 1.0 - (q.astype(np.float64) @ rows.astype(np.float64).T) / (
+        np.linalg.norm(q.astype(np.float64), axis=1)[:, None] * np.maximum(np.linalg.norm(rows.astype(np.float64), axis=1), 1e-300)[None, :])
+    idx = np.argsort(d, axis=1, kind="stable")[:, :k]
+    return idx, np.take_along_axis(d, idx, axis=1)
+
+
+@pytest.fixture(scope="module")
+def smt():
+    import semtools_amd as smt
+    return smt
+
+
+def _corpus(smt, ctx, rows):
+    c = smt.Corpus(ctx)
+    c.append(rows)
+    return c
+
+
+def _search(c, q, k):
+    res = c.search(q, top_k=k)
+    return [list(r) for r, _ in res], [list(d) for _, d in res]
+
+
+@pytest.mark.parametrize("nq", [8, 40, 130, 300])
+def test_same_answers_with_and_without_the_image(smt, nq):
+    ctx = smt.Context(0)
+    rows = _unit(200_003, 1)            # a ragged last tile
+    rows[77] = 0.0                      # a zero row
+    q = _unit(nq, 2)
+    q[3] = 0.0                          # a zero query
+    plain = _corpus(smt, ctx, rows)
+    ctx.set_tuning("corpus_image", 0)
+    r0, d0 = _search(plain, q, 10)
+    assert plain.image_bytes == 0
+    ctx.set_tuning("corpus_image", 1)
+    packed = _corpus(smt, ctx, rows)
+    r1, d1 = _search(packed, q, 10)
+    assert packed.image_bytes >= (200_003 + 31) // 32 * 16384      # built by the first batch
+    for a, b, da, db in zip(r0, r1, d0, d1):
+        assert list(a) == list(b)
+        assert list(da) == list(db)     # f64 re-scored from the f32 rows either way
+    want_rows, want_d = _topk64(rows, q[[0, 5]], 10)
+    for i, qi in enumerate((0, 5)):
+        assert list(r1[qi]) == list(want_rows[i])
+        np.testing.assert_allclose(d1[qi], want_d[i], atol=1e-12)
+
+
+def test_image_follows_appends_writes_and_truncation(smt):
+    ctx = smt.Context(0)
+    rows = _unit(70_000, 3)
+    q = _unit(16, 4)
+    c = _corpus(smt, ctx, rows[:66_000])
+    _search(c, q, 5)
+    assert c.image_bytes > 0
+    # append: the planted row must be found at once
+    extra = rows[66_000:].copy()
+    extra[1234] = q[7]
+    c.append(extra)
+    r, d = _search(c, q, 5)
+    assert r[7][0] == 66_000 + 1234 and d[7][0] < 1e-6
+    # write: the answer moves with the row
+    c.write_rows(100, q[2:3])
+    r, d = _search(c, q, 5)
+    assert r[2][0] == 100 and d[2][0] < 1e-6
+    # truncate below the planted rows, then append other rows into the same tiles
+    c.truncate(66_010)
+    c.append(rows[:500])
+    r, d = _search(c, q, 5)
+    assert r[7][0] != 66_000 + 1234
+    full = np.concatenate([rows[:66_000], extra[:10], rows[:500]])
+    full[100] = q[2]
+    want_rows, want_d = _topk64(full, q, 5)
+    for i in range(16):
+        assert list(r[i]) == list(want_rows[i])
+        np.testing.assert_allclose(d[i], want_d[i], atol=1e-12)
+
+
+def test_adopted_rows_get_an_image_only_on_request(smt):
+    ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    x = torch.from_numpy(_unit(100_000, 5)).cuda()
+    q = _unit(64, 6)
+    c = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=x.shape[0])
+    r0, d0 = _search(c, q, 10)
+    assert c.image_bytes == 0
+    c.prepack()
+    assert c.image_bytes > 0
+    r1, d1 = _search(c, q, 10)
+    for a, b, da, db in zip(r0, r1, d0, d1):
+        assert list(a) == list(b) and list(da) == list(db)
+    # the caller changed a row: prepack again
+    x[4321] = torch.from_numpy(q[9]).cuda()
+    torch.cuda.synchronize()
+    c.prepack()
+    r2, d2 = _search(c, q, 10)
+    assert r2[9][0] == 4321 and d2[9][0] < 1e-6
+    c.prepack(False)
+    assert c.image_bytes == 0
+    r3, d3 = _search(c, q, 10)
+    assert list(r3[9]) == list(r2[9])

@@ -24,6 +24,7 @@ def main():
                     help="1 = default routing, 2 = gemm_level_kernel instead of the LDS-row kernel (f32 / gemm_rowreg=0 modes)")
     ap.add_argument("--ranges", action="store_true", help="also time a range-filtered batch (two ranges, 90 %% of the rows)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--prepack", action="store_true", help="build the corpus' fp16 operand image first (smt_corpus_prepack)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for smt_set_tuning (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,6 +40,11 @@ def main():
     torch.cuda.synchronize()
     ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=args.rows)
+    if args.prepack:
+        t0 = time.perf_counter()
+        corpus.prepack()
+        ctx.synchronize()
+        print(json.dumps({"prepack_ms": round((time.perf_counter() - t0) * 1e3, 2), "image_bytes": corpus.image_bytes}))
     for kv in args.tune:
         key, val = kv.split("=")
         ctx.set_tuning(key, int(val))
