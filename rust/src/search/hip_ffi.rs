@@ -115,6 +115,8 @@ extern "C" {
     pub fn smt_corpus_write_rows(corpus: *mut SmtCorpus, first_row: u64, rows: *const f32, n_rows: u64) -> c_int;
     pub fn smt_corpus_read_rows(corpus: *mut SmtCorpus, first_row: u64, n_rows: u64, out_host: *mut f32) -> c_int;
     pub fn smt_corpus_truncate(corpus: *mut SmtCorpus, n_rows: u64) -> c_int;
+    pub fn smt_corpus_prepack(corpus: *mut SmtCorpus, enable: c_int) -> c_int;
+    pub fn smt_corpus_image_bytes(corpus: *const SmtCorpus) -> u64;
     pub fn smt_corpus_rows(corpus: *const SmtCorpus) -> u64;
     pub fn smt_corpus_dim(corpus: *const SmtCorpus) -> u32;
     pub fn smt_corpus_save(corpus: *mut SmtCorpus, path: *const c_char) -> c_int;
