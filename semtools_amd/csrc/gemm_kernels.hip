@@ -486,12 +486,8 @@ struct RrGeom {
     // during product pos into the slot that tile pos + AHEAD - SLOTS used: that one must belong to an EARLIER group than
     // pos (every wave is past it), hence AHEAD = SLOTS - GT; at a group border the tiles of the next group were staged at
     // least AHEAD - GT + 1 products ago.
-    // STAGGERED SWEEP: the waves 4 .. 7 of a block (the second wave of each SIMD) run half a product behind the waves 0 .. 3 --
-    // during position pos they finish product pos - 1 (K-steps 8 .. 15, epilogue) and start product pos (K-steps 0 .. 7) -- so a
-    // slot is read for one position longer than its own: one slot less ahead.
     static constexpr int GT = MODE == 2 ? SMT_RR_GT : 1;
-    static constexpr bool STAGGER = MODE != 0;   // (bf16 x 3 has no registers for an accumulator that lives across positions)
-    static constexpr int AHEAD = SLOTS - GT - (STAGGER ? 1 : 0);
+    static constexpr int AHEAD = SLOTS - GT;
     static constexpr int SMEM = SLOTS * SLOT_F4 * 16 + RR_WAVES * RR_TBUF + SLOTS * RR_QCONST;
 };
 constexpr int RR_SMEM = RrGeom<0>::SMEM;
@@ -823,6 +819,13 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
         const bool tracing = p.stamps != nullptr && blockIdx.x == 40 && step == 1 && p.level_tiles > 100000;
 #endif
         RR_STAMP(1);   // step start
+#if (SMT_RR_EXP & 256)
+        // the shader clock under this load: s_memtime against the 100 MHz s_memrealtime, one step apart
+        if (p.stamps != nullptr && blockIdx.x == 40 && wave == 0 && lane == 0 && (step == 1 || step == 9) && p.level_tiles > 100000) {
+            p.stamps[8 * 1024 + (step == 1 ? 0 : 2)] = __builtin_readcyclecounter();
+            p.stamps[8 * 1024 + (step == 1 ? 1 : 3)] = wall_clock64();
+        }
+#endif
 
 #if !(SMT_RR_EXP & 8)
         u32x4 Ah[16], Al[F16X2 ? 1 : 16];
@@ -1023,56 +1026,20 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             if (has)
                 for (uint32_t t = 0; t < n_qt; ++t) tile_product(qt_lo + t, (int)t, false, 0, 0);
         } else {
-            // waves 0 .. 3: one whole product per position.  Waves 4 .. 7 (the second wave of each SIMD): half a product behind --
-            // their epilogue (and the wait for the last MFMA in front of it) falls into the middle of the other wave's product
-            // and the other way round.  In lock step (both waves of a SIMD released by the same barrier, same instruction
-            // stream) the MFMA pipe sat idle through two epilogues per position: ablation at 1000 x 10 M, epilogue compiled
-            // out: 7.2 -> 6.0 ms.
-#if (SMT_RR_EXP & 32)
-            const bool late = false;
-#elif (SMT_RR_EXP & 64)
-            const bool late = wave & 1;
-#elif (SMT_RR_EXP & 128)
-            const bool late = (wave >> 1) & 1;
-#else
-            const bool late = RrGeom<MODE>::STAGGER && wave >= WAVES / 2;     // wave-uniform
-#endif
-            f32x16 acc;
-            uint32_t qt_prev = 0;
-            int slot_prev = 0;
             for (uint32_t t = 0; t < n_qt; ++t) {
-                const int slot = (int)(pos & (SLOTS - 1)), slot_ahead = (int)((pos + AHEAD) & (SLOTS - 1));
+                const int slot = (int)(pos & (SLOTS - 1)), slot_ahead = (int)((pos + AHEAD) & (SLOTS - 1));   // slot_ahead was read during step pos - 1
 #if (SMT_RR_EXP & 2)
                 if (has) tile_product(qt_lo + tq, slot, false, qt_lo + tq_ahead, slot_ahead);
 #else
-                if (has) {
-                    if (!late) {
-                        tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
-                    } else {
-                        RR_STAMP(5);
-                        if (t != 0) {
-                            product_part(acc, slot_prev, 8, 16, false, 0, 0);
-                            RR_STAMP(6);
-                            product_epilogue(acc, qt_prev, slot_prev);
-                            RR_STAMP(7);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                        product_part(acc, slot, 0, 8, true, qt_lo + tq_ahead, slot_ahead);
-                        RR_STAMP(10);  // (late waves) first half of the next product issued
-                        qt_prev = qt_lo + tq;
-                        slot_prev = slot;
-                    }
-                } else {
-                    stage_tile(qt_lo + tq_ahead, slot_ahead);
-                }
+                if (has) tile_product(qt_lo + tq, slot, true, qt_lo + tq_ahead, slot_ahead);
+                else stage_tile(qt_lo + tq_ahead, slot_ahead);
 #endif
                 // this wave's share of the next group's tiles has landed: only the younger DMAs may still fly
                 // (a raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), i.e. it would wait
                 // for the tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
                 // At the border in front of position pos + 1 the tiles pos + 1 .. pos + GT must have landed; the younger ones,
                 // pos + GT + 1 .. pos + AHEAD, may still fly.
-                constexpr int FLY = (AHEAD - GT) * (STAGE_ROWS + 1);               // 5 (four slots, GT 1) / 15 (eight, GT 2)
+                constexpr int FLY = (AHEAD - GT) * (STAGE_ROWS + 1);               // 10 (four slots, GT 1) / 20 (eight, GT 2)
                 static_assert(FLY >= 0 && FLY < 64, "vmcnt is a 6-bit counter");
                 if ((pos + 1) % GT == 0 && !(SMT_RR_EXP & 4)) {   // block-uniform
                     __builtin_amdgcn_s_waitcnt(0x0F70 | (FLY & 15) | ((FLY >> 4) << 14));  // vmcnt(FLY), expcnt / lgkmcnt unconstrained
@@ -1084,11 +1051,6 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 ++pos;
                 tq = tq + 1 == n_qt ? 0 : tq + 1;
                 tq_ahead = tq_ahead + 1 == n_qt ? 0 : tq_ahead + 1;
-            }
-            if (has && late) {   // the second half of the sweep's last product (its slot is not restaged before every wave passed
-                                 // the next group border: AHEAD = SLOTS - GT - 1)
-                product_part(acc, slot_prev, 8, 16, false, 0, 0);
-                product_epilogue(acc, qt_prev, slot_prev);
             }
         }
     }

@@ -7,7 +7,8 @@ cp /tmp/orig.so semtools_amd/lib/libsemtools_hip.so
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/r03_k3_wave_timeline.json"))
-for w in ("0", "3", "4"):
+print("shader clock over 8 steps of the traced block: %s GHz" % d.get("shader_clock_GHz_over_8_steps"))
+for w in ("0", "4"):
     v = d["waves"][w]
     print("wave", w, "total", v["total_ticks"])
     for k, t in v["transitions"].items():

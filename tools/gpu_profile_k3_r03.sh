@@ -5,8 +5,8 @@ root="$(pwd)"; out="$root/gpurun_out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   name="$1"; shift
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_k3_$name" -o k3 -- python "$root/tools/bench_small_batch.py" --nq 128 1000 --reps 2 > "$out/pmc_k3_$name.log" 2>&1
-  python "$root/tools/summarize_pmc.py" "$out/pmc_k3_$name" "$out/r03_k3_pmc_$name.json" "rocprofv3 --pmc $* --kernel-trace -- python tools/bench_small_batch.py --nq 128 1000 --reps 2 (10 M rows; _max = the main level of the 1000-query batch for gemm_rowreg_kernel<2>, of the 128-query batch for <1>)" > /dev/null
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_k3_$name" -o k3 -- python "$root/tools/bench_small_batch.py" --nq 128 1000 --reps 2 $K3_PROFILE_ARGS > "$out/pmc_k3_$name.log" 2>&1
+  python "$root/tools/summarize_pmc.py" "$out/pmc_k3_$name" "$out/r03_k3_pmc_$name.json" "rocprofv3 --pmc $* --kernel-trace -- python tools/bench_small_batch.py --nq 128 1000 --reps 2 $K3_PROFILE_ARGS (10 M rows; _max = the main level of the 1000-query batch for gemm_rowreg_kernel<2>, of the 128-query batch for <1>)" > /dev/null
 }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16
 run lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS

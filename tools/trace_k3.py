@@ -38,7 +38,8 @@ def main():
     corpus.search_topk_device(q.data_ptr(), nq, 10, 0, out_rows.data_ptr(), out_dist.data_ptr())
     ctx.synchronize()
     s = stamps[:8 * 1024].cpu().numpy().astype(np.uint64).reshape(8, 1024)
-    out = {"nq": nq, "waves": {}}
+    ck = stamps[8 * 1024:8 * 1024 + 4].cpu().numpy().astype(np.int64)
+    out = {"nq": nq, "waves": {}, "shader_clock_GHz_over_8_steps": round(float(ck[2] - ck[0]) / float(ck[3] - ck[1]) * 0.1, 3) if ck[3] > ck[1] else None}
     for w in range(8):
         v = s[w][s[w] != 0]
         ids = (v & np.uint64(255)).astype(int)
