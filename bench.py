@@ -595,23 +595,38 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     out_rows = torch.empty(nq, k, dtype=torch.int64, device=device)
     out_dist = torch.empty(nq, k, dtype=torch.float64, device=device)
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
-    corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())  # warm-up
-    torch.cuda.synchronize(device)
+
+    def timed():
+        corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())  # warm-up
+        torch.cuda.synchronize(device)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())
+        torch.cuda.synchronize(device)
+        w = (time.perf_counter() - t0) / reps
+        n, ms = ctx.prof_read("gemm")
+        ctx.prof_enable(False)
+        return w, n, ms / reps * 1e-3
+
     ctx.uncertain_count()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
+    # (1) from the f32 rows alone: what a corpus ADOPTED from device memory gets (this one is a torch tensor) until its owner asks
+    # for the operand image; (2) with the fp16 operand image (smt_corpus_prepack; a corpus the library owns -- the workspace
+    # store's -- builds it at its first batch): half the bytes per row, no row phase.  Same nominations, same answers.
+    wall_f32, n_g_f32, gemm_s_f32 = timed()
+    rows_f32, dist_f32 = out_rows.clone(), out_dist.clone()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())
-    torch.cuda.synchronize(device)
-    wall = (time.perf_counter() - t0) / reps
-    n_g, ms_g = ctx.prof_read("gemm")
-    ctx.prof_enable(False)
-    gemm_s = ms_g / reps * 1e-3
+    corpus.prepack()
+    ctx.synchronize()
+    prepack_s = time.perf_counter() - t0
+    image_bytes = corpus.image_bytes
+    wall, n_g, gemm_s = timed()
+    image_same = int(((rows_f32 == out_rows).all(dim=1) & (dist_f32 == out_dist).all(dim=1)).sum().item())
     flops = 2.0 * nq * rows * 256
     # gemm_kernels.hip launch_gemm_topk, the auto rule of gemm_nominate: MFMAs issued per algorithmic multiply-add
     small_shard = rows <= (1 << 25)
-    issued = 1.0 if (nq >= 256 and small_shard and k + 24 <= 64) else 2.0 if (nq >= 128 and small_shard) else 3.0
+    issued = 1.0 if (nq >= 256 and small_shard and k + 24 <= 64) else 2.0 if (small_shard and k + 16 <= 64) else 3.0   # (with the image)
     mode_name = {1.0: "f16 x 1", 2.0: "f16 x 2", 3.0: "bf16 x 3"}[issued]
     ok = True
     for i in range(min(3, nq)):  # independent fp64 check of a few queries
@@ -622,10 +637,12 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     # rows identical, distances bit-identical (both paths end in the same exact f64 rescoring)
     k2_rows = torch.empty_like(out_rows)
     k2_dist = torch.empty_like(out_dist)
+    ctx.set_tuning("gemm_min_nq", 8)     # (batches of 3 .. 7 queries would take K3 too on a shard this size: keep them on the scan kernel)
     for i in range(0, nq, 4):
         n = min(4, nq - i)
         corpus.search_topk_device(q[i:i + n].data_ptr(), n, k, 0, k2_rows[i:i + n].data_ptr(), k2_dist[i:i + n].data_ptr())
     torch.cuda.synchronize(device)
+    ctx.set_tuning("gemm_min_nq", 3)
     same = ((k2_rows == out_rows).all(dim=1) & (k2_dist == out_dist).all(dim=1))
     n_same = int(same.sum().item())
     uncertain = ctx.uncertain_count()
@@ -671,10 +688,24 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         "roofline": {"kernel": f"gemm_rowreg_kernel (K3, {mode_name})", "bound": "mfma",
                      "achieved": issued * flops / gemm_s / 1e12,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": issued * flops / gemm_s / 2500e12, "traffic": traffic,
-                     "traffic_source": traffic_source, "algorithmic_bytes_per_batch": rows * ROW_BYTES,
+                     "traffic_source": traffic_source, "algorithmic_bytes_per_batch": rows * ROW_BYTES // 2,
+                     "algorithmic_bytes_note": "512 B per row from the fp16 operand image (1024 B per row of f32 without it); `traffic` is the "
+                                               "largest launch of the batch, 7/8 of 15/16 of the rows",
                      "algorithmic_flops_per_batch": flops, "issued_16bit_mfma_flops_per_batch": issued * flops,
                      "algorithmic_rate_over_f32_mfma_peak": flops / gemm_s / 157.3e12,
-                     "gemm_ms_per_batch": gemm_s * 1e3, "gemm_launches_per_batch": n_g // reps},
+                     "gemm_ms_per_batch": gemm_s * 1e3, "gemm_launches_per_batch": n_g // reps,
+                     # what the 16-bit pipe of this part sustains on DATA (it is power-managed: constants run at 2.4 GHz and 0.98
+                     # of nominal, random fp16 operands at ~1.45 GHz): tools/micro/mfma_peak_f16.hip, profiles/r03_mfma_peak_f16.jsonl
+                     "sustained_peak_random_operands": {"registers_TFLOPs": 1635.0, "lds_fed_with_epilogue_TFLOPs": 1396.0,
+                                                        "frac_of_lds_fed": issued * flops / gemm_s / 1396e12,
+                                                        "source": "profiles/r03_mfma_peak_f16.jsonl (not measured by this run)"}},
+        "operand_image": {"build_ms": prepack_s * 1e3, "bytes": image_bytes, "bytes_per_row": image_bytes / max(rows, 1),
+                          "answers_identical_to_f32_rows_run": f"{image_same}/{nq}",
+                          "note": "derived fp16 copy of the rows in MFMA operand order; nominations only -- every returned distance is "
+                                  "re-scored in f64 from the f32 rows"},
+        "f32_rows_only": {"queries_per_s": nq / wall_f32, "ms_per_batch": wall_f32 * 1e3, "gemm_ms_per_batch": gemm_s_f32 * 1e3,
+                          "gemm_launches_per_batch": n_g_f32 // reps, "frac_of_2.5PF": issued * flops / gemm_s_f32 / 2500e12,
+                          "note": "the same batch before smt_corpus_prepack: gemm_rowreg_kernel converts the f32 rows in its row phase"},
         "roofline_f32_mfma": f32_leg,
         "checks": {"torch_fp64_topk_match": ok, "k2_path_agreement": f"{n_same}/{nq}",
                    "selects_without_exactness_certificate": uncertain},

@@ -81,10 +81,25 @@ def test_c3_thousand_queries_ten_million_rows_in_the_default_mode(gpu_ctx):
     assert out_rows[1, :2].tolist() == [5, 9_999_999]
     # every query against the single-query scan path (K2, <= 4 queries per pass): rows and f64 distances identical
     k2_rows, k2_dist = torch.empty_like(out_rows), torch.empty_like(out_dist)
-    for i in range(0, nq, 4):
-        c.search_topk_device(q[i:i + 4].data_ptr(), 4, k, 0, k2_rows[i:i + 4].data_ptr(), k2_dist[i:i + 4].data_ptr())
-    torch.cuda.synchronize()
+    gpu_ctx.set_tuning("gemm_min_nq", 8)                     # (4 queries over 10 M rows would take K3 too: keep them on the scan kernel)
+    gpu_ctx.prof_enable(True)
+    gpu_ctx.prof_reset()
+    try:
+        for i in range(0, nq, 4):
+            c.search_topk_device(q[i:i + 4].data_ptr(), 4, k, 0, k2_rows[i:i + 4].data_ptr(), k2_dist[i:i + 4].data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_tuning("gemm_min_nq", 3)
+    assert gpu_ctx.prof_read("gemm")[0] == 0                  # no batched kernel in the truth
+    gpu_ctx.prof_enable(False)
     assert bool((k2_rows == out_rows).all()) and bool((k2_dist == out_dist).all())
+    # ... and the same batch over the corpus' fp16 operand image (smt_corpus_prepack): identical again
+    c.prepack()
+    img_rows, img_dist = torch.empty_like(out_rows), torch.empty_like(out_dist)
+    c.search_topk_device(q.data_ptr(), nq, k, 0, img_rows.data_ptr(), img_dist.data_ptr())
+    torch.cuda.synchronize()
+    assert gpu_ctx.uncertain_count() == 0
+    assert bool((img_rows == out_rows).all()) and bool((img_dist == out_dist).all())
     # 16 queries against an independent fp64 evaluation: indices and distances
     for i in list(range(8)) + [100, 257, 400, 511, 640, 777, 901, 999]:
         tv, ti = _fp64_topk(x, q[i], k)

@@ -54,10 +54,12 @@ def main():
         # truth for every query: the single-query scan path (K2, <= 4 queries per pass)
         k2_rows = torch.empty(nq, args.k, dtype=torch.int64, device=dev)
         k2_dist = torch.empty(nq, args.k, dtype=torch.float64, device=dev)
+        ctx.set_tuning("gemm_min_nq", 8)   # (3 .. 7 queries would take K3 too on a shard this size)
         for i in range(0, nq, 4):
             n = min(4, nq - i)
             corpus.search_topk_device(q[i:i + n].data_ptr(), n, args.k, 0, k2_rows[i:i + n].data_ptr(), k2_dist[i:i + n].data_ptr())
         ctx.synchronize()
+        ctx.set_tuning("gemm_min_nq", 3)
         for variant in args.variants:
             # 1 = default routing; 2 = (with --tune gemm_rowreg=0 or gemm_bf16x3=0) gemm_level_kernel for every size
             # instead of the LDS-row kernel up to 64 queries.  (Variant 0, the first-generation resident-query
