@@ -1729,6 +1729,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             // something, and a nominating wave holds its block's other seven at the ring barrier (wave timeline: 63 % of the
             // barriers had such a straggler).  After the first eighth of the level a select pass tightens the thresholds to what
             // 18 % of the rows know (~3 x fewer nominations for the remaining 7/8); it costs one more launch and select pass.
+            // the LDS nomination buffer pays where a wave's sweep nominates fewer pairs than it holds (a level admits ~ratio x k'
+            // rows per query): the thin early levels go straight to the lists, one slot grab per lane and tile -- fewer atomics
+            // on the same thousand counters, which is what those levels are bound by
+            if ((double)LEVEL_RATIO * kp * a.nq / ((double)g.level_tiles * g.qsplit) > 0.75 * RR_CB_CAP) g.buffered = 0;
             const uint64_t level_end = g.level_tiles;
             uint64_t part_end = level_end;
             if (ctx->tune.gemm_split_last && lev == L - 1 && lev > 0 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&

@@ -113,3 +113,31 @@ def test_adopted_rows_get_an_image_only_on_request(smt):
     assert c.image_bytes == 0
     r3, d3 = _search(c, q, 10)
     assert list(r3[9]) == list(r2[9])
+
+
+def test_dealt_shards_build_their_images_and_answer_alike(smt):
+    """A corpus dealt over three shards of a logical group (what the host layer holds): every shard owns its rows, so each
+    builds its own image at the first batch; answers equal the unsharded corpus', before and after an append and a write."""
+    ctx = smt.Context(0)
+    g = smt.Group.logical(0, 3)
+    rows = _unit(400_000, 7)
+    q = _unit(24, 8)
+    one = _corpus(smt, ctx, rows[:300_000])
+    sc = smt.ShardedCorpus(g, empty=True)
+    sc.append(rows[:300_000])
+    want_r, want_d = _search(one, q, 10)
+    got = sc.search(q, top_k=10)
+    assert [list(r) for r, _ in got] == want_r and [list(d) for _, d in got] == want_d
+    assert all(sc.shard(i, want_base=False)[0].image_bytes > 0 for i in range(3))
+    extra = rows[300_000:].copy()
+    extra[777] = q[5]
+    sc.append(extra)
+    one.append(extra)
+    sc.write_rows(123_456, q[6:7])
+    one.write_rows(123_456, q[6:7])
+    want_r, want_d = _search(one, q, 10)
+    got = sc.search(q, top_k=10)
+    assert [list(r) for r, _ in got] == want_r and [list(d) for _, d in got] == want_d
+    assert got[5][0][0] == 300_777 and got[6][0][0] == 123_456
+    sc.close()
+    g.close()
