@@ -623,6 +623,27 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     image_bytes = corpus.image_bytes
     wall, n_g, gemm_s = timed()
     image_same = int(((rows_f32 == out_rows).all(dim=1) & (dist_f32 == out_dist).all(dim=1)).sum().item())
+
+    # one query over the same 10 M rows: the scan kernel over the f32 rows (K2) against the batched kernel over the image, which
+    # is what a corpus that has its image does from 4 M rows per shard on (topk_dispatch, tuning key image_scan_min_rows)
+    def one_query(reps1=20):
+        r1 = torch.empty(1, k, dtype=torch.int64, device=device)
+        d1 = torch.empty(1, k, dtype=torch.float64, device=device)
+        corpus.search_topk_device(q.data_ptr(), 1, k, 0, r1.data_ptr(), d1.data_ptr())
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(reps1):
+            corpus.search_topk_device(q.data_ptr(), 1, k, 0, r1.data_ptr(), d1.data_ptr())
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t1) / reps1, r1, d1
+    ctx.set_tuning("image_scan_min_rows", 0)
+    s_f32, r_f32, d_f32 = one_query()
+    ctx.set_tuning("image_scan_min_rows", 4_000_000)
+    s_img, r_img, d_img = one_query()
+    single = {"rows": rows, "f32_scan_ms": s_f32 * 1e3, "f32_scan_rows_per_s": rows / s_f32, "image_ms": s_img * 1e3,
+              "image_rows_per_s": rows / s_img, "image_frac_of_hbm_at_512B_per_row": rows * 512 / s_img / 8e12,
+              "answers_identical": bool((r_f32 == r_img).all().item()) and bool((d_f32 == d_img).all().item()),
+              "note": "whole calls incl. levels, selects and delivery; the c2 / c4 legs (the headline) always scan the f32 rows"}
     flops = 2.0 * nq * rows * 256
     # gemm_kernels.hip launch_gemm_topk, the auto rule of gemm_nominate: MFMAs issued per algorithmic multiply-add
     small_shard = rows <= (1 << 25)
@@ -703,6 +724,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
                           "answers_identical_to_f32_rows_run": f"{image_same}/{nq}",
                           "note": "derived fp16 copy of the rows in MFMA operand order; nominations only -- every returned distance is "
                                   "re-scored in f64 from the f32 rows"},
+        "single_query_same_corpus": single,
         "f32_rows_only": {"queries_per_s": nq / wall_f32, "ms_per_batch": wall_f32 * 1e3, "gemm_ms_per_batch": gemm_s_f32 * 1e3,
                           "gemm_launches_per_batch": n_g_f32 // reps, "frac_of_2.5PF": issued * flops / gemm_s_f32 / 2500e12,
                           "note": "the same batch before smt_corpus_prepack: gemm_rowreg_kernel converts the f32 rows in its row phase"},

@@ -405,6 +405,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_split_last") ctx->tune.gemm_split_last = (int)value;
     else if (k == "gemm_image") ctx->tune.gemm_image = (int)value;
     else if (k == "corpus_image") ctx->tune.corpus_image = (int)value;
+    else if (k == "image_scan_min_rows") ctx->tune.image_scan_min_rows = value < 0 ? 0 : value;
     else if (k == "prof_every") ctx->tune.prof_every = (int)value;
     else if (k == "merge_on_aux") {
         int rc2 = drain_async(ctx);
@@ -811,8 +812,13 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
 {
     const bool fast_k3 = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && a.n_ranges == 0;
     const uint64_t small = (uint64_t)ctx->tune.gemm_min_rows_small;
+    // A corpus that HAS its fp16 operand image answers even one or two queries through the batched kernel once the shard is
+    // large (tuning key image_scan_min_rows, 4 M): one pass over 512-B rows plus ~0.2 ms of levels and selects beats a scan
+    // pass over 1 KiB rows -- 10 M rows: 0.95 against 1.5 ms; the scan kernel keeps the small shards and the async mode.
+    const bool image_scan = fast_k3 && ctx->tune.gemm_image && corpus->image && corpus->image_mode >= 0 && !a.allow_async &&
+                            ctx->tune.image_scan_min_rows > 0 && a.rows >= (uint64_t)ctx->tune.image_scan_min_rows;
     const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && a.rows >= small) ||
-                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small);
+                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small) || image_scan;
     if (batched && a.n_ranges == 0 && corpus->d_rows == a.corpus && corpus->rows == a.rows) {
         if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
     }

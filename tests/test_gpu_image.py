@@ -141,3 +141,35 @@ def test_dealt_shards_build_their_images_and_answer_alike(smt):
     assert got[5][0][0] == 300_777 and got[6][0][0] == 123_456
     sc.close()
     g.close()
+
+
+def test_one_query_scans_the_image_of_a_large_shard(smt):
+    """topk_dispatch: a shard of >= image_scan_min_rows rows (4 M by default; lowered here) that HAS its image answers one or two
+    queries through the batched kernel (512 B per row) -- same rows, same f64 distances as the scan kernel over the f32 rows."""
+    ctx = smt.Context(0)
+    rows = _unit(300_000, 9)
+    q = _unit(2, 10)
+    rows[[5, 299_999]] = q[0]                      # a tie across the whole corpus: row order decides
+    c = _corpus(smt, ctx, rows)
+    want = [_search(c, q[:n], 10) for n in (1, 2)]  # scan kernel (no image yet: fewer than 8 queries never build one)
+    assert c.image_bytes == 0
+    c.prepack()
+    ctx.set_tuning("image_scan_min_rows", 100_000)
+    try:
+        for n in (1, 2):
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            got = _search(c, q[:n], 10)
+            launches, _ = ctx.prof_read("gemm")
+            ctx.prof_enable(False)
+            assert launches > 0                    # the batched kernel ran
+            assert got == want[n - 1]
+        assert want[0][0][0][:2] == [5, 299_999]
+        ctx.set_tuning("image_scan_min_rows", 0)   # off: back on the scan kernel
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        assert _search(c, q[:1], 10) == want[0]
+        assert ctx.prof_read("gemm")[0] == 0
+        ctx.prof_enable(False)
+    finally:
+        ctx.set_tuning("image_scan_min_rows", 4_000_000)
