@@ -137,7 +137,8 @@ int smt_corpus_truncate(smt_corpus *corpus, uint64_t n_rows);
  * order, 512 B per row beside the 1 KiB of f32), so that a batch of >= 8 queries reads half the bytes per row and converts
  * nothing.  Derived data only: nominations come from it, every returned distance is re-scored from the f32 rows, results are
  * identical with and without it.  A corpus whose memory the library owns builds and maintains it by itself (first batch of
- * >= 8 queries over >= 64 Ki rows; appends, writes and truncation are tracked; tuning key corpus_image = 0 turns that off).
+ * >= 8 queries over >= 64 Ki rows, or the fourth smaller search of a shard of >= 4 M rows, which then answers single queries
+ * from it as well; appends, writes and truncation are tracked; tuning key corpus_image = 0 turns that off).
  * smt_corpus_prepack(corpus, 1) builds it NOW from the rows as they are -- the way to have one for a corpus adopted with
  * smt_corpus_from_device, whose caller then answers for calling it again after changing rows; (corpus, 0) drops it and keeps the
  * corpus without one.  No reference counterpart (the reference scores Vec<Vec<f32>> rows one by one, src/search/mod.rs:84-119). */

@@ -815,8 +815,19 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     // A corpus that HAS its fp16 operand image answers even one or two queries through the batched kernel once the shard is
     // large (tuning key image_scan_min_rows, 4 M): one pass over 512-B rows plus ~0.2 ms of levels and selects beats a scan
     // pass over 1 KiB rows -- 10 M rows: 0.95 against 1.5 ms; the scan kernel keeps the small shards and the async mode.
-    const bool image_scan = fast_k3 && ctx->tune.gemm_image && corpus->image && corpus->image_mode >= 0 && !a.allow_async &&
+    // (A resident host asking one query at a time -- `semtools serve` -- never sends the batch of 8 that builds the image of an
+    // owned corpus: the fourth small search of a shard this large builds it.)
+    const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && corpus->d_rows == a.corpus && corpus->rows == a.rows &&
                             ctx->tune.image_scan_min_rows > 0 && a.rows >= (uint64_t)ctx->tune.image_scan_min_rows;
+    if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&
+        ++corpus->small_searches >= 4) {
+        const void *img;
+        const uint32_t *zero;
+        corpus->image_mode = 1;
+        if (int rc_img = corpus_image_sync(corpus, a.nq, &img, &zero)) return rc_img;
+        if (corpus->image_mode == 1) corpus->image_mode = 0;   // (-1 when there was no room)
+    }
+    const bool image_scan = scan_sized && corpus->image && corpus->image_mode >= 0;
     const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && a.rows >= small) ||
                          (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small) || image_scan;
     if (batched && a.n_ranges == 0 && corpus->d_rows == a.corpus && corpus->rows == a.rows) {

@@ -126,6 +126,7 @@ struct smt_corpus {
     uint32_t *image_zero = nullptr;
     uint64_t image_cap_tiles = 0;
     uint64_t image_rows = 0;
+    uint32_t small_searches = 0; // searches of < 8 queries seen while the shard was large enough to scan its image (api.cpp topk_dispatch)
     int image_mode = 0;          // 0: by policy (tuning key corpus_image; owned corpora only), 1: requested (smt_corpus_prepack), -1: refused
 };
 

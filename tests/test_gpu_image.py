@@ -173,3 +173,25 @@ def test_one_query_scans_the_image_of_a_large_shard(smt):
         ctx.prof_enable(False)
     finally:
         ctx.set_tuning("image_scan_min_rows", 4_000_000)
+
+
+def test_a_resident_host_gets_the_image_after_a_few_single_queries(smt):
+    """`semtools serve` asks one query at a time: the fourth small search of an owned shard that is large enough to scan its
+    image builds it (topk_dispatch)."""
+    ctx = smt.Context(0)
+    rows = _unit(200_000, 11)
+    q = _unit(6, 12)
+    c = _corpus(smt, ctx, rows)
+    ctx.set_tuning("image_scan_min_rows", 100_000)
+    try:
+        got = []
+        for i in range(3):
+            got.append(_search(c, q[i:i + 1], 10))
+            assert c.image_bytes == 0
+        got.append(_search(c, q[3:4], 10))
+        assert c.image_bytes > 0
+        ctx.set_tuning("image_scan_min_rows", 0)
+        for i in range(4):
+            assert _search(c, q[i:i + 1], 10) == got[i]          # the scan kernel says the same
+    finally:
+        ctx.set_tuning("image_scan_min_rows", 4_000_000)
