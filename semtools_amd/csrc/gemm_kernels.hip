@@ -832,9 +832,10 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
         unsigned zero16 = 0, valid16 = 0;
 #endif
         if constexpr (IMG) {
-            // ---- the operands are READY in the corpus' fp16 image (corpus_image.hip wrote them with the arithmetic of the branch
+            // ---- the operands are READY in the corpus' fp16 image (pack_image_kernel wrote them with the arithmetic of the branch
             // below): 16 loads of 1 KiB, quad m of lane l at 16 (64 m + l) in the tile's 16 KiB -- half the bytes of the f32 rows,
-            // no norms, no conversion, no transpose
+            // no norms, no conversion, no transpose.  (Requesting them one step ahead into a second register set was measured:
+            // 8-32 queries 0.95 -> 0.94 ms, one query 0.92 -> 0.89, 256-512 queries 3-5 % slower with the spills it brings: not kept.)
             if (has) {
                 const uint64_t tile = row0 >> 5;
                 const u32x4 *img = reinterpret_cast<const u32x4 *>(p.image) + tile * 1024 + lane;
@@ -1618,7 +1619,10 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // With the corpus' fp16 operand image at hand (ScanArgs::image) the fp16 modes read HALF the bytes per row and skip the row
     // phase: f16 x 2 then also takes the batches below 128 queries, which are HBM-bound.
     const bool have_image = a.image != nullptr && rowreg && ctx->tune.gemm_image != 0;
-    const bool f16x1 = rowreg && (ctx->tune.gemm_nominate == 3 || (auto_fp16 && nqt >= 8 && a.k_out + 24 <= 64));
+    // (measured with the image, 10 M rows, ms: 128 queries f16 x 1 1.16 / f16 x 2 1.32; 192: 1.23 / 2.09 -- six tiles no longer
+    // fit the four slots of the 1 KiB query image; <= 96: equal)
+    const bool f16x1 = rowreg && (ctx->tune.gemm_nominate == 3 ||
+                                  (auto_fp16 && (nqt >= 8 || (have_image && nqt >= 4)) && a.k_out + 24 <= 64));
     const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && (nqt >= 4 || (have_image && a.k_out + 16 <= 64))));
     const bool use_image = have_image && (f16x1 || f16x2);
     // guard band, see candidates_per_list (scan_kernels.hip): the wider the certificate band, the more rows are nominated
