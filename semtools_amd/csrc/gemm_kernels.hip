@@ -1615,7 +1615,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // (5.2e-4 / 1.0e-3 against 7e-5): auto takes f16 x 2 from 128 queries and f16 x 1 from 256 queries on shards of at most
     // 32 M rows (the rank spacing of the distances shrinks with the shard; at 10 M random rows the k-th and k+8-th distances
     // are ~8e-3 apart), provided the lists have room for the wider guard band.  Small batches are HBM-bound: bf16 x 3.
-    const bool auto_fp16 = rowreg && ctx->tune.gemm_nominate == 0 && a.rows <= (1ull << 25);
+    // ... and on larger shards when the operand image is there: at 100 M rows one query takes 7.6 ms from the image against
+    // 14.2 ms from the f32 rows, 64 queries 8.9 against 18.7, no query without its certificate (profiles/r03_image_scan_100M.json;
+    // a corpus full of near-duplicates pays with exhaustive re-answers instead -- guard_band).
+    const bool auto_fp16 = rowreg && ctx->tune.gemm_nominate == 0 &&
+                           (a.rows <= (1ull << 25) || (a.image != nullptr && ctx->tune.gemm_image != 0 && a.rows <= (1ull << 28)));
     // With the corpus' fp16 operand image at hand (ScanArgs::image) the fp16 modes read HALF the bytes per row and skip the row
     // phase: f16 x 2 then also takes the batches below 128 queries, which are HBM-bound.
     const bool have_image = a.image != nullptr && rowreg && ctx->tune.gemm_image != 0;
