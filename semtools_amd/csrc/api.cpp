@@ -188,7 +188,9 @@ int corpus_image_sync(smt_corpus *c, uint32_t nq, const void **image, const uint
     if (c->rows == 0) return SMT_OK;
     const uint64_t tiles = (c->rows + 31) / 32;
     if (tiles > c->image_cap_tiles) {
-        const uint64_t cap = std::max<uint64_t>(tiles, c->image ? c->image_cap_tiles + c->image_cap_tiles / 2 : (c->capacity + 31) / 32);
+        // room to grow: x 1.5 of what it held, or what the rows have reserved (at most twice the rows that exist)
+        const uint64_t cap = std::max<uint64_t>(tiles, c->image ? c->image_cap_tiles + c->image_cap_tiles / 2
+                                                                 : std::min<uint64_t>((c->capacity + 31) / 32, 2 * tiles));
         void *ni = nullptr;
         uint32_t *nz = nullptr;
         if (hipMalloc(&ni, (size_t)cap * 16384) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&nz), (size_t)cap * 4) != hipSuccess) {
