@@ -405,6 +405,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
     else if (k == "gemm_buffered") ctx->tune.gemm_buffered = (int)value;
     else if (k == "gemm_split_last") ctx->tune.gemm_split_last = (int)value;
+    else if (k == "embed_batched") ctx->tune.embed_batched = (int)value;
     else if (k == "gemm_image") ctx->tune.gemm_image = (int)value;
     else if (k == "corpus_image") ctx->tune.corpus_image = (int)value;
     else if (k == "image_scan_min_rows") ctx->tune.image_scan_min_rows = value < 0 ? 0 : value;
