@@ -24,6 +24,8 @@ def main():
                     help="1 = default routing, 2 = gemm_level_kernel instead of the LDS-row kernel (f32 / gemm_rowreg=0 modes)")
     ap.add_argument("--ranges", action="store_true", help="also time a range-filtered batch (two ranges, 90 %% of the rows)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--live-dims", type=int, default=256, help="rows (and queries) are zero outside their first N dims: the same instruction "
+                    "stream over operands that barely switch (power probe)")
     ap.add_argument("--prepack", action="store_true", help="build the corpus' fp16 operand image first (smt_corpus_prepack)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for smt_set_tuning (repeatable)")
     args = ap.parse_args()
@@ -33,9 +35,11 @@ def main():
     x = torch.empty(args.rows, 256, device=dev)
     for b in range(0, args.rows, 2_000_000):
         c = torch.randn(min(2_000_000, args.rows - b), 256, device=dev, generator=g)
+        c[:, args.live_dims:] = 0
         x[b:b + c.shape[0]] = c / c.norm(dim=1, keepdim=True)
     g.manual_seed(5)
     qall = torch.randn(max(args.nq), 256, device=dev, generator=g)
+    qall[:, args.live_dims:] = 0
     qall /= qall.norm(dim=1, keepdim=True)
     torch.cuda.synchronize()
     ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
