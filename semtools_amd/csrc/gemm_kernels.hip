@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     };
     auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };  // vmcnt(0)
     {
-        const uint32_t first = resident ? n_qt : (uint32_t)AHEAD;   // streaming: ring positions 0 .. AHEAD - 1
+        const uint32_t first = resident ? n_qt : (uint32_t)((SMT_RR_EXP & 2) ? SLOTS : AHEAD);   // streaming: ring positions 0 .. AHEAD - 1
         for (uint32_t t = 0; t < first; ++t) stage_tile(qt_lo + t, (int)t);
         stage_wait();
     }
@@ -950,7 +950,10 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 // issue the four reads of group g + 1, THEN run the four MFMAs of group g -- the reads fly under 128 cycles of
                 // this wave's MFMAs and no MFMA waits for a read issued an instruction earlier (hipcc guards a read issued
                 // one or two K-steps ahead, as below for the other modes, with lgkmcnt(0) at every second MFMA).
-                constexpr int BG = 4;
+#ifndef SMT_RR_BG
+#define SMT_RR_BG 4
+#endif
+                constexpr int BG = SMT_RR_BG;
                 u32x4 B[2][BG];
 #pragma unroll
                 for (int d = 0; d < BG; ++d) B[0][d] = bq[QS * (M0 + d)];

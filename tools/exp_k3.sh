@@ -5,6 +5,6 @@
 cp semtools_amd/lib/libsemtools_hip.so /tmp/orig.so
 for e in 0 $@; do
   if [ "$e" = 0 ]; then cp /tmp/orig.so semtools_amd/lib/libsemtools_hip.so; else cp tools/exp_libs/libsemtools_hip_exp$e.so semtools_amd/lib/libsemtools_hip.so; fi
-  echo "exp $e"; timeout 200 python tools/bench_small_batch.py --nq 256 1000 --reps 5 2>&1 | grep -o '"nq": [0-9]*\|"gemm_ms": [0-9.]*\|"gemm_launches": [0-9]*' | paste - - -
+  echo "exp $e"; timeout 200 python tools/bench_small_batch.py --nq 1000 --reps 5 $EXP_ARGS 2>&1 | grep -o '"nq": [0-9]*\|"gemm_ms": [0-9.]*\|"gemm_launches": [0-9]*' | paste - - -
 done
 cp /tmp/orig.so semtools_amd/lib/libsemtools_hip.so
