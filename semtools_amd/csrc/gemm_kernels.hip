@@ -950,10 +950,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 // issue the four reads of group g + 1, THEN run the four MFMAs of group g -- the reads fly under 128 cycles of
                 // this wave's MFMAs and no MFMA waits for a read issued an instruction earlier (hipcc guards a read issued
                 // one or two K-steps ahead, as below for the other modes, with lgkmcnt(0) at every second MFMA).
-#ifndef SMT_RR_BG
-#define SMT_RR_BG 4
-#endif
-                constexpr int BG = SMT_RR_BG;
+                constexpr int BG = 4;   // (8, and 16 = no overlap inside a product at all, measure the same: 5.84-5.88 ms at 1000 x 10 M)
                 u32x4 B[2][BG];
 #pragma unroll
                 for (int d = 0; d < BG; ++d) B[0][d] = bq[QS * (M0 + d)];
