@@ -29,6 +29,8 @@ def main():
     torch.cuda.synchronize()
     ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
+    if os.environ.get("TRACE_IMAGE", "1") != "0":
+        corpus.prepack()
     out_rows = torch.empty(nq, 10, dtype=torch.int64, device=dev)
     out_dist = torch.empty(nq, 10, dtype=torch.float64, device=dev)
     for _ in range(2):
