@@ -141,7 +141,9 @@ int smt_corpus_truncate(smt_corpus *corpus, uint64_t n_rows);
  * from it as well; appends, writes and truncation are tracked; tuning key corpus_image = 0 turns that off).
  * smt_corpus_prepack(corpus, 1) builds it NOW from the rows as they are -- the way to have one for a corpus adopted with
  * smt_corpus_from_device, whose caller then answers for calling it again after changing rows; (corpus, 0) drops it and keeps the
- * corpus without one.  No reference counterpart (the reference scores Vec<Vec<f32>> rows one by one, src/search/mod.rs:84-119). */
+ * corpus without one.  The shards of an smt_sharded_corpus are corpora like any other (smt_sharded_corpus_shard hands them out):
+ * shards the library filled keep their images by themselves, adopted shards get one per shard through this call.
+ * No reference counterpart (the reference scores Vec<Vec<f32>> rows one by one, src/search/mod.rs:84-119). */
 int smt_corpus_prepack(smt_corpus *corpus, int enable);
 uint64_t smt_corpus_image_bytes(const smt_corpus *corpus);
 uint64_t smt_corpus_rows(const smt_corpus *corpus);

@@ -195,3 +195,39 @@ def test_a_resident_host_gets_the_image_after_a_few_single_queries(smt):
             assert _search(c, q[i:i + 1], 10) == got[i]          # the scan kernel says the same
     finally:
         ctx.set_tuning("image_scan_min_rows", 4_000_000)
+
+
+def test_random_life_of_a_corpus_with_an_image(smt):
+    """Appends, overwrites, truncations and searches in random order on a corpus that keeps its image: every batch agrees with a
+    brute-force f64 top-k over a numpy mirror of the rows (indices and distances)."""
+    rng = np.random.default_rng(20)
+    ctx = smt.Context(0)
+    mirror = _unit(66_000, 21)
+    c = _corpus(smt, ctx, mirror)
+    c.prepack()
+    pool = _unit(40_000, 22)
+    for step in range(24):
+        op = rng.integers(0, 4)
+        if op == 0:                                   # append 1 .. 3000 rows (crosses tile borders at random places)
+            n = int(rng.integers(1, 3000))
+            rows = pool[rng.integers(0, len(pool), n)]
+            c.append(rows)
+            mirror = np.concatenate([mirror, rows])
+        elif op == 1:                                 # overwrite a run somewhere
+            n = int(rng.integers(1, 200))
+            at = int(rng.integers(0, len(mirror) - n))
+            rows = pool[rng.integers(0, len(pool), n)]
+            c.write_rows(at, rows)
+            mirror[at:at + n] = rows
+        elif op == 2 and len(mirror) > 66_000:        # cut the tail, sometimes inside a tile
+            to = int(rng.integers(65_600, len(mirror)))
+            c.truncate(to)
+            mirror = mirror[:to]
+        q = _unit(8, 100 + step)
+        q[0] = mirror[int(rng.integers(0, len(mirror)))]          # a query that sits in the corpus (duplicates tie by row order)
+        got_r, got_d = _search(c, q, 7)
+        want_r, want_d = _topk64(mirror, q, 7)
+        for i in range(8):
+            assert got_r[i] == list(want_r[i]), (step, i)
+            np.testing.assert_allclose(got_d[i], want_d[i], atol=1e-12)
+        assert c.image_bytes > 0
