@@ -677,7 +677,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
               "answers_identical": bool((r_f32 == r_img).all().item()) and bool((d_f32 == d_img).all().item()),
               "note": "whole calls incl. levels, selects and delivery; the c2 / c4 legs (the headline) always scan the f32 rows"}
     flops = 2.0 * nq * rows * 256
-    # gemm_kernels.hip launch_gemm_topk, the auto rule of gemm_nominate: MFMAs issued per algorithmic multiply-add
+    # gemm_topk.hip launch_gemm_topk, the auto rule of gemm_nominate: MFMAs issued per algorithmic multiply-add
     small_shard = rows <= (1 << 25)
     issued = 1.0 if (nq > 96 and small_shard and k + 24 <= 64) else 2.0 if (small_shard and k + 16 <= 64) else 3.0   # (with the image)
     mode_name = {1.0: "f16 x 1", 2.0: "f16 x 2", 3.0: "bf16 x 3"}[issued]

@@ -119,7 +119,7 @@ struct smt_corpus {
     uint64_t capacity = 0;
     uint32_t dim = 0;
     bool owned = true;
-    // fp16 OPERAND IMAGE (gemm_kernels.hip: pack_image_kernel): what the batched fp16 nomination modes multiply with, kept
+    // fp16 OPERAND IMAGE (gemm_rowreg.hip: pack_image_kernel): what the batched fp16 nomination modes multiply with, kept
     // beside the f32 rows -- 512 B per row, 16 KiB per 32-row tile -- so that a batch reads half the bytes and converts nothing.
     // Derived data: the f32 rows stay the truth (every returned distance is re-scored from them).  image_rows = the rows the
     // image describes; appends grow `rows` past it, smt_corpus_write_rows pulls it back: corpus_image_sync packs what is missing.
@@ -328,12 +328,12 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
 
 // K3: batched queries, f32 MFMA with fused candidate selection.
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);
-// bf16 hi / lo split image (mfma_tile.h layout) of n rows of 256 f32, padded with zero rows to n_pad (gemm_kernels.hip)
+// bf16 hi / lo split image (mfma_tile.h layout) of n rows of 256 f32, padded with zero rows to n_pad (gemm_topk.hip)
 int launch_split_rows_bf16(smt_ctx *ctx, const float *rows, uint32_t n, uint32_t n_pad, uint32_t *out);
-// batched threshold pass (gemm_kernels.hip): rows with nominating distance <= tau[q], per query, in scratch buffers
+// batched threshold pass (gemm_topk.hip): rows with nominating distance <= tau[q], per query, in scratch buffers
 int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const float *queries, uint32_t nq,
                           const float *tau, const key_t64 **cand_out, const unsigned int **counts_out, uint32_t *cand_stride);
-// test hook: the nominating f32 distances of the K3 kernels for <= 32 queries (gemm_kernels.hip)
+// test hook: the nominating f32 distances of the K3 kernels for <= 32 queries (gemm_topk.hip)
 int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_row, uint32_t n_rows, const float *queries,
                              uint32_t nq, float *out);
 
