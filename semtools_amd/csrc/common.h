@@ -303,7 +303,7 @@ int launch_largek_candidates(smt_ctx *ctx, const float *corpus, const float *que
                              std::vector<uint32_t> &rows_out, std::vector<double> &dist_out, float *next_d32 = nullptr
                              /* f32 distance of the best row NOT among the candidates (+inf if none) */);
 
-// IVF index as one rank of a shared-centroid build / packed search (ivfpq_kernels.hip <-> group.cpp)
+// IVF index as one rank of a shared-centroid build / packed search (ivfpq_build.hip / ivfpq_search.hip <-> group.cpp)
 struct IvfBuildShare {
     uint32_t rank = 0, n_ranks = 1;
     // sum `sums` (n_sums int64, 2^-32 fixed point) and `counts` (n_counts u32) over the ranks, in place, enqueued on
