@@ -1,0 +1,610 @@
+// search.cpp -- the search entry points of libsemtools_hip.so (include/semtools_hip.h: smt_search, smt_search_topk_device, the merge
+// calls) and the host logic behind them: which kernel answers a call (topk_dispatch), the exactness fall-backs, threshold mode,
+// delivery.  No CPU fallback: every path ends in a HIP kernel.
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace smt;
+
+namespace smt {
+
+static int validate_ranges(const smt_range *ranges, uint32_t n, uint64_t rows, uint64_t *total)
+{
+    uint64_t prev_end = 0, t = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        SMT_REQUIRE(ranges[i].begin <= ranges[i].end, "range begin > end");
+        SMT_REQUIRE(ranges[i].end <= rows, "range extends past the corpus");
+        SMT_REQUIRE(i == 0 || ranges[i].begin >= prev_end, "ranges must be sorted and disjoint");
+        prev_end = ranges[i].end;
+        t += ranges[i].end - ranges[i].begin;
+    }
+    *total = t;
+    return SMT_OK;
+}
+
+// Exhaustive answer for ONE query whose f32 nomination failed its exactness certificate: K4 collects every row
+// whose exact distance is <= bound (its own f32 prefilter carries an 8e-6 guard band; rescoring is exact f64), in
+// (distance asc, row asc) order; the answer is the first k_eff of them (after the workspace score filter).
+// `bound` is the k-th exact distance found so far -- an upper bound of the true k-th -- or, when fewer than k rows
+// passed the workspace threshold, the largest distance that threshold admits.  O(rows <= bound): a cluster of
+// near-duplicates costs its own size, exactly what the reference pays for every query (it sorts all N).
+static int exact_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *query_dev, const smt_range *ranges_dev,
+                          const uint64_t *chunk_prefix_dev, uint32_t nr, uint64_t n_virtual, uint64_t n_chunks, double bound,
+                          uint32_t k_eff, bool ws_thr, float thr_score, uint64_t row_base, LocalHits &out)
+{
+    ThresholdQuery t;
+    t.corpus = corpus->d_rows;
+    t.rows = corpus->rows;
+    t.query = query_dev;
+    t.ranges = ranges_dev;
+    t.range_chunk_prefix = chunk_prefix_dev;
+    t.n_chunks = n_chunks;
+    t.n_ranges = nr;
+    t.n_virtual = n_virtual;
+    t.max_distance = std::nextafter(bound, std::numeric_limits<double>::infinity());  // K4 keeps d < max_distance: include == bound
+    const uint32_t *h_rows = nullptr;
+    const double *h_dist = nullptr;
+    uint64_t n_ok = 0;
+    int rc = run_threshold_query(ctx, t, &h_rows, &h_dist, &n_ok);
+    if (rc) return rc;
+    out.rows.clear();
+    out.dist.clear();
+    for (uint64_t i = 0; i < n_ok && out.rows.size() < k_eff; ++i) {
+        if (ws_thr && !((1.0 - h_dist[i]) > (double)thr_score)) continue;  // store.rs:502-503
+        out.rows.push_back(row_base + h_rows[i]);
+        out.dist.push_back(h_dist[i]);
+    }
+    return SMT_OK;
+}
+
+// The same re-answer for MANY queries of one call at once.  One sweep of the batched kernel collects, per query, every
+// row whose nominating distance is <= bound + F32_ERR_BF16X3 (a superset of the rows with exact distance <= bound);
+// they are re-scored exactly, ordered (distance, row) and cut at k -- what exact_fallback does with one K4 scan per
+// query.  Queries whose band holds more rows than a candidate buffer (2048) come back in `left` for the K4 route.
+// The same sweep answers threshold searches of several queries at once (`strict`: distance < bound, every hit: k_eff = all).
+static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queries_dev, const std::vector<uint32_t> &redo,
+                            const std::vector<double> &bounds, uint64_t k_eff, bool ws_thr, float thr_score, uint64_t row_base,
+                            std::vector<LocalHits> &out, std::vector<uint32_t> &left, bool strict = false)
+{
+    const uint32_t n = (uint32_t)redo.size();
+    float *d_qc = nullptr;   // compact copies of the uncertain queries + their f32 thresholds (rare path: plain hipMalloc)
+    SMT_HIP_CHECK(hipMalloc(&d_qc, (size_t)n * (SMT_DIM + 1) * sizeof(float)));
+    struct Free { float *p; ~Free() { (void)hipFree(p); } } guard{d_qc};
+    float *d_tau = d_qc + (size_t)n * SMT_DIM;
+    std::vector<float> tau(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        SMT_HIP_CHECK(hipMemcpyAsync(d_qc + (size_t)i * SMT_DIM, queries_dev + (size_t)redo[i] * SMT_DIM, SMT_DIM * sizeof(float),
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+        tau[i] = std::nextafter((float)(bounds[i] + F32_ERR_BF16X3), std::numeric_limits<float>::infinity());
+    }
+    SMT_HIP_CHECK(hipMemcpyAsync(d_tau, tau.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const key_t64 *d_cand = nullptr;
+    const unsigned int *d_cnt = nullptr;
+    uint32_t stride = 0;
+    int rc = launch_gemm_threshold(ctx, corpus->d_rows, corpus->rows, d_qc, n, d_tau, &d_cand, &d_cnt, &stride);
+    if (rc) return rc;
+    std::vector<unsigned int> cnt(n);
+    std::vector<key_t64> keys((size_t)n * stride);
+    SMT_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, n * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipMemcpyAsync(keys.data(), d_cand, keys.size() * sizeof(key_t64), hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // exact distances of every collected row (the scratch that held the candidates is free again)
+    std::vector<uint32_t> rows;
+    std::vector<uint64_t> first(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        first[i] = rows.size();
+        if (cnt[i] > stride) continue;   // overflow: K4
+        for (uint32_t c = 0; c < cnt[i]; ++c) rows.push_back((uint32_t)(keys[(size_t)i * stride + c] & 0xFFFFFFFFull));
+    }
+    first[n] = rows.size();
+    std::vector<double> dist(rows.size());
+    if (!rows.empty()) {
+        const size_t b_rows = (rows.size() * sizeof(uint32_t) + 255) & ~(size_t)255;
+        if ((rc = ensure_scratch(ctx, b_rows + rows.size() * sizeof(double)))) return rc;
+        uint32_t *d_rows = reinterpret_cast<uint32_t *>(ctx->d_scratch);
+        double *d_dist = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_scratch) + b_rows);
+        SMT_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t m = (cnt[i] > stride) ? 0 : first[i + 1] - first[i];
+            if (m && (rc = launch_rescore_rows(ctx, corpus->d_rows, d_qc + (size_t)i * SMT_DIM, d_rows + first[i], m, d_dist + first[i]))) return rc;
+        }
+        SMT_HIP_CHECK(hipMemcpyAsync(dist.data(), d_dist, rows.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (cnt[i] > stride) { left.push_back(redo[i]); continue; }
+        std::vector<uint64_t> order;
+        for (uint64_t c = first[i]; c < first[i + 1]; ++c) {
+            if (strict ? !(dist[c] < bounds[i]) : !(dist[c] <= bounds[i])) continue;   // (also drops NaN)
+            if (ws_thr && !((1.0 - dist[c]) > (double)thr_score)) continue;         // store.rs:502-503
+            order.push_back(c);
+        }
+        std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+            if (dist[x] != dist[y]) return dist[x] < dist[y];
+            return rows[x] < rows[y];
+        });
+        LocalHits &o = out[redo[i]];
+        o.rows.clear();
+        o.dist.clear();
+        for (uint64_t c : order) {
+            if (o.rows.size() >= k_eff) break;
+            o.rows.push_back(row_base + rows[c]);
+            o.dist.push_back(dist[c]);
+        }
+    }
+    return SMT_OK;
+}
+
+// The body of smt_search with per-query result vectors instead of caller arrays: group.cpp runs it once per
+// local shard (threshold mode / top_k > 64, whose result sizes are not known up front) and exchanges the lists.
+
+// K2 (scan, <= 4 queries per corpus pass) or K3 (batched, one pass for the whole batch)?  8+ queries always take K3.
+// With the bf16 x 3 row-register kernel a batch costs about 1.15 single-query passes whatever its size, while a K2 pass
+// slows down with every query it carries (per row and query a DPP reduction tree: 10 M rows, 1 / 2 / 4 queries per
+// pass = 1.43 / 2.0 / 3.2 ms).  Measured on MI355X, wall ms per call, K2 | K3:
+//   10 M rows: 2 queries 2.03 | 1.77, 3: 3.54 | 1.84, 4: 3.24 | 1.71, 5: 4.83 | 1.75, 7: 6.71 | 1.77
+//    2 M rows: 2: 0.49 | 0.52, 3: 0.87 | 0.52, 4: 0.75 | 0.53;   1 M rows: 2: 0.27 | 0.36, 3: 0.44 | 0.37, 4: 0.42 | 0.37
+//  300 k rows: 3: 0.17 | 0.25 (K3's fixed cost: five level launches + selects)
+// => K3 from gemm_min_nq (3) queries on shards of gemm_min_rows_small (1 M) rows, from 2 queries on 4 x that.
+static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
+{
+    const bool fast_k3 = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && a.n_ranges == 0;
+    const uint64_t small = (uint64_t)ctx->tune.gemm_min_rows_small;
+    // A corpus that HAS its fp16 operand image answers even one or two queries through the batched kernel once the shard is
+    // large (tuning key image_scan_min_rows, 4 M): one pass over 512-B rows plus ~0.2 ms of levels and selects beats a scan
+    // pass over 1 KiB rows -- 10 M rows: 0.95 against 1.5 ms; the scan kernel keeps the small shards and the async mode.
+    // (A resident host asking one query at a time -- `semtools serve` -- never sends the batch of 8 that builds the image of an
+    // owned corpus: the fourth small search of a shard this large builds it.)
+    const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && corpus->d_rows == a.corpus && corpus->rows == a.rows &&
+                            ctx->tune.image_scan_min_rows > 0 && a.rows >= (uint64_t)ctx->tune.image_scan_min_rows;
+    if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&
+        ++corpus->small_searches >= 4) {
+        const void *img;
+        const uint32_t *zero;
+        corpus->image_mode = 1;
+        if (int rc_img = corpus_image_sync(corpus, a.nq, &img, &zero)) return rc_img;
+        if (corpus->image_mode == 1) corpus->image_mode = 0;   // (-1 when there was no room)
+    }
+    const bool image_scan = scan_sized && corpus->image && corpus->image_mode >= 0;
+    const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && a.rows >= small) ||
+                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small) || image_scan;
+    if (batched && a.n_ranges == 0 && corpus->d_rows == a.corpus && corpus->rows == a.rows) {
+        if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
+    }
+    int rc = batched ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
+    if (rc == SMT_E_UNSUPPORTED && batched) rc = launch_scan_topk(ctx, a);
+    return rc;
+}
+
+int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+                      const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out)
+{
+    SMT_REQUIRE(corpus != nullptr, "corpus");
+    SMT_REQUIRE(mode == SMT_MODE_DOCUMENTS || mode == SMT_MODE_WORKSPACE, "mode");
+    SMT_REQUIRE(nq == 0 || queries, "null argument");
+    SMT_REQUIRE(n_ranges == 0 || ranges != nullptr, "ranges");
+    smt_ctx *ctx = corpus->ctx;
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    out.assign(nq, LocalHits());
+    if (nq == 0) return SMT_OK;
+
+    const bool has_thr = !std::isnan(max_distance);
+    const bool all_under_threshold = (mode == SMT_MODE_DOCUMENTS) && has_thr;
+
+    // drop empty ranges; total rows to scan
+    std::vector<smt_range> rr;
+    uint64_t n_virtual = corpus->rows;
+    if (n_ranges) {
+        uint64_t total = 0;
+        if ((rc = validate_ranges(ranges, n_ranges, corpus->rows, &total))) return rc;
+        for (uint32_t i = 0; i < n_ranges; ++i) if (ranges[i].end > ranges[i].begin) rr.push_back(ranges[i]);
+        n_virtual = total;
+    }
+    if (n_virtual == 0) return SMT_OK;
+    if (!all_under_threshold && top_k == 0) return SMT_OK;  // take(0) / store.rs:489-491
+
+    // ---- device staging: queries, ranges(+prefix)
+    const uint32_t nr = (uint32_t)rr.size();
+    const size_t q_bytes = (size_t)nq * SMT_DIM * sizeof(float);
+    const size_t r_bytes = (size_t)nr * sizeof(smt_range);
+    const size_t p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
+    // one persistent staging buffer per context: [queries | ranges | prefix | result lists] (no per-call hipMalloc/hipFree)
+    const size_t in_bytes = (q_bytes + r_bytes + 2 * p_bytes + 255) & ~(size_t)255;
+    const uint32_t k_stage = all_under_threshold ? 0u : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(top_k, n_virtual), 64);
+    const size_t out_bytes_stage = (size_t)nq * k_stage * 16 + (size_t)2 * nq * sizeof(uint64_t);
+    if ((rc = ensure_stage(ctx, in_bytes + out_bytes_stage + 64))) return rc;
+    char *stage = reinterpret_cast<char *>(ctx->d_stage);
+    float *d_q = reinterpret_cast<float *>(stage);
+    smt_range *d_r = reinterpret_cast<smt_range *>(stage + q_bytes);
+    uint64_t *d_p = reinterpret_cast<uint64_t *>(stage + q_bytes + r_bytes);
+    uint64_t *d_cp = reinterpret_cast<uint64_t *>(stage + q_bytes + r_bytes + p_bytes);
+    SMT_HIP_CHECK(hipMemcpyAsync(d_q, queries, q_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // prefix: rows before range i (large-k path); chunk_prefix: FILTER_CHUNK-row chunks before range i (K2/K4)
+    std::vector<uint64_t> prefix(nr + 1, 0), chunk_prefix(nr + 1, 0);
+    if (nr) {
+        for (uint32_t i = 0; i < nr; ++i) {
+            const uint64_t len = rr[i].end - rr[i].begin;
+            prefix[i + 1] = prefix[i] + len;
+            chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
+        }
+        SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const uint64_t n_chunks = chunk_prefix[nr];
+
+    if (!all_under_threshold) {
+        // ---------------- top-k (optionally with the workspace score threshold)
+        const uint32_t k_eff = (uint32_t)std::min<uint64_t>(top_k, n_virtual);
+        if (k_eff > SCAN_MAX_K) {
+            // large-k request (also k in 57..64, where the f32 scan's candidate lists have no room left for the
+            // guard band): all keys + sort + exact rescoring of k + guard candidates
+            const uint64_t guard = std::max<uint64_t>(64, k_eff / 16);
+            const uint64_t n_cand = std::min<uint64_t>(n_virtual, (uint64_t)k_eff + guard);
+            const bool ws_thr = (mode == SMT_MODE_WORKSPACE && has_thr);
+            const float thr_score = 1.0f - (float)max_distance;
+            for (uint32_t q = 0; q < nq; ++q) {
+                std::vector<uint32_t> c_rows;
+                std::vector<double> c_dist;
+                float next_d32 = 0.f;
+                rc = launch_largek_candidates(ctx, corpus->d_rows, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr,
+                                              nr ? d_p : nullptr, nr, n_virtual, n_cand, c_rows, c_dist, &next_d32);
+                if (rc) return rc;
+                std::vector<uint64_t> order;
+                for (uint64_t i = 0; i < c_rows.size(); ++i) {
+                    if (c_dist[i] != c_dist[i]) continue;                                   // NaN rows never match
+                    if (ws_thr && !((1.0 - c_dist[i]) > (double)thr_score)) continue;      // store.rs:502-503
+                    order.push_back(i);
+                }
+                std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+                    if (c_dist[x] != c_dist[y]) return c_dist[x] < c_dist[y];
+                    return c_rows[x] < c_rows[y];
+                });
+                const uint64_t n = std::min<uint64_t>(order.size(), k_eff);
+                out[q].rows.resize(n);
+                out[q].dist.resize(n);
+                for (uint64_t i = 0; i < n; ++i) {
+                    out[q].rows[i] = row_base + c_rows[order[i]];
+                    out[q].dist[i] = c_dist[order[i]];
+                }
+                // exactness certificate (SelectArgs::f32_err): rows outside the candidates have exact distance >= floor_out
+                const double floor_out = (double)next_d32 - F32_ERR_SCAN;
+                const bool certain = n == k_eff ? floor_out > out[q].dist[n - 1]
+                                                : (ws_thr ? !((1.0 - floor_out) > (double)thr_score) : next_d32 == __builtin_inff());
+                if (!certain) {
+                    const double bound = n == k_eff ? out[q].dist[n - 1] : 1.0 - (double)thr_score;
+                    rc = exact_fallback(ctx, corpus, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr, nr ? d_cp : nullptr, nr,
+                                        n_virtual, n_chunks, bound, k_eff, ws_thr, thr_score, row_base, out[q]);
+                    if (rc) return rc;
+                }
+            }
+            return SMT_OK;
+        }
+        const size_t o_rows = (size_t)nq * k_eff * sizeof(uint64_t);
+        const size_t o_dist = (size_t)nq * k_eff * sizeof(double);
+        const size_t o_cnt = (size_t)2 * nq * sizeof(uint64_t);  // counts, then the "uncertain" flags
+        char *outs = stage + in_bytes;
+        uint64_t *d_orow = reinterpret_cast<uint64_t *>(outs);
+        double *d_odist = reinterpret_cast<double *>(outs + o_rows);
+        uint64_t *d_ocnt = reinterpret_cast<uint64_t *>(outs + o_rows + o_dist);
+
+        ScanArgs a;
+        a.corpus = corpus->d_rows;
+        a.rows = corpus->rows;
+        a.queries = d_q;
+        a.nq = nq;
+        a.k_out = k_eff;
+        a.ranges = nr ? d_r : nullptr;
+        a.range_prefix = nr ? d_p : nullptr;
+        a.range_chunk_prefix = nr ? d_cp : nullptr;
+        a.n_chunks = n_chunks;
+        a.n_ranges = nr;
+        a.n_virtual = n_virtual;
+        a.ws_threshold = (mode == SMT_MODE_WORKSPACE && has_thr) ? 1 : 0;
+        a.ws_thr_score = 1.0f - (float)max_distance;  // store.rs:502-503
+        a.row_base = row_base;
+        a.out_rows = d_orow;
+        a.out_dist = d_odist;
+        a.out_counts = d_ocnt;
+        a.out_uncertain = d_ocnt + nq;
+        // K2 or K3: topk_dispatch above
+        rc = topk_dispatch(ctx, corpus, a);
+        if (rc) return rc;
+
+        if ((rc = ensure_pinned(ctx, o_rows + o_dist + o_cnt))) return rc;
+        SMT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, outs, o_rows + o_dist + o_cnt, hipMemcpyDeviceToHost, ctx->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
+        const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows);
+        const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows + o_dist);
+        std::vector<uint32_t> redo;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint64_t n = h_cnt[q];
+            out[q].rows.assign(h_rows + (size_t)q * k_eff, h_rows + (size_t)q * k_eff + n);
+            out[q].dist.assign(h_dist + (size_t)q * k_eff, h_dist + (size_t)q * k_eff + n);
+            if (h_cnt[nq + q]) redo.push_back(q);  // (h_pinned is reused by the fallback: copy everything out first)
+        }
+        // queries whose f32 nomination could not be proven sufficient (a cluster of near-ties around the k-th
+        // place that is wider than the guard band): answer them exhaustively -- several of them with ONE batched
+        // threshold pass over the shard (batched_fallback), the rest (and whatever overflows there) one K4 scan each
+        const bool ws_thr = a.ws_threshold != 0;
+        auto bound_of = [&](uint32_t q) {
+            return out[q].rows.size() == k_eff ? out[q].dist.back() : 1.0 - (double)a.ws_thr_score;
+        };
+        if (nr == 0 && redo.size() >= 2 && ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg &&
+            corpus->rows >= (uint64_t)ctx->tune.fallback_batch_min_rows) {
+            std::vector<double> bounds;
+            for (uint32_t q : redo) bounds.push_back(bound_of(q));
+            std::vector<uint32_t> left;
+            rc = batched_fallback(ctx, corpus, d_q, redo, bounds, k_eff, ws_thr, a.ws_thr_score, row_base, out, left);
+            if (rc) return rc;
+            redo.swap(left);
+        }
+        for (uint32_t q : redo) {
+            rc = exact_fallback(ctx, corpus, d_q + (size_t)q * SMT_DIM, nr ? d_r : nullptr, nr ? d_cp : nullptr, nr, n_virtual,
+                                n_chunks, bound_of(q), k_eff, ws_thr, a.ws_thr_score, row_base, out[q]);
+            if (rc) return rc;
+        }
+        return SMT_OK;
+    }
+
+    // ---------------- all rows with distance < max_distance (mod.rs:88-89,115-116)
+    // several queries on a large unfiltered shard: ONE sweep of the batched kernel collects every query's hits (up to a
+    // candidate buffer, 2048 rows, each); a query with more hits than that takes the streaming K4 scan below
+    std::vector<uint32_t> todo(nq);
+    for (uint32_t q = 0; q < nq; ++q) todo[q] = q;
+    if (nr == 0 && nq >= 2 && ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && max_distance <= 2.5 &&
+        corpus->rows >= (uint64_t)ctx->tune.fallback_batch_min_rows) {
+        std::vector<double> bounds(nq, max_distance);
+        std::vector<uint32_t> left;
+        rc = batched_fallback(ctx, corpus, d_q, todo, bounds, ~0ull, false, 0.f, row_base, out, left, /*strict=*/true);
+        if (rc) return rc;
+        todo.swap(left);
+    }
+    for (uint32_t q : todo) {
+        ThresholdQuery t;
+        t.corpus = corpus->d_rows;
+        t.rows = corpus->rows;
+        t.query = d_q + (size_t)q * SMT_DIM;
+        t.ranges = nr ? d_r : nullptr;
+        t.range_chunk_prefix = nr ? d_cp : nullptr;
+        t.n_chunks = n_chunks;
+        t.n_ranges = nr;
+        t.n_virtual = n_virtual;
+        t.max_distance = max_distance;
+        const uint32_t *h_rows = nullptr;
+        const double *h_dist = nullptr;
+        uint64_t n_ok = 0;
+        if ((rc = run_threshold_query(ctx, t, &h_rows, &h_dist, &n_ok))) return rc;
+        out[q].rows.resize(n_ok);
+        for (uint64_t i = 0; i < n_ok; ++i) out[q].rows[i] = row_base + h_rows[i];
+        out[q].dist.assign(h_dist, h_dist + n_ok);
+    }
+    return SMT_OK;
+}
+
+// Copy per-query hit lists into the caller's [nq x out_cap] arrays; counts hold the TRUE sizes.
+int deliver_hits(const std::vector<LocalHits> &hits, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
+{
+    bool truncated = false;
+    for (size_t q = 0; q < hits.size(); ++q) {
+        const uint64_t n = hits[q].rows.size();
+        out_counts[q] = n;
+        const uint64_t w = std::min<uint64_t>(n, out_cap);
+        if (n > out_cap) truncated = true;
+        if (w) {
+            SMT_REQUIRE(out_rows && out_dist, "null output");
+            memcpy(out_rows + q * out_cap, hits[q].rows.data(), (size_t)w * sizeof(uint64_t));
+            memcpy(out_dist + q * out_cap, hits[q].dist.data(), (size_t)w * sizeof(double));
+        }
+    }
+    if (truncated) { set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
+    return SMT_OK;
+}
+
+// One shard's top-k with everything on the device (the exchange path of group.cpp).  queries_dev [nq x 256];
+// ranges_local = sorted, disjoint LOCAL row ranges (host array); filtered && n_ranges == 0 means "the filter
+// leaves this shard nothing to scan".  packed_dev [nq][2][k_pad] receives global rows, then f64 distance bit
+// patterns, padded with (UINT64_MAX, +inf).  1 <= k_pad <= SCAN_MAX_K.  Enqueued on the context's stream (the
+// select stage on the aux stream when allow_async and the async_select tuning key say so); no host sync.
+int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t k_pad, int ws_threshold,
+                             float ws_thr_score, const smt_range *ranges_local, uint32_t n_ranges, bool filtered,
+                             uint64_t row_base, uint64_t *packed_dev, uint64_t *uncertain_dev, bool allow_async)
+{
+    SMT_REQUIRE(corpus && queries_dev && packed_dev, "null argument");
+    SMT_REQUIRE(k_pad >= 1 && k_pad <= SCAN_MAX_K, "top_k of the device exchange path must be in [1, 56]");
+    smt_ctx *ctx = corpus->ctx;
+    uint64_t n_virtual = corpus->rows;
+    std::vector<smt_range> rr;
+    if (filtered) {
+        uint64_t total = 0;
+        int rcv = validate_ranges(ranges_local, n_ranges, corpus->rows, &total);
+        if (rcv) return rcv;
+        for (uint32_t i = 0; i < n_ranges; ++i) if (ranges_local[i].end > ranges_local[i].begin) rr.push_back(ranges_local[i]);
+        n_virtual = total;
+    }
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k_pad, n_virtual);
+    const bool async = allow_async && ctx->tune.async_select && nq == 1 && !filtered && k_eff == k_pad;
+    int rc = bind_device(ctx, !async);
+    if (rc) return rc;
+    if (k_eff < k_pad) {  // short or empty shard: padding first, the select then overwrites the head of each list
+        if ((rc = launch_merge_topk_packed_on(ctx, ctx->stream, packed_dev, 0, nq, 1, k_pad, packed_dev))) return rc;
+        if (k_eff == 0) {
+            if (uncertain_dev) SMT_HIP_CHECK(hipMemsetAsync(uncertain_dev, 0, (size_t)nq * sizeof(uint64_t), ctx->stream));
+            return SMT_OK;
+        }
+    }
+    const uint32_t nr = (uint32_t)rr.size();
+    smt_range *d_r = nullptr;
+    uint64_t *d_p = nullptr, *d_cp = nullptr;
+    uint64_t n_chunks = 0;
+    if (nr) {
+        const size_t r_bytes = (size_t)nr * sizeof(smt_range), p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
+        if ((rc = ensure_stage(ctx, r_bytes + 2 * p_bytes + 64))) return rc;
+        char *stage = reinterpret_cast<char *>(ctx->d_stage);
+        d_r = reinterpret_cast<smt_range *>(stage);
+        d_p = reinterpret_cast<uint64_t *>(stage + r_bytes);
+        d_cp = reinterpret_cast<uint64_t *>(stage + r_bytes + p_bytes);
+        std::vector<uint64_t> prefix(nr + 1, 0), chunk_prefix(nr + 1, 0);
+        for (uint32_t i = 0; i < nr; ++i) {
+            const uint64_t len = rr[i].end - rr[i].begin;
+            prefix[i + 1] = prefix[i] + len;
+            chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
+        }
+        n_chunks = chunk_prefix[nr];
+        SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    }
+    ScanArgs a;
+    a.corpus = corpus->d_rows;
+    a.rows = corpus->rows;
+    a.queries = queries_dev;
+    a.nq = nq;
+    a.k_out = k_eff;
+    a.ranges = d_r;
+    a.range_prefix = d_p;
+    a.range_chunk_prefix = d_cp;
+    a.n_chunks = n_chunks;
+    a.n_ranges = nr;
+    a.n_virtual = n_virtual;
+    a.ws_threshold = ws_threshold;
+    a.ws_thr_score = ws_thr_score;
+    a.row_base = row_base;
+    a.out_rows = packed_dev;
+    a.out_dist = reinterpret_cast<double *>(packed_dev + k_pad);
+    a.out_counts = nullptr;
+    a.out_uncertain = uncertain_dev;
+    a.allow_async = async;
+    a.out_stride = (uint64_t)2 * k_pad;
+    rc = topk_dispatch(ctx, corpus, a);
+    return rc;
+}
+
+}  // namespace smt
+
+extern "C" {
+
+int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+               const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, uint64_t *out_rows, double *out_dist,
+               uint64_t *out_counts, uint64_t out_cap)
+{
+    SMT_REQUIRE(nq == 0 || out_counts, "null argument");
+    std::vector<LocalHits> hits;
+    int rc = search_local_host(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, hits);
+    if (rc) return rc;
+    return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
+}
+
+int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,
+                           uint64_t *out_rows_dev, double *out_dist_dev)
+{
+    SMT_REQUIRE(corpus != nullptr, "corpus");
+    SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
+    SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
+    smt_ctx *ctx = corpus->ctx;
+    const bool async = ctx->tune.async_select && nq == 1 && corpus->rows > 0;  // launch_scan_topk keeps the pipeline going
+    int rc = bind_device(ctx, !async);
+    if (rc) return rc;
+    if (nq == 0) return SMT_OK;
+    ScanArgs a;
+    a.corpus = corpus->d_rows;
+    a.rows = corpus->rows;
+    a.queries = queries_dev;
+    a.nq = nq;
+    a.k_out = top_k;
+    a.ranges = nullptr;
+    a.range_prefix = nullptr;
+    a.range_chunk_prefix = nullptr;
+    a.n_chunks = 0;
+    a.n_ranges = 0;
+    a.n_virtual = corpus->rows;
+    a.ws_threshold = 0;
+    a.ws_thr_score = 0.f;
+    a.row_base = row_base;
+    a.out_rows = out_rows_dev;
+    a.out_dist = out_dist_dev;
+    a.out_counts = nullptr;
+    a.allow_async = async;
+    if (corpus->rows == 0) {
+        // nothing to scan: fill with padding through the merge kernel on zero lists
+        return launch_merge_topk(ctx, out_rows_dev, out_dist_dev, 0, nq, 1, top_k, out_rows_dev, out_dist_dev);
+    }
+    rc = topk_dispatch(ctx, corpus, a);
+    return rc;
+}
+
+int smt_debug_batched_scores(smt_corpus *corpus, const float *queries, uint32_t nq, uint64_t first_row, uint32_t n_rows,
+                             float *out)
+{
+    SMT_REQUIRE(corpus && queries && out, "null argument");
+    SMT_REQUIRE(first_row + n_rows <= corpus->rows, "row range outside the corpus");
+    smt_ctx *ctx = corpus->ctx;
+    int rc = bind_device(ctx, true);
+    if (rc) return rc;
+    const size_t b_q = (size_t)nq * 256 * 4, b_out = (size_t)n_rows * 32 * 4;
+    if ((rc = ensure_scratch(ctx, b_q + b_out + 256))) return rc;
+    float *d_q = reinterpret_cast<float *>(ctx->d_scratch);
+    float *d_out = reinterpret_cast<float *>(reinterpret_cast<char *>(ctx->d_scratch) + ((b_q + 255) & ~(size_t)255));
+    SMT_HIP_CHECK(hipMemcpyAsync(d_q, queries, b_q, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_gemm_debug_scores(ctx, corpus->d_rows, first_row, n_rows, d_q, nq, d_out))) return rc;
+    SMT_HIP_CHECK(hipMemcpyAsync(out, d_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMT_OK;
+}
+
+int smt_merge_topk(const uint64_t *rows, const double *dist, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
+                   uint64_t *out_rows, double *out_dist, uint64_t *out_counts)
+{
+    SMT_REQUIRE((rows && dist) || n_lists == 0 || nq == 0 || k_in == 0, "null input");
+    SMT_REQUIRE(nq == 0 || k_out == 0 || (out_rows && out_dist), "null output");
+    std::vector<std::pair<double, uint64_t>> cand;
+    for (uint32_t q = 0; q < nq; ++q) {
+        cand.clear();
+        for (uint32_t l = 0; l < n_lists; ++l)
+            for (uint32_t i = 0; i < k_in; ++i) {
+                const size_t idx = ((size_t)l * nq + q) * k_in + i;
+                if (rows[idx] != UINT64_MAX) cand.emplace_back(dist[idx], rows[idx]);
+            }
+        std::sort(cand.begin(), cand.end());
+        const uint64_t n = std::min<uint64_t>(cand.size(), k_out);
+        for (uint32_t i = 0; i < k_out; ++i) {
+            out_rows[(size_t)q * k_out + i] = i < n ? cand[i].second : UINT64_MAX;
+            out_dist[(size_t)q * k_out + i] = i < n ? cand[i].first : std::numeric_limits<double>::infinity();
+        }
+        if (out_counts) out_counts[q] = n;
+    }
+    return SMT_OK;
+}
+
+int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *dist_dev, uint32_t n_lists, uint32_t nq,
+                          uint32_t k_in, uint32_t k_out, uint64_t *out_rows_dev, double *out_dist_dev)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(nq == 0 || (out_rows_dev && out_dist_dev), "null output");
+    if ((rc = bind_device(ctx))) return rc;
+    if (nq == 0 || k_out == 0) return SMT_OK;
+    return launch_merge_topk(ctx, rows_dev, dist_dev, n_lists, nq, k_in, k_out, out_rows_dev, out_dist_dev);
+}
+
+int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint32_t n_lists, uint32_t nq, uint32_t k_in,
+                                 uint32_t k_out, uint64_t *out_packed_dev)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    SMT_REQUIRE(nq == 0 || k_out == 0 || (packed_dev && out_packed_dev), "null argument");
+    if ((rc = bind_device(ctx, !(ctx->tune.merge_on_aux && ctx->aux_stream)))) return rc;
+    if (nq == 0 || k_out == 0) return SMT_OK;
+    return launch_merge_topk_packed(ctx, packed_dev, n_lists, nq, k_in, k_out, out_packed_dev);
+}
+
+}  // extern "C"
