@@ -1,7 +1,7 @@
-// api.cpp -- host side of libsemtools_hip.so: handles, memory, orchestration of
-// the kernels, and the extern "C" entry points declared in
-// include/semtools_hip.h.  There is no CPU fallback anywhere in this file:
-// every compute entry point needs a live gfx950 context.
+// api.cpp -- host side of libsemtools_hip.so: error text, contexts, tuning keys, models, corpora (with their fp16 operand image),
+// embed, ids -- the extern "C" entry points of include/semtools_hip.h that are not searches (search.cpp), files (corpus_io.cpp),
+// groups (group.cpp, sharded.cpp) or indexes (ivfpq_*.hip).  There is no CPU fallback anywhere: every compute entry point needs
+// a live gfx950 context.
 #include <algorithm>
 #include <cerrno>
 #include <cmath>

@@ -72,7 +72,7 @@ struct Tuning {
     int64_t fallback_batch_min_rows = 100000;   // >= 2 uncertain queries of a call on a shard this large are re-answered by ONE batched threshold pass
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
     int gemm_min_nq = 3;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
-    int64_t gemm_min_rows_small = 1000000;   // (2 queries: 4 x this; api.cpp topk_dispatch)
+    int64_t gemm_min_rows_small = 1000000;   // (2 queries: 4 x this; search.cpp topk_dispatch)
     int gemm_nominate = 0;      // gemm_rowreg_kernel: 0 auto (shards <= 32 M rows: f16 x 2 from 128 queries, f16 x 1 from 256), 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1
     int gemm_rowreg = 1;        // 1: with gemm_bf16x3, unfiltered batches use gemm_rowreg_kernel (coalesced row loads + LDS transpose)
     int gemm_bf16x3 = 1;        // 1: K3 nominates candidates with bf16 x 3 split products on the bf16 MFMA pipe (mfma_tile.h); 0: f32 MFMA
@@ -127,7 +127,7 @@ struct smt_corpus {
     uint32_t *image_zero = nullptr;
     uint64_t image_cap_tiles = 0;
     uint64_t image_rows = 0;
-    uint32_t small_searches = 0; // searches of < 8 queries seen while the shard was large enough to scan its image (api.cpp topk_dispatch)
+    uint32_t small_searches = 0; // searches of < 8 queries seen while the shard was large enough to scan its image (search.cpp topk_dispatch)
     int image_mode = 0;          // 0: by policy (tuning key corpus_image; owned corpora only), 1: requested (smt_corpus_prepack), -1: refused
 };
 
@@ -267,7 +267,7 @@ constexpr double F32_ERR_F16X1 = 1.0e-3;
 // K2/K3 keep k + 8 <= 64 candidates per list: top_k above this goes to the all-keys path (largek.hip)
 constexpr uint32_t SCAN_MAX_K = 56;
 
-// per-query result list of the host-side search (api.cpp)
+// per-query result list of the host-side search (search.cpp)
 struct LocalHits {
     std::vector<uint64_t> rows;  // global rows (row_base added)
     std::vector<double> dist;
@@ -278,7 +278,7 @@ int deliver_hits(const std::vector<LocalHits> &hits, uint64_t *out_rows, double 
 int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t k_pad, int ws_threshold,
                              float ws_thr_score, const smt_range *ranges_local, uint32_t n_ranges, bool filtered,
                              uint64_t row_base, uint64_t *packed_dev, uint64_t *uncertain_dev, bool allow_async);
-// corpus file slices (api.cpp): shared by smt_corpus_save/load and the sharded corpus of group.cpp
+// corpus file slices (corpus_io.cpp): shared by smt_corpus_save/load and the sharded corpus of group.cpp
 int corpus_file_info(const char *path, uint64_t *rows, uint32_t *dim);
 int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint64_t n_rows);
 int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows);

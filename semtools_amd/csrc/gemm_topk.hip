@@ -12,7 +12,7 @@
 //                               157 TF peak) when gemm_bf16x3 = 0, or bf16 x 3 when gemm_rowreg = 0.  The level scheme,
 //                               the epilogue and the candidate buffers described below are shared by all three.
 //   level_select_kernel, split_queries_*_kernel, query_consts_kernel: per-level / per-batch helpers.
-//   launch_gemm_threshold       one sweep with preset thresholds: the batched exhaustive re-answer (api.cpp).
+//   launch_gemm_threshold       one sweep with preset thresholds: the batched exhaustive re-answer (search.cpp).
 //
 // The f32 design (gemm_level_kernel):
 //
@@ -509,7 +509,7 @@ int launch_split_rows_bf16(smt_ctx *ctx, const float *rows, uint32_t n, uint32_t
     return SMT_OK;
 }
 
-// ---- batched threshold pass: the exhaustive re-answer of MANY uncertain queries in one sweep (api.cpp).  Every row
+// ---- batched threshold pass: the exhaustive re-answer of MANY uncertain queries in one sweep (search.cpp).  Every row
 // whose nominating distance is <= tau[q] lands in query q's candidate buffer: gemm_rowreg_kernel over all tiles as a
 // single level with preset thresholds.  A query with more than CAND_CAP such rows reports count > CAND_CAP (the caller
 // re-answers it with the streaming K4 scan).  Buffers live in the context's scratch until the next launch.
