@@ -231,3 +231,30 @@ def test_random_life_of_a_corpus_with_an_image(smt):
             assert got_r[i] == list(want_r[i]), (step, i)
             np.testing.assert_allclose(got_d[i], want_d[i], atol=1e-12)
         assert c.image_bytes > 0
+
+
+@pytest.mark.parametrize("nominate", [0, 2, 3])
+def test_near_tie_clusters_over_the_image_stay_exact(smt, nominate):
+    """Forty rows within 1e-4 of every query -- closer together than the fp16 nomination can tell apart -- plus exact duplicates:
+    the certificate fails, the exhaustive re-answer takes over, and the answers over the operand image are the f64 truth in every
+    fp16 mode (gemm_nominate 2 / 3 forced, 0 = the default routing)."""
+    rng = np.random.default_rng(30)
+    ctx = smt.Context(0)
+    rows = _unit(90_000, 31)
+    q = _unit(12, 32)
+    for i in range(12):
+        at = rng.choice(90_000, 42, replace=False)
+        near = q[i][None, :] + 1e-4 * rng.standard_normal((42, 256)).astype(np.float32)
+        rows[at] = near / np.linalg.norm(near, axis=1, keepdims=True)
+        rows[at[:2]] = rows[at[2]]                    # three identical rows: row order decides
+    c = _corpus(smt, ctx, rows)
+    c.prepack()
+    ctx.set_tuning("gemm_nominate", nominate)
+    try:
+        got_r, got_d = _search(c, q, 10)
+    finally:
+        ctx.set_tuning("gemm_nominate", 0)
+    want_r, want_d = _topk64(rows, q, 10)
+    for i in range(12):
+        assert got_r[i] == list(want_r[i]), i
+        np.testing.assert_allclose(got_d[i], want_d[i], atol=1e-12)
