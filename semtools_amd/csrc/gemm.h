@@ -17,6 +17,8 @@ constexpr uint32_t CAND_CAP = 2048;            // candidate slots per query
 // per query.  Measured alternative (MI355X, 10 M rows): ratio 64 with 4096 slots -- three levels instead of five --
 // LOSES: its middle level (4.8 k tiles) leaves every wave two tiles, the O(n^2) level select over ~3 k candidates
 // costs 90 us per level instead of 8 (32 queries: 2.34 vs 2.07 ms per batch; 1000 queries: 41.2 vs 39.8 ms).
+// Round 3, with the operand image: ratios 8 and 4 (one resp. three more levels, half resp. a quarter of the nominations per
+// level) measure within +-2 % of 16 from 1 to 1000 queries (1000 x 10 M: 6.15 / 6.17 against 6.25 ms per call).
 constexpr int LEVEL_RATIO_SMALL_K = 16;
 constexpr int LEVEL_RATIO_LARGE_K = 16;
 constexpr uint32_t LEVEL_RATIO_KP_LIMIT = 24;
