@@ -675,6 +675,7 @@ std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<
         check(rc, "search_documents");
         break;
     }
+    PhaseTimer::mark("session_device_search");
     for (size_t q = 0; q < nq; ++q) {
         std::vector<SearchResult> &results = all[q];
         results.reserve(counts[q]);

@@ -393,10 +393,14 @@ int smt_host_session_search(smt_host_session *s, const char *const *queries, uin
         const auto cfg = make_config(n_lines, top_k, max_distance, s->ignore_case);
         std::vector<std::string> qs;
         for (uint64_t i = 0; i < n_queries; ++i) qs.push_back(s->ignore_case ? to_lowercase(queries[i]) : std::string(queries[i]));
+        search::PhaseTimer::mark("between_session_calls");
         const auto qemb = s->model->m->encode_with_args(qs, 512, 1024);  // encode_single per query
+        search::PhaseTimer::mark("session_encode_queries");
         const auto res = search::search_documents_batch(s->docs, *s->emb, qemb, cfg);
+        search::PhaseTimer::mark("session_search_and_build_results");
         for (uint64_t i = 0; i < n_queries; ++i)
             out_texts[i] = dup_text(json ? cmds::search_results_json(res[i]) : cmds::print_search_results(res[i], is_tty != 0));
+        search::PhaseTimer::mark("session_format");
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
 }
