@@ -217,6 +217,10 @@ int run_threshold_query(smt_ctx *ctx, const ThresholdQuery &t, const uint32_t **
                         uint64_t *n_pass);
 int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, const uint32_t *rows,
                         uint64_t n, double *out_dist);
+int launch_gather_rows256(smt_ctx *ctx, const float *src, const uint32_t *idx_dev, uint32_t n, float *dst);   // dst[i] = src[idx[i]]
+// ... of many queries at once: rows[i] against query qidx[i] of the [.][256] block (the batched exhaustive re-answer)
+int launch_rescore_rows_multi(smt_ctx *ctx, const float *corpus, const float *queries, const uint32_t *rows, const uint32_t *qidx,
+                              uint64_t n, double *out_dist);
 
 // Select stage: block lists -> best k_out per query with exact f64 distances (scan_kernels.hip).
 struct SelectArgs {
@@ -331,8 +335,9 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);
 // bf16 hi / lo split image (mfma_tile.h layout) of n rows of 256 f32, padded with zero rows to n_pad (gemm_topk.hip)
 int launch_split_rows_bf16(smt_ctx *ctx, const float *rows, uint32_t n, uint32_t n_pad, uint32_t *out);
 // batched threshold pass (gemm_topk.hip): rows with nominating distance <= tau[q], per query, in scratch buffers
-int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const float *queries, uint32_t nq,
-                          const float *tau, const key_t64 **cand_out, const unsigned int **counts_out, uint32_t *cand_stride);
+int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const void *image, const uint32_t *image_zero,
+                          const float *queries, uint32_t nq, const float *tau, const key_t64 **cand_out,
+                          const unsigned int **counts_out, uint32_t *cand_stride);
 // test hook: the nominating f32 distances of the K3 kernels for <= 32 queries (gemm_topk.hip)
 int launch_gemm_debug_scores(smt_ctx *ctx, const float *corpus, uint64_t first_row, uint32_t n_rows, const float *queries,
                              uint32_t nq, float *out);

@@ -513,9 +513,11 @@ int launch_split_rows_bf16(smt_ctx *ctx, const float *rows, uint32_t n, uint32_t
 // whose nominating distance is <= tau[q] lands in query q's candidate buffer: gemm_rowreg_kernel over all tiles as a
 // single level with preset thresholds.  A query with more than CAND_CAP such rows reports count > CAND_CAP (the caller
 // re-answers it with the streaming K4 scan).  Buffers live in the context's scratch until the next launch.
-int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const float *queries, uint32_t nq,
-                          const float *tau, const key_t64 **cand_out, const unsigned int **counts_out, uint32_t *cand_stride)
+int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, const void *image, const uint32_t *image_zero,
+                          const float *queries, uint32_t nq, const float *tau, const key_t64 **cand_out,
+                          const unsigned int **counts_out, uint32_t *cand_stride)
 {
+    const bool f16 = image != nullptr;   // over the corpus' operand image: f16 x 2 (the caller widened tau by F32_ERR_F16X2)
     SMT_REQUIRE(nq >= 1 && rows >= 1 && rows < 0xFFFFFFFFull, "threshold pass: bad sizes");
     if (int rc_attr = ensure_gemm_attrs(ctx)) return rc_attr;
     const uint32_t nqt = (nq + QT_ROWS - 1) / QT_ROWS;
@@ -531,8 +533,9 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     float *qconst = reinterpret_cast<float *>(base + b_cand + b_cnt);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + b_cand + b_cnt + b_qc);
     SMT_HIP_CHECK(hipMemsetAsync(counts, 0, b_cnt, ctx->stream));
-    hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, q_split);
-    hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, qconst, 0);
+    if (f16) hipLaunchKernelGGL(split_queries_f16_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, q_split);
+    else hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, q_split);
+    hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, queries, nq, nqt * QT_ROWS, qconst, f16 ? 1 : 0);
     hipLaunchKernelGGL(set_qconst_thresholds_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, qconst, tau, nq);
     GemmParams g;
     g.corpus = corpus;
@@ -552,14 +555,15 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     g.chunk_table = nullptr;
     g.stamps = nullptr;
     g.buffered = 0;
-    g.image = nullptr;
-    g.image_zero = nullptr;
+    g.image = image;
+    g.image_zero = image_zero;
     g.tile_begin = 0;
     g.n_chunks = 0;
     const int blocks = ctx->tune.gemm_blocks > 0 ? ctx->tune.gemm_blocks : ctx->num_cus;
     const int nb = (int)std::min<uint64_t>((uint64_t)blocks, (g.level_tiles + RR_WAVES - 1) / RR_WAVES);
-    prof_begin(ctx, "gemm_thr");   // (always bf16 x 3: the tighter band collects fewer rows)
-    gemm_rowreg_launch(ctx, 0, false, nb, g);
+    // from the f32 rows: bf16 x 3 (the tightest band collects the fewest rows); with the operand image: f16 x 2 over half the bytes
+    prof_begin(ctx, "gemm_thr");
+    gemm_rowreg_launch(ctx, f16 ? 1 : 0, f16, nb, g);
     prof_end(ctx, "gemm_thr");
     SMT_HIP_CHECK(hipGetLastError());
     *cand_out = cand;

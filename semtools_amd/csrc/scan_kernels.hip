@@ -368,6 +368,25 @@ __global__ void rescore_rows_kernel(const float *corpus, const float *query, con
                                 reinterpret_cast<const f32x4 *>(corpus + (uint64_t)rows[i] * 256));
 }
 
+// the same for the rows of MANY queries in one launch: row i belongs to query qidx[i] of the [n_queries][256] block
+__global__ void rescore_rows_multi_kernel(const float *corpus, const float *queries, const uint32_t *rows, const uint32_t *qidx,
+                                          uint64_t n, double *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = exact_distance(reinterpret_cast<const f32x4 *>(queries + (uint64_t)qidx[i] * 256),
+                                reinterpret_cast<const f32x4 *>(corpus + (uint64_t)rows[i] * 256));
+}
+
+// dst[i] = src[idx[i]] for rows of 256 f32: one wave per row
+__global__ void gather_rows256_kernel(const float *src, const uint32_t *idx, uint32_t n, float *dst)
+{
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i < n)
+        reinterpret_cast<f32x4 *>(dst + (size_t)i * 256)[threadIdx.x & 63] =
+            reinterpret_cast<const f32x4 *>(src + (size_t)idx[i] * 256)[threadIdx.x & 63];
+}
+
 // ------------------------------------------------ select: prune, rank, rescore
 // Input: n_lists sorted lists (one per scan block) of kp keys each, ascending,
 // padded with KEY_PAD; valid keys are distinct (distinct rows).  We need the kp
@@ -998,6 +1017,27 @@ int launch_rescore_rows(smt_ctx *ctx, const float *corpus, const float *query, c
     prof_begin(ctx, "select");
     hipLaunchKernelGGL(rescore_rows_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, corpus,
                        query, rows, n, out_dist);
+    prof_end(ctx, "select");
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_gather_rows256(smt_ctx *ctx, const float *src, const uint32_t *idx_dev, uint32_t n, float *dst)
+{
+    if (n == 0) return SMT_OK;
+    hipLaunchKernelGGL(gather_rows256_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, src, idx_dev, n, dst);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+int launch_rescore_rows_multi(smt_ctx *ctx, const float *corpus, const float *queries, const uint32_t *rows, const uint32_t *qidx,
+                              uint64_t n, double *out_dist)
+{
+    if (n == 0) return SMT_OK;
+    const int threads = 64;
+    prof_begin(ctx, "select");
+    hipLaunchKernelGGL(rescore_rows_multi_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream, corpus,
+                       queries, rows, qidx, n, out_dist);
     prof_end(ctx, "select");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
