@@ -676,7 +676,8 @@ std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<
         break;
     }
     PhaseTimer::mark("session_device_search");
-    for (size_t q = 0; q < nq; ++q) {
+    parallel_slices(nq, 128, [&](size_t q_begin, size_t q_end) {   // (results of different queries share nothing)
+    for (size_t q = q_begin; q < q_end; ++q) {
         std::vector<SearchResult> &results = all[q];
         results.reserve(counts[q]);
         for (uint64_t i = 0; i < counts[q]; ++i) {
@@ -696,6 +697,7 @@ std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<
             results.push_back(std::move(r));
         }
     }
+    });
     return all;  // each already (distance asc, document/line order) == stable sort; take(top_k) done on device
 }
 

@@ -8,6 +8,7 @@
 #include "../../../include/semtools_host.h"
 #include "../common.h"
 #include "host.h"
+#include "host_internal.h"
 #include "json.h"
 #include "fmt.h"
 
@@ -398,8 +399,10 @@ int smt_host_session_search(smt_host_session *s, const char *const *queries, uin
         search::PhaseTimer::mark("session_encode_queries");
         const auto res = search::search_documents_batch(s->docs, *s->emb, qemb, cfg);
         search::PhaseTimer::mark("session_search_and_build_results");
-        for (uint64_t i = 0; i < n_queries; ++i)
-            out_texts[i] = dup_text(json ? cmds::search_results_json(res[i]) : cmds::print_search_results(res[i], is_tty != 0));
+        semtools::parallel_slices((size_t)n_queries, 128, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i)
+                out_texts[i] = dup_text(json ? cmds::search_results_json(res[i]) : cmds::print_search_results(res[i], is_tty != 0));
+        });
         search::PhaseTimer::mark("session_format");
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
