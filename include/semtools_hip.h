@@ -422,8 +422,15 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *   gemm_min_nq, gemm_min_rows_small   from this many queries (default 3; 8+ always) on shards of this many rows (1 M)
  *                        a call takes the batched path K3 instead of K2 passes of <= 4 queries (2 queries: 4 x the rows)
  *   gemm_rowreg (1/0)    unfiltered batches run gemm_rowreg_kernel (coalesced row loads + LDS transpose)
- *   gemm_nominate (0/1/2) how the row-register kernel nominates: 1 bf16 x 3 (band 1.5e-4), 2 f16 x 2 (a third fewer
- *                        MFMAs, band 6e-4, guard band >= 16), 0 = f16 x 2 from 128 queries on shards <= 32 M rows
+ *   gemm_nominate (0/1/2/3) how the row-register kernel nominates: 1 bf16 x 3 (band 7e-5), 2 f16 x 2 (a third fewer MFMAs,
+ *                        band 5.2e-4, guard band >= 16), 3 f16 x 1 (a third of the MFMAs, band 1.0e-3, guard band >= 24);
+ *                        0 = on shards <= 32 M rows f16 x 1 from 256 queries, f16 x 2 from 128, bf16 x 3 below; with the corpus'
+ *                        operand image: f16 x 1 from 128 queries, f16 x 2 below, shards up to 2^28 rows
+ *   corpus_image (1/0)   corpora the library owns build and keep their fp16 operand image (smt_corpus_prepack)
+ *   gemm_image (1/0)     batched searches read the image when the corpus has one
+ *   image_scan_min_rows  shards of at least this many rows (4 000 000; 0 = never) that HAVE their image answer 1-2 queries
+ *                        from it as well, and build it at their fourth small search
+ *   gemm_buffered, gemm_split_last, embed_batched (1/0)   A/B switches of round-3 kernel changes
  *   gemm_bf16x3 (1/0)    K3 nominates with bf16 x 3 split products on the bf16 MFMA pipe (default) or with f32 MFMAs;
  *                        answers are identical either way (exact re-scoring + the exactness certificate)
  *   prof_select (0/1), prof_every (N: HIP events on one launch in N)       profiling cost control
