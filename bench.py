@@ -679,8 +679,9 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     flops = 2.0 * nq * rows * 256
     # gemm_topk.hip launch_gemm_topk, the auto rule of gemm_nominate: MFMAs issued per algorithmic multiply-add
     small_shard = rows <= (1 << 25)
-    issued = 1.0 if (nq > 96 and small_shard and k + 24 <= 64) else 2.0 if (small_shard and k + 16 <= 64) else 3.0   # (with the image)
-    mode_name = {1.0: "f16 x 1", 2.0: "f16 x 2", 3.0: "bf16 x 3"}[issued]
+    issued_f32 = 1.0 if (nq >= 256 and small_shard and k + 24 <= 64) else 2.0 if (nq >= 128 and small_shard) else 3.0   # from f32 rows
+    issued_img = 1.0 if (nq > 96 and k + 24 <= 64) else 2.0 if (k + 16 <= 64) else 3.0                                 # with the image
+    names = {1.0: "f16 x 1", 2.0: "f16 x 2", 3.0: "bf16 x 3"}
     ok = True
     for i in range(min(3, nq)):  # independent fp64 check of a few queries
         ref = 1.0 - (x.double() @ q[i].double())
@@ -725,41 +726,42 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         f32_leg = {"error": repr(exc)}
     finally:
         ctx.set_tuning("gemm_bf16x3", 1)
-    traffic, traffic_source = measured_traffic("c3", rows)
     corpus.close()
     del x
     torch.cuda.empty_cache()
+    def k3_roofline(gemm_seconds, launches, leg, bytes_per_row, issued):
+        t, src = measured_traffic(leg, rows)
+        return {"kernel": f"gemm_rowreg_kernel (K3, {names[issued]})", "bound": "mfma", "achieved": issued * flops / gemm_seconds / 1e12,
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": issued * flops / gemm_seconds / 2500e12, "traffic": t, "traffic_source": src,
+                "algorithmic_bytes_per_batch": rows * bytes_per_row,
+                "algorithmic_bytes_note": "`traffic` is the largest launch of the batch, 7/8 of 15/16 of the rows",
+                "algorithmic_flops_per_batch": flops, "issued_16bit_mfma_flops_per_batch": issued * flops,
+                "algorithmic_rate_over_f32_mfma_peak": flops / gemm_seconds / 157.3e12,
+                "gemm_ms_per_batch": gemm_seconds * 1e3, "gemm_launches_per_batch": launches,
+                # what the 16-bit pipe of this part sustains on DATA (it is power-managed: constants run at 2.4 GHz and 0.98 of
+                # nominal, random fp16 operands at ~1.45 GHz): tools/micro/mfma_peak_f16.hip, profiles/r03_mfma_peak_f16.jsonl
+                "sustained_peak_random_operands": {"registers_TFLOPs": 1635.0, "lds_fed_with_epilogue_TFLOPs": 1396.0,
+                                                   "frac_of_lds_fed": issued * flops / gemm_seconds / 1396e12,
+                                                   "source": "profiles/r03_mfma_peak_f16.jsonl (not measured by this run)"}}
+
     return {
-        "metric": "queries/sec at 10M-chunk corpus (batched)", "value": nq / wall, "unit": "queries/s",
-        "ms_per_batch": wall * 1e3, "rows_scanned_per_s": nq * rows / wall,
+        # `value`: the batch over the f32 rows as BASELINE c3 words it (the corpus adopted as it is).  `operand_image`: the same
+        # batch once the corpus has its fp16 operand image -- a derived copy in MFMA operand order the library keeps for the corpora
+        # it owns (the workspace store's); nominations only, every returned distance is re-scored in f64 from the f32 rows, the
+        # answers are identical.
+        "metric": "queries/sec at 10M-chunk corpus (batched)", "value": nq / wall_f32, "unit": "queries/s",
+        "ms_per_batch": wall_f32 * 1e3, "rows_scanned_per_s": nq * rows / wall_f32,
         "config": {"workload": f"c3: {nq} batched queries x {rows} chunks (D=256, f32), top-{k}, one MI355X"},
         # The score matrix only nominates candidates.  On shards <= 32 M rows the library's default is f16 x 1 from 256 queries
         # (one fp16 operand per row and per query = 1 x the algorithmic flops on the 16-bit MFMA pipe, dense peak 2.5 PF), f16 x 2
         # from 128 (hi + lo per query: 2 x); smaller batches / larger shards use bf16 x 3 (3 x).  `frac` is ISSUED MFMA flops over
         # the 16-bit peak -- a mode that issues fewer MFMAs for the same answers finishes sooner at a LOWER fraction; queries/s is
         # the figure of merit.  The same batch on f32 MFMAs (roofline_f32_mfma) is bounded by 157.3 TF.
-        "roofline": {"kernel": f"gemm_rowreg_kernel (K3, {mode_name})", "bound": "mfma",
-                     "achieved": issued * flops / gemm_s / 1e12,
-                     "peak": 2500.0, "unit": "TFLOP/s", "frac": issued * flops / gemm_s / 2500e12, "traffic": traffic,
-                     "traffic_source": traffic_source, "algorithmic_bytes_per_batch": rows * ROW_BYTES // 2,
-                     "algorithmic_bytes_note": "512 B per row from the fp16 operand image (1024 B per row of f32 without it); `traffic` is the "
-                                               "largest launch of the batch, 7/8 of 15/16 of the rows",
-                     "algorithmic_flops_per_batch": flops, "issued_16bit_mfma_flops_per_batch": issued * flops,
-                     "algorithmic_rate_over_f32_mfma_peak": flops / gemm_s / 157.3e12,
-                     "gemm_ms_per_batch": gemm_s * 1e3, "gemm_launches_per_batch": n_g // reps,
-                     # what the 16-bit pipe of this part sustains on DATA (it is power-managed: constants run at 2.4 GHz and 0.98
-                     # of nominal, random fp16 operands at ~1.45 GHz): tools/micro/mfma_peak_f16.hip, profiles/r03_mfma_peak_f16.jsonl
-                     "sustained_peak_random_operands": {"registers_TFLOPs": 1635.0, "lds_fed_with_epilogue_TFLOPs": 1396.0,
-                                                        "frac_of_lds_fed": issued * flops / gemm_s / 1396e12,
-                                                        "source": "profiles/r03_mfma_peak_f16.jsonl (not measured by this run)"}},
-        "operand_image": {"build_ms": prepack_s * 1e3, "bytes": image_bytes, "bytes_per_row": image_bytes / max(rows, 1),
-                          "answers_identical_to_f32_rows_run": f"{image_same}/{nq}",
-                          "note": "derived fp16 copy of the rows in MFMA operand order; nominations only -- every returned distance is "
-                                  "re-scored in f64 from the f32 rows"},
+        "roofline": k3_roofline(gemm_s_f32, n_g_f32 // reps, "c3_f32_rows", ROW_BYTES, issued_f32),
+        "operand_image": {"queries_per_s": nq / wall, "ms_per_batch": wall * 1e3, "build_ms": prepack_s * 1e3, "bytes": image_bytes,
+                          "bytes_per_row": image_bytes / max(rows, 1), "answers_identical_to_f32_rows_run": f"{image_same}/{nq}",
+                          "roofline": k3_roofline(gemm_s, n_g // reps, "c3", ROW_BYTES // 2, issued_img)},
         "single_query_same_corpus": single,
-        "f32_rows_only": {"queries_per_s": nq / wall_f32, "ms_per_batch": wall_f32 * 1e3, "gemm_ms_per_batch": gemm_s_f32 * 1e3,
-                          "gemm_launches_per_batch": n_g_f32 // reps, "frac_of_2.5PF": issued * flops / gemm_s_f32 / 2500e12,
-                          "note": "the same batch before smt_corpus_prepack: gemm_rowreg_kernel converts the f32 rows in its row phase"},
         "roofline_f32_mfma": f32_leg,
         "checks": {"torch_fp64_topk_match": ok, "k2_path_agreement": f"{n_same}/{nq}",
                    "selects_without_exactness_certificate": uncertain},
