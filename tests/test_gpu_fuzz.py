@@ -61,3 +61,28 @@ def test_threshold_random(gpu_ctx, n, seed, thr):
     orows, odist = _oracle(emb, q, 3, thr)
     assert rows.tolist() == orows and np.array_equal(dist, np.array(odist))
     c.close()
+
+
+@settings(max_examples=30 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(1, 5000), k=st.integers(1, 40), nq=st.sampled_from([1, 2, 8, 9, 33, 70, 130]),
+       seed=st.integers(0, 10_000), dup=st.sampled_from([0.0, 0.05, 0.5]))
+def test_topk_random_shapes_over_the_operand_image(gpu_ctx, n, k, nq, seed, dup):
+    """The same contract with the corpus' fp16 operand image in play (smt_corpus_prepack; 1-2 queries routed to it too): ragged
+    last tiles, duplicates (ties by row order), zero rows -- rows and f64 distances equal the oracle's."""
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(n, seed=seed, dup_frac=dup, zero_frac=0.01)
+    qs = synth.unit_query(seed + 1, nq=nq)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    c.prepack()
+    gpu_ctx.set_tuning("image_scan_min_rows", 1)
+    try:
+        got = c.search(qs, top_k=k)
+    finally:
+        gpu_ctx.set_tuning("image_scan_min_rows", 4_000_000)
+    for i in range(nq):
+        orows, odist = _oracle(emb, qs[i], k)
+        assert got[i][0].tolist() == orows, (i, n, k, nq, seed, dup)
+        assert np.array_equal(got[i][1], np.array(odist))
+    c.close()
