@@ -155,6 +155,11 @@ int main(int argc, char **argv)
             if (pending.size() >= batch && flush_batch()) return 1;
         }
         if (flush_batch()) return 1;
+        if (const char *t = getenv("SEMTOOLS_TIMING"); t && *t == '1') {
+            char *phases = smt_host_timing_json();
+            fprintf(stderr, "{\"timing_ms\": %s}\n", phases ? phases : "{}");
+            smt_host_free(phases);
+        }
         smt_host_session_close(session);
         smt_host_model_destroy(model);
         smt_group_destroy(group);

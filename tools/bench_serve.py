@@ -83,6 +83,24 @@ def main():
         m.close()
     t = result.pop("_texts")
     result["answers_identical"] = all(t[1][b] == t[0][b] for b in args.batches)
+    # ---- the C++ caller: `semtools serve --batch 1024` fed 65 536 queries on stdin, phases from SEMTOOLS_TIMING
+    import subprocess
+    cli = os.path.join(ROOT, "semtools_amd", "bin", "semtools")
+    many = synth.pseudo_prose(65536, vocab_size=V - 1, seed=10)
+    env = dict(os.environ, SEMTOOLS_MODEL_DIR=model_dir, SEMTOOLS_TIMING="1")
+    t0 = time.perf_counter()
+    pr = subprocess.run([cli, "serve", *files, "-n", "1", "--top-k", "3", "--batch", "1024"], input="\n".join(many) + "\n", capture_output=True, text=True, env=env)
+    wall = time.perf_counter() - t0
+    ph = {}
+    for line in pr.stderr.splitlines():
+        if line.startswith('{"timing_ms"'):
+            ph = json.loads(line)["timing_ms"]
+    sess = sum(v for k, v in ph.items() if k.startswith("session_"))
+    between = ph.get("between_session_calls", 0.0)
+    result["cli_serve_batch_1024"] = {"queries": len(many), "returncode": pr.returncode, "wall_s": round(wall, 3), "stdout_bytes": len(pr.stdout),
+                                      "phases_ms": {k: round(v, 1) for k, v in ph.items()},
+                                      "queries_per_s_inside_session_calls": round(len(many) / (sess / 1e3)) if sess else None,
+                                      "queries_per_s_incl_stdin_stdout": round(len(many) / ((sess + between) / 1e3)) if sess else None}
     print(json.dumps(result))
     if args.out:
         json.dump(result, open(args.out, "w"), indent=1)
