@@ -191,7 +191,7 @@ constexpr int RR_CB_CAP = 208;                    // 208 x 8 B keys + 208 x 4 B 
 template <int MODE>
 struct RrGeom {
     static constexpr int SLOTS = MODE == 2 ? 8 : RR_SLOTS;
-    static constexpr int ROW_F4 = MODE == 2 ? 33 : QT_STRIDE_F4;     // float4 per query row in LDS
+    static constexpr int ROW_F4 = MODE == 2 ? 32 : QT_STRIDE_F4;     // float4 per query row in LDS (f16 x 1: unpadded, swizzled)
     static constexpr int SLOT_F4 = QT_ROWS * ROW_F4;                  // float4 per slot
     static constexpr int QUERY_WORDS = MODE == 2 ? 128 : 256;         // words per query in the global split image
     // The ring advances in GROUPS of GT tiles: one block-wide barrier per group instead of per tile (between barriers the

@@ -219,6 +219,13 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     constexpr int QUERY_WORDS = RrGeom<MODE>::QUERY_WORDS, AHEAD = RrGeom<MODE>::AHEAD, GT = RrGeom<MODE>::GT;
     constexpr int WAVES = RR_WAVES;
     constexpr int STAGE_ROWS = QT_ROWS / WAVES;      // rows of a query tile each wave stages: 4
+    // ... in this many DMA instructions: one per row (64 lanes x 16 B = a 1 KiB row), or -- f16 x 1, 512 B per query -- one per PAIR
+    // of rows.  The pair form needs the two rows contiguous in LDS (LDS-DMA writes lane-linear), i.e. NO row padding: bank
+    // conflicts of the B reads are avoided by a swizzle instead -- the 16-B chunk c of row j sits at position c ^ (j & 7) of its
+    // row, applied to the SOURCE address of the DMA and to the read (an involution on both sides, as in gemm_ldsrow_kernel).
+    // Measured before (half-wave DMAs, one per row, padded rows): the staging instructions cost 0.73 of 5.9 ms at 1000 x 10 M;
+    // two full-wave DMAs in their place: -0.37 ms.
+    constexpr int STAGE_N = F16X1 ? STAGE_ROWS / 2 : STAGE_ROWS;
     constexpr int STAGE_EVERY = 2;                   // one DMA every so many K-steps at the start of a product
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4 *s_q = reinterpret_cast<f32x4 *>(smem_raw);                  // [4][32][65] float4: query tiles (split image)
@@ -235,28 +242,39 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     const bool resident = n_qt <= (uint32_t)SLOTS;
 
     // row u of this wave's share of query tile qt -> LDS slot (padding rows of the image are zero rows: no branch)
+    // f16 x 1: this lane's source offset (floats) inside pair u of the wave's four rows, swizzle included
+    uint32_t pair_src[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t row_in_tile = (uint32_t)(wave * STAGE_ROWS + 2 * u + (lane >> 5));
+        pair_src[u] = (uint32_t)(lane >> 5) * QUERY_WORDS + ((((uint32_t)lane & 31u) ^ (row_in_tile & 7u)) << 2);
+    }
+    uint32_t sw_low[4];   // f16 x 1: position of this lane's chunk of K-step m in its row, m mod 4
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) sw_low[mm] = (uint32_t)((2 * mm + h) ^ (j & 7));
     auto stage_row = [&](uint32_t qt, int slot, int u) __attribute__((always_inline)) {
-        const int r = wave * STAGE_ROWS + u;  // wave-uniform
+        const int r = wave * STAGE_ROWS + (F16X1 ? 2 * u : u);  // wave-uniform (f16 x 1: the first row of pair u)
         const uint32_t q = qt * QT_ROWS + r;
         f32x4 *dst = s_q + slot * SLOT_F4 + r * ROW_F4;
-        if constexpr (F16X1) {   // 512 B per query: the lower half of the wave carries it (every wave still issues ONE instruction)
-            if (lane < 32)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * QUERY_WORDS + lane * 4,
-                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        if constexpr (F16X1) {   // rows r, r + 1: lane l carries chunk (l & 31) ^ (row & 7) of row r + (l >> 5) to position l & 31
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * QUERY_WORDS + pair_src[u & 1],
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         } else {
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * QUERY_WORDS + lane * 4,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
     // the tile's 32 (threshold, 1/|q|) pairs: 256 B, one 4-byte DMA.  EVERY wave issues it (same bytes to the same
-    // place) so that all waves count the same number of DMA instructions per tile -- the vmcnt arithmetic below
+    // place) so that all waves count the same number of DMA instructions per tile -- the vmcnt arithmetic below.  (Issued by
+    // wave 0 alone, with its own vmcnt count, it measured SLOWER -- 1000 x 10 M 5.33 -> 5.58 ms: the one wave with more to do
+    // is the one the ring barrier waits for.)
     auto stage_consts = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
         __builtin_amdgcn_global_load_lds(p.qconst + (size_t)qt * QT_ROWS * 2 + lane,
                                          (__attribute__((address_space(3))) void *)(s_qconst + slot * RR_QCONST), 4, 0, 0);
     };
     auto stage_tile = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < STAGE_ROWS; ++u) stage_row(qt, slot, u);
+        for (int u = 0; u < STAGE_N; ++u) stage_row(qt, slot, u);
         stage_consts(qt, slot);
     };
     auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };  // vmcnt(0)
@@ -415,8 +433,12 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
         auto product_part = [&](f32x16 &acc, int slot, const int M0, const int M1, bool stage, uint32_t stage_qt, int stage_slot) __attribute__((always_inline)) {
             // quad of (K-step m, half h): [hi, lo] pairs at 4 m + 2 h (+ 1) in the 1 KiB image; hi only at 2 m + h in the compact one
             constexpr int QS = F16X1 ? 2 : 4;   // quads per K-step in a query row
-            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * SLOT_F4 + j * ROW_F4) + (F16X1 ? h : 2 * h);
-            const int M_CONSTS = M0 + (M1 - M0 > STAGE_EVERY * STAGE_ROWS ? STAGE_EVERY * STAGE_ROWS : M1 - M0 - 1);
+            const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * SLOT_F4 + j * ROW_F4) + (F16X1 ? 0 : 2 * h);
+            const int M_CONSTS = M0 + (M1 - M0 > STAGE_EVERY * STAGE_N ? STAGE_EVERY * STAGE_N : M1 - M0 - 1);
+            // f16 x 1: chunk 2m + h of row j sits at position (2m + h) ^ (j & 7): the low three bits are lane-dependent (four values
+            // per lane, m mod 4), the rest is the constant 8 (m >> 2)
+            auto b_chunk = [&](int m) __attribute__((always_inline)) { return (int)sw_low[m & 3] + 8 * (m >> 2); };
+            (void)b_chunk;
             if constexpr (F16X1) {
                 // B quads arrive in GROUPS of four K-steps, double-buffered: wait for group g (an explicit lgkmcnt(0)), THEN
                 // issue the four reads of group g + 1, THEN run the four MFMAs of group g -- the reads fly under 128 cycles of
@@ -425,19 +447,19 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 constexpr int BG = 4;   // (8, and 16 = no overlap inside a product at all, measure the same: 5.84-5.88 ms at 1000 x 10 M)
                 u32x4 B[2][BG];
 #pragma unroll
-                for (int d = 0; d < BG; ++d) B[0][d] = bq[QS * (M0 + d)];
+                for (int d = 0; d < BG; ++d) B[0][d] = bq[b_chunk(M0 + d)];
 #pragma unroll
                 for (int g = 0; g < (M1 - M0) / BG; ++g) {
                     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt unconstrained: group g is in registers
                     if (g + 1 < (M1 - M0) / BG) {
 #pragma unroll
-                        for (int d = 0; d < BG; ++d) B[(g + 1) & 1][d] = bq[QS * (M0 + BG * (g + 1) + d)];
+                        for (int d = 0; d < BG; ++d) B[(g + 1) & 1][d] = bq[b_chunk(M0 + BG * (g + 1) + d)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int d = 0; d < BG; ++d) {
                         const int m = M0 + BG * g + d;
-                        if ((m - M0) % STAGE_EVERY == 0 && (m - M0) / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, (m - M0) / STAGE_EVERY);
+                        if ((m - M0) % STAGE_EVERY == 0 && (m - M0) / STAGE_EVERY < STAGE_N && stage) stage_row(stage_qt, stage_slot, (m - M0) / STAGE_EVERY);
                         if (m == M_CONSTS && stage) stage_consts(stage_qt, stage_slot);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[m]), __builtin_bit_cast(f16x8, B[g & 1][d]), acc, 0, 0, 0);
                     }
@@ -459,7 +481,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                         bh[(m - M0 + BD) % NB] = bq[QS * (m + BD)];
                         bl[(m - M0 + BD) % NB] = bq[QS * (m + BD) + 1];
                     }
-                    if ((m - M0) % STAGE_EVERY == 0 && (m - M0) / STAGE_EVERY < STAGE_ROWS && stage) stage_row(stage_qt, stage_slot, (m - M0) / STAGE_EVERY);
+                    if ((m - M0) % STAGE_EVERY == 0 && (m - M0) / STAGE_EVERY < STAGE_N && stage) stage_row(stage_qt, stage_slot, (m - M0) / STAGE_EVERY);
                     if (m == M_CONSTS && stage) stage_consts(stage_qt, stage_slot);
                     if constexpr (F16X2) acc = mfma_f16x2(Ah[m], bh[(m - M0) % NB], bl[(m - M0) % NB], acc);
                     else acc = mfma_bf16x3(Ah[m], Al[m], bh[(m - M0) % NB], bl[(m - M0) % NB], acc);
@@ -512,7 +534,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 // for the tiles that are meant to stay in flight.  The LDS reads of this step were consumed by MFMAs.)
                 // At the border in front of position pos + 1 the tiles pos + 1 .. pos + GT must have landed; the younger ones,
                 // pos + GT + 1 .. pos + AHEAD, may still fly.
-                constexpr int FLY = (AHEAD - GT) * (STAGE_ROWS + 1);               // 10 (four slots, GT 1) / 20 (eight, GT 2)
+                constexpr int FLY = (AHEAD - GT) * (STAGE_N + 1);                  // 10 (four slots, GT 1) / 12 (eight, GT 2, pairs)
                 static_assert(FLY >= 0 && FLY < 64, "vmcnt is a 6-bit counter");
                 if ((pos + 1) % GT == 0 && !(SMT_RR_EXP & 4)) {   // block-uniform
                     __builtin_amdgcn_s_waitcnt(0x0F70 | (FLY & 15) | ((FLY >> 4) << 14));  // vmcnt(FLY), expcnt / lgkmcnt unconstrained
