@@ -181,7 +181,7 @@ constexpr int RR_QCONST = QT_ROWS * 8;            // per slot: (score threshold,
 constexpr int RR_CB_CAP = 208;                    // 208 x 8 B keys + 208 x 4 B queries = 2496 B <= RR_TBUF
 // Per nomination mode: how a query tile lies in LDS and how deep the ring is.  bf16 x 3 / f16 x 2 read a hi and a lo
 // quad per (K-step, half): 1 KiB per query (65-float4 rows), four slots.  f16 x 1 reads the hi quads only: its image is
-// COMPACT -- 512 B per query, rows UNPADDED and swizzled (chunk c of row j at c ^ (j & 7): conflict-free b128 reads, and two rows
+// COMPACT -- 512 B per query, rows UNPADDED and swizzled (chunk c of row j at c ^ (j & 15): conflict-free b128 reads, and two rows
 // are contiguous, so one full-wave LDS-DMA instruction stages a pair: gemm_rowreg.hip STAGE_N) -- so EIGHT slots fit
 // the same LDS: batches of up to 256 queries stay resident (no ring, no barrier), and a streamed batch has seven tiles
 // in flight or landed instead of three (a ring step is 16 MFMAs per wave now, half of f16 x 2's: three steps no longer

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     constexpr int STAGE_ROWS = QT_ROWS / WAVES;      // rows of a query tile each wave stages: 4
     // ... in this many DMA instructions: one per row (64 lanes x 16 B = a 1 KiB row), or -- f16 x 1, 512 B per query -- one per PAIR
     // of rows.  The pair form needs the two rows contiguous in LDS (LDS-DMA writes lane-linear), i.e. NO row padding: bank
-    // conflicts of the B reads are avoided by a swizzle instead -- the 16-B chunk c of row j sits at position c ^ (j & 7) of its
+    // conflicts of the B reads are avoided by a swizzle instead -- the 16-B chunk c of row j sits at position c ^ (j & 15) of its
     // row, applied to the SOURCE address of the DMA and to the read (an involution on both sides, as in gemm_ldsrow_kernel).
     // Measured before (half-wave DMAs, one per row, padded rows): the staging instructions cost 0.73 of 5.9 ms at 1000 x 10 M;
     // two full-wave DMAs in their place: -0.37 ms.
@@ -247,16 +247,16 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint32_t row_in_tile = (uint32_t)(wave * STAGE_ROWS + 2 * u + (lane >> 5));
-        pair_src[u] = (uint32_t)(lane >> 5) * QUERY_WORDS + ((((uint32_t)lane & 31u) ^ (row_in_tile & 7u)) << 2);
+        pair_src[u] = (uint32_t)(lane >> 5) * QUERY_WORDS + ((((uint32_t)lane & 31u) ^ (row_in_tile & 15u)) << 2);
     }
-    uint32_t sw_low[4];   // f16 x 1: position of this lane's chunk of K-step m in its row, m mod 4
+    uint32_t sw_low[8];   // f16 x 1: position of this lane's chunk of K-step m in its row, m mod 8
 #pragma unroll
-    for (int mm = 0; mm < 4; ++mm) sw_low[mm] = (uint32_t)((2 * mm + h) ^ (j & 7));
+    for (int mm = 0; mm < 8; ++mm) sw_low[mm] = (uint32_t)((2 * mm + h) ^ (j & 15));
     auto stage_row = [&](uint32_t qt, int slot, int u) __attribute__((always_inline)) {
         const int r = wave * STAGE_ROWS + (F16X1 ? 2 * u : u);  // wave-uniform (f16 x 1: the first row of pair u)
         const uint32_t q = qt * QT_ROWS + r;
         f32x4 *dst = s_q + slot * SLOT_F4 + r * ROW_F4;
-        if constexpr (F16X1) {   // rows r, r + 1: lane l carries chunk (l & 31) ^ (row & 7) of row r + (l >> 5) to position l & 31
+        if constexpr (F16X1) {   // rows r, r + 1: lane l carries chunk (l & 31) ^ (row & 15) of row r + (l >> 5) to position l & 31
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(p.queries_split) + (size_t)q * QUERY_WORDS + pair_src[u & 1],
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         } else {
@@ -438,9 +438,10 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             constexpr int QS = F16X1 ? 2 : 4;   // quads per K-step in a query row
             const u32x4 *bq = reinterpret_cast<const u32x4 *>(s_q + slot * SLOT_F4 + j * ROW_F4) + (F16X1 ? 0 : 2 * h);
             const int M_CONSTS = M0 + (M1 - M0 > STAGE_EVERY * STAGE_N ? STAGE_EVERY * STAGE_N : M1 - M0 - 1);
-            // f16 x 1: chunk 2m + h of row j sits at position (2m + h) ^ (j & 7): the low three bits are lane-dependent (four values
-            // per lane, m mod 4), the rest is the constant 8 (m >> 2)
-            auto b_chunk = [&](int m) __attribute__((always_inline)) { return (int)sw_low[m & 3] + 8 * (m >> 2); };
+            // f16 x 1: chunk 2m + h of row j sits at position (2m + h) ^ (j & 15): the low four bits are lane-dependent (eight values
+            // per lane, m mod 8), the rest is the constant 16 (m >> 3).  (SIXTEEN lanes of a ds_read_b128 must fall into different
+            // 16-byte bank groups: with c ^ (j & 7) the counters showed one conflict cycle per read cycle.)
+            auto b_chunk = [&](int m) __attribute__((always_inline)) { return (int)sw_low[m & 7] + 16 * (m >> 3); };
             (void)b_chunk;
             if constexpr (F16X1) {
                 // B quads arrive in GROUPS of four K-steps, double-buffered: wait for group g (an explicit lgkmcnt(0)), THEN
