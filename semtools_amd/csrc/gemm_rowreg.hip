@@ -268,9 +268,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     // place) so that all waves count the same number of DMA instructions per tile -- the vmcnt arithmetic below.  (Measured
     // alternatives, 1000 x 10 M with the image: wave 0 alone issues it, with its own vmcnt count: 5.33 -> 5.58 ms -- the one wave
     // with more to do is the one the ring barrier waits for; the pairs of ALL tiles loaded once per launch into the 10 KiB of LDS
-    // that are left: no better, 5.55 on a box that ran the unchanged 2000-query case 2 % slower.).  (Issued by
-    // wave 0 alone, with its own vmcnt count, it measured SLOWER -- 1000 x 10 M 5.33 -> 5.58 ms: the one wave with more to do
-    // is the one the ring barrier waits for.)
+    // that are left: no better, 5.55 on a box that ran the unchanged 2000-query case 2 % slower.)
     auto stage_consts = [&](uint32_t qt, int slot) __attribute__((always_inline)) {
         __builtin_amdgcn_global_load_lds(p.qconst + (size_t)qt * QT_ROWS * 2 + lane,
                                          (__attribute__((address_space(3))) void *)(s_qconst + slot * RR_QCONST), 4, 0, 0);
