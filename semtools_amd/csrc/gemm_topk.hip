@@ -103,7 +103,10 @@ __global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, ui
     *reinterpret_cast<u32x2 *>(out + (size_t)q * 128 + 2 * lane) = (u32x2){f16_pack2(v.x * s, v.y * s), f16_pack2(v.z * s, v.w * s)};
 }
 
-__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst, int f16x2)
+// (also the per-batch resets when `counts` is given: counts / overflow flags to 0, tau to +inf -- one launch instead of three at
+// the head of a call whose GPU is idle and waits out every launch latency: ~20 us of a 0.9 ms call)
+__global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst, int f16x2,
+                                    unsigned int *counts = nullptr, unsigned int *overflow = nullptr, float *tau = nullptr)
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -118,6 +121,10 @@ __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t 
     if (lane == 0) {
         qconst[2 * q] = score_threshold(q < nq ? __builtin_inff() : -1.0f, rq);  // padding: zero query, tau < 0 -> never passes
         qconst[2 * q + 1] = rq;
+        if (counts) {
+            tau[q] = __builtin_inff();
+            if (q < nq) { counts[q] = 0; overflow[q] = 0; }
+        }
     }
 }
 
@@ -343,11 +350,13 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                            nqt * QT_ROWS, q_split);
     if (rowreg)
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, qconst, (f16x2 || f16x1) ? 1 : 0);
+                           nqt * QT_ROWS, qconst, (f16x2 || f16x1) ? 1 : 0, counts, overflow, tau);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
-    SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
-    hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
-                       __builtin_inff(), nqt * QT_ROWS);
+    if (!rowreg) {
+        SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
+                           __builtin_inff(), nqt * QT_ROWS);
+    }
 
     // level plan: strides ratio^(L-1) ... ratio, 1 with level 0 <= LEVEL0_MAX_TILES tiles
     const int LEVEL_RATIO = kp <= LEVEL_RATIO_KP_LIMIT ? LEVEL_RATIO_SMALL_K : LEVEL_RATIO_LARGE_K;

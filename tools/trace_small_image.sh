@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # kernel timeline of ONE 1-query / 8-query call over the operand image (10 M rows): durations and the gaps between launches
 root="$(pwd)"; out="$root/gpurun_out"; cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$out/trace_small" -o t -- python "$root/tools/bench_small_batch.py" --nq 1 8 --reps 2 --prepack > "$out/trace_small.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$out/trace_small" -o t -- python "$root/tools/image_scan_probe.py" > "$out/trace_small.log" 2>&1
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("$out/trace_small/t_kernel_trace.csv")))
