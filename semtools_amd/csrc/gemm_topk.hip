@@ -68,9 +68,29 @@ __global__ void split_queries_kernel(const float *queries, uint32_t nq, uint32_t
     row[4] = lo;
 }
 
+// What the head of a row-register batch sets up per query besides the split image: (score threshold, 1/|q|) -- for the fp16 modes the
+// operands are unit vectors times 2^10 and 2^8, so 1/|q| becomes the inverse of that scale -- and the resets (nomination count and
+// overflow flag 0, tau +inf).  Riding in the split kernel it is ONE launch at the head of a call instead of four: the GPU is idle
+// there and waits out every launch latency (~10 us apiece of a 0.9 ms call).
+struct BatchHead {
+    float *qconst;          // [nq_pad][2], or nullptr: nothing but the image
+    unsigned int *counts, *overflow;
+    float *tau;
+};
+__device__ __forceinline__ void batch_head_f16(const BatchHead &b, uint32_t q, uint32_t nq, float a2, int lane)
+{
+    if (b.qconst && lane == 0) {
+        const float rq = a2 == 0.0f ? 0.0f : F16X2_INV_SCALE;
+        b.qconst[2 * q] = score_threshold(q < nq ? __builtin_inff() : -1.0f, q < nq ? rq : 0.0f);  // padding: zero query, tau < 0
+        b.qconst[2 * q + 1] = q < nq ? rq : 0.0f;
+        b.tau[q] = __builtin_inff();
+        if (q < nq) { b.counts[q] = 0; b.overflow[q] = 0; }
+    }
+}
+
 // The f16 x 2 image of the queries (same row layout: K-step m, half h -> 16 B of hi, 16 B of lo): the UNIT query times
 // 2^8, split into two fp16 parts.  One wave per query (the norm is needed first).
-__global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out)
+__global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out, BatchHead head = {})
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -86,10 +106,11 @@ __global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint
     uint32_t *row = out + (size_t)q * 256 + (lane >> 1) * 8 + 2 * (lane & 1);   // pair pr -> word (pr >> 2) * 8 + (pr & 3)
     *reinterpret_cast<u32x2 *>(row) = (u32x2){h0, h1};
     *reinterpret_cast<u32x2 *>(row + 4) = (u32x2){l0, l1};
+    batch_head_f16(head, q, nq, a2, lane);
 }
 
 // The f16 x 1 image: the hi halves only, 512 B per query -- (K-step m, half h) -> 16 B at word 8 m + 4 h.
-__global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out)
+__global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out, BatchHead head = {})
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -101,6 +122,7 @@ __global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, ui
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     // lane holds dims 4 lane .. 4 lane + 3 = pairs 2 lane, 2 lane + 1 -> words 2 lane, 2 lane + 1 of the 128
     *reinterpret_cast<u32x2 *>(out + (size_t)q * 128 + 2 * lane) = (u32x2){f16_pack2(v.x * s, v.y * s), f16_pack2(v.z * s, v.w * s)};
+    batch_head_f16(head, q, nq, a2, lane);
 }
 
 // (also the per-batch resets when `counts` is given: counts / overflow flags to 0, tau to +inf -- one launch instead of three at
@@ -339,18 +361,19 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     float *qconst = tau + (size_t)nqt * QT_ROWS;   // [nqt*32][2]
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
+    const BatchHead head{qconst, counts, overflow, tau};   // (fp16 modes are row-register modes)
     if (f16x1)
         hipLaunchKernelGGL(split_queries_f16x1_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, q_split);
+                           nqt * QT_ROWS, q_split, head);
     else if (f16x2)
         hipLaunchKernelGGL(split_queries_f16_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, q_split);
+                           nqt * QT_ROWS, q_split, head);
     else if (bf16)
         hipLaunchKernelGGL(split_queries_kernel, dim3(nqt * QT_ROWS / 2), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, q_split);
-    if (rowreg)
+    if (rowreg && !(f16x1 || f16x2))   // bf16 x 3: its split kernel has no wave per query
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, qconst, (f16x2 || f16x1) ? 1 : 0, counts, overflow, tau);
+                           nqt * QT_ROWS, qconst, 0, counts, overflow, tau);
     if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     if (!rowreg) {
         SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
