@@ -71,7 +71,7 @@ def test_c3_thousand_queries_ten_million_rows_in_the_default_mode(gpu_ctx):
     gpu_ctx.uncertain_count()
     gpu_ctx.prof_enable(True)
     gpu_ctx.prof_reset()
-    c.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())      # K3, nominated with f16 x 2
+    c.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())      # K3, nominated with f16 x 1 (the default from 256 queries)
     torch.cuda.synchronize()
     launches, _ = gpu_ctx.prof_read("gemm")
     gpu_ctx.prof_enable(False)
