@@ -153,7 +153,15 @@ int corpus_reserve(smt_corpus *c, uint64_t rows_needed)
     float *nd = nullptr;
     const size_t bytes = (size_t)cap * c->dim * sizeof(float);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&nd), bytes);
-    if (e != hipSuccess) { set_error("hipMalloc(%zu) for corpus rows: %s", bytes, hipGetErrorString(e)); return SMT_E_NOMEM; }
+    if (e != hipSuccess && c->image) {
+        // the operand image is derived data (up to as many bytes as the rows): the rows' growth goes first.  A later batch builds
+        // it again if there is room then (image_mode stays "by policy").
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(c->ctx->stream);
+        corpus_image_drop(c);
+        e = hipMalloc(reinterpret_cast<void **>(&nd), bytes);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu) for corpus rows: %s", bytes, hipGetErrorString(e)); return SMT_E_NOMEM; }
     if (c->rows) {
         e = hipMemcpyAsync(nd, c->d_rows, (size_t)c->rows * c->dim * sizeof(float), hipMemcpyDeviceToDevice, c->ctx->stream);
         if (e != hipSuccess) { (void)hipFree(nd); set_error("corpus grow copy: %s", hipGetErrorString(e)); return SMT_E_HIP; }
@@ -202,9 +210,15 @@ int corpus_image_sync(smt_corpus *c, uint32_t nq, const void **image, const uint
         }
         const uint64_t keep = c->image ? c->image_rows / 32 : 0;   // whole tiles that stay valid
         if (keep) {
-            SMT_HIP_CHECK(hipMemcpyAsync(ni, c->image, (size_t)keep * 16384, hipMemcpyDeviceToDevice, c->ctx->stream));
-            SMT_HIP_CHECK(hipMemcpyAsync(nz, c->image_zero, (size_t)keep * 4, hipMemcpyDeviceToDevice, c->ctx->stream));
-            SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+            hipError_t e = hipMemcpyAsync(ni, c->image, (size_t)keep * 16384, hipMemcpyDeviceToDevice, c->ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(nz, c->image_zero, (size_t)keep * 4, hipMemcpyDeviceToDevice, c->ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+            if (e != hipSuccess) {
+                (void)hipFree(ni);
+                (void)hipFree(nz);
+                set_error("operand image grow copy: %s", hipGetErrorString(e));
+                return SMT_E_HIP;
+            }
         }
         const uint64_t had = c->image_rows;
         corpus_image_drop(c);

@@ -178,6 +178,8 @@ struct ScanArgs {
     uint32_t n_ranges;
     uint64_t n_virtual;       // rows to scan (sum of ranges, or rows)
     uint64_t n_chunks;        // with ranges: total chunks = range_chunk_prefix[n_ranges]
+    const uint64_t *range_tile_prefix = nullptr;  // device exclusive prefix of the aligned 32-row tiles each range is the FIRST to touch [n_ranges+1]
+    uint64_t n_vtiles = 0;    // with ranges: tiles holding at least one wanted row = range_tile_prefix[n_ranges]
     int ws_threshold;         // 1: apply score > thr_score (f32) in the final stage
     float ws_thr_score;
     uint64_t row_base;
@@ -199,6 +201,12 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
 constexpr int FILTER_CHUNK = 4;
 int launch_build_chunk_table(smt_ctx *ctx, const smt_range *ranges, const uint64_t *chunk_prefix, uint32_t n_ranges,
                              uint64_t n_chunks, uint64_t *table);
+// ... and, for gemm_rowreg_kernel, the aligned 32-row tiles they touch: tile | row mask << 32 per tile (scan_kernels.hip)
+int launch_build_tile_table(smt_ctx *ctx, const smt_range *ranges, const uint64_t *tile_prefix, uint32_t n_ranges, uint64_t n_vtiles,
+                            uint64_t *table);
+// A filtered batch takes gemm_rowreg_kernel (and the operand image) when the wanted rows fill at least a quarter of the tiles they
+// touch; sparser subsets (documents of a few lines, every tenth one wanted) keep the LDS-row kernel, which gathers 4-row chunks.
+inline bool tiles_dense(uint64_t n_virtual, uint64_t n_vtiles) { return n_vtiles > 0 && n_vtiles * 32 <= 4 * n_virtual; }
 
 // K4 (threshold.hip): every row with distance < max_distance, ordered (distance asc, row asc).
 // Returns pointers into the context's pinned staging buffer, valid until the next call on the context.

@@ -46,6 +46,9 @@ struct GemmParams {
     // chunk table (scan_kernels.hip: row0 | valid rows << 32); a "tile" is then 8 consecutive chunks
     const uint64_t *chunk_table;
     uint64_t n_chunks;
+    // range-filtered batches of gemm_rowreg_kernel: the level's tiles are the ENTRIES of this table (aligned 32-row tile | mask of the
+    // wanted rows << 32, build_tile_table_kernel) instead of the tiles themselves; nullptr = every tile, every row
+    const uint64_t *tile_table = nullptr;
     const void *image;            // gemm_rowreg_kernel<MODE, true>: the corpus' fp16 operand image (16 KiB per 32-row tile) ...
     const uint32_t *image_zero;   // ... and per tile the mask of its zero rows
     int buffered;                 // gemm_rowreg_kernel: nominations go through the wave's LDS buffer (every level but the first)

@@ -305,7 +305,15 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
     uint32_t n_buf = 0;          // nominations waiting in this wave's LDS buffer (wave-uniform)
     for (uint64_t step = 0; step < steps; ++step, it += W) {
         const bool has = it < p.level_tiles;  // wave-uniform
-        const uint64_t row0 = (has ? level_tile(it, p.stride, p.skip16) : 0) * 32;
+        // (range-filtered: the level walks the tile table; the entry names the tile and which of its rows are wanted -- one scalar load)
+        uint64_t tile_v = has ? level_tile(it, p.stride, p.skip16) : 0;
+        uint32_t want32 = 0xffffffffu;
+        if (p.tile_table != nullptr && has) {
+            const uint64_t e = p.tile_table[tile_v];
+            tile_v = e & 0xffffffffull;
+            want32 = (uint32_t)(e >> 32);
+        }
+        const uint64_t row0 = tile_v * 32;
 #if (SMT_RR_EXP & 256)
         const bool tracing = p.stamps != nullptr && blockIdx.x == 40 && step == 1 && p.level_tiles > 100000;
 #endif
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         zero16 |= ((zm >> (8 * u + c)) & 1u) << (4 * u + c);
-                        if (row0 + 8 * u + c + 4 * h < p.n_rows) valid16 |= 1u << (4 * u + c);
+                        if (row0 + 8 * u + c + 4 * h < p.n_rows && ((want32 >> (8 * u + c + 4 * h)) & 1u)) valid16 |= 1u << (4 * u + c);
                     }
             }
         } else
@@ -423,7 +431,7 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     zero16 |= ((w >> (8 * c)) & 1u) << (4 * u + c);
-                    if (row0 + 8 * u + c + 4 * h < p.n_rows) valid16 |= 1u << (4 * u + c);
+                    if (row0 + 8 * u + c + 4 * h < p.n_rows && ((want32 >> (8 * u + c + 4 * h)) & 1u)) valid16 |= 1u << (4 * u + c);
                 }
             }
         }

@@ -296,7 +296,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // stream the query tiles through LDS (gemm_level_kernel), one sweep over the corpus for up to 3584 queries.
     // bf16 x 3 (the default): gemm_rowreg_kernel takes every unfiltered batch; range-filtered batches keep the LDS-row
     // kernel (its chunk table gathers the rows).  f32 MFMA (gemm_bf16x3 = 0): the round-1/2 routing below.
-    const bool rowreg = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && !filtered;
+    // ... and the range-filtered ones whose rows fill the aligned 32-row tiles they touch well enough (tiles_dense, common.h): the
+    // kernel then walks a TILE TABLE (tile | row mask, build_tile_table_kernel) instead of all tiles -- the unit of the fp16 operand
+    // image, so a workspace search over a subset of documents (src/workspace/store.rs:507-515) gets the image and the fp16 modes too.
+    const bool rowreg = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg &&
+                        (!filtered || (a.range_tile_prefix != nullptr && tiles_dense(a.n_virtual, a.n_vtiles)));
     // How gemm_rowreg_kernel nominates (tuning key gemm_nominate: 0 auto, 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1).  The fp16 modes
     // issue 2/3 resp. 1/3 of the MFMAs of bf16 x 3 -- what large batches are bound by -- for a wider certificate band
     // (5.2e-4 / 1.0e-3 against 7e-5): auto takes f16 x 2 from 128 queries and f16 x 1 from 256 queries on shards of at most
@@ -312,9 +316,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const bool have_image = a.image != nullptr && rowreg && ctx->tune.gemm_image != 0;
     // (measured with the image, 10 M rows, ms: 128 queries f16 x 1 1.16 / f16 x 2 1.32; 192: 1.23 / 2.09 -- six tiles no longer
     // fit the four slots of the 1 KiB query image; <= 96: equal)
+    // (every automatic fp16 choice needs room for its guard band in the 64-entry lists -- k + 24 resp. k + 16 -- or most queries
+    // would fail their certificate and be re-answered exhaustively: bf16 x 3 then)
     const bool f16x1 = rowreg && (ctx->tune.gemm_nominate == 3 ||
                                   (auto_fp16 && (nqt >= 8 || (have_image && nqt >= 4)) && a.k_out + 24 <= 64));
-    const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && (nqt >= 4 || (have_image && a.k_out + 16 <= 64))));
+    const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && (nqt >= 4 || have_image) && a.k_out + 16 <= 64));
     const bool use_image = have_image && (f16x1 || f16x2);
     // guard band, see candidates_per_list (scan_kernels.hip): the wider the certificate band, the more rows are nominated
     // (the proof needs the k-th exact distance to lie 2 x the band below the worst nominated one): 8 / 16 / 24
@@ -347,7 +353,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const size_t b_cand = (size_t)a.nq * CAND_CAP * sizeof(key_t64);
     const size_t b_cnt = (((size_t)a.nq * 4) + 15) & ~(size_t)15;
     const size_t b_tau = (size_t)nqt * QT_ROWS * 4;
-    const uint64_t n_chunks = filtered ? a.n_chunks : 0;
+    const uint64_t n_chunks = !filtered ? 0 : rowreg ? a.n_vtiles : a.n_chunks;   // entries of the chunk resp. tile table
     const size_t b_split = bf16 ? (size_t)nqt * QT_ROWS * 1024 : 0;
     const size_t o_split = (b_cand + 2 * b_cnt + 3 * b_tau + 255) & ~(size_t)255;  // tau | thr | rq
     const size_t b_head = o_split + b_split;
@@ -374,7 +380,9 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (rowreg && !(f16x1 || f16x2))   // bf16 x 3: its split kernel has no wave per query
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, qconst, 0, counts, overflow, tau);
-    if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
+    if (filtered && rowreg) {
+        if ((rc = launch_build_tile_table(ctx, a.ranges, a.range_tile_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
+    } else if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     if (!rowreg) {
         SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
         hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -383,7 +391,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
 
     // level plan: strides ratio^(L-1) ... ratio, 1 with level 0 <= LEVEL0_MAX_TILES tiles
     const int LEVEL_RATIO = kp <= LEVEL_RATIO_KP_LIMIT ? LEVEL_RATIO_SMALL_K : LEVEL_RATIO_LARGE_K;
-    const uint64_t n_tiles = filtered ? (n_chunks + 7) / 8 : (a.rows + 31) / 32;  // filtered: a tile = 8 chunks of <= 4 rows
+    // filtered: the entries of the tile table (row-register kernel), or 8 chunks of <= 4 rows each (LDS-row kernel)
+    const uint64_t n_tiles = !filtered ? (a.rows + 31) / 32 : rowreg ? n_chunks : (n_chunks + 7) / 8;
     int L = 1;
     uint64_t s0 = 1;
     while ((n_tiles + s0 - 1) / s0 > (uint64_t)LEVEL0_MAX_TILES) { s0 *= LEVEL_RATIO; ++L; }
@@ -409,7 +418,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.qconst = qconst;
         g.cand = cand;
         g.counts = counts;
-        g.chunk_table = filtered ? chunk_table : nullptr;
+        g.chunk_table = filtered && !rowreg ? chunk_table : nullptr;
+        g.tile_table = filtered && rowreg ? chunk_table : nullptr;
         g.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
         g.buffered = lev > 0 && ctx->tune.gemm_buffered != 0;
         g.image = use_image ? a.image : nullptr;
@@ -585,6 +595,7 @@ int launch_gemm_threshold(smt_ctx *ctx, const float *corpus, uint64_t rows, cons
     g.cand = cand;
     g.counts = counts;
     g.chunk_table = nullptr;
+    g.tile_table = nullptr;
     g.stamps = nullptr;
     g.buffered = 0;
     g.image = image;

@@ -770,14 +770,22 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
         const float thr_score = 1.0f - (float)max_distance;  // store.rs:502-503
         int local_rc = SMT_OK;
         std::string local_err;
+        // Pinned staging per local device: [queries][status word] (+ device 0: the merged lists and every rank's flags).  The
+        // loop below only ENQUEUES -- upload, scan, select, status -- so that the shards of a one-process group scan
+        // concurrently (a stack status word forced a stream sync per device, i.e. the SUM of the shard times).
+        const size_t flag_words = (size_t)g->n_ranks * (nq + 1);
+        const size_t pin_status_off = q_bytes, pin_res_off = q_bytes + 64;
         for (int i = 0; i < g->n_local; ++i) {
             const int r = g->first_rank + i;
             if ((rc = group_bind(g, i))) return rc;
             if ((rc = ensure_dev(g, i, dev_bytes))) return rc;   // (no exchange buffer: nothing to report through)
+            if ((rc = ensure_host(g, i, pin_res_off + (i == 0 ? (list_words + flag_words) * 8 : 0)))) return rc;
             char *base = reinterpret_cast<char *>(g->buf[i].dev);
+            char *pin = reinterpret_cast<char *>(g->buf[i].pinned);
             uint64_t *loc = reinterpret_cast<uint64_t *>(base + loc_off);
             const int stage_rc = [&]() -> int {
-                SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
+                memcpy(pin, queries, (size_t)nq * SMT_DIM * 4);
+                SMT_HIP_CHECK(hipMemcpyAsync(base, pin, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
                 std::vector<smt_range> lr;
                 if (n_ranges) layout_localize(sc, r, ranges, n_ranges, lr);
                 int rc2 = search_topk_packed_local(sc->shard[i], reinterpret_cast<const float *>(base), nq, K, ws, thr_score, lr.data(),
@@ -787,9 +795,9 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
                 return rc2;
             }();
             if (stage_rc && !local_rc) { local_rc = stage_rc; local_err = smt_last_error(); }
-            const uint64_t status = (uint64_t)(uint32_t)(stage_rc < 0 ? -stage_rc : stage_rc);
-            SMT_HIP_CHECK(hipMemcpyAsync(loc + list_words + nq, &status, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
-            SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->stream));   // (`status` is a stack word)
+            uint64_t *status = reinterpret_cast<uint64_t *>(pin + pin_status_off);   // lives in the pinned buffer until group_sync_all
+            *status = (uint64_t)(uint32_t)(stage_rc < 0 ? -stage_rc : stage_rc);
+            SMT_HIP_CHECK(hipMemcpyAsync(loc + list_words + nq, status, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
         }
         if ((rc = allgather_words(g, loc_off, gath_off, rank_words))) return rc;
         // the caller is one host thread and needs ONE copy of the answer: merge on local device 0
@@ -798,9 +806,7 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
         uint64_t *gath = reinterpret_cast<uint64_t *>(base0 + gath_off), *merged = reinterpret_cast<uint64_t *>(base0 + out_off);
         if (!local_rc && (rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, gath, (uint32_t)g->n_ranks, nq, K, K, merged, rank_words)))
             return rc;
-        const size_t flag_words = (size_t)g->n_ranks * (nq + 1);
-        if ((rc = ensure_host(g, 0, (list_words + flag_words) * 8))) return rc;
-        uint64_t *h = reinterpret_cast<uint64_t *>(g->buf[0].pinned);
+        uint64_t *h = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->buf[0].pinned) + pin_res_off);
         if (!local_rc) SMT_HIP_CHECK(hipMemcpyAsync(h, merged, list_words * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
         for (int r = 0; r < g->n_ranks; ++r)  // every rank's flags + status: all processes take the same decisions
             SMT_HIP_CHECK(hipMemcpyAsync(h + list_words + (size_t)r * (nq + 1), gath + (size_t)r * rank_words + list_words, (size_t)(nq + 1) * 8,

@@ -38,9 +38,10 @@ __device__ __forceinline__ f32x16 mfma_tile_32x32x256(const f32x4 (&A)[32], cons
 // lo = bf16(x - hi): x - hi is exact in f32, so |x - hi - lo| <= 2^-16 |x|.  x . q  ~=  xh.qh + xl.qh + xh.ql  (three
 // MFMAs into ONE f32 accumulator; the products of bf16 pairs are exact in f32).  Dropped: xl.ql (<= 2^-8 * 2^-8) and
 // the two residual terms, each <= 2^-16 sum |x_i q_i| <= 2^-16 |x||q| (Cauchy-Schwarz) => <= 3 * 2^-16 |x||q| =
-// 4.6e-5 |x||q|; accumulating 768 products in f32 adds at most 768 * 2^-24 * (1 + 2^-7) |x||q| = 4.6e-5 |x||q| with
-// round-to-nearest adds.  common.h: F32_ERR_BF16X3 = 1.5e-4 (the accumulation part counted twice: the MFMA's internal
-// adder tree is not documented to round to nearest).  Measured maximum on adversarial rows: 1.0e-5.  The scores only
+// 4.6e-5 |x||q|; the accumulation was MEASURED (tools/micro/mfma_rounding.hip, profiles/r03_mfma_rounding.json): a 16-bit MFMA
+// forms its 16 products exactly and rounds their sum into the accumulator ONCE, <= 2 ulp per instruction -- 48 instructions
+// add <= 1.1e-5.  common.h: F32_ERR_BF16X3 = 7e-5 (5.8e-5 derived + margin; the rounding property is re-checked on the device by
+// tests/test_gpu_batched.py).  Constructed worst case: 2.6e-5; random corpora: 1.0e-5.  The scores only
 // NOMINATE candidates; final distances are recomputed exactly (f64) and the certificate of section 5 of DESIGN.md uses
 // this bound.
 // Operand layout: lane (j, h) feeds row / query j with dims 16m + 8h .. + 7 of K-step m (8 bf16 = 4 VGPRs), the same
@@ -83,8 +84,8 @@ __device__ __forceinline__ f32x16 mfma_bf16x3(const u32x4 &ah, const u32x4 &al, 
 
 // ---- f16 x 2: one fp16 operand for the rows, hi + lo fp16 for the queries -- TWO MFMAs per 16 dims instead of three.
 // fp16 keeps 11 significant bits: a row element rounds with relative error <= 2^-11, so the score is off by at most
-// 2^-11 |x||q| = 4.9e-4 (the query, hi + lo, carries 22 bits: its residual is noise next to that); 512 f32 accumulations
-// add <= 3e-5 (counted twice: 6e-5).  common.h: F32_ERR_F16X2 = 6e-4, four times the bf16 x 3 bound -- the price of a
+// 2^-11 |x||q| = 4.9e-4 (the query, hi + lo, carries 22 bits: its residual is noise next to that); 32 instructions x 2 ulp
+// (measured, see above) add <= 7.6e-6.  common.h: F32_ERR_F16X2 = 5.2e-4, seven times the bf16 x 3 bound -- the price of a
 // third fewer MFMAs, which is what the part's power budget is spent on in large batches.  Scaling keeps everything away
 // from fp16's subnormals: unit rows are multiplied by 2^10, unit queries by 2^8 (an element would have to be below
 // 6e-8 resp. 2.4e-7 to be flushed); the accumulator then holds 2^18 cos, which the query's constant 1/|q| := 2^-18 undoes.

@@ -90,6 +90,43 @@ int launch_build_chunk_table(smt_ctx *ctx, const smt_range *ranges, const uint64
     return SMT_OK;
 }
 
+// The same filter for the MFMA kernel (gemm_rowreg_kernel), whose unit is the ALIGNED 32-row tile -- the unit of the corpus' fp16
+// operand image: one descriptor per tile that holds at least one wanted row, tile index | row mask << 32.  Ranges that meet
+// inside a tile share its descriptor (tile_prefix counts a tile for the first range that touches it: search.cpp stage_ranges),
+// so no tile is read twice however small the documents are.
+__global__ void build_tile_table_kernel(const smt_range *ranges, const uint64_t *tile_prefix, uint32_t n_ranges, uint64_t n_vtiles,
+                                        uint64_t *table)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vtiles) return;
+    uint32_t lo = 0, hi = n_ranges;  // first range i with tile_prefix[i + 1] > v (ranges that own no tile are skipped)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile_prefix[mid + 1] > v) hi = mid; else lo = mid + 1;
+    }
+    const uint32_t i = lo;
+    const uint64_t first = ranges[i].begin >> 5;
+    const bool shared = i > 0 && ((ranges[i - 1].end - 1) >> 5) == first;   // (empty ranges were dropped by the host)
+    const uint64_t tile = first + (shared ? 1 : 0) + (v - tile_prefix[i]);
+    const uint64_t t0 = tile << 5, t1 = t0 + 32;
+    uint32_t mask = 0;
+    for (uint32_t k = i; k < n_ranges && ranges[k].begin < t1; ++k) {
+        const uint64_t b = ranges[k].begin > t0 ? ranges[k].begin : t0, e = ranges[k].end < t1 ? ranges[k].end : t1;
+        if (e > b) mask |= (uint32_t)((~0ull >> (64 - (e - b))) << (b - t0));
+    }
+    table[v] = tile | ((uint64_t)mask << 32);
+}
+
+int launch_build_tile_table(smt_ctx *ctx, const smt_range *ranges, const uint64_t *tile_prefix, uint32_t n_ranges, uint64_t n_vtiles,
+                            uint64_t *table)
+{
+    if (n_vtiles == 0) return SMT_OK;
+    hipLaunchKernelGGL(build_tile_table_kernel, dim3((unsigned)((n_vtiles + 255) / 256)), dim3(256), 0, ctx->stream, ranges,
+                       tile_prefix, n_ranges, n_vtiles, table);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
 // ------------------------------------------------------------------------- K2
 template <int NQ, int U, bool NT, bool FILTERED>
 __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)

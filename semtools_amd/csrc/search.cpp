@@ -28,6 +28,25 @@ static int validate_ranges(const smt_range *ranges, uint32_t n, uint64_t rows, u
     return SMT_OK;
 }
 
+// The three exclusive prefixes a range-filtered search stages beside its ranges: rows before range i (large-k path), FILTER_CHUNK-row
+// chunks before it (K2 / K4 / the LDS-row kernel) and aligned 32-row tiles before it (gemm_rowreg_kernel: a tile counts for the
+// FIRST range that touches it).  host = [prefix | chunk_prefix | tile_prefix], each nr + 1 words.
+static void range_prefixes(const std::vector<smt_range> &rr, std::vector<uint64_t> &host)
+{
+    const size_t nr = rr.size();
+    host.assign(3 * (nr + 1), 0);
+    uint64_t *prefix = host.data(), *chunk_prefix = prefix + nr + 1, *tile_prefix = chunk_prefix + nr + 1;
+    uint64_t last_tile = UINT64_MAX;
+    for (size_t i = 0; i < nr; ++i) {
+        const uint64_t len = rr[i].end - rr[i].begin;
+        prefix[i + 1] = prefix[i] + len;
+        chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
+        const uint64_t ft = rr[i].begin >> 5, lt = (rr[i].end - 1) >> 5;
+        tile_prefix[i + 1] = tile_prefix[i] + (lt - ft + 1) - (ft == last_tile ? 1 : 0);
+        last_tile = lt;
+    }
+}
+
 // Exhaustive answer for ONE query whose f32 nomination failed its exactness certificate: K4 collects every row
 // whose exact distance is <= bound (its own f32 prefilter carries an 8e-6 guard band; rescoring is exact f64), in
 // (distance asc, row asc) order; the answer is the first k_eff of them (after the workspace score filter).
@@ -163,15 +182,19 @@ static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queri
 // => K3 from gemm_min_nq (3) queries on shards of gemm_min_rows_small (1 M) rows, from 2 queries on 4 x that.
 static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
 {
-    const bool fast_k3 = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && a.n_ranges == 0;
+    // (range-filtered calls whose rows fill their 32-row tiles well enough take the same kernel over a tile table -- tiles_dense,
+    // common.h -- and count with the rows they SCAN)
+    const bool fast_k3 = ctx->tune.gemm_bf16x3 && ctx->tune.gemm_rowreg && (a.n_ranges == 0 || tiles_dense(a.n_virtual, a.n_vtiles));
     const uint64_t small = (uint64_t)ctx->tune.gemm_min_rows_small;
+    const uint64_t scanned = a.n_virtual;
     // A corpus that HAS its fp16 operand image answers even one or two queries through the batched kernel once the shard is
     // large (tuning key image_scan_min_rows, 4 M): one pass over 512-B rows plus ~0.2 ms of levels and selects beats a scan
     // pass over 1 KiB rows -- 10 M rows: 0.95 against 1.5 ms; the scan kernel keeps the small shards and the async mode.
     // (A resident host asking one query at a time -- `semtools serve` -- never sends the batch of 8 that builds the image of an
     // owned corpus: the fourth small search of a shard this large builds it.)
-    const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && corpus->d_rows == a.corpus && corpus->rows == a.rows &&
-                            ctx->tune.image_scan_min_rows > 0 && a.rows >= (uint64_t)ctx->tune.image_scan_min_rows;
+    const bool whole = corpus->d_rows == a.corpus && corpus->rows == a.rows;
+    const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && whole &&
+                            ctx->tune.image_scan_min_rows > 0 && scanned >= (uint64_t)ctx->tune.image_scan_min_rows;
     if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&
         ++corpus->small_searches >= 4) {
         const void *img;
@@ -181,9 +204,9 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
         if (corpus->image_mode == 1) corpus->image_mode = 0;   // (-1 when there was no room)
     }
     const bool image_scan = scan_sized && corpus->image && corpus->image_mode >= 0;
-    const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && a.rows >= small) ||
-                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && a.rows >= 4 * small) || image_scan;
-    if (batched && a.n_ranges == 0 && corpus->d_rows == a.corpus && corpus->rows == a.rows) {
+    const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && scanned >= small) ||
+                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && scanned >= 4 * small) || image_scan;
+    if (batched && fast_k3 && whole) {
         if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
     }
     int rc = batched ? launch_gemm_topk(ctx, a) : launch_scan_topk(ctx, a);
@@ -224,8 +247,8 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     const size_t q_bytes = (size_t)nq * SMT_DIM * sizeof(float);
     const size_t r_bytes = (size_t)nr * sizeof(smt_range);
     const size_t p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
-    // one persistent staging buffer per context: [queries | ranges | prefix | result lists] (no per-call hipMalloc/hipFree)
-    const size_t in_bytes = (q_bytes + r_bytes + 2 * p_bytes + 255) & ~(size_t)255;
+    // one persistent staging buffer per context: [queries | ranges | 3 prefixes | result lists] (no per-call hipMalloc/hipFree)
+    const size_t in_bytes = (q_bytes + r_bytes + 3 * p_bytes + 255) & ~(size_t)255;
     const uint32_t k_stage = all_under_threshold ? 0u : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(top_k, n_virtual), 64);
     const size_t out_bytes_stage = (size_t)nq * k_stage * 16 + (size_t)2 * nq * sizeof(uint64_t);
     if ((rc = ensure_stage(ctx, in_bytes + out_bytes_stage + 64))) return rc;
@@ -233,21 +256,15 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     float *d_q = reinterpret_cast<float *>(stage);
     smt_range *d_r = reinterpret_cast<smt_range *>(stage + q_bytes);
     uint64_t *d_p = reinterpret_cast<uint64_t *>(stage + q_bytes + r_bytes);
-    uint64_t *d_cp = reinterpret_cast<uint64_t *>(stage + q_bytes + r_bytes + p_bytes);
+    uint64_t *d_cp = d_p + (nr + 1), *d_tp = d_cp + (nr + 1);
     SMT_HIP_CHECK(hipMemcpyAsync(d_q, queries, q_bytes, hipMemcpyHostToDevice, ctx->stream));
-    // prefix: rows before range i (large-k path); chunk_prefix: FILTER_CHUNK-row chunks before range i (K2/K4)
-    std::vector<uint64_t> prefix(nr + 1, 0), chunk_prefix(nr + 1, 0);
+    std::vector<uint64_t> prefixes;   // (lives until the synchronise that ends every path below)
+    range_prefixes(rr, prefixes);
     if (nr) {
-        for (uint32_t i = 0; i < nr; ++i) {
-            const uint64_t len = rr[i].end - rr[i].begin;
-            prefix[i + 1] = prefix[i] + len;
-            chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
-        }
         SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
-        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
-        SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefixes.data(), 3 * p_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    const uint64_t n_chunks = chunk_prefix[nr];
+    const uint64_t n_chunks = prefixes[2 * (nr + 1) - 1], n_vtiles = prefixes[3 * (nr + 1) - 1];
 
     if (!all_under_threshold) {
         // ---------------- top-k (optionally with the workspace score threshold)
@@ -314,6 +331,8 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
         a.range_prefix = nr ? d_p : nullptr;
         a.range_chunk_prefix = nr ? d_cp : nullptr;
         a.n_chunks = n_chunks;
+        a.range_tile_prefix = nr ? d_tp : nullptr;
+        a.n_vtiles = n_vtiles;
         a.n_ranges = nr;
         a.n_virtual = n_virtual;
         a.ws_threshold = (mode == SMT_MODE_WORKSPACE && has_thr) ? 1 : 0;
@@ -452,25 +471,22 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     }
     const uint32_t nr = (uint32_t)rr.size();
     smt_range *d_r = nullptr;
-    uint64_t *d_p = nullptr, *d_cp = nullptr;
-    uint64_t n_chunks = 0;
+    uint64_t *d_p = nullptr, *d_cp = nullptr, *d_tp = nullptr;
+    uint64_t n_chunks = 0, n_vtiles = 0;
     if (nr) {
         const size_t r_bytes = (size_t)nr * sizeof(smt_range), p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
-        if ((rc = ensure_stage(ctx, r_bytes + 2 * p_bytes + 64))) return rc;
+        if ((rc = ensure_stage(ctx, r_bytes + 3 * p_bytes + 64))) return rc;
         char *stage = reinterpret_cast<char *>(ctx->d_stage);
         d_r = reinterpret_cast<smt_range *>(stage);
         d_p = reinterpret_cast<uint64_t *>(stage + r_bytes);
-        d_cp = reinterpret_cast<uint64_t *>(stage + r_bytes + p_bytes);
-        std::vector<uint64_t> prefix(nr + 1, 0), chunk_prefix(nr + 1, 0);
-        for (uint32_t i = 0; i < nr; ++i) {
-            const uint64_t len = rr[i].end - rr[i].begin;
-            prefix[i + 1] = prefix[i] + len;
-            chunk_prefix[i + 1] = chunk_prefix[i] + (len + FILTER_CHUNK - 1) / FILTER_CHUNK;
-        }
-        n_chunks = chunk_prefix[nr];
+        d_cp = d_p + (nr + 1);
+        d_tp = d_cp + (nr + 1);
+        std::vector<uint64_t> prefixes;
+        range_prefixes(rr, prefixes);
+        n_chunks = prefixes[2 * (nr + 1) - 1];
+        n_vtiles = prefixes[3 * (nr + 1) - 1];
         SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
-        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
-        SMT_HIP_CHECK(hipMemcpyAsync(d_cp, chunk_prefix.data(), p_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SMT_HIP_CHECK(hipMemcpyAsync(d_p, prefixes.data(), 3 * p_bytes, hipMemcpyHostToDevice, ctx->stream));
         SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
     }
     ScanArgs a;
@@ -483,6 +499,8 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     a.range_prefix = d_p;
     a.range_chunk_prefix = d_cp;
     a.n_chunks = n_chunks;
+    a.range_tile_prefix = d_tp;
+    a.n_vtiles = n_vtiles;
     a.n_ranges = nr;
     a.n_virtual = n_virtual;
     a.ws_threshold = ws_threshold;

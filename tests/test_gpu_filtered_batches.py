@@ -1,0 +1,160 @@
+"""Range-filtered BATCHES (the workspace path-subset filter with several queries: src/workspace/store.rs:507-515 via
+src/search/mod.rs:211-213) on the row-register MFMA kernel: the kernel walks a tile table (aligned 32-row tile | mask of the wanted
+rows) instead of every tile, so filtered batches get the fp16 nomination modes and the corpus' operand image.  Bar: rows exactly the
+oracle's on the eligible rows, f64 distances bit-equal; identical with and without the image, with the round-2 LDS-row route
+(tuning key gemm_rowreg = 0) and with the single-query scan path."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_topk(emb, q, k):
+    res = orc.search_documents(emb, [len(emb)], q, n_lines=0, top_k=k, accurate=True)
+    return [r["match_line"] for r in res], [r["distance"] for r in res]
+
+
+def _docs(n_rows, sizes_seed, lo, hi):
+    """Cut [0, n_rows) into consecutive "documents" of lo..hi rows."""
+    rng = np.random.default_rng(sizes_seed)
+    out, b = [], 0
+    while b < n_rows:
+        e = min(n_rows, b + int(rng.integers(lo, hi + 1)))
+        out.append((b, e))
+        b = e
+    return out
+
+
+def _check(c, emb, qs, ranges, k, which=None):
+    elig = np.concatenate([np.arange(b, e) for b, e in ranges])
+    got = c.search(qs, top_k=k, ranges=ranges)
+    for i in (range(len(qs)) if which is None else which):
+        orows, odist = _oracle_topk(emb[elig], qs[i], k)
+        assert got[i][0].tolist() == elig[np.array(orows, dtype=np.int64)].tolist(), (k, i)
+        assert np.array_equal(got[i][1], np.array(odist)), (k, i)
+    return got
+
+
+@pytest.mark.parametrize("nq", [8, 40, 130, 300])
+@pytest.mark.parametrize("image", [False, True])
+def test_subset_of_small_documents_on_the_tile_table(gpu_ctx, nq, image):
+    """Documents of 3..60 lines, every second one wanted: almost every tile holds wanted and unwanted rows, ranges meet inside
+    tiles, the last document ends in a ragged tile.  8 / 40 queries nominate with bf16 x 3 (f16 x 2 with the image), 130 with
+    f16 x 2 (f16 x 1 with the image), 300 with f16 x 1."""
+    import semtools_amd as smt
+
+    n = 60_013
+    emb = synth.unit_rows(n, seed=31)
+    qs = synth.unit_query(32, nq=nq)
+    docs = _docs(n, 5, 3, 60)
+    ranges = docs[::2]
+    if ranges[-1] != docs[-1]:
+        ranges.append(docs[-1])            # the ragged end of the corpus is wanted
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    if image:
+        c.prepack()
+        assert c.image_bytes > 0
+    try:
+        for k in (1, 10):
+            got = _check(c, emb, qs, ranges, k, which=range(0, nq, max(1, nq // 12)))
+            # the single-query scan path over the same ranges
+            one = c.search(qs[1], top_k=k, ranges=ranges)[0]
+            assert got[1][0].tolist() == one[0].tolist() and np.array_equal(got[1][1], one[1])
+            # the LDS-row route over the chunk table (what filtered batches took before): identical lists
+            gpu_ctx.set_tuning("gemm_rowreg", 0)
+            try:
+                old = c.search(qs[:64], top_k=k, ranges=ranges)
+            finally:
+                gpu_ctx.set_tuning("gemm_rowreg", 1)
+            for a, b in zip(got[:64], old):
+                assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+    finally:
+        c.close()
+
+
+def test_tile_table_corner_cases(gpu_ctx):
+    """One-row ranges, ranges that share a tile with both neighbours, a range inside the previous range's last tile, ranges that
+    start / end exactly on tile borders, one range covering everything, a single row wanted in the whole corpus."""
+    import semtools_amd as smt
+
+    n = 4_100
+    emb = synth.unit_rows(n, seed=41)
+    emb[64] = 0.0                       # a zero row inside a wanted range
+    qs = synth.unit_query(42, nq=12)
+    qs[5] = 0.0                         # a zero query
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    cases = [
+        [(0, n)],
+        [(0, 32), (32, 64), (64, 96)],
+        [(5, 6), (7, 8), (9, 10), (31, 33), (33, 34), (63, 64), (64, 65), (100, 400)],
+        [(10, 40), (41, 42), (43, 50), (50, 63), (63, 64), (200, 1000), (1000, 1001), (4095, 4100)],
+        [(4099, 4100)],
+        [(31, 32)],
+        [(0, 1), (4096, 4100)],
+        [(1, 3000), (3001, 3002), (3003, 3004), (3010, 3040), (3050, 4000)],
+    ]
+    try:
+        for image in (False, True):
+            if image:
+                c.prepack()
+            for ranges in cases:
+                n_el = sum(e - b for b, e in ranges)
+                for k in (1, 7):
+                    _check(c, emb, qs, ranges, min(k, 56), which=None)
+                assert n_el > 0
+    finally:
+        c.close()
+
+
+def test_sparse_subsets_keep_the_chunk_route_and_agree(gpu_ctx):
+    """Every tenth 3-line document: the wanted rows fill < 1/4 of the tiles they touch -- the LDS-row kernel gathers 4-row chunks
+    instead (common.h tiles_dense).  Same contract."""
+    import semtools_amd as smt
+
+    n = 40_000
+    emb = synth.unit_rows(n, seed=51)
+    qs = synth.unit_query(52, nq=20)
+    ranges = [(b, b + 3) for b in range(0, n - 3, 30)]
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    try:
+        _check(c, emb, qs, ranges, 5)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("image", [False, True])
+def test_workspace_mode_over_a_subset_batched(gpu_ctx, image):
+    """Store::search_line_embeddings semantics (score threshold, then top-k always: store.rs:500-523, 543) for a batch over a
+    document subset: every query equals its own single-query call and the oracle's store search."""
+    import semtools_amd as smt
+
+    n = 50_000
+    emb = synth.unit_rows(n, seed=61, dup_frac=0, zero_frac=0)   # (the numpy restatement below has no tie / zero-row rules)
+    qs = synth.unit_query(62, nq=24)
+    docs = _docs(n, 7, 20, 400)
+    ranges = docs[1::2]
+    elig = np.concatenate([np.arange(b, e) for b, e in ranges])
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    if image:
+        c.prepack()
+    try:
+        for max_d in (0.80, 0.95):
+            got = c.search(qs, top_k=6, max_distance=max_d, mode=smt.MODE_WORKSPACE, ranges=ranges)
+            for i in range(len(qs)):
+                one = c.search(qs[i], top_k=6, max_distance=max_d, mode=smt.MODE_WORKSPACE, ranges=ranges)[0]
+                assert got[i][0].tolist() == one[0].tolist() and np.array_equal(got[i][1], one[1]), (max_d, i)
+                # independent f64 restatement: score = 1 - d (f32 compare as qdrant does), keep score > 1 - max_d, best 6
+                d = 1.0 - (emb[elig].astype(np.float64) @ qs[i].astype(np.float64)) / (
+                    np.linalg.norm(emb[elig].astype(np.float64), axis=1) * np.linalg.norm(qs[i].astype(np.float64)))
+                order = np.lexsort((elig, d))
+                keep = [j for j in order[:64] if (1.0 - d[j]) > float(np.float32(1.0) - np.float32(max_d))][:6]
+                assert got[i][0].tolist() == elig[keep].tolist(), (max_d, i)
+    finally:
+        c.close()
