@@ -413,7 +413,7 @@ int smt_debug_batched_scores(smt_corpus *corpus, const float *queries, uint32_t 
 int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
 
 /* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
- *   scan_blocks, scan_threads, scan_unroll (2/4/8/16), scan_nontemporal   K2 launch shape
+ *   scan_blocks, scan_threads, scan_unroll (2/4/8), scan_nontemporal   K2 launch shape
  *   gemm_blocks, gemm_qsplit, gemm_ldsrow, gemm_dma_nt                     K3 (f32 kernels / range-filtered batches)
  *   fallback_batch_min_rows   two or more uncertain queries of one call on a shard of at least this many rows (100 000)
  *                        are re-answered by ONE batched threshold pass instead of one exhaustive scan each

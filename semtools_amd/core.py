@@ -222,13 +222,7 @@ class Corpus:
             out_cap = max(int(top_k), 1)
             if max_distance is not None and mode == L.MODE_DOCUMENTS:
                 out_cap = max(self.rows, 1)
-        rng = None
-        n_rng = 0
-        if ranges is not None:
-            n_rng = len(ranges)
-            rng = (L.SmtRange * max(n_rng, 1))()
-            for i, (b, e) in enumerate(ranges):
-                rng[i].begin, rng[i].end = int(b), int(e)
+        rng, n_rng = _ranges_arg(ranges)
         while True:
             out_rows = np.empty((nq, out_cap), dtype=np.uint64)
             out_dist = np.empty((nq, out_cap), dtype=np.float64)
@@ -316,9 +310,18 @@ class IvfPq:
                                                 int(row_base), C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
 
 
+class PackedRanges:
+    """Row ranges marshalled once (a caller that searches the same document subset again and again: bench.py's workspace leg)."""
+
+    def __init__(self, ranges):
+        self.arr, self.n = _ranges_arg(list(ranges))
+
+
 def _ranges_arg(ranges):
     if ranges is None:
         return None, 0
+    if isinstance(ranges, PackedRanges):
+        return ranges.arr, ranges.n
     n = len(ranges)
     rng = (L.SmtRange * max(n, 1))()
     for i, (b, e) in enumerate(ranges):

@@ -401,12 +401,11 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
         SMT_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "scan_threads must be a multiple of 64 in [64,1024]");
         ctx->tune.scan_threads = (int)value;
     } else if (k == "scan_unroll") {
-        SMT_REQUIRE(value == 2 || value == 4 || value == 8 || value == 16, "scan_unroll must be 2, 4, 8 or 16");
+        SMT_REQUIRE(value == 2 || value == 4 || value == 8, "scan_unroll must be 2, 4 or 8");   // (16 spilled 40 VGPRs and never won a sweep: removed)
         ctx->tune.scan_unroll = (int)value;
     } else if (k == "scan_nontemporal") ctx->tune.scan_nontemporal = (int)value;
     else if (k == "scan_prefetch") ctx->tune.scan_prefetch = (int)value;
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
-    else if (k == "gemm_resident") { /* the first-generation resident-query kernel is gone; key accepted and ignored */ }
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
     else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
     else if (k == "gemm_rowreg") ctx->tune.gemm_rowreg = (int)value;

@@ -322,6 +322,8 @@ private:
     smt_group *group_ = nullptr;
     smt_sharded_corpus *corpus_ = nullptr;
     void drop_index();                           // index_ (points into corpus_) and its files: rows are about to move
+    void remove_index_files() const;             // every line_index.* of the directory, whatever rank count wrote it
+    uint64_t generation_ = 0;                    // bumped by drop_index; line_rows.json and line_index.gen carry it
     std::string index_file(int rank) const;
     std::map<std::string, DocMeta> docs_;        // documents shard
     std::map<std::string, Extent> extents_;      // path -> rows holding its lines (line i = first_row + i)

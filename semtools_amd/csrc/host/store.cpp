@@ -4,6 +4,7 @@
 #include "host.h"
 #include "host_internal.h"
 
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -140,8 +141,22 @@ std::unique_ptr<Store> Store::open(const std::string &workspace_dir, smt_group *
         }
     }
     if (!corpus_ok) check(smt_sharded_corpus_create(group, SMT_DIM, &s->corpus_), "Store::open");
-    // the index files name LOCAL rows by position: only valid on the layout they were built on
-    s->index_on_disk_ = corpus_ok && (n_ranks == 1 || layout_restored) && path_exists(s->index_file(0));
+    if (have_rows_json)
+        if (auto *gen = rows_json.get("generation")) s->generation_ = gen->as_u64();
+    // The index files name LOCAL rows by position: only valid on the layout they were built on AND for the rows as they lay when it
+    // was saved.  `line_index.gen` (written after every index save) names the corpus generation -- bumped whenever rows move or are
+    // rewritten in place -- and the rank count: an index left behind by a session with another number of GPUs, or one whose
+    // removal failed, is never loaded (such an index would pass smt_ivfpq_load's range checks and lose recall silently).
+    bool index_current = false;
+    if (corpus_ok && path_exists(workspace_dir + "/line_index.gen")) {
+        try {
+            const json::Value g = json::parse(read_to_string(workspace_dir + "/line_index.gen"));
+            auto *gg = g.get("generation");
+            auto *gr = g.get("n_ranks");
+            index_current = gg && gr && gg->as_u64() == s->generation_ && gr->as_u64() == (uint64_t)n_ranks;
+        } catch (const std::exception &) {}
+    }
+    s->index_on_disk_ = corpus_ok && index_current && (n_ranks == 1 || layout_restored) && path_exists(s->index_file(0));
     if (corpus_ok && have_rows_json) {
         const json::Value &v = rows_json;
         uint64_t live = 0;
@@ -181,12 +196,22 @@ std::string Store::index_file(int rank) const
 void Store::drop_index()
 {
     if (index_) { smt_sharded_ivfpq_destroy(index_); index_ = nullptr; }
-    if (index_on_disk_) {
-        int n_ranks = 1;
-        (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
-        for (int r = 0; r < n_ranks; ++r) (void)remove(index_file(r).c_str());
-        index_on_disk_ = false;
-    }
+    // rows are about to move or change: a new corpus generation (flushed with line_rows.json), and EVERY index file goes -- also the
+    // ones a session with a different number of GPUs wrote (`line_index.ivf` vs `line_index.ivf.r<r>of<n>`)
+    ++generation_;
+    remove_index_files();
+    index_on_disk_ = false;
+}
+
+void Store::remove_index_files() const
+{
+    DIR *d = opendir(dir_.c_str());
+    if (!d) return;
+    std::vector<std::string> victims;
+    while (const dirent *e = readdir(d))
+        if (strncmp(e->d_name, "line_index.", 11) == 0) victims.push_back(dir_ + "/" + e->d_name);
+    closedir(d);
+    for (auto &v : victims) (void)remove(v.c_str());
 }
 
 void Store::set_index_policy(size_t oversample_factor, uint64_t min_rows, uint32_t nprobe)
@@ -244,7 +269,16 @@ bool Store::ensure_index() const
         changed = true;
     }
     if (changed) {  // persist beside the vectors (a sibling first, then rename: smt_sharded_ivfpq_save)
-        if (smt_sharded_ivfpq_save(index_, file.c_str()) == SMT_OK) index_on_disk_ = true;
+        if (smt_sharded_ivfpq_save(index_, file.c_str()) == SMT_OK) {
+            json::Value g = json::Value::object();
+            g.set("generation", json::Value::uint(generation_));
+            g.set("n_ranks", json::Value::uint((uint64_t)n_ranks));
+            g.set("rows", json::Value::uint(rows));
+            try {
+                write_file_atomic(dir_ + "/line_index.gen", json::to_string_pretty(g));
+                index_on_disk_ = true;
+            } catch (const std::exception &) { remove_index_files(); }
+        }
     }
     return true;
 }
@@ -754,6 +788,7 @@ void Store::flush_line_embeddings() const
         arr.arr.push_back(std::move(e));
     }
     root.set("extents", std::move(arr));
+    root.set("generation", json::Value::uint(generation_));
     int n_ranks = 1;
     (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
     if (n_ranks > 1) {   // how the rows are dealt over the GPUs: [rows, rank] per piece, in global row order (see Store::open)

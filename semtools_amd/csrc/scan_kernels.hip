@@ -1016,7 +1016,6 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
             if (filtered) rc = launch_scan_filtered<1>(ctx, p, blocks, threads, nt);
             else if (U == 2) rc = launch_scan_variant<1, 2>(ctx, p, blocks, threads, nt);
             else if (U == 4) rc = launch_scan_variant<1, 4>(ctx, p, blocks, threads, nt);
-            else if (U == 16) rc = launch_scan_variant<1, 16>(ctx, p, blocks, threads, nt);
             else rc = launch_scan_variant<1, 8>(ctx, p, blocks, threads, nt);
             q0 += 1;
         }

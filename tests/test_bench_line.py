@@ -1,0 +1,51 @@
+"""bench.py's LAST stdout line must survive the driver's 8 KB tail with every leg's figures in it: the full
+per-leg objects go to a detail file, the line carries flat keys.  Checked here on a canned detail object (a real run's, with the
+longest strings a leg can produce), no GPU."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _canned():
+    with open(os.path.join(ROOT, "tests", "golden", "bench_detail_canned.json")) as f:
+        return json.load(f)
+
+
+def test_compact_line_fits_the_drivers_tail_and_carries_every_leg():
+    import bench
+
+    d = _canned()
+    line = bench.compact_line(d)
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+    assert len(line["cpu_baseline"]["sample"]) <= 120      # the driver's `parsed` cuts strings there
+    for key in ("c3_queries_per_s", "c3_ms_per_batch", "c3_frac_of_2p5PF", "c3_image_queries_per_s", "c3_f32mfma_frac_of_157TF",
+                "c4_rows_per_s", "c4_frac_hbm", "embed_frac_hbm_uniform", "ivf_recall_at_k", "ivf_queries_per_s",
+                "ws_1q_frac_hbm", "ws_batch_queries_per_s", "ws_batch_cost_per_scanned_row_vs_unfiltered", "ingest_lines_per_s", "ingest_cores",
+                "checks_ok", "checks_failed", "checks_total"):
+        assert key in line, key
+    assert line["checks_ok"] is True and line["checks_failed"] == []
+
+
+def test_failed_checks_and_leg_errors_surface_in_the_line():
+    import bench
+
+    d = _canned()
+    d["secondary"]["checks"]["k2_path_agreement"] = "999/1000"
+    d["c4"]["checks"]["rows_match_fp64_topk"] = False
+    d["embed"] = {"error": "RuntimeError('x' * 500)" + "y" * 500}
+    d["checks"]["oracle_dist_max_abs_diff"] = 3e-5
+    line = bench.compact_line(d)
+    assert line["checks_ok"] is False
+    joined = " ".join(line["checks_failed"])
+    for needle in ("k2_path_agreement=999/1000", "rows_match_fp64_topk=False", "embed:", "oracle_dist_max_abs_diff"):
+        assert needle in joined, (needle, joined)
+    assert len(json.dumps(line)) < 6000

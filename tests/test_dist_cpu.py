@@ -1,6 +1,6 @@
 """CPU, world_size 2, gloo: the N>1 path's exchange step.  Each rank owns a contiguous row shard,
 produces its sorted top-k list, all-gathers the fixed-size lists and merges redundantly
-(semtools_amd/dist.py).  No GPU here, so the per-shard list comes from the oracle (the checker
+(tests/dist_protocol.py: the library's exchange protocol restated over CPU tensors).  No GPU here, so the per-shard list comes from the oracle (the checker
 standing in for the local scan); what is under test is sharding + all-gather + merge: the
 result must equal the single-shard answer on every rank."""
 import os
@@ -27,7 +27,7 @@ def _worker(rank, world, port, n_rows, k, out_q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as orc
-    from semtools_amd import dist as sdist
+    from tests import dist_protocol as sdist
 
     emb = synth.unit_rows(n_rows, seed=3)
     qs = synth.unit_query(4, nq=2)
@@ -72,7 +72,7 @@ def test_two_rank_sharded_search_equals_single_shard():
 
 
 def test_shard_bounds_cover_and_are_contiguous():
-    from semtools_amd import dist as sdist
+    from tests import dist_protocol as sdist
 
     for n in (0, 1, 7, 8, 9, 100_000_001):
         for w in (1, 2, 3, 8):
@@ -115,7 +115,7 @@ def _worker_sharded(rank, world, port, n_rows, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from semtools_amd import dist as sdist
+    from tests import dist_protocol as sdist
 
     emb = synth.unit_rows(n_rows, seed=3)
     qs = synth.unit_query(4, nq=2)

@@ -163,7 +163,8 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
     env = dict(os.environ, SEMTOOLS_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--settle-steps", "8",
-           "--no-secondary", "--no-ivfpq", "--no-embed", "--no-cpu-baseline", "--c4-rows", "4000000", "--c4-steps", "4"]
+           "--no-secondary", "--no-ivfpq", "--no-embed", "--no-cpu-baseline", "--no-workspace", "--no-ingest", "--c4-rows", "4000000",
+           "--c4-steps", "4", "--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_forced_exchange.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = r.stdout.strip().split("\n")[-1]
@@ -172,10 +173,16 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
                 "dtype", "data", "config", "roofline"):
         assert key in res, key
     assert res["n_gpus"] == 1 and res["steps"] == 5 and res["value"] > 0
-    assert res["config"]["forced_exchange_on_one_rank"] is True and res["config"]["group"]["rccl_ranks"] == 1
-    assert res["checks"]["torch_fp64_topk_distances_match"] is True
-    assert res["c4"]["checks"]["torch_fp64_topk_distances_match"] is True and res["c4"]["checks"]["rows_match_fp64_topk"] is True
+    assert len(line) < 6000, len(line)                     # the driver keeps an 8 KB tail of stdout
+    assert res["config"]["forced_exchange_on_one_rank"] is True and res["config"]["rccl_ranks"] == 1
+    assert res["checks_ok"] is True and res["checks_failed"] == [] and res["checks_total"] >= 5, res
+    assert res["c4_rows_per_s"] > 0 and 0 < res["c4_frac_hbm"] < 1.0
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1.0
+    detail = json.load(open(os.path.join(ROOT, res["detail_file"])))   # the full per-leg objects
+    assert detail["config"]["group"]["rccl_ranks"] == 1
+    assert detail["checks"]["torch_fp64_topk_distances_match"] is True
+    assert detail["c4"]["checks"]["torch_fp64_topk_distances_match"] is True and detail["c4"]["checks"]["rows_match_fp64_topk"] is True
+    assert "rccl_ranks=1" in r.stderr                      # the pre-run diagnostics of a multi-rank launch
 
 
 def test_mfma_accumulate_rounding_probe():

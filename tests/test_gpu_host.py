@@ -546,6 +546,58 @@ def test_workspace_index_lifecycle(model, tmp_path, monkeypatch, capfd):
     assert got8 == host.search_with_workspace(model, query, files, workspace_name="big", n_lines=0, top_k=5)
 
 
+def test_index_files_of_another_gpu_count_are_never_loaded(gpu_ctx, model_dir, tmp_path, monkeypatch, capfd):
+    """index files are named per rank count (`line_index.ivf` vs `line_index.ivf.r<r>of<n>`).  A session with another
+    number of GPUs that moves or rewrites rows must take EVERY index file with it, and an index is only ever loaded when
+    `line_index.gen` names this corpus generation and this rank count -- a stale one would pass the loader's range checks and
+    lose recall silently."""
+    import semtools_amd as smt
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    files = []
+    for i in range(6):
+        f = tmp_path / f"gen{i}.txt"
+        f.write_text("\n".join(synth.pseudo_prose(1000, vocab_size=V - 1, seed=300 + i)) + "\n")
+        files.append(str(f))
+    query = synth.pseudo_prose(1, vocab_size=V - 1, seed=303)[0]
+    host.workspace_use(None, "gen")
+    root = tmp_path / ".semtools" / "workspaces" / "gen"
+    one = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
+    group = smt.Group.logical(0, 3)
+    three = host.StaticModel(group, model_dir=model_dir[0])
+    try:
+        monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "1000000000")
+        exact = host.search_with_workspace(one, query, files, workspace_name="gen", n_lines=0, top_k=5)
+        monkeypatch.setenv("SEMTOOLS_INDEX_MIN_ROWS", "4000")
+        monkeypatch.setenv("SEMTOOLS_INDEX_NPROBE", "512")
+        assert host.search_with_workspace(one, query, files, workspace_name="gen", n_lines=0, top_k=5) == exact
+        gen1 = json.loads((root / "line_index.gen").read_text())
+        assert (root / "line_index.ivf").exists() and gen1["n_ranks"] == 1
+        assert json.loads((root / "line_rows.json").read_text())["generation"] == gen1["generation"]
+        # three shards on the same workspace: the one-GPU index is not theirs -- they build and name their own
+        assert host.search_with_workspace(three, query, files, workspace_name="gen", n_lines=0, top_k=5) == exact
+        gen3 = json.loads((root / "line_index.gen").read_text())
+        assert gen3["n_ranks"] == 3 and all((root / f"line_index.ivf.r{r}of3").exists() for r in range(3))
+        # ... and the one-GPU session no longer trusts the file it left behind (the sidecar names three ranks): rebuilt, same answer
+        stale = root / "line_index.ivf"
+        before = stale.stat().st_mtime_ns if stale.exists() else None
+        assert host.search_with_workspace(one, query, files, workspace_name="gen", n_lines=0, top_k=5) == exact
+        assert json.loads((root / "line_index.gen").read_text())["n_ranks"] == 1
+        assert before is None or stale.stat().st_mtime_ns != before
+        # rows rewritten by the three-shard session (re-embed from the token cache): a new generation, EVERY index file gone
+        capfd.readouterr()
+        host.workspace_reembed(three, "gen")
+        assert not list(root.glob("line_index.*")), sorted(p.name for p in root.iterdir())
+        assert json.loads((root / "line_rows.json").read_text())["generation"] > gen1["generation"]
+        assert host.search_with_workspace(one, query, files, workspace_name="gen", n_lines=0, top_k=5) == exact
+    finally:
+        three.close()
+        group.close()
+        one.close()
+
+
 def test_resident_session_and_serve_mode(model, model_dir, prose_files):
     """Batched-query surface: one embedding pass, many queries; every answer equals what a
     one-shot `semtools search` prints -- for small batches (K2) and batches >= 8 queries (K3 MFMA path)."""

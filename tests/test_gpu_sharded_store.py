@@ -93,6 +93,61 @@ def test_sharded_embed_and_search_on_a_corpus_that_grows(gpu_ctx, table, n_shard
         x.close()
 
 
+def test_three_shards_against_the_oracle_directly(gpu_ctx):
+    """the other tests of this file compare N shards with one GPU (which is pinned to the oracle elsewhere) --
+    a regression that hits both identically would pass.  Here three shards answer and the C oracle checks, with nothing in
+    between: top-k (A6, src/search/mod.rs:77-120), every row under a threshold, a path subset, batches on the MFMA path with
+    and without a subset, and the store semantics (A10, src/workspace/store.rs:481-546)."""
+    import semtools_amd as smt
+
+    n = 20_011
+    emb = synth.unit_rows(n, seed=91)                    # ties (1 % duplicates) and zero rows included
+    qs = np.concatenate([synth.unit_query(92, nq=11), emb[[5, 7000, 19999]]])
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, rows=emb)
+
+    def oracle(q, k, max_d=None, elig=None):
+        rows = emb if elig is None else emb[elig]
+        res = orc.search_documents(rows, [len(rows)], q, n_lines=0, top_k=k, max_distance=max_d, accurate=True)
+        idx = np.array([r["match_line"] for r in res], dtype=np.int64)
+        return (idx if elig is None else elig[idx]).tolist(), np.array([r["distance"] for r in res])
+
+    try:
+        for k in (1, 10, 56):
+            got = sc.search(qs[:3], top_k=k)
+            for i in range(3):
+                orows, od = oracle(qs[i], k)
+                assert got[i][0].tolist() == orows and np.array_equal(got[i][1], od), (k, i)
+        got = sc.search(qs, top_k=10)                                     # 14 queries: the batched kernel inside every shard
+        for i in range(len(qs)):
+            orows, od = oracle(qs[i], 10)
+            assert got[i][0].tolist() == orows and np.array_equal(got[i][1], od), i
+        got = sc.search(qs[:2], top_k=3, max_distance=0.9)                # mod.rs:88-89, 115-116: every row under the threshold
+        for i in range(2):
+            orows, od = oracle(qs[i], 3, max_d=0.9)
+            assert got[i][0].tolist() == orows and np.array_equal(got[i][1], od), i
+        ranges = [(3, 1001), (1002, 1003), (6660, 6700), (7777, 15000), (20000, 20011)]     # crossing both shard borders
+        elig = np.concatenate([np.arange(b, e) for b, e in ranges])
+        for nq in (1, 14):
+            got = sc.search(qs[:nq], top_k=7, ranges=ranges)
+            for i in range(nq):
+                orows, od = oracle(qs[i], 7, elig=elig)
+                assert got[i][0].tolist() == orows and np.array_equal(got[i][1], od), (nq, i)
+        # store semantics: documents of 100 lines, the subset above expressed as paths; distances are f32 there
+        row_path, row_line = (np.arange(n) // 100).astype(np.uint32), (np.arange(n) % 100).astype(np.int32)
+        doc_ranges = [(100 * d, min(n, 100 * (d + 1))) for d in (0, 3, 66, 67, 150, 200)]
+        for max_d in (None, 0.93):
+            got = sc.search(qs[:4], top_k=5, max_distance=max_d, mode=smt.MODE_WORKSPACE, ranges=doc_ranges)
+            for i in range(4):
+                res = orc.search_line_embeddings(emb, row_path, row_line, qs[i], np.array([0, 3, 66, 67, 150, 200], np.uint32), 5, max_d)
+                assert np.allclose(got[i][1], [r["distance"] for r in res], rtol=0, atol=1e-5)
+                for gr, r in zip(got[i][0].tolist(), res):       # same rows; only f32-level near-ties of the store's scores may swap
+                    assert gr == r["row"] or abs(orc.cosine(qs[i], emb[gr]) - r["distance"]) < 5e-7, (max_d, i, gr, r)
+    finally:
+        sc.close()
+        g.close()
+
+
 def test_ties_across_pieces_come_back_in_insertion_order(gpu_ctx):
     """The reference's stable sort keeps equal distances in (document, line) order (src/search/mod.rs:107-111).  Duplicate
     rows spread over every shard and piece must come back by GLOBAL row, not by shard."""

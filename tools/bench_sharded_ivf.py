@@ -1,0 +1,74 @@
+"""Sharded IVF index at a meaningful size: 3 logical shards x 10 M rows, coarse centroids shared through the
+group's all-reduce (smt_sharded_ivfpq_build, shared_centroids = 1) against ONE index over the same 30 M rows on one GPU: build time,
+recall@10 vs the exact batched search, queries/s (host API: queries in, hits out).  On a 1-GPU box the shards are logical ranks
+(copy transport); their GPU work serialises, so the sharded q/s here is a LOWER bound of what three GPUs give -- what this run pins
+down is that the sharded index finds the same neighbours and what the build costs."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import semtools_amd as smt  # noqa: E402
+from tests import synth  # noqa: E402
+
+n_shards = int(os.environ.get("SHARDS", 3))
+per = int(os.environ.get("ROWS_PER_SHARD", 10_000_000))
+nq, k, nlist, nprobe, rerank = 1000, 10, 4096, 8, 128
+dev = torch.device("cuda:0")
+gen = synth.clustered_model_torch(20000, 8, 11, dev)
+x = synth.clustered_sample_torch(gen, n_shards * per, 12)
+q = synth.clustered_sample_torch(gen, nq, 13).cpu().numpy()
+del gen
+torch.cuda.synchronize()
+out = {"shards": n_shards, "rows_per_shard": per, "rows": n_shards * per, "nlist": nlist, "nprobe": nprobe, "rerank": rerank, "queries": nq, "top_k": k,
+       "corpus": "20000 topics, queries are independent draws of the generative model (as bench.py's c5 leg)",
+       "transport": "logical ranks on one device (their GPU work serialises)"}
+
+ctx = smt.Context(0)
+whole = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=n_shards * per)
+t0 = time.perf_counter()
+exact = whole.search(q, top_k=k)
+out["exact_batch_ms"] = (time.perf_counter() - t0) * 1e3
+
+
+def recall(got):
+    return sum(len(set(r.tolist()) & set(e.tolist())) for (r, _), (e, _) in zip(got, exact)) / (nq * k)
+
+
+def timed(fn, reps=5):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got = fn()
+    return (time.perf_counter() - t0) / reps, got
+
+
+t0 = time.perf_counter()
+ix = smt.IvfPq(whole, nlist=nlist, train_iters=10, local_pca=True)
+one_build = time.perf_counter() - t0
+dt, got = timed(lambda: ix.search(q, top_k=k, nprobe=nprobe, rerank=rerank))
+out["one_gpu_index"] = {"build_s": one_build, "recall_at_10": recall(got), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
+                        "index_bytes": ix.info()["index_bytes"]}
+ix.close()
+
+grp = smt.Group.logical(0, n_shards)
+sc = smt.ShardedCorpus(grp, device_ptrs=[x[i * per:(i + 1) * per].data_ptr() for i in range(n_shards)], shard_rows=[per] * n_shards)
+for shared in (True, False):
+    t0 = time.perf_counter()
+    six = smt.ShardedIvfPq(sc, nlist=nlist, train_iters=10, local_pca=True, shared_centroids=shared)
+    build = time.perf_counter() - t0
+    dt, got = timed(lambda: six.search(q, top_k=k, nprobe=nprobe, rerank=rerank))
+    rows_global_ok = all(int(r.max()) < n_shards * per for r, _ in got if len(r))
+    exact_d = all(np.array_equal(d, np.sort(d)) for _, d in got)
+    out["sharded_shared_centroids" if shared else "sharded_own_centroids"] = {
+        "build_s": build, "recall_at_10": recall(got), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
+        "index_bytes": six.info()["index_bytes"], "rows_are_global": rows_global_ok, "distances_ascending": exact_d}
+    six.close()
+sc.close()
+grp.close()
+whole.close()
+print(json.dumps(out, indent=1))

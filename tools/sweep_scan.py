@@ -63,7 +63,7 @@ def main():
     threads_blocks = [(256, 8), (512, 2), (512, 4), (1024, 1), (1024, 2), (256, 4), (512, 1), (256, 16)]
     if not args.full:
         threads_blocks = [(512, 2), (1024, 1), (256, 2), (512, 1)]
-    for (threads, bpc), unroll, nt in itertools.product(threads_blocks, (4, 8) if not args.full else (4, 8, 16), (1,) if not args.full else (1, 0)):
+    for (threads, bpc), unroll, nt in itertools.product(threads_blocks, (4, 8) if not args.full else (2, 4, 8), (1,) if not args.full else (1, 0)):
         run("sweep", scan_threads=threads, scan_blocks=bpc * 256, scan_unroll=unroll, scan_nontemporal=nt)
     ctx.set_tuning("scan_threads", 1024); ctx.set_tuning("scan_blocks", 0); ctx.set_tuning("scan_unroll", 4)
     ctx.set_tuning("scan_nontemporal", 1)
