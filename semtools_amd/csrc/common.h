@@ -64,7 +64,7 @@ struct Tuning {
     int gemm_image = 1;         // 1: batched searches read the corpus' fp16 operand image when it has one (0: A/B only)
     int64_t image_scan_min_rows = 4000000;   // shards this large answer 1-2 queries from the operand image too, when they have one (0: never)
     int corpus_image = 1;       // 1: a corpus this library owns builds its operand image at the first batch of >= 8 queries (>= 64 Ki rows)
-    int embed_batched = 1;      // 1: K1 finishes parked lines wave-wide (0: one by one; A/B only)
+    int embed_batched = 3;      // bit 0: K1 finishes parked lines wave-wide; bit 1: token ids prefetched one step ahead (A/B: 0 / 1; 7, 11: probes)
     int gemm_split_last = 1;    // 1: a streamed K3 sweep runs its last level in two parts with a select pass in between (0: A/B only)
     int gemm_buffered = 1;      // 1: gemm_rowreg_kernel nominations go through the wave's LDS buffer (0: straight to the lists; A/B only)
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks

@@ -48,40 +48,46 @@ struct EmbedParams {
     uint64_t lines_per_group;   // a group of 16 lanes walks lines [g * lines_per_group, ...)
 };
 
-__global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
+// PF: the token ids of step s + 1 are requested while the rows of step s are in flight (the next position is pure arithmetic on the
+// prefetched offsets), so a step waits for ONE memory round trip -- the rows -- instead of two in a row (ids, then rows).
+template <bool PF, int WAVES = 4, bool NT = false>
+__global__ void __launch_bounds__(256, WAVES) embed_kernel(EmbedParams p)
 {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int a = lane & 15;        // position inside the group
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    uint64_t line = group * p.lines_per_group;
-    const uint64_t line_end = min(p.n_lines, line + p.lines_per_group);
-    bool active = line < line_end;                       // group-uniform
+    // (register diet: the kernel sits at the 128-VGPR edge of four waves per SIMD -- the position inside the run is a 32-bit count,
+    // the parked line is always the one before the current, its token count is kept as the float the mean divides by)
+    const uint64_t line0 = group * p.lines_per_group;
+    const uint32_t n_run = line0 < p.n_lines ? (uint32_t)min(p.n_lines - line0, p.lines_per_group) : 0u;
+    uint32_t li = 0;                                     // current line = line0 + li
+    bool active = li < n_run;                            // group-uniform
 
     // token range of the current line [t, t_end) (max_tokens applied), its token count, and the NEXT line's end (read one
     // line ahead: a group that moves on must not wait for a dependent offsets load)
     uint64_t t = 0, t_end = 0, o_end = 0, o_next = 0;
     if (active) {
-        t = p.offsets[line];
-        o_end = p.offsets[line + 1];
-        o_next = line + 1 < line_end ? p.offsets[line + 2] : o_end;
+        t = p.offsets[line0];
+        o_end = p.offsets[line0 + 1];
+        o_next = 1 < n_run ? p.offsets[line0 + 2] : o_end;
         t_end = o_end;
         if (p.max_tokens != 0 && t_end - t > (uint64_t)p.max_tokens) t_end = t + p.max_tokens;
     }
-    uint64_t n_tok = t_end - t;
+    float cnt_cur = (float)(t_end - t > 0 ? t_end - t : 1);   // what the current line's sums are divided by (max(cnt, 1))
 
     float4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float4 pend[4];                  // the sums of a complete line waiting for its epilogue
-    uint64_t pend_line = 0, pend_tok = 0;
-    bool has_pend = false;           // group-uniform
+    float pend_cnt = 1.0f;
+    bool has_pend = false;           // group-uniform; the parked line is line0 + li - 1
 #pragma unroll
     for (int c = 0; c < 4; ++c) pend[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto finalize = [&]() __attribute__((always_inline)) {
         if (has_pend) {
-            const float cnt = (float)(pend_tok > 0 ? pend_tok : 1);
+            const float cnt = pend_cnt;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 pend[c].x = pend[c].x / cnt; pend[c].y = pend[c].y / cnt;
@@ -118,7 +124,7 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
                     pend[c].z = pend[c].z / norm; pend[c].w = pend[c].w / norm;
                 }
             }
-            float4 *o = reinterpret_cast<float4 *>(p.out + pend_line * 256);
+            float4 *o = reinterpret_cast<float4 *>(p.out + (line0 + li - 1) * 256);
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c * 16 + a] = pend[c];
             has_pend = false;
@@ -126,20 +132,48 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
     };
 
     constexpr int TU = 4;  // tokens in flight per group
+    // PF: the ids of the step about to run -- ONE per lane (lane a holds token a & 3 of its group's step; the gather reads it with a
+    // DPP quad broadcast), so the prefetch costs one register and a quarter of the id loads
+    static_assert(TU == 4, "one id per lane of a quad");
+    uint32_t nid = 0;
+    if constexpr (PF) nid = (active && (t + (a & 3)) < t_end) ? p.ids[t + (a & 3)] : 0u;
     while (__any(active)) {
         float4 r[TU][4];
+        uint32_t idq[TU] = {0u, 0u, 0u, 0u};
+        if constexpr (PF) {   // quad_perm broadcasts of lane u of every quad
+            idq[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nid, 0x00, 0xF, 0xF, false);
+            idq[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nid, 0x55, 0xF, 0xF, false);
+            idq[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nid, 0xAA, 0xF, 0xF, false);
+            idq[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nid, 0xFF, 0xF, 0xF, false);
+        }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
             const bool on = active && (t + u) < t_end;
-            uint64_t id = on ? (uint64_t)p.ids[t + u] : 0;
+            uint64_t id;
+            if constexpr (PF) id = idq[u];
+            else id = on ? (uint64_t)p.ids[t + u] : 0;
             const bool ok = on && id < p.V;  // out-of-vocab ids contribute nothing
             const float4 *row = reinterpret_cast<const float4 *>(p.table + (ok ? id : 0) * 256);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // (plain loads, not nontemporal: natural text is Zipf-distributed and its hot rows must stay in L2 / MALL --
                 // measured with the nt policy: Zipf ids 3.50 -> 4.59 ms, uniform ids 5.97 -> 6.27 ms)
-                r[u][c] = ok ? row[c * 16 + a] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (NT) {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v v = ok ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row) + c * 16 + a) : (f4v){0.f, 0.f, 0.f, 0.f};
+                    r[u][c] = make_float4(v.x, v.y, v.z, v.w);
+                }
+                else r[u][c] = ok ? row[c * 16 + a] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        // where the group stands after this step -- known before any row has arrived
+        const bool done = active && t + TU >= t_end;
+        if constexpr (PF) {
+            const bool n_active = done ? li + 1 < n_run : active;
+            const uint64_t nt = done ? o_end : t + TU;
+            uint64_t nt_end = done ? o_next : t_end;
+            if (done && p.max_tokens != 0 && nt_end - nt > (uint64_t)p.max_tokens) nt_end = nt + p.max_tokens;
+            nid = (n_active && (nt + (a & 3)) < nt_end) ? p.ids[nt + (a & 3)] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
@@ -158,7 +192,6 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
         // mean, norm chain, store: ~640 instructions, the bulk of a line's instruction count -- runs for all parked lines of the
         // wave at once: when every group has one parked, or when a group completes a second line before that.  (Run at once per
         // completion it executed with 16 of 64 lanes enabled, once per line; measured: Zipf ids 3.75 -> 3.39 ms)
-        const bool done = active && t >= t_end;
         if (__any(done && has_pend)) finalize();
         if (done) {
 #pragma unroll
@@ -166,18 +199,17 @@ __global__ void __launch_bounds__(256) embed_kernel(EmbedParams p)
                 pend[c] = acc[c];
                 acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            pend_line = line;
-            pend_tok = n_tok;
+            pend_cnt = cnt_cur;
             has_pend = true;
             // ---- next line of the run
-            ++line;
-            active = line < line_end;
+            ++li;
+            active = li < n_run;
             t = o_end;
             o_end = o_next;
-            if (line + 1 < line_end) o_next = p.offsets[line + 2];
+            if (li + 1 < n_run) o_next = p.offsets[line0 + li + 2];
             t_end = o_end;
             if (p.max_tokens != 0 && t_end - t > (uint64_t)p.max_tokens) t_end = t + p.max_tokens;
-            n_tok = t_end - t;
+            cnt_cur = (float)(t_end - t > 0 ? t_end - t : 1);
         }
         if (__any(has_pend) && (!p.batched || __all(has_pend || !active))) finalize();
     }
@@ -196,7 +228,7 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     p.n_lines = n_lines;
     p.max_tokens = max_tokens;
     p.normalize = normalize;
-    p.batched = ctx->tune.embed_batched;
+    p.batched = ctx->tune.embed_batched & 1;
     p.out = out;
     // a run of lines per group: enough groups to fill the chip (16 waves x 4 groups per CU), runs long enough that ragged
     // lines average out inside a run (a group with 100 lines of 0..32 tokens ends within ~5 % of its neighbours)
@@ -206,7 +238,11 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     const uint64_t blocks = (groups + 15) / 16;    // 256 threads = 16 groups
     SMT_REQUIRE(blocks < (1ull << 24), "too many lines for one embed launch");
     prof_begin(ctx, "embed");
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+    // (A/B: embed_batched bit 1 = ids prefetched one step ahead, bit 2 = that kernel at three waves per SIMD, no spills)
+    if ((ctx->tune.embed_batched & 10) == 10) hipLaunchKernelGGL((embed_kernel<true, 4, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);   // bit 3: nt row loads
+    else if ((ctx->tune.embed_batched & 6) == 6) hipLaunchKernelGGL((embed_kernel<true, 3>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+    else if (ctx->tune.embed_batched & 2) hipLaunchKernelGGL((embed_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((embed_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
     prof_end(ctx, "embed");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;

@@ -326,7 +326,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // (the proof needs the k-th exact distance to lie 2 x the band below the worst nominated one): 8 / 16 / 24
     const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)std::max(ctx->tune.guard_band, f16x1 ? 24 : f16x2 ? 16 : 8));
     const bool lds_rows = !rowreg && ctx->tune.gemm_ldsrow && (filtered || nqt <= 2);
-    if (filtered && !lds_rows) { set_error("range-filtered batches need the LDS-row kernel (tuning key gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
+    if (filtered && !lds_rows && !rowreg) { set_error("range-filtered batches need the row-register or the LDS-row kernel (tuning keys gemm_rowreg, gemm_ldsrow)"); return SMT_E_UNSUPPORTED; }
     const uint32_t pass_nq = lds_rows ? 2 * QT_ROWS : GEMM_MAX_NQ;
     if (a.nq > pass_nq) {
         // (GEMM_MAX_NQ: the per-query thresholds of one gemm_level_kernel launch live in LDS beside the four

@@ -140,28 +140,33 @@ int ensure_host(smt_group *g, int i, size_t bytes)
 int allgather_words(smt_group *g, size_t send_off, size_t recv_off, size_t words, const std::vector<char> *on_aux)
 {
     if (g->copies) {
+        // Copy transport (logical ranks of ONE process): gather into rank 0's receive buffer, then every other rank copies the
+        // whole block -- 2 n copies and ~5 n event calls instead of the n x n copies of rounds 2-3 (192 HIP calls per exchange at 8
+        // ranks: ~0.45 of the 0.58 ms one host thread needed to issue an 8-shard search, profiles/r04_group_issue.json).
         auto stream_of = [&](int i) { return (on_aux && (*on_aux)[i]) ? g->ctx[i]->aux_stream : g->ctx[i]->stream; };
-        for (int j = 0; j < g->n_local; ++j) {
+        const int n = g->n_local;
+        for (int j = 0; j < n; ++j) {
             SMT_HIP_CHECK(hipSetDevice(g->ctx[j]->device));
             SMT_HIP_CHECK(hipEventRecord(g->ev_ready[j], stream_of(j)));
         }
-        for (int i = 0; i < g->n_local; ++i) {
+        SMT_HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+        char *dst0 = reinterpret_cast<char *>(g->buf[0].dev) + recv_off;
+        for (int j = 0; j < n; ++j) {
+            if (j != 0) SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(0), g->ev_ready[j], 0));
+            const char *src = reinterpret_cast<const char *>(g->buf[j].dev) + send_off;
+            SMT_HIP_CHECK(hipMemcpyPeerAsync(dst0 + (size_t)j * words * 8, g->ctx[0]->device, src, g->ctx[j]->device, words * 8, stream_of(0)));
+        }
+        SMT_HIP_CHECK(hipEventRecord(g->ev_done[0], stream_of(0)));       // every send buffer has been read; rank 0 holds the block
+        for (int i = 1; i < n; ++i) {
             SMT_HIP_CHECK(hipSetDevice(g->ctx[i]->device));
-            char *dst = reinterpret_cast<char *>(g->buf[i].dev) + recv_off;
-            for (int j = 0; j < g->n_local; ++j) {
-                if (j != i) SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(i), g->ev_ready[j], 0));
-                const char *src = reinterpret_cast<const char *>(g->buf[j].dev) + send_off;
-                SMT_HIP_CHECK(hipMemcpyPeerAsync(dst + (size_t)j * words * 8, g->ctx[i]->device, src, g->ctx[j]->device, words * 8,
-                                                 stream_of(i)));
-            }
+            SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(i), g->ev_done[0], 0));   // (also: rank i may overwrite its send buffer after this)
+            SMT_HIP_CHECK(hipMemcpyPeerAsync(reinterpret_cast<char *>(g->buf[i].dev) + recv_off, g->ctx[i]->device, dst0, g->ctx[0]->device,
+                                             (size_t)n * words * 8, stream_of(i)));
             SMT_HIP_CHECK(hipEventRecord(g->ev_done[i], stream_of(i)));
         }
-        // a rank may not overwrite its send buffer (next call) before every reader is done with it
-        for (int j = 0; j < g->n_local; ++j) {
-            SMT_HIP_CHECK(hipSetDevice(g->ctx[j]->device));
-            for (int i = 0; i < g->n_local; ++i)
-                if (i != j) SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(j), g->ev_done[i], 0));
-        }
+        // rank 0 may not overwrite its receive block (the next exchange) before every rank has copied it
+        SMT_HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+        for (int i = 1; i < n; ++i) SMT_HIP_CHECK(hipStreamWaitEvent(stream_of(0), g->ev_done[i], 0));
         return SMT_OK;
     }
     SMT_NCCL_CHECK(g_rccl.GroupStart());
@@ -242,6 +247,58 @@ int group_agree(smt_group *g, int rc)
     return SMT_OK;
 }
 
+static void worker_main(smt_group *g, int i)
+{
+    GroupWorkers *w = g->workers;
+    (void)hipSetDevice(g->ctx[i]->device);   // the thread's current device (every entry point binds again: cheap when unchanged)
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<int(int)> *work;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv_go.wait(lk, [&] { return w->stop || w->epoch != seen; });
+            if (w->stop) return;
+            seen = w->epoch;
+            work = w->work;
+        }
+        const int rc = (*work)(i);
+        std::string err = rc ? smt_last_error() : "";   // (thread-local: carried back to the caller's thread)
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->rcs[i] = rc;
+            w->errs[i].swap(err);
+            if (--w->pending == 0) w->cv_done.notify_one();
+        }
+    }
+}
+
+static int group_start_workers(smt_group *g)
+{
+    if (g->n_local <= 1 || g->workers) return SMT_OK;
+    g->workers = new (std::nothrow) GroupWorkers();
+    if (!g->workers) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    g->workers->rcs.assign(g->n_local, SMT_OK);
+    g->workers->errs.assign(g->n_local, std::string());
+    for (int i = 0; i < g->n_local; ++i) g->workers->threads.emplace_back(worker_main, g, i);
+    return SMT_OK;
+}
+
+static void group_stop_workers(smt_group *g)
+{
+    GroupWorkers *w = g->workers;
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv_go.notify_all();
+    for (auto &t : w->threads) t.join();
+    delete w;
+    g->workers = nullptr;
+}
+
+// work(i) for every local device: on the group's issuing threads when it has them (n_local > 1), else on threads made for
+// the call (`threads`), else in a row on the caller's thread.  First error wins.
 int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool threads)
 {
     std::vector<int> rcs(g->n_local, SMT_OK);
@@ -252,6 +309,16 @@ int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool
     };
     if (g->n_local == 1 || !threads) {
         for (int i = 0; i < g->n_local; ++i) run(i);
+    } else if (GroupWorkers *w = g->workers) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->work = &work;
+        w->pending = g->n_local;
+        ++w->epoch;
+        w->cv_go.notify_all();
+        w->cv_done.wait(lk, [&] { return w->pending == 0; });
+        w->work = nullptr;
+        rcs = w->rcs;
+        errs = w->errs;
     } else {
         std::vector<std::thread> th;
         for (int i = 0; i < g->n_local; ++i) th.emplace_back(run, i);
@@ -269,6 +336,7 @@ int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool
 static void group_free(smt_group *g)
 {
     if (!g) return;
+    group_stop_workers(g);
     for (int i = 0; i < (int)g->ctx.size(); ++i) {
         if (!g->ctx[i]) continue;
         (void)hipSetDevice(g->ctx[i]->device);
@@ -560,6 +628,7 @@ int smt_group_create(const int *devices, int n_dev, smt_group **out)
     ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), n_dev, devices);
     if (r != ncclSuccess) { set_error("ncclCommInitAll(%d devices): %s", n_dev, g_rccl.GetErrorString(r)); group_free(g); return SMT_E_HIP; }
     if ((rc = group_barrier(g))) { group_free(g); return rc; }  // channel set-up happens on the first collective: do it now
+    if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
     return SMT_OK;
 }
@@ -585,6 +654,7 @@ int smt_group_create_logical(int device, int n_shards, smt_group **out)
         if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); group_free(g); return SMT_E_HIP; }
     }
     if ((rc = group_barrier(g))) { group_free(g); return rc; }
+    if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
     return SMT_OK;
 }
@@ -770,16 +840,20 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
         const float thr_score = 1.0f - (float)max_distance;  // store.rs:502-503
         int local_rc = SMT_OK;
         std::string local_err;
-        // Pinned staging per local device: [queries][status word] (+ device 0: the merged lists and every rank's flags).  The
-        // loop below only ENQUEUES -- upload, scan, select, status -- so that the shards of a one-process group scan
-        // concurrently (a stack status word forced a stream sync per device, i.e. the SUM of the shard times).
+        // Pinned staging per local device: [queries][status word] (+ device 0: the merged lists and every rank's flags).  A device's
+        // share only ENQUEUES -- upload, scan, select, status -- and the shares of a one-process group are issued at once by the
+        // group's issuing threads (group_for_each_local), so the shards scan concurrently and the caller's thread pays for one.
+        // (a stack status word once forced a stream sync per device here, i.e. the SUM of the shard times.)
         const size_t flag_words = (size_t)g->n_ranks * (nq + 1);
         const size_t pin_status_off = q_bytes, pin_res_off = q_bytes + 64;
-        for (int i = 0; i < g->n_local; ++i) {
+        std::vector<int> stage_rcs(g->n_local, SMT_OK);
+        std::vector<std::string> stage_errs(g->n_local);
+        rc = group_for_each_local(g, [&](int i) -> int {
             const int r = g->first_rank + i;
-            if ((rc = group_bind(g, i))) return rc;
-            if ((rc = ensure_dev(g, i, dev_bytes))) return rc;   // (no exchange buffer: nothing to report through)
-            if ((rc = ensure_host(g, i, pin_res_off + (i == 0 ? (list_words + flag_words) * 8 : 0)))) return rc;
+            int rc_i;
+            if ((rc_i = group_bind(g, i))) return rc_i;
+            if ((rc_i = ensure_dev(g, i, dev_bytes))) return rc_i;   // (no exchange buffer: nothing to report through)
+            if ((rc_i = ensure_host(g, i, pin_res_off + (i == 0 ? (list_words + flag_words) * 8 : 0)))) return rc_i;
             char *base = reinterpret_cast<char *>(g->buf[i].dev);
             char *pin = reinterpret_cast<char *>(g->buf[i].pinned);
             uint64_t *loc = reinterpret_cast<uint64_t *>(base + loc_off);
@@ -794,11 +868,15 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
                 if (!rc2 && !sc->contiguous) rc2 = layout_translate_packed(sc, i, g->ctx[i]->stream, loc, nq, K);
                 return rc2;
             }();
-            if (stage_rc && !local_rc) { local_rc = stage_rc; local_err = smt_last_error(); }
+            if (stage_rc) { stage_rcs[i] = stage_rc; stage_errs[i] = smt_last_error(); }
             uint64_t *status = reinterpret_cast<uint64_t *>(pin + pin_status_off);   // lives in the pinned buffer until group_sync_all
             *status = (uint64_t)(uint32_t)(stage_rc < 0 ? -stage_rc : stage_rc);
             SMT_HIP_CHECK(hipMemcpyAsync(loc + list_words + nq, status, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
-        }
+            return SMT_OK;
+        });
+        if (rc) return rc;
+        for (int i = 0; i < g->n_local; ++i)
+            if (stage_rcs[i] && !local_rc) { local_rc = stage_rcs[i]; local_err = stage_errs[i]; }
         if ((rc = allgather_words(g, loc_off, gath_off, rank_words))) return rc;
         // the caller is one host thread and needs ONE copy of the answer: merge on local device 0
         if ((rc = group_bind(g, 0))) return rc;
@@ -861,24 +939,28 @@ int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *q
     const size_t dev_bytes = gath_off + (size_t)g->n_ranks * list_words * 8 + 64;
     std::vector<char> on_aux(g->n_local, 0);
     int rc;
-    for (int i = 0; i < g->n_local; ++i) {
+    for (int i = 0; i < g->n_local; ++i) SMT_REQUIRE(queries_dev[i] != nullptr, "queries_dev");
+    // every device's scan + select is issued by its own thread (group_for_each_local); the collective follows on this one
+    rc = group_for_each_local(g, [&](int i) -> int {
         const int r = g->first_rank + i;
-        SMT_REQUIRE(queries_dev[i] != nullptr, "queries_dev");
-        if ((rc = group_bind(g, i))) return rc;
-        if ((rc = ensure_dev(g, i, dev_bytes))) return rc;
+        int rc_i;
+        if ((rc_i = group_bind(g, i))) return rc_i;
+        if ((rc_i = ensure_dev(g, i, dev_bytes))) return rc_i;
         smt_ctx *c = g->ctx[i];
         // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select);
         // the all-gather and the merge then follow it there, and the main stream carries nothing but scans
         const bool async = c->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k;
-        rc = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false,
-                                      sc->contiguous ? sc->rank_base[r] : 0, reinterpret_cast<uint64_t *>(g->buf[i].dev), nullptr, async);
-        if (rc) return rc;
-        if (!sc->contiguous && (rc = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream,
-                                                             reinterpret_cast<uint64_t *>(g->buf[i].dev), nq, top_k)))
-            return rc;
+        rc_i = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false,
+                                        sc->contiguous ? sc->rank_base[r] : 0, reinterpret_cast<uint64_t *>(g->buf[i].dev), nullptr, async);
+        if (rc_i) return rc_i;
+        if (!sc->contiguous && (rc_i = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream,
+                                                               reinterpret_cast<uint64_t *>(g->buf[i].dev), nq, top_k)))
+            return rc_i;
         on_aux[i] = async ? 1 : 0;
         if (async) c->async_pending = true;
-    }
+        return SMT_OK;
+    });
+    if (rc) return rc;
     if ((rc = allgather_words(g, 0, gath_off, list_words, &on_aux))) return rc;
     for (int i = 0; i < g->n_local; ++i) {
         if (!out_packed[i]) continue;

@@ -7,6 +7,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -19,7 +20,24 @@ struct GroupBuf {
     size_t pinned_bytes = 0;
 };
 
+// Issuing threads: one per local device of a single-process group.  The caller is ONE synchronous host thread
+// (src/bin/semtools.rs:134-135); issuing a search for 8 shards from it costs 8 x (bind + upload + scan + select launches) in a row --
+// measured 16 us per shard (profiles/r04_group_issue.json), i.e. about one shard's whole 150 us scan at 1 M rows.  The workers issue
+// every device's share at once; collectives stay on the caller's thread (ncclGroupStart / End needs all local ranks in one thread).
+struct GroupWorkers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<int(int)> *work = nullptr;
+    uint64_t epoch = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+};
+
 struct smt_group {
+    GroupWorkers *workers = nullptr; // n_local > 1: persistent issuing threads (group_for_each_local)
     int n_ranks = 0;
     int n_local = 0;
     int first_rank = 0;              // local device i is rank first_rank + i

@@ -61,6 +61,22 @@ for nsh in sorted({1, 2, 4, n_shards}):
                                                              "host_issue_us_per_shard": issued / n / nsh * 1e6}
     for i in range(nsh):
         grp.ctx(i).set_tuning("async_select", 0)
+    # what ONE thread pays when it issues the shards' scan + select itself, one after the other, with nothing to exchange
+    # (smt_search_topk_device per shard): the cost the group's issuing threads take off the caller
+    views = [sc.shard(i)[0] for i in range(nsh)]
+    o_r = [torch.empty(k, dtype=torch.int64, device=dev) for _ in range(nsh)]
+    o_d = [torch.empty(k, dtype=torch.float64, device=dev) for _ in range(nsh)]
+    fn1 = L.lib().smt_search_topk_device
+    args1 = [(views[i]._h, C.c_void_p(q[0].data_ptr()), 1, k, 0, C.c_void_p(o_r[i].data_ptr()), C.c_void_p(o_d[i].data_ptr())) for i in range(nsh)]
+    for a in args1:
+        L.check(fn1(*a))
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for j in range(n):
+        for a in args1:
+            fn1(*a)
+    leg["one_thread_issues_every_shard_us_per_search"] = (time.perf_counter() - t0) / n * 1e6
+    grp.synchronize()
     # the host API (what the store calls): one query in, hits out
     qh = q.cpu().numpy()
     for j in range(4):
@@ -81,6 +97,9 @@ for nsh in sorted({1, 2, 4, n_shards}):
     sc.close()
     grp.close()
 one_scan_us = 150.0
+out["note"] = ("host_issue = the caller's thread inside smt_sharded_search_topk_device: wake the issuing threads (one per shard; each binds, "
+               "launches scan + select), wait for them, then the exchange (copy transport here: ~5 n event / copy calls; RCCL on a real "
+               "node: ncclGroupStart + n ncclAllGather + ncclGroupEnd) and the merge launches")
 out["verdict"] = {"one_shard_scan_us": one_scan_us, "budget_us": one_scan_us / 2,
                   "host_issue_us_8_shards_in_order": out[f"{n_shards}_shards"]["in_order"]["host_issue_us_per_search"],
                   "within_budget": out[f"{n_shards}_shards"]["in_order"]["host_issue_us_per_search"] <= one_scan_us / 2}
