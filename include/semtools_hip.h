@@ -415,6 +415,8 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
 /* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
  *   scan_blocks, scan_threads, scan_unroll (2/4/8), scan_nontemporal   K2 launch shape
  *   gemm_blocks, gemm_qsplit, gemm_ldsrow, gemm_dma_nt                     K3 (f32 kernels / range-filtered batches)
+ *   gemm_bootstrap (1)                                                     K3 row-register kernel: first thresholds from a bootstrap level of
+ *                                                                          tile minima (0: the appended-levels plan of rounds 1-3; A/B only)
  *   fallback_batch_min_rows   two or more uncertain queries of one call on a shard of at least this many rows (100 000)
  *                        are re-answered by ONE batched threshold pass instead of one exhaustive scan each
  *   guard_band (8..56)   the scans nominate min(64, top_k + guard_band) rows per list; the exactness proof tolerates that

@@ -407,6 +407,7 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "scan_prefetch") ctx->tune.scan_prefetch = (int)value;
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
+    else if (k == "gemm_bootstrap") ctx->tune.gemm_bootstrap = (int)value;
     else if (k == "gemm_bf16x3") ctx->tune.gemm_bf16x3 = (int)value;
     else if (k == "gemm_rowreg") ctx->tune.gemm_rowreg = (int)value;
     else if (k == "gemm_nominate") ctx->tune.gemm_nominate = (value >= 1 && value <= 3) ? (int)value : 0;

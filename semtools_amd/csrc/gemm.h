@@ -23,6 +23,11 @@ constexpr int LEVEL_RATIO_SMALL_K = 16;
 constexpr int LEVEL_RATIO_LARGE_K = 16;
 constexpr uint32_t LEVEL_RATIO_KP_LIMIT = 24;
 constexpr int LEVEL0_MAX_TILES = 32;
+// gemm_rowreg_kernel starts from a BOOTSTRAP level instead: up to this many tiles (every stride-th), no candidate lists, only the
+// tiles' best distances -- the kp-th smallest of them bounds the final kp-th distance (the tiles are distinct, so are their best rows)
+// and is the first threshold.  Three levels (5, 77, 1221 tiles at 10 M rows: three launches whose nominations are slot grabs on the
+// same thousand counters with a memory round trip each, and three select passes) became one pass of plain stores.
+constexpr uint32_t BOOTSTRAP_MAX_TILES = 2048;
 constexpr uint32_t GEMM_MAX_NQ = 3584;         // 4 x 32.5 KiB tile slots + 8 B per query fit the 160 KiB LDS
 
 struct GemmParams {
@@ -49,6 +54,9 @@ struct GemmParams {
     // range-filtered batches of gemm_rowreg_kernel: the level's tiles are the ENTRIES of this table (aligned 32-row tile | mask of the
     // wanted rows << 32, build_tile_table_kernel) instead of the tiles themselves; nullptr = every tile, every row
     const uint64_t *tile_table = nullptr;
+    // BOOTSTRAP level of gemm_rowreg_kernel (gemm_topk.hip launch_gemm_topk): no nominations -- the kernel stores, per visited tile and
+    // query, the best nominating distance of the tile's wanted rows: tile_min[level tile index][nqt * 32]
+    float *tile_min = nullptr;
     const void *image;            // gemm_rowreg_kernel<MODE, true>: the corpus' fp16 operand image (16 KiB per 32-row tile) ...
     const uint32_t *image_zero;   // ... and per tile the mask of its zero rows
     int buffered;                 // gemm_rowreg_kernel: nominations go through the wave's LDS buffer (every level but the first)

@@ -503,6 +503,24 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
             // (thresholds from LDS, staged with the tile: a global load here would sit in the same in-order vmcnt queue as the
             // tile DMAs, and waiting for it would wait for them)
             const f32x2 qc = *reinterpret_cast<const f32x2 *>(s_qconst + slot * RR_QCONST + j * 8);
+            if (p.tile_min != nullptr) {   // bootstrap level (wave-uniform): the tile's best nominating distance per query, a plain store
+                float m;
+                if (__builtin_amdgcn_ballot_w64(valid16 != 0xffffu)) {   // ragged / filtered tile: only the wanted rows count
+                    m = -__builtin_inff();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, (valid16 >> r) & 1u ? acc[r] : -__builtin_inff());
+                } else {
+                    m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+                    for (int r = 3; r + 1 < 16; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
+                    m = fmaxf(m, acc[15]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 32));                          // the other half's 16 rows of the same query
+                const bool zero_row = __builtin_amdgcn_ballot_w64((zero16 & valid16) != 0u) != 0ull;   // simsimd: 0 against a zero row, else 1
+                const float d = qc.y == 0.0f ? (zero_row ? 0.0f : 1.0f) : fmaxf(1.0f - m * qc.y, 0.0f);
+                if (h == 0) p.tile_min[(size_t)it * ((size_t)p.nqt * QT_ROWS) + (size_t)qt * QT_ROWS + j] = d;
+                return;
+            }
 #if (SMT_RR_EXP & 1)
             if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.678f)
 #endif

@@ -182,6 +182,47 @@ __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
     }
 }
 
+// The first threshold of a row-register batch: per query the kp-th smallest of the bootstrap level's tile minima (GemmParams::
+// tile_min, [n_tiles][nq_pad]).  The tiles are distinct, so at least kp ROWS have a nominating distance <= that value: it bounds the
+// final kp-th distance from above, which is all a level threshold has to do.  One block per query tile: 32 queries x 32 threads, the
+// values of a query in one LDS row (two tiles folded into a slot by their minimum beyond 1024 tiles), bitonic sort of the 32 rows.
+constexpr int BOOT_SLOTS = 1024, BOOT_ROW = BOOT_SLOTS + 1;   // odd row stride: the 32 queries of a wave hit 32 different banks
+__global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_min, uint32_t n_tiles, uint32_t nq, uint32_t nq_pad, uint32_t kp,
+                                                             float *tau, float *qconst)
+{
+    extern __shared__ float s_v[];   // [32][BOOT_ROW]
+    const uint32_t qi = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const uint32_t q = blockIdx.x * QT_ROWS + qi;
+    const uint32_t fold = (n_tiles + BOOT_SLOTS - 1) / BOOT_SLOTS;   // 1 or 2
+    const uint32_t n_slots = (n_tiles + fold - 1) / fold;
+    float *row = s_v + qi * BOOT_ROW;
+    for (uint32_t e = s; e < (uint32_t)BOOT_SLOTS; e += 32) {
+        float v = __builtin_inff();
+        if (e < n_slots)
+            for (uint32_t f = 0; f < fold; ++f) {
+                const uint32_t t = e * fold + f;
+                if (t < n_tiles) v = fminf(v, tile_min[(size_t)t * nq_pad + q]);
+            }
+        row[e] = v;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= (uint32_t)BOOT_SLOTS; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = s; t < (uint32_t)BOOT_SLOTS / 2; t += 32) {
+                const uint32_t i = 2 * j * (t / j) + (t % j), p2 = i + j;
+                const float a = row[i], b = row[p2];
+                const bool up = (i & k) == 0;
+                if (up ? a > b : a < b) { row[i] = b; row[p2] = a; }
+            }
+            __syncthreads();
+        }
+    if (s == 0 && q < nq) {
+        const float t = kp <= n_slots ? row[kp - 1] : __builtin_inff();
+        tau[q] = t;
+        qconst[2 * q] = score_threshold(t, qconst[2 * q + 1]);
+    }
+}
+
 __global__ void fill_f32_kernel(float *p, float v, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +319,8 @@ static int ensure_gemm_attrs(smt_ctx *ctx)
         SMT_HIP_CHECK(gemm_level_set_attrs());
         SMT_HIP_CHECK(gemm_rowreg_set_attrs());
         SMT_HIP_CHECK(gemm_ldsrow_set_attrs());
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bootstrap_tau_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          QT_ROWS * BOOT_ROW * (int)sizeof(float)));
         ctx->attr_done |= ATTR_GEMM;
     }
     return SMT_OK;
@@ -357,7 +400,16 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const size_t b_split = bf16 ? (size_t)nqt * QT_ROWS * 1024 : 0;
     const size_t o_split = (b_cand + 2 * b_cnt + 3 * b_tau + 255) & ~(size_t)255;  // tau | thr | rq
     const size_t b_head = o_split + b_split;
-    int rc = ensure_scratch(ctx, b_head + (size_t)n_chunks * sizeof(uint64_t) + 64);
+    // the row-register kernel's bootstrap level: every s0-th tile, at most BOOTSTRAP_MAX_TILES of them (level plan below)
+    const uint64_t plan_tiles = !filtered ? (a.rows + 31) / 32 : rowreg ? n_chunks : (n_chunks + 7) / 8;
+    const bool bootstrap = rowreg && plan_tiles > (uint64_t)LEVEL0_MAX_TILES && ctx->tune.gemm_bootstrap != 0;
+    const int BOOT_RATIO = 16;
+    uint64_t boot_stride = 1;
+    while (bootstrap && (plan_tiles + boot_stride - 1) / boot_stride > (uint64_t)BOOTSTRAP_MAX_TILES) boot_stride *= BOOT_RATIO;
+    const uint64_t boot_tiles = bootstrap ? (plan_tiles + boot_stride - 1) / boot_stride : 0;
+    const size_t o_table = (b_head + 255) & ~(size_t)255;
+    const size_t o_tmin = (o_table + (size_t)n_chunks * sizeof(uint64_t) + 255) & ~(size_t)255;
+    int rc = ensure_scratch(ctx, o_tmin + (size_t)boot_tiles * nqt * QT_ROWS * sizeof(float) + 64);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(ctx->d_scratch);
     key_t64 *cand = reinterpret_cast<key_t64 *>(base);
@@ -365,7 +417,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     unsigned int *overflow = reinterpret_cast<unsigned int *>(base + b_cand + b_cnt);
     float *tau = reinterpret_cast<float *>(base + b_cand + 2 * b_cnt);
     float *qconst = tau + (size_t)nqt * QT_ROWS;   // [nqt*32][2]
-    uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + b_head);
+    uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + o_table);
+    float *tile_min = reinterpret_cast<float *>(base + o_tmin);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
     const BatchHead head{qconst, counts, overflow, tau};   // (fp16 modes are row-register modes)
     if (f16x1)
@@ -392,11 +445,53 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // level plan: strides ratio^(L-1) ... ratio, 1 with level 0 <= LEVEL0_MAX_TILES tiles
     const int LEVEL_RATIO = kp <= LEVEL_RATIO_KP_LIMIT ? LEVEL_RATIO_SMALL_K : LEVEL_RATIO_LARGE_K;
     // filtered: the entries of the tile table (row-register kernel), or 8 chunks of <= 4 rows each (LDS-row kernel)
-    const uint64_t n_tiles = !filtered ? (a.rows + 31) / 32 : rowreg ? n_chunks : (n_chunks + 7) / 8;
+    const uint64_t n_tiles = plan_tiles;
     int L = 1;
     uint64_t s0 = 1;
-    while ((n_tiles + s0 - 1) / s0 > (uint64_t)LEVEL0_MAX_TILES) { s0 *= LEVEL_RATIO; ++L; }
     int blocks = ctx->tune.gemm_blocks > 0 ? ctx->tune.gemm_blocks : ctx->num_cus;
+    if (bootstrap) {
+        // ---- BOOTSTRAP: every boot_stride-th tile, tile minima only, then the first thresholds; the appended levels start at
+        // stride boot_stride / ratio (or 1) and their first one visits EVERY multiple of its stride, the bootstrap's tiles included
+        // (1/ratio of that level: the price of a level without candidate lists)
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.corpus = a.corpus;
+        g.n_rows = a.rows;
+        g.queries = a.queries;
+        g.queries_split = q_split;
+        g.nq = a.nq;
+        g.nqt = nqt;
+        g.level_tiles = boot_tiles;
+        g.tile_begin = 0;
+        g.stride = boot_stride;
+        g.skip16 = 0;
+        g.qsplit = 1;
+        g.tau = tau;
+        g.qconst = qconst;
+        g.cand = cand;
+        g.counts = counts;
+        g.tile_table = filtered ? chunk_table : nullptr;
+        g.tile_min = tile_min;
+        g.image = use_image ? a.image : nullptr;
+        g.image_zero = use_image ? a.image_zero : nullptr;
+        const uint64_t need_blocks = (boot_tiles + RR_WAVES - 1) / RR_WAVES;
+        int nb = (int)std::min<uint64_t>((uint64_t)blocks, need_blocks);
+        if (ctx->tune.gemm_qsplit && need_blocks < (uint64_t)blocks) {
+            g.qsplit = (uint32_t)std::min<uint64_t>(nqt, std::max<uint64_t>(1, (uint64_t)2 * blocks / need_blocks));
+            nb = (int)(need_blocks * g.qsplit);
+        }
+        prof_begin(ctx, "gemm");
+        gemm_rowreg_launch(ctx, f16x1 ? 2 : f16x2 ? 1 : 0, use_image, nb, g);
+        prof_end(ctx, "gemm");
+        prof_begin(ctx, "select");
+        hipLaunchKernelGGL(bootstrap_tau_kernel, dim3(nqt), dim3(1024), (size_t)QT_ROWS * BOOT_ROW * sizeof(float), ctx->stream, tile_min,
+                           (uint32_t)boot_tiles, a.nq, nqt * QT_ROWS, kp, tau, qconst);
+        prof_end(ctx, "select");
+        s0 = boot_stride > 1 ? boot_stride / BOOT_RATIO : 1;
+        for (uint64_t t = s0; t > 1; t /= LEVEL_RATIO) ++L;
+    } else {
+        while ((n_tiles + s0 - 1) / s0 > (uint64_t)LEVEL0_MAX_TILES) { s0 *= LEVEL_RATIO; ++L; }
+    }
 
     uint64_t stride = s0;
     for (int lev = 0; lev < L; ++lev, stride /= LEVEL_RATIO) {
@@ -420,8 +515,9 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.counts = counts;
         g.chunk_table = filtered && !rowreg ? chunk_table : nullptr;
         g.tile_table = filtered && rowreg ? chunk_table : nullptr;
+        g.tile_min = nullptr;
         g.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
-        g.buffered = lev > 0 && ctx->tune.gemm_buffered != 0;
+        g.buffered = (lev > 0 || bootstrap) && ctx->tune.gemm_buffered != 0;   // (thresholds exist: nominations are few)
         g.image = use_image ? a.image : nullptr;
         g.image_zero = use_image ? a.image_zero : nullptr;
         g.n_chunks = n_chunks;
@@ -443,7 +539,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             if ((double)LEVEL_RATIO * kp * a.nq / ((double)g.level_tiles * g.qsplit) > 0.75 * RR_CB_CAP) g.buffered = 0;
             const uint64_t level_end = g.level_tiles;
             uint64_t part_end = level_end;
-            if (ctx->tune.gemm_split_last && lev == L - 1 && lev > 0 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
+            if (ctx->tune.gemm_split_last && lev == L - 1 && (lev > 0 || bootstrap) && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
                 level_end >= (uint64_t)64 * blocks * RR_WAVES)
                 part_end = (level_end / 8 + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
             for (;;) {

@@ -275,6 +275,8 @@ static void worker_main(smt_group *g, int i)
 static int group_start_workers(smt_group *g)
 {
     if (g->n_local <= 1 || g->workers) return SMT_OK;
+    // SEMTOOLS_GROUP_THREADS=0: the caller's thread issues every device's share itself (A/B, debugging)
+    if (const char *e = getenv("SEMTOOLS_GROUP_THREADS"); e && e[0] == '0') return SMT_OK;
     g->workers = new (std::nothrow) GroupWorkers();
     if (!g->workers) { set_error("out of host memory"); return SMT_E_NOMEM; }
     g->workers->rcs.assign(g->n_local, SMT_OK);
@@ -873,7 +875,7 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
             *status = (uint64_t)(uint32_t)(stage_rc < 0 ? -stage_rc : stage_rc);
             SMT_HIP_CHECK(hipMemcpyAsync(loc + list_words + nq, status, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
             return SMT_OK;
-        });
+        }, g->workers != nullptr);
         if (rc) return rc;
         for (int i = 0; i < g->n_local; ++i)
             if (stage_rcs[i] && !local_rc) { local_rc = stage_rcs[i]; local_err = stage_errs[i]; }
@@ -959,7 +961,7 @@ int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *q
         on_aux[i] = async ? 1 : 0;
         if (async) c->async_pending = true;
         return SMT_OK;
-    });
+    }, g->workers != nullptr);
     if (rc) return rc;
     if ((rc = allgather_words(g, 0, gath_off, list_words, &on_aux))) return rc;
     for (int i = 0; i < g->n_local; ++i) {

@@ -163,11 +163,8 @@ int layout_translate_packed(smt_sharded_corpus *sc, int i, hipStream_t st, uint6
     if (rp.empty() || nq == 0 || k == 0) return SMT_OK;
     int rc = group_bind(g, i);
     if (rc) return rc;
-    if (sc->d_table.size() != (size_t)g->n_local) {
-        sc->d_table.assign(g->n_local, nullptr);
-        sc->d_table_cap.assign(g->n_local, 0);
-        sc->d_table_version.assign(g->n_local, 0);
-    }
+    // (sized in sharded_new: the group's issuing threads call this for their devices at the same time)
+    SMT_REQUIRE(sc->d_table.size() == (size_t)g->n_local, "sharded corpus without device tables");
     if (sc->d_table_version[i] != sc->layout_version) {
         if (sc->d_table_cap[i] < rp.size()) {
             // (the old table may still be read by a kernel in flight: free after the device has drained)
@@ -209,6 +206,9 @@ static smt_sharded_corpus *sharded_new(smt_group *group)
     if (!sc) { set_error("out of host memory"); return nullptr; }
     sc->group = group;
     sc->shard.assign(group->n_local, nullptr);
+    sc->d_table.assign(group->n_local, nullptr);
+    sc->d_table_cap.assign(group->n_local, 0);
+    sc->d_table_version.assign(group->n_local, 0);
     layout_set_contiguous(sc, std::vector<uint64_t>(group->n_ranks, 0));
     return sc;
 }

@@ -161,6 +161,38 @@ def test_batched_with_row_ranges_reaches_the_mfma_path(gpu_ctx, nq):
     c.close()
 
 
+@pytest.mark.parametrize("n_rows", [33 * 32 + 5, 64 * 32, 1500 * 32 + 1, 2049 * 32 + 7, 300_000])
+def test_bootstrap_plan_and_appended_levels_plan_agree(gpu_ctx, n_rows):
+    """The row-register kernel's level plan starts from a BOOTSTRAP level (tile minima, no candidate lists: gemm_topk.hip) instead
+    of up to three appended levels.  Same answers as the round-1..3 plan (tuning key gemm_bootstrap = 0) and as the oracle, at the
+    sizes where the plan changes shape: 34 tiles (the smallest bootstrap), 64, 1501 (two tiles folded per slot), 2050 (the first
+    strided bootstrap), 9376; with a zero query, a zero row in the ragged last tile and duplicate rows."""
+    import semtools_amd as smt
+
+    emb = synth.unit_rows(n_rows, seed=7 + n_rows % 97)
+    emb[-1] = 0.0
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    try:
+        for nq in (8, 40, 300):
+            qs = synth.unit_query(90 + nq, nq=nq)
+            qs[3] = 0.0
+            for k in (1, 10, 40):
+                new = c.search(qs, top_k=k)
+                gpu_ctx.set_tuning("gemm_bootstrap", 0)
+                try:
+                    old = c.search(qs, top_k=k)
+                finally:
+                    gpu_ctx.set_tuning("gemm_bootstrap", 1)
+                for i, (x, y) in enumerate(zip(new, old)):
+                    assert x[0].tolist() == y[0].tolist() and np.array_equal(x[1], y[1]), (nq, k, i)
+                for i in (0, 3, nq - 1):
+                    orows, odist = _oracle_topk(emb, qs[i], k)
+                    assert new[i][0].tolist() == orows and np.array_equal(new[i][1], np.array(odist)), (nq, k, i)
+    finally:
+        c.close()
+
+
 def test_level_kernel_and_lds_row_kernel_agree(gpu_ctx):
     """In the non-row-register modes up to 64 queries take the LDS-row kernel; gemm_ldsrow = 0 sends them through
     gemm_level_kernel instead (A/B runs).  Same answers."""
