@@ -18,21 +18,76 @@ use std::ffi::CString;
 use std::path::{Path, PathBuf};
 use std::ptr;
 
-#[derive(Clone, Copy, serde::Serialize, serde::Deserialize)]
+#[derive(Clone, Copy)]
 struct Extent {
     first_row: u64,
     n_lines: u64,
 }
 
-/// `line_rows.json`
+/// `line_rows.json` AS THE C++ HOST LAYER WRITES IT (semtools_amd/csrc/host/store.cpp `flush_line_embeddings`): the two
+/// implementations open each other's workspaces.
+/// `{"extents": [{"path", "first_row", "n_rows"}], "generation": n, "shards": {"n_ranks": n, "pieces": [[rows, rank], ...]}}`
+#[derive(serde::Serialize, serde::Deserialize)]
+struct ExtentEntry {
+    path: String,
+    first_row: u64,
+    n_rows: u64,
+}
+#[derive(Default, serde::Serialize, serde::Deserialize)]
+struct Shards {
+    #[serde(default)]
+    n_ranks: i32,
+    /// (rows, rank) per piece of the global row numbering, in global order
+    #[serde(default)]
+    pieces: Vec<(u64, u32)>,
+}
 #[derive(Default, serde::Serialize, serde::Deserialize)]
 struct RowsFile {
-    extents: BTreeMap<String, Extent>,
-    /// (rows, rank) per piece of the global row numbering, in global order, and the group size it was dealt over
+    #[serde(default)]
+    extents: Vec<ExtentEntry>,
+    /// bumped whenever rows move or are rewritten in place; `line_index.gen` must name the same value for an index to be loaded
+    #[serde(default)]
+    generation: u64,
+    #[serde(default)]
+    shards: Shards,
+}
+
+/// What earlier revisions of THIS file wrote (round 2: a bare map path -> extent; round 3: `{extents: {path: ..}, n_ranks, pieces}`).
+/// Read for compatibility, never written.
+#[derive(serde::Deserialize)]
+struct OldExtent {
+    first_row: u64,
+    n_lines: u64,
+}
+#[derive(serde::Deserialize)]
+struct OldRowsFile {
+    extents: BTreeMap<String, OldExtent>,
     #[serde(default)]
     n_ranks: i32,
     #[serde(default)]
     pieces: Vec<(u64, u32)>,
+}
+#[derive(serde::Deserialize)]
+#[serde(untagged)]
+enum AnyRowsFile {
+    Current(RowsFile),
+    Round3(OldRowsFile),
+    Round2(BTreeMap<String, OldExtent>),
+}
+
+/// (extents, generation, n_ranks, pieces) of whatever form the file has; an unreadable table is an EMPTY one -- every document then
+/// counts as changed and is embedded again (a parse error must not brick the workspace)
+fn read_rows_file(text: &str) -> (BTreeMap<String, Extent>, u64, i32, Vec<(u64, u32)>) {
+    match serde_json::from_str::<AnyRowsFile>(text) {
+        Ok(AnyRowsFile::Current(f)) => (
+            f.extents.into_iter().map(|e| (e.path, Extent { first_row: e.first_row, n_lines: e.n_rows })).collect(),
+            f.generation, f.shards.n_ranks, f.shards.pieces),
+        Ok(AnyRowsFile::Round3(f)) => (
+            f.extents.into_iter().map(|(p, e)| (p, Extent { first_row: e.first_row, n_lines: e.n_lines })).collect(), 0, f.n_ranks, f.pieces),
+        Ok(AnyRowsFile::Round2(m)) => (
+            m.into_iter().map(|(p, e)| (p, Extent { first_row: e.first_row, n_lines: e.n_lines })).collect(), 0, 0, Vec::new()),
+        Err(_) => (BTreeMap::new(), 0, 0, Vec::new()),
+    }
 }
 
 pub struct HipLineStore {
@@ -41,6 +96,7 @@ pub struct HipLineStore {
     extents: BTreeMap<String, Extent>,
     dir: PathBuf,
     rows_on_disk: u64,
+    generation: u64,
 }
 
 impl HipLineStore {
@@ -48,20 +104,20 @@ impl HipLineStore {
         let dir = Path::new(root_dir).to_path_buf();
         let file = dir.join("line_embeddings.f32");
         let mut corpus = ptr::null_mut();
-        let mut table = RowsFile::default();
+        let (mut extents, mut generation, mut file_ranks, mut pieces) = (BTreeMap::new(), 0u64, 0i32, Vec::new());
         if file.exists() {
             let c = CString::new(file.to_string_lossy().as_bytes())?;
             if let Ok(text) = std::fs::read_to_string(dir.join("line_rows.json")) {
-                table = serde_json::from_str(&text)?;
+                (extents, generation, file_ranks, pieces) = read_rows_file(&text);
             }
             let mut n_ranks = 0i32;
             check(unsafe { smt_group_info(group, &mut n_ranks, ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut()) })?;
             // the same number of GPUs as the run that wrote the store: every shard gets its rows back; otherwise the
             // matrix is cut into ceil(N / n_ranks) ranges (the file is in global row order either way)
             let mut rc = SMT_E_INVALID;
-            if n_ranks > 1 && table.n_ranks == n_ranks && !table.pieces.is_empty() {
-                let rows: Vec<u64> = table.pieces.iter().map(|p| p.0).collect();
-                let rank: Vec<u32> = table.pieces.iter().map(|p| p.1).collect();
+            if n_ranks > 1 && file_ranks == n_ranks && !pieces.is_empty() {
+                let rows: Vec<u64> = pieces.iter().map(|p| p.0).collect();
+                let rank: Vec<u32> = pieces.iter().map(|p| p.1).collect();
                 rc = unsafe { smt_sharded_corpus_load_layout(group, c.as_ptr(), rows.as_ptr(), rank.as_ptr(), rows.len() as u64, &mut corpus) };
             }
             if rc == SMT_E_INVALID {
@@ -72,7 +128,9 @@ impl HipLineStore {
             check(unsafe { smt_sharded_corpus_create(group, SMT_DIM, &mut corpus) })?;
         }
         let rows_on_disk = if file.exists() { unsafe { smt_sharded_corpus_rows(corpus) } } else { 0 };
-        Ok(Self { group, corpus, extents: table.extents, dir, rows_on_disk })
+        // torn write: an extent that points past the rows on disk is dropped (its document is embedded again)
+        extents.retain(|_, e: &mut Extent| e.first_row + e.n_lines <= rows_on_disk);
+        Ok(Self { group, corpus, extents, dir, rows_on_disk, generation })
     }
 
     /// `upsert_line_embeddings` for one document: its lines are pooled on the GPUs straight into fresh corpus rows
@@ -100,8 +158,15 @@ impl HipLineStore {
         let n = unsafe { smt_sharded_corpus_layout(self.corpus, ptr::null_mut(), ptr::null_mut(), 0) } as usize;
         let (mut rows, mut rank) = (vec![0u64; n], vec![0u32; n]);
         unsafe { smt_sharded_corpus_layout(self.corpus, rows.as_mut_ptr(), rank.as_mut_ptr(), n as u64) };
-        let table = RowsFile { extents: self.extents.clone(), n_ranks, pieces: rows.into_iter().zip(rank).collect() };
-        std::fs::write(self.dir.join("line_rows.json"), serde_json::to_string(&table)?)?;
+        let table = RowsFile {
+            extents: self.extents.iter().map(|(p, e)| ExtentEntry { path: p.clone(), first_row: e.first_row, n_rows: e.n_lines }).collect(),
+            generation: self.generation,
+            shards: if n_ranks > 1 { Shards { n_ranks, pieces: rows.into_iter().zip(rank).collect() } } else { Shards::default() },
+        };
+        // (a sibling first, then rename: the table is replaced atomically, as store.cpp's write_file_atomic does)
+        let tmp = self.dir.join("line_rows.json.tmp");
+        std::fs::write(&tmp, serde_json::to_string_pretty(&table)?)?;
+        std::fs::rename(&tmp, self.dir.join("line_rows.json"))?;
         Ok(())
     }
 
