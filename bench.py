@@ -588,6 +588,13 @@ def measured_traffic(leg, rows=None):
     return entry.get("hbm_bytes_per_launch"), f"{entry.get('source')} ({entry.get('counter', 'FETCH_SIZE x2')}; not measured by this run)"
 
 
+def _traffic_entry(leg):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("legs", {}).get(leg)
+    except Exception:
+        return None
+
+
 def torch_topk_fp64(x, qv, k, chunk=2_000_000):
     """(distances, rows) of the k smallest fp64 cosine distances of the rows of x (unit rows / unit query), chunked:
     x.double() of a 100M-row shard would not fit."""
@@ -1224,8 +1231,9 @@ def bench_c5(smt, ctx, device, rows, k, nq=1000, nlist=4096, nprobe=8, rerank=12
                              "traffic_source": measured_traffic("ivf_adc_lpca" if local_pca else "ivf_adc_pq", rows)[1],
                              "algorithmic_bytes_per_launch": code_bytes + rescore_bytes, "code_bytes": code_bytes, "rescored_row_bytes": rescore_bytes,
                              "adc_ms_per_batch": adc_s * 1e3, "probe_ms_per_batch": ms_pr / max(n_pr, 1), "launches": n_adc,
-                             "note": "the re-scored rows are random 1 KiB reads that repeat across the queries of a batch (MALL hits); "
-                                     "the kernel is bound by shortlist selection (instruction issue), not by HBM: DESIGN.md 4.6"}}
+                             "valu_busy_frac": (_traffic_entry("ivf_adc_lpca" if local_pca else "ivf_adc_pq") or {}).get("valu_busy_frac"),
+                             "note": "counters (profiles/r04_ivf/): HBM traffic = 1.1-1.2 x these algorithmic bytes at 5.6 TB/s (0.70 of peak) "
+                                     "WHILE the VALUs are 0.65-0.68 busy (LUT lookups, shortlist selection): bound by both, HBM first"}}
 
     shipped = one_coding(True)
     try:

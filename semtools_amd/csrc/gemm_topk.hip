@@ -193,19 +193,30 @@ __global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_m
     extern __shared__ float s_v[];   // [32][BOOT_ROW]
     const uint32_t fold = (n_tiles + BOOT_SLOTS - 1) / BOOT_SLOTS;   // 1 or 2
     const uint32_t n_slots = (n_tiles + fold - 1) / fold;
-    {   // coalesced: a wave reads two 128-byte rows of the [tile][query] matrix per step; transposed into LDS
+    {   // coalesced: a wave reads two 128-byte rows of the [tile][query] matrix per load; ALL of a thread's loads are issued before the
+        // first is used (32 or 64 independent L2 reads in flight -- one after the other they cost a round trip each: 30 us of this
+        // kernel's first version); transposed into LDS
         const uint32_t qi = threadIdx.x & 31, s = threadIdx.x >> 5;
         const uint32_t q = blockIdx.x * QT_ROWS + qi;
         float *row = s_v + qi * BOOT_ROW;
-        for (uint32_t e = s; e < (uint32_t)BOOT_SLOTS; e += 32) {
-            float v = __builtin_inff();
-            if (e < n_slots)
-                for (uint32_t f = 0; f < fold; ++f) {
-                    const uint32_t t = e * fold + f;
-                    if (t < n_tiles) v = fminf(v, tile_min[(size_t)t * nq_pad + q]);
-                }
-            row[e] = v;
+        float v0[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t t = (s + 32u * e) * fold;
+            v0[e] = t < n_tiles ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
         }
+        if (fold == 2) {
+            float v1[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const uint32_t t = (s + 32u * e) * 2u + 1u;
+                v1[e] = t < n_tiles ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
+            }
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v0[e] = fminf(v0[e], v1[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 32; ++e) row[s + 32 * e] = v0[e];
     }
     __syncthreads();
     // the kp-th smallest of a query's 1024 values, built bit by bit (distances are >= 0: their bit patterns order like unsigned
