@@ -931,6 +931,10 @@ def bench_ingest(smt, ctx, n_lines, vocab=50_000):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         first = host._take_text(out).split("\n")[0]
+    try:   # where the calls' wall time went (PhaseTimer of the host layer: cumulative over the three calls)
+        phases = json.loads(host._take_text(L.lib().smt_host_timing_json()) or "{}")
+    except Exception:
+        phases = None
     model.close()
     try:
         first_d = float(first[first.rindex("(") + 1:first.rindex(")")])
@@ -940,7 +944,7 @@ def bench_ingest(smt, ctx, n_lines, vocab=50_000):
     return {"metric": "lines ingested/sec (split + tokenise + upload + K1 + one search, one MI355X)", "lines": n_lines, "text_bytes": len(content),
             "tokens": int(n_tok), "seconds": best, "lines_per_s": n_lines / best, "text_MB_per_s": len(content) / best / 1e6,
             "tokens_per_s": n_tok / best, "cores": cores, "host_cpu": _cpu_model(), "tokenizer": "whitespace-hash (host threads)",
-            "first_hit": first[:80], "checks": {"first_hit_is_the_query_line": bool(first_d < 1e-6)}}
+            "host_phases_ms_over_3_calls": phases, "first_hit": first[:80], "checks": {"first_hit_is_the_query_line": bool(first_d < 1e-6)}}
 
 
 def bench_embed(smt, ctx, device, n_lines, vocab=500_000, reps=5):

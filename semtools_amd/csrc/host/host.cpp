@@ -470,7 +470,9 @@ void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size
 {
     // encode_batch_fast is rayon-parallel upstream; here: one slice per hardware thread
     const size_t n = end - begin;
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 256));
+    // (at least 2048 lines per thread: starting a thread costs ~25 us, a whitespace-hashed line ~0.1 us -- 256 threads for a
+    // 65536-line batch spent more time being started than tokenising: profiles/r04_ingest.json)
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 2048));
     std::vector<std::vector<uint32_t>> part_ids(n_threads);
     std::vector<std::vector<uint64_t>> part_len(n_threads);
     const auto unk = tok_->unk_id();
@@ -536,10 +538,10 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
     if (batch_size == 0) batch_size = 1;
     // The reference's 16384-line batches are an allocation bound of its own pipeline; rows do not depend on how the lines
     // are batched.  Here a batch is what one round of tokenizer threads chews on, so it must be large enough to amortise
-    // starting them: SEMTOOLS_EMBED_BATCH overrides (default: the caller's value, at least 65536).
+    // starting them: SEMTOOLS_EMBED_BATCH overrides (default: the caller's value, at least 262144).
     {
         static const size_t env_batch = [] { const char *e = getenv("SEMTOOLS_EMBED_BATCH"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();
-        batch_size = env_batch ? env_batch : std::max<size_t>(batch_size, 65536);
+        batch_size = env_batch ? env_batch : std::max<size_t>(batch_size, 262144);
     }
     struct Slot { std::vector<uint32_t> ids; std::vector<uint64_t> offsets; };
     Slot slots[2];

@@ -179,7 +179,8 @@ static int batched_fallback(smt_ctx *ctx, smt_corpus *corpus, const float *queri
 //   10 M rows: 2 queries 2.03 | 1.77, 3: 3.54 | 1.84, 4: 3.24 | 1.71, 5: 4.83 | 1.75, 7: 6.71 | 1.77
 //    2 M rows: 2: 0.49 | 0.52, 3: 0.87 | 0.52, 4: 0.75 | 0.53;   1 M rows: 2: 0.27 | 0.36, 3: 0.44 | 0.37, 4: 0.42 | 0.37
 //  300 k rows: 3: 0.17 | 0.25 (K3's fixed cost: five level launches + selects)
-// => K3 from gemm_min_nq (3) queries on shards of gemm_min_rows_small (1 M) rows, from 2 queries on 4 x that.
+// => (rounds 2-3) K3 from gemm_min_nq (3) queries on shards of gemm_min_rows_small (1 M) rows, from 2 queries on 4 x that;
+// round 4: from gemm_min_nq queries when rows x queries >= 1.2 x gemm_min_rows_small (see below).
 static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
 {
     // (range-filtered calls whose rows fill their 32-row tiles well enough take the same kernel over a tile table -- tiles_dense,
@@ -204,7 +205,12 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
         if (corpus->image_mode == 1) corpus->image_mode = 0;   // (-1 when there was no room)
     }
     const bool image_scan = scan_sized && corpus->image && corpus->image_mode >= 0;
-    const bool batched = a.nq >= 8 || (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && scanned >= small) ||
+    // Round 4 (bootstrap level: three launches and three select passes fewer per batch) moved the crossover down; measured again
+    // (profiles/r04_k2_k3_small.json, us per device-resident call, K2 | K3, no image): 400 k rows 3 queries 175 | 172, 4: 182 | 170,
+    // 5: 244 | 171; 200 k rows 4: 115 | 134, 5: 152 | 133, 7: 210 | 138; 100 k rows 5: 104 | 120, 7: 141 | 129; 1 M rows 2: 236 | 275,
+    // 3: 377 | 296; 2 M rows 2: 428 | 457 -- K3 from gemm_min_nq queries once rows x queries reaches 1.2 x gemm_min_rows_small.
+    const bool batched = a.nq >= 8 ||
+                         (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && scanned * a.nq >= small + small / 5) ||
                          (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && scanned >= 4 * small) || image_scan;
     if (batched && fast_k3 && whole) {
         if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
