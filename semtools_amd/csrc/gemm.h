@@ -27,7 +27,7 @@ constexpr int LEVEL0_MAX_TILES = 32;
 // tiles' best distances -- the kp-th smallest of them bounds the final kp-th distance (the tiles are distinct, so are their best rows)
 // and is the first threshold.  Three levels (5, 77, 1221 tiles at 10 M rows: three launches whose nominations are slot grabs on the
 // same thousand counters with a memory round trip each, and three select passes) became one pass of plain stores.
-constexpr uint32_t BOOTSTRAP_MAX_TILES = 2048;
+constexpr uint32_t BOOTSTRAP_MAX_TILES = 8192;   // (bootstrap_tau_kernel folds up to 8 tiles into one of its 1024 slots)
 constexpr uint32_t GEMM_MAX_NQ = 3584;         // 4 x 32.5 KiB tile slots + 8 B per query fit the 160 KiB LDS
 
 struct GemmParams {
@@ -40,7 +40,7 @@ struct GemmParams {
     uint64_t level_tiles;     // tiles of the level: this launch visits [tile_begin, level_tiles) (gemm_rowreg_kernel; the others start at 0)
     uint64_t tile_begin;
     uint64_t stride;          // visited tile = stride * u(i)
-    int skip16;               // LEVEL_RATIO (64 or 16) when u skips the multiples of the ratio (they belong to earlier levels), else 0
+    int skip16;               // 64, 16 or 4 when u skips the multiples of that ratio (they belong to earlier levels), else 0
     uint32_t qsplit;          // gemm_level_kernel: blocks per row-tile group, each sweeping 1/qsplit of the query tiles
     const float *tau;         // [nqt*32] distance thresholds (+inf = take everything, <0 = padding)
     const float *qconst;      // gemm_rowreg_kernel: [nqt*32][2] = (score threshold = score_threshold(tau, rq), 1/|q|) per query;
@@ -67,7 +67,7 @@ __device__ __forceinline__ uint64_t level_tile(uint64_t i, uint64_t stride, int 
 {
     if (!skip16) return i * stride;
     // i-th positive integer that is not a multiple of the ratio (constant divisors: no runtime division)
-    const uint64_t d = skip16 == 64 ? i / 63 : i / 15;
+    const uint64_t d = skip16 == 64 ? i / 63 : skip16 == 16 ? i / 15 : i / 3;
     const uint64_t u = d * (uint64_t)skip16 + (i - d * (uint64_t)(skip16 - 1)) + 1;
     return u * stride;
 }

@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
 // The first threshold of a row-register batch: per query the kp-th smallest of the bootstrap level's tile minima (GemmParams::
 // tile_min, [n_tiles][nq_pad]).  The tiles are distinct, so at least kp ROWS have a nominating distance <= that value: it bounds the
 // final kp-th distance from above, which is all a level threshold has to do.  One block per query tile: 32 queries x 32 threads, the
-// values of a query in one LDS row (two tiles folded into a slot by their minimum beyond 1024 tiles), bitonic sort of the 32 rows.
+// values of a query in one LDS row (several tiles folded into a slot by their minimum beyond 1024 tiles), then the k'-th smallest bit by bit.
 constexpr int BOOT_SLOTS = 1024, BOOT_ROW = BOOT_SLOTS + 1;   // odd row stride: the 32 queries of a wave hit 32 different banks
 __global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_min, uint32_t n_tiles, uint32_t nq, uint32_t nq_pad, uint32_t kp,
                                                              float *tau, float *qconst)
 {
     extern __shared__ float s_v[];   // [32][BOOT_ROW]
-    const uint32_t fold = (n_tiles + BOOT_SLOTS - 1) / BOOT_SLOTS;   // 1 or 2
+    const uint32_t fold = (n_tiles + BOOT_SLOTS - 1) / BOOT_SLOTS;   // tiles per slot: 1 .. 8 (BOOTSTRAP_MAX_TILES)
     const uint32_t n_slots = (n_tiles + fold - 1) / fold;
     {   // coalesced: a wave reads two 128-byte rows of the [tile][query] matrix per load; ALL of a thread's loads are issued before the
         // first is used (32 or 64 independent L2 reads in flight -- one after the other they cost a round trip each: 30 us of this
@@ -201,15 +201,12 @@ __global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_m
         float *row = s_v + qi * BOOT_ROW;
         float v0[32];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const uint32_t t = (s + 32u * e) * fold;
-            v0[e] = t < n_tiles ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
-        }
-        if (fold == 2) {
+        for (int e = 0; e < 32; ++e) v0[e] = __builtin_inff();
+        for (uint32_t f = 0; f < fold; ++f) {   // slot e of this thread = the minimum over tiles (s + 32 e) * fold + f: distinct tiles, distinct rows
             float v1[32];
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
-                const uint32_t t = (s + 32u * e) * 2u + 1u;
+                const uint32_t t = (s + 32u * e) * fold + f;
                 v1[e] = t < n_tiles ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
             }
 #pragma unroll
@@ -427,9 +424,13 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // the row-register kernel's bootstrap level: every s0-th tile, at most BOOTSTRAP_MAX_TILES of them (level plan below)
     const uint64_t plan_tiles = !filtered ? (a.rows + 31) / 32 : rowreg ? n_chunks : (n_chunks + 7) / 8;
     const bool bootstrap = rowreg && plan_tiles > (uint64_t)LEVEL0_MAX_TILES && ctx->tune.gemm_bootstrap != 0;
-    const int BOOT_RATIO = 16;
+    // Bootstrap stride (see the level plan below): every tile up to 2048 tiles; every 16th up to 128 Ki tiles (4 M rows) -- ONE
+    // appended level over all tiles follows; beyond that every 64th (x 16 until <= BOOTSTRAP_MAX_TILES tiles are left).
     uint64_t boot_stride = 1;
-    while (bootstrap && (plan_tiles + boot_stride - 1) / boot_stride > (uint64_t)BOOTSTRAP_MAX_TILES) boot_stride *= BOOT_RATIO;
+    if (bootstrap && plan_tiles > 2048) {
+        boot_stride = plan_tiles <= (uint64_t)131072 ? 16 : 64;
+        while ((plan_tiles + boot_stride - 1) / boot_stride > (uint64_t)BOOTSTRAP_MAX_TILES) boot_stride *= 16;
+    }
     const uint64_t boot_tiles = bootstrap ? (plan_tiles + boot_stride - 1) / boot_stride : 0;
     const size_t o_table = (b_head + 255) & ~(size_t)255;
     const size_t o_tmin = (o_table + (size_t)n_chunks * sizeof(uint64_t) + 255) & ~(size_t)255;
@@ -466,12 +467,23 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                            __builtin_inff(), nqt * QT_ROWS);
     }
 
-    // level plan: strides ratio^(L-1) ... ratio, 1 with level 0 <= LEVEL0_MAX_TILES tiles
+    // LEVEL PLAN.  A level = every stride-th tile that no coarser level has visited (`skip` = the ratio to the coarser level: the
+    // multiples of it are left out; 0 = none left out), appended under the thresholds the levels before it produced.
+    //  * appended-levels plan (rounds 1-3; the f32 / LDS-row kernels, gemm_bootstrap = 0): strides 16^(L-1) ... 16, 1, the first level
+    //    <= LEVEL0_MAX_TILES tiles appended without a threshold.
+    //  * bootstrap plan (gemm_rowreg_kernel, round 4): a bootstrap level of tile minima gives the first thresholds; then
+    //      <= 2048 tiles: bootstrap over ALL tiles, one appended level over all of them (twice the work of a corpus of <= 64 k rows);
+    //      <= 128 Ki tiles: bootstrap over every 16th, one appended level over ALL tiles (1/16 multiplied twice; admits ~16 k');
+    //      larger: bootstrap over every 64th (x 16 while more than BOOTSTRAP_MAX_TILES are left), appended levels at strides
+    //      ... 64, 4 -- the first visits every multiple of its stride, the bootstrap's tiles included -- and a LAST level of
+    //      ratio 4: the 3/4 of the corpus it holds are appended under thresholds a quarter of the corpus produced (~4 k' rows per
+    //      query), and the level before it is a quarter of the corpus -- no level is thin any more.  (Rounds 2-3 had a 1/16 level
+    //      whose ~16 k' admissions per query fell on 6 % of the products -- 0.87 nominations per product against 0.06 in the main
+    //      level -- and a main level split in two to tighten its thresholds after an eighth: profiles/r04_k3/.)
     const int LEVEL_RATIO = kp <= LEVEL_RATIO_KP_LIMIT ? LEVEL_RATIO_SMALL_K : LEVEL_RATIO_LARGE_K;
-    // filtered: the entries of the tile table (row-register kernel), or 8 chunks of <= 4 rows each (LDS-row kernel)
     const uint64_t n_tiles = plan_tiles;
-    int L = 1;
-    uint64_t s0 = 1;
+    struct PlanLevel { uint64_t stride; int skip; };
+    std::vector<PlanLevel> plan;
     int blocks = ctx->tune.gemm_blocks > 0 ? ctx->tune.gemm_blocks : ctx->num_cus;
     if (bootstrap) {
         // ---- BOOTSTRAP: every boot_stride-th tile, tile minima only, then the first thresholds; the appended levels start at
@@ -511,16 +523,26 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         hipLaunchKernelGGL(bootstrap_tau_kernel, dim3(nqt), dim3(1024), (size_t)QT_ROWS * BOOT_ROW * sizeof(float), ctx->stream, tile_min,
                            (uint32_t)boot_tiles, a.nq, nqt * QT_ROWS, kp, tau, qconst);
         prof_end(ctx, "select");
-        s0 = boot_stride > 1 ? boot_stride / BOOT_RATIO : 1;
-        for (uint64_t t = s0; t > 1; t /= LEVEL_RATIO) ++L;
+        if (boot_stride <= 16) plan.push_back({1, 0});
+        else {
+            uint64_t st = boot_stride / 16;           // 4 x 16^j
+            plan.push_back({st, 0});
+            while (st > 4) { st /= 16; plan.push_back({st, 16}); }
+            plan.push_back({1, 4});
+        }
     } else {
-        while ((n_tiles + s0 - 1) / s0 > (uint64_t)LEVEL0_MAX_TILES) { s0 *= LEVEL_RATIO; ++L; }
+        uint64_t s0 = 1;
+        while ((n_tiles + s0 - 1) / s0 > (uint64_t)LEVEL0_MAX_TILES) s0 *= LEVEL_RATIO;
+        plan.push_back({s0, 0});
+        for (uint64_t st = s0; st > 1;) { st /= LEVEL_RATIO; plan.push_back({st, LEVEL_RATIO}); }
     }
+    const int L = (int)plan.size();
 
-    uint64_t stride = s0;
-    for (int lev = 0; lev < L; ++lev, stride /= LEVEL_RATIO) {
+    for (int lev = 0; lev < L; ++lev) {
+        const uint64_t stride = plan[lev].stride;
+        const int skip = plan[lev].skip;
         const uint64_t multiples = (n_tiles + stride - 1) / stride;                        // u in [0, multiples)
-        const uint64_t parents = lev == 0 ? 0 : (multiples + LEVEL_RATIO - 1) / LEVEL_RATIO;  // u % 16 == 0
+        const uint64_t parents = skip == 0 ? 0 : (multiples + (uint64_t)skip - 1) / (uint64_t)skip;   // u % skip == 0: visited before
         GemmParams g;
         g.corpus = a.corpus;
         g.n_rows = a.rows;
@@ -531,7 +553,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.level_tiles = multiples - parents;
         g.tile_begin = 0;
         g.stride = stride;
-        g.skip16 = lev == 0 ? 0 : LEVEL_RATIO;
+        g.skip16 = skip;
         g.qsplit = 1;
         g.tau = tau;
         g.qconst = qconst;
@@ -560,10 +582,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             // the LDS nomination buffer pays where a wave's sweep nominates fewer pairs than it holds (a level admits ~ratio x k'
             // rows per query): the thin early levels go straight to the lists, one slot grab per lane and tile -- fewer atomics
             // on the same thousand counters, which is what those levels are bound by
-            if ((double)LEVEL_RATIO * kp * a.nq / ((double)g.level_tiles * g.qsplit) > 0.75 * RR_CB_CAP) g.buffered = 0;
+            const int admit_ratio = skip ? skip : 16;   // rows admitted per query ~ admit_ratio x k'
+            if ((double)admit_ratio * kp * a.nq / ((double)g.level_tiles * g.qsplit) > 0.75 * RR_CB_CAP) g.buffered = 0;
             const uint64_t level_end = g.level_tiles;
             uint64_t part_end = level_end;
-            if (ctx->tune.gemm_split_last && lev == L - 1 && (lev > 0 || bootstrap) && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
+            if (ctx->tune.gemm_split_last && lev == L - 1 && (lev > 0 || bootstrap) && admit_ratio >= 16 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
                 level_end >= (uint64_t)64 * blocks * RR_WAVES)
                 part_end = (level_end / 8 + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
             for (;;) {
