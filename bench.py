@@ -1060,7 +1060,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     image_same = int(((rows_f32 == out_rows).all(dim=1) & (dist_f32 == out_dist).all(dim=1)).sum().item())
 
     # one query over the same 10 M rows: the scan kernel over the f32 rows (K2) against the batched kernel over the image, which
-    # is what a corpus that has its image does from 4 M rows per shard on (topk_dispatch, tuning key image_scan_min_rows)
+    # is what a corpus that has its image does from 1.5 M rows per shard on (topk_dispatch, tuning key image_scan_min_rows)
     def one_query(reps1=20):
         r1 = torch.empty(1, k, dtype=torch.int64, device=device)
         d1 = torch.empty(1, k, dtype=torch.float64, device=device)
@@ -1073,7 +1073,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         return (time.perf_counter() - t1) / reps1, r1, d1
     ctx.set_tuning("image_scan_min_rows", 0)
     s_f32, r_f32, d_f32 = one_query()
-    ctx.set_tuning("image_scan_min_rows", 4_000_000)
+    ctx.set_tuning("image_scan_min_rows", 1_500_000)
     s_img, r_img, d_img = one_query()
     single = {"rows": rows, "f32_scan_ms": s_f32 * 1e3, "f32_scan_rows_per_s": rows / s_f32, "image_ms": s_img * 1e3,
               "image_rows_per_s": rows / s_img, "image_frac_of_hbm_at_512B_per_row": rows * 512 / s_img / 8e12,

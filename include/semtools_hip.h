@@ -430,8 +430,8 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *                        operand image: f16 x 1 from 128 queries, f16 x 2 below, shards up to 2^28 rows
  *   corpus_image (1/0)   corpora the library owns build and keep their fp16 operand image (smt_corpus_prepack)
  *   gemm_image (1/0)     batched searches read the image when the corpus has one
- *   image_scan_min_rows  shards of at least this many rows (4 000 000; 0 = never) that HAVE their image answer 1-2 queries
- *                        from it as well, and build it at their fourth small search
+ *   image_scan_min_rows  shards of at least this many rows (1 500 000; 0 = never) that HAVE their image answer ONE query
+ *                        from it as well (2..7 queries from a third of that), and build it at their fourth small search
  *   gemm_buffered, gemm_split_last, embed_batched (1/0)   A/B switches of round-3 kernel changes
  *   gemm_bf16x3 (1/0)    K3 nominates with bf16 x 3 split products on the bf16 MFMA pipe (default) or with f32 MFMAs;
  *                        answers are identical either way (exact re-scoring + the exactness certificate)

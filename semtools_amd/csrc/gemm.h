@@ -27,7 +27,8 @@ constexpr int LEVEL0_MAX_TILES = 32;
 // tiles' best distances -- the kp-th smallest of them bounds the final kp-th distance (the tiles are distinct, so are their best rows)
 // and is the first threshold.  Three levels (5, 77, 1221 tiles at 10 M rows: three launches whose nominations are slot grabs on the
 // same thousand counters with a memory round trip each, and three select passes) became one pass of plain stores.
-constexpr uint32_t BOOTSTRAP_MAX_TILES = 8192;   // (bootstrap_tau_kernel folds up to 8 tiles into one of its 1024 slots)
+constexpr uint32_t BOOTSTRAP_MAX_TILES = 8192;   // (their minima are folded into 1024 slots: up to 8 tiles per slot)
+constexpr uint32_t BOOTSTRAP_SLOTS = 1024;
 constexpr uint32_t GEMM_MAX_NQ = 3584;         // 4 x 32.5 KiB tile slots + 8 B per query fit the 160 KiB LDS
 
 struct GemmParams {
@@ -55,7 +56,8 @@ struct GemmParams {
     // wanted rows << 32, build_tile_table_kernel) instead of the tiles themselves; nullptr = every tile, every row
     const uint64_t *tile_table = nullptr;
     // BOOTSTRAP level of gemm_rowreg_kernel (gemm_topk.hip launch_gemm_topk): no nominations -- the kernel stores, per visited tile and
-    // query, the best nominating distance of the tile's wanted rows: tile_min[level tile index][nqt * 32]
+    // query, the best nominating distance of the tile's wanted rows, folded by minimum into tile_min[level tile index % 1024][nqt * 32]
+    // (preset to +inf)
     float *tile_min = nullptr;
     const void *image;            // gemm_rowreg_kernel<MODE, true>: the corpus' fp16 operand image (16 KiB per 32-row tile) ...
     const uint32_t *image_zero;   // ... and per tile the mask of its zero rows

@@ -518,7 +518,12 @@ __global__ void __launch_bounds__(RR_THREADS, 2) gemm_rowreg_kernel(GemmParams p
                 m = fmaxf(m, __shfl_xor(m, 32));                          // the other half's 16 rows of the same query
                 const bool zero_row = __builtin_amdgcn_ballot_w64((zero16 & valid16) != 0u) != 0ull;   // simsimd: 0 against a zero row, else 1
                 const float d = qc.y == 0.0f ? (zero_row ? 0.0f : 1.0f) : fmaxf(1.0f - m * qc.y, 0.0f);
-                if (h == 0) p.tile_min[(size_t)it * ((size_t)p.nqt * QT_ROWS) + (size_t)qt * QT_ROWS + j] = d;
+                // slot = level tile index mod 1024: the tiles that share a slot are distinct (so are their best rows), the slot keeps
+                // their minimum -- a fire-and-forget atomic (distances are >= 0: their bit patterns order like unsigned integers)
+                if (h == 0)
+                    (void)__hip_atomic_fetch_min(reinterpret_cast<unsigned int *>(p.tile_min) + (size_t)(it & 1023u) * ((size_t)p.nqt * QT_ROWS) +
+                                                     (size_t)qt * QT_ROWS + j,
+                                                 __float_as_uint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
 #if (SMT_RR_EXP & 1)

@@ -186,56 +186,47 @@ __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
 // tile_min, [n_tiles][nq_pad]).  The tiles are distinct, so at least kp ROWS have a nominating distance <= that value: it bounds the
 // final kp-th distance from above, which is all a level threshold has to do.  One block per query tile: 32 queries x 32 threads, the
 // values of a query in one LDS row (several tiles folded into a slot by their minimum beyond 1024 tiles), then the k'-th smallest bit by bit.
-constexpr int BOOT_SLOTS = 1024, BOOT_ROW = BOOT_SLOTS + 1;   // odd row stride: the 32 queries of a wave hit 32 different banks
-__global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_min, uint32_t n_tiles, uint32_t nq, uint32_t nq_pad, uint32_t kp,
+constexpr int BOOT_SLOTS = (int)BOOTSTRAP_SLOTS, BOOT_ROW = BOOT_SLOTS + 1;   // odd row stride: the 32 queries of a wave hit 32 different banks
+__global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_min, uint32_t n_slots, uint32_t nq, uint32_t nq_pad, uint32_t kp,
                                                              float *tau, float *qconst)
 {
     extern __shared__ float s_v[];   // [32][BOOT_ROW]
-    const uint32_t fold = (n_tiles + BOOT_SLOTS - 1) / BOOT_SLOTS;   // tiles per slot: 1 .. 8 (BOOTSTRAP_MAX_TILES)
-    const uint32_t n_slots = (n_tiles + fold - 1) / fold;
-    {   // coalesced: a wave reads two 128-byte rows of the [tile][query] matrix per load; ALL of a thread's loads are issued before the
-        // first is used (32 or 64 independent L2 reads in flight -- one after the other they cost a round trip each: 30 us of this
-        // kernel's first version); transposed into LDS
+    {   // coalesced: a wave reads two 128-byte rows of the [slot][query] matrix per load, all 32 loads of a thread in flight at once
+        // (one after the other they cost a round trip each: 30 us of this kernel's first version); transposed into LDS
         const uint32_t qi = threadIdx.x & 31, s = threadIdx.x >> 5;
         const uint32_t q = blockIdx.x * QT_ROWS + qi;
         float *row = s_v + qi * BOOT_ROW;
         float v0[32];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) v0[e] = __builtin_inff();
-        for (uint32_t f = 0; f < fold; ++f) {   // slot e of this thread = the minimum over tiles (s + 32 e) * fold + f: distinct tiles, distinct rows
-            float v1[32];
-#pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                const uint32_t t = (s + 32u * e) * fold + f;
-                v1[e] = t < n_tiles ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
-            }
-#pragma unroll
-            for (int e = 0; e < 32; ++e) v0[e] = fminf(v0[e], v1[e]);
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t t = s + 32u * e;
+            v0[e] = t < n_slots ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
         }
 #pragma unroll
         for (int e = 0; e < 32; ++e) row[s + 32 * e] = v0[e];
     }
     __syncthreads();
     // the kp-th smallest of a query's 1024 values, built bit by bit (distances are >= 0: their bit patterns order like unsigned
-    // integers): 32 consecutive lanes own a query, 32 values each in registers; per bit one count over the lanes (31 x 32 compares and
-    // a five-step half-wave sum -- the bitonic sort this replaced took 150 us, longer than the three levels it stood in for)
+    // integers): 32 consecutive lanes own a query (two queries per wave), 32 values each in registers; per bit the count of values
+    // below the trial is 32 ballots and their popcounts -- scalar work, no cross-lane traffic (a bitonic sort of the rows took 150 us, a
+    // shuffle-reduced count 30)
     const uint32_t ql = threadIdx.x >> 5, l = threadIdx.x & 31;
     const uint32_t q = blockIdx.x * QT_ROWS + ql;
+    const bool upper = (threadIdx.x & 32u) != 0;
     uint32_t v[32];
 #pragma unroll
     for (int e = 0; e < 32; ++e) v[e] = __float_as_uint(s_v[ql * BOOT_ROW + l + 32 * e]);
     uint32_t ans = 0;
     for (int bit = 30; bit >= 0; --bit) {
         const uint32_t test = ans | (1u << bit);
-        uint32_t c = 0;
+        uint32_t c_lo = 0, c_hi = 0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) c += v[e] < test ? 1u : 0u;
-        c += __shfl_xor(c, 1);
-        c += __shfl_xor(c, 2);
-        c += __shfl_xor(c, 4);
-        c += __shfl_xor(c, 8);
-        c += __shfl_xor(c, 16);
-        if (c < kp) ans = test;   // fewer than kp values lie below `test`: the kp-th smallest is >= test
+        for (int e = 0; e < 32; ++e) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(v[e] < test);
+            c_lo += (uint32_t)__builtin_popcount((uint32_t)m);
+            c_hi += (uint32_t)__builtin_popcount((uint32_t)(m >> 32));
+        }
+        if ((upper ? c_hi : c_lo) < kp) ans = test;   // fewer than kp values lie below `test`: the kp-th smallest is >= test
     }
     if (l == 0 && q < nq) {
         const float t = kp <= n_slots ? __uint_as_float(ans) : __builtin_inff();
@@ -434,7 +425,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     const uint64_t boot_tiles = bootstrap ? (plan_tiles + boot_stride - 1) / boot_stride : 0;
     const size_t o_table = (b_head + 255) & ~(size_t)255;
     const size_t o_tmin = (o_table + (size_t)n_chunks * sizeof(uint64_t) + 255) & ~(size_t)255;
-    int rc = ensure_scratch(ctx, o_tmin + (size_t)boot_tiles * nqt * QT_ROWS * sizeof(float) + 64);
+    const uint64_t boot_slots = std::min<uint64_t>(boot_tiles, BOOTSTRAP_SLOTS);
+    int rc = ensure_scratch(ctx, o_tmin + (size_t)boot_slots * nqt * QT_ROWS * sizeof(float) + 64);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(ctx->d_scratch);
     key_t64 *cand = reinterpret_cast<key_t64 *>(base);
@@ -516,12 +508,14 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             g.qsplit = (uint32_t)std::min<uint64_t>(nqt, std::max<uint64_t>(1, (uint64_t)2 * blocks / need_blocks));
             nb = (int)(need_blocks * g.qsplit);
         }
+        const uint32_t n_fill = (uint32_t)(boot_slots * nqt * QT_ROWS);
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((n_fill + 255) / 256), dim3(256), 0, ctx->stream, tile_min, __builtin_inff(), n_fill);
         prof_begin(ctx, "gemm");
         gemm_rowreg_launch(ctx, f16x1 ? 2 : f16x2 ? 1 : 0, use_image, nb, g);
         prof_end(ctx, "gemm");
         prof_begin(ctx, "select");
         hipLaunchKernelGGL(bootstrap_tau_kernel, dim3(nqt), dim3(1024), (size_t)QT_ROWS * BOOT_ROW * sizeof(float), ctx->stream, tile_min,
-                           (uint32_t)boot_tiles, a.nq, nqt * QT_ROWS, kp, tau, qconst);
+                           (uint32_t)boot_slots, a.nq, nqt * QT_ROWS, kp, tau, qconst);
         prof_end(ctx, "select");
         if (boot_stride <= 16) plan.push_back({1, 0});
         else {

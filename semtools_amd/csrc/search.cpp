@@ -189,13 +189,17 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     const uint64_t small = (uint64_t)ctx->tune.gemm_min_rows_small;
     const uint64_t scanned = a.n_virtual;
     // A corpus that HAS its fp16 operand image answers even one or two queries through the batched kernel once the shard is
-    // large (tuning key image_scan_min_rows, 4 M): one pass over 512-B rows plus ~0.2 ms of levels and selects beats a scan
+    // large (tuning key image_scan_min_rows; 4 M in round 3, 1.5 M now): one pass over 512-B rows plus the levels and selects beats a scan
     // pass over 1 KiB rows -- 10 M rows: 0.95 against 1.5 ms; the scan kernel keeps the small shards and the async mode.
     // (A resident host asking one query at a time -- `semtools serve` -- never sends the batch of 8 that builds the image of an
     // owned corpus: the fourth small search of a shard this large builds it.)
     const bool whole = corpus->d_rows == a.corpus && corpus->rows == a.rows;
+    // Round 4, measured again with the bootstrap plan (profiles/r04_image_scan_sweep.json, us per call, scan of the f32 rows | batched
+    // kernel over the image): ONE query 1 M rows 170 | 170, 1.5 M 245 | 214, 2 M 321 | 264, 4 M 612 | 461; TWO queries 0.5 M 134 | 120,
+    // 1 M 230 | 167, 2 M 424 | 261 -- the image answers one query from image_scan_min_rows (1.5 M) rows, two and more from a third of that.
+    const uint64_t image_min = (uint64_t)ctx->tune.image_scan_min_rows / (a.nq >= 2 ? 3 : 1);
     const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && whole &&
-                            ctx->tune.image_scan_min_rows > 0 && scanned >= (uint64_t)ctx->tune.image_scan_min_rows;
+                            ctx->tune.image_scan_min_rows > 0 && scanned >= image_min;
     if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&
         ++corpus->small_searches >= 4) {
         const void *img;

@@ -80,7 +80,7 @@ def test_topk_random_shapes_over_the_operand_image(gpu_ctx, n, k, nq, seed, dup)
     try:
         got = c.search(qs, top_k=k)
     finally:
-        gpu_ctx.set_tuning("image_scan_min_rows", 4_000_000)
+        gpu_ctx.set_tuning("image_scan_min_rows", 1_500_000)
     for i in range(nq):
         orows, odist = _oracle(emb, qs[i], k)
         assert got[i][0].tolist() == orows, (i, n, k, nq, seed, dup)

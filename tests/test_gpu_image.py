@@ -144,7 +144,7 @@ def test_dealt_shards_build_their_images_and_answer_alike(smt):
 
 
 def test_one_query_scans_the_image_of_a_large_shard(smt):
-    """topk_dispatch: a shard of >= image_scan_min_rows rows (4 M by default; lowered here) that HAS its image answers one or two
+    """topk_dispatch: a shard of >= image_scan_min_rows rows (1.5 M by default; lowered here) that HAS its image answers one or two
     queries through the batched kernel (512 B per row) -- same rows, same f64 distances as the scan kernel over the f32 rows."""
     ctx = smt.Context(0)
     rows = _unit(300_000, 9)
@@ -172,7 +172,7 @@ def test_one_query_scans_the_image_of_a_large_shard(smt):
         assert ctx.prof_read("gemm")[0] == 0
         ctx.prof_enable(False)
     finally:
-        ctx.set_tuning("image_scan_min_rows", 4_000_000)
+        ctx.set_tuning("image_scan_min_rows", 1_500_000)
 
 
 def test_a_resident_host_gets_the_image_after_a_few_single_queries(smt):
@@ -194,7 +194,7 @@ def test_a_resident_host_gets_the_image_after_a_few_single_queries(smt):
         for i in range(4):
             assert _search(c, q[i:i + 1], 10) == got[i]          # the scan kernel says the same
     finally:
-        ctx.set_tuning("image_scan_min_rows", 4_000_000)
+        ctx.set_tuning("image_scan_min_rows", 1_500_000)
 
 
 def test_random_life_of_a_corpus_with_an_image(smt):

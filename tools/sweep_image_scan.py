@@ -36,7 +36,7 @@ for rows in (500_000, 1_000_000, 1_500_000, 2_000_000, 3_000_000, 4_000_000, 6_0
                 c.search_topk_device(q.data_ptr(), nq, 10, 0, o_r.data_ptr(), o_d.data_ptr())
             ctx.synchronize()
             row[name] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
-        ctx.set_tuning("image_scan_min_rows", 4_000_000)
+        ctx.set_tuning("image_scan_min_rows", 1_500_000)
         out.append(row)
         print(json.dumps(row), flush=True)
     c.close()
