@@ -182,40 +182,27 @@ __global__ void __launch_bounds__(1024) level_select_kernel(LevelSelectParams p)
     }
 }
 
-// The first threshold of a row-register batch: per query the kp-th smallest of the bootstrap level's tile minima (GemmParams::
-// tile_min, [n_tiles][nq_pad]).  The tiles are distinct, so at least kp ROWS have a nominating distance <= that value: it bounds the
-// final kp-th distance from above, which is all a level threshold has to do.  One block per query tile: 32 queries x 32 threads, the
-// values of a query in one LDS row (several tiles folded into a slot by their minimum beyond 1024 tiles), then the k'-th smallest bit by bit.
-constexpr int BOOT_SLOTS = (int)BOOTSTRAP_SLOTS, BOOT_ROW = BOOT_SLOTS + 1;   // odd row stride: the 32 queries of a wave hit 32 different banks
-__global__ void __launch_bounds__(1024) bootstrap_tau_kernel(const float *tile_min, uint32_t n_slots, uint32_t nq, uint32_t nq_pad, uint32_t kp,
-                                                             float *tau, float *qconst)
+// The first threshold of a row-register batch: per query the kp-th smallest of the bootstrap level's slot minima (GemmParams::
+// tile_min, [<= 1024 slots][nq_pad]; a slot = the minimum over the tiles that share it).  The tiles are distinct, so at least kp ROWS
+// have a nominating distance <= that value: it bounds the final kp-th distance from above, which is all a level threshold has to do.
+// One WAVE per pair of queries (32 lanes each, 32 slot values per lane in registers, read straight from the [slot][query] matrix: 4-byte
+// reads of 1024 different rows -- 16 x over-fetch of an L2-resident 4 MB, latency-bound at ~3 us); the k'-th smallest is then built
+// bit by bit, per bit 32 ballots and their popcounts.  Earlier forms, all one 1024-thread block per query TILE: a bitonic sort of the
+// 32 LDS rows (150 us -- more than the three levels it replaced), dependent loads + shuffle sums (35 us), one round of loads + ballots
+// (35 us still: sixteen waves on the four SIMDs of one CU issue 4 x 31 x 32 compares each, and at most 32 CUs were busy at all).
+__global__ void __launch_bounds__(64) bootstrap_tau_kernel(const float *tile_min, uint32_t n_slots, uint32_t nq, uint32_t nq_pad, uint32_t kp,
+                                                           float *tau, float *qconst)
 {
-    extern __shared__ float s_v[];   // [32][BOOT_ROW]
-    {   // coalesced: a wave reads two 128-byte rows of the [slot][query] matrix per load, all 32 loads of a thread in flight at once
-        // (one after the other they cost a round trip each: 30 us of this kernel's first version); transposed into LDS
-        const uint32_t qi = threadIdx.x & 31, s = threadIdx.x >> 5;
-        const uint32_t q = blockIdx.x * QT_ROWS + qi;
-        float *row = s_v + qi * BOOT_ROW;
-        float v0[32];
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const uint32_t t = s + 32u * e;
-            v0[e] = t < n_slots ? tile_min[(size_t)t * nq_pad + q] : __builtin_inff();
-        }
-#pragma unroll
-        for (int e = 0; e < 32; ++e) row[s + 32 * e] = v0[e];
-    }
-    __syncthreads();
-    // the kp-th smallest of a query's 1024 values, built bit by bit (distances are >= 0: their bit patterns order like unsigned
-    // integers): 32 consecutive lanes own a query (two queries per wave), 32 values each in registers; per bit the count of values
-    // below the trial is 32 ballots and their popcounts -- scalar work, no cross-lane traffic (a bitonic sort of the rows took 150 us, a
-    // shuffle-reduced count 30)
     const uint32_t ql = threadIdx.x >> 5, l = threadIdx.x & 31;
-    const uint32_t q = blockIdx.x * QT_ROWS + ql;
-    const bool upper = (threadIdx.x & 32u) != 0;
+    const uint32_t q = blockIdx.x * 2 + ql;
+    if (blockIdx.x * 2 >= nq) return;           // (both queries of the wave are padding)
+    const bool upper = ql != 0;
     uint32_t v[32];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) v[e] = __float_as_uint(s_v[ql * BOOT_ROW + l + 32 * e]);
+    for (int e = 0; e < 32; ++e) {
+        const uint32_t t = l + 32u * e;
+        v[e] = t < n_slots ? __float_as_uint(tile_min[(size_t)t * nq_pad + q]) : 0x7F800000u;
+    }
     uint32_t ans = 0;
     for (int bit = 30; bit >= 0; --bit) {
         const uint32_t test = ans | (1u << bit);
@@ -331,8 +318,6 @@ static int ensure_gemm_attrs(smt_ctx *ctx)
         SMT_HIP_CHECK(gemm_level_set_attrs());
         SMT_HIP_CHECK(gemm_rowreg_set_attrs());
         SMT_HIP_CHECK(gemm_ldsrow_set_attrs());
-        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bootstrap_tau_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          QT_ROWS * BOOT_ROW * (int)sizeof(float)));
         ctx->attr_done |= ATTR_GEMM;
     }
     return SMT_OK;
@@ -514,8 +499,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         gemm_rowreg_launch(ctx, f16x1 ? 2 : f16x2 ? 1 : 0, use_image, nb, g);
         prof_end(ctx, "gemm");
         prof_begin(ctx, "select");
-        hipLaunchKernelGGL(bootstrap_tau_kernel, dim3(nqt), dim3(1024), (size_t)QT_ROWS * BOOT_ROW * sizeof(float), ctx->stream, tile_min,
-                           (uint32_t)boot_slots, a.nq, nqt * QT_ROWS, kp, tau, qconst);
+        hipLaunchKernelGGL(bootstrap_tau_kernel, dim3(nqt * QT_ROWS / 2), dim3(64), 0, ctx->stream, tile_min, (uint32_t)boot_slots, a.nq,
+                           nqt * QT_ROWS, kp, tau, qconst);
         prof_end(ctx, "select");
         if (boot_stride <= 16) plan.push_back({1, 0});
         else {
