@@ -294,6 +294,14 @@ def main():
         if exchange:
             result["config"]["group"] = ginfo
 
+    # (K1 before the legs that allocate and free 10-100 GB: the 4 GB table of its uniform-id case is gathered ~5 % slower when it is
+    # allocated after such a cycle in the same process -- 6.2 ms alone, 6.55-6.9 ms after c4, same box, same binary)
+    if rank == 0 and world == 1 and not args.no_embed:
+        try:
+            result["embed"] = bench_embed(smt, ctx, device, args.embed_lines)
+        except Exception as exc:
+            result["embed"] = {"error": repr(exc)}
+
     if not args.no_c4:
         try:    # every rank takes part (row-sharded corpus, collective exchange); rank 0 reports
             c4 = bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host)
@@ -319,12 +327,6 @@ def main():
             result["ingest"] = bench_ingest(smt, ctx, args.ingest_lines)
         except Exception as exc:
             result["ingest"] = {"error": repr(exc)}
-
-    if rank == 0 and world == 1 and not args.no_embed:
-        try:
-            result["embed"] = bench_embed(smt, ctx, device, args.embed_lines)
-        except Exception as exc:
-            result["embed"] = {"error": repr(exc)}
 
     if rank == 0 and world == 1 and not args.no_ivfpq:
         try:
