@@ -836,7 +836,8 @@ def bench_workspace(smt, ctx, device, rows, k, nq_batch=256, n_docs=10_000, max_
         else:
             ach = scanned * ROW_BYTES / ker1 / 1e9 if ker1 else None
             one["roofline"] = {"kernel": "scan_topk_kernel<1, 4, nt, FILTERED> (K2 over the chunk table)", "bound": "hbm", "achieved": ach,
-                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS if ach else None, "traffic": None,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS if ach else None,
+                               "traffic": measured_traffic("workspace_one_query", scanned)[0], "traffic_source": measured_traffic("workspace_one_query", scanned)[1],
                                "algorithmic_bytes_per_launch": scanned * ROW_BYTES, "launches": n1 * 20}
         # a batch
         tb, kerb, nb, gotb = timed(q, True, 5, "gemm")
@@ -1143,7 +1144,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         return {"kernel": f"gemm_rowreg_kernel (K3, {names[issued]})", "bound": "mfma", "achieved": issued * flops / gemm_seconds / 1e12,
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": issued * flops / gemm_seconds / 2500e12, "traffic": t, "traffic_source": src,
                 "algorithmic_bytes_per_batch": rows * bytes_per_row,
-                "algorithmic_bytes_note": "`traffic` is the largest launch of the batch, 7/8 of 15/16 of the rows",
+                "algorithmic_bytes_note": "`traffic` is the largest launch of the batch: its last level, 3/4 of the rows",
                 "algorithmic_flops_per_batch": flops, "issued_16bit_mfma_flops_per_batch": issued * flops,
                 "algorithmic_rate_over_f32_mfma_peak": flops / gemm_seconds / 157.3e12,
                 "gemm_ms_per_batch": gemm_seconds * 1e3, "gemm_launches_per_batch": launches,
