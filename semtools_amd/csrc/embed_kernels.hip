@@ -50,8 +50,8 @@ struct EmbedParams {
 
 // PF: the token ids of step s + 1 are requested while the rows of step s are in flight (the next position is pure arithmetic on the
 // prefetched offsets), so a step waits for ONE memory round trip -- the rows -- instead of two in a row (ids, then rows).
-template <bool PF, int WAVES = 4, bool NT = false>
-__global__ void __launch_bounds__(256, WAVES) embed_kernel(EmbedParams p)
+template <bool PF>
+__global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
 {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
@@ -157,13 +157,8 @@ __global__ void __launch_bounds__(256, WAVES) embed_kernel(EmbedParams p)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // (plain loads, not nontemporal: natural text is Zipf-distributed and its hot rows must stay in L2 / MALL --
-                // measured with the nt policy: Zipf ids 3.50 -> 4.59 ms, uniform ids 5.97 -> 6.27 ms)
-                if constexpr (NT) {
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v v = ok ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row) + c * 16 + a) : (f4v){0.f, 0.f, 0.f, 0.f};
-                    r[u][c] = make_float4(v.x, v.y, v.z, v.w);
-                }
-                else r[u][c] = ok ? row[c * 16 + a] : make_float4(0.f, 0.f, 0.f, 0.f);
+                // measured with the nt policy: Zipf ids 3.50 -> 4.59 ms, uniform ids 5.97 -> 6.27 ms; round 4: 3.18 -> 4.68, 6.56 -> 6.77)
+                r[u][c] = ok ? row[c * 16 + a] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         // where the group stands after this step -- known before any row has arrived
@@ -238,11 +233,10 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     const uint64_t blocks = (groups + 15) / 16;    // 256 threads = 16 groups
     SMT_REQUIRE(blocks < (1ull << 24), "too many lines for one embed launch");
     prof_begin(ctx, "embed");
-    // (A/B: embed_batched bit 1 = ids prefetched one step ahead, bit 2 = that kernel at three waves per SIMD, no spills)
-    if ((ctx->tune.embed_batched & 10) == 10) hipLaunchKernelGGL((embed_kernel<true, 4, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);   // bit 3: nt row loads
-    else if ((ctx->tune.embed_batched & 6) == 6) hipLaunchKernelGGL((embed_kernel<true, 3>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
-    else if (ctx->tune.embed_batched & 2) hipLaunchKernelGGL((embed_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((embed_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+    // (A/B: embed_batched bit 1 = ids prefetched one step ahead.  Probed in round 4 and removed: the same kernel at three waves per
+    // SIMD without spills -- Zipf 3.11 -> 3.32 ms -- and nontemporal row loads -- 4.68 / 6.77 ms; profiles/r04_k1/)
+    if (ctx->tune.embed_batched & 2) hipLaunchKernelGGL(embed_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(embed_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
     prof_end(ctx, "embed");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;

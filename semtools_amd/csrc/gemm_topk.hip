@@ -76,7 +76,15 @@ struct BatchHead {
     float *qconst;          // [nq_pad][2], or nullptr: nothing but the image
     unsigned int *counts, *overflow;
     float *tau;
+    float *fill = nullptr;  // the bootstrap level's slot minima: n_fill floats preset to +inf by the same launch
+    uint32_t n_fill = 0;
 };
+__device__ __forceinline__ void batch_head_fill(const BatchHead &b)
+{
+    if (b.fill == nullptr) return;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n_fill; i += stride) b.fill[i] = __builtin_inff();
+}
 __device__ __forceinline__ void batch_head_f16(const BatchHead &b, uint32_t q, uint32_t nq, float a2, int lane)
 {
     if (b.qconst && lane == 0) {
@@ -92,6 +100,7 @@ __device__ __forceinline__ void batch_head_f16(const BatchHead &b, uint32_t q, u
 // 2^8, split into two fp16 parts.  One wave per query (the norm is needed first).
 __global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out, BatchHead head = {})
 {
+    batch_head_fill(head);
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq_pad) return;
@@ -112,6 +121,7 @@ __global__ void split_queries_f16_kernel(const float *queries, uint32_t nq, uint
 // The f16 x 1 image: the hi halves only, 512 B per query -- (K-step m, half h) -> 16 B at word 8 m + 4 h.
 __global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, uint32_t *out, BatchHead head = {})
 {
+    batch_head_fill(head);
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq_pad) return;
@@ -128,8 +138,15 @@ __global__ void split_queries_f16x1_kernel(const float *queries, uint32_t nq, ui
 // (also the per-batch resets when `counts` is given: counts / overflow flags to 0, tau to +inf -- one launch instead of three at
 // the head of a call whose GPU is idle and waits out every launch latency: ~20 us of a 0.9 ms call)
 __global__ void query_consts_kernel(const float *queries, uint32_t nq, uint32_t nq_pad, float *qconst, int f16x2,
-                                    unsigned int *counts = nullptr, unsigned int *overflow = nullptr, float *tau = nullptr)
+                                    unsigned int *counts = nullptr, unsigned int *overflow = nullptr, float *tau = nullptr,
+                                    float *fill = nullptr, uint32_t n_fill = 0)
 {
+    {
+        BatchHead f{};
+        f.fill = fill;
+        f.n_fill = n_fill;
+        batch_head_fill(f);
+    }
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq_pad) return;
@@ -422,7 +439,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     uint64_t *chunk_table = reinterpret_cast<uint64_t *>(base + o_table);
     float *tile_min = reinterpret_cast<float *>(base + o_tmin);
     uint32_t *q_split = reinterpret_cast<uint32_t *>(base + o_split);
-    const BatchHead head{qconst, counts, overflow, tau};   // (fp16 modes are row-register modes)
+    BatchHead head{qconst, counts, overflow, tau};   // (fp16 modes are row-register modes)
+    if (bootstrap) {   // the bootstrap level's slot minima are preset to +inf by the head launch (one launch fewer in front of the batch)
+        head.fill = tile_min;
+        head.n_fill = (uint32_t)(boot_slots * nqt * QT_ROWS);
+    }
     if (f16x1)
         hipLaunchKernelGGL(split_queries_f16x1_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, q_split, head);
@@ -434,7 +455,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                            nqt * QT_ROWS, q_split);
     if (rowreg && !(f16x1 || f16x2))   // bf16 x 3: its split kernel has no wave per query
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
-                           nqt * QT_ROWS, qconst, 0, counts, overflow, tau);
+                           nqt * QT_ROWS, qconst, 0, counts, overflow, tau, head.fill, head.n_fill);
     if (filtered && rowreg) {
         if ((rc = launch_build_tile_table(ctx, a.ranges, a.range_tile_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
     } else if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
@@ -493,8 +514,6 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             g.qsplit = (uint32_t)std::min<uint64_t>(nqt, std::max<uint64_t>(1, (uint64_t)2 * blocks / need_blocks));
             nb = (int)(need_blocks * g.qsplit);
         }
-        const uint32_t n_fill = (uint32_t)(boot_slots * nqt * QT_ROWS);
-        hipLaunchKernelGGL(fill_f32_kernel, dim3((n_fill + 255) / 256), dim3(256), 0, ctx->stream, tile_min, __builtin_inff(), n_fill);
         prof_begin(ctx, "gemm");
         gemm_rowreg_launch(ctx, f16x1 ? 2 : f16x2 ? 1 : 0, use_image, nb, g);
         prof_end(ctx, "gemm");

@@ -1,5 +1,6 @@
-"""K1 A/B in one process (boxes differ by more than the effect): tuning key embed_batched = 1 (parked lines, the round-3 kernel),
-3 (+ token ids prefetched one step ahead, four waves per SIMD) and 7 (the same at three waves per SIMD, no spills), alternating;
+"""K1 A/B in one process (boxes differ by more than the effect): tuning key embed_batched = 1 (parked lines, the round-3 kernel) and
+3 (+ token ids prefetched one step ahead; the default), alternating (the round-4 probes 7 = three waves per SIMD and 11 = nontemporal row
+loads were measured with this script -- profiles/r04_k1/ -- and removed from the library);
 Zipf ids over a 500 k-row table and uniform ids over a 4 M-row table, 2 M ragged lines -- kernel ms (HIP events) per variant, with the
 shader / memory clocks and the power draw rocm-smi reports beside them."""
 import json
@@ -26,7 +27,7 @@ def smi():
 dev = torch.device("cuda:0")
 ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 out = {"idle": smi()}
-variants = [int(v) for v in sys.argv[1:]] or [1, 3, 7]
+variants = [int(v) for v in sys.argv[1:]] or [1, 3]
 for rnd in range(3):
     for b in variants:
         ctx.set_tuning("embed_batched", b)
