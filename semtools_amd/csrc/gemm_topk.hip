@@ -220,20 +220,39 @@ __global__ void __launch_bounds__(64) bootstrap_tau_kernel(const float *tile_min
         const uint32_t t = l + 32u * e;
         v[e] = t < n_slots ? __float_as_uint(tile_min[(size_t)t * nq_pad + q]) : 0x7F800000u;
     }
+    // Each lane keeps only its KEEP smallest values (insertion through a min / max chain): the k'-th smallest of that SUBSET is >= the
+    // k'-th smallest of all 1024 -- still at least k' slots lie at or below it, so it is still a valid threshold -- and equal to it
+    // unless one lane holds more than KEEP of the k' best (k' = 34 over 32 lanes: ~1 per lane expected).  The bit loop then counts
+    // KEEP values per lane instead of 32.
+    constexpr int KEEP = 6;
+    uint32_t s6[KEEP];
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) s6[i] = 0x7F800000u;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        uint32_t x = v[e];
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const uint32_t lo = x < s6[i] ? x : s6[i], hi = x < s6[i] ? s6[i] : x;
+            s6[i] = lo;
+            x = hi;
+        }
+    }
     uint32_t ans = 0;
     for (int bit = 30; bit >= 0; --bit) {
         const uint32_t test = ans | (1u << bit);
         uint32_t c_lo = 0, c_hi = 0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(v[e] < test);
+        for (int i = 0; i < KEEP; ++i) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(s6[i] < test);
             c_lo += (uint32_t)__builtin_popcount((uint32_t)m);
             c_hi += (uint32_t)__builtin_popcount((uint32_t)(m >> 32));
         }
         if ((upper ? c_hi : c_lo) < kp) ans = test;   // fewer than kp values lie below `test`: the kp-th smallest is >= test
     }
     if (l == 0 && q < nq) {
-        const float t = kp <= n_slots ? __uint_as_float(ans) : __builtin_inff();
+        // (fewer than kp finite values in the subset: the construction ends at the pattern of +inf or above -- no threshold yet)
+        const float t = kp <= n_slots && ans < 0x7F800000u ? __uint_as_float(ans) : __builtin_inff();
         tau[q] = t;
         qconst[2 * q] = score_threshold(t, qconst[2 * q + 1]);
     }
