@@ -24,6 +24,8 @@
 #include <limits>
 #include <condition_variable>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <thread>
 
 #include <functional>
@@ -261,7 +263,10 @@ static void worker_main(smt_group *g, int i)
             seen = w->epoch;
             work = w->work;
         }
-        const int rc = (*work)(i);
+        int rc;
+        try { rc = (*work)(i); }   // (an exception must reach the caller as a status, not std::terminate the process from this thread)
+        catch (const std::bad_alloc &) { set_error("out of host memory"); rc = SMT_E_NOMEM; }
+        catch (const std::exception &e) { set_error("%s", e.what()); rc = SMT_E_INVALID; }
         std::string err = rc ? smt_last_error() : "";   // (thread-local: carried back to the caller's thread)
         {
             std::lock_guard<std::mutex> lk(w->mu);
@@ -306,7 +311,9 @@ int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool
     std::vector<int> rcs(g->n_local, SMT_OK);
     std::vector<std::string> errs(g->n_local);
     auto run = [&](int i) {
-        rcs[i] = work(i);
+        try { rcs[i] = work(i); }
+        catch (const std::bad_alloc &) { set_error("out of host memory"); rcs[i] = SMT_E_NOMEM; }
+        catch (const std::exception &e) { set_error("%s", e.what()); rcs[i] = SMT_E_INVALID; }
         if (rcs[i]) errs[i] = smt_last_error();   // (thread-local: carry it back to the caller's thread)
     };
     if (g->n_local == 1 || !threads) {
