@@ -34,7 +34,7 @@ void check(int rc, const char *what)
 }
 
 // ------------------------------------------------------------------ strings / files
-std::vector<std::string> lines_of(const std::string &content)
+std::vector<std::string> lines_of(std::string_view content)
 {
     // str::lines() (mod.rs:51): split at '\n', a '\r' before it belongs to the line ending, a last line without terminator is kept.
     // Pass 1 finds the line starts; pass 2 builds the strings -- on several threads for big files (a million small allocations were
@@ -54,7 +54,7 @@ std::vector<std::string> lines_of(const std::string &content)
             size_t end = i + 1 < starts.size() ? starts[i + 1] - 1 : n;       // the '\n' (or the end of the content)
             if (i + 1 == starts.size() && end > start && content[end - 1] == '\n') --end;   // (last line WITH a terminator)
             if (end > start && content[end - 1] == '\r' && (i + 1 < starts.size() || (end < n && content[end] == '\n'))) --end;  // "\r\n"
-            out[i].assign(content, start, end - start);
+            out[i].assign(content.data() + start, end - start);
         }
     };
     if (starts.size() >= 65536) parallel_slices(starts.size(), 16384, build);
@@ -460,17 +460,20 @@ std::string PhaseTimer::json()
 }
 
 // model2vec-rs truncate_str: keep at most max_tokens * median_token_length characters
-static std::string truncate_str(const std::string &s, size_t max_tokens, size_t median_len)
+// (returns the number of BYTES to keep: almost every line is kept whole, and copying it just to hand it to the tokenizer was a heap
+// allocation per line)
+static size_t truncate_len(const std::string &s, size_t max_tokens, size_t median_len)
 {
     const size_t max_chars = max_tokens * median_len;
+    if (s.size() <= max_chars) return s.size();   // (at least one byte per character)
     size_t chars = 0;
     for (size_t i = 0; i < s.size(); ++i) {
         if (((unsigned char)s[i] & 0xC0) != 0x80) {
-            if (chars == max_chars) return s.substr(0, i);
+            if (chars == max_chars) return i;
             ++chars;
         }
     }
-    return s;
+    return s.size();
 }
 
 void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size_t begin, size_t end,
@@ -494,8 +497,10 @@ void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size
         std::vector<uint32_t> tmp;
         for (size_t i = b; i < e; ++i) {
             tmp.clear();
-            if (max_length) tok_->encode(truncate_str(sentences[i], *max_length, tok_->median_token_length()), tmp);
-            else tok_->encode(sentences[i], tmp);
+            const std::string &src = sentences[i];
+            const size_t keep = max_length ? truncate_len(src, *max_length, tok_->median_token_length()) : src.size();
+            if (keep == src.size()) tok_->encode(src, tmp);
+            else tok_->encode(src.substr(0, keep), tmp);
             if (unk) tmp.erase(std::remove(tmp.begin(), tmp.end(), *unk), tmp.end());
             if (max_length && tmp.size() > *max_length) tmp.resize(*max_length);
             part_ids[t].insert(part_ids[t].end(), tmp.begin(), tmp.end());
@@ -613,7 +618,7 @@ Embeddings::Embeddings(smt_group *group) { check(smt_sharded_corpus_create(group
 Embeddings::~Embeddings() { smt_sharded_corpus_destroy(corpus_); }
 uint64_t Embeddings::rows() const { return smt_sharded_corpus_rows(corpus_); }
 
-std::optional<Document> create_document_from_content(const std::string &filename, const std::string &content,
+std::optional<Document> create_document_from_content(const std::string &filename, std::string_view content,
                                                      const StaticModel &model, bool ignore_case, Embeddings &emb)
 {
     std::vector<std::string> lines = lines_of(content);

@@ -21,6 +21,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -33,7 +34,7 @@ struct Error : std::runtime_error {
 };
 
 // Rust str::lines(): split on '\n', strip one trailing '\r', no trailing empty piece.
-std::vector<std::string> lines_of(const std::string &content);
+std::vector<std::string> lines_of(std::string_view content);
 // Rust str::to_lowercase() (simple per-code-point mapping; see DESIGN.md for the caveat).
 std::string to_lowercase(const std::string &s);
 std::string read_to_string(const std::string &path);  // throws Error like `?` on io::Error
@@ -171,7 +172,7 @@ private:
 };
 
 // src/search/mod.rs:49-75: None for empty content; original lines kept; lower-cased copy embedded
-std::optional<Document> create_document_from_content(const std::string &filename, const std::string &content,
+std::optional<Document> create_document_from_content(const std::string &filename, std::string_view content,
                                                      const StaticModel &model, bool ignore_case, Embeddings &emb);
 
 // src/search/mod.rs:77-120.  `documents` must be in the order their lines were embedded into `emb`.
