@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip BASELINE config c4 (100M rows over the N GPUs)")
     ap.add_argument("--c4-rows", type=int, default=100_000_000, help="TOTAL rows of config c4 (split over the GPUs)")
     ap.add_argument("--c4-steps", type=int, default=40)
+    ap.add_argument("--no-group-issue", action="store_true", help="skip the host-issue cost of an 8-shard logical group")
     ap.add_argument("--no-workspace", action="store_true", help="skip the workspace-mode leg (range-filtered searches, A10)")
     ap.add_argument("--ws-rows", type=int, default=10_000_000)
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest leg (tokenise || H2D || K1 through the host layer)")
@@ -315,6 +316,12 @@ def main():
             result["secondary"] = bench_c3(smt, ctx, device, args.c3_rows, args.c3_queries, k)
         except Exception as exc:  # never let an auxiliary leg take the headline line down with it
             result["secondary"] = {"error": repr(exc)}
+
+    if rank == 0 and world == 1 and not args.no_group_issue:
+        try:
+            result["group_issue"] = bench_group_issue(smt, device)
+        except Exception as exc:
+            result["group_issue"] = {"error": repr(exc)}
 
     if rank == 0 and world == 1 and not args.no_workspace:
         try:
@@ -549,6 +556,9 @@ def compact_line(d):
     put("ws_batch_image_queries_per_s", "workspace", "batch_image", "queries_per_s")
     put("ws_batch_image_ms", "workspace", "batch_image", "ms_per_call")
     put("ws_batch_image_cost_per_scanned_row_vs_unfiltered", "workspace", "batch_image", "cost_per_scanned_row_vs_unfiltered")
+    # several shards driven by one host thread (logical group on one GPU: the issue cost, not the collective)
+    put("group_issue_us_8_logical_shards", "group_issue", "host_issue_us_per_search")
+    put("group_launches_only_us_8_shards", "group_issue", "one_thread_issues_every_shard_us")
     # K1 (embed) and the host step in front of it
     put("embed_lines_per_s_zipf", "embed", "zipf_ids_500k_table", "lines_per_s")
     put("embed_frac_hbm_zipf_measured_traffic", "embed", "zipf_ids_500k_table", "roofline", "frac")
@@ -753,6 +763,70 @@ def bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host):
         "checks": {"torch_fp64_topk_distances_match": ok, "rows_in_range": rows_ok, "rows_match_fp64_topk": rows_match,
                    "selects_without_exactness_certificate": uncertain},
     }
+
+
+def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):
+    """What ONE host thread pays to issue a 1-query search over n_shards row shards (the caller of the library is one
+    synchronous thread: src/bin/semtools.rs:134-135).  On one GPU the shards are logical ranks of this device (device copies in
+    place of RCCL; their GPU work serialises): the figure of interest is the HOST time inside smt_sharded_search_topk_device, not the
+    end-to-end time.  Beside it: the same thread issuing the shards' scan + select launches itself, one after the other."""
+    import ctypes as C
+
+    from semtools_amd import _lib as L
+    g = torch.Generator(device=device)
+    g.manual_seed(3)
+    shards = []
+    for _ in range(n_shards):
+        x = torch.randn(rows, 256, device=device, generator=g)
+        x /= x.norm(dim=1, keepdim=True)
+        shards.append(x)
+    q = torch.randn(16, 256, device=device, generator=g)
+    q /= q.norm(dim=1, keepdim=True)
+    torch.cuda.synchronize(device)
+    grp = smt.Group.logical(device.index or 0, n_shards)
+    sc = smt.ShardedCorpus(grp, device_ptrs=[sh.data_ptr() for sh in shards], shard_rows=[rows] * n_shards)
+    outs = [torch.empty((2, k), dtype=torch.int64, device=device) for _ in range(n_shards)]
+    qp = [(C.c_void_p * n_shards)(*[C.c_void_p(q[j].data_ptr())] * n_shards) for j in range(16)]
+    op = (C.c_void_p * n_shards)(*[C.c_void_p(o.data_ptr()) for o in outs])
+    fn = L.lib().smt_sharded_search_topk_device
+    for j in range(8):
+        L.check(fn(sc._h, qp[j % 16], 1, k, op))
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for j in range(n):
+        fn(sc._h, qp[j % 16], 1, k, op)
+    issued = time.perf_counter() - t0
+    grp.synchronize()
+    total = time.perf_counter() - t0
+    got = outs[0].cpu().numpy()
+    allx = torch.cat(shards)
+    d = 1.0 - (allx.double() @ q[(n - 1) % 16].double())
+    tv, ti = torch.topk(d, k, largest=False)
+    ok = bool(got[0].tolist() == ti.cpu().tolist())
+    del allx, d
+    views = [sc.shard(i)[0] for i in range(n_shards)]
+    o_r = [torch.empty(k, dtype=torch.int64, device=device) for _ in range(n_shards)]
+    o_d = [torch.empty(k, dtype=torch.float64, device=device) for _ in range(n_shards)]
+    fn1 = L.lib().smt_search_topk_device
+    args1 = [(views[i]._h, C.c_void_p(q[0].data_ptr()), 1, k, 0, C.c_void_p(o_r[i].data_ptr()), C.c_void_p(o_d[i].data_ptr())) for i in range(n_shards)]
+    for a in args1:
+        L.check(fn1(*a))
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        for a in args1:
+            fn1(*a)
+    serial = (time.perf_counter() - t0) / n
+    grp.synchronize()
+    sc.close()
+    grp.close()
+    del shards
+    torch.cuda.empty_cache()
+    return {"metric": "host microseconds to issue one sharded search (one caller thread)", "shards": n_shards, "rows_per_shard": rows,
+            "transport": "logical ranks on one device: event-ordered device copies instead of RCCL (the collective itself cannot run on one GPU)",
+            "host_issue_us_per_search": issued / n * 1e6, "end_to_end_us_per_search": total / n * 1e6,
+            "one_thread_issues_every_shard_us": serial * 1e6, "one_shard_scan_us": 150.0,
+            "checks": {"last_answer_matches_fp64_topk": ok}}
 
 
 def bench_workspace(smt, ctx, device, rows, k, nq_batch=256, n_docs=10_000, max_d=0.9):

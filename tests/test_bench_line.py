@@ -29,7 +29,7 @@ def test_compact_line_fits_the_drivers_tail_and_carries_every_leg():
     assert len(line["cpu_baseline"]["sample"]) <= 120      # the driver's `parsed` cuts strings there
     for key in ("c3_queries_per_s", "c3_ms_per_batch", "c3_frac_of_2p5PF", "c3_image_queries_per_s", "c3_f32mfma_frac_of_157TF",
                 "c4_rows_per_s", "c4_frac_hbm", "embed_frac_hbm_uniform", "ivf_recall_at_k", "ivf_queries_per_s",
-                "ws_1q_frac_hbm", "ws_batch_queries_per_s", "ws_batch_cost_per_scanned_row_vs_unfiltered", "ingest_lines_per_s", "ingest_cores",
+                "ws_1q_frac_hbm", "ws_batch_queries_per_s", "ws_batch_cost_per_scanned_row_vs_unfiltered", "ingest_lines_per_s", "ingest_cores", "group_issue_us_8_logical_shards",
                 "checks_ok", "checks_failed", "checks_total"):
         assert key in line, key
     assert line["checks_ok"] is True and line["checks_failed"] == []

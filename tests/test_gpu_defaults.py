@@ -163,7 +163,7 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
     env = dict(os.environ, SEMTOOLS_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--settle-steps", "8",
-           "--no-secondary", "--no-ivfpq", "--no-embed", "--no-cpu-baseline", "--no-workspace", "--no-ingest", "--c4-rows", "4000000",
+           "--no-secondary", "--no-ivfpq", "--no-embed", "--no-cpu-baseline", "--no-workspace", "--no-ingest", "--no-group-issue", "--c4-rows", "4000000",
            "--c4-steps", "4", "--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_forced_exchange.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

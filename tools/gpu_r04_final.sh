@@ -20,15 +20,15 @@ stats() {  # name, bench flags...
   head -4 "$out/${tag}_bench_${name}_kernel_stats.csv" | cut -c1-160
 }
 step "kernel stats per leg"
-stats c2 --steps 1000 --warmup 100 --no-c4 --no-secondary --no-embed --no-ivfpq --no-workspace --no-ingest
-stats c4 --steps 20 --warmup 5 --no-secondary --no-embed --no-ivfpq --no-workspace --no-ingest
-stats c3 --steps 20 --warmup 5 --no-c4 --no-embed --no-ivfpq --no-workspace --no-ingest
-stats workspace --steps 20 --warmup 5 --no-c4 --no-secondary --no-embed --no-ivfpq --no-ingest
-stats embed --steps 20 --warmup 5 --no-c4 --no-secondary --no-ivfpq --no-workspace --no-ingest
-stats ivfpq --steps 20 --warmup 5 --no-c4 --no-secondary --no-embed --no-workspace --no-ingest
+stats c2 --steps 1000 --warmup 100 --no-c4 --no-secondary --no-embed --no-ivfpq --no-workspace --no-ingest --no-group-issue
+stats c4 --steps 20 --warmup 5 --no-secondary --no-embed --no-ivfpq --no-workspace --no-ingest --no-group-issue
+stats c3 --steps 20 --warmup 5 --no-c4 --no-embed --no-ivfpq --no-workspace --no-ingest --no-group-issue
+stats workspace --steps 20 --warmup 5 --no-c4 --no-secondary --no-embed --no-ivfpq --no-ingest --no-group-issue
+stats embed --steps 20 --warmup 5 --no-c4 --no-secondary --no-ivfpq --no-workspace --no-ingest --no-group-issue
+stats ivfpq --steps 20 --warmup 5 --no-c4 --no-secondary --no-embed --no-workspace --no-ingest --no-group-issue
 step "FETCH_SIZE"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch_$tag" -o bench -- python "$root/bench.py" --steps 20 --warmup 3 --settle-steps 8 --no-cpu-baseline --no-ivfpq --no-ingest --c4-steps 3 --detail-out "$out/${tag}_bench_detail_pmc.json" > "$out/pmc_fetch_$tag.log" 2>&1
-python "$root/tools/summarize_pmc.py" "$out/pmc_fetch_$tag" "$out/${tag}_pmc_fetch.json" "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 20 --warmup 3 --settle-steps 8 --no-cpu-baseline --no-ivfpq --no-ingest --c4-steps 3" > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch_$tag" -o bench -- python "$root/bench.py" --steps 20 --warmup 3 --settle-steps 8 --no-cpu-baseline --no-ivfpq --no-ingest --no-group-issue --c4-steps 3 --detail-out "$out/${tag}_bench_detail_pmc.json" > "$out/pmc_fetch_$tag.log" 2>&1
+python "$root/tools/summarize_pmc.py" "$out/pmc_fetch_$tag" "$out/${tag}_pmc_fetch.json" "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 20 --warmup 3 --settle-steps 8 --no-cpu-baseline --no-ivfpq --no-ingest --no-group-issue --c4-steps 3" > /dev/null 2>&1
 python - "$out/${tag}_pmc_fetch.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
