@@ -86,3 +86,40 @@ def test_topk_random_shapes_over_the_operand_image(gpu_ctx, n, k, nq, seed, dup)
         assert got[i][0].tolist() == orows, (i, n, k, nq, seed, dup)
         assert np.array_equal(got[i][1], np.array(odist))
     c.close()
+
+
+@settings(max_examples=30 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(40, 9000), k=st.integers(1, 40), nq=st.sampled_from([1, 2, 8, 9, 40, 130]), seed=st.integers(0, 10_000),
+       max_doc=st.sampled_from([1, 4, 70, 700]), p_want=st.sampled_from([0.1, 0.5, 0.9]), image=st.booleans())
+def test_document_subsets_random_shapes(gpu_ctx, n, k, nq, seed, max_doc, p_want, image):
+    """Random "documents" (1 .. max_doc lines each), a random subset of them wanted: one-line ranges, ranges meeting inside 32-row
+    tiles, dense and sparse subsets (tile table of gemm_rowreg_kernel / chunk table of the LDS-row and scan kernels), with and
+    without the operand image -- rows and f64 distances equal the oracle's on the eligible rows."""
+    import semtools_amd as smt
+
+    rng = np.random.default_rng(seed)
+    emb = synth.unit_rows(n, seed=seed, dup_frac=0.05, zero_frac=0.01)
+    qs = synth.unit_query(seed + 1, nq=nq)
+    ranges, b = [], 0
+    while b < n:
+        e = min(n, b + int(rng.integers(1, max_doc + 1)))
+        if rng.random() < p_want:
+            ranges.append((b, e))
+        b = e
+    if not ranges:
+        ranges = [(0, min(n, 3))]
+    idx = np.concatenate([np.arange(a, e) for a, e in ranges])
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    if image:
+        c.prepack()
+    gpu_ctx.set_tuning("image_scan_min_rows", 1)
+    try:
+        got = c.search(qs, top_k=k, ranges=ranges)
+    finally:
+        gpu_ctx.set_tuning("image_scan_min_rows", 1_500_000)
+    for i in range(0, nq, max(1, nq // 6)):
+        orows, odist = _oracle(emb[idx], qs[i], k)
+        assert got[i][0].tolist() == idx[np.array(orows, dtype=np.int64)].tolist(), (i, n, k, nq, seed, max_doc, p_want, image)
+        assert np.array_equal(got[i][1], np.array(odist))
+    c.close()
