@@ -93,6 +93,19 @@ int ensure_pinned(smt_ctx *ctx, size_t bytes)
     return SMT_OK;
 }
 
+int ensure_pinned_in(smt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_in_bytes) return SMT_OK;
+    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned_in) SMT_HIP_CHECK(hipHostFree(ctx->h_pinned_in));
+    ctx->h_pinned_in = nullptr;
+    ctx->pinned_in_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 16);
+    SMT_HIP_CHECK(hipHostMalloc(&ctx->h_pinned_in, want, hipHostMallocDefault));
+    ctx->pinned_in_bytes = want;
+    return SMT_OK;
+}
+
 void prof_begin(smt_ctx *ctx, const char *name)
 {
     if (!ctx->prof_on) return;
@@ -314,6 +327,7 @@ void smt_ctx_destroy(smt_ctx *ctx)
         for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_pinned_in) (void)hipHostFree(ctx->h_pinned_in);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

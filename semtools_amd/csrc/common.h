@@ -95,6 +95,8 @@ struct smt_ctx {
     size_t scratch_bytes = 0;
     void *h_pinned = nullptr;
     size_t pinned_bytes = 0;
+    void *h_pinned_in = nullptr;   // smt_search's inputs (queries, ranges, prefixes) assembled for ONE upload
+    size_t pinned_in_bytes = 0;
     void *d_stage = nullptr;   // smt_search's per-call inputs/outputs (queries, ranges, result lists)
     size_t stage_bytes = 0;
     // async select (tuning key async_select): the select of query i runs on aux_stream WHILE query i+1 scans;
@@ -153,6 +155,7 @@ int launch_pack_image(smt_ctx *ctx, const float *corpus, uint64_t n_rows, uint64
                       uint32_t *image_zero);
 int ensure_scratch(smt_ctx *ctx, size_t bytes);
 int ensure_pinned(smt_ctx *ctx, size_t bytes);
+int ensure_pinned_in(smt_ctx *ctx, size_t bytes);
 int ensure_stage(smt_ctx *ctx, size_t bytes);
 // Wait for select kernels still running on the aux stream (no-op unless async_select was used).  Every entry
 // point that touches the context's scratch or reads results on the main stream calls this first.
