@@ -641,7 +641,7 @@ int smt_embed_device(smt_model *model, const uint32_t *ids_dev, const uint64_t *
     int rc = bind_device(model->ctx);
     if (rc) return rc;
     return launch_embed(model->ctx, model->d_table, model->V, model->normalize, ids_dev, offsets_dev, n_lines,
-                        max_tokens, out_dev);
+                        max_tokens, out_dev, 0);
 }
 
 int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens,
@@ -686,7 +686,8 @@ int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, ui
         if ((rc = corpus_reserve(append_to, append_to->rows + n_lines))) return rc;
         d_out = append_to->d_rows + (size_t)append_to->rows * append_to->dim;
     }
-    rc = launch_embed(ctx, model->d_table, model->V, model->normalize, d_ids, d_off, n_lines, max_tokens, d_out);
+    rc = launch_embed(ctx, model->d_table, model->V, model->normalize, d_ids, d_off, n_lines, max_tokens, d_out,
+                      std::max<uint64_t>(n_ids, 1));
     if (rc) return rc;
     if (out_host)
         SMT_HIP_CHECK(hipMemcpyAsync(out_host, d_out, (size_t)n_lines * model->D * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

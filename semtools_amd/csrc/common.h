@@ -340,7 +340,8 @@ int ivfpq_search_packed(smt_ivfpq *ix, const float *queries_dev, uint32_t nq, ui
 
 // K1
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
-                 const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out);
+                 const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out,
+                 uint64_t n_tokens_known /* total tokens of the batch when the host has the offsets, else 0 */);
 
 // K3: batched queries, f32 MFMA with fused candidate selection.
 int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a);

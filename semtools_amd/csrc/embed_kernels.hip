@@ -28,6 +28,8 @@ namespace smt {
 
 // row_ror:n rotates the 16-lane DPP row right by n: lane i receives lane (i - n) mod 16.
 constexpr int DPP_ROW_ROR1 = 0x121;
+// 32-bit positions of the PF kernel step up to TU + 3 past a line's end before they are compared
+constexpr uint64_t EMBED_SPAN_LIMIT = (1ull << 32) - 16;
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v)
 {
@@ -46,10 +48,15 @@ struct EmbedParams {
     int batched;                // 1: parked lines wait for a wave-wide epilogue (0: each line is finished when it completes; A/B)
     float *out;
     uint64_t lines_per_group;   // a group of 16 lanes walks lines [g * lines_per_group, ...)
+    uint64_t span_limit;        // PF kernel: runs spanning this many tokens or more are left to the generic kernel (2^32; tests: small)
+    int only_large;             // generic kernel: 1 = walk only the runs the PF kernel left
 };
 
 // PF: the token ids of step s + 1 are requested while the rows of step s are in flight (the next position is pure arithmetic on the
 // prefetched offsets), so a step waits for ONE memory round trip -- the rows -- instead of two in a row (ids, then rows).
+// The PF kernel keeps token positions as 32-bit counts from the first token of its run (six position registers instead of twelve:
+// that is what takes it under the 128-VGPR line of four waves per SIMD without spilling); a run spanning 2^32 tokens or more --
+// 16 GiB of ids under one group -- is skipped here and walked by the generic kernel, launched behind it with only_large = 1.
 template <bool PF>
 __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
 {
@@ -60,19 +67,30 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
     // (register diet: the kernel sits at the 128-VGPR edge of four waves per SIMD -- the position inside the run is a 32-bit count,
     // the parked line is always the one before the current, its token count is kept as the float the mean divides by)
     const uint64_t line0 = group * p.lines_per_group;
-    const uint32_t n_run = line0 < p.n_lines ? (uint32_t)min(p.n_lines - line0, p.lines_per_group) : 0u;
+    uint32_t n_run = line0 < p.n_lines ? (uint32_t)min(p.n_lines - line0, p.lines_per_group) : 0u;
+    // positions are counted from `tb`: the run's first token in the PF kernel, 0 in the generic one
+    using pos_t = typename std::conditional<PF, uint32_t, uint64_t>::type;
+    uint64_t tb = 0;
+    if (n_run != 0) {
+        const uint64_t first = p.offsets[line0];
+        const bool large = p.offsets[line0 + n_run] - first >= p.span_limit;
+        if constexpr (PF) {
+            tb = first;
+            if (large) n_run = 0;
+        } else if (p.only_large && !large) n_run = 0;
+    }
     uint32_t li = 0;                                     // current line = line0 + li
     bool active = li < n_run;                            // group-uniform
 
     // token range of the current line [t, t_end) (max_tokens applied), its token count, and the NEXT line's end (read one
     // line ahead: a group that moves on must not wait for a dependent offsets load)
-    uint64_t t = 0, t_end = 0, o_end = 0, o_next = 0;
+    pos_t t = 0, t_end = 0, o_end = 0, o_next = 0;
     if (active) {
-        t = p.offsets[line0];
-        o_end = p.offsets[line0 + 1];
-        o_next = 1 < n_run ? p.offsets[line0 + 2] : o_end;
+        t = (pos_t)(p.offsets[line0] - tb);
+        o_end = (pos_t)(p.offsets[line0 + 1] - tb);
+        o_next = 1 < n_run ? (pos_t)(p.offsets[line0 + 2] - tb) : o_end;
         t_end = o_end;
-        if (p.max_tokens != 0 && t_end - t > (uint64_t)p.max_tokens) t_end = t + p.max_tokens;
+        if (p.max_tokens != 0 && t_end - t > (pos_t)p.max_tokens) t_end = t + p.max_tokens;
     }
     float cnt_cur = (float)(t_end - t > 0 ? t_end - t : 1);   // what the current line's sums are divided by (max(cnt, 1))
 
@@ -136,7 +154,8 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
     // DPP quad broadcast), so the prefetch costs one register and a quarter of the id loads
     static_assert(TU == 4, "one id per lane of a quad");
     uint32_t nid = 0;
-    if constexpr (PF) nid = (active && (t + (a & 3)) < t_end) ? p.ids[t + (a & 3)] : 0u;
+    const uint32_t *ids = p.ids + tb;
+    if constexpr (PF) nid = (active && (t + (a & 3)) < t_end) ? ids[t + (a & 3)] : 0u;
     while (__any(active)) {
         float4 r[TU][4];
         uint32_t idq[TU] = {0u, 0u, 0u, 0u};
@@ -151,7 +170,7 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
             const bool on = active && (t + u) < t_end;
             uint64_t id;
             if constexpr (PF) id = idq[u];
-            else id = on ? (uint64_t)p.ids[t + u] : 0;
+            else id = on ? (uint64_t)ids[t + u] : 0;
             const bool ok = on && id < p.V;  // out-of-vocab ids contribute nothing
             const float4 *row = reinterpret_cast<const float4 *>(p.table + (ok ? id : 0) * 256);
 #pragma unroll
@@ -165,10 +184,10 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
         const bool done = active && t + TU >= t_end;
         if constexpr (PF) {
             const bool n_active = done ? li + 1 < n_run : active;
-            const uint64_t nt = done ? o_end : t + TU;
-            uint64_t nt_end = done ? o_next : t_end;
-            if (done && p.max_tokens != 0 && nt_end - nt > (uint64_t)p.max_tokens) nt_end = nt + p.max_tokens;
-            nid = (n_active && (nt + (a & 3)) < nt_end) ? p.ids[nt + (a & 3)] : 0u;
+            const pos_t nt = done ? o_end : t + TU;
+            pos_t nt_end = done ? o_next : t_end;
+            if (done && p.max_tokens != 0 && nt_end - nt > (pos_t)p.max_tokens) nt_end = nt + p.max_tokens;
+            nid = (n_active && (nt + (a & 3)) < nt_end) ? ids[nt + (a & 3)] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
@@ -201,9 +220,9 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
             active = li < n_run;
             t = o_end;
             o_end = o_next;
-            if (li + 1 < n_run) o_next = p.offsets[line0 + li + 2];
+            if (li + 1 < n_run) o_next = (pos_t)(p.offsets[line0 + li + 2] - tb);
             t_end = o_end;
-            if (p.max_tokens != 0 && t_end - t > (uint64_t)p.max_tokens) t_end = t + p.max_tokens;
+            if (p.max_tokens != 0 && t_end - t > (pos_t)p.max_tokens) t_end = t + p.max_tokens;
             cnt_cur = (float)(t_end - t > 0 ? t_end - t : 1);
         }
         if (__any(has_pend) && (!p.batched || __all(has_pend || !active))) finalize();
@@ -212,7 +231,7 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
 }
 
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,
-                 const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out)
+                 const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens, float *out, uint64_t n_tokens_known)
 {
     if (n_lines == 0) return SMT_OK;
     EmbedParams p;
@@ -235,8 +254,18 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     prof_begin(ctx, "embed");
     // (A/B: embed_batched bit 1 = ids prefetched one step ahead.  Probed in round 4 and removed: the same kernel at three waves per
     // SIMD without spills -- Zipf 3.11 -> 3.32 ms -- and nontemporal row loads -- 4.68 / 6.77 ms; profiles/r04_k1/)
-    if (ctx->tune.embed_batched & 2) hipLaunchKernelGGL(embed_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL(embed_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+    // embed_batched bit 2 (tests): the PF kernel leaves every run of 64 tokens or more to the generic kernel
+    p.span_limit = (ctx->tune.embed_batched & 4) ? 64ull : EMBED_SPAN_LIMIT;
+    p.only_large = 0;
+    if (ctx->tune.embed_batched & 2) {
+        hipLaunchKernelGGL(embed_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+        // the runs it left: none when the caller knows the batch holds fewer tokens than the limit (n_tokens_known = 0: offsets
+        // only exist on the device -- the launch finds nothing to do and costs a few microseconds)
+        if (n_tokens_known == 0 || n_tokens_known >= p.span_limit) {
+            p.only_large = 1;
+            hipLaunchKernelGGL(embed_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
+        }
+    } else hipLaunchKernelGGL(embed_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p);
     prof_end(ctx, "embed");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;

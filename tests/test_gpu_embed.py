@@ -40,6 +40,30 @@ def test_embed_runs_of_lines_per_group_bit_exact(model):
         assert not got[lens == 0].any()
 
 
+def test_embed_runs_too_long_for_32_bit_positions_take_the_generic_kernel(model, gpu_ctx):
+    """The default kernel counts token positions in 32 bits from the first token of a group's run and leaves runs that do not fit
+    (2^32 tokens) to the generic kernel launched behind it.  Tuning bit 2 of embed_batched lowers that limit to 64 tokens so the
+    split is exercised at test sizes: runs of ~19 ragged lines (mostly over the limit, a stretch of empty lines under it), and one
+    line per group (0..40 tokens with a few long ones): both kernels write their share, bit-exact, no row written twice wrongly."""
+    table, m = model
+    rng = np.random.default_rng(12)
+    gpu_ctx.set_tuning("embed_batched", 7)
+    try:
+        for n in (300_000, 1500):
+            lens = rng.integers(0, 41, size=n)
+            lens[rng.integers(0, n, size=20)] = rng.integers(64, 900, size=20)
+            lens[n // 3: n // 3 + 400] = 0
+            offsets = np.zeros(n + 1, dtype=np.uint64)
+            np.cumsum(lens, out=offsets[1:])
+            ids = rng.integers(0, 5000, size=int(offsets[-1])).astype(np.uint32)
+            for cap in (2048, 16):
+                got, _ = m.embed(ids, offsets, max_tokens=cap)
+                ref = orc.embed_lines(table, ids, offsets, normalize=True, max_tokens=cap)
+                assert np.array_equal(got, ref), f"n {n} cap {cap}: max |diff| {np.abs(got - ref).max()}"
+    finally:
+        gpu_ctx.set_tuning("embed_batched", 3)
+
+
 def test_embed_bit_exact(model):
     table, m = model
     ids, offsets = synth.token_lines(1003, V=5000, seed=1, min_tok=0, max_tok=40)
