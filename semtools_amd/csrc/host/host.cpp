@@ -16,9 +16,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <exception>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -34,31 +37,72 @@ void check(int rc, const char *what)
 }
 
 // ------------------------------------------------------------------ strings / files
-std::vector<std::string> lines_of(std::string_view content)
+std::vector<std::string_view> line_views(std::string_view content)
 {
     // str::lines() (mod.rs:51): split at '\n', a '\r' before it belongs to the line ending, a last line without terminator is kept.
-    // Pass 1 finds the line starts; pass 2 builds the strings -- on several threads for big files (a million small allocations were
-    // three quarters of the wall time of embedding a 1 M-line file: profiles/r04_ingest.json).
-    std::vector<size_t> starts;
+    // A line ends where a '\n' is, whatever came before: big contents are cut into byte slices whose '\n' positions are found on several
+    // threads (memchr over 64 MB was 14 ms of a 55 ms call on one), then the views are laid out from the per-slice counts.
     const size_t n = content.size();
-    for (size_t start = 0; start < n;) {
-        starts.push_back(start);
-        const void *nl = memchr(content.data() + start, '\n', n - start);
-        if (!nl) break;
-        start = (size_t)(static_cast<const char *>(nl) - content.data()) + 1;
-    }
-    std::vector<std::string> out(starts.size());
-    auto build = [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-            const size_t start = starts[i];
-            size_t end = i + 1 < starts.size() ? starts[i + 1] - 1 : n;       // the '\n' (or the end of the content)
-            if (i + 1 == starts.size() && end > start && content[end - 1] == '\n') --end;   // (last line WITH a terminator)
-            if (end > start && content[end - 1] == '\r' && (i + 1 < starts.size() || (end < n && content[end] == '\n'))) --end;  // "\r\n"
-            out[i].assign(content.data() + start, end - start);
+    const char *base = content.data();
+    std::vector<std::string_view> out;
+    if (n == 0) return out;
+    const size_t n_slices = n >= (4u << 20) ? std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::vector<size_t>> nl(n_slices);   // positions of the '\n's of each slice
+    auto find = [&](size_t t) {
+        const size_t b = n * t / n_slices, e = n * (t + 1) / n_slices;
+        std::vector<size_t> v;   // (grown in this thread's frame, handed over once: the headers of nl[] share cache lines)
+        v.reserve((e - b) / 48 + 16);
+        for (size_t at = b; at < e;) {
+            const void *p = memchr(base + at, '\n', e - at);
+            if (!p) break;
+            const size_t pos = (size_t)(static_cast<const char *>(p) - base);
+            v.push_back(pos);
+            at = pos + 1;
+        }
+        nl[t] = std::move(v);
+    };
+    if (n_slices == 1) find(0);
+    else parallel_slices(n_slices, 1, [&](size_t b, size_t e) { for (size_t t = b; t < e; ++t) find(t); });
+    std::vector<size_t> first(n_slices + 1, 0);      // index of each slice's first line end
+    for (size_t t = 0; t < n_slices; ++t) first[t + 1] = first[t] + nl[t].size();
+    const size_t terminated = first[n_slices];
+    const bool tail = base[n - 1] != '\n';           // a last line without terminator
+    out.resize(terminated + (tail ? 1 : 0));
+    auto lay = [&](size_t t) {
+        // the line that ends at nl[t][j] starts right after the previous '\n' (the last one of an earlier non-empty slice, or 0)
+        size_t start = 0;
+        for (size_t u = t; u-- > 0;)
+            if (!nl[u].empty()) { start = nl[u].back() + 1; break; }
+        for (size_t j = 0; j < nl[t].size(); ++j) {
+            size_t end = nl[t][j];
+            const size_t next = end + 1;
+            if (end > start && base[end - 1] == '\r') --end;   // "\r\n"
+            out[first[t] + j] = std::string_view(base + start, end - start);
+            start = next;
         }
     };
-    if (starts.size() >= 65536) parallel_slices(starts.size(), 16384, build);
-    else build(0, starts.size());
+    if (n_slices == 1) lay(0);
+    else parallel_slices(n_slices, 1, [&](size_t b, size_t e) { for (size_t t = b; t < e; ++t) lay(t); });
+    if (tail) {
+        size_t start = 0;
+        for (size_t u = n_slices; u-- > 0;)
+            if (!nl[u].empty()) { start = nl[u].back() + 1; break; }
+        out[terminated] = std::string_view(base + start, n - start);   // (a lone '\r' at the very end stays: no '\n' follows it)
+    }
+    return out;
+}
+
+std::vector<std::string> lines_of(std::string_view content)
+{
+    // the strings are built on several threads for big files (a million small allocations were three quarters of the wall time of
+    // embedding a 1 M-line file: profiles/r04_ingest.json; the search path itself keeps views and builds none)
+    const std::vector<std::string_view> views = line_views(content);
+    std::vector<std::string> out(views.size());
+    auto build = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) out[i].assign(views[i].data(), views[i].size());
+    };
+    if (views.size() >= 65536) parallel_slices(views.size(), 16384, build);
+    else build(0, views.size());
     return out;
 }
 
@@ -229,15 +273,21 @@ void mkdir_p(const std::string &dir)
 // ------------------------------------------------------------------ tokenizers
 namespace {
 
-void split_whitespace(const std::string &text, std::vector<std::pair<size_t, size_t>> &spans)
+// fn(offset, length) for every maximal run of non-whitespace bytes (isspace of the "C" locale, whatever locale the host process has
+// set: ' ', \t, \n, \v, \f, \r).  No span list: a vector per line was a heap allocation and five regrowths per line -- most of the
+// 1.4 us a thread spent per line of a big file (profiles/r04_ingest_phases.json).
+inline bool is_space_c(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+template <typename Fn>
+inline void for_each_word(const std::string &text, Fn fn)
 {
     size_t i = 0;
     const size_t n = text.size();
+    const char *p = text.data();
     while (i < n) {
-        while (i < n && isspace((unsigned char)text[i])) ++i;
+        while (i < n && is_space_c((unsigned char)p[i])) ++i;
         const size_t s = i;
-        while (i < n && !isspace((unsigned char)text[i])) ++i;
-        if (i > s) spans.emplace_back(s, i - s);
+        while (i < n && !is_space_c((unsigned char)p[i])) ++i;
+        if (i > s) fn(s, i - s);
     }
 }
 
@@ -274,13 +324,11 @@ public:
     }
     void encode(const std::string &text, std::vector<uint32_t> &ids) const override
     {
-        std::vector<std::pair<size_t, size_t>> spans;
-        split_whitespace(text, spans);
-        for (auto &sp : spans) {
-            const int64_t hit = vocab_.find(text.data() + sp.first, sp.second);
+        for_each_word(text, [&](size_t at, size_t len) {
+            const int64_t hit = vocab_.find(text.data() + at, len);
             if (hit >= 0) ids.push_back((uint32_t)hit);
             else if (unk_) ids.push_back(*unk_);
-        }
+        });
     }
     std::optional<uint32_t> unk_id() const override { return unk_; }
     size_t median_token_length() const override { return median_; }
@@ -298,10 +346,9 @@ public:
     explicit HashTokenizer(uint64_t v) : v_(v) {}
     void encode(const std::string &text, std::vector<uint32_t> &ids) const override
     {
-        std::vector<std::pair<size_t, size_t>> spans;
-        split_whitespace(text, spans);
-        for (auto &sp : spans)
-            ids.push_back((uint32_t)(smt_fnv1a_hash(reinterpret_cast<const uint8_t *>(text.data() + sp.first), sp.second) % v_));
+        for_each_word(text, [&](size_t at, size_t len) {
+            ids.push_back((uint32_t)(smt_fnv1a_hash(reinterpret_cast<const uint8_t *>(text.data() + at), len) % v_));
+        });
     }
     uint64_t vocab_size() const override { return v_; }
 
@@ -438,18 +485,25 @@ void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<
 namespace {
 std::vector<std::pair<std::string, double>> g_phases;
 std::chrono::steady_clock::time_point g_phase_t0 = std::chrono::steady_clock::now();
+std::mutex g_phase_mu;   // (add() is called from the embedding pipeline's tokenizer thread)
 }  // namespace
+void PhaseTimer::add(const char *phase, double ms)
+{
+    std::lock_guard<std::mutex> lk(g_phase_mu);
+    for (auto &p : g_phases)
+        if (p.first == phase) { p.second += ms; return; }
+    g_phases.emplace_back(phase, ms);
+}
 void PhaseTimer::mark(const char *phase)
 {
     const auto now = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(now - g_phase_t0).count();
     g_phase_t0 = now;
-    for (auto &p : g_phases)
-        if (p.first == phase) { p.second += ms; return; }
-    g_phases.emplace_back(phase, ms);
+    add(phase, ms);
 }
 std::string PhaseTimer::json()
 {
+    std::lock_guard<std::mutex> lk(g_phase_mu);
     std::string out = "{";
     char buf[64];
     for (size_t i = 0; i < g_phases.size(); ++i) {
@@ -462,7 +516,7 @@ std::string PhaseTimer::json()
 // model2vec-rs truncate_str: keep at most max_tokens * median_token_length characters
 // (returns the number of BYTES to keep: almost every line is kept whole, and copying it just to hand it to the tokenizer was a heap
 // allocation per line)
-static size_t truncate_len(const std::string &s, size_t max_tokens, size_t median_len)
+static size_t truncate_len(std::string_view s, size_t max_tokens, size_t median_len)
 {
     const size_t max_chars = max_tokens * median_len;
     if (s.size() <= max_chars) return s.size();   // (at least one byte per character)
@@ -476,37 +530,76 @@ static size_t truncate_len(const std::string &s, size_t max_tokens, size_t media
     return s.size();
 }
 
-void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size_t begin, size_t end,
+void StaticModel::tokenize_batch(const std::string_view *sentences, size_t begin, size_t end,
                                  std::optional<size_t> max_length, std::vector<uint32_t> &ids,
                                  std::vector<uint64_t> &offsets) const
 {
-    // encode_batch_fast is rayon-parallel upstream; here: one slice per hardware thread
+    // encode_batch_fast is rayon-parallel upstream; here: one contiguous slice of the batch per thread, in two steps with a barrier
+    // between them -- (A) tokenise the slice into the thread's own buffers, [the last thread to arrive sizes the batch's arrays from
+    // the slices' token counts], (B) copy the slice's ids to their place and write its offsets.  (Round 4: 128 threads of 2048 lines
+    // and a serial merge of the parts took 11 ms per 262144-line batch of which 0.3 ms was tokenising -- starting a thread costs
+    // ~30 us, a whitespace-hashed line ~0.15 us: profiles/r04_ingest_phases.json.)
     const size_t n = end - begin;
-    // (at least 2048 lines per thread: starting a thread costs ~25 us, a whitespace-hashed line ~0.1 us -- 256 threads for a
-    // 65536-line batch spent more time being started than tokenising: profiles/r04_ingest.json)
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 2048));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)48, n / 8192}));
     std::vector<std::vector<uint32_t>> part_ids(n_threads);
-    std::vector<std::vector<uint64_t>> part_len(n_threads);
+    std::vector<std::vector<uint32_t>> part_len(n_threads);
+    std::vector<uint64_t> id_base(n_threads + 1, 0);
     const auto unk = tok_->unk_id();
     // a throwing tokenizer (callback failure, bad_alloc) must reach the caller -- and through it the extern "C"
-    // wrappers' catch blocks -- not std::terminate the process from a worker thread
+    // wrappers' catch blocks -- not std::terminate the process from a worker thread (and it must still arrive at the barrier)
     std::vector<std::exception_ptr> failed(n_threads);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t arrived = 0;
+    bool sized = false, any_failed = false;
+    auto slice = [&](size_t t) { return std::make_pair(begin + n * t / n_threads, begin + n * (t + 1) / n_threads); };
     auto work = [&](size_t t) {
-      try {
-        const size_t b = begin + n * t / n_threads, e = begin + n * (t + 1) / n_threads;
-        std::vector<uint32_t> tmp;
-        for (size_t i = b; i < e; ++i) {
-            tmp.clear();
-            const std::string &src = sentences[i];
-            const size_t keep = max_length ? truncate_len(src, *max_length, tok_->median_token_length()) : src.size();
-            if (keep == src.size()) tok_->encode(src, tmp);
-            else tok_->encode(src.substr(0, keep), tmp);
-            if (unk) tmp.erase(std::remove(tmp.begin(), tmp.end(), *unk), tmp.end());
-            if (max_length && tmp.size() > *max_length) tmp.resize(*max_length);
-            part_ids[t].insert(part_ids[t].end(), tmp.begin(), tmp.end());
-            part_len[t].push_back(tmp.size());
+        const auto [b, e] = slice(t);
+        try {
+            std::vector<uint32_t> tmp;
+            std::string text;   // (the tokenizers take a std::string: one buffer per thread, refilled per line -- no allocation once it has grown)
+            // the slice's ids and lengths grow in vectors of THIS thread's frame and are handed over once: the headers of
+            // part_ids[t] / part_len[t] of neighbouring threads share cache lines, and an append per line into them made every
+            // thread's line cost 0.7 us instead of 0.25 (false sharing; profiles/r04_ingest_phases.json)
+            std::vector<uint32_t> my_ids, my_len;
+            my_len.reserve(e - b);
+            my_ids.reserve((e - b) * 16);
+            const size_t median = tok_->median_token_length();
+            for (size_t i = b; i < e; ++i) {
+                tmp.clear();
+                const std::string_view src = sentences[i];
+                const size_t keep = max_length ? truncate_len(src, *max_length, median) : src.size();
+                text.assign(src.data(), keep);
+                tok_->encode(text, tmp);
+                if (unk) tmp.erase(std::remove(tmp.begin(), tmp.end(), *unk), tmp.end());
+                if (max_length && tmp.size() > *max_length) tmp.resize(*max_length);
+                my_ids.insert(my_ids.end(), tmp.begin(), tmp.end());
+                my_len.push_back((uint32_t)tmp.size());
+            }
+            part_ids[t] = std::move(my_ids);
+            part_len[t] = std::move(my_len);
+        } catch (...) { failed[t] = std::current_exception(); }
+        {   // ---- barrier; the last thread to arrive lays the batch out
+            std::unique_lock<std::mutex> lk(mu);
+            if (failed[t]) any_failed = true;
+            if (++arrived == n_threads) {
+                if (!any_failed) {
+                    try {
+                        for (size_t u = 0; u < n_threads; ++u) id_base[u + 1] = id_base[u] + part_ids[u].size();
+                        ids.resize(id_base[n_threads]);
+                        offsets.resize(n + 1);
+                        offsets[0] = 0;
+                    } catch (...) { failed[t] = std::current_exception(); any_failed = true; }
+                }
+                sized = true;
+                cv.notify_all();
+            } else cv.wait(lk, [&] { return sized; });
+            if (any_failed) return;
         }
-      } catch (...) { failed[t] = std::current_exception(); }
+        if (!part_ids[t].empty()) memcpy(ids.data() + id_base[t], part_ids[t].data(), part_ids[t].size() * sizeof(uint32_t));
+        uint64_t at = id_base[t];
+        uint64_t *off = offsets.data() + (b - begin) + 1;
+        for (uint32_t l : part_len[t]) { at += l; *off++ = at; }
     };
     if (n_threads == 1) work(0);
     else {
@@ -515,12 +608,6 @@ void StaticModel::tokenize_batch(const std::vector<std::string> &sentences, size
         for (auto &x : th) x.join();
     }
     for (auto &f : failed) if (f) std::rethrow_exception(f);
-    ids.clear();
-    offsets.assign(1, 0);
-    for (size_t t = 0; t < n_threads; ++t) {
-        ids.insert(ids.end(), part_ids[t].begin(), part_ids[t].end());
-        for (uint64_t l : part_len[t]) offsets.push_back(offsets.back() + l);
-    }
 }
 
 std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<std::string> &sentences,
@@ -533,9 +620,10 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
     std::vector<uint64_t> offsets;
     std::vector<float> buf;
     if (batch_size == 0) batch_size = 1;
+    const std::vector<std::string_view> views(sentences.begin(), sentences.end());
     for (size_t b = 0; b < sentences.size(); b += batch_size) {
         const size_t e = std::min(sentences.size(), b + batch_size);
-        tokenize_batch(sentences, b, e, max_length, ids, offsets);
+        tokenize_batch(views.data(), b, e, max_length, ids, offsets);
         buf.resize((e - b) * SMT_DIM);
         embed_csr(ids, offsets, e - b, buf.data(), nullptr);   // (tokenize_batch already truncated to max_length)
         for (size_t i = 0; i < e - b; ++i) out.emplace_back(buf.begin() + i * SMT_DIM, buf.begin() + (i + 1) * SMT_DIM);
@@ -544,6 +632,12 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
 }
 
 uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
+                                  size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink) const
+{
+    return encode_into(std::vector<std::string_view>(sentences.begin(), sentences.end()), max_length, batch_size, corpus, sink);
+}
+
+uint64_t StaticModel::encode_into(const std::vector<std::string_view> &sentences, std::optional<size_t> max_length,
                                   size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink) const
 {
     // Double-buffered pipeline: while the GPU gathers/pools batch i (H2D of the ids + K1),
@@ -562,7 +656,13 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
     const size_t n = sentences.size();
     if (n == 0) return first;
     if (!model_ && n > 32768) full_model();   // lazy mode: a large job wants the whole table, decide before the pipeline starts
-    auto tokenize = [&](size_t b, Slot &s) { tokenize_batch(sentences, b, std::min(n, b + batch_size), max_length, s.ids, s.offsets); };
+    // ("within_*": the two sides of the pipeline, overlapping each other inside the caller's tokenize_and_embed phase)
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    auto tokenize = [&](size_t b, Slot &s) {
+        const auto t0 = std::chrono::steady_clock::now();
+        tokenize_batch(sentences.data(), b, std::min(n, b + batch_size), max_length, s.ids, s.offsets);
+        PhaseTimer::add("within_embed:tokenize_batches", ms_since(t0));
+    };
     tokenize(0, slots[0]);
     int cur = 0;
     for (size_t b = 0; b < n; b += batch_size) {
@@ -573,7 +673,9 @@ uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std
             try { tokenize(e, slots[cur ^ 1]); } catch (...) { next_failed = std::current_exception(); }
         });
         std::exception_ptr embed_failed;
+        const auto t_embed = std::chrono::steady_clock::now();
         try { embed_csr(slots[cur].ids, slots[cur].offsets, e - b, nullptr, corpus); } catch (...) { embed_failed = std::current_exception(); }
+        PhaseTimer::add("within_embed:upload_and_K1", ms_since(t_embed));
         if (next.joinable()) next.join();
         if (embed_failed) std::rethrow_exception(embed_failed);
         if (next_failed) std::rethrow_exception(next_failed);
@@ -621,21 +723,30 @@ uint64_t Embeddings::rows() const { return smt_sharded_corpus_rows(corpus_); }
 std::optional<Document> create_document_from_content(const std::string &filename, std::string_view content,
                                                      const StaticModel &model, bool ignore_case, Embeddings &emb)
 {
-    std::vector<std::string> lines = lines_of(content);
+    std::vector<std::string_view> lines = line_views(content);
     if (lines.empty()) return std::nullopt;  // mod.rs:57-59
     PhaseTimer::mark("split_lines");
     Document doc;
     doc.filename = filename;
     if (ignore_case) {
-        std::vector<std::string> lowered;
-        lowered.reserve(lines.size());
-        for (auto &s : lines) lowered.push_back(to_lowercase(s));
+        std::vector<std::string> lowered(lines.size());
+        parallel_slices(lines.size(), 16384, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) lowered[i] = to_lowercase(std::string(lines[i]));
+        });
         doc.first_row = model.encode_into(lowered, 2048, 16384, emb.corpus());  // mod.rs:69
     } else {
         doc.first_row = model.encode_into(lines, 2048, 16384, emb.corpus());
     }
     PhaseTimer::mark("tokenize_and_embed");
     doc.lines = std::move(lines);
+    return doc;
+}
+
+std::optional<Document> create_document_from_content(const std::string &filename, std::shared_ptr<const std::string> content,
+                                                     const StaticModel &model, bool ignore_case, Embeddings &emb)
+{
+    auto doc = create_document_from_content(filename, std::string_view(*content), model, ignore_case, emb);
+    if (doc) doc->text = std::move(content);
     return doc;
 }
 
@@ -726,16 +837,23 @@ std::vector<SearchResult> search_files(const std::vector<std::string> &files, co
     // mod.rs:128-134 reads and embeds file by file; the rows do not depend on how the lines are batched, so all files
     // are read first (the first error still aborts before anything is printed) and embedded in ONE pipeline run
     // (tokenise || H2D || K1 across file borders instead of a round of threads and a K1 launch per file)
-    std::vector<std::string> all;
+    std::vector<std::string_view> all;
+    std::deque<std::string> lowered;   // (mod.rs:61-67: the lowered copies are what is embedded; a deque never moves its elements)
     for (auto &f : files) {
-        const std::string content = read_to_string(f);  // `?`: first error aborts (mod.rs:130)
-        std::vector<std::string> lines = lines_of(content);
+        auto text = std::make_shared<const std::string>(read_to_string(f));  // `?`: first error aborts (mod.rs:130)
+        std::vector<std::string_view> lines = line_views(*text);
         if (lines.empty()) continue;                     // create_document_from_content -> None (mod.rs:57-59)
         Document doc;
         doc.filename = f;
         doc.first_row = all.size();
-        for (auto &l : lines) all.push_back(config.ignore_case ? to_lowercase(l) : l);   // mod.rs:61-67: embed the lowered copy
+        if (config.ignore_case) {
+            for (auto &l : lines) {
+                lowered.push_back(to_lowercase(std::string(l)));
+                all.push_back(lowered.back());
+            }
+        } else all.insert(all.end(), lines.begin(), lines.end());
         doc.lines = std::move(lines);
+        doc.text = std::move(text);
         documents.push_back(std::move(doc));
     }
     PhaseTimer::mark("split_lines");
@@ -777,12 +895,17 @@ std::vector<workspace::RankedLine> search_with_workspace(const std::vector<std::
     // Step 2+3: embed new/changed documents straight into the resident store
     size_t n_lines_upserted = 0;
     std::vector<DocMeta> docs_to_upsert;
-    std::vector<std::pair<std::string, std::vector<std::string>>> pending;
+    std::vector<std::pair<std::string, std::vector<std::string_view>>> pending;   // views into doc_states' contents ...
+    std::deque<std::string> lowered;                                                // ... or into the lowered copies (mod.rs:61-67)
     for (auto &st : doc_states) {
         if (st.kind == DocumentState::Unchanged) continue;
-        std::vector<std::string> lines = lines_of(st.info.content);
+        std::vector<std::string_view> lines = line_views(st.info.content);
         if (lines.empty()) continue;  // create_document_from_content -> None
-        if (config.ignore_case) for (auto &s : lines) s = to_lowercase(s);
+        if (config.ignore_case)
+            for (auto &s : lines) {
+                lowered.push_back(to_lowercase(std::string(s)));
+                s = lowered.back();
+            }
         n_lines_upserted += lines.size();
         pending.emplace_back(st.info.filename, std::move(lines));
         docs_to_upsert.push_back(st.info.meta);

@@ -34,6 +34,8 @@ struct Error : std::runtime_error {
 };
 
 // Rust str::lines(): split on '\n', strip one trailing '\r', no trailing empty piece.
+// line_views: the lines as views into `content` (no allocation per line); lines_of: the same lines as owned strings.
+std::vector<std::string_view> line_views(std::string_view content);
 std::vector<std::string> lines_of(std::string_view content);
 // Rust str::to_lowercase() (simple per-code-point mapping; see DESIGN.md for the caveat).
 std::string to_lowercase(const std::string &s);
@@ -71,6 +73,7 @@ constexpr const char *MODEL_NAME = "minishlab/potion-multilingual-128M";  // src
 // time of `semtools search` goes when the scan itself takes 0.15 ms.
 struct PhaseTimer {
     static void mark(const char *phase);   // closes the running phase under `phase`
+    static void add(const char *phase, double ms);   // a span measured by the caller (may overlap the running phase: "within_*")
     static std::string json();             // {"phase": ms, ...} in order of first appearance
 };
 
@@ -105,6 +108,9 @@ public:
     // (sink, if given, receives the pooled token ids of every sentence in order)
     uint64_t encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
                          size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr) const;
+    // (the sentences as views: the lines of a file are embedded where they lie in its content)
+    uint64_t encode_into(const std::vector<std::string_view> &sentences, std::optional<size_t> max_length,
+                         size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr) const;
     // pool step only: n_lines lines given as token CSR (already filtered / truncated) appended to `corpus`
     void embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_sharded_corpus *corpus) const;
     // identifies the tokenizer (vocab size, unk id, ids of a fixed probe text): cached tokens are only valid for it
@@ -116,7 +122,7 @@ public:
     const Tokenizer &tokenizer() const { return *tok_; }
 
 private:
-    void tokenize_batch(const std::vector<std::string> &sentences, size_t begin, size_t end,
+    void tokenize_batch(const std::string_view *sentences, size_t begin, size_t end,
                         std::optional<size_t> max_length, std::vector<uint32_t> &ids,
                         std::vector<uint64_t> &offsets) const;
     // one batch of token CSR -> rows (host buffer and / or appended to a corpus) through the full or a compact table
@@ -136,9 +142,12 @@ private:
 };
 
 // src/search/mod.rs:18-22.  `embeddings: Vec<Vec<f32>>` became a row range of the resident corpus.
+// `lines: Vec<String>` became views into the document's content: a million-line file is a million heap strings to build and
+// to free otherwise -- two thirds of the wall time of embedding it (profiles/r04_ingest_phases.json).
 struct Document {
     std::string filename;
-    std::vector<std::string> lines;
+    std::vector<std::string_view> lines;       // views into *text, or into a buffer the caller keeps alive as long as the document
+    std::shared_ptr<const std::string> text;   // the content, when the document owns it
     uint64_t first_row = 0;  // rows [first_row, first_row + lines.size()) of the owning corpus
 };
 
@@ -171,8 +180,12 @@ private:
     smt_sharded_corpus *corpus_ = nullptr;
 };
 
-// src/search/mod.rs:49-75: None for empty content; original lines kept; lower-cased copy embedded
+// src/search/mod.rs:49-75: None for empty content; original lines kept; lower-cased copy embedded.
+// The document's lines are views into `content`: the first form leaves the buffer with the caller (it must outlive the document),
+// the second hands the content to the document.
 std::optional<Document> create_document_from_content(const std::string &filename, std::string_view content,
+                                                     const StaticModel &model, bool ignore_case, Embeddings &emb);
+std::optional<Document> create_document_from_content(const std::string &filename, std::shared_ptr<const std::string> content,
                                                      const StaticModel &model, bool ignore_case, Embeddings &emb);
 
 // src/search/mod.rs:77-120.  `documents` must be in the order their lines were embedded into `emb`.
@@ -275,11 +288,12 @@ public:
     // host-vector form (reference signature) ...
     void upsert_line_embeddings(const std::vector<LineEmbedding> &line_embeddings);
     // ... and the resident form used by search_with_workspace: embed straight into the store's corpus
-    void upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
+    void upsert_document_lines(const std::string &path, const std::vector<std::string_view> &lines_for_embedding,
                                const search::StaticModel &model);
     // the same for a batch of documents through ONE embedding pipeline run (tokenise || H2D || K1 across document
     // borders; one round of tokenizer threads per 65536 lines instead of one per file)
-    void upsert_documents_lines(std::vector<std::pair<std::string, std::vector<std::string>>> &docs, const search::StaticModel &model);
+    // (the lines are views: into the documents' contents, or into the lowered copies the caller holds)
+    void upsert_documents_lines(const std::vector<std::pair<std::string, std::vector<std::string_view>>> &docs, const search::StaticModel &model);
     WorkspaceStats get_stats() const;
     std::vector<std::string> get_all_document_paths() const;
     std::vector<RankedLine> search_line_embeddings(const std::vector<float> &query_vec,

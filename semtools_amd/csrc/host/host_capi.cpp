@@ -322,6 +322,7 @@ int smt_host_search_files(smt_host_model *model, const char *query, const char *
     if (!model || !query || !out_text || (n_files && !files)) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out_text = nullptr;
     try {
+        search::PhaseTimer::mark("between_calls");   // (a library caller's own time since the last phase is not split_lines)
         const auto cfg = make_config(n_lines, top_k, max_distance, ignore_case);
         const std::string q = ignore_case ? to_lowercase(query) : std::string(query);  // src/cmds/search.rs:130-134
         const auto res = search::search_files(std::vector<std::string>(files, files + n_files), q, *model->m, cfg);
@@ -336,14 +337,19 @@ int smt_host_search_content(smt_host_model *model, const char *query, const char
     if (!model || !query || !content || !out_text) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out_text = nullptr;
     try {
+        search::PhaseTimer::mark("between_calls");   // (a library caller's own time since the last phase is not split_lines)
         const auto cfg = make_config(n_lines, top_k, max_distance, ignore_case);
         const std::string q = ignore_case ? to_lowercase(query) : std::string(query);
-        search::Embeddings emb(model->m->group());
-        std::vector<search::Document> docs;
-        auto doc = search::create_document_from_content(filename ? filename : "<stdin>", content, *model->m, ignore_case != 0, emb);
-        if (doc) docs.push_back(std::move(*doc));
-        const auto res = search::search_documents(docs, emb, model->m->encode_single(q), cfg);
-        *out_text = dup_text(json ? cmds::search_results_json(res) : cmds::print_search_results(res, is_tty != 0));
+        {
+            search::Embeddings emb(model->m->group());
+            std::vector<search::Document> docs;
+            auto doc = search::create_document_from_content(filename ? filename : "<stdin>", std::string_view(content), *model->m, ignore_case != 0, emb);
+            if (doc) docs.push_back(std::move(*doc));
+            const auto res = search::search_documents(docs, emb, model->m->encode_single(q), cfg);
+            *out_text = dup_text(json ? cmds::search_results_json(res) : cmds::print_search_results(res, is_tty != 0));
+            search::PhaseTimer::mark("format_output");
+        }
+        search::PhaseTimer::mark("release_lines_and_rows");
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
 }
@@ -355,6 +361,7 @@ int smt_host_search_workspace(smt_host_model *model, const char *query, const ch
     if (!model || !query || !out_text || (n_files && !files)) { smt::set_error("null argument"); return SMT_E_INVALID; }
     *out_text = nullptr;
     try {
+        search::PhaseTimer::mark("between_calls");   // (a library caller's own time since the last phase is not split_lines)
         const auto cfg = make_config(n_lines, top_k, max_distance, ignore_case);
         const std::string q = ignore_case ? to_lowercase(query) : std::string(query);
         std::optional<std::string> ws;
@@ -376,8 +383,8 @@ int smt_host_session_open(smt_host_model *model, const char *const *files, uint6
         s->ignore_case = ignore_case != 0;
         s->emb = std::make_unique<search::Embeddings>(model->m->group());
         for (uint64_t i = 0; i < n_files; ++i) {
-            const std::string content = read_to_string(files[i]);
-            auto doc = search::create_document_from_content(files[i], content, *model->m, s->ignore_case, *s->emb);
+            auto doc = search::create_document_from_content(files[i], std::make_shared<const std::string>(read_to_string(files[i])), *model->m,
+                                                            s->ignore_case, *s->emb);
             if (doc) s->docs.push_back(std::move(*doc));
         }
         *out = s.release();

@@ -373,18 +373,18 @@ void Store::upsert_line_embeddings(const std::vector<LineEmbedding> &line_embedd
 
 static bool token_cache_enabled();
 
-void Store::upsert_documents_lines(std::vector<std::pair<std::string, std::vector<std::string>>> &docs, const search::StaticModel &model)
+void Store::upsert_documents_lines(const std::vector<std::pair<std::string, std::vector<std::string_view>>> &docs, const search::StaticModel &model)
 {
     if (docs.empty()) return;
     if (docs.size() == 1) { upsert_document_lines(docs[0].first, docs[0].second, model); return; }
     size_t total = 0;
     for (auto &d : docs) total += d.second.size();
-    std::vector<std::string> all;
+    std::vector<std::string_view> all;
     all.reserve(total);
     for (auto &d : docs) {
         auto it = extents_.find(d.first);
         if (it != extents_.end()) dead_rows_ += it->second.n_rows;  // the whole old document is replaced (no stale tail)
-        for (auto &l : d.second) all.push_back(std::move(l));
+        all.insert(all.end(), d.second.begin(), d.second.end());
     }
     const bool cache = token_cache_enabled();
     search::TokenCsr tokens;
@@ -408,7 +408,7 @@ void Store::upsert_documents_lines(std::vector<std::pair<std::string, std::vecto
     }
 }
 
-void Store::upsert_document_lines(const std::string &path, const std::vector<std::string> &lines_for_embedding,
+void Store::upsert_document_lines(const std::string &path, const std::vector<std::string_view> &lines_for_embedding,
                                   const search::StaticModel &model)
 {
     auto it = extents_.find(path);

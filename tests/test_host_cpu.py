@@ -57,6 +57,24 @@ def test_lines_like_rust(content):
     assert host.split_lines(content) == refimpl.rust_lines(content)
 
 
+@pytest.mark.parametrize("tail", ["", "\n", "\r", "\r\n", "last"])
+def test_lines_of_a_big_content_cut_into_slices(tail):
+    """Contents of 4 MiB and more have their line ends found on several threads, slice by slice: every mix of "\\n", "\\r\\n", lone
+    "\\r" and empty lines -- also right at a slice border -- must come out as str::lines() gives it (mod.rs:51)."""
+    rng = np.random.default_rng(5)
+    pieces = ["word", "two words", "", "x", "carriage\rinside", "é ü"]
+    ends = ["\n", "\r\n", "\n", "\n\n", "\r\r\n"]
+    parts = []
+    size = 0
+    while size < (5 << 20):
+        p = pieces[int(rng.integers(len(pieces)))] * int(rng.integers(1, 30)) + ends[int(rng.integers(len(ends)))]
+        parts.append(p)
+        size += len(p)
+    content = "".join(parts) + tail
+    assert len(content.encode()) >= (4 << 20)
+    assert host.split_lines(content) == refimpl.rust_lines(content)
+
+
 def test_rust_lines_examples():
     assert refimpl.rust_lines("Line 1\nLine 2\nLine 3") == ["Line 1", "Line 2", "Line 3"]   # mod.rs:419-430
     assert refimpl.rust_lines("") == []                                                       # mod.rs:434-441
