@@ -540,7 +540,7 @@ void StaticModel::tokenize_batch(const std::string_view *sentences, size_t begin
     // and a serial merge of the parts took 11 ms per 262144-line batch of which 0.3 ms was tokenising -- starting a thread costs
     // ~30 us, a whitespace-hashed line ~0.15 us: profiles/r04_ingest_phases.json.)
     const size_t n = end - begin;
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)48, n / 8192}));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)64, n / std::max<size_t>(tok_->lines_per_thread(), 1)}));
     std::vector<std::vector<uint32_t>> part_ids(n_threads);
     std::vector<std::vector<uint32_t>> part_len(n_threads);
     std::vector<uint64_t> id_base(n_threads + 1, 0);

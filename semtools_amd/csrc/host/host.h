@@ -52,6 +52,9 @@ public:
     virtual std::optional<uint32_t> unk_id() const { return std::nullopt; }
     virtual size_t median_token_length() const { return 5; }
     virtual uint64_t vocab_size() const = 0;
+    // lines worth starting one more thread for, in a batch (a thread costs ~30 us to start: ~0.15 us per hashed line, ~1-4 us per
+    // line through a tokenizer.json pipeline)
+    virtual size_t lines_per_thread() const { return 8192; }
 };
 // whitespace words looked up in a vocab file (one token per line, id = line index)
 std::unique_ptr<Tokenizer> make_vocab_tokenizer(const std::string &vocab_path, const std::string &unk_token);

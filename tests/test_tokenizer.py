@@ -50,6 +50,16 @@ def samples(seed, n=300):
     out = list(CORPUS[:8]) + ["", " ", "   ", "a", "[UNK]", "x[PAD]y [UNK]", "ΟΔΥΣΣΕΥΣ", "İ", "word" * 40, "é" * 120]
     for _ in range(n):
         out.append("".join(rng.choice(pool) for _ in range(rng.randint(1, 60))))
+    # pure-ASCII lines (the native tokenizer's one-pass path for BertNormalizer -> BertPreTokenizer -> WordPiece): prose-like words,
+    # every ASCII punctuation character, tabs / newlines / other control characters, upper case, words longer than 100 characters,
+    # and lines that do or do not contain the first byte of an added token
+    words = ["the", "quick", "Search", "TEXT", "embeddings", "cosine", "x", "fox,", "(again)", "a_b", "e-mail", "1e-5", "0xDEADBEEF", "[UNK]",
+             "[PAD]", "[", "]", "<unk>", "zzzqqqxxyy", "w" * 101, "don't", "semi;colon", "q" * 100]
+    ascii_pool = [chr(c) for c in range(1, 128)]
+    for _ in range(n // 2):
+        parts = [rng.choice(words) for _ in range(rng.randint(1, 14))]
+        out.append(rng.choice([" ", "  ", "\t", "\n", " \r\n"]).join(parts))
+        out.append("".join(rng.choice(ascii_pool) for _ in range(rng.randint(1, 80))))
     return out
 
 
