@@ -742,14 +742,6 @@ std::optional<Document> create_document_from_content(const std::string &filename
     return doc;
 }
 
-std::optional<Document> create_document_from_content(const std::string &filename, std::shared_ptr<const std::string> content,
-                                                     const StaticModel &model, bool ignore_case, Embeddings &emb)
-{
-    auto doc = create_document_from_content(filename, std::string_view(*content), model, ignore_case, emb);
-    if (doc) doc->text = std::move(content);
-    return doc;
-}
-
 std::vector<SearchResult> search_documents(const std::vector<Document> &documents, const Embeddings &emb,
                                            const std::vector<float> &query_embedding, const SearchConfig &config)
 {
@@ -828,15 +820,12 @@ std::vector<std::vector<SearchResult>> search_documents_batch(const std::vector<
     return all;  // each already (distance asc, document/line order) == stable sort; take(top_k) done on device
 }
 
-std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,
-                                       const StaticModel &model, const SearchConfig &config)
+std::vector<Document> load_documents(const std::vector<std::string> &files, const StaticModel &model, bool ignore_case, Embeddings &emb)
 {
-    PhaseTimer::mark("model_load");
-    Embeddings emb(model.group());
-    std::vector<Document> documents;
     // mod.rs:128-134 reads and embeds file by file; the rows do not depend on how the lines are batched, so all files
     // are read first (the first error still aborts before anything is printed) and embedded in ONE pipeline run
     // (tokenise || H2D || K1 across file borders instead of a round of threads and a K1 launch per file)
+    std::vector<Document> documents;
     std::vector<std::string_view> all;
     std::deque<std::string> lowered;   // (mod.rs:61-67: the lowered copies are what is embedded; a deque never moves its elements)
     for (auto &f : files) {
@@ -846,7 +835,7 @@ std::vector<SearchResult> search_files(const std::vector<std::string> &files, co
         Document doc;
         doc.filename = f;
         doc.first_row = all.size();
-        if (config.ignore_case) {
+        if (ignore_case) {
             for (auto &l : lines) {
                 lowered.push_back(to_lowercase(std::string(l)));
                 all.push_back(lowered.back());
@@ -862,6 +851,15 @@ std::vector<SearchResult> search_files(const std::vector<std::string> &files, co
         for (auto &d : documents) d.first_row += first;
     }
     PhaseTimer::mark("tokenize_and_embed");
+    return documents;
+}
+
+std::vector<SearchResult> search_files(const std::vector<std::string> &files, const std::string &query,
+                                       const StaticModel &model, const SearchConfig &config)
+{
+    PhaseTimer::mark("model_load");
+    Embeddings emb(model.group());
+    const std::vector<Document> documents = load_documents(files, model, config.ignore_case, emb);
     const std::vector<float> query_embedding = model.encode_single(query);
     PhaseTimer::mark("embed_query");
     auto res = search_documents(documents, emb, query_embedding, config);

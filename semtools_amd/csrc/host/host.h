@@ -184,12 +184,14 @@ private:
 };
 
 // src/search/mod.rs:49-75: None for empty content; original lines kept; lower-cased copy embedded.
-// The document's lines are views into `content`: the first form leaves the buffer with the caller (it must outlive the document),
-// the second hands the content to the document.
+// The document's lines are views into `content`: the buffer stays with the caller and must outlive the document (documents read
+// from files own their content: load_documents).
 std::optional<Document> create_document_from_content(const std::string &filename, std::string_view content,
                                                      const StaticModel &model, bool ignore_case, Embeddings &emb);
-std::optional<Document> create_document_from_content(const std::string &filename, std::shared_ptr<const std::string> content,
-                                                     const StaticModel &model, bool ignore_case, Embeddings &emb);
+
+// The documents of `files` (mod.rs:128-134: empty files give none), their lines embedded into `emb` in ONE pipeline run across the
+// file borders; throws on the first unreadable file.
+std::vector<Document> load_documents(const std::vector<std::string> &files, const StaticModel &model, bool ignore_case, Embeddings &emb);
 
 // src/search/mod.rs:77-120.  `documents` must be in the order their lines were embedded into `emb`.
 std::vector<SearchResult> search_documents(const std::vector<Document> &documents, const Embeddings &emb,

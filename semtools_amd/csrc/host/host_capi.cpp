@@ -382,11 +382,8 @@ int smt_host_session_open(smt_host_model *model, const char *const *files, uint6
         s->model = model;
         s->ignore_case = ignore_case != 0;
         s->emb = std::make_unique<search::Embeddings>(model->m->group());
-        for (uint64_t i = 0; i < n_files; ++i) {
-            auto doc = search::create_document_from_content(files[i], std::make_shared<const std::string>(read_to_string(files[i])), *model->m,
-                                                            s->ignore_case, *s->emb);
-            if (doc) s->docs.push_back(std::move(*doc));
-        }
+        // (one embedding pipeline run over all files, like search_files: a repository is thousands of small files)
+        s->docs = search::load_documents(std::vector<std::string>(files, files + n_files), *model->m, s->ignore_case, *s->emb);
         *out = s.release();
         return SMT_OK;
     } catch (const std::exception &e) { return fail(e); }
