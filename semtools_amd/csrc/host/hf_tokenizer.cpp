@@ -411,6 +411,7 @@ void apply_pre(const PreTokenizer &p, std::vector<U32> &pieces, bool first_secti
 
 struct AddedToken {
     U32 content;
+    std::string bytes;   // the content as bytes when it is pure ASCII and matched on the raw text (encode_ascii)
     uint32_t id = 0;
     bool single_word = false, lstrip = false, rstrip = false, normalized = false;
 };
@@ -510,11 +511,17 @@ public:
                 size_ = std::max<uint64_t>(size_, (uint64_t)t.id + 1);
                 if (!t.content.empty()) added_.push_back(std::move(t));
             }
-        for (const AddedToken &t : added_)
-            if (!t.normalized && t.content[0] < 0x80) {
-                added_first_[t.content[0]] = true;
-                // lstrip / rstrip tokens swallow neighbouring white space, which cannot change what a line WITHOUT the token encodes to
-            }
+        for (AddedToken &t : added_) {
+            if (t.normalized) continue;
+            bool ascii = true;
+            for (uint32_t c : t.content) ascii = ascii && c < 0x80;
+            if (!ascii) continue;   // (cannot stand in a pure-ASCII line)
+            t.bytes.assign(t.content.begin(), t.content.end());
+            added_first_[t.content[0]] = true;
+            // lstrip / rstrip tokens swallow neighbouring white space, which cannot change what a line WITHOUT the token encodes to;
+            // single_word tokens that do not match because of their neighbours still send the line to the general path (rare, correct)
+        }
+        for (const AddedToken &t : added_) if (!t.bytes.empty()) added_ascii_.push_back(t);
         ascii_fast_ = wordpiece_ && has_pre_ && pre_.kind == PreTokenizer::Bert && (!has_norm_ || norm_.kind == Normalizer::Bert);
     }
 
@@ -580,15 +587,19 @@ private:
     // the pre-tokenizer isolates ASCII punctuation and splits at white space, WordPiece matches greedily -- without the u32 copy of
     // the text, a string per piece and three vectors per word (3.9 -> ~0.8 us per line of prose; tests/test_tokenizer.py runs both
     // paths against the `tokenizers` wheel).  Returns false -- nothing appended -- when the line is not its case: a byte >= 0x80, or a
-    // byte an added token starts with (those are matched on the raw text first: the general path does it).
+    // place where an added token stands (those are matched on the raw text first: the general path does it).
     bool encode_ascii(const std::string &text, std::vector<uint32_t> &ids) const
     {
         static thread_local std::string norm;
         norm.clear();
         const bool bert_norm = has_norm_;
-        for (const char ch : text) {
-            const unsigned char c = (unsigned char)ch;
-            if (c >= 0x80 || added_first_[c]) return false;
+        for (size_t at = 0; at < text.size(); ++at) {
+            const unsigned char c = (unsigned char)text[at];
+            if (c >= 0x80) return false;
+            if (added_first_[c]) {   // ('[' is in every Markdown or source line: only a token that really stands here sends the line away)
+                for (const AddedToken &t : added_ascii_)
+                    if (text.compare(at, t.bytes.size(), t.bytes) == 0) return false;
+            }
             if (!bert_norm) { norm.push_back((char)c); continue; }
             if (norm_.clean_text) {
                 if (c == '\t' || c == '\n' || c == '\r') { norm.push_back(' '); continue; }
@@ -706,7 +717,8 @@ private:
     PreTokenizer pre_;
     bool has_norm_ = false, has_pre_ = false, wordpiece_ = false;
     bool ascii_fast_ = false;          // BertNormalizer (or none) -> BertPreTokenizer -> WordPiece: encode_ascii applies
-    bool added_first_[128] = {};       // ASCII bytes a (non-normalized) added token starts with
+    bool added_first_[128] = {};       // ASCII bytes a (non-normalized, pure-ASCII) added token starts with
+    std::vector<AddedToken> added_ascii_;   // those tokens
     FlatVocab vocab_;
     std::vector<double> scores_;
     std::string prefix_ = "##";
