@@ -828,9 +828,23 @@ std::vector<Document> load_documents(const std::vector<std::string> &files, cons
     std::vector<Document> documents;
     std::vector<std::string_view> all;
     std::deque<std::string> lowered;   // (mod.rs:61-67: the lowered copies are what is embedded; a deque never moves its elements)
-    for (auto &f : files) {
-        auto text = std::make_shared<const std::string>(read_to_string(f));  // `?`: first error aborts (mod.rs:130)
-        std::vector<std::string_view> lines = line_views(*text);
+    // the files are read (and cut into lines) on up to eight threads; the first unreadable file IN ORDER is the error (mod.rs:130 `?`)
+    std::vector<std::shared_ptr<const std::string>> texts(files.size());
+    std::vector<std::vector<std::string_view>> views(files.size());
+    std::vector<std::exception_ptr> unreadable(files.size());
+    parallel_slices(files.size(), 8, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            try {
+                texts[i] = std::make_shared<const std::string>(read_to_string(files[i]));
+                views[i] = line_views(*texts[i]);
+            } catch (...) { unreadable[i] = std::current_exception(); }
+        }
+    });
+    for (auto &u : unreadable) if (u) std::rethrow_exception(u);
+    for (size_t fi = 0; fi < files.size(); ++fi) {
+        const std::string &f = files[fi];
+        std::shared_ptr<const std::string> text = std::move(texts[fi]);
+        std::vector<std::string_view> lines = std::move(views[fi]);
         if (lines.empty()) continue;                     // create_document_from_content -> None (mod.rs:57-59)
         Document doc;
         doc.filename = f;

@@ -709,34 +709,48 @@ std::vector<RankedLine> Store::search_line_embeddings(const std::vector<float> &
 std::vector<DocumentState> Store::analyze_document_states(const std::vector<std::string> &file_paths) const
 {
     const auto existing = get_existing_docs(file_paths);
-    std::vector<DocumentState> states;
-    for (auto &fp : file_paths) {
-        struct stat st;
-        if (stat(fp.c_str(), &st) != 0) continue;  // file doesn't exist: skipped (store.rs:573-576)
-        DocMeta cur;
-        cur.path = fp;
-        cur.size_bytes = (uint64_t)st.st_size;
-        cur.mtime = (int64_t)st.st_mtime;
-        cur._version = CURRENT_EMBEDDING_VERSION;
-        auto it = existing.find(fp);
-        DocumentState ds;
-        if (it != existing.end()) {
-            const DocMeta &ex = it->second;
-            // (a document whose line rows are gone -- torn write, unreadable corpus file -- must be re-embedded even
-            // though its metadata says "unchanged": it would otherwise silently drop out of every search)
-            const bool rows_missing = extents_.find(fp) == extents_.end();
-            if (rows_missing || ex.size_bytes != cur.size_bytes || ex.mtime != cur.mtime || ex._version != CURRENT_EMBEDDING_VERSION) {
-                ds.kind = DocumentState::Changed;
-                ds.info = DocumentInfo{fp, read_to_string(fp), cur};
-            } else {
-                ds.kind = DocumentState::Unchanged;
-                ds.filename = fp;
-            }
-        } else {
-            ds.kind = DocumentState::New;
-            ds.info = DocumentInfo{fp, read_to_string(fp), cur};
+    // stat + read on up to eight threads (a repository is thousands of small files: open / read / close one by one was the whole
+    // change-detection phase); states keep the order of file_paths, the first unreadable file IN THAT ORDER is the error raised
+    // (store.rs:549-611 reads them in order with `?`)
+    std::vector<std::optional<DocumentState>> found(file_paths.size());
+    std::vector<std::exception_ptr> failed(file_paths.size());
+    parallel_slices(file_paths.size(), 8, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const std::string &fp = file_paths[i];
+            try {
+                struct stat st;
+                if (stat(fp.c_str(), &st) != 0) continue;  // file doesn't exist: skipped (store.rs:573-576)
+                DocMeta cur;
+                cur.path = fp;
+                cur.size_bytes = (uint64_t)st.st_size;
+                cur.mtime = (int64_t)st.st_mtime;
+                cur._version = CURRENT_EMBEDDING_VERSION;
+                auto it = existing.find(fp);
+                DocumentState ds;
+                if (it != existing.end()) {
+                    const DocMeta &ex = it->second;
+                    // (a document whose line rows are gone -- torn write, unreadable corpus file -- must be re-embedded even
+                    // though its metadata says "unchanged": it would otherwise silently drop out of every search)
+                    const bool rows_missing = extents_.find(fp) == extents_.end();
+                    if (rows_missing || ex.size_bytes != cur.size_bytes || ex.mtime != cur.mtime || ex._version != CURRENT_EMBEDDING_VERSION) {
+                        ds.kind = DocumentState::Changed;
+                        ds.info = DocumentInfo{fp, read_to_string(fp), cur};
+                    } else {
+                        ds.kind = DocumentState::Unchanged;
+                        ds.filename = fp;
+                    }
+                } else {
+                    ds.kind = DocumentState::New;
+                    ds.info = DocumentInfo{fp, read_to_string(fp), cur};
+                }
+                found[i] = std::move(ds);
+            } catch (...) { failed[i] = std::current_exception(); }
         }
-        states.push_back(std::move(ds));
+    });
+    std::vector<DocumentState> states;
+    for (size_t i = 0; i < file_paths.size(); ++i) {
+        if (failed[i]) std::rethrow_exception(failed[i]);
+        if (found[i]) states.push_back(std::move(*found[i]));
     }
     return states;
 }
