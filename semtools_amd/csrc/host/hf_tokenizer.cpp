@@ -252,6 +252,48 @@ PreTokenizer parse_pre(const json::Value &v)
     return p;
 }
 
+// BertNormalizer in ONE pass for a text whose code points are all below U+0300 (ASCII, Latin-1, Latin Extended, IPA: no combining
+// mark, no CJK): per character exactly what the four passes of apply_normalizer's Bert case do one after the other -- clean_text
+// drops NUL / controls / format characters and turns white space into ' '; Chinese characters cannot occur; strip_accents keeps the
+// base of the canonical decomposition (every mark such a character decomposes into is a non-spacing mark U+0300..U+036F, so the
+// canonical reordering only permutes characters that are removed); lower-casing is per character.
+bool bert_normalize_below_0300(const Normalizer &n, const U32 &in, U32 &out)
+{
+    for (uint32_t c : in) if (c >= 0x300) return false;
+    out.clear();
+    out.reserve(in.size());
+    const size_t n_nfd = sizeof(unicode::NFD_TABLE) / sizeof(unicode::NFD_TABLE[0]);
+    for (uint32_t c : in) {
+        if (n.clean_text) {
+            const bool tnr = c == '\t' || c == '\n' || c == '\r';
+            if (c == 0 || (!tnr && is_other(c))) continue;
+            if (tnr || is_white_space(c)) c = ' ';
+        }
+        if (c < 0x80) { out.push_back(n.lowercase && c >= 'A' && c <= 'Z' ? c + 32 : c); continue; }
+        if (n.strip_accents && c >= 0xC0) {
+            size_t lo = 0, hi = n_nfd;
+            bool found = false;
+            while (lo < hi) {
+                const size_t mid = (lo + hi) / 2;
+                if (c > unicode::NFD_TABLE[mid].cp) lo = mid + 1;
+                else if (c < unicode::NFD_TABLE[mid].cp) hi = mid;
+                else {
+                    for (uint32_t k = 0; k < unicode::NFD_TABLE[mid].n; ++k) {
+                        const uint32_t d = unicode::NFD_TABLE[mid].to[k];
+                        if (is_mn(d)) continue;
+                        if (n.lowercase) lower_char(d, out); else out.push_back(d);
+                    }
+                    found = true;
+                    break;
+                }
+            }
+            if (found) continue;
+        }
+        if (n.lowercase) lower_char(c, out); else out.push_back(c);
+    }
+    return true;
+}
+
 void apply_normalizer(const Normalizer &n, U32 &s)
 {
     U32 t;
@@ -288,6 +330,7 @@ void apply_normalizer(const Normalizer &n, U32 &s)
             return;
         }
         case Normalizer::Bert: {
+            if (bert_normalize_below_0300(n, s, t)) { s.swap(t); return; }
             if (n.clean_text) {  // drop NUL / U+FFFD / control characters, every white space becomes ' '
                 for (uint32_t c : s) {
                     const bool ws = c == '\t' || c == '\n' || c == '\r' || is_white_space(c);
@@ -572,6 +615,7 @@ private:
     void encode_section(U32 s, bool first_section, std::vector<uint32_t> &ids) const
     {
         if (has_norm_) apply_normalizer(norm_, s);
+        if (wordpiece_ && has_pre_ && pre_.kind == PreTokenizer::Bert) { wordpiece_bert_words(s, ids); return; }
         std::vector<U32> pieces(1, std::move(s));
         if (has_pre_) apply_pre(pre_, pieces, first_section);
         for (const U32 &w : pieces) {
@@ -642,6 +686,49 @@ private:
             if (bad) { ids.resize(mark); ids.push_back(*unk_); }
         }
         return true;
+    }
+
+    // BertPreTokenizer + WordPiece over the normalised text without a string per word: the words are spans of `s` (white space
+    // skipped, every punctuation character a word of its own: apply_pre's Bert case), each converted once into a per-thread byte
+    // buffer with the byte offset of every character, then matched greedily like wordpiece() below.  (Lines with one accented
+    // letter take this path -- most lines of most European languages: 3.9 -> 2 us per line.)
+    void wordpiece_bert_words(const U32 &s, std::vector<uint32_t> &ids) const
+    {
+        static thread_local std::string bytes, cand;
+        static thread_local std::vector<uint32_t> off;
+        size_t i = 0;
+        const size_t n = s.size();
+        while (i < n) {
+            if (is_white_space(s[i])) { ++i; continue; }
+            const size_t b = i;
+            if (is_bert_punc(s[i])) ++i;
+            else while (i < n && !is_white_space(s[i]) && !is_bert_punc(s[i])) ++i;
+            const size_t len = i - b, mark = ids.size();
+            if (len > max_chars_) { ids.push_back(*unk_); continue; }
+            bytes.clear();
+            off.resize(len + 1);
+            for (size_t c = 0; c < len; ++c) { off[c] = (uint32_t)bytes.size(); encode_cp(bytes, s[b + c]); }
+            off[len] = (uint32_t)bytes.size();
+            size_t start = 0;
+            bool bad = false;
+            while (start < len) {
+                size_t end = len;
+                int64_t hit = -1;
+                if (start == 0) {
+                    for (; end > start; --end)
+                        if ((hit = vocab_.find(bytes.data(), off[end])) >= 0) break;
+                } else {
+                    cand.assign(prefix_);
+                    cand.append(bytes, off[start], std::string::npos);
+                    for (; end > start; --end)
+                        if ((hit = vocab_.find(cand.data(), prefix_.size() + (off[end] - off[start]))) >= 0) break;
+                }
+                if (hit < 0) { bad = true; break; }
+                ids.push_back((uint32_t)hit);
+                start = end;
+            }
+            if (bad) { ids.resize(mark); ids.push_back(*unk_); }
+        }
     }
 
     // WordPiece::tokenize: greedy longest match; a word with an unmatched tail (or too many chars) is ONE unk token

@@ -60,6 +60,11 @@ def samples(seed, n=300):
         parts = [rng.choice(words) for _ in range(rng.randint(1, 14))]
         out.append(rng.choice([" ", "  ", "\t", "\n", " \r\n"]).join(parts))
         out.append("".join(rng.choice(ascii_pool) for _ in range(rng.randint(1, 80))))
+    # Latin text below U+0300 (the one-pass BertNormalizer of the native reader): accented letters with and without canonical
+    # decompositions, ligatures and digraphs, NBSP / NEL / soft hyphen / C1 controls, dotted and dotless i
+    latin = [chr(c) for c in list(range(0x20, 0x7F)) + list(range(0x80, 0x250))] + ["\t", "\n", " the ", " search ", "İ", "ı", "ǅ", "ß"]
+    for _ in range(n // 2):
+        out.append("".join(rng.choice(latin) for _ in range(rng.randint(1, 60))))
     return out
 
 
