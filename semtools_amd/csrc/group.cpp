@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 
 #include <functional>
@@ -249,6 +250,35 @@ int group_agree(smt_group *g, int rc)
     return SMT_OK;
 }
 
+// fn(i) for i in [0, n) on n threads that ALL exist before any of them starts: a thread that cannot be created must not leave the
+// others waiting for it inside a collective.  false = the threads could not be had and nothing ran.
+static bool run_on_threads(int n, const std::function<void(int)> &fn)
+{
+    std::mutex mu;
+    std::condition_variable cv;
+    int go = 0;   // 0: wait, 1: run, -1: leave
+    std::vector<std::thread> th;
+    auto body = [&](int i) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return go != 0; });
+        }
+        if (go == 1) fn(i);
+    };
+    bool ok = true;
+    try {
+        for (int i = 0; i < n; ++i) th.emplace_back(body, i);
+    } catch (const std::system_error &) { ok = false; }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        go = ok ? 1 : -1;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+    if (!ok) set_error("cannot start a host thread per device");
+    return ok;
+}
+
 static void worker_main(smt_group *g, int i)
 {
     GroupWorkers *w = g->workers;
@@ -277,6 +307,8 @@ static void worker_main(smt_group *g, int i)
     }
 }
 
+static void group_stop_workers(smt_group *g);
+
 static int group_start_workers(smt_group *g)
 {
     if (g->n_local <= 1 || g->workers) return SMT_OK;
@@ -286,7 +318,11 @@ static int group_start_workers(smt_group *g)
     if (!g->workers) { set_error("out of host memory"); return SMT_E_NOMEM; }
     g->workers->rcs.assign(g->n_local, SMT_OK);
     g->workers->errs.assign(g->n_local, std::string());
-    for (int i = 0; i < g->n_local; ++i) g->workers->threads.emplace_back(worker_main, g, i);
+    try {
+        for (int i = 0; i < g->n_local; ++i) g->workers->threads.emplace_back(worker_main, g, i);
+    } catch (const std::system_error &) {
+        group_stop_workers(g);   // (the ones that exist leave; the group then issues from threads made per call, or from the caller's)
+    }
     return SMT_OK;
 }
 
@@ -328,11 +364,7 @@ int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool
         w->work = nullptr;
         rcs = w->rcs;
         errs = w->errs;
-    } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < g->n_local; ++i) th.emplace_back(run, i);
-        for (auto &t : th) t.join();
-    }
+    } else if (!run_on_threads(g->n_local, run)) return SMT_E_NOMEM;
     for (int i = 0; i < g->n_local; ++i)
         if (rcs[i]) {
             if (g->n_ranks > 1) set_error("shard %d: %s", g->first_rank + i, errs[i].c_str());
@@ -494,11 +526,7 @@ static int local_host_search(smt_sharded_corpus *sc, const float *queries, uint3
                 for (uint64_t &row : h.rows) row = layout_to_global(sc, r, row);
     };
     if (g->n_local == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < g->n_local; ++i) th.emplace_back(work, i);
-        for (auto &t : th) t.join();
-    }
+    else if (!run_on_threads(g->n_local, work)) return SMT_E_NOMEM;
     for (int i = 0; i < g->n_local; ++i)
         if (rcs[i]) { set_error("shard %d: %s", g->first_rank + i, errs[i].c_str()); return rcs[i]; }
     return SMT_OK;
@@ -1013,11 +1041,7 @@ int smt_sharded_ivfpq_build(smt_sharded_corpus *sc, const smt_ivfpq_params *para
         if (rcs[i]) errs[i] = smt_last_error();
     };
     if (g->n_local == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < g->n_local; ++i) th.emplace_back(work, i);
-        for (auto &t : th) t.join();
-    }
+    else if (!run_on_threads(g->n_local, work)) { smt_sharded_ivfpq_destroy(six); return SMT_E_NOMEM; }
     for (int i = 0; i < g->n_local; ++i)
         if (rcs[i]) {
             set_error("shard %d: %s", g->first_rank + i, errs[i].c_str());

@@ -451,25 +451,17 @@ void StaticModel::embed_csr(const std::vector<uint32_t> &ids, const std::vector<
     std::sort(uniq.begin(), uniq.end());          // file order: neighbouring rows share pages
     for (size_t s = 0; s < uniq.size(); ++s) lazy_slot_[uniq[s]] = (uint32_t)s + 1;
     std::vector<float> compact(std::max<size_t>(uniq.size(), 1) * SMT_DIM, 0.0f);
-    {
-        const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)8, uniq.size() / 512}));
-        std::vector<std::exception_ptr> failed(n_threads);
-        auto work = [&](size_t t) {
-            try {
-                for (size_t s = uniq.size() * t / n_threads; s < uniq.size() * (t + 1) / n_threads; ++s) {
-                    const off_t at = (off_t)(lazy_offset_ + (uint64_t)uniq[s] * SMT_DIM * sizeof(float));
-                    if (pread(lazy_fd_, &compact[s * SMT_DIM], SMT_DIM * sizeof(float), at) != (ssize_t)(SMT_DIM * sizeof(float)))
-                        throw Error("short read from " + lazy_path_);
-                }
-            } catch (...) { failed[t] = std::current_exception(); }
-        };
-        if (n_threads == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
-            for (auto &x : th) x.join();
-        }
-        for (auto &f : failed) if (f) { for (uint32_t id : uniq) lazy_slot_[id] = 0; std::rethrow_exception(f); }
+    try {
+        parallel_slices(uniq.size(), 512, [&](size_t sb, size_t se) {
+            for (size_t s = sb; s < se; ++s) {
+                const off_t at = (off_t)(lazy_offset_ + (uint64_t)uniq[s] * SMT_DIM * sizeof(float));
+                if (pread(lazy_fd_, &compact[s * SMT_DIM], SMT_DIM * sizeof(float), at) != (ssize_t)(SMT_DIM * sizeof(float)))
+                    throw Error("short read from " + lazy_path_);
+            }
+        });
+    } catch (...) {
+        for (uint32_t id : uniq) lazy_slot_[id] = 0;
+        throw;
     }
     std::vector<uint32_t> remapped(ids.size());
     for (size_t i = 0; i < ids.size(); ++i) remapped[i] = lazy_slot_[ids[i]] - 1;
@@ -553,7 +545,7 @@ void StaticModel::tokenize_batch(const std::string_view *sentences, size_t begin
     size_t arrived = 0;
     bool sized = false, any_failed = false;
     auto slice = [&](size_t t) { return std::make_pair(begin + n * t / n_threads, begin + n * (t + 1) / n_threads); };
-    auto work = [&](size_t t) {
+    auto tokenise = [&](size_t t) {   // (A)
         const auto [b, e] = slice(t);
         try {
             std::vector<uint32_t> tmp;
@@ -579,34 +571,48 @@ void StaticModel::tokenize_batch(const std::string_view *sentences, size_t begin
             part_ids[t] = std::move(my_ids);
             part_len[t] = std::move(my_len);
         } catch (...) { failed[t] = std::current_exception(); }
-        {   // ---- barrier; the last thread to arrive lays the batch out
-            std::unique_lock<std::mutex> lk(mu);
-            if (failed[t]) any_failed = true;
-            if (++arrived == n_threads) {
-                if (!any_failed) {
-                    try {
-                        for (size_t u = 0; u < n_threads; ++u) id_base[u + 1] = id_base[u] + part_ids[u].size();
-                        ids.resize(id_base[n_threads]);
-                        offsets.resize(n + 1);
-                        offsets[0] = 0;
-                    } catch (...) { failed[t] = std::current_exception(); any_failed = true; }
-                }
-                sized = true;
-                cv.notify_all();
-            } else cv.wait(lk, [&] { return sized; });
-            if (any_failed) return;
-        }
+    };
+    // the barrier: slices [t0, t0 + count) of the calling thread are done; the last thread to arrive lays the batch out.  Returns
+    // whether (B) may run.
+    auto arrive = [&](size_t t0, size_t count) -> bool {
+        std::unique_lock<std::mutex> lk(mu);
+        for (size_t t = t0; t < t0 + count; ++t) if (failed[t]) any_failed = true;
+        arrived += count;
+        if (arrived == n_threads) {
+            if (!any_failed) {
+                try {
+                    for (size_t u = 0; u < n_threads; ++u) id_base[u + 1] = id_base[u] + part_ids[u].size();
+                    ids.resize(id_base[n_threads]);
+                    offsets.resize(n + 1);
+                    offsets[0] = 0;
+                } catch (...) { failed[t0] = std::current_exception(); any_failed = true; }
+            }
+            sized = true;
+            cv.notify_all();
+        } else cv.wait(lk, [&] { return sized; });
+        return !any_failed;
+    };
+    auto place = [&](size_t t) {      // (B)
         if (!part_ids[t].empty()) memcpy(ids.data() + id_base[t], part_ids[t].data(), part_ids[t].size() * sizeof(uint32_t));
         uint64_t at = id_base[t];
-        uint64_t *off = offsets.data() + (b - begin) + 1;
+        uint64_t *off = offsets.data() + (slice(t).first - begin) + 1;
         for (uint32_t l : part_len[t]) { at += l; *off++ = at; }
     };
-    if (n_threads == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+    auto work = [&](size_t t) {
+        tokenise(t);
+        if (arrive(t, 1)) place(t);
+    };
+    // the LAST slice runs on the calling thread; a thread that cannot be started leaves its slice -- and all later ones -- to the
+    // caller too, who arrives for all of them at once: nobody waits for a thread that does not exist
+    std::vector<std::thread> th;
+    size_t started = 0;
+    try {
+        for (; started + 1 < n_threads; ++started) th.emplace_back(work, started);
+    } catch (const std::system_error &) {}
+    for (size_t t = started; t < n_threads; ++t) tokenise(t);
+    if (arrive(started, n_threads - started))
+        for (size_t t = started; t < n_threads; ++t) place(t);
+    for (auto &x : th) x.join();
     for (auto &f : failed) if (f) std::rethrow_exception(f);
 }
 

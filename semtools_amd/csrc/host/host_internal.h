@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <exception>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -26,10 +27,15 @@ inline void parallel_slices(size_t n, size_t grain, Fn fn)
     if (n_threads == 1) { fn((size_t)0, n); return; }
     std::vector<std::exception_ptr> failed(n_threads);
     std::vector<std::thread> th;
-    for (size_t t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() {
-            try { fn(n * t / n_threads, n * (t + 1) / n_threads); } catch (...) { failed[t] = std::current_exception(); }
-        });
+    auto run = [&](size_t t) {
+        try { fn(n * t / n_threads, n * (t + 1) / n_threads); } catch (...) { failed[t] = std::current_exception(); }
+    };
+    // the last slice runs here; so does every slice whose thread could not be started
+    size_t started = 0;
+    try {
+        for (; started + 1 < n_threads; ++started) th.emplace_back(run, started);
+    } catch (const std::system_error &) {}
+    for (size_t t = started; t < n_threads; ++t) run(t);
     for (auto &x : th) x.join();
     for (auto &f : failed) if (f) std::rethrow_exception(f);
 }
