@@ -137,6 +137,21 @@ int check_ctx(const smt_ctx *ctx)
     return SMT_OK;
 }
 
+int api_catch() noexcept
+{
+    try { throw; }
+    catch (const std::bad_alloc &) {
+        try { set_error("out of host memory"); } catch (...) {}
+        return SMT_E_NOMEM;
+    } catch (const std::exception &e) {
+        try { set_error("%s", e.what()); } catch (...) {}
+        return SMT_E_INVALID;
+    } catch (...) {
+        try { set_error("unknown C++ exception"); } catch (...) {}
+        return SMT_E_INVALID;
+    }
+}
+
 int bind_device(smt_ctx *ctx, bool drain)
 {
     SMT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -261,12 +276,12 @@ const char *smt_last_error(void) { return g_err; }
 const char *smt_version(void) { return "semtools-hip 0.1.0 (gfx950)"; }
 
 int smt_device_count(void)
-{
+try {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return SMT_E_HIP; }
     return n;
-}
+} catch (...) { return smt::api_catch(); }
 
 static int ctx_create_impl(int device, void *stream, bool use_given, smt_ctx **out)
 {
@@ -311,9 +326,9 @@ static int ctx_create_impl(int device, void *stream, bool use_given, smt_ctx **o
 int smt_ctx_create(int device, smt_ctx **out) { return ctx_create_impl(device, nullptr, false, out); }
 
 int smt_ctx_create_on_stream(int device, void *stream, smt_ctx **out)
-{
+try {
     return ctx_create_impl(device, stream, true, out);
-}
+} catch (...) { return smt::api_catch(); }
 
 void smt_ctx_destroy(smt_ctx *ctx)
 {
@@ -334,16 +349,16 @@ void smt_ctx_destroy(smt_ctx *ctx)
 }
 
 int smt_ctx_synchronize(smt_ctx *ctx)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_HIP_CHECK(hipSetDevice(ctx->device));
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return drain_async(ctx);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(count != nullptr, "null argument");
@@ -354,10 +369,10 @@ int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset)
     if (reset && v) SMT_HIP_CHECK(hipMemset(ctx->d_status, 0, sizeof(v)));
     *count = v;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(stream_out != nullptr, "null argument");
@@ -365,27 +380,27 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out)
     if ((rc = ensure_async(ctx))) return rc;
     *stream_out = reinterpret_cast<void *>(ctx->aux_stream);
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_prof_enable(smt_ctx *ctx, int on)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->prof_on = on != 0;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_prof_reset(smt_ctx *ctx)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (auto &kv : ctx->prof) { kv.second.used = 0; kv.second.calls = 0; kv.second.armed = false; }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_prof_read(smt_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(kernel && launches && total_ms, "null argument");
@@ -402,10 +417,10 @@ int smt_prof_read(smt_ctx *ctx, const char *kernel, uint64_t *launches, double *
         *launches += 1;
     }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(key != nullptr, "key");
@@ -453,13 +468,13 @@ int smt_set_tuning(smt_ctx *ctx, const char *key, int64_t value)
     else if (k == "prof_select") ctx->tune.prof_select = (int)value;
     else { set_error("unknown tuning key '%s'", key); return SMT_E_INVALID; }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 /* ---------------------------------------------------------------- model ---- */
 
 int smt_model_create(smt_ctx *ctx, const float *table_host, uint64_t V, uint32_t D, int normalize,
                      smt_model **out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(out && table_host, "null argument");
@@ -478,11 +493,11 @@ int smt_model_create(smt_ctx *ctx, const float *table_host, uint64_t V, uint32_t
     if (e != hipSuccess) { (void)hipFree(m->d_table); delete m; set_error("table upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
     *out = m;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_model_create_from_device(smt_ctx *ctx, const float *table_dev, uint64_t V, uint32_t D,
                                  int normalize, smt_model **out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(out && table_dev, "null argument");
@@ -495,7 +510,7 @@ int smt_model_create_from_device(smt_ctx *ctx, const float *table_dev, uint64_t 
     m->owned = false;
     *out = m;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 void smt_model_destroy(smt_model *model)
 {
@@ -509,7 +524,7 @@ void smt_model_destroy(smt_model *model)
 /* --------------------------------------------------------------- corpus ---- */
 
 int smt_corpus_create(smt_ctx *ctx, uint32_t D, uint64_t capacity_rows, smt_corpus **out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(out != nullptr, "out");
@@ -525,10 +540,10 @@ int smt_corpus_create(smt_ctx *ctx, uint32_t D, uint64_t capacity_rows, smt_corp
     }
     *out = c;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_corpus_from_device(smt_ctx *ctx, const float *rows_dev, uint64_t n_rows, uint32_t D, smt_corpus **out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(out && (rows_dev || n_rows == 0), "null argument");
@@ -541,7 +556,7 @@ int smt_corpus_from_device(smt_ctx *ctx, const float *rows_dev, uint64_t n_rows,
     c->rows = n_rows; c->capacity = n_rows;
     *out = c;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 void smt_corpus_destroy(smt_corpus *corpus)
 {
@@ -558,7 +573,7 @@ uint64_t smt_corpus_rows(const smt_corpus *corpus) { return corpus ? corpus->row
 uint32_t smt_corpus_dim(const smt_corpus *corpus) { return corpus ? corpus->dim : 0; }
 
 int smt_corpus_append_host(smt_corpus *c, const float *rows, uint64_t n_rows, uint64_t *first_row)
-{
+try {
     SMT_REQUIRE(c != nullptr, "corpus");
     SMT_REQUIRE(rows || n_rows == 0, "rows");
     int rc = bind_device(c->ctx);
@@ -571,10 +586,10 @@ int smt_corpus_append_host(smt_corpus *c, const float *rows, uint64_t n_rows, ui
     SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
     c->rows += n_rows;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_corpus_write_rows(smt_corpus *c, uint64_t first_row, const float *rows, uint64_t n_rows)
-{
+try {
     SMT_REQUIRE(c != nullptr && (rows || n_rows == 0), "null argument");
     SMT_REQUIRE(first_row + n_rows <= c->rows, "row range outside the corpus");
     int rc = bind_device(c->ctx);
@@ -585,10 +600,10 @@ int smt_corpus_write_rows(smt_corpus *c, uint64_t first_row, const float *rows, 
     SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
     c->image_rows = std::min<uint64_t>(c->image_rows, first_row / 32 * 32);   // the operand image is packed again from this tile on
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_corpus_prepack(smt_corpus *c, int enable)
-{
+try {
     SMT_REQUIRE(c != nullptr, "corpus");
     int rc = bind_device(c->ctx);
     if (rc) return rc;
@@ -605,12 +620,12 @@ int smt_corpus_prepack(smt_corpus *c, int enable)
     if ((rc = corpus_image_sync(c, 0, &img, &zero))) return rc;
     if (c->rows && !img) { set_error("no room for the operand image (%llu bytes)", (unsigned long long)((c->rows + 31) / 32 * 16384)); return SMT_E_NOMEM; }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 uint64_t smt_corpus_image_bytes(const smt_corpus *c) { return c && c->image ? c->image_cap_tiles * (16384 + 4) : 0; }
 
 int smt_corpus_read_rows(smt_corpus *c, uint64_t first_row, uint64_t n_rows, float *out_host)
-{
+try {
     SMT_REQUIRE(c != nullptr && (out_host || n_rows == 0), "null argument");
     SMT_REQUIRE(first_row + n_rows <= c->rows, "row range outside the corpus");
     int rc = bind_device(c->ctx);
@@ -620,33 +635,33 @@ int smt_corpus_read_rows(smt_corpus *c, uint64_t first_row, uint64_t n_rows, flo
                                  hipMemcpyDeviceToHost, c->ctx->stream));
     SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_corpus_truncate(smt_corpus *c, uint64_t n_rows)
-{
+try {
     SMT_REQUIRE(c != nullptr, "corpus");
     SMT_REQUIRE(n_rows <= c->rows, "cannot truncate to more rows than stored");
     c->rows = n_rows;
     c->image_rows = std::min<uint64_t>(c->image_rows, n_rows / 32 * 32);   // rows appended later land in tiles the image packs again
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 /* ---------------------------------------------------------------- embed ---- */
 
 int smt_embed_device(smt_model *model, const uint32_t *ids_dev, const uint64_t *offsets_dev, uint64_t n_lines,
                      uint32_t max_tokens, float *out_dev)
-{
+try {
     SMT_REQUIRE(model != nullptr, "model");
     SMT_REQUIRE(n_lines == 0 || (offsets_dev && out_dev), "null argument");
     int rc = bind_device(model->ctx);
     if (rc) return rc;
     return launch_embed(model->ctx, model->d_table, model->V, model->normalize, ids_dev, offsets_dev, n_lines,
                         max_tokens, out_dev, 0);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens,
               float *out_host, smt_corpus *append_to, uint64_t *first_row)
-{
+try {
     SMT_REQUIRE(model != nullptr, "model");
     SMT_REQUIRE(n_lines == 0 || offsets != nullptr, "offsets");
     smt_ctx *ctx = model->ctx;
@@ -694,7 +709,7 @@ int smt_embed(smt_model *model, const uint32_t *ids, const uint64_t *offsets, ui
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (append_to) append_to->rows += n_lines;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 /* ------------------------------------------------------------------ ids ---- */
 

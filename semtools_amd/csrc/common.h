@@ -147,6 +147,9 @@ namespace smt {
 
 int check_ctx(const smt_ctx *ctx);
 int bind_device(smt_ctx *ctx, bool drain = true);   // hipSetDevice + (drain) wait for async selects
+// The handler of every int-returning extern "C" entry point (each is a function-try-block): a C++ exception -- bad_alloc from a host
+// vector, anything a callee throws -- becomes an error code and message; it must never unwind into a C, Rust or ctypes caller.
+int api_catch() noexcept;
 int corpus_reserve(smt_corpus *c, uint64_t rows_needed);
 // the image up to date for a batch of nq queries, or left alone (policy, memory): sets *image / *image_zero (nullptr = none)
 int corpus_image_sync(smt_corpus *c, uint32_t nq, const void **image, const uint32_t **image_zero);

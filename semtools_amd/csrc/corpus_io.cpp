@@ -250,7 +250,7 @@ int corpus_file_commit(const char *path, uint64_t rows)
 extern "C" {
 
 int smt_corpus_save(smt_corpus *c, const char *path)
-{
+try {
     SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
     // never rewrite the live file in place: a crash or ENOSPC half way would leave a truncated corpus that
     // every later workspace command rejects.  Write a sibling, fsync, rename.
@@ -264,10 +264,10 @@ int smt_corpus_save(smt_corpus *c, const char *path)
         return SMT_E_IO;
     }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_corpus_append_to_file(smt_corpus *c, const char *path, uint64_t rows_on_disk)
-{
+try {
     SMT_REQUIRE(c != nullptr && path != nullptr, "null argument");
     SMT_REQUIRE(rows_on_disk <= c->rows, "file holds more rows than the corpus");
     int rc = bind_device(c->ctx);
@@ -294,10 +294,10 @@ int smt_corpus_append_to_file(smt_corpus *c, const char *path, uint64_t rows_on_
     if (fclose(f) != 0) ok = false;
     if (!ok) { set_error("short write to '%s'", path); return SMT_E_IO; }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(path && out, "null argument");
@@ -310,11 +310,11 @@ int smt_corpus_load(smt_ctx *ctx, const char *path, smt_corpus **out)
     if ((rc = corpus_load_slice(c, path, 0, rows))) { smt_corpus_destroy(c); return rc; }
     *out = c;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_model_create_from_file(smt_ctx *ctx, const char *path, uint64_t byte_offset, uint64_t V, uint32_t D, int normalize,
                                smt_model **out)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(out && path, "null argument");
@@ -350,6 +350,6 @@ int smt_model_create_from_file(smt_ctx *ctx, const char *path, uint64_t byte_off
     if (e != hipSuccess) { (void)hipFree(m->d_table); delete m; set_error("table upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
     *out = m;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"

@@ -648,7 +648,7 @@ extern "C" {
 /* ------------------------------------------------------------------ group ---- */
 
 int smt_group_create(const int *devices, int n_dev, smt_group **out)
-{
+try {
     SMT_REQUIRE(out != nullptr, "out");
     *out = nullptr;
     SMT_REQUIRE(devices != nullptr && n_dev >= 1, "device list");
@@ -668,10 +668,10 @@ int smt_group_create(const int *devices, int n_dev, smt_group **out)
     if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_group_create_logical(int device, int n_shards, smt_group **out)
-{
+try {
     SMT_REQUIRE(out != nullptr, "out");
     *out = nullptr;
     SMT_REQUIRE(n_shards >= 1 && n_shards <= 64, "1..64 logical shards");
@@ -694,10 +694,10 @@ int smt_group_create_logical(int device, int n_shards, smt_group **out)
     if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_group_from_ctx(smt_ctx *ctx, smt_group **out)
-{
+try {
     SMT_REQUIRE(ctx && out, "null argument");
     *out = nullptr;
     smt_group *g = new (std::nothrow) smt_group();
@@ -719,10 +719,10 @@ int smt_group_from_ctx(smt_ctx *ctx, smt_group **out)
     if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); group_free(g); return SMT_E_HIP; }
     *out = g;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_group_unique_id(void *id_out)
-{
+try {
     SMT_REQUIRE(id_out != nullptr, "id_out");
     int rc = load_rccl();
     if (rc) return rc;
@@ -731,10 +731,10 @@ int smt_group_unique_id(void *id_out)
     SMT_NCCL_CHECK(g_rccl.GetUniqueId(&id));
     memcpy(id_out, &id, sizeof(id));
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_group_create_rank(int device, int rank, int n_ranks, const void *unique_id, smt_group **out)
-{
+try {
     SMT_REQUIRE(out != nullptr, "out");
     *out = nullptr;
     SMT_REQUIRE(unique_id != nullptr, "unique_id");
@@ -756,7 +756,7 @@ int smt_group_create_rank(int device, int rank, int n_ranks, const void *unique_
     if ((rc = group_barrier(g))) { group_free(g); return rc; }
     *out = g;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 void smt_group_destroy(smt_group *group)
 {
@@ -765,7 +765,7 @@ void smt_group_destroy(smt_group *group)
 }
 
 int smt_group_info(const smt_group *group, int *n_ranks, int *n_local, int *first_rank, int *rccl_ranks, int *rccl_version)
-{
+try {
     SMT_REQUIRE(group != nullptr, "group");
     if (n_ranks) *n_ranks = group->n_ranks;
     if (n_local) *n_local = group->n_local;
@@ -777,7 +777,7 @@ int smt_group_info(const smt_group *group, int *n_ranks, int *n_local, int *firs
         *rccl_ranks = count;
     }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 smt_ctx *smt_group_ctx(smt_group *group, int local_index)
 {
@@ -786,21 +786,21 @@ smt_ctx *smt_group_ctx(smt_group *group, int local_index)
 }
 
 int smt_group_synchronize(smt_group *group)
-{
+try {
     SMT_REQUIRE(group != nullptr, "group");
     return group_sync_all(group);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_group_barrier(smt_group *group)
-{
+try {
     SMT_REQUIRE(group != nullptr, "group");
     int rc = group_sync_all(group);
     if (rc) return rc;
     return group_barrier(group);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_init(const int *devices, int n_dev)
-{
+try {
     if (g_default_group) {
         // idempotent for the same device list
         bool same = g_default_group->n_local == n_dev;
@@ -818,15 +818,15 @@ int smt_init(const int *devices, int n_dev)
         n_dev = n;
     }
     return smt_group_create(devices, n_dev, &g_default_group);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_shutdown(void)
-{
+try {
     smt_group *g = g_default_group;
     g_default_group = nullptr;
     group_free(g);
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 smt_group *smt_default_group(void) { return g_default_group; }
 
@@ -835,7 +835,7 @@ smt_group *smt_default_group(void) { return g_default_group; }
 int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
                        const smt_range *ranges, uint32_t n_ranges, uint64_t *out_rows, double *out_dist, uint64_t *out_counts,
                        uint64_t out_cap)
-{
+try {
     SMT_REQUIRE(sc != nullptr, "corpus");
     SMT_REQUIRE(mode == SMT_MODE_DOCUMENTS || mode == SMT_MODE_WORKSPACE, "mode");
     SMT_REQUIRE(nq == 0 || (queries && out_counts), "null argument");
@@ -961,11 +961,11 @@ int smt_sharded_search(smt_sharded_corpus *sc, const float *queries, uint32_t nq
         for (size_t j = 0; j < redo.size(); ++j) hits[redo[j]] = std::move(merged[j]);
     }
     return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
                                    uint64_t *const *out_packed)
-{
+try {
     SMT_REQUIRE(sc && queries_dev && out_packed, "null argument");
     SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
     smt_group *g = sc->group;
@@ -1009,12 +1009,12 @@ int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *q
         if (rc) return rc;
     }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 /* ------------------------------------------------------------ sharded IVF ---- */
 
 int smt_sharded_ivfpq_build(smt_sharded_corpus *sc, const smt_ivfpq_params *params, int shared_centroids, smt_sharded_ivfpq **out)
-{
+try {
     SMT_REQUIRE(sc && params && out, "null argument");
     *out = nullptr;
     smt_group *g = sc->group;
@@ -1051,7 +1051,7 @@ int smt_sharded_ivfpq_build(smt_sharded_corpus *sc, const smt_ivfpq_params *para
         }
     *out = six;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 void smt_sharded_ivfpq_destroy(smt_sharded_ivfpq *six)
 {
@@ -1068,7 +1068,7 @@ smt_ivfpq *smt_sharded_ivfpq_shard(smt_sharded_ivfpq *six, int local_index)
 
 int smt_sharded_ivfpq_search(smt_sharded_ivfpq *six, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
                              uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
-{
+try {
     SMT_REQUIRE(six != nullptr, "index");
     SMT_REQUIRE(nq == 0 || (queries && out_rows && out_dist && out_counts), "null argument");
     SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
@@ -1116,6 +1116,6 @@ int smt_sharded_ivfpq_search(smt_sharded_ivfpq *six, const float *queries, uint3
         }
     }
     return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"

@@ -534,9 +534,9 @@ double ms_since(hipEvent_t a, hipEvent_t b)
 extern "C" {
 
 int smt_ivfpq_build(smt_corpus *corpus, const smt_ivfpq_params *prm, smt_ivfpq **out)
-{
+try {
     return smt::ivfpq_build_shared(corpus, prm, nullptr, out);
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"
 
@@ -738,7 +738,7 @@ __global__ void iota_from_kernel(uint32_t *v, uint64_t n, uint32_t first)
 extern "C" {
 
 int smt_ivfpq_append(smt_ivfpq *ix, uint64_t *n_added)
-{
+try {
     SMT_REQUIRE(ix != nullptr, "index");
     smt_corpus *corpus = ix->corpus;
     smt_ctx *ctx = corpus->ctx;
@@ -813,6 +813,6 @@ int smt_ivfpq_append(smt_ivfpq *ix, uint64_t *n_added)
     ix->n_rows = N;
     if (n_added) *n_added = n_new;
     return compute_max_list(ix);
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"

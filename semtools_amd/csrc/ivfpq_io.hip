@@ -29,7 +29,7 @@ void smt_ivfpq_destroy(smt_ivfpq *ix)
 }
 
 int smt_ivfpq_info(const smt_ivfpq *ix, uint64_t *n_rows, uint32_t *nlist, uint64_t *index_bytes, double *build_ms4)
-{
+try {
     SMT_REQUIRE(ix != nullptr, "index");
     if (n_rows) *n_rows = ix->n_rows;
     if (nlist) *nlist = ix->nlist;
@@ -39,17 +39,17 @@ int smt_ivfpq_info(const smt_ivfpq *ix, uint64_t *n_rows, uint32_t *nlist, uint6
                        (ix->kind == 1 ? (uint64_t)ix->nlist * LP_DIMS * 257 * 4 : 0);
     if (build_ms4) for (int i = 0; i < 4; ++i) build_ms4[i] = ix->build_ms[i];
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_ivfpq_list_sizes(const smt_ivfpq *ix, uint64_t *sizes_host)
-{
+try {
     SMT_REQUIRE(ix && sizes_host, "null argument");
     std::vector<uint64_t> off(ix->nlist + 1);
     IVF_HIP(hipSetDevice(ix->corpus->ctx->device));
     IVF_HIP(hipMemcpy(off.data(), ix->d_offsets, off.size() * 8, hipMemcpyDeviceToHost));
     for (uint32_t l = 0; l < ix->nlist; ++l) sizes_host[l] = off[l + 1] - off[l];
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 // Shared by the host and the device entry points.  queries: host pointer (queries_on_device = false, staged into
 // the scratch) or device pointer; the k best (row, exact distance) pairs and the counts are written to the DEVICE
@@ -108,7 +108,7 @@ __global__ void count_ids_out_of_range_kernel(const uint32_t *ids, uint64_t n, u
 extern "C" {
 
 int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
-{
+try {
     SMT_REQUIRE(ix && path, "null argument");
     smt_ctx *ctx = ix->corpus->ctx;
     IVF_HIP(hipSetDevice(ctx->device));
@@ -141,10 +141,10 @@ int smt_ivfpq_save(smt_ivfpq *ix, const char *path)
     if (fclose(f) != 0) ok = false;
     if (!ok) { smt::set_error("short write to '%s'", path); return SMT_E_IO; }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
-{
+try {
     SMT_REQUIRE(corpus && path && out, "null argument");
     *out = nullptr;
     smt_ctx *ctx = corpus->ctx;
@@ -221,6 +221,6 @@ int smt_ivfpq_load(smt_corpus *corpus, const char *path, smt_ivfpq **out)
     for (uint32_t l = 0; l < h.nlist; ++l) ix->max_list = std::max<uint64_t>(ix->max_list, offs[l + 1] - offs[l]);
     *out = guard.release();
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"

@@ -491,7 +491,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
 
 int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
                      uint64_t row_base, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap)
-{
+try {
     SMT_REQUIRE(ix != nullptr, "index");
     SMT_REQUIRE(nq == 0 || (queries && out_rows && out_dist && out_counts), "null argument");
     smt_ctx *ctx = ix->corpus->ctx;
@@ -523,11 +523,11 @@ int smt_ivfpq_search(smt_ivfpq *ix, const float *queries, uint32_t nq, uint32_t 
     }
     if (truncated) { smt::set_error("out_cap smaller than the number of hits"); return SMT_E_TRUNCATED; }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_ivfpq_search_device(smt_ivfpq *ix, const float *queries_dev, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
                             uint64_t row_base, uint64_t *out_rows_dev, double *out_dist_dev)
-{
+try {
     SMT_REQUIRE(ix != nullptr, "index");
     SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
     SMT_REQUIRE(top_k >= 1, "top_k");
@@ -536,7 +536,7 @@ int smt_ivfpq_search_device(smt_ivfpq *ix, const float *queries_dev, uint32_t nq
     { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     if (nq == 0) return SMT_OK;
     return ivfpq_search_core(ix, queries_dev, true, nq, top_k, nprobe, rerank, row_base, out_rows_dev, out_dist_dev, nullptr, nullptr, nullptr);
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"
 

@@ -541,17 +541,17 @@ extern "C" {
 int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
                const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, uint64_t *out_rows, double *out_dist,
                uint64_t *out_counts, uint64_t out_cap)
-{
+try {
     SMT_REQUIRE(nq == 0 || out_counts, "null argument");
     std::vector<LocalHits> hits;
     int rc = search_local_host(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, hits);
     if (rc) return rc;
     return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,
                            uint64_t *out_rows_dev, double *out_dist_dev)
-{
+try {
     SMT_REQUIRE(corpus != nullptr, "corpus");
     SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
     SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
@@ -585,11 +585,11 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
     }
     rc = topk_dispatch(ctx, corpus, a);
     return rc;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_debug_batched_scores(smt_corpus *corpus, const float *queries, uint32_t nq, uint64_t first_row, uint32_t n_rows,
                              float *out)
-{
+try {
     SMT_REQUIRE(corpus && queries && out, "null argument");
     SMT_REQUIRE(first_row + n_rows <= corpus->rows, "row range outside the corpus");
     smt_ctx *ctx = corpus->ctx;
@@ -604,11 +604,11 @@ int smt_debug_batched_scores(smt_corpus *corpus, const float *queries, uint32_t 
     SMT_HIP_CHECK(hipMemcpyAsync(out, d_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_merge_topk(const uint64_t *rows, const double *dist, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
                    uint64_t *out_rows, double *out_dist, uint64_t *out_counts)
-{
+try {
     SMT_REQUIRE((rows && dist) || n_lists == 0 || nq == 0 || k_in == 0, "null input");
     SMT_REQUIRE(nq == 0 || k_out == 0 || (out_rows && out_dist), "null output");
     std::vector<std::pair<double, uint64_t>> cand;
@@ -628,28 +628,28 @@ int smt_merge_topk(const uint64_t *rows, const double *dist, uint32_t n_lists, u
         if (out_counts) out_counts[q] = n;
     }
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_merge_topk_device(smt_ctx *ctx, const uint64_t *rows_dev, const double *dist_dev, uint32_t n_lists, uint32_t nq,
                           uint32_t k_in, uint32_t k_out, uint64_t *out_rows_dev, double *out_dist_dev)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(nq == 0 || (out_rows_dev && out_dist_dev), "null output");
     if ((rc = bind_device(ctx))) return rc;
     if (nq == 0 || k_out == 0) return SMT_OK;
     return launch_merge_topk(ctx, rows_dev, dist_dev, n_lists, nq, k_in, k_out, out_rows_dev, out_dist_dev);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint32_t n_lists, uint32_t nq, uint32_t k_in,
                                  uint32_t k_out, uint64_t *out_packed_dev)
-{
+try {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     SMT_REQUIRE(nq == 0 || k_out == 0 || (packed_dev && out_packed_dev), "null argument");
     if ((rc = bind_device(ctx, !(ctx->tune.merge_on_aux && ctx->aux_stream)))) return rc;
     if (nq == 0 || k_out == 0) return SMT_OK;
     return launch_merge_topk_packed(ctx, packed_dev, n_lists, nq, k_in, k_out, out_packed_dev);
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"

@@ -237,7 +237,7 @@ void smt_sharded_corpus_destroy(smt_sharded_corpus *sc)
 }
 
 int smt_sharded_corpus_create(smt_group *group, uint32_t D, smt_sharded_corpus **out)
-{
+try {
     SMT_REQUIRE(group && out, "null argument");
     *out = nullptr;
     if (D != SMT_DIM) { set_error("embedding dim %u unsupported (kernels are specialised for 256)", D); return SMT_E_UNSUPPORTED; }
@@ -249,10 +249,10 @@ int smt_sharded_corpus_create(smt_group *group, uint32_t D, smt_sharded_corpus *
     }
     *out = sc;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_from_host(smt_group *group, const float *rows, uint64_t total_rows, uint32_t D, smt_sharded_corpus **out)
-{
+try {
     SMT_REQUIRE(group && out, "null argument");
     *out = nullptr;
     SMT_REQUIRE(rows || total_rows == 0, "rows");
@@ -271,11 +271,11 @@ int smt_sharded_corpus_from_host(smt_group *group, const float *rows, uint64_t t
     }
     *out = sc;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_from_device(smt_group *group, const float *const *shard_rows_dev, const uint64_t *shard_rows, uint32_t D,
                                    smt_sharded_corpus **out)
-{
+try {
     SMT_REQUIRE(group && out && shard_rows_dev && shard_rows, "null argument");
     *out = nullptr;
     if (D != SMT_DIM) { set_error("embedding dim %u unsupported", D); return SMT_E_UNSUPPORTED; }
@@ -304,7 +304,7 @@ int smt_sharded_corpus_from_device(smt_group *group, const float *const *shard_r
     layout_set_contiguous(sc, rr);
     *out = sc;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 // Load `path` with the given piece list (global order).  Every local rank streams ITS pieces, one host thread per device.
 static int sharded_load_pieces(smt_group *group, const char *path, uint32_t dim, const std::vector<std::pair<uint64_t, int>> &pieces,
@@ -333,7 +333,7 @@ static int sharded_load_pieces(smt_group *group, const char *path, uint32_t dim,
 }
 
 int smt_sharded_corpus_load(smt_group *group, const char *path, smt_sharded_corpus **out)
-{
+try {
     SMT_REQUIRE(group && path && out, "null argument");
     *out = nullptr;
     uint64_t total = 0;
@@ -346,11 +346,11 @@ int smt_sharded_corpus_load(smt_group *group, const char *path, smt_sharded_corp
     std::vector<std::pair<uint64_t, int>> pieces;
     for (int r = 0; r < group->n_ranks; ++r) if (rr[r]) pieces.emplace_back(rr[r], r);
     return sharded_load_pieces(group, path, dim, pieces, out);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_load_layout(smt_group *group, const char *path, const uint64_t *piece_rows, const uint32_t *piece_rank,
                                    uint64_t n_pieces, smt_sharded_corpus **out)
-{
+try {
     SMT_REQUIRE(group && path && out && (n_pieces == 0 || (piece_rows && piece_rank)), "null argument");
     *out = nullptr;
     uint64_t total = 0, sum = 0;
@@ -366,7 +366,7 @@ int smt_sharded_corpus_load_layout(smt_group *group, const char *path, const uin
     }
     if (sum != total) { set_error("the layout describes %llu rows, '%s' holds %llu", (unsigned long long)sum, path, (unsigned long long)total); return SMT_E_INVALID; }
     return sharded_load_pieces(group, path, dim, pieces, out);
-}
+} catch (...) { return smt::api_catch(); }
 
 uint64_t smt_sharded_corpus_layout(const smt_sharded_corpus *sc, uint64_t *piece_rows, uint32_t *piece_rank, uint64_t cap)
 {
@@ -395,7 +395,7 @@ static int sharded_write_pieces(smt_sharded_corpus *sc, const char *path, uint64
 }
 
 int smt_sharded_corpus_save(smt_sharded_corpus *sc, const char *path)
-{
+try {
     SMT_REQUIRE(sc && path, "null argument");
     smt_group *g = sc->group;
     if (g->n_ranks == 1) return smt_corpus_save(sc->shard[0], path);
@@ -413,10 +413,10 @@ int smt_sharded_corpus_save(smt_sharded_corpus *sc, const char *path)
         rc = SMT_E_IO;
     }
     return group_agree(g, rc);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_append_to_file(smt_sharded_corpus *sc, const char *path, uint64_t rows_on_disk)
-{
+try {
     SMT_REQUIRE(sc && path, "null argument");
     smt_group *g = sc->group;
     SMT_REQUIRE(rows_on_disk <= sc->total(), "file holds more rows than the corpus");
@@ -427,12 +427,12 @@ int smt_sharded_corpus_append_to_file(smt_sharded_corpus *sc, const char *path, 
     if ((rc = group_agree(g, rc))) return rc;
     if (g->first_rank == 0) rc = corpus_file_commit(path, sc->total());   // header last
     return group_agree(g, rc);
-}
+} catch (...) { return smt::api_catch(); }
 
 uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *sc) { return sc ? sc->total() : 0; }
 
 int smt_sharded_corpus_shard(smt_sharded_corpus *sc, int local_index, smt_corpus **shard, uint64_t *row_base, uint64_t *rows)
-{
+try {
     SMT_REQUIRE(sc != nullptr, "corpus");
     SMT_REQUIRE(local_index >= 0 && local_index < sc->group->n_local, "local index");
     const int r = sc->group->first_rank + local_index;
@@ -444,17 +444,17 @@ int smt_sharded_corpus_shard(smt_sharded_corpus *sc, int local_index, smt_corpus
     }
     if (rows) *rows = sc->rank_rows[r];
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_rank_rows(const smt_sharded_corpus *sc, uint64_t *rows_per_rank)
-{
+try {
     SMT_REQUIRE(sc && rows_per_rank, "null argument");
     for (int r = 0; r < sc->group->n_ranks; ++r) rows_per_rank[r] = sc->rank_rows[r];
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_append_host(smt_sharded_corpus *sc, const float *rows, uint64_t n_rows, uint64_t *first_row)
-{
+try {
     SMT_REQUIRE(sc != nullptr && (rows || n_rows == 0), "null argument");
     smt_group *g = sc->group;
     if (first_row) *first_row = sc->total();
@@ -473,7 +473,7 @@ int smt_sharded_corpus_append_host(smt_sharded_corpus *sc, const float *rows, ui
     if ((rc = group_agree(g, rc))) return rc;
     layout_append(sc, add);
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 // rows [first_row, first_row + n_rows) in global order <-> host buffer.  The caller is ONE process that sees the whole
 // matrix (the workspace store's compaction and in-place upserts): groups whose ranks live in other processes refuse.
@@ -497,18 +497,18 @@ static int sharded_copy_rows(smt_sharded_corpus *sc, uint64_t first_row, uint64_
 }
 
 int smt_sharded_corpus_read_rows(smt_sharded_corpus *sc, uint64_t first_row, uint64_t n_rows, float *out_host)
-{
+try {
     SMT_REQUIRE(sc && (out_host || n_rows == 0), "null argument");
     if (n_rows == 0) return SMT_OK;
     return sharded_copy_rows(sc, first_row, n_rows, out_host, nullptr);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_corpus_write_rows(smt_sharded_corpus *sc, uint64_t first_row, const float *rows, uint64_t n_rows)
-{
+try {
     SMT_REQUIRE(sc && (rows || n_rows == 0), "null argument");
     if (n_rows == 0) return SMT_OK;
     return sharded_copy_rows(sc, first_row, n_rows, nullptr, rows);
-}
+} catch (...) { return smt::api_catch(); }
 
 /* ------------------------------------------------- replicated model + sharded K1 ---- */
 
@@ -534,21 +534,21 @@ static int sharded_model_make(smt_group *group, const std::function<int(int, smt
 }
 
 int smt_sharded_model_create(smt_group *group, const float *table_host, uint64_t V, uint32_t D, int normalize, smt_sharded_model **out)
-{
+try {
     SMT_REQUIRE(group && table_host && out, "null argument");
     return sharded_model_make(group, [&](int i, smt_model **m) { return smt_model_create(group->ctx[i], table_host, V, D, normalize, m); }, out);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_model_create_from_file(smt_group *group, const char *path, uint64_t byte_offset, uint64_t V, uint32_t D, int normalize,
                                        smt_sharded_model **out)
-{
+try {
     SMT_REQUIRE(group && path && out, "null argument");
     return sharded_model_make(group, [&](int i, smt_model **m) { return smt_model_create_from_file(group->ctx[i], path, byte_offset, V, D, normalize, m); }, out);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_embed(smt_sharded_model *model, const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, uint32_t max_tokens,
                       float *out_host, smt_sharded_corpus *append_to, uint64_t *first_row)
-{
+try {
     SMT_REQUIRE(model != nullptr, "model");
     SMT_REQUIRE(n_lines == 0 || offsets != nullptr, "offsets");
     smt_group *g = model->group;
@@ -583,12 +583,12 @@ int smt_sharded_embed(smt_sharded_model *model, const uint32_t *ids, const uint6
     if ((rc = group_agree(g, rc))) return rc;
     if (append_to) layout_append(append_to, add);
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 /* ------------------------------------------------ sharded index: life cycle ---- */
 
 int smt_sharded_ivfpq_save(smt_sharded_ivfpq *six, const char *path)
-{
+try {
     SMT_REQUIRE(six && path, "null argument");
     smt_group *g = six->corpus->group;
     int rc = group_for_each_local(g, [&](int i) -> int {
@@ -600,10 +600,10 @@ int smt_sharded_ivfpq_save(smt_sharded_ivfpq *six, const char *path)
         return rc2;
     });
     return group_agree(g, rc);
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_ivfpq_load(smt_sharded_corpus *sc, const char *path, smt_sharded_ivfpq **out)
-{
+try {
     SMT_REQUIRE(sc && path && out, "null argument");
     *out = nullptr;
     smt_group *g = sc->group;
@@ -617,10 +617,10 @@ int smt_sharded_ivfpq_load(smt_sharded_corpus *sc, const char *path, smt_sharded
     if ((rc = group_agree(g, rc))) { smt_sharded_ivfpq_destroy(six); return rc; }
     *out = six;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_ivfpq_append(smt_sharded_ivfpq *six, uint64_t *n_added)
-{
+try {
     SMT_REQUIRE(six != nullptr, "index");
     smt_group *g = six->corpus->group;
     std::vector<uint64_t> added(g->n_local, 0);
@@ -628,10 +628,10 @@ int smt_sharded_ivfpq_append(smt_sharded_ivfpq *six, uint64_t *n_added)
     if ((rc = group_agree(g, rc))) return rc;
     if (n_added) { *n_added = 0; for (uint64_t a : added) *n_added += a; }   // (local ranks)
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 int smt_sharded_ivfpq_info(const smt_sharded_ivfpq *six, uint64_t *rows_covered, uint32_t *nlist, uint64_t *index_bytes)
-{
+try {
     SMT_REQUIRE(six != nullptr, "index");
     uint64_t rows = 0, bytes = 0;
     uint32_t lists = 0;
@@ -646,6 +646,6 @@ int smt_sharded_ivfpq_info(const smt_sharded_ivfpq *six, uint64_t *rows_covered,
     if (nlist) *nlist = lists;
     if (index_bytes) *index_bytes = bytes;
     return SMT_OK;
-}
+} catch (...) { return smt::api_catch(); }
 
 }  // extern "C"

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -74,6 +75,31 @@ def test_host_merge_topk():
         assert mr[q, : len(want)].tolist() == [w[1] for w in want]
         assert md[q, : len(want)].tolist() == [w[0] for w in want]
         assert (mr[q, len(want):] == np.iinfo(np.uint64).max).all() and np.isinf(md[q, len(want):]).all()
+
+
+def test_a_cxx_exception_becomes_an_error_code_not_an_unwinding_abi():
+    """include/semtools_hip.h: "Nothing unwinds or aborts across the ABI."  Every int-returning entry point is a function-try-block
+    (csrc/common.h api_catch).  Provoked here without a GPU: smt_merge_topk gathers its candidates into a host vector; with the
+    process' address space capped just above what it already uses, that vector cannot grow -- std::bad_alloc inside the library --
+    and the call must come back with SMT_E_NOMEM and a message, the process alive."""
+    code = r'''
+import ctypes as C, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from semtools_amd import _lib as L
+lib = L.lib()
+k_in = 8 << 20
+rows = np.arange(k_in, dtype=np.uint64)
+dist = np.linspace(0.0, 1.0, k_in)
+out_r = np.empty(4, np.uint64); out_d = np.empty(4, np.float64); cnt = np.empty(1, np.uint64)
+used = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (used + (48 << 20), resource.RLIM_INFINITY))     # the candidates need 128 MiB and more
+rc = lib.smt_merge_topk(L.np_ptr(rows), L.np_ptr(dist), 1, 1, k_in, 4, L.np_ptr(out_r), L.np_ptr(out_d), L.np_ptr(cnt))
+print("rc", rc, "|", lib.smt_last_error().decode())
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.startswith("rc -3 |") and "memory" in p.stdout, p.stdout     # SMT_E_NOMEM
 
 
 @pytest.mark.skipif(L.lib().smt_device_count() > 0, reason="a GPU is present")
