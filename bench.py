@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip BASELINE config c4 (100M rows over the N GPUs)")
     ap.add_argument("--c4-rows", type=int, default=100_000_000, help="TOTAL rows of config c4 (split over the GPUs)")
     ap.add_argument("--c4-steps", type=int, default=40)
+    ap.add_argument("--c4-timeout", type=float, default=300.0, help="several ranks: seconds after which a c4 leg that hangs is abandoned")
     ap.add_argument("--no-group-issue", action="store_true", help="skip the host-issue cost of an 8-shard logical group")
     ap.add_argument("--no-workspace", action="store_true", help="skip the workspace-mode leg (range-filtered searches, A10)")
     ap.add_argument("--ws-rows", type=int, default=10_000_000)
@@ -304,10 +305,38 @@ def main():
             result["embed"] = {"error": repr(exc)}
 
     if not args.no_c4:
+        # With several ranks c4 is collective: a rank that fails inside it (out of memory, a communicator error) leaves the others
+        # waiting in ncclAllGather for ever, and the c2 figures -- complete at this point -- would never be printed.  A watchdog on
+        # every rank abandons the leg after --c4-timeout seconds: rank 0 prints the line without it, everybody leaves.
+        watchdog = None
+        fake_hang = os.environ.get("SEMTOOLS_BENCH_FAKE_C4_HANG") == "1"   # tests: the leg sleeps for ever, on one rank too
+        if world > 1 or fake_hang:
+            import threading
+
+            def abandon():
+                sys.stderr.write(f"[bench rank {rank}/{world}] c4 gave no answer within {args.c4_timeout} s: leg abandoned\n")
+                sys.stderr.flush()
+                if rank == 0:
+                    result["c4"] = {"error": f"no answer within {args.c4_timeout} s on {world} ranks: leg abandoned (the c2 figures were complete)"}
+                    emit_line(result, args)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.c4_timeout, abandon)
+            watchdog.daemon = True
+            watchdog.start()
         try:    # every rank takes part (row-sharded corpus, collective exchange); rank 0 reports
+            if fake_hang:
+                time.sleep(1e9)
             c4 = bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host)
         except Exception as exc:
             c4 = {"error": repr(exc)}
+        if world > 1:
+            try:    # (a rank that failed alone must not be waited for: only when every rank got here is the leg over)
+                dist.barrier()
+            except Exception:
+                pass
+        if watchdog is not None:
+            watchdog.cancel()
         if rank == 0:
             result["c4"] = c4
 
@@ -414,21 +443,32 @@ def main():
     if world > 1:
         dist.barrier()          # every rank's banner is out before rank 0 writes the line
     if rank == 0:
-        line = compact_line(result)
-        try:
-            path = args.detail_out or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            with open(path, "w") as f:
-                json.dump(result, f, indent=1)
-            line["detail_file"] = os.path.relpath(path, ROOT)
-        except Exception:
-            line["detail_file"] = None
-        sys.stderr.write("[bench detail] " + json.dumps(result) + "\n")
-        sys.stderr.flush()
-        sys.stdout.write(json.dumps(line) + "\n")
-        sys.stdout.flush()
+        emit_line(result, args)
     if exchange:
         dist.destroy_process_group()
+
+
+def emit_line(result, args):
+    """Rank 0: the full per-leg objects to the detail file and stderr, the compact line LAST on stdout."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    line = compact_line(result)
+    try:
+        path = args.detail_out or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(result, f, indent=1)
+        line["detail_file"] = os.path.relpath(path, ROOT)
+    except Exception:
+        line["detail_file"] = None
+    sys.stderr.write("[bench detail] " + json.dumps(result) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 def _g(d, *path, default=None):

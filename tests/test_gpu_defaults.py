@@ -185,6 +185,23 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
     assert "rccl_ranks=1" in r.stderr                      # the pre-run diagnostics of a multi-rank launch
 
 
+def test_bench_abandons_a_c4_leg_that_hangs_and_still_prints_the_line():
+    """With several ranks c4 is collective: a rank that fails inside it would leave the others in ncclAllGather for ever and the c2
+    figures, complete by then, unprinted.  bench.py's watchdog abandons the leg after --c4-timeout seconds.  Driven here on one rank
+    with a leg that sleeps for ever (SEMTOOLS_BENCH_FAKE_C4_HANG): exit code 0, the JSON line last on stdout with the c2 figures,
+    the abandoned leg listed among the failed checks."""
+    env = dict(os.environ, SEMTOOLS_BENCH_FAKE_C4_HANG="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--settle-steps", "8", "--no-secondary", "--no-ivfpq",
+           "--no-embed", "--no-cpu-baseline", "--no-workspace", "--no-ingest", "--no-group-issue", "--c4-timeout", "3",
+           "--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_c4_abandoned.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().split("\n")[-1])
+    assert res["value"] > 0 and 0 < res["roofline"]["frac"] < 1.0
+    assert "c4_rows_per_s" not in res and res["checks_ok"] is False and any("c4" in c for c in res["checks_failed"]), res
+    assert "leg abandoned" in r.stderr
+
+
 def test_mfma_accumulate_rounding_probe():
     """tools/micro/mfma_rounding: the certificate's error bounds (common.h F32_ERR_*) assume that every MFMA instruction adds
     its K products to the accumulator with ONE rounding to nearest.  If this part ever rounds differently the bounds must be
