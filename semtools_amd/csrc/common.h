@@ -65,7 +65,7 @@ struct Tuning {
     int64_t image_scan_min_rows = 1500000;   // shards this large answer ONE query from the operand image too, when they have one; 2..7 queries from a third of this (0: never)
     int corpus_image = 1;       // 1: a corpus this library owns builds its operand image at the first batch of >= 8 queries (>= 64 Ki rows)
     int embed_batched = 3;      // bit 0: K1 finishes parked lines wave-wide; bit 1: token ids prefetched one step ahead (A/B only)
-    int gemm_split_last = 1;    // 1: a streamed K3 sweep runs its last level in two parts with a select pass in between (0: A/B only)
+    int gemm_split_last = 2;    // a streamed K3 sweep runs a thin-threshold level in two parts with a select pass in between: 1 = its last level (ratio >= 16), 2 = also the quarter-corpus level of a bootstrap plan (0: none; A/B)
     int gemm_bootstrap = 1;     // 1: gemm_rowreg_kernel batches start from a bootstrap level of tile minima (0: the round-1..3 plan of appended levels; A/B only)
     int gemm_buffered = 1;      // 1: gemm_rowreg_kernel nominations go through the wave's LDS buffer (0: straight to the lists; A/B only)
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks

@@ -603,9 +603,15 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             if ((double)admit_ratio * kp * a.nq / ((double)g.level_tiles * g.qsplit) > 0.75 * RR_CB_CAP) g.buffered = 0;
             const uint64_t level_end = g.level_tiles;
             uint64_t part_end = level_end;
-            if (ctx->tune.gemm_split_last && lev == L - 1 && (lev > 0 || bootstrap) && admit_ratio >= 16 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
-                level_end >= (uint64_t)64 * blocks * RR_WAVES)
-                part_end = (level_end / 8 + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
+            // ... and the FIRST appended level of a bootstrap plan (the quarter-corpus level) likewise: its thresholds come from the
+            // bootstrap's 1/64 sample (~16 k' admissions per query, 0.2 nominations per product); after its first quarter a select
+            // pass tightens them to what 1/16 of the corpus knows.  Timelines on one box (1000 x 10 M, image): 1598 -> 431 + 1061 us
+            // for the level and 42 -> 11 + 9 us of select: 5.82 -> 5.69 ms per call (-2.3 %); from f32 rows 6.55 -> 6.42; 512
+            // queries 3.27 -> 3.16.  (Tuning key gemm_split_last: 0 none, 1 the last level only, 2 both.)
+            const bool split_level = lev == L - 1 || (ctx->tune.gemm_split_last >= 2 && bootstrap && lev == 0);
+            if (ctx->tune.gemm_split_last && split_level && (lev > 0 || bootstrap) && admit_ratio >= 16 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
+                level_end >= (uint64_t)(lev == L - 1 ? 64 : 16) * blocks * RR_WAVES)
+                part_end = (level_end / (lev == L - 1 ? 8 : 4) + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
             for (;;) {
                 g.level_tiles = part_end;
                 prof_begin(ctx, "gemm");
