@@ -607,11 +607,14 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             // bootstrap's 1/64 sample (~16 k' admissions per query, 0.2 nominations per product); after its first quarter a select
             // pass tightens them to what 1/16 of the corpus knows.  Timelines on one box (1000 x 10 M, image): 1598 -> 431 + 1061 us
             // for the level and 42 -> 11 + 9 us of select: 5.82 -> 5.69 ms per call (-2.3 %); from f32 rows 6.55 -> 6.42; 512
-            // queries 3.27 -> 3.16.  (Tuning key gemm_split_last: 0 none, 1 the last level only, 2 both.)
-            const bool split_level = lev == L - 1 || (ctx->tune.gemm_split_last >= 2 && bootstrap && lev == 0);
+            // queries 3.27 -> 3.16.  The same for the ONE appended level of a mid-sized corpus (<= 128 Ki tiles: bootstrap over every
+            // 16th tile, then everything under ~16 k' admissions per query): 1000 x 1 M 867 -> 803 us, x 2 M 1441 -> 1347, x 4 M
+            // 2513 -> 2428, 512 x 1 M 512 -> 482.  (Tuning key gemm_split_last: 0 none, 1 a ratio-16 last level only, 2 both.)
+            const bool first_after_boot = ctx->tune.gemm_split_last >= 2 && bootstrap && lev == 0;   // (also when it is the only level)
+            const bool split_level = lev == L - 1 || first_after_boot;
             if (ctx->tune.gemm_split_last && split_level && (lev > 0 || bootstrap) && admit_ratio >= 16 && nqt > (uint32_t)(f16x1 ? RrGeom<2>::SLOTS : RR_SLOTS) &&
-                level_end >= (uint64_t)(lev == L - 1 ? 64 : 16) * blocks * RR_WAVES)
-                part_end = (level_end / (lev == L - 1 ? 8 : 4) + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
+                level_end >= (uint64_t)(first_after_boot ? 12 : 64) * blocks * RR_WAVES)
+                part_end = (level_end / (first_after_boot ? 4 : 8) + (uint64_t)blocks * RR_WAVES - 1) / ((uint64_t)blocks * RR_WAVES) * ((uint64_t)blocks * RR_WAVES);
             for (;;) {
                 g.level_tiles = part_end;
                 prof_begin(ctx, "gemm");
