@@ -175,3 +175,53 @@ def test_workspace_mode_over_a_subset_batched(gpu_ctx, image):
                 assert got[i][0].tolist() == elig[keep].tolist(), (max_d, i)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_a_level_run_in_two_parts_answers_like_the_whole_level(gpu_ctx, subset):
+    """A bootstrap plan runs its first appended level in two parts with a select pass after the first quarter (tuning key
+    gemm_split_last = 2) once the level holds >= 12 tiles per wave and the batch more query tiles than ring slots.  300 queries over
+    1.7 M rows -- all of them, or every second 1000-row document through the tile table: the split plan launches more MFMA kernels
+    than the whole-level plan (= 1), both give identical rows and distances, and the rows of a few queries are those of an fp64
+    top-k over the eligible rows on the device."""
+    import torch
+
+    import semtools_amd as smt
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    rows = 1_700_000 if not subset else 3_400_000
+    x = torch.randn(rows, 256, device=dev, generator=g)
+    x /= x.norm(dim=1, keepdim=True)
+    q = torch.randn(300, 256, device=dev, generator=g)
+    q /= q.norm(dim=1, keepdim=True)
+    torch.cuda.synchronize()
+    ranges = smt.PackedRanges([(d * 1000, (d + 1) * 1000) for d in range(0, rows // 1000, 2)]) if subset else None
+    qh = q.cpu().numpy()
+    c = smt.Corpus(gpu_ctx, device_ptr=x.data_ptr(), rows=rows)
+    c.prepack()
+    try:
+        out, launches = {}, {}
+        for v in (1, 2):
+            gpu_ctx.set_tuning("gemm_split_last", v)
+            out[v], ran = _kernels_of(gpu_ctx, lambda: c.search(qh, top_k=10, ranges=ranges))
+            assert ran["gemm"] > 0 and ran["scan"] == 0, ran
+            launches[v] = ran["gemm"]
+        assert launches[2] == launches[1] + 1, launches          # the level really ran in two parts
+        for i in range(len(qh)):
+            assert out[1][i][0].tolist() == out[2][i][0].tolist() and np.array_equal(out[1][i][1], out[2][i][1]), i
+        elig = None
+        if subset:
+            elig = torch.zeros(rows, dtype=torch.bool, device=dev)
+            elig.view(-1, 1000)[0::2] = True
+        for i in (0, 151, 299):
+            ref = 1.0 - (x.double() @ q[i].double())
+            if elig is not None:
+                ref[~elig] = 9.0
+            tv, ti = torch.topk(ref, 10, largest=False)
+            assert out[2][i][0].astype(np.int64).tolist() == ti.cpu().tolist(), i
+            assert np.abs(out[2][i][1] - tv.cpu().numpy()).max() < 1e-6, i
+    finally:
+        gpu_ctx.set_tuning("gemm_split_last", 2)
+        c.close()
