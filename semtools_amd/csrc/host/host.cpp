@@ -95,7 +95,7 @@ std::vector<std::string_view> line_views(std::string_view content)
 std::vector<std::string> lines_of(std::string_view content)
 {
     // the strings are built on several threads for big files (a million small allocations were three quarters of the wall time of
-    // embedding a 1 M-line file: profiles/r04_ingest.json; the search path itself keeps views and builds none)
+    // embedding a 1 M-line file before round 4; the search path itself keeps views and builds none)
     const std::vector<std::string_view> views = line_views(content);
     std::vector<std::string> out(views.size());
     auto build = [&](size_t b, size_t e) {

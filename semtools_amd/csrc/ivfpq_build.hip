@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256) lpca_train_kernel(const float *corpus, co
 // one wave per row (list order): code_k = clamp(round(Q_l[k] . (x - c_l) / scale_l[k])).  Grid-stride over the rows: a launch
 // carries at most 2^32 - 1 work-items per dimension (the AQL packet's grid size is a u32 count of work-items), and 64 lanes
 // per row pass that at 67 M rows -- the first version launched n * 64 threads and, at config c5's 100 M rows, silently
-// encoded the first third of them only (recall 0.35; profiles/r03_ivf_sweep_100M_20k_topics.json has before and after).
+// encoded the first third of them only (recall 0.35; profiles/r03_ivf_sweep_100M_before_encode_fix.json is the run before, profiles/r03_ivfpq_100M.json the one after).
 constexpr unsigned LPCA_ENCODE_MAX_BLOCKS = 1u << 20;   // x 4 waves: rows per pass of the grid
 __global__ void __launch_bounds__(256) lpca_encode_kernel(const float *corpus, const uint32_t *ids, const uint32_t *sorted_lists,
                                                            uint64_t n, const float *centroids, const float *basis, const float *lscale,
