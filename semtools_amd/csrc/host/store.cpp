@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -388,7 +389,10 @@ void Store::upsert_documents_lines(const std::vector<std::pair<std::string, std:
     }
     const bool cache = token_cache_enabled();
     search::TokenCsr tokens;
+    const auto t_embed = std::chrono::steady_clock::now();
     uint64_t row = model.encode_into(all, 2048, 16384, corpus_, cache ? &tokens : nullptr);
+    search::PhaseTimer::add("within_persist:encode_into", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_embed).count());
+    const auto t_tok = std::chrono::steady_clock::now();
     const uint64_t fingerprint = cache ? model.tokenizer_fingerprint() : 0;
     size_t line = 0, id_at = 0;
     for (auto &d : docs) {
@@ -406,6 +410,7 @@ void Store::upsert_documents_lines(const std::vector<std::pair<std::string, std:
         row += n;
         line += n;
     }
+    search::PhaseTimer::add("within_persist:token_log_append", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tok).count());
 }
 
 void Store::upsert_document_lines(const std::string &path, const std::vector<std::string_view> &lines_for_embedding,
@@ -780,16 +785,20 @@ void Store::flush_documents() const
 
 void Store::flush_line_embeddings() const
 {
+    const auto t_log = std::chrono::steady_clock::now();
     token_log_close();
+    search::PhaseTimer::add("within_persist:token_log_close", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_log).count());
     // vectors first, then the extent table that references them (a crash in between leaves extra
     // rows that no extent points at -- harmless; the reverse order could reference missing rows)
     const std::string emb = dir_ + "/line_embeddings.f32";
     const uint64_t rows = smt_sharded_corpus_rows(corpus_);
+    const auto t_rows = std::chrono::steady_clock::now();
     if (rows_on_disk_valid_ && rows >= rows_on_disk_ && path_exists(emb)) {
         if (rows > rows_on_disk_) check(smt_sharded_corpus_append_to_file(corpus_, emb.c_str(), rows_on_disk_), "flush_line_embeddings");
     } else {
         check(smt_sharded_corpus_save(corpus_, emb.c_str()), "flush_line_embeddings");  // first flush or after a compaction
     }
+    search::PhaseTimer::add("within_persist:rows_file", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count());
     rows_on_disk_ = rows;
     rows_on_disk_valid_ = true;
     json::Value root = json::Value::object();
