@@ -1104,7 +1104,7 @@ def bench_ingest(smt, ctx, n_lines, vocab=50_000):
                                            "text_MB_per_s": w["text_MB_per_s"], "tokens_per_s": w_tok / w["seconds"],
                                            "host_phases_ms_over_3_calls": w["host_phases_ms_over_3_calls"], "first_hit": w["first_hit"]}
         res["checks"]["wordpiece_first_hit_is_the_query_line"] = w["first_hit_is_the_query_line"]
-    except ImportError as exc:
+    except Exception as exc:   # (a secondary figure: the wheel missing or behaving differently must not take the hash-tokenizer figure down)
         res["wordpiece_tokenizer_json"] = {"skipped": repr(exc)}
     return res
 
