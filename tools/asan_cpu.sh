@@ -2,7 +2,7 @@
 # The library's host code under AddressSanitizer + UBSan on the CPU test suite (tokenizers, line splitting, formatting, the C ABI
 # surface): every TU rebuilt into /tmp/asan with -fsanitize=address,undefined -fno-gpu-sanitize (device code untouched), swapped in
 # for the run and swapped back.  (On a GPU box ROCm's ASan runtime intercepts the HSA allocator and runs out of memory at HIP
-# start-up: the GPU paths are not covered this way.)
+# start-up: the GPU paths are not covered this way.  The bad_alloc test is left out: under ASan an allocation over the limit aborts.)
 set -eu
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 here="$root/semtools_amd/csrc"; out=/tmp/asan; mkdir -p "$out"
@@ -22,5 +22,5 @@ trap 'cp "$out/prod.so" "$lib"' EXIT
 cp "$out/libsemtools_hip.so" "$lib"
 rt="$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)"
 cd "$root"
-LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 python -m pytest tests -q -m "not gpu" -s 2>&1 \
+LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 python -m pytest tests -q -m "not gpu" -s -k "not a_cxx_exception_becomes" 2>&1 \
   | grep -E "runtime error|AddressSanitizer|SUMMARY|passed|failed" || true
