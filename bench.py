@@ -1261,7 +1261,7 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
         n = min(4, nq - i)
         corpus.search_topk_device(q[i:i + n].data_ptr(), n, k, 0, k2_rows[i:i + n].data_ptr(), k2_dist[i:i + n].data_ptr())
     torch.cuda.synchronize(device)
-    ctx.set_tuning("gemm_min_nq", 3)
+    ctx.set_tuning("gemm_min_nq", 5)
     same = ((k2_rows == out_rows).all(dim=1) & (k2_dist == out_dist).all(dim=1))
     n_same = int(same.sum().item())
     uncertain = ctx.uncertain_count()

@@ -72,8 +72,8 @@ struct Tuning {
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
     int64_t fallback_batch_min_rows = 100000;   // >= 2 uncertain queries of a call on a shard this large are re-answered by ONE batched threshold pass
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
-    int gemm_min_nq = 3;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
-    int64_t gemm_min_rows_small = 1000000;   // K3 from gemm_min_nq queries when rows x queries >= 1.2 x this (2 queries: rows >= 4 x this; search.cpp topk_dispatch)
+    int gemm_min_nq = 5;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
+    int64_t gemm_min_rows_small = 1000000;   // K3 from gemm_min_nq queries when rows x queries >= 1.2 x this (search.cpp topk_dispatch)
     int gemm_nominate = 0;      // gemm_rowreg_kernel: 0 auto (shards <= 32 M rows: f16 x 2 from 128 queries, f16 x 1 from 256), 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1
     int gemm_rowreg = 1;        // 1: with gemm_bf16x3, unfiltered batches use gemm_rowreg_kernel (coalesced row loads + LDS transpose)
     int gemm_bf16x3 = 1;        // 1: K3 nominates candidates with bf16 x 3 split products on the bf16 MFMA pipe (mfma_tile.h); 0: f32 MFMA

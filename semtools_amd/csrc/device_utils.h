@@ -41,6 +41,41 @@ __device__ __forceinline__ float wave_sum(float v)
     return (s0 + s1) + (s2 + s3);
 }
 
+// FOUR sums over the 64 lanes at once: lane l of the result holds the sum over all lanes of the input with index l % 4 (a, b, c, d).
+// A transposing tree: the xor-1 and xor-2 steps halve the number of live values instead of repeating each step per value, rotations
+// by 4 and 8 finish the 16-lane rows, v_permlane16_swap / v_permlane32_swap (gfx950) add the rows -- 15 VALU instructions for four
+// sums against 4 x 11 of wave_sum (whose four v_readlane + scalar adds per value are most of its cost).  Fixed tree => deterministic.
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;   // lane i of a row <- lane (i - n) mod 16
+// (v_permlane{16,32}_swap_b32 through inline asm: __builtin_amdgcn_permlane*_swap of clang 22 / ROCm 7.2 hands back its FIRST result
+// for both elements -- the generated code added v + v -- so the builtin cannot give "lane + partner".  The two wait states a VALU
+// write needs before the swap reads the register are in the asm, the assembler adds none for inline code.
+// tools/micro/wave_sum4.hip is the on-device test of what comes out.)
+__device__ __forceinline__ float add_lane_xor32(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));   // a = {lo, lo}, b = {hi, hi}
+    return a + b;
+}
+__device__ __forceinline__ float add_lane_xor16(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));   // a = rows {0, 0, 2, 2}, b = rows {1, 1, 3, 3}
+    return a + b;
+}
+__device__ __forceinline__ float wave_sum4(float a, float b, float c, float d, int lane)
+{
+    const bool odd = lane & 1, upper = lane & 2;
+    // xor 1: even lanes keep a (c), odd lanes keep b (d), each adds its neighbour's share of the value it keeps
+    const float ab = (odd ? b : a) + dpp_f<DPP_XOR1>(odd ? a : b);
+    const float cd = (odd ? d : c) + dpp_f<DPP_XOR1>(odd ? c : d);
+    // xor 2: lanes 0, 1 of a quad keep a | b, lanes 2, 3 keep c | d
+    float v = (upper ? cd : ab) + dpp_f<DPP_XOR2>(upper ? ab : cd);
+    v += dpp_f<DPP_ROW_ROR4>(v);
+    v += dpp_f<DPP_ROW_ROR8>(v);
+    v = add_lane_xor16(v);
+    return add_lane_xor32(v);
+}
+
 // Integer sum over the 64 lanes, result in every lane.
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {

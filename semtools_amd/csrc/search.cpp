@@ -197,7 +197,10 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     // Round 4, measured again with the bootstrap plan (profiles/r04_image_scan_sweep.json, us per call, scan of the f32 rows | batched
     // kernel over the image): ONE query 1 M rows 170 | 170, 1.5 M 245 | 214, 2 M 321 | 264, 4 M 612 | 461; TWO queries 0.5 M 134 | 120,
     // 1 M 230 | 167, 2 M 424 | 261 -- the image answers one query from image_scan_min_rows (1.5 M) rows, two and more from a third of that.
-    const uint64_t image_min = (uint64_t)ctx->tune.image_scan_min_rows / (a.nq >= 2 ? 3 : 1);
+    // Late in round 4 the scan kernel reduces the four rows of a chunk together when it carries several queries (scan_kernels.hip
+    // SMT_REDUCE_CHUNK4): two queries cost 1.06 x one query's pass, four 1.4 x (were 1.4 x / 2.3 x) -- 1 M rows: 172 / 230 us, 2 M: 315 /
+    // 381 -- so the image takes over where it does for one query (two queries) or at two thirds of that (three, four).
+    const uint64_t image_min = (uint64_t)ctx->tune.image_scan_min_rows * (a.nq >= 3 ? 2 : 3) / 3;
     const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && whole &&
                             ctx->tune.image_scan_min_rows > 0 && scanned >= image_min;
     if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&
@@ -213,9 +216,11 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     // (profiles/r04_k2_k3_small.json, us per device-resident call, K2 | K3, no image): 400 k rows 3 queries 175 | 172, 4: 182 | 170,
     // 5: 244 | 171; 200 k rows 4: 115 | 134, 5: 152 | 133, 7: 210 | 138; 100 k rows 5: 104 | 120, 7: 141 | 129; 1 M rows 2: 236 | 275,
     // 3: 377 | 296; 2 M rows 2: 428 | 457 -- K3 from gemm_min_nq queries once rows x queries reaches 1.2 x gemm_min_rows_small.
+    // With the chunk-wise reduction (us per call, K2 | K3, profiles/r04_k2_k3_small.json refreshed): 1 M rows 2 queries 172 | 264, 4: 230 |
+    // 270, 5: 379 | 280; 400 k rows 4: 134 | 161, 5: 196 | 162; 100 k rows 5: 98 | 111, 7: 133 | 117; 2 M rows 4: 381 | 455, 5: 672 | 475 --
+    // up to four queries stay on the scan kernel (gemm_min_nq = 5), five to seven move as before.
     const bool batched = a.nq >= 8 ||
-                         (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && scanned * a.nq >= small + small / 5) ||
-                         (fast_k3 && a.nq == 2 && ctx->tune.gemm_min_nq <= 3 && scanned >= 4 * small) || image_scan;
+                         (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && scanned * a.nq >= small + small / 5) || image_scan;
     if (batched && fast_k3 && whole) {
         if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
     }

@@ -370,7 +370,7 @@ def test_two_to_seven_queries_take_the_batched_path_on_large_shards(gpu_ctx, nq,
         gpu_ctx.prof_enable(False)
     finally:
         gpu_ctx.set_tuning("gemm_min_rows_small", 1_000_000)
-        gpu_ctx.set_tuning("gemm_min_nq", 3)
+        gpu_ctx.set_tuning("gemm_min_nq", 5)
     if nominate_with and gpu_ctx_is_rowreg(gpu_ctx):
         assert launches > 0            # really went through K3
     for a, b in zip(via_k2, via_k3):
@@ -409,4 +409,4 @@ def test_random_shapes_against_the_oracle(gpu_ctx, nominate_with):
             c.close()
     finally:
         gpu_ctx.set_tuning("gemm_min_rows_small", 1_000_000)
-        gpu_ctx.set_tuning("gemm_min_nq", 3)
+        gpu_ctx.set_tuning("gemm_min_nq", 5)

@@ -89,7 +89,7 @@ def test_c3_thousand_queries_ten_million_rows_in_the_default_mode(gpu_ctx):
             c.search_topk_device(q[i:i + 4].data_ptr(), 4, k, 0, k2_rows[i:i + 4].data_ptr(), k2_dist[i:i + 4].data_ptr())
         torch.cuda.synchronize()
     finally:
-        gpu_ctx.set_tuning("gemm_min_nq", 3)
+        gpu_ctx.set_tuning("gemm_min_nq", 5)
     assert gpu_ctx.prof_read("gemm")[0] == 0                  # no batched kernel in the truth
     gpu_ctx.prof_enable(False)
     assert bool((k2_rows == out_rows).all()) and bool((k2_dist == out_dist).all())

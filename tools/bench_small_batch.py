@@ -63,7 +63,7 @@ def main():
             n = min(4, nq - i)
             corpus.search_topk_device(q[i:i + n].data_ptr(), n, args.k, 0, k2_rows[i:i + n].data_ptr(), k2_dist[i:i + n].data_ptr())
         ctx.synchronize()
-        ctx.set_tuning("gemm_min_nq", 3)
+        ctx.set_tuning("gemm_min_nq", 5)
         for variant in args.variants:
             # 1 = default routing; 2 = (with --tune gemm_rowreg=0 or gemm_bf16x3=0) gemm_level_kernel for every size
             # instead of the LDS-row kernel up to 64 queries.  (Variant 0, the first-generation resident-query

@@ -38,7 +38,7 @@ for rows in (100_000, 200_000, 400_000, 700_000, 1_000_000, 2_000_000):
                 c.search_topk_device(q.data_ptr(), nq, 10, 0, o_r.data_ptr(), o_d.data_ptr())
             ctx.synchronize()
             row[name + "_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
-            ctx.set_tuning("gemm_min_nq", 3)
+            ctx.set_tuning("gemm_min_nq", 5)
             ctx.set_tuning("gemm_min_rows_small", 1_000_000)
         out.append(row)
         print(json.dumps(row), flush=True)
