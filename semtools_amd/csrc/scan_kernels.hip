@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
         }                                                                                                         \
     } while (0)
 
-    // Several queries (NQ >= 2, four rows per chunk): the four rows' partial products are reduced TOGETHER -- wave_sum4 leaves the sum
+    // Four rows per chunk (the default U): the four rows' partial products are reduced TOGETHER -- wave_sum4 leaves the sum
     // of row j in the lanes with lane % 4 == j -- once for <c, c> and once per query, the distance is computed lane-parallel (four
     // (row, query) pairs per instruction) and one ballot finds the pairs under the query's threshold; only those (rare once the
     // lists have filled) are read out and inserted.  Per chunk and query 15 + ~14 instructions instead of 4 x (11 + ~14): with the
@@ -270,7 +270,9 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
-    constexpr bool CHUNK4 = NQ >= 2 && U == 4;
+    // (one query too: 2 x 15 instead of 8 x 11 reduction instructions per chunk -- A/B of two builds on one box, tools/ab_libs.sh:
+    // 155.6 -> 152.8 us per 1 M-row launch, 0.822 -> 0.838 of HBM)
+    constexpr bool CHUNK4 = U == 4;
 
     // Software pipeline: the rows of the next chunk are requested right after the current chunk's rows arrived
     // (the register copy below waits for them) and fly during the current reduction; the chunk after that is
