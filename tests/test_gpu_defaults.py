@@ -223,3 +223,15 @@ def test_mfma_accumulate_rounding_probe():
         # what DESIGN.md section 5 states and common.h's bounds use: nearest, at most one rounding per instruction
         assert m["accumulate_rounding"].startswith("round-to-nearest"), (name, m)
         assert m["dot256_positive"]["max_abs_error_in_units_of_2^-24_relative"] <= k_adds, (name, m)
+
+
+def test_wave_sum4_reduction_tree_on_the_device():
+    """tools/micro/wave_sum4: the scan kernel reduces the four rows of a chunk with one transposing tree (device_utils.h wave_sum4:
+    quad permutes, row rotations, v_permlane16_swap / v_permlane32_swap through inline asm).  Lane l must hold the 64-lane sum of
+    input l % 4 -- checked with integer-valued floats against host sums."""
+    exe = os.path.join(ROOT, "tools", "micro", "wave_sum4")
+    if not os.path.exists(exe):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                               exe + ".hip", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PASS wave_sum4" in r.stdout, r.stdout + r.stderr
