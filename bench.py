@@ -17,8 +17,15 @@ copy of the k (row, distance) pairs to pinned host memory.  Inputs (corpus,
 queries) are resident in HBM before the timed region starts; steps are enqueued
 back to back on one stream and the region ends with a full synchronise.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
-torch.distributed.run (one rank per GPU, RCCL).
+Launch: python bench.py [--gpus N --steps K --warmup W] starts by itself for every N:
+  * WORLD_SIZE unset (the plain command line): ONE process drives the N GPUs -- the reference's process model
+    (src/bin/semtools.rs:134-135: one synchronous task) and the one the Rust wrappers use (rust/src/search/hip.rs:
+    smt_group_create -> ncclCommInitAll, peer access between the devices): one smt_group, one ShardedCorpus over N device
+    shards, one issuing thread per device inside the library.  --ranks-per-process 1 re-executes the same command under
+    torch.distributed.run (one rank per process, ncclCommInitRank);
+  * WORLD_SIZE set (launched by torch.distributed.run / the driver): one rank per process, as before.
+Fewer than N devices visible, or a group that cannot be created, is reported as a JSON line with "value": null, "error" and
+"n_gpus_visible", exit code 0 -- never a traceback without a line.
 
 Output: the LAST stdout line is one compact JSON object (< 6 KB: the driver keeps an 8 KB tail) -- the contract keys, the c2
 `roofline` and `cpu_baseline`, and every other leg's figures hoisted to flat top-level keys (c3_*, c4_*, ws_*, embed_*, ingest_*,
@@ -59,7 +66,7 @@ def make_shard(rows, seed, device):
     return x.contiguous()
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -93,21 +100,98 @@ def main():
     ap.add_argument("--detail-out", default=None, help="where the full per-leg JSON goes (default gpurun_out/bench_detail.json)")
     ap.add_argument("--min-bracketed", type=int, default=32,
                     help="at least this many K2 launches are bracketed by HIP events whatever --steps is")
-    args = ap.parse_args()
+    ap.add_argument("--ranks-per-process", type=int, default=0, choices=[0, 1],
+                    help="0 (default when WORLD_SIZE is unset): ONE process drives all --gpus devices through one smt_group "
+                         "(ncclCommInitAll); 1: one rank per process -- the command re-executes itself under torch.distributed.run")
+    ap.add_argument("--single-process", action="store_true",
+                    help="take the one-process GROUP path even for --gpus 1 (smt_group_create on one device: what a 1-GPU box can run of it)")
+    ap.add_argument("--logical-shards", type=int, default=0,
+                    help="test hook: the one-process group path over N LOGICAL ranks of cuda:0 (a 1-GPU box runs the N-shard bench code; "
+                         "n_gpus stays 1 and the line says so)")
+    ap.add_argument("--group-transport", default=None, choices=["peer", "rccl", "copy"],
+                    help="how the per-shard k-lists meet in the one-process group (default: the library's -- peer reads)")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+class EnvironmentProblem(Exception):
+    """The run cannot start for a reason outside the code (devices missing, communicator refused): reported, exit 0."""
+
+
+def error_line(args, message, visible):
+    """The contract keys with value null: what a scaling record needs when the run could not start."""
+    return {"metric": "chunk-vectors scanned/sec (whole job)", "value": None, "unit": "rows/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "error": str(message)[:600], "n_gpus_visible": visible,
+            "config": {"workload": "c2: 1 query x 1M chunks (D=256, f32) per GPU, brute-force cosine + top-k"}}
+
+
+def launcher_argv(args, argv, port=None):
+    """--ranks-per-process 1 without WORLD_SIZE: the torch.distributed.run command this process becomes (pinned by a CPU test)."""
+    rest = [a for a in argv]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or os.environ.get("MASTER_PORT", "29511")), os.path.abspath(__file__)] + rest
+
+
+def visible_gpus():
+    try:
+        return int(torch.cuda.device_count()) if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    under_launcher = "WORLD_SIZE" in os.environ
+    rank_env = int(os.environ.get("RANK", "0"))
+    try:
+        n_vis = visible_gpus()
+        need = 1 if args.logical_shards else args.gpus
+        if not under_launcher and n_vis < need:
+            raise EnvironmentProblem(f"--gpus {args.gpus} but {n_vis} HIP device(s) visible")
+        if under_launcher and int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise EnvironmentProblem(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch with --nproc-per-node {args.gpus}, "
+                                     "or without torch.distributed.run (one process then drives every GPU)")
+        if not under_launcher and args.ranks_per_process == 1 and args.gpus > 1:
+            cmd = launcher_argv(args, argv)
+            sys.stderr.write("[bench] one rank per process: " + " ".join(cmd) + "\n")
+            sys.stderr.flush()
+            os.execv(cmd[0], cmd)
+        run(args, under_launcher)
+    except EnvironmentProblem as exc:
+        if rank_env == 0:
+            sys.stderr.write(f"[bench] cannot start: {exc}\n")
+            sys.stdout.write(json.dumps(error_line(args, exc, visible_gpus())) + "\n")
+            sys.stdout.flush()
+        return 0
+    return 0
+
+
+def run(args, under_launcher):
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # SEMTOOLS_BENCH_FORCE_EXCHANGE=1 drives the N>1 code path (RCCL all-gather + device merge) on ONE rank:
-    # the only way to exercise it on a 1-GPU box.  Never set by the driver; the JSON line says when it is on.
-    exchange = world > 1 or os.environ.get("SEMTOOLS_BENCH_FORCE_EXCHANGE") == "1"
-    if exchange:
+    # Process model.  sp: ONE process drives `n_dev` devices (or logical ranks) through one smt_group; otherwise one rank per process
+    # (WORLD_SIZE of them) or, at N = 1 without --single-process, a plain context with nothing to exchange.
+    sp = (not under_launcher) and (args.gpus > 1 or args.single_process or args.logical_shards > 0)
+    n_dev = (args.logical_shards or args.gpus) if sp else 1
+    world = int(os.environ["WORLD_SIZE"]) if under_launcher else (args.gpus if not args.logical_shards else 1)
+    n_shards = n_dev if sp else world          # row shards of the whole job
+    # SEMTOOLS_BENCH_FORCE_EXCHANGE=1 drives the rank-per-process code path (RCCL all-gather + device merge) on ONE rank.
+    # Never set by the driver; the JSON line says when it is on.
+    exchange = sp or world > 1 or os.environ.get("SEMTOOLS_BENCH_FORCE_EXCHANGE") == "1"
+    use_dist = exchange and not sp             # torch.distributed only joins processes
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        except Exception as exc:
+            raise EnvironmentProblem(f"torch.distributed (nccl) could not start on rank {rank}/{world}: {exc!r}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # local device i of this process: cuda:i in a one-process group of real GPUs, cuda:0 for logical ranks, cuda:LOCAL_RANK otherwise
+    devs = [torch.device("cuda", 0 if args.logical_shards else i) for i in range(n_dev)] if sp else [device]
 
     import semtools_amd as smt
 
@@ -115,34 +199,55 @@ def main():
     rows = args.rows
     # a 1 GB shard is 4x the 256 MiB Infinity Cache, but rotate >= 2 copies anyway so that no residue
     # of the previous pass can flatter the HBM figure (measured effect: 149.3 us with one copy, 149.9 with two)
-    shards = [make_shard(rows, seed=3 + rank + 1000 * c, device=device) for c in range(max(1, args.corpus_copies))]
+    n_copies = max(1, args.corpus_copies)
+    shards_of = [[make_shard(rows, seed=3 + (rank if not sp else i) + 1000 * c, device=devs[i]) for c in range(n_copies)]
+                 for i in range(len(devs))]       # [local device][copy]
+    shards = shards_of[0]
     shard = shards[0]
     n_queries = 16
     gq = torch.Generator(device=device)
     gq.manual_seed(4)
     queries = torch.randn(n_queries, 256, device=device, generator=gq)
     queries /= queries.norm(dim=1, keepdim=True)
+    queries_on = [queries if d == device else queries.to(d) for d in devs]   # the query is resident on every device
 
     # the library enqueues on torch's current stream, so its kernels, the RCCL
     # all-gather and the D2H copies are ordered without extra synchronisation
     # A dedicated (non-null) stream: the legacy default stream serialises against RCCL's stream, which costs
     # the one-step pipelining of the exchange its overlap (measured: 200 -> 189 us/step on one forced rank).
-    if os.environ.get("SEMTOOLS_BENCH_STREAM", "side") == "side":
+    if os.environ.get("SEMTOOLS_BENCH_STREAM", "side") == "side" and not sp:
         torch.cuda.synchronize(device)                        # inputs above were generated on the default stream
         torch.cuda.set_stream(torch.cuda.Stream(device))
     stream = torch.cuda.current_stream(device)
     group = None
+    ginfo = None
     if exchange:
-        # N > 1: the ranks join ONE library group; scan, select, ncclAllGather and merge are all enqueued by
+        # N > 1: the ranks join ONE library group; scan, select, exchange and merge are all enqueued by
         # smt_sharded_search_topk_device on the library's own streams (main: scans only; aux: the rest)
         from semtools_amd import dist as sdist
 
-        torch.cuda.synchronize(device)
-        group = sdist.group_from_torch(local_rank) if world > 1 else smt.Group([local_rank])
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+        try:
+            if sp and args.logical_shards:
+                group = smt.Group.logical(0, n_dev)
+            elif sp:
+                group = smt.Group(list(range(n_dev)))              # smt_group_create: ncclCommInitAll + peer access
+            else:
+                group = sdist.group_from_torch(local_rank)         # smt_group_create_rank (ncclCommInitRank), one rank included
+            if args.group_transport:
+                group.set_transport(args.group_transport)
+        except Exception as exc:
+            raise EnvironmentProblem(f"the group of {n_shards} rank(s) could not be created: {exc}")
         ctx = group.ctx(0)
         ginfo = group.info()
-        assert ginfo["n_ranks"] == world and ginfo["rccl_ranks"] == world, ginfo
-        corpora = [smt.ShardedCorpus(group, device_ptrs=[sh.data_ptr()], shard_rows=[rows]) for sh in shards]
+        ginfo["transport"] = group.transport
+        ginfo["mode"] = ("one process, logical ranks on one device" if args.logical_shards else
+                         "one process drives every GPU (smt_group_create: ncclCommInitAll)" if sp else
+                         "one rank per process (smt_group_create_rank: ncclCommInitRank)")
+        assert ginfo["n_ranks"] == n_shards and (args.logical_shards or ginfo["rccl_ranks"] == n_shards), ginfo
+        corpora = [smt.ShardedCorpus(group, device_ptrs=[shards_of[i][c].data_ptr() for i in range(len(devs))],
+                                     shard_rows=[rows] * len(devs)) for c in range(n_copies)]
     else:
         ctx = smt.Context(local_rank, stream=stream.cuda_stream)
         corpora = [smt.Corpus(ctx, device_ptr=sh.data_ptr(), rows=rows) for sh in shards]
@@ -154,9 +259,23 @@ def main():
     host_rows = host[:, 0]
     host_dist = host[:, 1].view(torch.float64)
     async_select = os.environ.get("SEMTOOLS_BENCH_ASYNC_SELECT", "1") != "0"
+    if sp:
+        # one process, n_dev devices: the raw C call with its pointer arrays made once (the ctypes marshalling of the Python wrapper
+        # would be ~10 us of the caller's thread per step).  ONE answer per search, delivered by local device 0 into pinned memory.
+        import ctypes as C
+
+        from semtools_amd import _lib as L
+        q_arrays = [(C.c_void_p * n_dev)(*[C.c_void_p(queries_on[i][j].data_ptr()) for i in range(n_dev)]) for j in range(n_queries)]
+        o_arrays = [(C.c_void_p * n_dev)(*([C.c_void_p(host[r].data_ptr())] + [C.c_void_p(None)] * (n_dev - 1))) for r in range(ring)]
+        sharded_fn = L.lib().smt_sharded_search_topk_device
 
     def step(i, corpora=None, slot_of=None):
         cs = corpora if corpora is not None else CORPORA
+        if sp:
+            rc = sharded_fn(cs[i % len(cs)]._h, q_arrays[i % n_queries], 1, k, o_arrays[i % ring])
+            if rc:
+                L.check(rc)
+            return
         q = queries[i % n_queries]
         slot = host[i % ring]      # pinned host memory is device-addressable: zero-copy result delivery
         if not exchange:
@@ -168,7 +287,7 @@ def main():
     def sync():
         if exchange:
             group.synchronize()
-            if world > 1:
+            if use_dist and world > 1:
                 dist.barrier()
                 torch.cuda.synchronize(device)
         else:
@@ -184,10 +303,19 @@ def main():
         sys.stderr.flush()
     except Exception as exc:  # diagnostics never take the run down
         sys.stderr.write(f"[bench rank {rank}] diagnostics failed: {exc!r}\n")
+    local_ctxs = [group.ctx(i) for i in range(n_dev)] if sp else [ctx]
+
+    def tune_all(key, value):
+        for c in local_ctxs:
+            c.set_tuning(key, value)
+
+    def uncertain_all():
+        return sum(c.uncertain_count() for c in local_ctxs)
+
     # The select stage of query i runs on the library's aux stream WHILE query i+1 scans (device-scope flags between
     # the two kernels); with the exchange the all-gather and the merge follow it on that stream.
     # Every step's result lands inside the timed region (sync() drains the pipeline).
-    ctx.set_tuning("async_select", 1 if async_select else 0)
+    tune_all("async_select", 1 if async_select else 0)
     for i in range(args.settle_steps):
         step(i)
     sync()
@@ -201,7 +329,7 @@ def main():
     ctx.prof_enable(True)
     ctx.prof_reset()
     sync()
-    ctx.uncertain_count()                         # reset the "exactness certificate failed" counter
+    uncertain_all()                               # reset the "exactness certificate failed" counters
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -221,9 +349,9 @@ def main():
             extra_steps += 1
         sync()
         n_scan, scan_ms = ctx.prof_read("scan")
-    uncertain = ctx.uncertain_count()
+    uncertain = uncertain_all()
     ctx.set_tuning("prof_every", 1)
-    ctx.set_tuning("async_select", 0)             # the select stage is timed on its own, back to back with the scan
+    tune_all("async_select", 0)                   # the select stage is timed on its own, back to back with the scan
     ctx.set_tuning("prof_select", 1)
     ctx.prof_reset()
     for i in range(20):
@@ -232,31 +360,49 @@ def main():
     n_sel, sel_ms = ctx.prof_read("select")
     ctx.prof_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if exchange:
+    if use_dist:                                  # MAX over the ranks (one process: there is one clock)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
 
     # ---- sanity of the last step's result against an independent fp64 torch reference
     last = (args.steps - 1) % n_queries
-    shard = shards[(args.steps - 1) % len(shards)]   # the copy the last timed step scanned
-    ref = 1.0 - (shard.double() @ queries[last].double())
-    lv, li = torch.topk(ref, k, largest=False)
-    if not exchange:
-        torch_ok = bool(np.allclose(np.sort(got_dist), np.sort(lv.cpu().numpy()), rtol=0, atol=1e-6))
+    last_copy = (args.steps - 1) % n_copies          # the copy the last timed step scanned
+    shard = shards[last_copy]
+    if sp:
+        # every local shard contributes its fp64 top-k (global rows = shard index x rows + local row); the merged truth must
+        # equal the pipeline's output, rows included
+        cand_v, cand_r = [], []
+        for i, d in enumerate(devs):
+            ref = 1.0 - (shards_of[i][last_copy].double() @ queries_on[i][last].double())
+            lv, li = torch.topk(ref, k, largest=False)
+            cand_v.append(lv.cpu())
+            cand_r.append(li.cpu() + i * rows)
+            del ref
+        allv, allr = torch.cat(cand_v).numpy(), torch.cat(cand_r).numpy()
+        order = np.lexsort((allr, allv))[:k]
+        torch_ok = bool(np.allclose(got_dist, allv[order], rtol=0, atol=1e-6)) and \
+            bool(np.array_equal(got_rows[np.argsort(got_dist, kind="stable")], got_rows))
+        rows_ok = got_rows.tolist() == allr[order].tolist()
     else:
-        # N>1: every rank contributes its local fp64 top-k; the merged truth must equal the pipeline's output
-        try:
-            allv = [torch.empty_like(lv) for _ in range(world)]
-            dist.all_gather(allv, lv.contiguous())
-            truth = torch.sort(torch.cat(allv))[0][:k].cpu().numpy()
-            torch_ok = bool(np.allclose(got_dist, truth, rtol=0, atol=1e-6))
-        except Exception:
-            torch_ok = None
+        ref = 1.0 - (shard.double() @ queries[last].double())
+        lv, li = torch.topk(ref, k, largest=False)
+        rows_ok = None
+        if not exchange:
+            torch_ok = bool(np.allclose(np.sort(got_dist), np.sort(lv.cpu().numpy()), rtol=0, atol=1e-6))
+        else:
+            # N>1: every rank contributes its local fp64 top-k; the merged truth must equal the pipeline's output
+            try:
+                allv = [torch.empty_like(lv) for _ in range(world)]
+                dist.all_gather(allv, lv.contiguous())
+                truth = torch.sort(torch.cat(allv))[0][:k].cpu().numpy()
+                torch_ok = bool(np.allclose(got_dist, truth, rtol=0, atol=1e-6))
+            except Exception:
+                torch_ok = None
 
     result = {
         "metric": "chunk-vectors scanned/sec (whole job)",
-        "value": world * rows * args.steps / elapsed,
+        "value": n_shards * rows * args.steps / elapsed,
         "unit": "rows/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -272,12 +418,15 @@ def main():
         "config": {"workload": "c2: 1 query x 1M chunks (D=256, f32) per GPU, brute-force cosine + top-k",
                    "rows_per_gpu": rows, "dim": 256, "top_k": k, "queries_rotated": n_queries,
                    "corpus_copies_rotated": len(shards),
-                   "sharding": ("row-sharded over one smt_group (library-side ncclAllGather of the packed k-lists + device "
-                                "merge on the aux stream, overlapping the next scan)") if exchange else "single shard",
+                   "sharding": (f"row-sharded over one smt_group of {n_shards} ranks; the per-shard k-lists meet through the group's "
+                                f"'{ginfo['transport']}' transport (peer: the merge kernel reads them in place; rccl: one ncclAllGather) "
+                                "+ device merge on the aux stream, overlapping the next scan") if exchange else "single shard",
                    "select_stage": "overlapped with the next query's scan (aux stream)" if async_select else "in stream order"},
     }
-    if exchange and world == 1:
+    if exchange and world == 1 and not sp:
         result["config"]["forced_exchange_on_one_rank"] = True
+    if args.logical_shards:
+        result["config"]["logical_shards_on_one_gpu"] = n_dev   # test hook: n_gpus is 1, the N shards' GPU work serialises
     if rank == 0:
         scan_us = scan_ms / max(n_scan, 1) * 1e3
         achieved = rows * ROW_BYTES / (scan_us * 1e-6) / 1e9 if n_scan else None
@@ -293,12 +442,23 @@ def main():
         }
         result["checks"] = {"torch_fp64_topk_distances_match": torch_ok,
                             "selects_without_exactness_certificate": uncertain}
+        if rows_ok is not None:
+            result["checks"]["rows_match_fp64_topk_over_all_shards"] = rows_ok
         if exchange:
             result["config"]["group"] = ginfo
 
+    # the legs below describe ONE GPU driven through a plain context on torch's stream: they run at N = 1 only, and not in the
+    # one-process group mode (whose contexts own their streams)
+    solo = world == 1 and not sp
+    if sp:
+        # the c2 shards of the other devices are not needed any more (c4 wants the memory)
+        for c in corpora:
+            c.close()
+        shards_of = [shards_of[0]]
+        torch.cuda.empty_cache()
     # (K1 before the legs that allocate and free 10-100 GB: the 4 GB table of its uniform-id case is gathered ~5 % slower when it is
     # allocated after such a cycle in the same process -- 6.2 ms alone, 6.55-6.9 ms after c4, same box, same binary)
-    if rank == 0 and world == 1 and not args.no_embed:
+    if rank == 0 and solo and not args.no_embed:
         try:
             result["embed"] = bench_embed(smt, ctx, device, args.embed_lines)
         except Exception as exc:
@@ -310,7 +470,7 @@ def main():
         # every rank abandons the leg after --c4-timeout seconds: rank 0 prints the line without it, everybody leaves.
         watchdog = None
         fake_hang = os.environ.get("SEMTOOLS_BENCH_FAKE_C4_HANG") == "1"   # tests: the leg sleeps for ever, on one rank too
-        if world > 1 or fake_hang:
+        if n_shards > 1 or fake_hang:
             import threading
 
             def abandon():
@@ -327,10 +487,13 @@ def main():
         try:    # every rank takes part (row-sharded corpus, collective exchange); rank 0 reports
             if fake_hang:
                 time.sleep(1e9)
-            c4 = bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host)
+            if sp:
+                c4 = bench_c4_one_process(smt, args, devs, group, local_ctxs, k, queries_on, host, world)
+            else:
+                c4 = bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host)
         except Exception as exc:
             c4 = {"error": repr(exc)}
-        if world > 1:
+        if use_dist and world > 1:
             try:    # (a rank that failed alone must not be waited for: only when every rank got here is the leg over)
                 dist.barrier()
             except Exception:
@@ -340,37 +503,37 @@ def main():
         if rank == 0:
             result["c4"] = c4
 
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and solo and not args.no_secondary:
         try:
             result["secondary"] = bench_c3(smt, ctx, device, args.c3_rows, args.c3_queries, k)
         except Exception as exc:  # never let an auxiliary leg take the headline line down with it
             result["secondary"] = {"error": repr(exc)}
 
-    if rank == 0 and world == 1 and not args.no_group_issue:
+    if rank == 0 and solo and not args.no_group_issue:
         try:
             result["group_issue"] = bench_group_issue(smt, device)
         except Exception as exc:
             result["group_issue"] = {"error": repr(exc)}
 
-    if rank == 0 and world == 1 and not args.no_workspace:
+    if rank == 0 and solo and not args.no_workspace:
         try:
             result["workspace"] = bench_workspace(smt, ctx, device, args.ws_rows, k)
         except Exception as exc:
             result["workspace"] = {"error": repr(exc)}
 
-    if rank == 0 and world == 1 and not args.no_ingest:
+    if rank == 0 and solo and not args.no_ingest:
         try:
             result["ingest"] = bench_ingest(smt, ctx, args.ingest_lines)
         except Exception as exc:
             result["ingest"] = {"error": repr(exc)}
 
-    if rank == 0 and world == 1 and not args.no_ivfpq:
+    if rank == 0 and solo and not args.no_ivfpq:
         try:
             result["ivfpq"] = bench_c5(smt, ctx, device, args.c5_rows, k)
         except Exception as exc:  # the approximate index is a "next" row: never let it break the headline line
             result["ivfpq"] = {"error": repr(exc)}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and solo and not args.no_cpu_baseline:
         try:
             from oracle import oracle as orc
 
@@ -440,11 +603,11 @@ def main():
     except Exception:
         pass
     sys.stdout.flush()
-    if world > 1:
+    if use_dist and world > 1:
         dist.barrier()          # every rank's banner is out before rank 0 writes the line
     if rank == 0:
         emit_line(result, args)
-    if exchange:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -533,10 +696,12 @@ def compact_line(d):
     cfg = d.get("config", {})
     line["config"] = {"workload": cfg.get("workload"), "rows_per_gpu": cfg.get("rows_per_gpu"), "dim": cfg.get("dim"), "top_k": cfg.get("top_k"),
                       "corpus_copies_rotated": cfg.get("corpus_copies_rotated"),
-                      "sharding": "row-sharded, library-side ncclAllGather + device merge" if cfg.get("group") else "single shard"}
+                      "sharding": "row-sharded over one smt_group, k-lists exchanged inside the library + device merge" if cfg.get("group") else "single shard"}
     if cfg.get("group"):
-        line["config"]["n_ranks"] = _g(cfg, "group", "n_ranks")
-        line["config"]["rccl_ranks"] = _g(cfg, "group", "rccl_ranks")
+        line["config"]["group"] = {key: _g(cfg, "group", key) for key in ("n_ranks", "n_local", "rccl_ranks", "rccl_version", "transport", "mode")}
+        line["config"]["parallelism"] = f"row shards x {_g(cfg, 'group', 'n_ranks')}"
+    if cfg.get("logical_shards_on_one_gpu"):
+        line["config"]["logical_shards_on_one_gpu"] = cfg["logical_shards_on_one_gpu"]
     if cfg.get("forced_exchange_on_one_rank"):
         line["config"]["forced_exchange_on_one_rank"] = True
     rf = d.get("roofline")
@@ -599,6 +764,7 @@ def compact_line(d):
     # several shards driven by one host thread (logical group on one GPU: the issue cost, not the collective)
     put("group_issue_us_8_logical_shards", "group_issue", "host_issue_us_per_search")
     put("group_launches_only_us_8_shards", "group_issue", "one_thread_issues_every_shard_us")
+    put("group_issue_copy_transport_us", "group_issue", "copy_transport_us")
     # K1 (embed) and the host step in front of it
     put("embed_lines_per_s_zipf", "embed", "zipf_ids_500k_table", "lines_per_s")
     put("embed_frac_hbm_zipf_measured_traffic", "embed", "zipf_ids_500k_table", "roofline", "frac")
@@ -806,11 +972,107 @@ def bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host):
     }
 
 
+def bench_c4_one_process(smt, args, devs, group, local_ctxs, k, queries_on, host, n_gpus):
+    """bench_c4 for the one-process group: the 100M rows cut into len(devs) contiguous shards, shard i generated on local device i,
+    one ShardedCorpus, ONE answer per query delivered by local device 0 into pinned memory."""
+    import ctypes as C
+
+    from semtools_amd import _lib as L
+    total = args.c4_rows
+    n = len(devs)
+    per = -(-total // n)
+    sizes = [max(0, min(per, total - i * per)) for i in range(n)]
+    xs = []
+    for i, d in enumerate(devs):
+        x = torch.empty((sizes[i], 256), device=d, dtype=torch.float32)
+        g = torch.Generator(device=d)
+        g.manual_seed(3 + i)
+        for b in range(0, sizes[i], 2_000_000):
+            e = min(sizes[i], b + 2_000_000)
+            c = torch.randn(e - b, 256, device=d, generator=g)
+            c /= c.norm(dim=1, keepdim=True)
+            x[b:e] = c
+            del c
+        xs.append(x)
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    corpus = smt.ShardedCorpus(group, device_ptrs=[x.data_ptr() if x.numel() else 0 for x in xs], shard_rows=sizes)
+    ring, nq16 = host.shape[0], queries_on[0].shape[0]
+    q_arrays = [(C.c_void_p * n)(*[C.c_void_p(queries_on[i][j].data_ptr()) for i in range(n)]) for j in range(nq16)]
+    o_arrays = [(C.c_void_p * n)(*([C.c_void_p(host[r].data_ptr())] + [C.c_void_p(None)] * (n - 1))) for r in range(ring)]
+    fn = L.lib().smt_sharded_search_topk_device
+
+    def one(i):
+        L.check(fn(corpus._h, q_arrays[i % nq16], 1, k, o_arrays[i % ring]))
+
+    ctx = local_ctxs[0]
+    for c in local_ctxs:
+        c.set_tuning("async_select", 1)
+    ctx.set_tuning("prof_select", 0)
+    ctx.set_tuning("prof_every", 1)
+    for i in range(3):
+        one(i)
+    group.synchronize()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    for c in local_ctxs:
+        c.uncertain_count()
+    group.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.c4_steps):
+        one(i)
+    group.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_scan, scan_ms = ctx.prof_read("scan")
+    ctx.prof_enable(False)
+    for c in local_ctxs:
+        c.set_tuning("async_select", 0)
+    ctx.set_tuning("prof_select", 1)
+    uncertain = sum(c.uncertain_count() for c in local_ctxs)
+    last = args.c4_steps - 1
+    got_dist = host[last % ring, 1].view(torch.float64).numpy().copy()
+    got_rows = host[last % ring, 0].numpy().copy()
+    cv, cr = [], []
+    for i in range(n):
+        if not sizes[i]:
+            continue
+        lv, li = torch_topk_fp64(xs[i], queries_on[i][last % nq16], k)
+        cv.append(lv.cpu())
+        cr.append(li.cpu() + i * per)
+    allv, allr = torch.cat(cv).numpy(), torch.cat(cr).numpy()
+    order = np.lexsort((allr, allv))[:k]
+    ok = bool(np.allclose(got_dist, allv[order], rtol=0, atol=1e-6))
+    rows_match = bool(got_rows.tolist() == allr[order].tolist())
+    rows_ok = bool(((got_rows >= 0) & (got_rows < total)).all())
+    corpus.close()
+    del xs
+    torch.cuda.empty_cache()
+    scan_us = scan_ms / max(n_scan, 1) * 1e3
+    frac = (sizes[0] * ROW_BYTES / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if n_scan else None
+    return {
+        "metric": "chunk-vectors scanned/sec (whole job)", "value": total * args.c4_steps / elapsed, "unit": "rows/s",
+        "ms_per_query": elapsed / args.c4_steps * 1e3, "scaling": "strong", "n_gpus": n_gpus, "steps": args.c4_steps,
+        "config": {"workload": f"c4: 1 query x {total // 1_000_000}M chunks (D=256, f32) row-sharded over {n} shard(s) of ONE process' group, "
+                               f"{per / 1e6:g}M per shard, per-shard top-{k} + '{group.transport}' exchange + merge on device 0",
+                   "rows_total": total, "rows_per_gpu": per},
+        "roofline": {"kernel": "scan_topk_kernel (K2), shard 0", "bound": "hbm",
+                     "achieved": (frac * HBM_PEAK_GBPS) if frac else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac,
+                     "avg_kernel_us": scan_us, "launches": n_scan, "algorithmic_bytes_per_launch": sizes[0] * ROW_BYTES,
+                     "traffic": None, "traffic_source": None},
+        "operand_image": None,
+        "checks": {"torch_fp64_topk_distances_match": ok, "rows_in_range": rows_ok, "rows_match_fp64_topk": rows_match,
+                   "selects_without_exactness_certificate": uncertain},
+    }
+
+
 def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):
     """What ONE host thread pays to issue a 1-query search over n_shards row shards (the caller of the library is one
-    synchronous thread: src/bin/semtools.rs:134-135).  On one GPU the shards are logical ranks of this device (device copies in
-    place of RCCL; their GPU work serialises): the figure of interest is the HOST time inside smt_sharded_search_topk_device, not the
-    end-to-end time.  Beside it: the same thread issuing the shards' scan + select launches itself, one after the other."""
+    synchronous thread: src/bin/semtools.rs:134-135) and receive ONE answer (on local device 0, as smt_sharded_search does).  On
+    one GPU the shards are logical ranks of this device (their GPU work serialises): the figure of interest is the HOST time inside
+    smt_sharded_search_topk_device, not the end-to-end time.  Default transport of a one-process group: PEER -- the merge kernel
+    reads the ranks' k-lists in place, ordered by one event per rank (a group of real GPUs does exactly the same over xGMI).
+    Beside it: the copy transport (gather into rank 0's block), every rank wanting the answer, and the same thread issuing the
+    shards' scan + select launches itself, one after the other."""
     import ctypes as C
 
     from semtools_amd import _lib as L
@@ -828,23 +1090,33 @@ def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):
     sc = smt.ShardedCorpus(grp, device_ptrs=[sh.data_ptr() for sh in shards], shard_rows=[rows] * n_shards)
     outs = [torch.empty((2, k), dtype=torch.int64, device=device) for _ in range(n_shards)]
     qp = [(C.c_void_p * n_shards)(*[C.c_void_p(q[j].data_ptr())] * n_shards) for j in range(16)]
-    op = (C.c_void_p * n_shards)(*[C.c_void_p(o.data_ptr()) for o in outs])
+    op_all = (C.c_void_p * n_shards)(*[C.c_void_p(o.data_ptr()) for o in outs])
+    op_one = (C.c_void_p * n_shards)(*([C.c_void_p(outs[0].data_ptr())] + [C.c_void_p(None)] * (n_shards - 1)))
     fn = L.lib().smt_sharded_search_topk_device
-    for j in range(8):
-        L.check(fn(sc._h, qp[j % 16], 1, k, op))
-    grp.synchronize()
-    t0 = time.perf_counter()
-    for j in range(n):
-        fn(sc._h, qp[j % 16], 1, k, op)
-    issued = time.perf_counter() - t0
-    grp.synchronize()
-    total = time.perf_counter() - t0
-    got = outs[0].cpu().numpy()
     allx = torch.cat(shards)
     d = 1.0 - (allx.double() @ q[(n - 1) % 16].double())
-    tv, ti = torch.topk(d, k, largest=False)
-    ok = bool(got[0].tolist() == ti.cpu().tolist())
+    truth = torch.topk(d, k, largest=False)[1].cpu().tolist()
     del allx, d
+
+    def run(op):
+        for j in range(8):
+            L.check(fn(sc._h, qp[j % 16], 1, k, op))
+        grp.synchronize()
+        t0 = time.perf_counter()
+        for j in range(n):
+            fn(sc._h, qp[j % 16], 1, k, op)
+        issued = time.perf_counter() - t0
+        grp.synchronize()
+        total = time.perf_counter() - t0
+        return issued / n * 1e6, total / n * 1e6, bool(outs[0].cpu().numpy()[0].tolist() == truth)
+
+    default_transport = grp.transport
+    peer_us, peer_e2e, ok_peer = run(op_one)
+    peer_all_us, _, ok_peer_all = run(op_all)
+    grp.set_transport("copy")
+    copy_us, _, ok_copy = run(op_one)
+    copy_all_us, _, ok_copy_all = run(op_all)
+    grp.set_transport(default_transport)
     views = [sc.shard(i)[0] for i in range(n_shards)]
     o_r = [torch.empty(k, dtype=torch.int64, device=device) for _ in range(n_shards)]
     o_d = [torch.empty(k, dtype=torch.float64, device=device) for _ in range(n_shards)]
@@ -863,11 +1135,14 @@ def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):
     grp.close()
     del shards
     torch.cuda.empty_cache()
-    return {"metric": "host microseconds to issue one sharded search (one caller thread)", "shards": n_shards, "rows_per_shard": rows,
-            "transport": "logical ranks on one device: event-ordered device copies instead of RCCL (the collective itself cannot run on one GPU)",
-            "host_issue_us_per_search": issued / n * 1e6, "end_to_end_us_per_search": total / n * 1e6,
+    return {"metric": "host microseconds to issue one sharded search (one caller thread, one answer)", "shards": n_shards, "rows_per_shard": rows,
+            "transport": f"{default_transport} (default of a one-process group): logical ranks on one device, merge kernel reads the ranks' k-lists "
+                         "in place, one event per rank; the RCCL collective itself cannot run on one GPU",
+            "host_issue_us_per_search": peer_us, "end_to_end_us_per_search": peer_e2e,
+            "every_rank_wants_the_answer_us": peer_all_us,
+            "copy_transport_us": copy_us, "copy_transport_every_rank_us": copy_all_us,
             "one_thread_issues_every_shard_us": serial * 1e6, "one_shard_scan_us": 150.0,
-            "checks": {"last_answer_matches_fp64_topk": ok}}
+            "checks": {"last_answer_matches_fp64_topk": ok_peer and ok_peer_all, "copy_transport_answer_matches": ok_copy and ok_copy_all}}
 
 
 def bench_workspace(smt, ctx, device, rows, k, nq_batch=256, n_docs=10_000, max_d=0.9):

@@ -299,6 +299,23 @@ int smt_group_info(const smt_group *group, int *n_ranks, int *n_local, int *firs
 smt_ctx *smt_group_ctx(smt_group *group, int local_index);
 int smt_group_synchronize(smt_group *group); /* every local stream, async pipelines drained */
 int smt_group_barrier(smt_group *group);     /* + an all-gather across the ranks */
+/* How the per-shard k-lists of a sharded top-k search meet ("all-gather of the per-shard top-k"):
+ *   SMT_TRANSPORT_RCCL  one ncclAllGather of the packed lists, then merge_topk_kernel.  The only choice when the ranks are
+ *                       separate processes (smt_group_create_rank); available to smt_group_create groups.
+ *   SMT_TRANSPORT_COPY  logical groups: the same all-gather made of event-ordered device copies.
+ *   SMT_TRANSPORT_PEER  one-process groups (smt_group_create when every device can read every other's memory -- peer access is
+ *                       enabled at creation --, smt_group_create_logical): nothing is gathered; the merge kernel of the device
+ *                       that needs the answer reads the ranks' lists where they lie, ordered by one stream event per rank.
+ *                       DEFAULT wherever it is possible: the caller's thread pays n - 1 stream waits and one launch per answer
+ *                       instead of RCCL's per-call host cost for a 960-byte payload.
+ * $SEMTOOLS_GROUP_TRANSPORT = rccl | copy | peer overrides the default at creation (ignored where impossible).
+ * smt_group_set_transport synchronises the group first; SMT_E_INVALID if the group cannot use that transport.
+ * Threshold mode / large k (host-list exchange), barriers and the shared-centroid all-reduce always use RCCL (or copies). */
+#define SMT_TRANSPORT_RCCL 0
+#define SMT_TRANSPORT_COPY 1
+#define SMT_TRANSPORT_PEER 2
+int smt_group_set_transport(smt_group *group, int transport);
+int smt_group_transport(const smt_group *group); /* SMT_TRANSPORT_*; negative = error */
 
 /* A corpus row-sharded over the group.  Global row = position in the whole corpus = INSERTION ORDER (the reference's tie
  * order: document, then line -- src/search/mod.rs:84-85,107-111).  A corpus made in one go is cut into contiguous ranges,

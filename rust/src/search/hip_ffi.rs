@@ -41,6 +41,9 @@ pub const SMT_DIM: u32 = 256;
 pub const SMT_MODE_DOCUMENTS: c_int = 0;
 pub const SMT_MODE_WORKSPACE: c_int = 1;
 pub const SMT_UNIQUE_ID_BYTES: usize = 128;
+pub const SMT_TRANSPORT_RCCL: c_int = 0;
+pub const SMT_TRANSPORT_COPY: c_int = 1;
+pub const SMT_TRANSPORT_PEER: c_int = 2;
 
 extern "C" {
     pub fn smt_ctx_create(device: c_int, out: *mut *mut SmtCtx) -> c_int;
@@ -240,6 +243,8 @@ extern "C" {
     pub fn smt_group_ctx(group: *mut SmtGroup, local_index: c_int) -> *mut SmtCtx;
     pub fn smt_group_synchronize(group: *mut SmtGroup) -> c_int;
     pub fn smt_group_barrier(group: *mut SmtGroup) -> c_int;
+    pub fn smt_group_set_transport(group: *mut SmtGroup, transport: c_int) -> c_int;
+    pub fn smt_group_transport(group: *const SmtGroup) -> c_int;
     pub fn smt_sharded_corpus_create(group: *mut SmtGroup, D: u32, out: *mut *mut SmtShardedCorpus) -> c_int;
     pub fn smt_sharded_corpus_from_host(
         group: *mut SmtGroup,

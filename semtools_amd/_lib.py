@@ -38,7 +38,10 @@ EXPORTS = [
     "smt_sharded_corpus_append_to_file", "smt_sharded_corpus_read_rows", "smt_sharded_corpus_write_rows",
     "smt_sharded_model_create", "smt_sharded_model_create_from_file", "smt_sharded_model_destroy", "smt_sharded_embed",
     "smt_sharded_ivfpq_save", "smt_sharded_ivfpq_load", "smt_sharded_ivfpq_append", "smt_sharded_ivfpq_info",
+    "smt_group_set_transport", "smt_group_transport",
 ]
+TRANSPORT_RCCL, TRANSPORT_COPY, TRANSPORT_PEER = 0, 1, 2
+TRANSPORT_NAMES = {TRANSPORT_RCCL: "rccl", TRANSPORT_COPY: "copy", TRANSPORT_PEER: "peer"}
 UNIQUE_ID_BYTES = 128
 HOST_EXPORTS = [
     "smt_host_model_create", "smt_host_model_from_dir", "smt_host_model_destroy", "smt_host_encode",
@@ -179,6 +182,8 @@ def lib():
     L.smt_group_ctx.restype = vp
     L.smt_group_synchronize.argtypes = [vp]
     L.smt_group_barrier.argtypes = [vp]
+    L.smt_group_set_transport.argtypes = [vp, i32]
+    L.smt_group_transport.argtypes = [vp]
     L.smt_sharded_corpus_from_host.argtypes = [vp, vp, u64, u32, P(vp)]
     L.smt_sharded_corpus_from_device.argtypes = [vp, P(vp), P(u64), u32, P(vp)]
     L.smt_sharded_corpus_load.argtypes = [vp, C.c_char_p, P(vp)]

@@ -352,7 +352,7 @@ class Group:
 
     @classmethod
     def logical(cls, device, n_shards):
-        """n logical ranks on one device (copy transport instead of RCCL): the sharded path on a 1-GPU box."""
+        """n logical ranks on one device (peer reads or device copies instead of RCCL): the sharded path on a 1-GPU box."""
         h = C.c_void_p()
         L.check(L.lib().smt_group_create_logical(int(device), int(n_shards), C.byref(h)))
         return cls(_handle=h)
@@ -404,6 +404,17 @@ class Group:
 
     def synchronize(self):
         L.check(L.lib().smt_group_synchronize(self._h))
+
+    @property
+    def transport(self):
+        """"peer" (k-lists read in place by the merging device: the default of one-process groups), "rccl" or "copy"."""
+        t = L.lib().smt_group_transport(self._h)
+        L.check(min(t, 0))
+        return L.TRANSPORT_NAMES[t]
+
+    def set_transport(self, name):
+        code = {v: k for k, v in L.TRANSPORT_NAMES.items()}[name]
+        L.check(L.lib().smt_group_set_transport(self._h, code))
 
     def barrier(self):
         L.check(L.lib().smt_group_barrier(self._h))

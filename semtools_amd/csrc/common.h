@@ -311,6 +311,12 @@ int corpus_file_commit(const char *path, uint64_t rows);
 int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *packed, uint32_t n_lists, uint32_t nq,
                                 uint32_t k_in, uint32_t k_out, uint64_t *out_packed, uint64_t list_stride_words = 0);
 
+// merge of lists read where they lie (one base pointer per list): the peer transport of group.cpp
+#define SMT_MAX_MERGE_SOURCES 64
+struct MergeSources { const uint64_t *list[SMT_MAX_MERGE_SOURCES]; };
+int launch_merge_topk_sources_on(hipStream_t st, const MergeSources &src, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
+                                 uint64_t *out_packed);
+
 int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,
                       double *out_dist);

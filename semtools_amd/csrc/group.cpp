@@ -188,6 +188,147 @@ int allgather_words(smt_group *g, size_t send_off, size_t recv_off, size_t words
     return SMT_OK;
 }
 
+// ---------------------------------------------------------------- peer transport (one-process groups)
+// Rank j, after the last kernel that writes its list on `st`.
+static int peer_publish(smt_group *g, int j, hipStream_t st)
+{
+    SMT_HIP_CHECK(hipEventRecord(g->ev_ready[j], st));
+    g->pub_stream[j] = st;
+    return SMT_OK;
+}
+
+// The caller's thread, after every local rank has published: local device i merges the n_ranks packed lists [nq][2][k_in] that start
+// `off` bytes into the ranks' buffers `bases` (exchange buffers, or ring slots), reading them in place, into out_packed
+// [nq][2][k_out] on its stream `st`; `done` (may be null) is recorded behind the merge.
+static int peer_merge(smt_group *g, int i, hipStream_t st, void *const *bases, size_t off, uint32_t nq, uint32_t k_in, uint32_t k_out,
+                      uint64_t *out_packed, hipEvent_t done)
+{
+    int rc = group_bind(g, i);
+    if (rc) return rc;
+    MergeSources src;
+    for (int j = 0; j < g->n_local; ++j) {
+        src.list[j] = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(bases[j]) + off);
+        if (j == i && g->pub_stream[j] == st) continue;   // stream order
+        SMT_HIP_CHECK(hipStreamWaitEvent(st, g->ev_ready[j], 0));
+    }
+    if ((rc = launch_merge_topk_sources_on(st, src, (uint32_t)g->n_local, nq, k_in, k_out, out_packed))) return rc;
+    if (done) SMT_HIP_CHECK(hipEventRecord(done, st));
+    return SMT_OK;
+}
+
+static int sync_every_stream(smt_group *g)
+{
+    int rc = group_sync_all(g);
+    if (rc) return rc;
+    for (int i = 0; i < g->n_local; ++i) {
+        if ((rc = group_bind(g, i))) return rc;
+        if (g->ctx[i]->aux_stream) SMT_HIP_CHECK(hipStreamSynchronize(g->ctx[i]->aux_stream));
+    }
+    return SMT_OK;
+}
+
+static void ring_free(smt_group *g)
+{
+    smt_group::Ring &r = g->ring;
+    for (int i = 0; i < (int)r.dev.size(); ++i)
+        if (r.dev[i]) { (void)hipSetDevice(g->ctx[i]->device); (void)hipFree(r.dev[i]); }
+    for (auto &row : r.done)
+        for (hipEvent_t e : row)
+            if (e) (void)hipEventDestroy(e);
+    r = smt_group::Ring();
+}
+
+// The ring holds slots of at least `slot_bytes`; (re)made -- everything in flight finishes first -- when a call needs larger ones.
+static int ring_ensure(smt_group *g, size_t slot_bytes)
+{
+    smt_group::Ring &r = g->ring;
+    if (!r.dev.empty() && slot_bytes <= r.slot_bytes) return SMT_OK;
+    int rc = sync_every_stream(g);
+    if (rc) return rc;
+    ring_free(g);
+    r.slot_bytes = (slot_bytes + 255) & ~(size_t)255;
+    r.slots = (int)std::min<size_t>(64, std::max<size_t>(2, ((size_t)16 << 20) / r.slot_bytes));
+    r.dev.assign(g->n_local, nullptr);
+    r.done.assign(r.slots, std::vector<hipEvent_t>(g->n_local, nullptr));
+    r.merged.assign(r.slots, 0);
+    for (int i = 0; i < g->n_local; ++i) {
+        if ((rc = group_bind(g, i))) return rc;
+        SMT_HIP_CHECK(hipMalloc(&r.dev[i], (size_t)r.slots * r.slot_bytes));
+    }
+    return SMT_OK;
+}
+
+// The slot of the next exchange, free to be written: the merges that read it `slots` exchanges ago are over (normally long since;
+// otherwise the caller's thread waits here -- it may not run more than `slots` searches ahead of the devices).
+static int ring_next_slot(smt_group *g, int *slot_out)
+{
+    smt_group::Ring &r = g->ring;
+    const int slot = (int)(r.seq % (uint64_t)r.slots);
+    for (int i = 0; r.merged[slot] && i < g->n_local; ++i)
+        if (r.merged[slot] >> i & 1) SMT_HIP_CHECK(hipEventSynchronize(r.done[slot][i]));
+    r.merged[slot] = 0;
+    ++r.seq;
+    *slot_out = slot;
+    return SMT_OK;
+}
+
+static int ring_done_event(smt_group *g, int slot, int i, hipEvent_t *ev)
+{
+    smt_group::Ring &r = g->ring;
+    if (!r.done[slot][i]) SMT_HIP_CHECK(hipEventCreateWithFlags(&r.done[slot][i], hipEventDisableTiming));
+    r.merged[slot] |= (uint64_t)1 << i;
+    *ev = r.done[slot][i];
+    return SMT_OK;
+}
+
+static int group_make_events(smt_group *g)
+{
+    g->ev_ready.assign(g->n_local, nullptr);
+    g->ev_done.assign(g->n_local, nullptr);
+    g->pub_stream.assign(g->n_local, nullptr);
+    for (int i = 0; i < g->n_local; ++i) {
+        // (the default system-scope release of an event record is what makes a rank's list visible to a reader on another device)
+        hipError_t e = hipSetDevice(g->ctx[i]->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_ready[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); return SMT_E_HIP; }
+    }
+    return SMT_OK;
+}
+
+// Every device of a one-process group may read every other's memory?  Enables peer access both ways (RCCL may have done so already).
+static bool group_enable_peers(const int *devices, int n)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (i == j) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+        }
+    for (int i = 0; i < n; ++i) {
+        if (hipSetDevice(devices[i]) != hipSuccess) { (void)hipGetLastError(); return false; }
+        for (int j = 0; j < n; ++j) {
+            if (i == j) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+            (void)hipGetLastError();
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return false;
+        }
+    }
+    return true;
+}
+
+// $SEMTOOLS_GROUP_TRANSPORT over the default `def`, where the group can use it
+static int pick_transport(const smt_group *g, int def)
+{
+    const char *e = getenv("SEMTOOLS_GROUP_TRANSPORT");
+    if (!e || !*e) return def;
+    const std::string v(e);
+    if (v == "peer" && g->peer_ok) return SMT_TRANSPORT_PEER;
+    if (v == "rccl" && !g->copies) return SMT_TRANSPORT_RCCL;
+    if (v == "copy" && g->copies) return SMT_TRANSPORT_COPY;
+    return def;
+}
+
 int group_sync_all(smt_group *g)
 {
     for (int i = 0; i < g->n_local; ++i) {
@@ -312,8 +453,13 @@ static void group_stop_workers(smt_group *g);
 static int group_start_workers(smt_group *g)
 {
     if (g->n_local <= 1 || g->workers) return SMT_OK;
-    // SEMTOOLS_GROUP_THREADS=0: the caller's thread issues every device's share itself (A/B, debugging)
-    if (const char *e = getenv("SEMTOOLS_GROUP_THREADS"); e && e[0] == '0') return SMT_OK;
+    // SEMTOOLS_GROUP_THREADS=0: the caller's thread issues every device's share itself (A/B, debugging); =1: threads even for logical
+    // ranks.  Logical ranks share ONE device, i.e. one runtime lock and one set of hardware queues: eight threads issuing into it
+    // measured SLOWER than the caller's thread alone (125-170 us vs 104 us per 8-shard search, profiles/r05_group_issue.json), so a
+    // logical group has no issuing threads unless asked; a group of real GPUs has one per device.
+    const char *e = getenv("SEMTOOLS_GROUP_THREADS");
+    if (e && e[0] == '0') return SMT_OK;
+    if (g->copies && !(e && e[0] == '1')) return SMT_OK;
     g->workers = new (std::nothrow) GroupWorkers();
     if (!g->workers) { set_error("out of host memory"); return SMT_E_NOMEM; }
     g->workers->rcs.assign(g->n_local, SMT_OK);
@@ -378,6 +524,13 @@ static void group_free(smt_group *g)
 {
     if (!g) return;
     group_stop_workers(g);
+    for (int i = 0; i < (int)g->ctx.size(); ++i) {
+        if (!g->ctx[i]) continue;
+        (void)hipSetDevice(g->ctx[i]->device);
+        (void)hipStreamSynchronize(g->ctx[i]->stream);
+        if (g->ctx[i]->aux_stream) (void)hipStreamSynchronize(g->ctx[i]->aux_stream);
+    }
+    ring_free(g);
     for (int i = 0; i < (int)g->ctx.size(); ++i) {
         if (!g->ctx[i]) continue;
         (void)hipSetDevice(g->ctx[i]->device);
@@ -665,6 +818,11 @@ try {
     ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), n_dev, devices);
     if (r != ncclSuccess) { set_error("ncclCommInitAll(%d devices): %s", n_dev, g_rccl.GetErrorString(r)); group_free(g); return SMT_E_HIP; }
     if ((rc = group_barrier(g))) { group_free(g); return rc; }  // channel set-up happens on the first collective: do it now
+    // the k-lists of a top-k search are read in place by the merging device when every device can map every other's memory
+    // (one hive of xGMI-linked GPUs: always, in practice); otherwise they travel through ncclAllGather
+    if ((rc = group_make_events(g))) { group_free(g); return rc; }
+    g->peer_ok = n_dev <= SMT_MAX_MERGE_SOURCES && (n_dev == 1 || group_enable_peers(devices, n_dev));
+    g->transport = pick_transport(g, g->peer_ok ? SMT_TRANSPORT_PEER : SMT_TRANSPORT_RCCL);
     if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
     return SMT_OK;
@@ -683,13 +841,9 @@ try {
     std::vector<int> devs(n_shards, device);
     int rc = group_make_contexts(g, devs.data(), n_shards);
     if (rc) { group_free(g); return rc; }
-    g->ev_ready.assign(n_shards, nullptr);
-    g->ev_done.assign(n_shards, nullptr);
-    for (int i = 0; i < n_shards; ++i) {
-        hipError_t e = hipEventCreateWithFlags(&g->ev_ready[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_done[i], hipEventDisableTiming);
-        if (e != hipSuccess) { set_error("hipEventCreate: %s", hipGetErrorString(e)); group_free(g); return SMT_E_HIP; }
-    }
+    if ((rc = group_make_events(g))) { group_free(g); return rc; }
+    g->peer_ok = true;   // one device
+    g->transport = pick_transport(g, SMT_TRANSPORT_PEER);
     if ((rc = group_barrier(g))) { group_free(g); return rc; }
     if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
@@ -713,6 +867,8 @@ try {
     g->ar_counts.assign(1, nullptr);
     g->ev_ready.assign(1, nullptr);
     g->ev_done.assign(1, nullptr);
+    g->pub_stream.assign(1, nullptr);
+    g->transport = SMT_TRANSPORT_COPY;
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_ready[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_done[0], hipEventDisableTiming);
@@ -799,6 +955,25 @@ try {
     return group_barrier(group);
 } catch (...) { return smt::api_catch(); }
 
+int smt_group_set_transport(smt_group *group, int transport)
+try {
+    SMT_REQUIRE(group != nullptr, "group");
+    SMT_REQUIRE(transport == SMT_TRANSPORT_RCCL || transport == SMT_TRANSPORT_COPY || transport == SMT_TRANSPORT_PEER, "transport");
+    SMT_REQUIRE(transport != SMT_TRANSPORT_PEER || group->peer_ok, "peer transport needs a one-process group whose devices can read each other's memory");
+    SMT_REQUIRE(transport != SMT_TRANSPORT_RCCL || !group->copies, "this group has no RCCL communicator");
+    SMT_REQUIRE(transport != SMT_TRANSPORT_COPY || group->copies, "copy transport is the all-gather of logical groups");
+    int rc = sync_every_stream(group);   // nothing of an earlier exchange is in flight when the protocol changes
+    if (rc) return rc;
+    group->transport = transport;
+    return SMT_OK;
+} catch (...) { return smt::api_catch(); }
+
+int smt_group_transport(const smt_group *group)
+try {
+    SMT_REQUIRE(group != nullptr, "group");
+    return group->transport;
+} catch (...) { return smt::api_catch(); }
+
 int smt_init(const int *devices, int n_dev)
 try {
     if (g_default_group) {
@@ -883,6 +1058,9 @@ try {
         // (a stack status word once forced a stream sync per device here, i.e. the SUM of the shard times.)
         const size_t flag_words = (size_t)g->n_ranks * (nq + 1);
         const size_t pin_status_off = q_bytes, pin_res_off = q_bytes + 64;
+        // peer transport (one-process groups): no gather -- device 0's merge reads the ranks' lists in place, every rank copies
+        // its own flag words to its own pinned block on its own stream (issued by its thread)
+        const bool peer = g->transport == SMT_TRANSPORT_PEER;
         std::vector<int> stage_rcs(g->n_local, SMT_OK);
         std::vector<std::string> stage_errs(g->n_local);
         rc = group_for_each_local(g, [&](int i) -> int {
@@ -890,10 +1068,12 @@ try {
             int rc_i;
             if ((rc_i = group_bind(g, i))) return rc_i;
             if ((rc_i = ensure_dev(g, i, dev_bytes))) return rc_i;   // (no exchange buffer: nothing to report through)
-            if ((rc_i = ensure_host(g, i, pin_res_off + (i == 0 ? (list_words + flag_words) * 8 : 0)))) return rc_i;
+            if ((rc_i = ensure_host(g, i, pin_res_off + (i == 0 ? (list_words + flag_words) * 8 : (size_t)(nq + 1) * 8)))) return rc_i;
             char *base = reinterpret_cast<char *>(g->buf[i].dev);
             char *pin = reinterpret_cast<char *>(g->buf[i].pinned);
             uint64_t *loc = reinterpret_cast<uint64_t *>(base + loc_off);
+            // a pipelined smt_sharded_search_topk_device (rccl / copy transport) may still be gathering out of this buffer on the aux stream
+            if ((rc_i = drain_async(g->ctx[i]))) return rc_i;
             const int stage_rc = [&]() -> int {
                 memcpy(pin, queries, (size_t)nq * SMT_DIM * 4);
                 SMT_HIP_CHECK(hipMemcpyAsync(base, pin, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
@@ -909,32 +1089,49 @@ try {
             uint64_t *status = reinterpret_cast<uint64_t *>(pin + pin_status_off);   // lives in the pinned buffer until group_sync_all
             *status = (uint64_t)(uint32_t)(stage_rc < 0 ? -stage_rc : stage_rc);
             SMT_HIP_CHECK(hipMemcpyAsync(loc + list_words + nq, status, 8, hipMemcpyHostToDevice, g->ctx[i]->stream));
+            if (peer) {
+                uint64_t *my_flags = reinterpret_cast<uint64_t *>(pin + pin_res_off) + (i == 0 ? list_words : 0);
+                SMT_HIP_CHECK(hipMemcpyAsync(my_flags, loc + list_words, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost, g->ctx[i]->stream));
+                if ((rc_i = peer_publish(g, i, g->ctx[i]->stream))) return rc_i;
+            }
             return SMT_OK;
         }, g->workers != nullptr);
         if (rc) return rc;
         for (int i = 0; i < g->n_local; ++i)
             if (stage_rcs[i] && !local_rc) { local_rc = stage_rcs[i]; local_err = stage_errs[i]; }
-        if ((rc = allgather_words(g, loc_off, gath_off, rank_words))) return rc;
+        if (!peer && (rc = allgather_words(g, loc_off, gath_off, rank_words))) return rc;
         // the caller is one host thread and needs ONE copy of the answer: merge on local device 0
         if ((rc = group_bind(g, 0))) return rc;
         char *base0 = reinterpret_cast<char *>(g->buf[0].dev);
         uint64_t *gath = reinterpret_cast<uint64_t *>(base0 + gath_off), *merged = reinterpret_cast<uint64_t *>(base0 + out_off);
-        if (!local_rc && (rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, gath, (uint32_t)g->n_ranks, nq, K, K, merged, rank_words)))
-            return rc;
         uint64_t *h = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->buf[0].pinned) + pin_res_off);
+        if (peer) {
+            // (this entry point ends with every stream drained: the next call may overwrite the lists without asking)
+            std::vector<void *> bases(g->n_local);
+            for (int j = 0; j < g->n_local; ++j) bases[j] = g->buf[j].dev;
+            if (!local_rc && (rc = peer_merge(g, 0, g->ctx[0]->stream, bases.data(), loc_off, nq, K, K, merged, nullptr))) return rc;
+        } else {
+            if (!local_rc && (rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, gath, (uint32_t)g->n_ranks, nq, K, K, merged, rank_words)))
+                return rc;
+            for (int r = 0; r < g->n_ranks; ++r)  // every rank's flags + status: all processes take the same decisions
+                SMT_HIP_CHECK(hipMemcpyAsync(h + list_words + (size_t)r * (nq + 1), gath + (size_t)r * rank_words + list_words, (size_t)(nq + 1) * 8,
+                                             hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        }
         if (!local_rc) SMT_HIP_CHECK(hipMemcpyAsync(h, merged, list_words * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-        for (int r = 0; r < g->n_ranks; ++r)  // every rank's flags + status: all processes take the same decisions
-            SMT_HIP_CHECK(hipMemcpyAsync(h + list_words + (size_t)r * (nq + 1), gath + (size_t)r * rank_words + list_words, (size_t)(nq + 1) * 8,
-                                         hipMemcpyDeviceToHost, g->ctx[0]->stream));
         if ((rc = group_sync_all(g))) return rc;
         if (local_rc) { set_error("%s", local_err.c_str()); return local_rc; }
+        // rank r's [nq uncertain flags][status]: gathered into device 0's block, or (peer) in rank r's own pinned block
+        auto flags_of = [&](int r) -> const uint64_t * {
+            if (!peer || r == 0) return h + list_words + (size_t)r * (nq + 1);
+            return reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(g->buf[r].pinned) + pin_res_off);
+        };
         for (int r = 0; r < g->n_ranks; ++r) {
-            const uint64_t st = h[list_words + (size_t)r * (nq + 1) + nq];
+            const uint64_t st = flags_of(r)[nq];
             if (st) { set_error("rank %d failed with status -%llu; this rank gives up with it", r, (unsigned long long)st); return -(int)st; }
         }
         for (uint32_t q = 0; q < nq; ++q) {
             bool uncertain = false;
-            for (int r = 0; r < g->n_ranks; ++r) uncertain |= h[list_words + (size_t)r * (nq + 1) + q] != 0;
+            for (int r = 0; r < g->n_ranks; ++r) uncertain |= flags_of(r)[q] != 0;
             if (uncertain) { redo.push_back(q); continue; }
             const uint64_t *rws = h + (size_t)q * 2 * K, *bits = rws + K;
             for (uint32_t e = 0; e < K && rws[e] != UINT64_MAX; ++e) {
@@ -975,37 +1172,53 @@ try {
     const size_t gath_off = (list_words * 8 + 255) & ~(size_t)255;
     const size_t dev_bytes = gath_off + (size_t)g->n_ranks * list_words * 8 + 64;
     std::vector<char> on_aux(g->n_local, 0);
+    const bool peer = g->transport == SMT_TRANSPORT_PEER;
     int rc;
     for (int i = 0; i < g->n_local; ++i) SMT_REQUIRE(queries_dev[i] != nullptr, "queries_dev");
+    int slot = 0;
+    if (peer) {   // rank j writes its list into slot `slot` of its ring; whoever needs the answer reads the slots in place
+        if ((rc = ring_ensure(g, list_words * 8))) return rc;
+        if ((rc = ring_next_slot(g, &slot))) return rc;
+    }
     // every device's scan + select is issued by its own thread (group_for_each_local); the collective follows on this one
     rc = group_for_each_local(g, [&](int i) -> int {
         const int r = g->first_rank + i;
         int rc_i;
         if ((rc_i = group_bind(g, i))) return rc_i;
-        if ((rc_i = ensure_dev(g, i, dev_bytes))) return rc_i;
+        if (!peer && (rc_i = ensure_dev(g, i, dev_bytes))) return rc_i;
         smt_ctx *c = g->ctx[i];
         // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select);
         // the all-gather and the merge then follow it there, and the main stream carries nothing but scans
         const bool async = c->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k;
+        uint64_t *list = peer ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->ring.dev[i]) + (size_t)slot * g->ring.slot_bytes)
+                              : reinterpret_cast<uint64_t *>(g->buf[i].dev);
         rc_i = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false,
-                                        sc->contiguous ? sc->rank_base[r] : 0, reinterpret_cast<uint64_t *>(g->buf[i].dev), nullptr, async);
+                                        sc->contiguous ? sc->rank_base[r] : 0, list, nullptr, async);
         if (rc_i) return rc_i;
-        if (!sc->contiguous && (rc_i = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream,
-                                                               reinterpret_cast<uint64_t *>(g->buf[i].dev), nq, top_k)))
+        if (!sc->contiguous && (rc_i = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream, list, nq, top_k)))
             return rc_i;
         on_aux[i] = async ? 1 : 0;
         if (async) c->async_pending = true;
+        if (peer && (rc_i = peer_publish(g, i, async ? c->aux_stream : c->stream))) return rc_i;
         return SMT_OK;
     }, g->workers != nullptr);
     if (rc) return rc;
-    if ((rc = allgather_words(g, 0, gath_off, list_words, &on_aux))) return rc;
+    if (!peer && (rc = allgather_words(g, 0, gath_off, list_words, &on_aux))) return rc;
     for (int i = 0; i < g->n_local; ++i) {
         if (!out_packed[i]) continue;
-        if ((rc = group_bind(g, i))) return rc;
         smt_ctx *c = g->ctx[i];
+        hipStream_t st = on_aux[i] ? c->aux_stream : c->stream;
+        if (peer) {
+            // (an answer wanted on ONE device -- the one-thread caller of SURVEY 8(b) -- costs n - 1 waits + a launch + a record here)
+            hipEvent_t done = nullptr;
+            if ((rc = ring_done_event(g, slot, i, &done))) return rc;
+            if ((rc = peer_merge(g, i, st, g->ring.dev.data(), (size_t)slot * g->ring.slot_bytes, nq, top_k, top_k, out_packed[i], done))) return rc;
+            if (on_aux[i]) c->async_pending = true;
+            continue;
+        }
+        if ((rc = group_bind(g, i))) return rc;
         const uint64_t *gath = reinterpret_cast<const uint64_t *>(reinterpret_cast<char *>(g->buf[i].dev) + gath_off);
-        rc = launch_merge_topk_packed_on(c, on_aux[i] ? c->aux_stream : c->stream, gath, (uint32_t)g->n_ranks, nq, top_k, top_k,
-                                         out_packed[i], 0);
+        rc = launch_merge_topk_packed_on(c, st, gath, (uint32_t)g->n_ranks, nq, top_k, top_k, out_packed[i], 0);
         if (rc) return rc;
     }
     return SMT_OK;
@@ -1081,25 +1294,32 @@ try {
     const size_t q_bytes = ((size_t)nq * SMT_DIM * 4 + 255) & ~(size_t)255;
     const size_t loc_off = q_bytes, gath_off = loc_off + ((list_words * 8 + 255) & ~(size_t)255);
     const size_t out_off = gath_off + (((size_t)g->n_ranks * list_words * 8 + 255) & ~(size_t)255);
+    const bool peer = g->transport == SMT_TRANSPORT_PEER && (uint64_t)g->n_ranks * top_k <= 4096;
     int rc;
     for (int i = 0; i < g->n_local; ++i) {
         const int r = g->first_rank + i;
         if ((rc = group_bind(g, i))) return rc;
         if ((rc = ensure_dev(g, i, out_off + list_words * 8 + 64))) return rc;
         char *base = reinterpret_cast<char *>(g->buf[i].dev);
+        if ((rc = drain_async(g->ctx[i]))) return rc;   // (see smt_sharded_search: the buffer may still be read on the aux stream)
         SMT_HIP_CHECK(hipMemcpyAsync(base, queries, (size_t)nq * SMT_DIM * 4, hipMemcpyHostToDevice, g->ctx[i]->stream));
         if ((rc = ivfpq_search_packed(six->shard[i], reinterpret_cast<const float *>(base), nq, top_k, nprobe, rerank,
                                       sc->contiguous ? sc->rank_base[r] : 0, reinterpret_cast<uint64_t *>(base + loc_off))))
             return rc;
         if (!sc->contiguous && (rc = layout_translate_packed(sc, i, g->ctx[i]->stream, reinterpret_cast<uint64_t *>(base + loc_off), nq, top_k)))
             return rc;
+        if (peer && (rc = peer_publish(g, i, g->ctx[i]->stream))) return rc;
     }
-    if ((rc = allgather_words(g, loc_off, gath_off, list_words))) return rc;
+    if (!peer && (rc = allgather_words(g, loc_off, gath_off, list_words))) return rc;
     if ((rc = group_bind(g, 0))) return rc;
     char *base0 = reinterpret_cast<char *>(g->buf[0].dev);
     uint64_t *merged = reinterpret_cast<uint64_t *>(base0 + out_off);
-    if ((rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, reinterpret_cast<const uint64_t *>(base0 + gath_off),
-                                          (uint32_t)g->n_ranks, nq, top_k, top_k, merged, 0)))
+    if (peer) {
+        std::vector<void *> bases(g->n_local);
+        for (int j = 0; j < g->n_local; ++j) bases[j] = g->buf[j].dev;
+        if ((rc = peer_merge(g, 0, g->ctx[0]->stream, bases.data(), loc_off, nq, top_k, top_k, merged, nullptr))) return rc;
+    } else if ((rc = launch_merge_topk_packed_on(g->ctx[0], g->ctx[0]->stream, reinterpret_cast<const uint64_t *>(base0 + gath_off),
+                                                 (uint32_t)g->n_ranks, nq, top_k, top_k, merged, 0)))
         return rc;
     if ((rc = ensure_host(g, 0, list_words * 8))) return rc;
     uint64_t *h = reinterpret_cast<uint64_t *>(g->buf[0].pinned);

@@ -51,6 +51,27 @@ struct smt_group {
     bool copies = false;
     std::vector<hipEvent_t> ev_ready;   // [n_local] rank j's send buffer is complete
     std::vector<hipEvent_t> ev_done;    // [n_local] rank i has finished reading everybody's send buffer
+    // Peer transport (SMT_TRANSPORT_PEER, the default of every one-process group whose devices can read each other's memory):
+    // the per-shard k-lists are not moved at all -- the merge kernel of the device that needs the answer loads them from the
+    // ranks' exchange buffers where they lie (merge_topk_sources_kernel), ordered by ONE event per rank: ev_ready[j] after rank j's
+    // select.  The caller's thread pays n - 1 stream waits + one launch + one record per answer; an RCCL all-gather of the same
+    // 960 B costs ncclGroupStart + n ncclAllGather + ncclGroupEnd there.
+    int transport = SMT_TRANSPORT_RCCL;
+    bool peer_ok = false;               // every local device may read every other local device's memory
+    std::vector<hipStream_t> pub_stream;   // [n_local] the stream ev_ready[j] was last recorded on
+    // The pipelined entry point (smt_sharded_search_topk_device: nothing synchronises) writes rank j's list of exchange e into slot
+    // e % slots of rank j's RING, so that no rank ever waits for a reader on the device: a slot is reused `slots` exchanges later,
+    // and the caller's thread first makes sure -- hipEventSynchronize on an event that has long completed, or real back-pressure
+    // when the host runs `slots` searches ahead of the GPUs -- that the merges which read it are over.  (One cross-stream
+    // hipStreamWaitEvent costs ~3-5 us of host time: a per-rank wait for the previous merge would double the exchange's cost.)
+    struct Ring {
+        std::vector<void *> dev;                    // [n_local] slots x slot_bytes
+        size_t slot_bytes = 0;
+        int slots = 0;
+        uint64_t seq = 0;                           // exchanges issued
+        std::vector<std::vector<hipEvent_t>> done;  // [slots][n_local], made on first use: device i's merge of the slot's exchange is over
+        std::vector<uint64_t> merged;               // [slots] bit i: done[slot][i] was recorded for the slot's last exchange
+    } ring;
     // copy-transport all-reduce (shared-centroid IVF builds run one host thread per local rank): a thread barrier
     // and the ranks' buffer addresses
     std::mutex ar_mu;

@@ -934,6 +934,47 @@ __global__ void merge_topk_kernel(const uint64_t *rows, const double *dist, uint
     }
 }
 
+// The same merge over lists that are NOT gathered: list l starts at src.list[l] -- for a one-process group the exchange buffer of
+// rank l, read IN PLACE over xGMI (peer access) or on this device (logical ranks).  Nothing is copied between the ranks: the
+// exchange is this kernel's loads (n_lists x k_in x 16 B per query -- 1280 B at 8 ranks, k = 10: latency-bound), ordered
+// after the ranks' select kernels by one stream event per rank (group.cpp: peer transport).  The candidates are staged in LDS once
+// (16 B each, M <= 4096) so that the M x M rank computation never goes back over the links.
+__global__ void merge_topk_sources_kernel(MergeSources src, uint32_t n_lists, uint64_t query_stride, uint32_t k_in, uint32_t k_out,
+                                          uint64_t *out_rows, double *out_dist, uint64_t out_query_stride)
+{
+    extern __shared__ unsigned char smem_raw[];
+    uint64_t *s_row = reinterpret_cast<uint64_t *>(smem_raw);
+    const uint32_t qi = blockIdx.x;
+    const uint32_t M = n_lists * k_in;
+    double *s_dist = reinterpret_cast<double *>(s_row + M);
+    uint64_t *orow = out_rows + (size_t)qi * out_query_stride;
+    double *odist = out_dist + (size_t)qi * out_query_stride;
+    for (uint32_t t = threadIdx.x; t < k_out; t += blockDim.x) {
+        orow[t] = 0xFFFFFFFFFFFFFFFFull;
+        odist[t] = __builtin_inf();
+    }
+    for (uint32_t e = threadIdx.x; e < M; e += blockDim.x) {
+        const uint64_t *l = src.list[e / k_in] + (size_t)qi * query_stride;
+        const uint32_t i = e % k_in;
+        s_row[e] = l[i];
+        s_dist[e] = reinterpret_cast<const double *>(l + k_in)[i];
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < M; e += blockDim.x) {
+        const uint64_t r = s_row[e];
+        if (r == 0xFFFFFFFFFFFFFFFFull) continue;
+        const double d = s_dist[e];
+        uint32_t rank = 0;
+        for (uint32_t f = 0; f < M; ++f) {
+            const uint64_t rf = s_row[f];
+            if (rf == 0xFFFFFFFFFFFFFFFFull) continue;
+            const double df = s_dist[f];
+            if (df < d || (df == d && rf < r)) ++rank;
+        }
+        if (rank < k_out) { orow[rank] = r; odist[rank] = d; }
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 static inline uint32_t candidates_per_list(const smt_ctx *ctx, uint32_t k_out)
 {
@@ -1164,6 +1205,19 @@ int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *pa
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), 0, st, packed, reinterpret_cast<const double *>(packed + k_in),
                        n_lists, ls, (uint64_t)2 * k_in, k_in, k_out, out_packed, reinterpret_cast<double *>(out_packed + k_out),
                        (uint64_t)2 * k_out);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+// Packed lists [nq][2][k_in], one per source pointer (see merge_topk_sources_kernel) -> out_packed [nq][2][k_out] on stream `st`.
+int launch_merge_topk_sources_on(hipStream_t st, const MergeSources &src, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
+                                 uint64_t *out_packed)
+{
+    SMT_REQUIRE(n_lists >= 1 && n_lists <= SMT_MAX_MERGE_SOURCES, "1..64 lists are merged in place");
+    SMT_REQUIRE((uint64_t)n_lists * k_in <= 4096, "the in-place merge stages up to 4096 candidates per query");
+    const size_t smem = (size_t)n_lists * k_in * 16;
+    hipLaunchKernelGGL(merge_topk_sources_kernel, dim3(nq), dim3(256), smem, st, src, n_lists, (uint64_t)2 * k_in, k_in, k_out, out_packed,
+                       reinterpret_cast<double *>(out_packed + k_out), (uint64_t)2 * k_out);
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }

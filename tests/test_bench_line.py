@@ -49,3 +49,35 @@ def test_failed_checks_and_leg_errors_surface_in_the_line():
     for needle in ("k2_path_agreement=999/1000", "rows_match_fp64_topk=False", "embed:", "oracle_dist_max_abs_diff"):
         assert needle in joined, (needle, joined)
     assert len(json.dumps(line)) < 6000
+
+
+def test_launcher_argv_for_one_rank_per_process():
+    """--ranks-per-process 1 with WORLD_SIZE unset: bench.py becomes this torch.distributed.run command (the form the driver itself
+    uses for N > 1: one rank per GPU, rendezvous on 127.0.0.1) with its own arguments passed through."""
+    import sys
+
+    import bench
+
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5", "--ranks-per-process", "1"]
+    cmd = bench.launcher_argv(bench.parse_args(argv), argv, port=29555)
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29555", os.path.join(ROOT, "bench.py")] + argv
+
+
+def test_a_run_that_cannot_start_prints_a_line_and_exits_zero():
+    """`python3 bench.py --gpus 8 --steps 20 --warmup 5` as the driver types it, on a machine without 8 GPUs (this container has none):
+    the last stdout line parses, value is null, the error and the visible device count are in it, exit code 0."""
+    import subprocess
+    import sys
+
+    for extra, env in (([], {}), (["--ranks-per-process", "1"], {}), ([], {"WORLD_SIZE": "4", "RANK": "0"})):
+        e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"] + extra,
+                           capture_output=True, text=True, env=e, cwd=ROOT, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res = json.loads(r.stdout.strip().split("\n")[-1])
+        assert res["value"] is None and res["n_gpus"] == 8 and res["steps"] == 20 and res["warmup"] == 5
+        assert isinstance(res["n_gpus_visible"], int) and res["error"]
+        for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert key in res, key

@@ -174,7 +174,8 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
         assert key in res, key
     assert res["n_gpus"] == 1 and res["steps"] == 5 and res["value"] > 0
     assert len(line) < 6000, len(line)                     # the driver keeps an 8 KB tail of stdout
-    assert res["config"]["forced_exchange_on_one_rank"] is True and res["config"]["rccl_ranks"] == 1
+    assert res["config"]["forced_exchange_on_one_rank"] is True and res["config"]["group"]["rccl_ranks"] == 1
+    assert res["config"]["group"]["transport"] == "rccl" and "ncclCommInitRank" in res["config"]["group"]["mode"]
     assert res["checks_ok"] is True and res["checks_failed"] == [] and res["checks_total"] >= 5, res
     assert res["c4_rows_per_s"] > 0 and 0 < res["c4_frac_hbm"] < 1.0
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1.0
@@ -183,6 +184,59 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
     assert detail["checks"]["torch_fp64_topk_distances_match"] is True
     assert detail["c4"]["checks"]["torch_fp64_topk_distances_match"] is True and detail["c4"]["checks"]["rows_match_fp64_topk"] is True
     assert "rccl_ranks=1" in r.stderr                      # the pre-run diagnostics of a multi-rank launch
+
+
+SMALL = ["--steps", "5", "--warmup", "2", "--settle-steps", "8", "--no-secondary", "--no-ivfpq", "--no-embed", "--no-cpu-baseline",
+         "--no-workspace", "--no-ingest", "--no-group-issue", "--c4-rows", "4000000", "--c4-steps", "4"]
+
+
+def _bench(args, timeout=600, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    line = r.stdout.strip().split("\n")[-1]
+    return r, json.loads(line), line
+
+
+@pytest.mark.parametrize("transport", [None, "rccl"])
+def test_bench_one_process_group_path_on_one_gpu(transport):
+    """`python bench.py --gpus N` with WORLD_SIZE unset = ONE process drives the N GPUs through smt_group_create (ncclCommInitAll), the
+    reference's process model.  What a 1-GPU box runs of it: --gpus 1 --single-process -- the same code with one device -- with the default
+    transport (peer reads) and with the RCCL all-gather."""
+    args = ["--gpus", "1", "--single-process"] + SMALL + ["--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_one_process.json")]
+    if transport:
+        args += ["--group-transport", transport]
+    r, res, line = _bench(args)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert res["n_gpus"] == 1 and res["value"] > 0 and len(line) < 6000
+    grp = res["config"]["group"]
+    assert grp["n_ranks"] == 1 and grp["rccl_ranks"] == 1 and grp["transport"] == (transport or "peer") and "ncclCommInitAll" in grp["mode"]
+    assert res["checks_ok"] is True and res["checks_failed"] == [] and res["checks_total"] >= 6, res
+    assert res["c4_rows_per_s"] > 0 and 0 < res["c4_frac_hbm"] < 1.0 and 0 < res["roofline"]["frac"] < 1.0
+
+
+def test_bench_one_process_over_logical_shards():
+    """The N > 1 branch of the one-process bench (per-device shards and queries, one answer on device 0, c4 cut over the shards,
+    the fp64 check over every shard) on 3 logical ranks of the one GPU."""
+    r, res, line = _bench(["--logical-shards", "3"] + SMALL + ["--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_logical.json")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert res["n_gpus"] == 1 and res["config"]["logical_shards_on_one_gpu"] == 3 and res["config"]["group"]["n_ranks"] == 3
+    assert res["config"]["group"]["transport"] == "peer" and res["config"]["group"]["rccl_ranks"] == 0
+    assert res["checks_ok"] is True and res["checks_failed"] == [], res
+    detail = json.load(open(os.path.join(ROOT, res["detail_file"])))
+    assert detail["checks"]["rows_match_fp64_topk_over_all_shards"] is True
+    assert detail["c4"]["checks"]["rows_match_fp64_topk"] is True and detail["c4"]["config"]["rows_per_gpu"] == 1333334
+    assert abs(res["value"] - 3 * 1_000_000 * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3   # rows of ALL shards / time
+
+
+def test_bench_more_gpus_than_the_box_has_is_a_line_not_a_traceback():
+    """--gpus 2 on a 1-GPU box, typed as the driver types it (no torch.distributed.run): a parseable line with value null, the error and
+    the number of visible devices; exit code 0."""
+    for extra in ([], ["--ranks-per-process", "1"]):
+        r, res, _ = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5"] + extra, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert res["value"] is None and res["n_gpus"] == 2 and res["n_gpus_visible"] == 1 and "visible" in res["error"]
+        for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert key in res, key
 
 
 def test_bench_abandons_a_c4_leg_that_hangs_and_still_prints_the_line():

@@ -1,9 +1,11 @@
 """GPU: groups of GPUs behind the C ABI (include/semtools_hip.h: smt_group_* / smt_sharded_*).
 
 A 1-GPU box offers two things: (i) the real RCCL path with ONE rank -- ncclCommInitAll / ncclCommInitRank,
-ncclAllGather, device merge -- and (ii) "logical" groups, N ranks on one device whose exchange is device copies
-(RCCL refuses two ranks on one GPU).  (ii) drives everything except the RCCL call itself with N > 1: HIP scan on every
-shard -> gather -> merge kernel, range localisation, global row numbering, the variable-length threshold exchange.
+ncclAllGather, device merge -- and (ii) "logical" groups, N ranks on one device (RCCL refuses two ranks on one GPU) whose
+k-lists meet through the PEER transport -- the merge kernel reads every rank's list in place, one event per rank, exactly
+what a one-process group of N real GPUs does over xGMI -- or, as the fallback, through event-ordered device copies.  (ii)
+drives everything except the RCCL call itself with N > 1: HIP scan on every shard -> exchange -> merge kernel, range
+localisation, global row numbering, the variable-length threshold exchange.
 Contract everywhere: sharded result == smt_search on the unsharded matrix (which the other GPU tests pin to the
 oracle)."""
 import numpy as np
@@ -52,7 +54,26 @@ def test_rccl_group_of_one_rank(plain):
     g = smt.Group([0])
     info = g.info()
     assert info["n_ranks"] == 1 and info["n_local"] == 1 and info["rccl_ranks"] == 1 and info["rccl_version"] > 20000
+    assert g.transport == "peer"                      # one-process group: lists are read in place by default
+    with pytest.raises(RuntimeError):
+        g.set_transport("copy")                       # (the all-gather of logical groups; this one has a communicator)
     sc = smt.ShardedCorpus(g, rows=emb)
+    # the device form through both transports of a real group: peer reads and ncclAllGather
+    import torch
+    k, nq = 10, 3
+    qd = torch.from_numpy(synth.unit_query(8, nq=nq)).cuda()
+    want = c.search(qd.cpu().numpy(), top_k=k)
+    for transport in ("rccl", "peer"):
+        g.set_transport(transport)
+        assert g.transport == transport
+        out = torch.zeros((nq, 2, k), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        sc.search_topk_device([qd.data_ptr()], nq, k, [out.data_ptr()])
+        g.synchronize()
+        m = out.cpu().numpy()
+        for i in range(nq):
+            assert np.ascontiguousarray(m[i, 0]).view(np.uint64).tolist() == want[i][0].tolist()
+            assert np.array_equal(np.ascontiguousarray(m[i, 1]).view(np.float64), want[i][1])
     assert sc.rows == len(emb) and sc.rank_rows().tolist() == [len(emb)]
     qs = synth.unit_query(4, nq=3)
     for kw in CASES:
@@ -79,13 +100,19 @@ def test_rank_per_process_group_of_one(plain):
     g.close()
 
 
+@pytest.mark.parametrize("transport", ["peer", "copy"])
 @pytest.mark.parametrize("n_shards", [2, 3, 8])
-def test_logical_shards_equal_the_unsharded_search(plain, n_shards):
+def test_logical_shards_equal_the_unsharded_search(plain, n_shards, transport):
     import semtools_amd as smt
 
     emb, c = plain
     g = smt.Group.logical(0, n_shards)
     assert g.info()["n_ranks"] == n_shards and g.info()["rccl_ranks"] == 0
+    assert g.transport == "peer"
+    with pytest.raises(RuntimeError):
+        g.set_transport("rccl")                       # no communicator behind logical ranks
+    g.set_transport(transport)
+    assert g.transport == transport
     sc = smt.ShardedCorpus(g, rows=emb)
     per = -(-len(emb) // n_shards)
     assert sc.rank_rows().tolist() == [max(0, min(per, len(emb) - r * per)) for r in range(n_shards)]
@@ -109,13 +136,15 @@ def test_logical_shards_equal_the_unsharded_search(plain, n_shards):
     g.close()
 
 
-def test_sharded_device_form_and_file_round_trip(plain, tmp_path):
+@pytest.mark.parametrize("transport", ["peer", "copy"])
+def test_sharded_device_form_and_file_round_trip(plain, tmp_path, transport):
     """smt_sharded_search_topk_device (what bench.py --gpus N times) + save/load through the corpus file."""
     import torch
     import semtools_amd as smt
 
     emb, c = plain
     g = smt.Group.logical(0, 4)
+    g.set_transport(transport)
     sc = smt.ShardedCorpus(g, rows=emb)
     path = tmp_path / "corpus.f32"
     sc.save(path)
@@ -154,6 +183,62 @@ def test_sharded_device_form_and_file_round_trip(plain, tmp_path):
     sc.close(); sc2.close(); g.close()
 
 
+@pytest.mark.parametrize("transport", ["peer", "copy"])
+def test_back_to_back_exchanges_keep_their_answers_apart(plain, transport):
+    """Nothing synchronises between the calls: rank j's list of exchange e + 1 may only overwrite the one of exchange e after
+    every merge of e has read it, and a merge may only read a list its rank has finished writing (peer transport: ev_done /
+    ev_ready).  300 searches back to back, the merging device and the query count changing from call to call, the
+    host-in / host-out form (which lays the same buffers out differently) mixed in; every answer is checked."""
+    import torch
+    import semtools_amd as smt
+
+    emb, c = plain
+    n = 5
+    g = smt.Group.logical(0, n)
+    g.set_transport(transport)
+    sc = smt.ShardedCorpus(g, rows=emb)
+    k = 10
+    qs = synth.unit_query(21, nq=16)
+    qd = torch.from_numpy(qs).cuda()
+    want = c.search(qs, top_k=k)
+    steps = 300
+    outs = torch.zeros((steps, 3, 2, k), dtype=torch.int64, device="cuda")
+    outs2 = torch.zeros((steps, 3, 2, k), dtype=torch.int64, device="cuda")   # the second copy of an answer two devices asked for
+    torch.cuda.synchronize()
+    for async_select in (0, 1):
+        for i in range(n):
+            g.ctx(i).set_tuning("async_select", async_select)
+        outs.zero_()
+        torch.cuda.synchronize()
+        plan = []
+        for s in range(steps):
+            nq = 1 if s % 3 else 3
+            q0 = s % (16 - nq + 1)
+            merger = s % n
+            if s % 50 == 49:
+                got = sc.search(qs[q0:q0 + nq], top_k=k)          # host form in between (synchronises)
+                for j in range(nq):
+                    assert got[j][0].tolist() == want[q0 + j][0].tolist()
+            ptrs = [0] * n
+            ptrs[merger] = outs[s].data_ptr()
+            if s % 7 == 0:
+                ptrs[(merger + 2) % n] = outs2[s].data_ptr()                # two devices want this answer
+            sc.search_topk_device([qd[q0].data_ptr()] * n, nq, k, ptrs)
+            plan.append((q0, nq))
+        g.synchronize()
+        m, m2 = outs.cpu().numpy(), outs2.cpu().numpy()
+        for s, (q0, nq) in enumerate(plan):
+            if s % 7 == 0:
+                assert np.array_equal(m2[s, :nq], m[s, :nq]), (transport, async_select, s)
+            for j in range(nq):
+                assert np.ascontiguousarray(m[s, j, 0]).view(np.uint64).tolist() == want[q0 + j][0].tolist(), (transport, async_select, s)
+                assert np.array_equal(np.ascontiguousarray(m[s, j, 1]).view(np.float64), want[q0 + j][1])
+    for i in range(n):
+        g.ctx(i).set_tuning("async_select", 0)
+        assert g.ctx(i).uncertain_count() == 0
+    sc.close(); g.close()
+
+
 def test_adopted_device_shards_of_unequal_size(plain):
     import torch
     import semtools_amd as smt
@@ -189,6 +274,11 @@ def test_sharded_ivf_with_shared_centroids(gpu_ctx):
     g = smt.Group.logical(0, 3)
     sc = smt.ShardedCorpus(g, rows=x)
     shared = smt.ShardedIvfPq(sc, nlist=128, train_iters=6, shared_centroids=True)
+    by_peer = shared.search(qs, top_k=10, nprobe=16, rerank=128)
+    g.set_transport("copy")
+    by_copy = shared.search(qs, top_k=10, nprobe=16, rerank=128)
+    g.set_transport("peer")
+    _same(by_peer, by_copy)
     indep = smt.ShardedIvfPq(sc, nlist=128, train_iters=6, shared_centroids=False)
     s0, s1 = shared.shard_list_sizes(0, 128).astype(float), shared.shard_list_sizes(1, 128).astype(float)
     i0, i1 = indep.shard_list_sizes(0, 128).astype(float), indep.shard_list_sizes(1, 128).astype(float)
