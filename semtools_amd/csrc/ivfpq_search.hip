@@ -160,10 +160,14 @@ struct AdcParams {
     key_t64 *lists;            // [nq][nprobe][kp]
 };
 
-template <int ADC_THREADS>
+// KIND 0: product quantisation, the query's 32 x 256 LUT staged in LDS (32 KiB: 4 blocks per CU); KIND 1: per-list PCA codes scored
+// with 32 block-uniform weights -- no LUT, 2-4 KiB of LDS per block, so the register budget (50 VGPRs) decides the occupancy:
+// 8 waves per SIMD instead of 4.  (Until round 5 both kinds were one kernel and the unused LUT array halved the resident waves of
+// the shipped coding: the re-score stage is random 1 KiB row reads, i.e. latency hidden by waves in flight.)
+template <int ADC_THREADS, int KIND>
 __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
 {
-    __shared__ __attribute__((aligned(16))) float s_lut[PQ_M * PQ_K];  // 32 KiB
+    __shared__ __attribute__((aligned(16))) float s_lut[KIND == 0 ? PQ_M * PQ_K : 4];
     __shared__ key_t64 s_keys[(ADC_THREADS / 64) * 64];
     const uint32_t pi = blockIdx.x / p.n_seg, seg = blockIdx.x % p.n_seg, qi = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -181,19 +185,25 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         }
     }
 
-    if (p.lw == nullptr) {
+    if constexpr (KIND == 0) {
         const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(p.lut + (size_t)qi * PQ_M * PQ_K);
         for (int e = threadIdx.x; e < PQ_M * PQ_K / 4; e += ADC_THREADS) reinterpret_cast<f32x4 *>(s_lut)[e] = lsrc[e];
     }
     // kind 1: the 32 weights of this (query, list) pair, block-uniform (scalar loads)
     float lw[PQ_M];
-    if (p.lw != nullptr) {
+    if constexpr (KIND == 1) {
         const float *src = p.lw + ((size_t)qi * p.nprobe + pi) * PQ_M;
 #pragma unroll
         for (int k = 0; k < PQ_M; ++k) lw[k] = src[k];
     } else {
 #pragma unroll
         for (int k = 0; k < PQ_M; ++k) lw[k] = 0.0f;
+    }
+    float lw_bias = 0.0f;
+    if constexpr (KIND == 1) {
+#pragma unroll
+        for (int k = 0; k < PQ_M; ++k) lw_bias += lw[k];
+        lw_bias *= 128.0f;
     }
     const f32x4 qv = reinterpret_cast<const f32x4 *>(p.queries + (size_t)qi * 256)[lane];
     const float a2 = wave_sum(qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w);
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
     // ---- stage 1: ADC scan of the list's codes -> the wave's `ks` best approximate candidates (an unordered SET:
     // lane i < n_short ends up holding one of them in (ld, lr)).  A wave takes 64 x ADC_R codes per pass, keeps
     // their ADC distances in registers next to the set carried over from the previous pass, finds the ks-th
-    // smallest by bisection on the distance bits (ballot-free: per-lane counts + one DPP sum per step) and
+    // smallest by bisection on the distance bits (one ballot + scalar popcount per register and step) and
     // compacts the winners through LDS.  (The first version inserted candidates one at a time into a sorted
     // lane-distributed list: ~160 serial inserts per wave at ks = 64 -- that, not the re-score reads, was what
     // bounded this kernel.)
@@ -245,13 +255,17 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
                 const uint4 c1 = reinterpret_cast<const uint4 *>(p.codes + i * PQ_M)[1];
                 const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                 float acc = base;
-                if (p.lw != nullptr) {   // block-uniform branch: signed bytes times the pair's weights
+                if constexpr (KIND == 1) {   // signed bytes times the pair's weights
+                    // s = u - 128 with u = s ^ 0x80 as an unsigned byte: one v_cvt_f32_ubyteN per byte instead of a sign-extending
+                    // bit-field extract + convert, and 128 x sum(lw) comes off the block-uniform base (lw_bias)
+                    acc = base - lw_bias;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        acc += lw[4 * u + 0] * (float)(int8_t)(w[u] & 0xFF);
-                        acc += lw[4 * u + 1] * (float)(int8_t)((w[u] >> 8) & 0xFF);
-                        acc += lw[4 * u + 2] * (float)(int8_t)((w[u] >> 16) & 0xFF);
-                        acc += lw[4 * u + 3] * (float)(int8_t)(w[u] >> 24);
+                        const uint32_t x = w[u] ^ 0x80808080u;
+                        acc += lw[4 * u + 0] * (float)(x & 0xFF);
+                        acc += lw[4 * u + 1] * (float)((x >> 8) & 0xFF);
+                        acc += lw[4 * u + 2] * (float)((x >> 16) & 0xFF);
+                        acc += lw[4 * u + 3] * (float)(x >> 24);
                     }
                 } else {
 #pragma unroll
@@ -271,10 +285,11 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         }
         kd[ADC_R] = lr != 0xFFFFFFFFu ? __float_as_uint(ld) : 0xFFFFFFFFu;  // (ld keeps only the top 16 bits: enough here)
         kpos[ADC_R] = lr;
+        // (wave-wide counts through ballots: the compare writes a lane mask to SGPRs and s_bcnt1 counts it on the scalar unit --
+        // 9 VALU instructions per bisection step instead of 9 + 9 + an 11-instruction lane reduction)
         uint32_t total = 0;
 #pragma unroll
-        for (int r = 0; r <= ADC_R; ++r) total += kd[r] != 0xFFFFFFFFu ? 1u : 0u;
-        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(total));
+        for (int r = 0; r <= ADC_R; ++r) total += (uint32_t)__popcll(__ballot(kd[r] != 0xFFFFFFFFu));
         // The ADC distance is itself an approximation (error ~1e-2): its top 16 bits (relative step 2^-8 of the value)
         // are all the selection needs, which halves the bisection; ties in that bucket go by scan order.
 #pragma unroll
@@ -286,15 +301,13 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
                 const uint32_t mid = lo + ((hi - lo) >> 1);
                 uint32_t cnt = 0;
 #pragma unroll
-                for (int r = 0; r <= ADC_R; ++r) cnt += kd[r] <= mid ? 1u : 0u;
-                cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(cnt));
+                for (int r = 0; r <= ADC_R; ++r) cnt += (uint32_t)__popcll(__ballot(kd[r] <= mid));
                 if (cnt >= (uint32_t)ks) hi = mid; else lo = mid + 1u;
             }
             T = lo;
             uint32_t n_lt = 0;
 #pragma unroll
-            for (int r = 0; r <= ADC_R; ++r) n_lt += kd[r] < T ? 1u : 0u;
-            n_lt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(n_lt));
+            for (int r = 0; r <= ADC_R; ++r) n_lt += (uint32_t)__popcll(__ballot(kd[r] < T));
             need_eq = (uint32_t)ks - n_lt;
         }
         // compaction: winners take consecutive LDS slots, then lane i reads slot i
@@ -344,10 +357,18 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
             rr[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_row, src);
             c[u] = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)(ok[u] ? rr[u] : 0u) * 256)[lane];
         }
+        // the four rows' norms and dot products reduced together (device_utils.h wave_sum4: lane l ends with the sum of row l % 4)
+        float pb[4], pa[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float b2 = wave_sum(c[u].x * c[u].x + c[u].y * c[u].y + c[u].z * c[u].z + c[u].w * c[u].w);
-            const float ab = wave_sum(c[u].x * qv.x + c[u].y * qv.y + c[u].z * qv.z + c[u].w * qv.w);
+            pb[u] = c[u].x * c[u].x + c[u].y * c[u].y + c[u].z * c[u].z + c[u].w * c[u].w;
+            pa[u] = c[u].x * qv.x + c[u].y * qv.y + c[u].z * qv.z + c[u].w * qv.w;
+        }
+        const float b2s = wave_sum4(pb[0], pb[1], pb[2], pb[3], lane);
+        const float abs4 = wave_sum4(pa[0], pa[1], pa[2], pa[3], lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float b2 = readlane_f(b2s, u), ab = readlane_f(abs4, u);
             if (ok[u]) insert(dist_f32(ab, b2, rq, qz), rr[u], ld2, lr2, thr2_d, thr2_r, kp);
         }
     }
@@ -382,7 +403,9 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     SMT_REQUIRE(top_k <= 56, "top_k must be <= 56 for the IVF-PQ path");
     if (rerank == 0) rerank = 512;
     SMT_REQUIRE(rerank >= 4 && rerank <= 512, "rerank (full-precision re-scored ADC candidates per probed list) must be in [4, 512]");
-    const int adc_waves = rerank > 256 ? 8 : 4;   // waves per (query, list segment) block
+    // waves per (query, list segment) block.  (PQ, kind 0, with 8-wave blocks -- two blocks' worth of waves sharing one 32 KiB LUT --
+    // measured +4 % queries/s for -0.5 point of recall@10 at rerank 128: sixteen candidates per wave are too few.  Not taken.)
+    const int adc_waves = rerank > 256 ? 8 : 4;
     const uint32_t shortlist = (rerank + adc_waves - 1) / adc_waves;  // per wave
     const uint32_t kp = top_k + 8;                // re-scored candidates handed to the exact select stage
     // A list longer than ADC_SEGMENT codes is scanned by several blocks, each with its own shortlist of `rerank`
@@ -461,8 +484,14 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     ap.kp = kp;
     ap.lists = reinterpret_cast<key_t64 *>(base + o_lists);
     prof_begin(ctx, "ivf_adc");
-    if (adc_waves == 8) hipLaunchKernelGGL(ivf_adc_kernel<512>, dim3(nprobe * n_seg, nq), dim3(512), 0, ctx->stream, ap);
-    else hipLaunchKernelGGL(ivf_adc_kernel<256>, dim3(nprobe * n_seg, nq), dim3(256), 0, ctx->stream, ap);
+    const dim3 adc_grid(nprobe * n_seg, nq);
+    if (ix->kind == 1) {
+        if (adc_waves == 8) hipLaunchKernelGGL((ivf_adc_kernel<512, 1>), adc_grid, dim3(512), 0, ctx->stream, ap);
+        else hipLaunchKernelGGL((ivf_adc_kernel<256, 1>), adc_grid, dim3(256), 0, ctx->stream, ap);
+    } else {
+        if (adc_waves == 8) hipLaunchKernelGGL((ivf_adc_kernel<512, 0>), adc_grid, dim3(512), 0, ctx->stream, ap);
+        else hipLaunchKernelGGL((ivf_adc_kernel<256, 0>), adc_grid, dim3(256), 0, ctx->stream, ap);
+    }
     prof_end(ctx, "ivf_adc");
     IVF_HIP(hipGetLastError());
     uint64_t *d_or = d_or_user ? d_or_user : reinterpret_cast<uint64_t *>(base + o_or);
