@@ -417,6 +417,11 @@ int smt_sharded_ivfpq_info(const smt_sharded_ivfpq *index, uint64_t *rows_covere
  * synchronises), they count such queries here.  reset != 0 clears the counter. */
 int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset);
 
+/* Test hook for the kept range sets: a range list (the path subset of a workspace search) that a corpus sees for the second time
+ * is kept on the device with its tile / chunk tables -- up to 4 lists per corpus, least recently used first out -- so that a session
+ * searching the same file set again uploads only its queries.  kept: sets alive; hits: searches answered from one; builds: sets made. */
+int smt_debug_range_sets(const smt_corpus *corpus, uint64_t *kept, uint64_t *hits, uint64_t *builds);
+
 /* Test hook for the certificate's error bound: the f32 distances the batched kernels NOMINATE candidates with
  * (f32 MFMA, or bf16 x 3 split products when tuning key gemm_bf16x3 is set -- the default), for nq <= 32 host
  * queries against rows [first_row, first_row + n_rows) of the corpus; out is a host buffer [n_rows][32].

@@ -396,6 +396,7 @@ extern "C" {
         index_bytes: *mut u64,
     ) -> c_int;
     pub fn smt_ctx_uncertain_count(ctx: *mut SmtCtx, count: *mut u64, reset: c_int) -> c_int;
+    pub fn smt_debug_range_sets(corpus: *const SmtCorpus, kept: *mut u64, hits: *mut u64, builds: *mut u64) -> c_int;
     pub fn smt_debug_batched_scores(
         corpus: *mut SmtCorpus,
         queries: *const f32,

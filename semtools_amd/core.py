@@ -238,6 +238,12 @@ class Corpus:
             break
         return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
 
+    def range_sets(self):
+        """(kept, hits, builds) of the range lists this corpus keeps on the device (smt_debug_range_sets)."""
+        v = [C.c_uint64() for _ in range(3)]
+        L.check(L.lib().smt_debug_range_sets(self._h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
     def search_topk_device(self, queries_ptr, nq, top_k, row_base, out_rows_ptr, out_dist_ptr):
         L.check(L.lib().smt_search_topk_device(self._h, C.c_void_p(queries_ptr), int(nq), int(top_k), int(row_base),
                                                C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))

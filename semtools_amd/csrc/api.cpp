@@ -566,6 +566,7 @@ void smt_corpus_destroy(smt_corpus *corpus)
     (void)drain_async(corpus->ctx);  // an async select may still be rescoring rows of this corpus
     if (corpus->owned && corpus->d_rows) (void)hipFree(corpus->d_rows);
     corpus_image_drop(corpus);
+    corpus_range_sets_drop(corpus);
     delete corpus;
 }
 

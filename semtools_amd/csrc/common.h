@@ -115,6 +115,28 @@ struct smt_ctx {
     smt::Tuning tune;
 };
 
+namespace smt {
+// A range list (the path subset of a workspace search, src/workspace/store.rs:495-515) staged on the device and KEPT on the corpus:
+// a `serve -w` session, an `ask` agent or a shell loop search the same file set again and again, and validating + prefixing +
+// uploading 5000 ranges and rebuilding their tile table was 0.17 ms of a 0.59 ms one-query call.  Identified by two independent
+// 64-bit hashes of the list; built the SECOND time a list is seen (one-shot subsets never allocate); at most RANGE_SETS_MAX per
+// corpus, least recently used goes first.  The tables depend on the ranges only, never on the rows: appends do not invalidate them.
+struct RangeSet {
+    uint64_t h1 = 0, h2 = 0;
+    uint32_t n_in = 0;                 // ranges as passed (empty ones included: part of the identity)
+    uint32_t nr = 0;                   // non-empty ranges on the device
+    uint64_t n_virtual = 0, n_chunks = 0, n_vtiles = 0, max_end = 0;
+    char *dev = nullptr;               // [ranges | prefix | chunk_prefix | tile_prefix | tile table | chunk table]
+    smt_range *d_r = nullptr;
+    uint64_t *d_p = nullptr, *d_cp = nullptr, *d_tp = nullptr;
+    uint64_t *d_tile_table = nullptr, *d_chunk_table = nullptr;   // nullptr: too large to keep (rebuilt per call in scratch)
+    bool have_tile_table = false, have_chunk_table = false;
+    uint64_t last_use = 0;
+};
+constexpr int RANGE_SETS_MAX = 4;
+constexpr size_t RANGE_SET_TABLE_BYTES_MAX = (size_t)96 << 20;   // tile + chunk table of one set
+}  // namespace smt
+
 struct smt_corpus {
     smt_ctx *ctx = nullptr;
     float *d_rows = nullptr;
@@ -132,6 +154,11 @@ struct smt_corpus {
     uint64_t image_rows = 0;
     uint32_t small_searches = 0; // searches of < 8 queries seen while the shard was large enough to scan its image (search.cpp topk_dispatch)
     int image_mode = 0;          // 0: by policy (tuning key corpus_image; owned corpora only), 1: requested (smt_corpus_prepack), -1: refused
+    std::vector<smt::RangeSet *> range_sets;   // search.cpp: ranges_on_device
+    uint64_t range_clock = 0;
+    uint64_t range_seen[16][2] = {};           // hashes of lists seen once (a set is built on the second sight)
+    uint32_t range_seen_next = 0;
+    uint64_t range_set_hits = 0, range_set_builds = 0;
 };
 
 struct smt_model {
@@ -201,8 +228,13 @@ struct ScanArgs {
     const uint32_t *image_zero = nullptr;
     uint64_t out_stride = 0;  // words between the output lists of consecutive queries (0 = k_out); the packed
                               // [nq][2][k] exchange layout of group.cpp uses 2*k with out_dist = out_rows + k
+    struct RangeSet *range_set = nullptr;   // the ranges come from a kept set: its tile / chunk tables are built once and reused
 };
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
+void corpus_range_sets_drop(smt_corpus *c);   // search.cpp (smt_corpus_destroy)
+// the kept set's table when there is one (built on first use), else `scratch_table` built for this call
+int range_tile_table(smt_ctx *ctx, const ScanArgs &a, uint64_t *scratch_table, const uint64_t **table);
+int range_chunk_table(smt_ctx *ctx, const ScanArgs &a, uint64_t *scratch_table, const uint64_t **table);
 
 // Range-filtered scans stream FILTER_CHUNK-row chunks described by a per-chunk table (scan_kernels.hip).
 constexpr int FILTER_CHUNK = 4;
@@ -262,6 +294,11 @@ struct SelectArgs {
     // sticky counter is bumped) and the host entry points re-answer it exhaustively.  0 = no certificate (IVF-PQ).
     double f32_err = 0.0;
     uint64_t *out_uncertain = nullptr;
+    // batched path: != 0 where a query's candidate buffer overflowed between two level selects (rows were dropped: the lists may
+    // miss an answer row).  Such a query is flagged like a failed certificate -- the host entry points re-answer it exhaustively,
+    // the device entry points count it -- so that no batched call needs a host synchronisation of its own (until round 5
+    // launch_gemm_topk read this flag back after every batch).
+    const unsigned int *overflow = nullptr;
 };
 int launch_select(smt_ctx *ctx, const SelectArgs &s);
 

@@ -475,9 +475,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (rowreg && !(f16x1 || f16x2))   // bf16 x 3: its split kernel has no wave per query
         hipLaunchKernelGGL(query_consts_kernel, dim3(nqt * QT_ROWS / 4), dim3(256), 0, ctx->stream, a.queries, a.nq,
                            nqt * QT_ROWS, qconst, 0, counts, overflow, tau, head.fill, head.n_fill);
+    // (the table of a KEPT range set -- search.cpp -- is built the first time a call needs it and then only read)
+    const uint64_t *use_table = chunk_table;
     if (filtered && rowreg) {
-        if ((rc = launch_build_tile_table(ctx, a.ranges, a.range_tile_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
-    } else if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, chunk_table))) return rc;
+        if ((rc = range_tile_table(ctx, a, chunk_table, &use_table))) return rc;
+    } else if (filtered && (rc = range_chunk_table(ctx, a, chunk_table, &use_table))) return rc;
     if (!rowreg) {
         SMT_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * b_cnt, ctx->stream));
         hipLaunchKernelGGL(fill_f32_kernel, dim3((nqt * QT_ROWS + 255) / 256), dim3(256), 0, ctx->stream, tau,
@@ -523,7 +525,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.qconst = qconst;
         g.cand = cand;
         g.counts = counts;
-        g.tile_table = filtered ? chunk_table : nullptr;
+        g.tile_table = filtered ? use_table : nullptr;
         g.tile_min = tile_min;
         g.image = use_image ? a.image : nullptr;
         g.image_zero = use_image ? a.image_zero : nullptr;
@@ -576,8 +578,8 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
         g.qconst = qconst;
         g.cand = cand;
         g.counts = counts;
-        g.chunk_table = filtered && !rowreg ? chunk_table : nullptr;
-        g.tile_table = filtered && rowreg ? chunk_table : nullptr;
+        g.chunk_table = filtered && !rowreg ? use_table : nullptr;
+        g.tile_table = filtered && rowreg ? use_table : nullptr;
         g.tile_min = nullptr;
         g.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
         g.buffered = (lev > 0 || bootstrap) && ctx->tune.gemm_buffered != 0;   // (thresholds exist: nominations are few)
@@ -685,25 +687,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     sel.out_stride = a.out_stride;
     sel.f32_err = f16x1 ? F32_ERR_F16X1 : f16x2 ? F32_ERR_F16X2 : bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
     sel.out_uncertain = a.out_uncertain;
+    sel.overflow = overflow;
     rc = launch_select(ctx, sel);
     if (rc) return rc;
 
-    // overflow check (host sync: a batch is tens of milliseconds, the flag read is noise)
-    std::vector<unsigned int> h_over(a.nq);
-    SMT_HIP_CHECK(hipMemcpyAsync(h_over.data(), overflow, (size_t)a.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (uint32_t q = 0; q < a.nq; ++q) {
-        if (!h_over[q]) continue;
-        ScanArgs one = a;  // exact fallback for this query through K2
-        one.queries = a.queries + (size_t)q * 256;
-        one.nq = 1;
-        one.out_rows = a.out_rows + (size_t)q * ostride;
-        one.out_dist = a.out_dist + (size_t)q * ostride;
-        one.out_counts = a.out_counts ? a.out_counts + q : nullptr;
-        one.out_uncertain = a.out_uncertain ? a.out_uncertain + q : nullptr;
-        if ((rc = launch_scan_topk(ctx, one))) return rc;
-    }
-    return SMT_OK;
+    return SMT_OK;   // (nothing synchronises: a query whose buffer overflowed is flagged by the select -- SelectArgs::overflow)
 }
 
 __global__ void set_qconst_thresholds_kernel(float *qconst, const float *tau, uint32_t nq)

@@ -575,6 +575,7 @@ struct FinalParams {
     unsigned long long *dbg;  // optional: s_memtime stamps of query 0's phases (tuning key select_debug_ptr)
     unsigned long long *flags;  // async select (or nullptr), see ScanParams
     unsigned long long step;
+    const unsigned int *overflow;  // SelectArgs::overflow
 };
 
 #define SEL_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
@@ -874,10 +875,14 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
             decide = true;
             uncertain = p.ws_threshold ? ((1.0 - floor_out) > (double)p.ws_thr_score) : true;
         }
+        if (decide && !uncertain && p.overflow && p.overflow[qi]) uncertain = true;   // rows were dropped on the way (SelectArgs::overflow)
         if (decide && uncertain) {
             if (p.out_uncertain) p.out_uncertain[qi] = 1;
             if (p.status) atomicAdd(p.status, 1ull);
         }
+    } else if (threadIdx.x == 0 && p.overflow && p.overflow[qi]) {
+        if (p.out_uncertain) p.out_uncertain[qi] = 1;
+        if (p.status) atomicAdd(p.status, 1ull);
     }
     if (threadIdx.x == 0 && p.out_counts)
         p.out_counts[qi] = s_cnt[1] < p.k_out ? s_cnt[1] : p.k_out;
@@ -1041,6 +1046,7 @@ int launch_select(smt_ctx *ctx, const SelectArgs &a)
     f.dbg = reinterpret_cast<unsigned long long *>(ctx->tune.select_debug_ptr);
     f.flags = a.async_step ? ctx->d_flags : nullptr;
     f.step = a.async_step;
+    f.overflow = a.overflow;
     const bool small = (uint64_t)a.n_lists * a.kp <= (uint64_t)8 * SEL_THREADS;
     const size_t smem = final_smem_bytes(a.n_lists, a.kp);
     if (a.async_step) {
@@ -1090,13 +1096,14 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
 
     const bool nt = ctx->tune.scan_nontemporal != 0;
     prof_begin(ctx, "scan");
-    if (filtered && (rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, n_chunks, table))) return rc;
+    const uint64_t *use_table = table;
+    if (filtered && (rc = range_chunk_table(ctx, a, table, &use_table))) return rc;
     for (uint32_t q0 = 0; q0 < a.nq;) {
         ScanParams p;
         p.corpus = a.corpus;
         p.queries = a.queries + (size_t)q0 * 256;
         p.n_virtual = a.n_virtual;
-        p.chunk_table = filtered ? table : nullptr;
+        p.chunk_table = filtered ? use_table : nullptr;
         p.n_chunks = n_chunks;
         p.kp = kp;
         p.block_lists = lists + (size_t)q0 * blocks * kp;

@@ -14,20 +14,6 @@ using namespace smt;
 
 namespace smt {
 
-static int validate_ranges(const smt_range *ranges, uint32_t n, uint64_t rows, uint64_t *total)
-{
-    uint64_t prev_end = 0, t = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        SMT_REQUIRE(ranges[i].begin <= ranges[i].end, "range begin > end");
-        SMT_REQUIRE(ranges[i].end <= rows, "range extends past the corpus");
-        SMT_REQUIRE(i == 0 || ranges[i].begin >= prev_end, "ranges must be sorted and disjoint");
-        prev_end = ranges[i].end;
-        t += ranges[i].end - ranges[i].begin;
-    }
-    *total = t;
-    return SMT_OK;
-}
-
 // The three exclusive prefixes a range-filtered search stages beside its ranges: rows before range i (large-k path), FILTER_CHUNK-row
 // chunks before it (K2 / K4 / the LDS-row kernel) and aligned 32-row tiles before it (gemm_rowreg_kernel: a tile counts for the
 // FIRST range that touches it).  host = [prefix | chunk_prefix | tile_prefix], each nr + 1 words.
@@ -45,6 +31,149 @@ static void range_prefixes(const std::vector<smt_range> &rr, std::vector<uint64_
         tile_prefix[i + 1] = tile_prefix[i] + (lt - ft + 1) - (ft == last_tile ? 1 : 0);
         last_tile = lt;
     }
+}
+
+// ---------------------------------------------------------------- kept range sets (common.h RangeSet)
+static inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+    return x;
+}
+
+static void range_set_free(RangeSet *rs)
+{
+    if (!rs) return;
+    if (rs->dev) (void)hipFree(rs->dev);
+    delete rs;
+}
+
+void corpus_range_sets_drop(smt_corpus *c)
+{
+    for (RangeSet *rs : c->range_sets) range_set_free(rs);
+    c->range_sets.clear();
+}
+
+// Ranges validated (as validate_ranges) and identified in one pass; the set kept for this list if there is one, else nullptr
+// (with *build = true when the list has been seen before and deserves one now).
+static int range_set_find(smt_corpus *corpus, const smt_range *ranges, uint32_t n, uint64_t *total, RangeSet **found, bool *build,
+                          uint64_t *h1_out, uint64_t *h2_out)
+{
+    uint64_t prev_end = 0, t = 0, h1 = 0x9E3779B97F4A7C15ull ^ n, h2 = 0xC2B2AE3D27D4EB4Full + n;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t b = ranges[i].begin, e = ranges[i].end;
+        SMT_REQUIRE(b <= e, "range begin > end");
+        SMT_REQUIRE(e <= corpus->rows, "range extends past the corpus");
+        SMT_REQUIRE(i == 0 || b >= prev_end, "ranges must be sorted and disjoint");
+        prev_end = e;
+        t += e - b;
+        h1 = (h1 ^ b) * 0x100000001B3ull; h1 = (h1 ^ e) * 0x100000001B3ull; h1 ^= h1 >> 29;
+        h2 = (h2 + b) * 0x9FB21C651E98DF25ull; h2 = ((h2 << 31) | (h2 >> 33)) + e;
+    }
+    h1 = mix64(h1); h2 = mix64(h2 ^ t);
+    *total = t;
+    *h1_out = h1; *h2_out = h2;
+    *found = nullptr;
+    *build = false;
+    for (RangeSet *rs : corpus->range_sets)
+        if (rs->h1 == h1 && rs->h2 == h2 && rs->n_in == n && rs->n_virtual == t) {
+            rs->last_use = ++corpus->range_clock;
+            ++corpus->range_set_hits;
+            *found = rs;
+            return SMT_OK;
+        }
+    for (auto &seen : corpus->range_seen)
+        if (seen[0] == h1 && seen[1] == h2) { *build = true; return SMT_OK; }
+    corpus->range_seen[corpus->range_seen_next % 16][0] = h1;
+    corpus->range_seen[corpus->range_seen_next % 16][1] = h2;
+    ++corpus->range_seen_next;
+    return SMT_OK;
+}
+
+// A new kept set for (rr, prefixes): one device block, uploaded on the context's stream from pinned memory.
+static int range_set_build(smt_corpus *corpus, uint32_t n_in, uint64_t h1, uint64_t h2, const std::vector<smt_range> &rr,
+                           const std::vector<uint64_t> &prefixes, uint64_t n_virtual, RangeSet **out)
+{
+    smt_ctx *ctx = corpus->ctx;
+    *out = nullptr;
+    const uint32_t nr = (uint32_t)rr.size();
+    const uint64_t n_chunks = prefixes[2 * (nr + 1) - 1], n_vtiles = prefixes[3 * (nr + 1) - 1];
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t r_bytes = al((size_t)nr * sizeof(smt_range)), p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
+    const size_t head = r_bytes + al(3 * p_bytes);
+    const bool keep_tables = (n_vtiles + n_chunks) * 8 <= RANGE_SET_TABLE_BYTES_MAX;
+    const size_t b_tile = keep_tables ? al((size_t)n_vtiles * 8) : 0, b_chunk = keep_tables ? al((size_t)n_chunks * 8) : 0;
+    if (corpus->range_sets.size() >= (size_t)RANGE_SETS_MAX) {
+        // the least recently used set goes; kernels of earlier calls may still read it
+        size_t lru = 0;
+        for (size_t i = 1; i < corpus->range_sets.size(); ++i)
+            if (corpus->range_sets[i]->last_use < corpus->range_sets[lru]->last_use) lru = i;
+        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->aux_stream) SMT_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+        range_set_free(corpus->range_sets[lru]);
+        corpus->range_sets.erase(corpus->range_sets.begin() + (long)lru);
+    }
+    RangeSet *rs = new RangeSet();
+    if (hipMalloc(reinterpret_cast<void **>(&rs->dev), head + b_tile + b_chunk + 64) != hipSuccess) {
+        (void)hipGetLastError();   // no room for a kept set: the call goes on without one
+        delete rs;
+        return SMT_OK;
+    }
+    rs->h1 = h1; rs->h2 = h2; rs->n_in = n_in; rs->nr = nr;
+    rs->n_virtual = n_virtual; rs->n_chunks = n_chunks; rs->n_vtiles = n_vtiles;
+    rs->d_r = reinterpret_cast<smt_range *>(rs->dev);
+    rs->d_p = reinterpret_cast<uint64_t *>(rs->dev + r_bytes);
+    rs->d_cp = rs->d_p + (nr + 1);
+    rs->d_tp = rs->d_cp + (nr + 1);
+    rs->d_tile_table = keep_tables ? reinterpret_cast<uint64_t *>(rs->dev + head) : nullptr;
+    rs->d_chunk_table = keep_tables ? reinterpret_cast<uint64_t *>(rs->dev + head + b_tile) : nullptr;
+    int rc = ensure_pinned_in(ctx, head);
+    if (!rc) {
+        // (h_pinned_in is reused by the caller for the queries: the upload must have left it before this returns -- once per set)
+        char *pin = reinterpret_cast<char *>(ctx->h_pinned_in);
+        memcpy(pin, rr.data(), (size_t)nr * sizeof(smt_range));
+        memcpy(pin + r_bytes, prefixes.data(), 3 * p_bytes);
+        hipError_t e = hipMemcpyAsync(rs->dev, pin, head, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { set_error("range set upload: %s", hipGetErrorString(e)); rc = SMT_E_HIP; }
+    }
+    if (rc) { range_set_free(rs); return rc; }
+    rs->last_use = ++corpus->range_clock;
+    ++corpus->range_set_builds;
+    corpus->range_sets.push_back(rs);
+    *out = rs;
+    return SMT_OK;
+}
+
+int range_tile_table(smt_ctx *ctx, const ScanArgs &a, uint64_t *scratch_table, const uint64_t **table)
+{
+    RangeSet *rs = a.range_set;
+    if (rs && rs->d_tile_table) {
+        if (!rs->have_tile_table) {
+            int rc = launch_build_tile_table(ctx, a.ranges, a.range_tile_prefix, a.n_ranges, a.n_vtiles, rs->d_tile_table);
+            if (rc) return rc;
+            rs->have_tile_table = true;
+        }
+        *table = rs->d_tile_table;
+        return SMT_OK;
+    }
+    *table = scratch_table;
+    return launch_build_tile_table(ctx, a.ranges, a.range_tile_prefix, a.n_ranges, a.n_vtiles, scratch_table);
+}
+
+int range_chunk_table(smt_ctx *ctx, const ScanArgs &a, uint64_t *scratch_table, const uint64_t **table)
+{
+    RangeSet *rs = a.range_set;
+    if (rs && rs->d_chunk_table) {
+        if (!rs->have_chunk_table) {
+            int rc = launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, a.n_chunks, rs->d_chunk_table);
+            if (rc) return rc;
+            rs->have_chunk_table = true;
+        }
+        *table = rs->d_chunk_table;
+        return SMT_OK;
+    }
+    *table = scratch_table;
+    return launch_build_chunk_table(ctx, a.ranges, a.range_chunk_prefix, a.n_ranges, a.n_chunks, scratch_table);
 }
 
 // Exhaustive answer for ONE query whose f32 nomination failed its exactness certificate: K4 collects every row
@@ -245,20 +374,29 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     const bool has_thr = !std::isnan(max_distance);
     const bool all_under_threshold = (mode == SMT_MODE_DOCUMENTS) && has_thr;
 
-    // drop empty ranges; total rows to scan
+    // drop empty ranges; total rows to scan.  A list searched before has its device copy (and tables) kept on the corpus.
     std::vector<smt_range> rr;
     uint64_t n_virtual = corpus->rows;
+    RangeSet *rset = nullptr;
+    bool rset_build = false;
+    uint64_t rh1 = 0, rh2 = 0;
     if (n_ranges) {
         uint64_t total = 0;
-        if ((rc = validate_ranges(ranges, n_ranges, corpus->rows, &total))) return rc;
-        for (uint32_t i = 0; i < n_ranges; ++i) if (ranges[i].end > ranges[i].begin) rr.push_back(ranges[i]);
+        if ((rc = range_set_find(corpus, ranges, n_ranges, &total, &rset, &rset_build, &rh1, &rh2))) return rc;
         n_virtual = total;
+        if (!rset)
+            for (uint32_t i = 0; i < n_ranges; ++i) if (ranges[i].end > ranges[i].begin) rr.push_back(ranges[i]);
     }
     if (n_virtual == 0) return SMT_OK;
     if (!all_under_threshold && top_k == 0) return SMT_OK;  // take(0) / store.rs:489-491
+    std::vector<uint64_t> prefixes;
+    if (!rset && !rr.empty()) {
+        range_prefixes(rr, prefixes);
+        if (rset_build && (rc = range_set_build(corpus, n_ranges, rh1, rh2, rr, prefixes, n_virtual, &rset))) return rc;
+    }
 
     // ---- device staging: queries, ranges(+prefix)
-    const uint32_t nr = (uint32_t)rr.size();
+    const uint32_t nr = rset ? rset->nr : (uint32_t)rr.size();
     const size_t q_bytes = (size_t)nq * SMT_DIM * sizeof(float);
     const size_t r_bytes = (size_t)nr * sizeof(smt_range);
     const size_t p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
@@ -274,20 +412,20 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     uint64_t *d_cp = d_p + (nr + 1), *d_tp = d_cp + (nr + 1);
     // queries, ranges and the three prefixes are assembled in ONE pinned buffer (laid out like the device stage) and go up in one
     // copy: four pageable hipMemcpyAsync calls -- each staged by the runtime before it returns -- were ~50 us of a 0.6 ms call
-    std::vector<uint64_t> prefixes;
-    range_prefixes(rr, prefixes);
-    const size_t up_bytes = q_bytes + (nr ? r_bytes + 3 * p_bytes : 0);
+    const size_t up_bytes = q_bytes + (nr && !rset ? r_bytes + 3 * p_bytes : 0);
     if ((rc = ensure_pinned_in(ctx, up_bytes))) return rc;
     {
         char *pin = reinterpret_cast<char *>(ctx->h_pinned_in);
         memcpy(pin, queries, q_bytes);
-        if (nr) {
+        if (nr && !rset) {
             memcpy(pin + q_bytes, rr.data(), r_bytes);
             memcpy(pin + q_bytes + r_bytes, prefixes.data(), 3 * p_bytes);
         }
         SMT_HIP_CHECK(hipMemcpyAsync(stage, pin, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    const uint64_t n_chunks = prefixes[2 * (nr + 1) - 1], n_vtiles = prefixes[3 * (nr + 1) - 1];
+    if (rset) { d_r = rset->d_r; d_p = rset->d_p; d_cp = rset->d_cp; d_tp = rset->d_tp; }   // (only the queries went up)
+    const uint64_t n_chunks = rset ? rset->n_chunks : nr ? prefixes[2 * (nr + 1) - 1] : 0;
+    const uint64_t n_vtiles = rset ? rset->n_vtiles : nr ? prefixes[3 * (nr + 1) - 1] : 0;
 
     if (!all_under_threshold) {
         // ---------------- top-k (optionally with the workspace score threshold)
@@ -365,6 +503,7 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
         a.out_dist = d_odist;
         a.out_counts = d_ocnt;
         a.out_uncertain = d_ocnt + nq;
+        a.range_set = rset;
         // K2 or K3: topk_dispatch above
         rc = topk_dispatch(ctx, corpus, a);
         if (rc) return rc;
@@ -474,11 +613,15 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     smt_ctx *ctx = corpus->ctx;
     uint64_t n_virtual = corpus->rows;
     std::vector<smt_range> rr;
+    RangeSet *rset = nullptr;
+    bool rset_build = false;
+    uint64_t rh1 = 0, rh2 = 0;
     if (filtered) {
         uint64_t total = 0;
-        int rcv = validate_ranges(ranges_local, n_ranges, corpus->rows, &total);
+        int rcv = range_set_find(corpus, ranges_local, n_ranges, &total, &rset, &rset_build, &rh1, &rh2);
         if (rcv) return rcv;
-        for (uint32_t i = 0; i < n_ranges; ++i) if (ranges_local[i].end > ranges_local[i].begin) rr.push_back(ranges_local[i]);
+        if (!rset)
+            for (uint32_t i = 0; i < n_ranges; ++i) if (ranges_local[i].end > ranges_local[i].begin) rr.push_back(ranges_local[i]);
         n_virtual = total;
     }
     const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k_pad, n_virtual);
@@ -492,11 +635,19 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
             return SMT_OK;
         }
     }
-    const uint32_t nr = (uint32_t)rr.size();
+    std::vector<uint64_t> prefixes;
+    if (!rset && !rr.empty()) {
+        range_prefixes(rr, prefixes);
+        if (rset_build && (rc = range_set_build(corpus, n_ranges, rh1, rh2, rr, prefixes, n_virtual, &rset))) return rc;
+    }
+    const uint32_t nr = rset ? rset->nr : (uint32_t)rr.size();
     smt_range *d_r = nullptr;
     uint64_t *d_p = nullptr, *d_cp = nullptr, *d_tp = nullptr;
     uint64_t n_chunks = 0, n_vtiles = 0;
-    if (nr) {
+    if (rset) {
+        d_r = rset->d_r; d_p = rset->d_p; d_cp = rset->d_cp; d_tp = rset->d_tp;
+        n_chunks = rset->n_chunks; n_vtiles = rset->n_vtiles;
+    } else if (nr) {
         const size_t r_bytes = (size_t)nr * sizeof(smt_range), p_bytes = (size_t)(nr + 1) * sizeof(uint64_t);
         if ((rc = ensure_stage(ctx, r_bytes + 3 * p_bytes + 64))) return rc;
         char *stage = reinterpret_cast<char *>(ctx->d_stage);
@@ -504,8 +655,6 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
         d_p = reinterpret_cast<uint64_t *>(stage + r_bytes);
         d_cp = d_p + (nr + 1);
         d_tp = d_cp + (nr + 1);
-        std::vector<uint64_t> prefixes;
-        range_prefixes(rr, prefixes);
         n_chunks = prefixes[2 * (nr + 1) - 1];
         n_vtiles = prefixes[3 * (nr + 1) - 1];
         SMT_HIP_CHECK(hipMemcpyAsync(d_r, rr.data(), r_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -535,6 +684,7 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     a.out_uncertain = uncertain_dev;
     a.allow_async = async;
     a.out_stride = (uint64_t)2 * k_pad;
+    a.range_set = rset;
     rc = topk_dispatch(ctx, corpus, a);
     return rc;
 }
@@ -552,6 +702,15 @@ try {
     int rc = search_local_host(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, hits);
     if (rc) return rc;
     return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
+} catch (...) { return smt::api_catch(); }
+
+int smt_debug_range_sets(const smt_corpus *corpus, uint64_t *kept, uint64_t *hits, uint64_t *builds)
+try {
+    SMT_REQUIRE(corpus != nullptr, "corpus");
+    if (kept) *kept = corpus->range_sets.size();
+    if (hits) *hits = corpus->range_set_hits;
+    if (builds) *builds = corpus->range_set_builds;
+    return SMT_OK;
 } catch (...) { return smt::api_catch(); }
 
 int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,

@@ -410,3 +410,38 @@ def test_random_shapes_against_the_oracle(gpu_ctx, nominate_with):
     finally:
         gpu_ctx.set_tuning("gemm_min_rows_small", 1_000_000)
         gpu_ctx.set_tuning("gemm_min_nq", 5)
+
+
+def test_device_form_counts_an_overflowed_query_instead_of_synchronising(gpu_ctx):
+    """The batched device form (smt_search_topk_device: nothing synchronises) on the corpus that floods the candidate buffers: until
+    round 5 launch_gemm_topk read an overflow flag back after every batch (one host synchronisation per call) and re-answered such
+    queries with the scan kernel; now the final select flags them like a failed certificate -- counted by the context for the device
+    form, re-answered exhaustively by the host form (the test above).  Every query is either exact or counted."""
+    import torch
+    import semtools_amd as smt
+
+    n = 70_000
+    rng = np.random.default_rng(3)
+    qs = synth.unit_query(8, nq=9)
+    far = synth.unit_rows(n, seed=4, dup_frac=0, zero_frac=0)
+    near = qs[rng.integers(0, 9, n)] + 0.05 * rng.standard_normal((n, 256)).astype(np.float32)
+    near /= np.linalg.norm(near, axis=1, keepdims=True)
+    tile = np.arange(n) // 32
+    emb = np.where((tile % 16 == 0)[:, None], far, near).astype(np.float32)
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    qd = torch.from_numpy(qs).cuda()
+    o_r = torch.zeros((9, 10), dtype=torch.int64, device="cuda")
+    o_d = torch.zeros((9, 10), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.uncertain_count()
+    c.search_topk_device(qd.data_ptr(), 9, 10, 0, o_r.data_ptr(), o_d.data_ptr())
+    gpu_ctx.synchronize()
+    flagged = gpu_ctx.uncertain_count()
+    inexact = 0
+    rows = o_r.cpu().numpy()
+    for i in range(9):
+        res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
+        inexact += rows[i].tolist() != [r["match_line"] for r in res]
+    assert flagged >= max(inexact, 1), (flagged, inexact)      # this corpus does overflow: at least one query is counted
+    c.close()

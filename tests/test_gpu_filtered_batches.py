@@ -225,3 +225,61 @@ def test_a_level_run_in_two_parts_answers_like_the_whole_level(gpu_ctx, subset):
     finally:
         gpu_ctx.set_tuning("gemm_split_last", 2)
         c.close()
+
+
+def test_a_range_list_seen_twice_is_kept_on_the_device_and_answers_the_same(gpu_ctx):
+    """The path subset of a workspace session repeats (src/workspace/store.rs:495 chunks the same paths every call): the second time a
+    corpus sees a range list it keeps the list, its prefixes and its tile / chunk tables on the device (common.h RangeSet); from the
+    third search on only the queries go up.  Same answers on every sight, for one query (scan kernel, chunk table) and for batches
+    (MFMA kernel, tile table), with and without the image; at most four lists are kept, the least recently used one goes; a list
+    that reaches past a truncated corpus is refused even though it is kept."""
+    import semtools_amd as smt
+
+    n = 60_000
+    emb = synth.unit_rows(n, seed=51)
+    qs = synth.unit_query(52, nq=40)
+    docs = _docs(n, 53, 20, 400)
+    lists = [docs[i::5 + i] for i in range(6)]                    # six different subsets
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    try:
+        assert c.range_sets() == (0, 0, 0)
+        first = _check(c, emb, qs, lists[0], 10, which=[0, 7, 39])
+        assert c.range_sets() == (0, 0, 0)                        # seen once: nothing kept
+        second = _check(c, emb, qs, lists[0], 10, which=[0, 7, 39])
+        assert c.range_sets() == (1, 0, 1)                        # built on the second sight
+        third, ran = _kernels_of(c.ctx, lambda: c.search(qs, top_k=10, ranges=lists[0]))
+        assert c.range_sets() == (1, 1, 1) and ran["gemm"] > 0 and ran["scan"] == 0
+        for a, b, d in zip(first, second, third):
+            assert a[0].tolist() == b[0].tolist() == d[0].tolist() and np.array_equal(a[1], b[1]) and np.array_equal(a[1], d[1])
+        # one query over the kept list: the scan kernel and the set's CHUNK table (built on this first use), workspace mode too
+        for _ in range(2):
+            _check(c, emb, qs[:1], lists[0], 7, expect_mfma=False)
+        ws = c.search(qs[:3], top_k=5, max_distance=0.9, mode=1, ranges=lists[0])
+        assert c.range_sets()[1] >= 4
+        c.prepack()                                               # the same kept tile table under the operand image
+        img = _check(c, emb, qs, lists[0], 10, which=[0, 7, 39])
+        for a, b in zip(first, img):
+            assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+        ws_img = c.search(qs[:3], top_k=5, max_distance=0.9, mode=1, ranges=lists[0])
+        for a, b in zip(ws, ws_img):
+            assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+        # five more lists, each searched three times: four sets stay, list 0 (least recently used) has gone and comes back
+        for lst in lists[1:]:
+            for _ in range(3):
+                _check(c, emb, qs[:9], lst, 6, which=[0, 8])
+        kept, hits, builds = c.range_sets()
+        assert kept == 4 and builds == 6
+        _check(c, emb, qs[:9], lists[0], 6, which=[0, 8])
+        _check(c, emb, qs[:9], lists[0], 6, which=[0, 8])
+        assert c.range_sets()[2] == builds + 1 and c.range_sets()[0] == 4
+        # a subset that grows by one document is a different list
+        grown = sorted(lists[0] + [d for d in docs if d not in lists[0]][:1])
+        _check(c, emb, qs[:9], grown, 6, which=[0, 8])
+        # truncation below a kept list's last range: refused
+        last_end = max(e for _, e in lists[0])
+        c.truncate(last_end - 1)
+        with pytest.raises(RuntimeError):
+            c.search(qs[:9], top_k=6, ranges=lists[0])
+    finally:
+        c.close()
