@@ -454,7 +454,12 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *   gemm_image (1/0)     batched searches read the image when the corpus has one
  *   image_scan_min_rows  shards of at least this many rows (1 500 000; 0 = never) that HAVE their image answer ONE query
  *                        from it as well (2..7 queries from a third of that), and build it at their fourth small search
- *   gemm_buffered, gemm_split_last, embed_batched (1/0)   A/B switches of round-3 kernel changes
+ *   gemm_buffered (1/0)  A/B switch of the LDS nomination buffer
+ *   gemm_split_last (0/1/2)  levels run in two parts with a select pass in between: 0 none, 1 a ratio-16 last level, 2 (default)
+ *                        also the first level after the bootstrap
+ *   embed_batched (bit mask, default 3)  K1: bit 0 batched id loads, bit 1 the id-prefetch kernel, bit 2 a test hook (64-token
+ *                        spans); 0 = the round-2 kernel.  NOTE: 1 no longer means "everything on" -- pass 3
+ *   gemm_resident        accepted and ignored (its kernel left in round 2)
  *   gemm_bf16x3 (1/0)    K3 nominates with bf16 x 3 split products on the bf16 MFMA pipe (default) or with f32 MFMAs;
  *                        answers are identical either way (exact re-scoring + the exactness certificate)
  *   prof_select (0/1), prof_every (N: HIP events on one launch in N)       profiling cost control

@@ -41,7 +41,11 @@ struct Shards {
     #[serde(default)]
     pieces: Vec<(u64, u32)>,
 }
+/// `deny_unknown_fields`: every field here has a default, so without it ANY JSON object -- a round-2 table, whose keys are paths --
+/// would parse as an empty `Current` table before the older forms are tried: the store would re-embed every document
+/// and leave the old rows behind as garbage.
 #[derive(Default, serde::Serialize, serde::Deserialize)]
+#[serde(deny_unknown_fields)]
 struct RowsFile {
     #[serde(default)]
     extents: Vec<ExtentEntry>,
@@ -213,5 +217,42 @@ impl HipLineStore {
 impl Drop for HipLineStore {
     fn drop(&mut self) {
         unsafe { smt_sharded_corpus_destroy(self.corpus) };
+    }
+}
+
+#[cfg(test)]
+mod rows_file_formats {
+    use super::read_rows_file;
+
+    #[test]
+    fn current_form() {
+        let t = r#"{"extents":[{"path":"a.txt","first_row":0,"n_rows":3},{"path":"b.txt","first_row":3,"n_rows":2}],"generation":7,
+                    "shards":{"n_ranks":2,"pieces":[[3,0],[2,1]]}}"#;
+        let (ext, gen, ranks, pieces) = read_rows_file(t);
+        assert_eq!(ext.len(), 2);
+        assert_eq!(ext["b.txt"].first_row, 3);
+        assert_eq!((gen, ranks, pieces.len()), (7, 2, 2));
+    }
+
+    #[test]
+    fn round3_form() {
+        let t = r#"{"extents":{"a.txt":{"first_row":0,"n_lines":3}},"n_ranks":1,"pieces":[[3,0]]}"#;
+        let (ext, gen, ranks, pieces) = read_rows_file(t);
+        assert_eq!(ext["a.txt"].n_lines, 3);
+        assert_eq!((gen, ranks, pieces.len()), (0, 1, 1));
+    }
+
+    #[test]
+    fn round2_form_is_not_mistaken_for_an_empty_current_table() {
+        let t = r#"{"a.txt":{"first_row":0,"n_lines":3},"dir/b.txt":{"first_row":3,"n_lines":9}}"#;
+        let (ext, gen, ranks, pieces) = read_rows_file(t);
+        assert_eq!(ext.len(), 2);
+        assert_eq!(ext["dir/b.txt"].first_row, 3);
+        assert_eq!((gen, ranks, pieces.len()), (0, 0, 0));
+    }
+
+    #[test]
+    fn garbage_is_an_empty_table() {
+        assert!(read_rows_file("not json").0.is_empty());
     }
 }

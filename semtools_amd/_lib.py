@@ -182,7 +182,10 @@ def lib():
     L.smt_group_ctx.restype = vp
     L.smt_group_synchronize.argtypes = [vp]
     L.smt_group_barrier.argtypes = [vp]
-    L.smt_debug_range_sets.argtypes = [vp, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+    try:   # (a test hook: an older build of the library under tools/ab_* A/B runs does not have it)
+        L.smt_debug_range_sets.argtypes = [vp, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+    except AttributeError:
+        pass
     L.smt_group_set_transport.argtypes = [vp, i32]
     L.smt_group_transport.argtypes = [vp]
     L.smt_sharded_corpus_from_host.argtypes = [vp, vp, u64, u32, P(vp)]

@@ -323,7 +323,10 @@ static int ctx_create_impl(int device, void *stream, bool use_given, smt_ctx **o
     return SMT_OK;
 }
 
-int smt_ctx_create(int device, smt_ctx **out) { return ctx_create_impl(device, nullptr, false, out); }
+int smt_ctx_create(int device, smt_ctx **out)
+try {
+    return ctx_create_impl(device, nullptr, false, out);
+} catch (...) { return smt::api_catch(); }
 
 int smt_ctx_create_on_stream(int device, void *stream, smt_ctx **out)
 try {
@@ -447,8 +450,13 @@ try {
     else if (k == "gemm_dma_nt") ctx->tune.gemm_dma_nt = (int)value;
     else if (k == "gemm_qsplit") ctx->tune.gemm_qsplit = (int)value;
     else if (k == "gemm_buffered") ctx->tune.gemm_buffered = (int)value;
-    else if (k == "gemm_split_last") ctx->tune.gemm_split_last = (int)value;
-    else if (k == "embed_batched") ctx->tune.embed_batched = (int)value;
+    else if (k == "gemm_split_last") {
+        SMT_REQUIRE(value >= 0 && value <= 2, "gemm_split_last: 0 no level in two parts, 1 a ratio-16 last level, 2 (default) also the first level after the bootstrap");
+        ctx->tune.gemm_split_last = (int)value;
+    } else if (k == "embed_batched") {
+        SMT_REQUIRE(value >= 0 && value <= 7, "embed_batched is a bit mask: 1 batched id loads, 2 id prefetch kernel, 4 (tests) 64-token spans");
+        ctx->tune.embed_batched = (int)value;
+    } else if (k == "gemm_resident") { /* the kernel it selected left in round 2: accepted and ignored, as before round 4 */ }
     else if (k == "gemm_image") ctx->tune.gemm_image = (int)value;
     else if (k == "corpus_image") ctx->tune.corpus_image = (int)value;
     else if (k == "image_scan_min_rows") ctx->tune.image_scan_min_rows = value < 0 ? 0 : value;

@@ -55,57 +55,69 @@ struct PinnedPair {
 
 // `bytes` from file offset `off` into `dst`, a large chunk on four threads: one thread copies out of the page cache at 10-12 GB/s,
 // a fifth of what the link to the GPU takes (a warm 1 M-line workspace spent 80 ms of its 300 loading 1 GB: profiles/r04_cli_end_to_end.json)
-static bool pread_chunk(int fd, void *dst, size_t bytes, uint64_t off)
+// Returns 0, the errno of the failing pread, or -1 when the file ends early.  (The slices run on helper threads and errno is
+// thread-local: each slice RETURNS its error and the first one is handed back -- and left in the caller's errno -- ADVICE r4.)
+static int pread_chunk(int fd, void *dst, size_t bytes, uint64_t off)
 {
-    auto slice = [&](size_t b, size_t e) -> bool {
+    auto slice = [&](size_t b, size_t e) -> int {
         while (b < e) {
             const ssize_t got = pread(fd, static_cast<char *>(dst) + b, e - b, (off_t)(off + b));
             if (got < 0 && errno == EINTR) continue;
-            if (got <= 0) return false;
+            if (got < 0) return errno ? errno : EIO;
+            if (got == 0) return -1;
             b += (size_t)got;
         }
-        return true;
+        return 0;
     };
     const size_t n_threads = bytes >= ((size_t)8 << 20) ? 4 : 1;
-    if (n_threads == 1) return slice(0, bytes);
-    bool ok[4] = {false, false, false, false};
-    std::thread th[3];
-    bool started[3] = {false, false, false};
-    for (size_t t = 1; t < n_threads; ++t) {
-        try { th[t - 1] = std::thread([&, t] { ok[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }); started[t - 1] = true; }
-        catch (...) { ok[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }   // (no thread to be had: read it here)
+    int err[4] = {0, 0, 0, 0};
+    if (n_threads == 1) err[0] = slice(0, bytes);
+    else {
+        std::thread th[3];
+        bool started[3] = {false, false, false};
+        for (size_t t = 1; t < n_threads; ++t) {
+            try { th[t - 1] = std::thread([&, t] { err[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }); started[t - 1] = true; }
+            catch (...) { err[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }   // (no thread to be had: read it here)
+        }
+        err[0] = slice(0, bytes / n_threads);
+        for (size_t t = 0; t + 1 < n_threads; ++t) if (started[t]) th[t].join();
     }
-    ok[0] = slice(0, bytes / n_threads);
-    for (size_t t = 0; t + 1 < n_threads; ++t) if (started[t]) th[t].join();
-    return ok[0] && ok[1] && ok[2] && ok[3];
+    for (int e : err)
+        if (e) { errno = e > 0 ? e : 0; return e; }
+    return 0;
 }
 
 // the same for writing: `bytes` from `src` to file offset `off`.  (Measured on the bench box: no gain there -- persisting the 1 GB of
 // rows of a 1 M-line workspace takes ~230 ms with one writer or four, i.e. the fsync at the device's ~4.4 GB/s; kept for hosts where
 // the page-cache copy is the slower side.)
-static bool pwrite_chunk(int fd, const void *src, size_t bytes, uint64_t off)
+static int pwrite_chunk(int fd, const void *src, size_t bytes, uint64_t off)   // 0 or the errno of the failing pwrite (also left in errno)
 {
-    auto slice = [&](size_t b, size_t e) -> bool {
+    auto slice = [&](size_t b, size_t e) -> int {
         while (b < e) {
             const ssize_t put = pwrite(fd, static_cast<const char *>(src) + b, e - b, (off_t)(off + b));
             if (put < 0 && errno == EINTR) continue;
-            if (put <= 0) return false;
+            if (put < 0) return errno ? errno : EIO;
+            if (put == 0) return ENOSPC;
             b += (size_t)put;
         }
-        return true;
+        return 0;
     };
     const size_t n_threads = bytes >= ((size_t)8 << 20) ? 4 : 1;
-    if (n_threads == 1) return slice(0, bytes);
-    bool ok[4] = {false, false, false, false};
-    std::thread th[3];
-    bool started[3] = {false, false, false};
-    for (size_t t = 1; t < n_threads; ++t) {
-        try { th[t - 1] = std::thread([&, t] { ok[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }); started[t - 1] = true; }
-        catch (...) { ok[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }
+    int err[4] = {0, 0, 0, 0};
+    if (n_threads == 1) err[0] = slice(0, bytes);
+    else {
+        std::thread th[3];
+        bool started[3] = {false, false, false};
+        for (size_t t = 1; t < n_threads; ++t) {
+            try { th[t - 1] = std::thread([&, t] { err[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }); started[t - 1] = true; }
+            catch (...) { err[t] = slice(bytes * t / n_threads, bytes * (t + 1) / n_threads); }
+        }
+        err[0] = slice(0, bytes / n_threads);
+        for (size_t t = 0; t + 1 < n_threads; ++t) if (started[t]) th[t].join();
     }
-    ok[0] = slice(0, bytes / n_threads);
-    for (size_t t = 0; t + 1 < n_threads; ++t) if (started[t]) th[t].join();
-    return ok[0] && ok[1] && ok[2] && ok[3];
+    for (int e : err)
+        if (e) { errno = e; return e; }
+    return 0;
 }
 
 static size_t io_chunk_rows(uint64_t n_rows)
@@ -153,7 +165,11 @@ int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint6
     for (uint64_t r = 0; r < n_rows; r += chunk, j ^= 1) {
         const size_t n = (size_t)std::min<uint64_t>(chunk, n_rows - r);
         if ((rc = pp.wait(j))) { fclose(f); return rc; }
-        if (!pread_chunk(fileno(f), pp.buf[j], n * row_bytes, base_off + r * row_bytes)) { fclose(f); set_error("'%s' is truncated", path); return SMT_E_IO; }
+        if (const int io = pread_chunk(fileno(f), pp.buf[j], n * row_bytes, base_off + r * row_bytes)) {
+            fclose(f);
+            if (io < 0) set_error("'%s' is truncated", path); else set_error("reading '%s': %s", path, strerror(io));
+            return SMT_E_IO;
+        }
         hipError_t e = hipMemcpyAsync(c->d_rows + (size_t)(c->rows + r) * c->dim, pp.buf[j], n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
         if (e != hipSuccess) { fclose(f); set_error("corpus upload: %s", hipGetErrorString(e)); return SMT_E_HIP; }
@@ -218,16 +234,16 @@ int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_
     };
     if ((rc = issue(0, 0))) { fclose(f); return rc; }
     int j = 0;
-    bool ok = true;
-    for (size_t k = 0; k < chunks.size() && ok; ++k, j ^= 1) {
+    int io = 0;   // the errno of the first failing step
+    for (size_t k = 0; k < chunks.size() && !io; ++k, j ^= 1) {
         if (k + 1 < chunks.size() && (rc = issue(k + 1, j ^ 1))) { fclose(f); return rc; }
         if ((rc = pp.wait(j))) { fclose(f); return rc; }
         // (positional writes on the descriptor, a large chunk on four threads: nothing goes through the FILE's buffer)
-        ok = pwrite_chunk(fileno(f), pp.buf[j], (size_t)chunks[k].n * row_bytes, sizeof(CorpusFileHeader) + chunks[k].file_row * row_bytes);
+        io = pwrite_chunk(fileno(f), pp.buf[j], (size_t)chunks[k].n * row_bytes, sizeof(CorpusFileHeader) + chunks[k].file_row * row_bytes);
     }
-    ok = ok && fsync(fileno(f)) == 0;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) { set_error("short write to '%s': %s", path, strerror(errno)); return SMT_E_IO; }
+    if (!io && fsync(fileno(f)) != 0) io = errno ? errno : EIO;
+    if (fclose(f) != 0 && !io) io = errno ? errno : EIO;
+    if (io) { set_error("short write to '%s': %s", path, strerror(io)); return SMT_E_IO; }
     return SMT_OK;
 }
 
@@ -349,7 +365,10 @@ try {
     for (uint64_t r = 0; r < V; r += chunk, j ^= 1) {
         const size_t n = (size_t)std::min<uint64_t>(chunk, V - r);
         if ((rc = pp.wait(j))) return bail(rc);
-        if (!pread_chunk(fileno(f), pp.buf[j], n * row_bytes, byte_offset + r * row_bytes)) { set_error("'%s' is truncated", path); return bail(SMT_E_IO); }
+        if (const int io = pread_chunk(fileno(f), pp.buf[j], n * row_bytes, byte_offset + r * row_bytes)) {
+            if (io < 0) set_error("'%s' is truncated", path); else set_error("reading '%s': %s", path, strerror(io));
+            return bail(SMT_E_IO);
+        }
         e = hipMemcpyAsync(m->d_table + (size_t)r * D, pp.buf[j], n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(pp.ev[j], ctx->stream);
         if (e != hipSuccess) { set_error("table upload: %s", hipGetErrorString(e)); return bail(SMT_E_HIP); }

@@ -407,9 +407,11 @@ static bool run_on_threads(int n, const std::function<void(int)> &fn)
         if (go == 1) fn(i);
     };
     bool ok = true;
-    try {
+    try {   // (reserve first: a bad_alloc from the vector's growth, like a system_error from the thread, must find every started thread
+            //  still joinable HERE -- unwinding past them would end in std::terminate inside ~thread)
+        th.reserve((size_t)n);
         for (int i = 0; i < n; ++i) th.emplace_back(body, i);
-    } catch (const std::system_error &) { ok = false; }
+    } catch (...) { ok = false; }
     {
         std::lock_guard<std::mutex> lk(mu);
         go = ok ? 1 : -1;
@@ -465,8 +467,9 @@ static int group_start_workers(smt_group *g)
     g->workers->rcs.assign(g->n_local, SMT_OK);
     g->workers->errs.assign(g->n_local, std::string());
     try {
+        g->workers->threads.reserve((size_t)g->n_local);
         for (int i = 0; i < g->n_local; ++i) g->workers->threads.emplace_back(worker_main, g, i);
-    } catch (const std::system_error &) {
+    } catch (...) {
         group_stop_workers(g);   // (the ones that exist leave; the group then issues from threads made per call, or from the caller's)
     }
     return SMT_OK;

@@ -130,3 +130,28 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.replace("the oracle", "").replace("oracle/", "ORACLE_DOC/").lower() or \
                     all("import" not in ln and "#include" not in ln and "dlopen" not in ln and "CDLL" not in ln
                         for ln in text.splitlines() if "oracle" in ln.lower()), f
+
+
+def test_every_int_entry_point_is_a_function_try_block():
+    """common.h / INTEGRATION.md: no C++ exception unwinds into a C, Rust or ctypes caller -- every int-returning extern "C" entry
+    point is a function-try-block ending in api_catch() (ADVICE r4 found smt_ctx_create without one)."""
+    import glob
+    import re
+
+    root = os.path.join(ROOT, "semtools_amd", "csrc")
+    missing, seen = [], 0
+    # (include/semtools_hip.h's entry points; the host layer of semtools_host.h catches inside its bodies -- host_capi.cpp `fail(e)`)
+    for path in sorted(glob.glob(os.path.join(root, "*.cpp")) + glob.glob(os.path.join(root, "*.hip"))):
+        text = open(path).read()
+        for m in re.finditer(r"^int (smt_\w+)\(", text, re.M):
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            rest = text[i:i + 40].lstrip()
+            if rest.startswith(";"):
+                continue                      # a declaration
+            seen += 1
+            if not rest.startswith("try"):
+                missing.append(f"{os.path.basename(path)}: {m.group(1)}")
+    assert seen > 60 and not missing, (seen, missing)
