@@ -347,6 +347,19 @@ int smt_sharded_corpus_load_layout(smt_group *group, const char *path, const uin
 uint64_t smt_sharded_corpus_layout(const smt_sharded_corpus *corpus, uint64_t *piece_rows, uint32_t *piece_rank, uint64_t cap);
 int smt_sharded_corpus_save(smt_sharded_corpus *corpus, const char *path);
 int smt_sharded_corpus_append_to_file(smt_sharded_corpus *corpus, const char *path, uint64_t rows_on_disk);
+/* The same in two steps, so that persisting overlaps embedding (src/workspace/store.rs:402-434 flushes every 1000-point chunk while
+ * it goes; a 1 M-line workspace is 1 GB of rows whose fsync takes as long as tokenising + pooling them):
+ *   SMT_APPEND_WRITE_AHEAD  rows [rows_written, rows) go to their places in the file and the kernel is asked to start writing them
+ *                           out (sync_file_range), but nothing is durable and the header still names rows_on_disk rows -- a crash
+ *                           leaves the old, consistent prefix.  Call it after every embedded batch; one-shard corpora only
+ *                           (SMT_E_UNSUPPORTED otherwise: keep the rows for the commit).
+ *   SMT_APPEND_CREATE       rows_on_disk == 0 and no file yet: start one (empty header).
+ *   flags 0                 the commit: rows [rows_written, rows) written, fsync, header last.  rows_on_disk <= rows_written: what
+ *                           earlier WRITE_AHEAD calls put there.  smt_sharded_corpus_append_to_file(c, p, r) == _ex(c, p, r, r, 0). */
+#define SMT_APPEND_WRITE_AHEAD 1
+#define SMT_APPEND_CREATE 2
+int smt_sharded_corpus_append_to_file_ex(smt_sharded_corpus *corpus, const char *path, uint64_t rows_on_disk, uint64_t rows_written,
+                                         int flags);
 void smt_sharded_corpus_destroy(smt_sharded_corpus *corpus);
 uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *corpus);
 int smt_sharded_corpus_rank_rows(const smt_sharded_corpus *corpus, uint64_t *rows_per_rank /* [n_ranks] */);

@@ -44,6 +44,8 @@ pub const SMT_UNIQUE_ID_BYTES: usize = 128;
 pub const SMT_TRANSPORT_RCCL: c_int = 0;
 pub const SMT_TRANSPORT_COPY: c_int = 1;
 pub const SMT_TRANSPORT_PEER: c_int = 2;
+pub const SMT_APPEND_WRITE_AHEAD: c_int = 1;
+pub const SMT_APPEND_CREATE: c_int = 2;
 
 extern "C" {
     pub fn smt_ctx_create(device: c_int, out: *mut *mut SmtCtx) -> c_int;
@@ -284,6 +286,13 @@ extern "C" {
         corpus: *mut SmtShardedCorpus,
         path: *const c_char,
         rows_on_disk: u64,
+    ) -> c_int;
+    pub fn smt_sharded_corpus_append_to_file_ex(
+        corpus: *mut SmtShardedCorpus,
+        path: *const c_char,
+        rows_on_disk: u64,
+        rows_written: u64,
+        flags: c_int,
     ) -> c_int;
     pub fn smt_sharded_corpus_destroy(corpus: *mut SmtShardedCorpus);
     pub fn smt_sharded_corpus_rows(corpus: *const SmtShardedCorpus) -> u64;

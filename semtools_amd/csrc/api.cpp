@@ -175,6 +175,7 @@ static uint64_t fnv1a(const uint8_t *b, uint64_t n)
 int corpus_reserve(smt_corpus *c, uint64_t rows_needed)
 {
     if (rows_needed <= c->capacity) return SMT_OK;
+    corpus_writer_drain(c);   // the rows are about to move: a write-ahead job reads them where they are
     if (!c->owned) { set_error("corpus adopted from device memory cannot grow"); return SMT_E_NOMEM; }
     uint64_t cap = std::max<uint64_t>(c->capacity * 2, rows_needed);
     cap = std::max<uint64_t>(cap, 1024);
@@ -572,6 +573,7 @@ void smt_corpus_destroy(smt_corpus *corpus)
     (void)hipSetDevice(corpus->ctx->device);
     (void)hipStreamSynchronize(corpus->ctx->stream);
     (void)drain_async(corpus->ctx);  // an async select may still be rescoring rows of this corpus
+    corpus_writer_destroy(corpus);   // (waits for queued write-ahead jobs)
     if (corpus->owned && corpus->d_rows) (void)hipFree(corpus->d_rows);
     corpus_image_drop(corpus);
     corpus_range_sets_drop(corpus);
@@ -604,6 +606,7 @@ try {
     int rc = bind_device(c->ctx);
     if (rc) return rc;
     if (n_rows == 0) return SMT_OK;
+    corpus_writer_drain(c);   // (a write-ahead job may be reading these rows)
     SMT_HIP_CHECK(hipMemcpyAsync(c->d_rows + (size_t)first_row * c->dim, rows, (size_t)n_rows * c->dim * sizeof(float),
                                  hipMemcpyHostToDevice, c->ctx->stream));
     SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
@@ -650,6 +653,7 @@ int smt_corpus_truncate(smt_corpus *c, uint64_t n_rows)
 try {
     SMT_REQUIRE(c != nullptr, "corpus");
     SMT_REQUIRE(n_rows <= c->rows, "cannot truncate to more rows than stored");
+    corpus_writer_drain(c);   // (later appends reuse the space: a write-ahead job must not still be reading the old rows there)
     c->rows = n_rows;
     c->image_rows = std::min<uint64_t>(c->image_rows, n_rows / 32 * 32);   // rows appended later land in tiles the image packs again
     return SMT_OK;

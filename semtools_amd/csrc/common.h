@@ -133,6 +133,7 @@ struct RangeSet {
     bool have_tile_table = false, have_chunk_table = false;
     uint64_t last_use = 0;
 };
+struct FileWriter;
 constexpr int RANGE_SETS_MAX = 4;
 constexpr size_t RANGE_SET_TABLE_BYTES_MAX = (size_t)96 << 20;   // tile + chunk table of one set
 }  // namespace smt
@@ -154,6 +155,7 @@ struct smt_corpus {
     uint64_t image_rows = 0;
     uint32_t small_searches = 0; // searches of < 8 queries seen while the shard was large enough to scan its image (search.cpp topk_dispatch)
     int image_mode = 0;          // 0: by policy (tuning key corpus_image; owned corpora only), 1: requested (smt_corpus_prepack), -1: refused
+    struct smt::FileWriter *writer = nullptr;  // corpus_io.cpp: the background writer of SMT_APPEND_WRITE_AHEAD
     std::vector<smt::RangeSet *> range_sets;   // search.cpp: ranges_on_device
     uint64_t range_clock = 0;
     uint64_t range_seen[16][2] = {};           // hashes of lists seen once (a set is built on the second sight)
@@ -342,7 +344,11 @@ int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint6
 int corpus_file_begin(const char *path, uint32_t dim, uint64_t total_rows);
 int corpus_save_slice(smt_corpus *c, const char *path, uint64_t file_first_row);
 struct FileRun { uint64_t local_first, n_rows, file_first_row; };
-int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_t n_runs);
+int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_t n_runs, bool durable = true);
+int corpus_append_to_file_ex(smt_corpus *c, const char *path, uint64_t rows_on_disk, uint64_t rows_written, int flags);
+// the background writer of write-ahead appends: wait for it before the rows it reads move, change or go (and before a commit)
+int corpus_writer_drain(smt_corpus *c, std::string *failed = nullptr);
+void corpus_writer_destroy(smt_corpus *c);
 int corpus_file_extend(const char *path, uint32_t dim, uint64_t expect_rows, uint64_t new_rows);
 int corpus_file_commit(const char *path, uint64_t rows);
 int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *packed, uint32_t n_lists, uint32_t nq,

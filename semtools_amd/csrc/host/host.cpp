@@ -638,13 +638,13 @@ std::vector<std::vector<float>> StaticModel::encode_with_args(const std::vector<
 }
 
 uint64_t StaticModel::encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
-                                  size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink) const
+                                  size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink, const std::function<void()> *after_batch) const
 {
-    return encode_into(std::vector<std::string_view>(sentences.begin(), sentences.end()), max_length, batch_size, corpus, sink);
+    return encode_into(std::vector<std::string_view>(sentences.begin(), sentences.end()), max_length, batch_size, corpus, sink, after_batch);
 }
 
 uint64_t StaticModel::encode_into(const std::vector<std::string_view> &sentences, std::optional<size_t> max_length,
-                                  size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink) const
+                                  size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink, const std::function<void()> *after_batch) const
 {
     // Double-buffered pipeline: while the GPU gathers/pools batch i (H2D of the ids + K1),
     // the host threads already tokenise batch i+1.  Batches are appended in order, so rows == line order.
@@ -682,6 +682,11 @@ uint64_t StaticModel::encode_into(const std::vector<std::string_view> &sentences
         const auto t_embed = std::chrono::steady_clock::now();
         try { embed_csr(slots[cur].ids, slots[cur].offsets, e - b, nullptr, corpus); } catch (...) { embed_failed = std::current_exception(); }
         PhaseTimer::add("within_embed:upload_and_K1", ms_since(t_embed));
+        if (!embed_failed && after_batch && *after_batch) {   // (the tokenizer threads of the next batch are running meanwhile)
+            const auto t_after = std::chrono::steady_clock::now();
+            try { (*after_batch)(); } catch (...) { embed_failed = std::current_exception(); }
+            PhaseTimer::add("within_embed:after_batch", ms_since(t_after));
+        }
         if (next.joinable()) next.join();
         if (embed_failed) std::rethrow_exception(embed_failed);
         if (next_failed) std::rethrow_exception(next_failed);

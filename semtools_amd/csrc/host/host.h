@@ -109,11 +109,15 @@ public:
                                                      std::optional<size_t> max_length, size_t batch_size) const;
     // same, but the rows are appended to `corpus` (resident); returns the first new row
     // (sink, if given, receives the pooled token ids of every sentence in order)
+    // (after_batch, if given, runs on the calling thread each time a batch's rows are resident in `corpus` -- while the next
+    // batch is being tokenised: the workspace store writes the new rows ahead to its file there)
     uint64_t encode_into(const std::vector<std::string> &sentences, std::optional<size_t> max_length,
-                         size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr) const;
+                         size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr,
+                         const std::function<void()> *after_batch = nullptr) const;
     // (the sentences as views: the lines of a file are embedded where they lie in its content)
     uint64_t encode_into(const std::vector<std::string_view> &sentences, std::optional<size_t> max_length,
-                         size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr) const;
+                         size_t batch_size, smt_sharded_corpus *corpus, TokenCsr *sink = nullptr,
+                         const std::function<void()> *after_batch = nullptr) const;
     // pool step only: n_lines lines given as token CSR (already filtered / truncated) appended to `corpus`
     void embed_tokens_into(const uint32_t *ids, const uint64_t *offsets, uint64_t n_lines, smt_sharded_corpus *corpus) const;
     // identifies the tokenizer (vocab size, unk id, ids of a fixed probe text): cached tokens are only valid for it
@@ -350,6 +354,10 @@ private:
     uint64_t dead_rows_ = 0;                     // rows of deleted/replaced documents awaiting compaction
     mutable uint64_t rows_on_disk_ = 0;          // prefix of the corpus already in line_embeddings.f32
     mutable bool rows_on_disk_valid_ = false;
+    // rows [rows_on_disk_, rows_written_ahead_) sit in the file already (written while later batches were embedded, not durable,
+    // not named by its header): the next flush only writes what is missing, syncs and commits (store.rs:402-434 flushes as it goes)
+    mutable uint64_t rows_written_ahead_ = 0;
+    void write_rows_ahead() const;
     // approximate index (built / extended lazily by the first search that qualifies)
     bool ensure_index() const;
     mutable smt_sharded_ivfpq *index_ = nullptr;

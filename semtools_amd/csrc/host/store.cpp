@@ -390,7 +390,8 @@ void Store::upsert_documents_lines(const std::vector<std::pair<std::string, std:
     const bool cache = token_cache_enabled();
     search::TokenCsr tokens;
     const auto t_embed = std::chrono::steady_clock::now();
-    uint64_t row = model.encode_into(all, 2048, 16384, corpus_, cache ? &tokens : nullptr);
+    const std::function<void()> ahead = [this] { write_rows_ahead(); };
+    uint64_t row = model.encode_into(all, 2048, 16384, corpus_, cache ? &tokens : nullptr, &ahead);
     search::PhaseTimer::add("within_persist:encode_into", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_embed).count());
     const auto t_tok = std::chrono::steady_clock::now();
     const uint64_t fingerprint = cache ? model.tokenizer_fingerprint() : 0;
@@ -411,6 +412,33 @@ void Store::upsert_documents_lines(const std::vector<std::pair<std::string, std:
         line += n;
     }
     search::PhaseTimer::add("within_persist:token_log_append", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tok).count());
+}
+
+// The rows embedded so far, beyond what the file holds, go to their places in line_embeddings.f32 NOW -- queued to the corpus'
+// background writer (its own copy stream, page-cache writes and the device write-out off this thread) -- while the next batch is
+// tokenised and pooled.  Not durable and not named by the
+// header until flush_line_embeddings commits: a crash leaves the previous, consistent store.  Only in the append-only case (the file
+// is the prefix of the corpus, or there is no store yet) and on one GPU; anything else keeps the rows for the flush.
+void Store::write_rows_ahead() const
+{
+    static const bool off = [] { const char *e = getenv("SEMTOOLS_WRITE_AHEAD"); return e && e[0] == '0'; }();
+    if (off) return;
+    int n_ranks = 1;
+    (void)smt_group_info(group_, &n_ranks, nullptr, nullptr, nullptr, nullptr);
+    if (n_ranks != 1) return;
+    const std::string emb = dir_ + "/line_embeddings.f32";
+    const bool exists = path_exists(emb);
+    if (exists && !rows_on_disk_valid_) return;                       // rows already in the file changed: the flush rewrites it
+    if (!exists && (rows_on_disk_valid_ || rows_on_disk_ != 0)) return;
+    const uint64_t rows = smt_sharded_corpus_rows(corpus_);
+    const uint64_t written = std::max(rows_on_disk_, rows_written_ahead_);
+    if (rows < rows_on_disk_ || rows <= written) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = smt_sharded_corpus_append_to_file_ex(corpus_, emb.c_str(), rows_on_disk_, written, SMT_APPEND_WRITE_AHEAD | (exists ? 0 : SMT_APPEND_CREATE));
+    search::PhaseTimer::add("within_persist:rows_written_ahead", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (rc != SMT_OK) return;                                          // (the flush writes everything and reports what is wrong)
+    rows_written_ahead_ = rows;
+    if (!exists) rows_on_disk_valid_ = true;                           // an empty file now: the prefix (0 rows) of the corpus
 }
 
 void Store::upsert_document_lines(const std::string &path, const std::vector<std::string_view> &lines_for_embedding,
@@ -794,10 +822,13 @@ void Store::flush_line_embeddings() const
     const uint64_t rows = smt_sharded_corpus_rows(corpus_);
     const auto t_rows = std::chrono::steady_clock::now();
     if (rows_on_disk_valid_ && rows >= rows_on_disk_ && path_exists(emb)) {
-        if (rows > rows_on_disk_) check(smt_sharded_corpus_append_to_file(corpus_, emb.c_str(), rows_on_disk_), "flush_line_embeddings");
+        // (rows written ahead while the later batches were embedded are only synced here; the header goes last)
+        const uint64_t written = std::min(rows, std::max(rows_on_disk_, rows_written_ahead_));
+        if (rows > rows_on_disk_) check(smt_sharded_corpus_append_to_file_ex(corpus_, emb.c_str(), rows_on_disk_, written, 0), "flush_line_embeddings");
     } else {
         check(smt_sharded_corpus_save(corpus_, emb.c_str()), "flush_line_embeddings");  // first flush or after a compaction
     }
+    rows_written_ahead_ = 0;
     search::PhaseTimer::add("within_persist:rows_file", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count());
     rows_on_disk_ = rows;
     rows_on_disk_valid_ = true;

@@ -429,6 +429,17 @@ try {
     return group_agree(g, rc);
 } catch (...) { return smt::api_catch(); }
 
+int smt_sharded_corpus_append_to_file_ex(smt_sharded_corpus *sc, const char *path, uint64_t rows_on_disk, uint64_t rows_written, int flags)
+try {
+    SMT_REQUIRE(sc && path, "null argument");
+    smt_group *g = sc->group;
+    if (g->n_ranks == 1) return corpus_append_to_file_ex(sc->shard[0], path, rows_on_disk, rows_written, flags);
+    // several shards: their pieces interleave in the file; writing ahead is not offered (the caller keeps everything for the commit)
+    if (flags & SMT_APPEND_WRITE_AHEAD) { set_error("write-ahead appends need a one-shard corpus"); return SMT_E_UNSUPPORTED; }
+    SMT_REQUIRE(rows_written == rows_on_disk, "rows written ahead on a sharded corpus");
+    return smt_sharded_corpus_append_to_file(sc, path, rows_on_disk);
+} catch (...) { return smt::api_catch(); }
+
 uint64_t smt_sharded_corpus_rows(const smt_sharded_corpus *sc) { return sc ? sc->total() : 0; }
 
 int smt_sharded_corpus_shard(smt_sharded_corpus *sc, int local_index, smt_corpus **shard, uint64_t *row_base, uint64_t *rows)

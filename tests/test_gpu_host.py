@@ -1,6 +1,7 @@
 """GPU: the host layer end to end (config c1: `semtools search` of 1 query over 1k plaintext lines) --
 create_document_from_content / search_documents / search_files / search_with_workspace and the
 CLI replica -- compared BYTE FOR BYTE with the reference's output format filled with oracle numbers."""
+import ctypes
 import json
 import os
 import subprocess
@@ -742,3 +743,89 @@ def test_reference_search_unit_tests_through_the_abi(model, model_dir, tmp_path)
     empty = tmp_path / "empty.txt"
     empty.write_text("")
     assert search("w1", [str(empty)], n_lines=1, top_k=3) == []
+
+
+def test_rows_written_ahead_are_not_durable_until_the_commit(gpu_ctx, tmp_path):
+    """smt_sharded_corpus_append_to_file_ex: WRITE_AHEAD puts rows into the file without touching the header -- a reader (a crash
+    before the commit) sees the old, consistent prefix; the commit writes what is missing, syncs, and names all rows.  The file ends
+    byte-identical to a plain smt_corpus_save of the same rows."""
+    import ctypes as C
+
+    import semtools_amd as smt
+    from semtools_amd import _lib as L
+
+    emb = synth.unit_rows(5000, seed=61)
+    g = smt.Group.from_ctx(gpu_ctx)
+    sc = smt.ShardedCorpus(g, empty=True)
+    path = tmp_path / "rows.f32"
+    fn = L.lib().smt_sharded_corpus_append_to_file_ex
+    AHEAD, CREATE = 1, 2
+    sc.append(emb[:1200])
+    L.check(fn(sc._h, str(path).encode(), 0, 0, AHEAD | CREATE))            # first batch: the file is started (header: 0 rows)
+    assert smt.Corpus.load(gpu_ctx, path).rows == 0 and path.stat().st_size == 32 + 1200 * 1024
+    sc.append(emb[1200:3000])
+    L.check(fn(sc._h, str(path).encode(), 0, 1200, AHEAD))                  # second batch: rows 1200.. only
+    assert smt.Corpus.load(gpu_ctx, path).rows == 0
+    sc.append(emb[3000:3600])
+    L.check(fn(sc._h, str(path).encode(), 0, 3000, 0))                      # the commit writes 3000..3600, syncs, header last
+    c = smt.Corpus.load(gpu_ctx, path)
+    assert c.rows == 3600 and np.array_equal(c.read_rows(0, 3600), emb[:3600])
+    c.close()
+    sc.append(emb[3600:])
+    L.check(fn(sc._h, str(path).encode(), 3600, 3600, AHEAD))               # everything written ahead ...
+    assert smt.Corpus.load(gpu_ctx, path).rows == 3600
+    L.check(fn(sc._h, str(path).encode(), 3600, 5000, 0))                   # ... the commit only syncs and names the rows
+    plain = smt.Corpus(gpu_ctx)
+    plain.append(emb)
+    plain.save(tmp_path / "plain.f32")
+    assert path.read_bytes() == (tmp_path / "plain.f32").read_bytes()
+    with pytest.raises(RuntimeError):                                       # the header must name exactly rows_on_disk rows
+        L.check(fn(sc._h, str(path).encode(), 3600, 3600, AHEAD))
+    g3 = smt.Group.logical(0, 3)                                            # several shards: no write-ahead (pieces interleave)
+    sc3 = smt.ShardedCorpus(g3, rows=emb)
+    assert fn(sc3._h, str(tmp_path / "s3.f32").encode(), 0, 0, AHEAD | CREATE) == L.SMT_E_UNSUPPORTED
+    sc3.close(); g3.close(); plain.close(); sc.close(); g.close()
+
+
+def test_workspace_written_ahead_equals_the_workspace_written_at_the_end(gpu_ctx, model_dir, prose_files, tmp_path, monkeypatch, capfd):
+    """The cold path of a workspace search embeds in batches and writes each batch's rows to line_embeddings.f32 while the next one
+    is tokenised (Store::write_rows_ahead; src/workspace/store.rs:402-434 flushes as it goes).  With small batches -- many
+    write-ahead calls -- the store on disk and the answers are byte-identical to SEMTOOLS_WRITE_AHEAD=0, also when a second call
+    appends a new file to the existing store."""
+    from semtools_amd import host
+
+    files = []
+    lines = prose_files[1][1]
+    for i in range(6):
+        f = tmp_path / f"doc{i}.txt"
+        f.write_text("\n".join(lines[i * 40:(i + 1) * 40 + 100]) + "\n")
+        files.append(str(f))
+    monkeypatch.setenv("SEMTOOLS_EMBED_BATCH", "64")
+    results, stores = {}, {}
+    for mode in ("1", "0"):
+        home = tmp_path / f"home{mode}"
+        home.mkdir()
+        monkeypatch.setenv("HOME", str(home))
+        monkeypatch.setenv("SEMTOOLS_WRITE_AHEAD", mode)
+        m = host.StaticModel(gpu_ctx, model_dir=model_dir[0])
+        try:
+            host.workspace_use(None, "wa")
+            r1 = host.search_with_workspace(m, lines[17], files[:4], workspace_name="wa", n_lines=1, top_k=5)
+            r2 = host.search_with_workspace(m, lines[17], files, workspace_name="wa", n_lines=1, top_k=5)   # two more files: an append
+            from semtools_amd import _lib as L
+            L.lib().smt_host_timing_json.restype = ctypes.c_void_p
+            ptr = L.lib().smt_host_timing_json()
+            timing = json.loads(ctypes.string_at(ptr).decode()) if ptr else {}
+        finally:
+            m.close()
+        root = home / ".semtools" / "workspaces" / "wa"
+        results[mode] = (r1, r2)
+        stores[mode] = ((root / "line_embeddings.f32").read_bytes(), json.loads((root / "line_rows.json").read_text())["extents"])
+        assert not (root / "line_embeddings.f32.tmp").exists()
+        if mode == "1" and timing:
+            assert any("rows_written_ahead" in k for k in timing), timing
+    capfd.readouterr()
+    assert results["1"] == results["0"]
+    assert stores["1"][0] == stores["0"][0]
+    strip = lambda ext: [(os.path.basename(e["path"]), e["first_row"], e["n_rows"]) for e in ext]
+    assert strip(stores["1"][1]) == strip(stores["0"][1])
