@@ -167,6 +167,83 @@ def main(argv=None):
     return 0
 
 
+class ClockSampler:
+    """Shader / memory clock and socket power of one GPU, sampled WHILE a leg runs (the same binary measures
+    5-10 % apart on different leases and the record had no clock beside it).  Reads the amdgpu sysfs files every 20 ms on a thread
+    (pp_dpm_sclk / pp_dpm_mclk: the line marked '*'; hwmon power1_average / power1_input in microwatts); falls back to one rocm-smi
+    call after the leg when sysfs is not there.  with sampler.leg("c3"): ... ; sampler.report -> {leg: {sclk_mhz_median, ...}}."""
+
+    def __init__(self, index=0):
+        import glob
+        self.report = {}
+        self.dev = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            self.dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+        hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*"))) if self.dev else []
+        self.power_file = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+
+    @staticmethod
+    def _current(path):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    return float("".join(ch for ch in line.split(":")[1] if ch.isdigit() or ch == "."))
+        except Exception:
+            pass
+        return None
+
+    def _sample(self):
+        s = {"sclk": self._current(os.path.join(self.dev, "pp_dpm_sclk")), "mclk": self._current(os.path.join(self.dev, "pp_dpm_mclk"))}
+        try:
+            s["w"] = float(open(self.power_file).read()) / 1e6 if self.power_file else None
+        except Exception:
+            s["w"] = None
+        return s
+
+    def leg(self, name):
+        import contextlib
+        import threading
+
+        @contextlib.contextmanager
+        def cm():
+            samples, stop = [], threading.Event()
+
+            def loop():
+                while not stop.is_set():
+                    samples.append(self._sample())
+                    stop.wait(0.02)
+
+            th = None
+            if self.dev:
+                th = threading.Thread(target=loop, daemon=True)
+                th.start()
+            try:
+                yield
+            finally:
+                stop.set()
+                if th:
+                    th.join(timeout=1.0)
+                self.report[name] = self._summarise(samples)
+        return cm()
+
+    def _summarise(self, samples):
+        if not samples:
+            try:   # no sysfs: one reading right after the leg (the clocks have begun to fall by then)
+                import subprocess
+                d = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout)
+                card = d[sorted(d)[0]]
+                return {"source": "rocm-smi after the leg", **{k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power"))}}
+            except Exception as exc:
+                return {"error": repr(exc)}
+        out = {"source": "amdgpu sysfs, 20 ms period, during the leg", "samples": len(samples)}
+        for key, label in (("sclk", "sclk_mhz"), ("mclk", "mclk_mhz"), ("w", "power_w")):
+            v = sorted(x[key] for x in samples if x.get(key) is not None)
+            if v:
+                out[label + "_median"], out[label + "_min"], out[label + "_max"] = v[len(v) // 2], v[0], v[-1]
+        return out
+
+
 def run(args, under_launcher):
 
     rank = int(os.environ.get("RANK", "0"))
@@ -330,12 +407,14 @@ def run(args, under_launcher):
     ctx.prof_reset()
     sync()
     uncertain_all()                               # reset the "exactness certificate failed" counters
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    issued = time.perf_counter() - t0             # host time to enqueue everything (diagnostic only)
-    sync()
-    elapsed = time.perf_counter() - t0
+    clocks = ClockSampler(local_rank)
+    with clocks.leg("c2"):
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        issued = time.perf_counter() - t0             # host time to enqueue everything (diagnostic only)
+        sync()
+        elapsed = time.perf_counter() - t0
     n_scan, scan_ms = ctx.prof_read("scan")
     got_rows = host_rows[(args.steps - 1) % ring].numpy().copy()   # the last timed step's answer (checked below)
     got_dist = host_dist[(args.steps - 1) % ring].numpy().copy()
@@ -460,7 +539,8 @@ def run(args, under_launcher):
     # allocated after such a cycle in the same process -- 6.2 ms alone, 6.55-6.9 ms after c4, same box, same binary)
     if rank == 0 and solo and not args.no_embed:
         try:
-            result["embed"] = bench_embed(smt, ctx, device, args.embed_lines)
+            with clocks.leg("embed"):
+                result["embed"] = bench_embed(smt, ctx, device, args.embed_lines)
         except Exception as exc:
             result["embed"] = {"error": repr(exc)}
 
@@ -487,10 +567,11 @@ def run(args, under_launcher):
         try:    # every rank takes part (row-sharded corpus, collective exchange); rank 0 reports
             if fake_hang:
                 time.sleep(1e9)
-            if sp:
-                c4 = bench_c4_one_process(smt, args, devs, group, local_ctxs, k, queries_on, host, world)
-            else:
-                c4 = bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host)
+            with clocks.leg("c4"):
+                if sp:
+                    c4 = bench_c4_one_process(smt, args, devs, group, local_ctxs, k, queries_on, host, world)
+                else:
+                    c4 = bench_c4(smt, args, device, rank, world, group, ctx, k, queries, host)
         except Exception as exc:
             c4 = {"error": repr(exc)}
         if use_dist and world > 1:
@@ -505,19 +586,22 @@ def run(args, under_launcher):
 
     if rank == 0 and solo and not args.no_secondary:
         try:
-            result["secondary"] = bench_c3(smt, ctx, device, args.c3_rows, args.c3_queries, k)
+            with clocks.leg("c3"):
+                result["secondary"] = bench_c3(smt, ctx, device, args.c3_rows, args.c3_queries, k)
         except Exception as exc:  # never let an auxiliary leg take the headline line down with it
             result["secondary"] = {"error": repr(exc)}
 
     if rank == 0 and solo and not args.no_group_issue:
         try:
-            result["group_issue"] = bench_group_issue(smt, device)
+            with clocks.leg("group_issue"):
+                result["group_issue"] = bench_group_issue(smt, device)
         except Exception as exc:
             result["group_issue"] = {"error": repr(exc)}
 
     if rank == 0 and solo and not args.no_workspace:
         try:
-            result["workspace"] = bench_workspace(smt, ctx, device, args.ws_rows, k)
+            with clocks.leg("workspace"):
+                result["workspace"] = bench_workspace(smt, ctx, device, args.ws_rows, k)
         except Exception as exc:
             result["workspace"] = {"error": repr(exc)}
 
@@ -529,7 +613,8 @@ def run(args, under_launcher):
 
     if rank == 0 and solo and not args.no_ivfpq:
         try:
-            result["ivfpq"] = bench_c5(smt, ctx, device, args.c5_rows, k)
+            with clocks.leg("ivfpq"):
+                result["ivfpq"] = bench_c5(smt, ctx, device, args.c5_rows, k)
         except Exception as exc:  # the approximate index is a "next" row: never let it break the headline line
             result["ivfpq"] = {"error": repr(exc)}
 
@@ -593,6 +678,8 @@ def run(args, under_launcher):
             }
         except Exception as exc:
             result["cpu_baseline"] = {"error": repr(exc)}
+    if rank == 0:
+        result["clocks"] = clocks.report
     # The JSON line must be the LAST thing on stdout.  RCCL prints a version banner through C stdio when a communicator is
     # created; redirected to a file, that text sits in libc's buffer until exit and would land BEHIND the line.  Flush C
     # stdio first, then print and flush the line.
@@ -765,6 +852,11 @@ def compact_line(d):
     put("group_issue_us_8_logical_shards", "group_issue", "host_issue_us_per_search")
     put("group_launches_only_us_8_shards", "group_issue", "one_thread_issues_every_shard_us")
     put("group_issue_copy_transport_us", "group_issue", "copy_transport_us")
+    # shader clock (MHz, median of the samples taken DURING the leg) and socket power beside the legs that vary from lease to lease
+    for leg in ("c2", "c3", "c4", "embed"):
+        put(f"clk_{leg}_mhz", "clocks", leg, "sclk_mhz_median", digits=3)
+    put("pwr_c3_w", "clocks", "c3", "power_w_median", digits=2)
+    put("pwr_c2_w", "clocks", "c2", "power_w_median", digits=2)
     # K1 (embed) and the host step in front of it
     put("embed_lines_per_s_zipf", "embed", "zipf_ids_500k_table", "lines_per_s")
     put("embed_frac_hbm_zipf_measured_traffic", "embed", "zipf_ids_500k_table", "roofline", "frac")
