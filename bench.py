@@ -4,10 +4,12 @@
 Metric (BASELINE.json): chunk-vectors scanned/sec (whole job).  Workload at N=1:
 config c2 = 1 query x 1M chunks, f32, brute-force cosine, top-k on one MI355X
 (HBM-bound single-vector path).  For N>1 the corpus is row-sharded, every rank
-scans ITS 1M-row shard (weak scaling: `value`), and the per-shard top-k lists are
-exchanged with one RCCL all-gather + merge -- the only collective on the path
- -- INSIDE the library (smt_sharded_search_topk_device,
-csrc/group.cpp): the ranks of the torchrun job join one smt_group (ncclCommInitRank).
+scans ITS 1M-row shard (weak scaling: `value`), and the per-shard top-k lists meet
+in the path's one exchange step INSIDE the library
+(smt_sharded_search_topk_device, csrc/group.cpp): in a one-process group the merge
+kernel of device 0 reads the ranks' lists in place over xGMI (peer transport: one event
+per rank, no gather); between processes (torchrun: ncclCommInitRank) it is one RCCL
+all-gather of the packed lists + the merge.
 Every N also runs BASELINE config c4 -- 1 query x 100M chunks row-sharded over the
 N GPUs, 100M / N rows per GPU -- reported in the "c4" object of the same line.
 

@@ -467,7 +467,7 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *   gemm_image (1/0)     batched searches read the image when the corpus has one
  *   image_scan_min_rows  shards of at least this many rows (1 500 000; 0 = never) that HAVE their image answer ONE query
  *                        from it as well (2..7 queries from a third of that), and build it at their fourth small search
- *   gemm_buffered (1/0)  A/B switch of the LDS nomination buffer (DESIGN.md 4.3c)
+ *   gemm_buffered (1/0)  A/B switch of the LDS nomination buffer (DESIGN.md 4.3)
  *   gemm_split_last (0/1/2)  levels run in two parts with a select pass in between: 0 none, 1 a ratio-16 last level, 2 (default)
  *                        also the first level after the bootstrap
  *   embed_batched (bit mask, default 3)  K1: bit 0 batched id loads, bit 1 the id-prefetch kernel, bit 2 a test hook (64-token

@@ -1,5 +1,5 @@
 // gemm_ldsrow.hip -- gemm_ldsrow_kernel: the K3 kernel of range-filtered batches (and of small batches when gemm_rowreg = 0).
-// DESIGN.md 4.3b.
+// DESIGN.md 4.3, profiles/HISTORY.md 4.3b.
 #include "gemm.h"
 
 namespace smt {

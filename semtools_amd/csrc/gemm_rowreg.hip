@@ -1,4 +1,4 @@
-// gemm_rowreg.hip -- gemm_rowreg_kernel<MODE, IMG>: the default K3 kernel of every unfiltered batch (DESIGN.md 4.3c), the nomination
+// gemm_rowreg.hip -- gemm_rowreg_kernel<MODE, IMG>: the default K3 kernel of every unfiltered batch (DESIGN.md 4.3), the nomination
 // buffer in LDS, and pack_image_kernel, which writes the corpus' fp16 operand image the IMG instantiations read.
 #include "gemm.h"
 

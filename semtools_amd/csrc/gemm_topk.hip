@@ -6,7 +6,7 @@
 // The kernels, and who runs when (launch_gemm_topk):
 //   gemm_rowreg_kernel<F16X2>   DEFAULT for every unfiltered batch.  Row tiles arrive with coalesced loads, are split
 //                               into 16-bit operands once and transposed through LDS; bf16 x 3 products below 128
-//                               queries, f16 x 2 from there (tuning key gemm_nominate).  DESIGN.md 4.3c.
+//                               queries, f16 x 2 from there (tuning key gemm_nominate).  DESIGN.md 4.3.
 //   gemm_ldsrow_kernel<..>      range-filtered batches (chunk table), <= 64 queries per pass; f32 or bf16 x 3 MFMAs.
 //   gemm_level_kernel<BF16>     the round-1 corpus-stationary kernel: f32 MFMAs (v_mfma_f32_32x32x2_f32, exact f32,
 //                               157 TF peak) when gemm_bf16x3 = 0, or bf16 x 3 when gemm_rowreg = 0.  The level scheme,
