@@ -179,9 +179,20 @@ class ClockSampler:
         import glob
         self.report = {}
         self.dev = None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if cards:
-            self.dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+        # the sysfs directory of THIS device: by PCI address (a lease sees one GPU of a node whose sysfs lists all eight -- the first
+        # closing run of round 5 read card0, an idle neighbour: 94 MHz, 243 W under every leg)
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if os.path.exists(f"/sys/bus/pci/devices/{pci}/pp_dpm_sclk"):
+                self.dev = f"/sys/bus/pci/devices/{pci}"
+                self.pci = pci
+        except Exception:
+            pass
+        if self.dev is None:
+            cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            if len(cards) == 1:          # (only trusted when there is nothing to confuse it with)
+                self.dev = os.path.dirname(cards[0])
         hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*"))) if self.dev else []
         self.power_file = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
 
@@ -238,7 +249,7 @@ class ClockSampler:
                 return {"source": "rocm-smi after the leg", **{k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power"))}}
             except Exception as exc:
                 return {"error": repr(exc)}
-        out = {"source": "amdgpu sysfs, 20 ms period, during the leg", "samples": len(samples)}
+        out = {"source": f"amdgpu sysfs ({getattr(self, 'pci', os.path.basename(self.dev))}), 20 ms period, during the leg", "samples": len(samples)}
         for key, label in (("sclk", "sclk_mhz"), ("mclk", "mclk_mhz"), ("w", "power_w")):
             v = sorted(x[key] for x in samples if x.get(key) is not None)
             if v:

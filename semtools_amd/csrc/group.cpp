@@ -317,6 +317,49 @@ static bool group_enable_peers(const int *devices, int n)
     return true;
 }
 
+// The peer transport's self-test (smt_group_create, several devices): every rank's KERNEL writes a small list into its exchange
+// buffer, device 0 merges the lists in place, the host checks the merge -- three rounds over the SAME addresses with different
+// values, so that a reader serving stale lines from its own cache, or a writer whose lines have not left its L2 when its event
+// fires, is caught here and not in an answer.  false = the group falls back to the ncclAllGather transport.
+__global__ void peer_test_fill_kernel(uint64_t *list, uint32_t k, uint32_t rank, uint32_t n_ranks, uint32_t round)
+{
+    const uint32_t i = threadIdx.x;
+    if (i >= k) return;
+    list[i] = (uint64_t)round * 100000u + rank * 100u + i;                                  // "row"
+    const double d = (double)(i * n_ranks + rank) + 0.001 * round;                            // interleaves the ranks' entries
+    reinterpret_cast<double *>(list + k)[i] = d;
+}
+
+static bool peer_self_test(smt_group *g)
+{
+    const uint32_t k = 4, n = (uint32_t)g->n_local;
+    const size_t out_off = 4096;
+    for (int i = 0; i < g->n_local; ++i)
+        if (group_bind(g, i) || ensure_dev(g, i, out_off + 1024)) return false;
+    std::vector<void *> bases(g->n_local);
+    for (int j = 0; j < g->n_local; ++j) bases[j] = g->buf[j].dev;
+    for (uint32_t round = 0; round < 3; ++round) {
+        for (int j = 0; j < g->n_local; ++j) {
+            if (group_bind(g, j)) return false;
+            hipLaunchKernelGGL(peer_test_fill_kernel, dim3(1), dim3(64), 0, g->ctx[j]->stream, reinterpret_cast<uint64_t *>(g->buf[j].dev), k,
+                               (uint32_t)j, n, round);
+            if (hipGetLastError() != hipSuccess || peer_publish(g, j, g->ctx[j]->stream)) return false;
+        }
+        uint64_t *merged = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->buf[0].dev) + out_off);
+        if (peer_merge(g, 0, g->ctx[0]->stream, bases.data(), 0, 1, k, k, merged, nullptr)) return false;
+        uint64_t got[8];
+        if (hipMemcpyAsync(got, merged, sizeof(got), hipMemcpyDeviceToHost, g->ctx[0]->stream) != hipSuccess) return false;
+        if (group_sync_all(g)) return false;
+        for (uint32_t e = 0; e < k; ++e) {   // the k smallest distances are entry 0 of ranks 0 .. k-1 (n >= k), else i * n + rank order
+            const uint32_t i = e / n, r = e % n;
+            double want_d = (double)(i * n + r) + 0.001 * round, got_d;
+            memcpy(&got_d, &got[k + e], 8);
+            if (got[e] != (uint64_t)round * 100000u + r * 100u + i || got_d != want_d) return false;
+        }
+    }
+    return true;
+}
+
 // $SEMTOOLS_GROUP_TRANSPORT over the default `def`, where the group can use it
 static int pick_transport(const smt_group *g, int def)
 {
@@ -825,6 +868,12 @@ try {
     // (one hive of xGMI-linked GPUs: always, in practice); otherwise they travel through ncclAllGather
     if ((rc = group_make_events(g))) { group_free(g); return rc; }
     g->peer_ok = n_dev <= SMT_MAX_MERGE_SOURCES && (n_dev == 1 || group_enable_peers(devices, n_dev));
+    if (g->peer_ok && n_dev > 1 && !peer_self_test(g)) {
+        // (never seen; a node whose devices map each other's memory but do not serve it coherently to a reader's kernel)
+        fprintf(stderr, "libsemtools_hip: peer reads between the devices of this group failed their self-test: using ncclAllGather\n");
+        (void)hipGetLastError();
+        g->peer_ok = false;
+    }
     g->transport = pick_transport(g, g->peer_ok ? SMT_TRANSPORT_PEER : SMT_TRANSPORT_RCCL);
     if ((rc = group_start_workers(g))) { group_free(g); return rc; }
     *out = g;
@@ -846,6 +895,7 @@ try {
     if (rc) { group_free(g); return rc; }
     if ((rc = group_make_events(g))) { group_free(g); return rc; }
     g->peer_ok = true;   // one device
+    if (n_shards > 1 && !peer_self_test(g)) { set_error("the peer-read self-test failed on logical ranks of one device"); group_free(g); return SMT_E_HIP; }
     g->transport = pick_transport(g, SMT_TRANSPORT_PEER);
     if ((rc = group_barrier(g))) { group_free(g); return rc; }
     if ((rc = group_start_workers(g))) { group_free(g); return rc; }

@@ -584,7 +584,11 @@ struct FinalParams {
 // KREG = keys a thread holds in registers: 8 covers n_lists * k' <= 8192 (every k <= 24 at 256 lists) in 70
 // VGPRs, so that the 16-wave block fits on a CU NEXT TO a scan block (async select); 36 covers the maximum
 // (512 lists x 72) and takes the whole register file.
-template <int KREG>
+// OVF: the batched path's instantiation, which also reads the candidate-buffer overflow flag (SelectArgs::overflow).  A template
+// parameter and not a null test: with the flag code in it final_select_kernel<8> allocated 106 VGPRs instead of 90 and no longer
+// fitted on a CU NEXT TO a scan block (4 waves/SIMD x 96 + the scan's 2 x 56 <= 512) -- the async select of the one-query pipeline
+// then waited for scan blocks to leave and a 1 M-row step went from 153 to 204 us (found by the round-5 closing bench run).
+template <int KREG, bool OVF = false>
 __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -875,14 +879,18 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
             decide = true;
             uncertain = p.ws_threshold ? ((1.0 - floor_out) > (double)p.ws_thr_score) : true;
         }
-        if (decide && !uncertain && p.overflow && p.overflow[qi]) uncertain = true;   // rows were dropped on the way (SelectArgs::overflow)
+        if constexpr (OVF) {
+            if (decide && !uncertain && p.overflow[qi]) uncertain = true;   // rows were dropped on the way (SelectArgs::overflow)
+        }
         if (decide && uncertain) {
             if (p.out_uncertain) p.out_uncertain[qi] = 1;
             if (p.status) atomicAdd(p.status, 1ull);
         }
-    } else if (threadIdx.x == 0 && p.overflow && p.overflow[qi]) {
-        if (p.out_uncertain) p.out_uncertain[qi] = 1;
-        if (p.status) atomicAdd(p.status, 1ull);
+    } else if constexpr (OVF) {
+        if (threadIdx.x == 0 && p.overflow[qi]) {
+            if (p.out_uncertain) p.out_uncertain[qi] = 1;
+            if (p.status) atomicAdd(p.status, 1ull);
+        }
     }
     if (threadIdx.x == 0 && p.out_counts)
         p.out_counts[qi] = s_cnt[1] < p.k_out ? s_cnt[1] : p.k_out;
@@ -1023,6 +1031,10 @@ int launch_select(smt_ctx *ctx, const SelectArgs &a)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<36>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<8, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(final_select_kernel<36, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_done |= ATTR_SELECT;
     }
     FinalParams f;
@@ -1057,8 +1069,13 @@ int launch_select(smt_ctx *ctx, const SelectArgs &a)
         return SMT_OK;
     }
     if (ctx->tune.prof_select) prof_begin(ctx, "select");
-    if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
-    else hipLaunchKernelGGL(final_select_kernel<36>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
+    if (a.overflow) {
+        if (small) hipLaunchKernelGGL((final_select_kernel<8, true>), dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
+        else hipLaunchKernelGGL((final_select_kernel<36, true>), dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
+    } else {
+        if (small) hipLaunchKernelGGL(final_select_kernel<8>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
+        else hipLaunchKernelGGL(final_select_kernel<36>, dim3(a.nq), dim3(SEL_THREADS), smem, ctx->stream, f);
+    }
     if (ctx->tune.prof_select) prof_end(ctx, "select");
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
