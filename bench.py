@@ -866,10 +866,11 @@ def compact_line(d):
     put("group_launches_only_us_8_shards", "group_issue", "one_thread_issues_every_shard_us")
     put("group_issue_copy_transport_us", "group_issue", "copy_transport_us")
     # shader clock (MHz, median of the samples taken DURING the leg) and socket power beside the legs that vary from lease to lease
+    # (a leg also generates and checks its data: the LOWEST clock and the HIGHEST power seen are the ones under its heaviest kernels)
     for leg in ("c2", "c3", "c4", "embed"):
         put(f"clk_{leg}_mhz", "clocks", leg, "sclk_mhz_median", digits=3)
-    put("pwr_c3_w", "clocks", "c3", "power_w_median", digits=2)
-    put("pwr_c2_w", "clocks", "c2", "power_w_median", digits=2)
+        put(f"clk_{leg}_min_mhz", "clocks", leg, "sclk_mhz_min", digits=3)
+        put(f"pwr_{leg}_max_w", "clocks", leg, "power_w_max", digits=3)
     # K1 (embed) and the host step in front of it
     put("embed_lines_per_s_zipf", "embed", "zipf_ids_500k_table", "lines_per_s")
     put("embed_frac_hbm_zipf_measured_traffic", "embed", "zipf_ids_500k_table", "roofline", "frac")
