@@ -398,6 +398,12 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                                   (auto_fp16 && (nqt >= 8 || (have_image && nqt >= 4)) && a.k_out + 24 <= 64));
     const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && (nqt >= 4 || have_image) && a.k_out + 16 <= 64));
     const bool use_image = have_image && (f16x1 || f16x2);
+    // (Round 5 built the obvious alternative for ONE to FOUR queries over the image -- a single pass with per-wave candidate lists,
+    // K2's structure over 512-byte rows on the fp16 MFMA pipe, no levels -- and measured it on one box against this plan, ms per
+    // device-resident call: 1 query x 10 M rows 0.802 against 0.836, but 4 x 10 M 1.08 against 0.84, 1 x 1 M 0.148 against 0.132,
+    // 2 x 2 M 0.310 against 0.228, one / three queries over a 5 M-row document subset 0.494 / 0.669 against 0.484 / 0.497
+    // (profiles/r05_ab_image_scan.txt).  A wave's own k'-th is a loose threshold -- ~100 inserts per wave and query, each a
+    // wave-wide affair out of MFMA accumulators -- where the levels' thresholds come from merged lists.  Not kept.)
     // guard band, see candidates_per_list (scan_kernels.hip): the wider the certificate band, the more rows are nominated
     // (the proof needs the k-th exact distance to lie 2 x the band below the worst nominated one): 8 / 16 / 24
     const uint32_t kp = std::min<uint32_t>(64, a.k_out + (uint32_t)std::max(ctx->tune.guard_band, f16x1 ? 24 : f16x2 ? 16 : 8));
