@@ -1304,15 +1304,22 @@ def bench_workspace(smt, ctx, device, rows, k, nq_batch=256, n_docs=10_000, max_
         call(queries, filtered)
         call(queries, filtered)
         ctx.synchronize()
+
+        def loop():
+            for _ in range(reps):
+                L.lib().smt_search(corpus._h, L.np_ptr(queries), queries.shape[0], k, float(max_d), smt.MODE_WORKSPACE,
+                                   C.cast(packed.arr, C.c_void_p) if filtered else None, packed.n if filtered else 0, 0,
+                                   L.np_ptr(o_rows), L.np_ptr(o_dist), L.np_ptr(o_cnt), k)
+
+        # whole calls timed WITHOUT the profiling events (each bracketed launch costs ~5 us of stream time: 40 us of a 0.5 ms one-query
+        # call over the image, where eight kernels are bracketed); the kernel time comes from a second, profiled loop
+        t0 = time.perf_counter()
+        loop()
+        dt = (time.perf_counter() - t0) / reps
         ctx.set_tuning("prof_every", 1)
         ctx.prof_enable(True)
         ctx.prof_reset()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            L.lib().smt_search(corpus._h, L.np_ptr(queries), queries.shape[0], k, float(max_d), smt.MODE_WORKSPACE,
-                               C.cast(packed.arr, C.c_void_p) if filtered else None, packed.n if filtered else 0, 0,
-                               L.np_ptr(o_rows), L.np_ptr(o_dist), L.np_ptr(o_cnt), k)
-        dt = (time.perf_counter() - t0) / reps
+        loop()
         n, ms = ctx.prof_read(prof)
         ctx.prof_enable(False)
         flagged.append(int(ctx.uncertain_count()))   # selects whose certificate failed (re-answered exhaustively by the host call)
@@ -1575,15 +1582,20 @@ def bench_c3(smt, ctx, device, rows, nq, k, reps=3):
     corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
 
     def timed():
+        # wall time of whole calls WITHOUT the profiling events (a HIP event pair costs ~5 us of stream time and a batch has eight
+        # bracketed launches: until round 5 they sat inside this timed loop), then the same batches again with them for the kernel time
         corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())  # warm-up
         torch.cuda.synchronize(device)
-        ctx.prof_enable(True)
-        ctx.prof_reset()
         t0 = time.perf_counter()
         for _ in range(reps):
             corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())
         torch.cuda.synchronize(device)
         w = (time.perf_counter() - t0) / reps
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        for _ in range(reps):
+            corpus.search_topk_device(q.data_ptr(), nq, k, 0, out_rows.data_ptr(), out_dist.data_ptr())
+        torch.cuda.synchronize(device)
         n, ms = ctx.prof_read("gemm")
         ctx.prof_enable(False)
         return w, n, ms / reps * 1e-3
@@ -1745,13 +1757,16 @@ def bench_c5(smt, ctx, device, rows, k, nq=1000, nlist=4096, nprobe=8, rerank=12
         ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
         torch.cuda.synchronize(device)
         reps = 5
-        ctx.prof_enable(True)
-        ctx.prof_reset()
         t0 = time.perf_counter()
         for _ in range(reps):
             ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
         torch.cuda.synchronize(device)
-        dt = (time.perf_counter() - t0) / reps
+        dt = (time.perf_counter() - t0) / reps          # (whole calls, no profiling events inside)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        for _ in range(reps):
+            ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
+        torch.cuda.synchronize(device)
         n_adc, ms_adc = ctx.prof_read("ivf_adc")
         n_pr, ms_pr = ctx.prof_read("ivf_probe")
         ctx.prof_enable(False)

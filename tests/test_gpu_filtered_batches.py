@@ -283,3 +283,31 @@ def test_a_range_list_seen_twice_is_kept_on_the_device_and_answers_the_same(gpu_
             c.search(qs[:9], top_k=6, ranges=lists[0])
     finally:
         c.close()
+
+
+def test_kept_range_sets_on_a_sharded_corpus(gpu_ctx):
+    """The same on a corpus row-sharded over three logical ranks: every shard keeps ITS localised range list (the global ranges cut
+    along the shard's pieces), the answers stay those of the unsharded corpus call after call."""
+    import semtools_amd as smt
+
+    n = 30_000
+    emb = synth.unit_rows(n, seed=81)
+    qs = synth.unit_query(82, nq=20)
+    docs = _docs(n, 83, 30, 500)
+    subset = docs[::2]
+    plain = smt.Corpus(gpu_ctx)
+    plain.append(emb)
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, rows=emb)
+    try:
+        want = plain.search(qs, top_k=9, ranges=subset)
+        want1 = plain.search(qs[:1], top_k=9, ranges=subset)
+        for _ in range(4):
+            got = sc.search(qs, top_k=9, ranges=subset)
+            got1 = sc.search(qs[:1], top_k=9, ranges=subset)
+            for a, b in zip(got + got1, want + want1):
+                assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1], b[1])
+        kept = [sc.shard(i, want_base=False)[0].range_sets() for i in range(3)]
+        assert all(k[0] >= 1 and k[1] >= 2 for k in kept), kept       # every shard built a set and answered from it
+    finally:
+        sc.close(); g.close(); plain.close()
