@@ -254,6 +254,11 @@ class ClockSampler:
             v = sorted(x[key] for x in samples if x.get(key) is not None)
             if v:
                 out[label + "_median"], out[label + "_min"], out[label + "_max"] = v[len(v) // 2], v[0], v[-1]
+        # a leg also generates and checks its data (idle and boost clocks in between): the clock AT THE HIGHEST POWER SAMPLE is the
+        # one under its heaviest kernels
+        loaded = [x for x in samples if x.get("w") is not None and x.get("sclk") is not None]
+        if loaded:
+            out["sclk_mhz_at_max_power"] = max(loaded, key=lambda x: x["w"])["sclk"]
         return out
 
 
@@ -866,10 +871,9 @@ def compact_line(d):
     put("group_launches_only_us_8_shards", "group_issue", "one_thread_issues_every_shard_us")
     put("group_issue_copy_transport_us", "group_issue", "copy_transport_us")
     # shader clock (MHz, median of the samples taken DURING the leg) and socket power beside the legs that vary from lease to lease
-    # (a leg also generates and checks its data: the LOWEST clock and the HIGHEST power seen are the ones under its heaviest kernels)
+    # (a leg also generates and checks its data: the clock at the HIGHEST power sample is the one under its heaviest kernels)
     for leg in ("c2", "c3", "c4", "embed"):
-        put(f"clk_{leg}_mhz", "clocks", leg, "sclk_mhz_median", digits=3)
-        put(f"clk_{leg}_min_mhz", "clocks", leg, "sclk_mhz_min", digits=3)
+        put(f"clk_{leg}_mhz", "clocks", leg, "sclk_mhz_at_max_power", digits=3)
         put(f"pwr_{leg}_max_w", "clocks", leg, "power_w_max", digits=3)
     # K1 (embed) and the host step in front of it
     put("embed_lines_per_s_zipf", "embed", "zipf_ids_500k_table", "lines_per_s")
