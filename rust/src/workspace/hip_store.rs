@@ -100,6 +100,9 @@ pub struct HipLineStore {
     extents: BTreeMap<String, Extent>,
     dir: PathBuf,
     rows_on_disk: u64,
+    /// rows [rows_on_disk, rows_written_ahead) already sit in the file (queued by `write_rows_ahead`; not durable, not named by the
+    /// header until `flush` commits)
+    rows_written_ahead: u64,
     generation: u64,
 }
 
@@ -134,7 +137,7 @@ impl HipLineStore {
         let rows_on_disk = if file.exists() { unsafe { smt_sharded_corpus_rows(corpus) } } else { 0 };
         // torn write: an extent that points past the rows on disk is dropped (its document is embedded again)
         extents.retain(|_, e: &mut Extent| e.first_row + e.n_lines <= rows_on_disk);
-        Ok(Self { group, corpus, extents, dir, rows_on_disk, generation })
+        Ok(Self { group, corpus, extents, dir, rows_on_disk, rows_written_ahead: 0, generation })
     }
 
     /// `upsert_line_embeddings` for one document: its lines are pooled on the GPUs straight into fresh corpus rows
@@ -144,19 +147,42 @@ impl HipLineStore {
         let mut first = 0u64;
         check(unsafe { smt_sharded_embed(model, ids.as_ptr(), offsets.as_ptr(), n, 2048, ptr::null_mut(), self.corpus, &mut first) })?;
         self.extents.insert(path.to_string(), Extent { first_row: first, n_lines: n });
+        self.write_rows_ahead();
         Ok(())
+    }
+
+    /// What `Store::write_rows_ahead` of the C++ host layer does (semtools_amd/csrc/host/store.cpp; the reference flushes every
+    /// 1000-point chunk while it goes, src/workspace/store.rs:402-434): the rows embedded so far are queued to the library's
+    /// background file writer while the next document is tokenised and pooled.  Nothing is durable and the header is untouched
+    /// until `flush`; any failure here (several shards: SMT_E_UNSUPPORTED) just leaves everything for the commit.
+    fn write_rows_ahead(&mut self) {
+        let path = self.dir.join("line_embeddings.f32");
+        let exists = path.exists();
+        if !exists && self.rows_on_disk != 0 { return; }
+        let Ok(file) = CString::new(path.to_string_lossy().as_bytes()) else { return };
+        let rows = unsafe { smt_sharded_corpus_rows(self.corpus) };
+        let written = self.rows_on_disk.max(self.rows_written_ahead);
+        if rows <= written { return; }
+        let flags = SMT_APPEND_WRITE_AHEAD | if exists { 0 } else { SMT_APPEND_CREATE };
+        if unsafe { smt_sharded_corpus_append_to_file_ex(self.corpus, file.as_ptr(), self.rows_on_disk, written, flags) } == SMT_OK {
+            self.rows_written_ahead = rows;
+        }
     }
 
     /// `flush_line_embeddings`: append the new rows to the file (O(new rows): every GPU writes its own pieces), then
     /// the row table with the layout.
     pub fn flush(&mut self) -> Result<()> {
         let file = CString::new(self.dir.join("line_embeddings.f32").to_string_lossy().as_bytes())?;
-        if self.rows_on_disk == 0 {
+        let rows = unsafe { smt_sharded_corpus_rows(self.corpus) };
+        if self.rows_on_disk == 0 && self.rows_written_ahead == 0 {
             check(unsafe { smt_sharded_corpus_save(self.corpus, file.as_ptr()) })?;
         } else {
-            check(unsafe { smt_sharded_corpus_append_to_file(self.corpus, file.as_ptr(), self.rows_on_disk) })?;
+            // the commit: what was not written ahead goes out now, fsync, header last
+            let written = rows.min(self.rows_on_disk.max(self.rows_written_ahead));
+            check(unsafe { smt_sharded_corpus_append_to_file_ex(self.corpus, file.as_ptr(), self.rows_on_disk, written, 0) })?;
         }
-        self.rows_on_disk = unsafe { smt_sharded_corpus_rows(self.corpus) };
+        self.rows_on_disk = rows;
+        self.rows_written_ahead = 0;
         let mut n_ranks = 0i32;
         check(unsafe { smt_group_info(self.group, &mut n_ranks, ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut()) })?;
         let n = unsafe { smt_sharded_corpus_layout(self.corpus, ptr::null_mut(), ptr::null_mut(), 0) } as usize;
