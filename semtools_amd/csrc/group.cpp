@@ -275,7 +275,12 @@ static int ring_next_slot(smt_group *g, int *slot_out)
 static int ring_done_event(smt_group *g, int slot, int i, hipEvent_t *ev)
 {
     smt_group::Ring &r = g->ring;
-    if (!r.done[slot][i]) SMT_HIP_CHECK(hipEventCreateWithFlags(&r.done[slot][i], hipEventDisableTiming));
+    if (!r.done[slot][i]) {
+        // (an event belongs to the device that is current when it is made, and is recorded on a stream of THAT device)
+        int rc = group_bind(g, i);
+        if (rc) return rc;
+        SMT_HIP_CHECK(hipEventCreateWithFlags(&r.done[slot][i], hipEventDisableTiming));
+    }
     r.merged[slot] |= (uint64_t)1 << i;
     *ev = r.done[slot][i];
     return SMT_OK;
