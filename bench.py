@@ -89,6 +89,7 @@ def parse_args(argv):
     ap.add_argument("--embed-lines", type=int, default=2_000_000)
     ap.add_argument("--no-ivfpq", action="store_true", help="skip the c5 (IVF-PQ, one GPU) measurement")
     ap.add_argument("--c5-rows", type=int, default=10_000_000)
+    ap.add_argument("--c5-full-rows", type=int, default=100_000_000, help="the c5 leg once more at BASELINE's named size on this one GPU (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-c4", action="store_true", help="skip BASELINE config c4 (100M rows over the N GPUs)")
     ap.add_argument("--c4-rows", type=int, default=100_000_000, help="TOTAL rows of config c4 (split over the GPUs)")
@@ -636,6 +637,13 @@ def run(args, under_launcher):
         except Exception as exc:  # the approximate index is a "next" row: never let it break the headline line
             result["ivfpq"] = {"error": repr(exc)}
 
+    if rank == 0 and solo and not args.no_ivfpq and args.c5_full_rows > 0:
+        try:
+            with clocks.leg("ivfpq_full"):
+                result["ivfpq_full"] = bench_c5_full(smt, ctx, device, args.c5_full_rows, k)
+        except Exception as exc:
+            result["ivfpq_full"] = {"error": repr(exc)}
+
     if rank == 0 and solo and not args.no_cpu_baseline:
         try:
             from oracle import oracle as orc
@@ -891,6 +899,12 @@ def compact_line(d):
     put("ivf_build_s", "ivfpq", "build_s")
     put("ivf_adc_bound", "ivfpq", "roofline", "bound")
     put("ivf_adc_frac", "ivfpq", "roofline", "frac")
+    # ... and at c5's named size (100 M rows on this one GPU)
+    put("ivf100m_build_s", "ivfpq_full", "build_s")
+    put("ivf100m_recall_at_k", "ivfpq_full", "nprobe_8", "recall_at_k_vs_exact")
+    put("ivf100m_queries_per_s", "ivfpq_full", "nprobe_8", "queries_per_s")
+    put("ivf100m_np1_recall_at_k", "ivfpq_full", "nprobe_1", "recall_at_k_vs_exact")
+    put("ivf100m_np1_queries_per_s", "ivfpq_full", "nprobe_1", "queries_per_s")
     put("ivf_pq_recall_at_k", "ivfpq", "global_pq_m32", "recall_at_k_vs_exact")
     put("ivf_pq_queries_per_s", "ivfpq", "global_pq_m32", "queries_per_s")
     put("ivf_pq_build_s", "ivfpq", "global_pq_m32", "build_s")
@@ -1208,17 +1222,23 @@ def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):
     truth = torch.topk(d, k, largest=False)[1].cpu().tolist()
     del allx, d
 
-    def run(op):
-        for j in range(8):
-            L.check(fn(sc._h, qp[j % 16], 1, k, op))
-        grp.synchronize()
-        t0 = time.perf_counter()
-        for j in range(n):
-            fn(sc._h, qp[j % 16], 1, k, op)
-        issued = time.perf_counter() - t0
-        grp.synchronize()
-        total = time.perf_counter() - t0
-        return issued / n * 1e6, total / n * 1e6, bool(outs[0].cpu().numpy()[0].tolist() == truth)
+    def run(op, rounds=5):
+        # the MEDIAN of `rounds` rounds of n searches: 4 ms of one host thread's time per round is at the mercy of whatever else the
+        # host does (the same box read 70 and 140 us in two bench runs minutes apart when this was a single round)
+        issued_us, total_us = [], []
+        for _ in range(rounds):
+            for j in range(8):
+                L.check(fn(sc._h, qp[j % 16], 1, k, op))
+            grp.synchronize()
+            t0 = time.perf_counter()
+            for j in range(n):
+                fn(sc._h, qp[j % 16], 1, k, op)
+            issued = time.perf_counter() - t0
+            grp.synchronize()
+            total = time.perf_counter() - t0
+            issued_us.append(issued / n * 1e6)
+            total_us.append(total / n * 1e6)
+        return sorted(issued_us)[rounds // 2], sorted(total_us)[rounds // 2], bool(outs[0].cpu().numpy()[0].tolist() == truth)
 
     default_transport = grp.transport
     peer_us, peer_e2e, ok_peer = run(op_one)
@@ -1815,6 +1835,57 @@ def bench_c5(smt, ctx, device, rows, k, nq=1000, nlist=4096, nprobe=8, rerank=12
                                   f"top-{k}; two codings: per-list PCA (shipped) and global PQ m=32 (as BASELINE c5 names it)"}}
     out.update(shipped)                       # the shipped coding's figures at the top level (as in rounds 1-2)
     out["global_pq_m32"] = pq
+    return out
+
+
+def bench_c5_full(smt, ctx, device, rows, k, nq=1000, nlist=4096, rerank=128):
+    """BASELINE config c5 at its NAMED size on one GPU: 100 M chunks (102 GB of rows resident), nlist 4096, 32-byte codes (the shipped
+    per-list PCA coding), build + query; recall@k against the exact batched search over the same rows.  (On eight GPUs every rank
+    indexes 12.5 M rows: the c5 leg above, at 10 M rows, is about one rank's share.)"""
+    from tests import synth
+
+    free_b, _ = torch.cuda.mem_get_info(device)
+    need = rows * 1024 * 1.12 + (8 << 30)
+    if free_b < need:
+        return {"skipped": f"needs {need / 1e9:.0f} GB of free HBM, {free_b / 1e9:.0f} GB are free"}
+    gen = synth.clustered_model_torch(20000, 8, 11, device)
+    x = synth.clustered_sample_torch(gen, rows, 12)
+    q = synth.clustered_sample_torch(gen, nq, 13).cpu().numpy()
+    del gen
+    torch.cuda.synchronize(device)
+    corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
+    t0 = time.perf_counter()
+    exact = corpus.search(q, top_k=k)
+    exact_s = time.perf_counter() - t0
+    qd = torch.from_numpy(q).to(device)
+    o_rows = torch.empty((nq, k), dtype=torch.int64, device=device)
+    o_dist = torch.empty((nq, k), dtype=torch.float64, device=device)
+    t0 = time.perf_counter()
+    ix = smt.IvfPq(corpus, nlist=nlist, train_iters=10, local_pca=True)
+    build_s = time.perf_counter() - t0
+    info = ix.info()
+    out = {"config": {"workload": f"c5 at its named size on one GPU: IVF index nlist={nlist}, 32 B codes per row, over {rows} chunks in 20000 topics, "
+                                  f"{nq} independent queries, {rerank} ADC candidates per list segment re-scored, top-{k}"},
+           "rows": rows, "build_s": build_s, "build_ms": info["build_ms"], "index_bytes": info["index_bytes"], "exact_batch_search_s": exact_s}
+    for nprobe in (8, 1):
+        got = ix.search(q, top_k=k, nprobe=nprobe, rerank=rerank)
+        hit = sum(len(set(r.tolist()) & set(e.tolist())) for (r, _), (e, _) in zip(got, exact))
+        ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
+        torch.cuda.synchronize(device)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / reps
+        dev_rows = o_rows.cpu().numpy().view(np.uint64)
+        same = all(dev_rows[i, :len(got[i][0])].tolist() == got[i][0].tolist() for i in range(nq))
+        out[f"nprobe_{nprobe}"] = {"recall_at_k_vs_exact": hit / (nq * k), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
+                                   "checks": {"device_and_host_forms_agree": bool(same)}}
+    ix.close()
+    corpus.close()
+    del x
+    torch.cuda.empty_cache()
     return out
 
 

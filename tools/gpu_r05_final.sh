@@ -14,7 +14,7 @@ for leg in c2 c4 c3 embed workspace ivfpq; do
     c3) flags="${all_off/--no-secondary/} --steps 20 --warmup 5";;
     embed) flags="${all_off/--no-embed/} --steps 20 --warmup 5";;
     workspace) flags="${all_off/--no-workspace/} --steps 20 --warmup 5";;
-    ivfpq) flags="${all_off/--no-ivfpq/} --steps 20 --warmup 5";;
+    ivfpq) flags="${all_off/--no-ivfpq/} --c5-full-rows 0 --steps 20 --warmup 5";;
   esac
   timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$out/prof_${tag}_$leg" -o bench -- python "$root/bench.py" $flags --detail-out "$out/${tag}_bench_detail_prof_$leg.json" > "$out/prof_${tag}_$leg.log" 2>&1
   trace=$(find "$out/prof_${tag}_$leg" -name "*kernel_trace.csv" | head -1)
