@@ -89,6 +89,7 @@ def parse_args(argv):
     ap.add_argument("--embed-lines", type=int, default=2_000_000)
     ap.add_argument("--no-ivfpq", action="store_true", help="skip the c5 (IVF-PQ, one GPU) measurement")
     ap.add_argument("--c5-rows", type=int, default=10_000_000)
+    ap.add_argument("--c5-rows-total", type=int, default=100_000_000, help="N > 1: TOTAL rows of the sharded c5 leg (split over the GPUs; 0 = skip)")
     ap.add_argument("--c5-full-rows", type=int, default=100_000_000, help="the c5 leg once more at BASELINE's named size on this one GPU (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-c4", action="store_true", help="skip BASELINE config c4 (100M rows over the N GPUs)")
@@ -603,6 +604,35 @@ def run(args, under_launcher):
         if rank == 0:
             result["c4"] = c4
 
+    if n_shards > 1 and not args.no_ivfpq and args.c5_rows_total > 0:
+        # c5 on the job's GPUs: collective like c4 (shared-centroid build, the exchange of every search): the same watchdog
+        import threading
+
+        def abandon_c5():
+            sys.stderr.write(f"[bench rank {rank}/{world}] the sharded c5 leg gave no answer within {args.c4_timeout} s: leg abandoned\n")
+            sys.stderr.flush()
+            if rank == 0:
+                result["ivfpq_sharded"] = {"error": f"no answer within {args.c4_timeout} s on {n_shards} ranks: leg abandoned"}
+                emit_line(result, args)
+            os._exit(0)
+
+        watchdog5 = threading.Timer(args.c4_timeout, abandon_c5)
+        watchdog5.daemon = True
+        watchdog5.start()
+        try:
+            with clocks.leg("ivfpq_sharded"):
+                c5s = bench_c5_sharded(smt, args, devs, rank, n_shards, group, k)
+        except Exception as exc:
+            c5s = {"error": repr(exc)}
+        if use_dist and world > 1:
+            try:
+                dist.barrier()
+            except Exception:
+                pass
+        watchdog5.cancel()
+        if rank == 0:
+            result["ivfpq_sharded"] = c5s
+
     if rank == 0 and solo and not args.no_secondary:
         try:
             with clocks.leg("c3"):
@@ -899,6 +929,11 @@ def compact_line(d):
     put("ivf_build_s", "ivfpq", "build_s")
     put("ivf_adc_bound", "ivfpq", "roofline", "bound")
     put("ivf_adc_frac", "ivfpq", "roofline", "frac")
+    # ... sharded over the job's GPUs (N > 1)
+    put("ivf_sharded_build_s", "ivfpq_sharded", "build_s")
+    put("ivf_sharded_recall_at_k", "ivfpq_sharded", "recall_at_k_vs_exact_sharded_search")
+    put("ivf_sharded_queries_per_s", "ivfpq_sharded", "queries_per_s")
+    put("ivf_sharded_rows_total", "ivfpq_sharded", "rows_total")
     # ... and at c5's named size (100 M rows on this one GPU)
     put("ivf100m_build_s", "ivfpq_full", "build_s")
     put("ivf100m_recall_at_k", "ivfpq_full", "nprobe_8", "recall_at_k_vs_exact")
@@ -1187,6 +1222,56 @@ def bench_c4_one_process(smt, args, devs, group, local_ctxs, k, queries_on, host
         "checks": {"torch_fp64_topk_distances_match": ok, "rows_in_range": rows_ok, "rows_match_fp64_topk": rows_match,
                    "selects_without_exactness_certificate": uncertain},
     }
+
+
+def bench_c5_sharded(smt, args, devs, rank, n_shards, group, k, nq=1000, nlist=4096, nprobe=8, rerank=128):
+    """BASELINE config c5 on the job's GPUs (N > 1): --c5-rows-total rows (default 100 M) of the clustered corpus row-sharded over the
+    group -- shard s generated on its device from seed 12 + s --, ONE IVF index with shared centroids (the coarse k-means is
+    data-parallel: fixed-point centroid sums all-reduced per iteration; codes fitted per shard), searched through the group's exchange;
+    recall@k against the exact sharded search of the same rows.  SPMD: every process makes the same calls; rank 0 reports."""
+    from tests import synth
+
+    total = args.c5_rows_total
+    per = -(-total // n_shards)
+    first_shard = 0 if len(devs) > 1 else rank                 # one process: shards 0 .. n-1; one rank per process: shard = rank
+    xs, sizes = [], []
+    for i, d in enumerate(devs):
+        sidx = first_shard + i
+        n_rows = max(0, min(per, total - sidx * per))
+        gen = synth.clustered_model_torch(20000, 8, 11, d)     # (the same generative model on every device)
+        xs.append(synth.clustered_sample_torch(gen, n_rows, 12 + sidx))
+        sizes.append(n_rows)
+        if i == 0:
+            q = synth.clustered_sample_torch(gen, nq, 13).cpu().numpy()
+        del gen
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    sc = smt.ShardedCorpus(group, device_ptrs=[x.data_ptr() for x in xs], shard_rows=sizes)
+    t0 = time.perf_counter()
+    exact = sc.search(q, top_k=k)
+    exact_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    six = smt.ShardedIvfPq(sc, nlist=nlist, train_iters=10, local_pca=True, shared_centroids=True)
+    build_s = time.perf_counter() - t0
+    six.search(q, top_k=k, nprobe=nprobe, rerank=rerank)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got = six.search(q, top_k=k, nprobe=nprobe, rerank=rerank)
+    dt = (time.perf_counter() - t0) / reps
+    hit = sum(len(set(r.tolist()) & set(e.tolist())) for (r, _), (e, _) in zip(got, exact))
+    rows_global = all(int(r.max()) < total for r, _ in got if len(r))
+    ascending = all(bool((np.diff(d) >= 0).all()) for _, d in got)
+    info = six.info()
+    six.close()
+    sc.close()
+    del xs
+    torch.cuda.empty_cache()
+    return {"config": {"workload": f"c5 sharded: IVF index nlist={nlist} with shared centroids, 32 B codes per row, over {total} chunks row-sharded over "
+                                   f"{n_shards} ranks ({per} per rank), {nq} independent queries through the host form, nprobe={nprobe}, {rerank} re-scored, top-{k}"},
+            "rows_total": total, "rows_per_rank": per, "n_shards": n_shards, "build_s": build_s, "index_bytes_local": info["index_bytes"],
+            "recall_at_k_vs_exact_sharded_search": hit / (nq * k), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3, "exact_batch_search_s": exact_s,
+            "checks": {"rows_are_global": bool(rows_global), "distances_ascending": bool(ascending)}}
 
 
 def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):

@@ -217,8 +217,10 @@ def test_bench_one_process_group_path_on_one_gpu(transport):
 def test_bench_one_process_over_logical_shards():
     """The N > 1 branch of the one-process bench (per-device shards and queries, one answer on device 0, c4 cut over the shards,
     the fp64 check over every shard) on 3 logical ranks of the one GPU."""
-    r, res, line = _bench(["--logical-shards", "3"] + SMALL + ["--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_logical.json")])
+    args = [a for a in SMALL if a != "--no-ivfpq"] + ["--c5-rows-total", "300000"]      # ... and the sharded c5 leg at a small size
+    r, res, line = _bench(["--logical-shards", "3"] + args + ["--detail-out", os.path.join(ROOT, "gpurun_out", "bench_detail_logical.json")])
     assert r.returncode == 0, r.stderr[-2000:]
+    assert res["ivf_sharded_rows_total"] == 300000 and res["ivf_sharded_recall_at_k"] >= 0.9 and res["ivf_sharded_queries_per_s"] > 0, res
     assert res["n_gpus"] == 1 and res["config"]["logical_shards_on_one_gpu"] == 3 and res["config"]["group"]["n_ranks"] == 3
     assert res["config"]["group"]["transport"] == "peer" and res["config"]["group"]["rccl_ranks"] == 0
     assert res["checks_ok"] is True and res["checks_failed"] == [], res
