@@ -89,6 +89,7 @@ def parse_args(argv):
     ap.add_argument("--embed-lines", type=int, default=2_000_000)
     ap.add_argument("--no-ivfpq", action="store_true", help="skip the c5 (IVF-PQ, one GPU) measurement")
     ap.add_argument("--c5-rows", type=int, default=10_000_000)
+    ap.add_argument("--c5-timeout", type=float, default=120.0, help="several ranks: seconds after which a sharded c5 leg that hangs is abandoned")
     ap.add_argument("--c5-rows-total", type=int, default=100_000_000, help="N > 1: TOTAL rows of the sharded c5 leg (split over the GPUs; 0 = skip)")
     ap.add_argument("--c5-full-rows", type=int, default=100_000_000, help="the c5 leg once more at BASELINE's named size on this one GPU (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -609,14 +610,14 @@ def run(args, under_launcher):
         import threading
 
         def abandon_c5():
-            sys.stderr.write(f"[bench rank {rank}/{world}] the sharded c5 leg gave no answer within {args.c4_timeout} s: leg abandoned\n")
+            sys.stderr.write(f"[bench rank {rank}/{world}] the sharded c5 leg gave no answer within {args.c5_timeout} s: leg abandoned\n")
             sys.stderr.flush()
             if rank == 0:
-                result["ivfpq_sharded"] = {"error": f"no answer within {args.c4_timeout} s on {n_shards} ranks: leg abandoned"}
+                result["ivfpq_sharded"] = {"error": f"no answer within {args.c5_timeout} s on {n_shards} ranks: leg abandoned"}
                 emit_line(result, args)
             os._exit(0)
 
-        watchdog5 = threading.Timer(args.c4_timeout, abandon_c5)
+        watchdog5 = threading.Timer(args.c5_timeout, abandon_c5)
         watchdog5.daemon = True
         watchdog5.start()
         try:
