@@ -326,3 +326,27 @@ def test_reference_store_search_matches_the_oracle():
         hits = case["hits"]
         assert [(names[r["path_id"]], r["line_number"]) for r in res] == [(h["path"], h["line_number"]) for h in hits], case
         assert np.allclose([r["distance"] for r in res], [h["distance"] for h in hits], rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------ third implementations (neither the reference's crates nor ours)
+def test_cosine_and_pool_against_scipy_and_sklearn():
+    """Not a pin on the reference (its crates cannot be had here: DESIGN 6) -- a check that the oracle's two arithmetic steps agree with
+    two widely used independent implementations that ARE installed: scipy's cosine distance (f64) and mean + sklearn `normalize`
+    for the model2vec pool step.  Tolerances: the accurate cosine to 1e-12 of scipy on f32 inputs; the serial-f32 form within the 1e-5
+    contract; the pooled vector within f32 rounding of the f64 mean / norm."""
+    from scipy.spatial.distance import cosine as sp_cosine
+    from sklearn.preprocessing import normalize
+
+    rng = np.random.default_rng(31)
+    for _ in range(200):
+        a = rng.standard_normal(256).astype(np.float32) * float(rng.uniform(0.01, 30))
+        b = rng.standard_normal(256).astype(np.float32) * float(rng.uniform(0.01, 30))
+        ref = sp_cosine(a.astype(np.float64), b.astype(np.float64))
+        assert abs(orc.cosine(a, b, accurate=True) - max(ref, 0.0)) <= 1e-12
+        assert abs(orc.cosine(a, b, accurate=False) - max(ref, 0.0)) <= 1e-5
+    table = synth.table(500, seed=7)
+    for n in (1, 3, 40, 512):
+        ids = rng.integers(0, 500, n)
+        want = normalize(table[ids].astype(np.float64).mean(axis=0, keepdims=True))[0]
+        got = orc.pool_ids(table, ids, True)
+        assert np.abs(got.astype(np.float64) - want).max() <= 2e-6, n
