@@ -470,10 +470,12 @@ static bool run_on_threads(int n, const std::function<void(int)> &fn)
     return ok;
 }
 
-static void worker_main(smt_group *g, int i)
+// issuing thread t of T: it issues the shares of local ranks t, t + T, ... (T = one per device for a group of real GPUs)
+static void worker_main(smt_group *g, int t)
 {
     GroupWorkers *w = g->workers;
-    (void)hipSetDevice(g->ctx[i]->device);   // the thread's current device (every entry point binds again: cheap when unchanged)
+    const int T = w->n_threads;
+    (void)hipSetDevice(g->ctx[t]->device);   // the thread's current device (every entry point binds again: cheap when unchanged)
     uint64_t seen = 0;
     for (;;) {
         const std::function<int(int)> *work;
@@ -484,15 +486,18 @@ static void worker_main(smt_group *g, int i)
             seen = w->epoch;
             work = w->work;
         }
-        int rc;
-        try { rc = (*work)(i); }   // (an exception must reach the caller as a status, not std::terminate the process from this thread)
-        catch (const std::bad_alloc &) { set_error("out of host memory"); rc = SMT_E_NOMEM; }
-        catch (const std::exception &e) { set_error("%s", e.what()); rc = SMT_E_INVALID; }
-        std::string err = rc ? smt_last_error() : "";   // (thread-local: carried back to the caller's thread)
-        {
+        for (int i = t; i < g->n_local; i += T) {
+            int rc;
+            try { rc = (*work)(i); }   // (an exception must reach the caller as a status, not std::terminate the process from this thread)
+            catch (const std::bad_alloc &) { set_error("out of host memory"); rc = SMT_E_NOMEM; }
+            catch (const std::exception &e) { set_error("%s", e.what()); rc = SMT_E_INVALID; }
+            std::string err = rc ? smt_last_error() : "";   // (thread-local: carried back to the caller's thread)
             std::lock_guard<std::mutex> lk(w->mu);
             w->rcs[i] = rc;
             w->errs[i].swap(err);
+        }
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
             if (--w->pending == 0) w->cv_done.notify_one();
         }
     }
@@ -503,20 +508,25 @@ static void group_stop_workers(smt_group *g);
 static int group_start_workers(smt_group *g)
 {
     if (g->n_local <= 1 || g->workers) return SMT_OK;
-    // SEMTOOLS_GROUP_THREADS=0: the caller's thread issues every device's share itself (A/B, debugging); =1: threads even for logical
-    // ranks.  Logical ranks share ONE device, i.e. one runtime lock and one set of hardware queues: eight threads issuing into it
-    // measured SLOWER than the caller's thread alone (125-170 us vs 104 us per 8-shard search, profiles/r05_group_issue.json), so a
-    // logical group has no issuing threads unless asked; a group of real GPUs has one per device.
+    // SEMTOOLS_GROUP_THREADS=0: the caller's thread issues every device's share itself (A/B, debugging); =1: one thread per local rank;
+    // =N >= 2: N issuing threads, each serving every N-th rank.  Default: one per device for a group of real GPUs; FOUR for logical
+    // ranks, which share one device, i.e. one runtime lock and one set of hardware queues -- measured on 8 logical shards, host us per
+    // search (tools/ab_group_threads.sh, one box): no threads 83, 2 threads 70, 3: 67, 4: 65, 8: 73.  (With the per-rank stream waits of
+    // the first peer protocol eight threads were SLOWER than none: 125-170 against 104 us -- the waits serialised on the device's lock.)
     const char *e = getenv("SEMTOOLS_GROUP_THREADS");
     if (e && e[0] == '0') return SMT_OK;
-    if (g->copies && !(e && e[0] == '1')) return SMT_OK;
+    int n_threads = g->copies ? (g->n_local >= 4 ? 4 : 0) : g->n_local;   // (2 logical ranks: 24 us from the caller's thread, 32 with two threads)
+    if (e && atoi(e) >= 2) n_threads = std::min(g->n_local, atoi(e));
+    else if (e && e[0] == '1') n_threads = g->n_local;
+    if (n_threads < 2) return SMT_OK;
     g->workers = new (std::nothrow) GroupWorkers();
     if (!g->workers) { set_error("out of host memory"); return SMT_E_NOMEM; }
+    g->workers->n_threads = n_threads;
     g->workers->rcs.assign(g->n_local, SMT_OK);
     g->workers->errs.assign(g->n_local, std::string());
     try {
-        g->workers->threads.reserve((size_t)g->n_local);
-        for (int i = 0; i < g->n_local; ++i) g->workers->threads.emplace_back(worker_main, g, i);
+        g->workers->threads.reserve((size_t)n_threads);
+        for (int t = 0; t < n_threads; ++t) g->workers->threads.emplace_back(worker_main, g, t);
     } catch (...) {
         group_stop_workers(g);   // (the ones that exist leave; the group then issues from threads made per call, or from the caller's)
     }
@@ -554,7 +564,7 @@ int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool
     } else if (GroupWorkers *w = g->workers) {
         std::unique_lock<std::mutex> lk(w->mu);
         w->work = &work;
-        w->pending = g->n_local;
+        w->pending = w->n_threads;
         ++w->epoch;
         w->cv_go.notify_all();
         w->cv_done.wait(lk, [&] { return w->pending == 0; });

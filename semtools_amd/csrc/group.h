@@ -26,6 +26,7 @@ struct GroupBuf {
 // every device's share at once; collectives stay on the caller's thread (ncclGroupStart / End needs all local ranks in one thread).
 struct GroupWorkers {
     std::vector<std::thread> threads;
+    int n_threads = 0;               // thread t issues the shares of local ranks t, t + n_threads, ...
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     const std::function<int(int)> *work = nullptr;
