@@ -169,6 +169,13 @@ def main(argv=None):
             sys.stdout.write(json.dumps(error_line(args, exc, visible_gpus())) + "\n")
             sys.stdout.flush()
         return 0
+    except Exception as exc:   # a failure past start-up: the traceback on stderr AND a parseable line saying so (exit 1: not a result)
+        import traceback
+        traceback.print_exc()
+        if rank_env == 0:
+            sys.stdout.write(json.dumps(error_line(args, f"failed after start-up: {exc!r}", visible_gpus())) + "\n")
+            sys.stdout.flush()
+        return 1
     return 0
 
 
@@ -1986,4 +1993,4 @@ def _cpu_model():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

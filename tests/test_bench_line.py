@@ -81,3 +81,23 @@ def test_a_run_that_cannot_start_prints_a_line_and_exits_zero():
         assert isinstance(res["n_gpus_visible"], int) and res["error"]
         for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
             assert key in res, key
+
+
+def test_a_failure_after_start_up_prints_a_line_and_exits_one(monkeypatch, capsys):
+    """Anything that goes wrong once the run has started (a library error in the timed loop of an N-GPU run nobody could try here) leaves
+    the traceback on stderr AND a parseable last line with value null and the error -- exit code 1, because it is not an environment
+    problem."""
+    import bench
+
+    def boom(args, under_launcher):
+        raise RuntimeError("hipErrorLaunchFailure in step 3")
+
+    monkeypatch.setattr(bench, "run", boom)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.main(["--gpus", "8", "--steps", "20", "--warmup", "5"]) == 1
+    out, err = capsys.readouterr()
+    res = json.loads(out.strip().split("\n")[-1])
+    assert res["value"] is None and res["n_gpus"] == 8 and "hipErrorLaunchFailure" in res["error"] and "failed after start-up" in res["error"]
+    assert "Traceback" in err
