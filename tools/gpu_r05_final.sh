@@ -16,8 +16,10 @@ for leg in c2 c4 c3 embed workspace ivfpq; do
     workspace) flags="${all_off/--no-workspace/} --steps 20 --warmup 5";;
     ivfpq) flags="${all_off/--no-ivfpq/} --c5-full-rows 0 --steps 20 --warmup 5";;
   esac
-  timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$out/prof_${tag}_$leg" -o bench -- python "$root/bench.py" $flags --detail-out "$out/${tag}_bench_detail_prof_$leg.json" > "$out/prof_${tag}_$leg.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_$leg" -o bench -- python "$root/bench.py" $flags --detail-out "$out/${tag}_bench_detail_prof_$leg.json" > "$out/prof_${tag}_$leg.log" 2>&1
   trace=$(find "$out/prof_${tag}_$leg" -name "*kernel_trace.csv" | head -1)
+  stats=$(find "$out/prof_${tag}_$leg" -name "*kernel_stats.csv" | head -1)
+  [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench_${leg}_kernel_stats.csv"
   [ -n "$trace" ] && python "$root/tools/kernel_shapes.py" "$trace" > "$out/${tag}_bench_${leg}_kernel_shapes.csv" && head -4 "$out/${tag}_bench_${leg}_kernel_shapes.csv" | cut -c1-160
 done
 cd "$root"
