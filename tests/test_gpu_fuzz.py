@@ -123,3 +123,62 @@ def test_document_subsets_random_shapes(gpu_ctx, n, k, nq, seed, max_doc, p_want
         assert got[i][0].tolist() == idx[np.array(orows, dtype=np.int64)].tolist(), (i, n, k, nq, seed, max_doc, p_want, image)
         assert np.array_equal(got[i][1], np.array(odist))
     c.close()
+
+
+@settings(max_examples=25 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n_shards=st.sampled_from([2, 3, 4, 7]), transport=st.sampled_from(["peer", "copy"]), seed=st.integers(0, 10_000),
+       pieces=st.lists(st.integers(1, 1500), min_size=1, max_size=6), k=st.integers(1, 70), nq=st.sampled_from([1, 1, 2, 4, 9, 40]),
+       what=st.sampled_from(["topk", "topk", "subset", "threshold", "workspace"]))
+def test_sharded_random_shapes_against_the_oracle(gpu_ctx, n_shards, transport, seed, pieces, k, nq, what):
+    """A corpus GROWN by appends of random sizes over 2..7 logical shards (pieces dealt over the ranks: shards smaller than k, empty
+    shards, pieces of one row), either transport, every search form of the host API -- checked by the C oracle directly: global rows
+    in insertion order, f64 distances bit for bit (workspace mode: the store's f32 scores, 1e-5)."""
+    import semtools_amd as smt
+
+    n = sum(pieces)
+    emb = synth.unit_rows(n, seed=seed, dup_frac=0.05, zero_frac=0.01)
+    qs = synth.unit_query(seed + 1, nq=nq)
+    rng = np.random.default_rng(seed)
+    g = smt.Group.logical(0, n_shards)
+    g.set_transport(transport)
+    sc = smt.ShardedCorpus(g, empty=True)
+    try:
+        b = 0
+        for p in pieces:
+            sc.append(emb[b:b + p])
+            b += p
+        ranges, idx = None, np.arange(n)
+        if what in ("subset", "workspace") and n > 4:
+            cuts = np.sort(rng.choice(np.arange(1, n), size=min(8, n - 1), replace=False))
+            segs = [(int(a), int(e)) for a, e in zip(cuts[::2], cuts[1::2])]
+            if segs:
+                ranges = segs
+                idx = np.concatenate([np.arange(a, e) for a, e in segs])
+        note = (n_shards, transport, seed, pieces, k, nq, what)
+        if what == "threshold":
+            thr = float(rng.uniform(0.7, 1.1))
+            got = sc.search(qs, top_k=k, max_distance=thr)
+            for i in range(nq):
+                orows, odist = _oracle(emb, qs[i], k, thr)
+                assert got[i][0].tolist() == orows and np.array_equal(got[i][1], np.array(odist)), (note, i)
+        elif what == "workspace":
+            thr = None if seed % 2 else float(rng.uniform(0.8, 1.0))
+            kk = min(k, 28)
+            got = sc.search(qs, top_k=kk, max_distance=thr, mode=smt.MODE_WORKSPACE, ranges=ranges)
+            row_path = np.zeros(n, dtype=np.uint32)          # path 1 = the wanted rows
+            row_path[idx] = 1
+            for i in range(0, nq, max(1, nq // 4)):
+                res = orc.search_line_embeddings(emb, row_path, np.arange(n, dtype=np.int32), qs[i], np.array([1], np.uint32), kk, thr)
+                assert len(got[i][0]) == len(res), (note, i)
+                assert np.allclose(got[i][1], [r["distance"] for r in res], rtol=0, atol=1e-5), (note, i)
+                for gr, r in zip(got[i][0].tolist(), res):   # only f32-level near-ties of the store's scores may swap
+                    assert gr == r["row"] or abs(orc.cosine(qs[i], emb[gr]) - r["distance"]) < 5e-7, (note, i, gr, r)
+        else:
+            got = sc.search(qs, top_k=k, ranges=ranges)
+            for i in range(nq):
+                orows, odist = _oracle(emb[idx], qs[i], k)
+                want = idx[np.array(orows, dtype=np.int64)].tolist() if orows else []
+                assert got[i][0].tolist() == want and np.array_equal(got[i][1], np.array(odist)), (note, i)
+    finally:
+        sc.close()
+        g.close()
