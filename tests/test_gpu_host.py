@@ -829,3 +829,93 @@ def test_workspace_written_ahead_equals_the_workspace_written_at_the_end(gpu_ctx
     assert stores["1"][0] == stores["0"][0]
     strip = lambda ext: [(os.path.basename(e["path"]), e["first_row"], e["n_rows"]) for e in ext]
     assert strip(stores["1"][1]) == strip(stores["0"][1])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_workspace_random_life_of_a_store(model, model_dir, tmp_path, monkeypatch, capfd, seed):
+    """A workspace lived in for 120 random steps -- new files, files that grow, shrink or are rewritten, deleted files and prune,
+    searches over random subsets with and without a threshold -- against a model of it: after every search the hits are exactly
+    what Store::search_line_embeddings (src/workspace/store.rs:481-546, oracle restatement) returns on the CURRENT contents of the
+    searched files: as many hits, the same sorted distances (1e-5), every hit an eligible (file, line) with that distance.  One GPU
+    and three shards; the store sees holes, re-used extents, documents that move, and a second process state (status) in between."""
+    from semtools_amd import host
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("SEMTOOLS_WORKSPACE", raising=False)
+    table = model_dir[1]
+    rng = np.random.default_rng(1000 + seed)
+    ws = f"life{seed}"
+    host.workspace_use(None, ws)
+    pool = synth.pseudo_prose(3000, vocab_size=V - 1, seed=50 + seed)
+    pool[7] = ""                                  # zero vectors take part
+    pool[8] = "unknownword"
+    files = {}                                    # path -> lines now on disk
+    clock = [1_800_000_000]
+    emb_of = {}
+
+    def emb(line):
+        if line not in emb_of:
+            emb_of[line] = oracle_embed(table, [line], 2048)[0]
+        return emb_of[line]
+
+    def write(path, lines):
+        with open(path, "w") as f:
+            f.write("".join(l + "\n" for l in lines))
+        clock[0] += 10
+        os.utime(path, (clock[0], clock[0]))
+        files[path] = lines
+
+    def some_lines(lo, hi):
+        return [pool[int(i)] for i in rng.integers(0, len(pool), size=int(rng.integers(lo, hi + 1)))]
+
+    n_made = 0
+    searched = 0
+    for step in range(120):
+        op = rng.choice(["new", "new", "grow", "shrink", "rewrite", "delete", "search", "search", "search"]) if files else "new"
+        if op == "new":
+            p = str(tmp_path / f"f{seed}_{n_made}.txt")
+            n_made += 1
+            write(p, some_lines(1, 300))
+            continue
+        victim = sorted(files)[int(rng.integers(0, len(files)))]
+        if op == "grow":
+            write(victim, files[victim] + some_lines(1, 200))
+        elif op == "shrink":
+            write(victim, files[victim][:max(1, len(files[victim]) // 2)])
+        elif op == "rewrite":
+            write(victim, some_lines(1, 300))
+        elif op == "delete":
+            os.unlink(victim)
+            del files[victim]
+            text = host.workspace_prune(model.ctx, ws)
+            assert "stale" in text.lower() or "clean" in text.lower()
+        else:
+            names = sorted(files)
+            want = [names[int(i)] for i in rng.choice(len(names), size=int(rng.integers(1, len(names) + 1)), replace=False)]
+            k = int(rng.integers(1, 25))
+            thr = None if rng.random() < 0.5 else float(rng.uniform(0.6, 1.0))
+            query = pool[int(rng.integers(10, len(pool)))]
+            js = json.loads(host.search_with_workspace(model, query, want, workspace_name=ws, n_lines=0, top_k=k, max_distance=thr, json=True))
+            capfd.readouterr()
+            e = np.stack([emb(l) for p in want for l in files[p]])
+            path = np.concatenate([np.full(len(files[p]), i, np.uint32) for i, p in enumerate(want)])
+            line = np.concatenate([np.arange(len(files[p]), dtype=np.int32) for p in want])
+            q = oracle_embed(table, [query], 512)[0]
+            exp = orc.search_line_embeddings(e, path, line, q, np.arange(len(want), dtype=np.uint32), k, thr)
+            got = js["results"]
+            note = (seed, step, len(want), k, thr)
+            assert len(got) == len(exp), note
+            np.testing.assert_allclose([r["distance"] for r in got], [r["distance"] for r in exp], rtol=0, atol=1e-5, err_msg=str(note))
+            seen = set()
+            for r in got:
+                key = (r["filename"], r["match_line_number"])
+                assert r["filename"] in want and 0 <= r["match_line_number"] < len(files[r["filename"]]) and key not in seen, (note, r)
+                seen.add(key)
+                ln = files[r["filename"]][r["match_line_number"]]
+                assert r["content"] == ln, (note, r)
+                assert abs(orc.cosine(q, emb(ln)) - r["distance"]) < 1e-5, (note, r)
+            searched += 1
+            if step % 7 == 0:
+                st = json.loads(host.workspace_status(model.ctx, ws, json=True))
+                assert st["total_documents"] >= len(want)
+    assert searched >= 15
