@@ -306,8 +306,8 @@ int smt_group_barrier(smt_group *group);     /* + an all-gather across the ranks
  *   SMT_TRANSPORT_PEER  one-process groups (smt_group_create when every device can read every other's memory -- peer access is
  *                       enabled at creation --, smt_group_create_logical): nothing is gathered; the merge kernel of the device
  *                       that needs the answer reads the ranks' lists where they lie, ordered by one stream event per rank.
- *                       DEFAULT wherever it is possible: the caller's thread pays n - 1 stream waits and one launch per answer
- *                       instead of RCCL's per-call host cost for a 960-byte payload.
+ *                       DEFAULT wherever it is possible: an answer costs n - 1 stream waits (enqueued by the ranks' issuing threads)
+ *                       and one launch instead of RCCL's per-call host cost for a 960-byte payload.
  * $SEMTOOLS_GROUP_TRANSPORT = rccl | copy | peer overrides the default at creation (ignored where impossible).
  * smt_group_set_transport synchronises the group first; SMT_E_INVALID if the group cannot use that transport.
  * Threshold mode / large k (host-list exchange), barriers and the shared-centroid all-reduce always use RCCL (or copies). */

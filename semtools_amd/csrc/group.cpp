@@ -197,18 +197,27 @@ static int peer_publish(smt_group *g, int j, hipStream_t st)
     return SMT_OK;
 }
 
+// Rank j's issuer, right behind peer_publish(j): the merge that local device i will launch on `st_i` waits for rank j's list.
+// (The wait names a stream of ANOTHER device when i != j: legal -- a stream carries its device -- and checked by the self-test.)
+static int peer_await(smt_group *g, int j, int i, hipStream_t st_i)
+{
+    if (j == i && g->pub_stream[j] == st_i) return SMT_OK;   // stream order
+    SMT_HIP_CHECK(hipStreamWaitEvent(st_i, g->ev_ready[j], 0));
+    return SMT_OK;
+}
+
 // The caller's thread, after every local rank has published: local device i merges the n_ranks packed lists [nq][2][k_in] that start
 // `off` bytes into the ranks' buffers `bases` (exchange buffers, or ring slots), reading them in place, into out_packed
 // [nq][2][k_out] on its stream `st`; `done` (may be null) is recorded behind the merge.
 static int peer_merge(smt_group *g, int i, hipStream_t st, void *const *bases, size_t off, uint32_t nq, uint32_t k_in, uint32_t k_out,
-                      uint64_t *out_packed, hipEvent_t done)
+                      uint64_t *out_packed, hipEvent_t done, bool waits_enqueued = false)
 {
     int rc = group_bind(g, i);
     if (rc) return rc;
     MergeSources src;
     for (int j = 0; j < g->n_local; ++j) {
         src.list[j] = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(bases[j]) + off);
-        if (j == i && g->pub_stream[j] == st) continue;   // stream order
+        if (waits_enqueued || (j == i && g->pub_stream[j] == st)) continue;   // (the ranks' issuers did it: peer_await / stream order)
         SMT_HIP_CHECK(hipStreamWaitEvent(st, g->ev_ready[j], 0));
     }
     if ((rc = launch_merge_topk_sources_on(st, src, (uint32_t)g->n_local, nq, k_in, k_out, out_packed))) return rc;
@@ -291,6 +300,7 @@ static int group_make_events(smt_group *g)
     g->ev_ready.assign(g->n_local, nullptr);
     g->ev_done.assign(g->n_local, nullptr);
     g->pub_stream.assign(g->n_local, nullptr);
+    if (const char *w = getenv("SEMTOOLS_GROUP_WAITS")) g->spread_waits = std::string(w) != "caller";
     for (int i = 0; i < g->n_local; ++i) {
         // (the default system-scope release of an event record is what makes a rank's list visible to a reader on another device)
         hipError_t e = hipSetDevice(g->ctx[i]->device);
@@ -349,9 +359,15 @@ static bool peer_self_test(smt_group *g)
             hipLaunchKernelGGL(peer_test_fill_kernel, dim3(1), dim3(64), 0, g->ctx[j]->stream, reinterpret_cast<uint64_t *>(g->buf[j].dev), k,
                                (uint32_t)j, n, round);
             if (hipGetLastError() != hipSuccess || peer_publish(g, j, g->ctx[j]->stream)) return false;
+            // (with device j current, as rank j's issuing thread will have it)
+            if (g->spread_waits && peer_await(g, j, 0, g->ctx[0]->stream)) {
+                (void)hipGetLastError();
+                g->spread_waits = false;
+                return peer_self_test(g);   // once more from the start, every wait enqueued by the merging device's side
+            }
         }
         uint64_t *merged = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->buf[0].dev) + out_off);
-        if (peer_merge(g, 0, g->ctx[0]->stream, bases.data(), 0, 1, k, k, merged, nullptr)) return false;
+        if (peer_merge(g, 0, g->ctx[0]->stream, bases.data(), 0, 1, k, k, merged, nullptr, g->spread_waits)) return false;
         uint64_t got[8];
         if (hipMemcpyAsync(got, merged, sizeof(got), hipMemcpyDeviceToHost, g->ctx[0]->stream) != hipSuccess) return false;
         if (group_sync_all(g)) return false;
@@ -1243,6 +1259,10 @@ try {
     const bool peer = g->transport == SMT_TRANSPORT_PEER;
     int rc;
     for (int i = 0; i < g->n_local; ++i) SMT_REQUIRE(queries_dev[i] != nullptr, "queries_dev");
+    // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select); the exchange and
+    // the merge then follow it there, and the main stream carries nothing but scans
+    for (int i = 0; i < g->n_local; ++i) on_aux[i] = g->ctx[i]->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k ? 1 : 0;
+    const bool spread = peer && g->spread_waits && g->workers != nullptr;
     int slot = 0;
     if (peer) {   // rank j writes its list into slot `slot` of its ring; whoever needs the answer reads the slots in place
         if ((rc = ring_ensure(g, list_words * 8))) return rc;
@@ -1255,9 +1275,7 @@ try {
         if ((rc_i = group_bind(g, i))) return rc_i;
         if (!peer && (rc_i = ensure_dev(g, i, dev_bytes))) return rc_i;
         smt_ctx *c = g->ctx[i];
-        // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select);
-        // the all-gather and the merge then follow it there, and the main stream carries nothing but scans
-        const bool async = c->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k;
+        const bool async = on_aux[i] != 0;
         uint64_t *list = peer ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->ring.dev[i]) + (size_t)slot * g->ring.slot_bytes)
                               : reinterpret_cast<uint64_t *>(g->buf[i].dev);
         rc_i = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false,
@@ -1265,9 +1283,11 @@ try {
         if (rc_i) return rc_i;
         if (!sc->contiguous && (rc_i = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream, list, nq, top_k)))
             return rc_i;
-        on_aux[i] = async ? 1 : 0;
         if (async) c->async_pending = true;
         if (peer && (rc_i = peer_publish(g, i, async ? c->aux_stream : c->stream))) return rc_i;
+        if (spread)   // every merge that will want this rank's list waits for it: enqueued here, off the caller's thread
+            for (int m = 0; m < g->n_local; ++m)
+                if (out_packed[m] && (rc_i = peer_await(g, i, m, on_aux[m] ? g->ctx[m]->aux_stream : g->ctx[m]->stream))) return rc_i;
         return SMT_OK;
     }, g->workers != nullptr);
     if (rc) return rc;
@@ -1280,7 +1300,7 @@ try {
             // (an answer wanted on ONE device -- the one-thread caller of SURVEY 8(b) -- costs n - 1 waits + a launch + a record here)
             hipEvent_t done = nullptr;
             if ((rc = ring_done_event(g, slot, i, &done))) return rc;
-            if ((rc = peer_merge(g, i, st, g->ring.dev.data(), (size_t)slot * g->ring.slot_bytes, nq, top_k, top_k, out_packed[i], done))) return rc;
+            if ((rc = peer_merge(g, i, st, g->ring.dev.data(), (size_t)slot * g->ring.slot_bytes, nq, top_k, top_k, out_packed[i], done, spread))) return rc;
             if (on_aux[i]) c->async_pending = true;
             continue;
         }

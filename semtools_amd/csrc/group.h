@@ -55,11 +55,16 @@ struct smt_group {
     // Peer transport (SMT_TRANSPORT_PEER, the default of every one-process group whose devices can read each other's memory):
     // the per-shard k-lists are not moved at all -- the merge kernel of the device that needs the answer loads them from the
     // ranks' exchange buffers where they lie (merge_topk_sources_kernel), ordered by ONE event per rank: ev_ready[j] after rank j's
-    // select.  The caller's thread pays n - 1 stream waits + one launch + one record per answer; an RCCL all-gather of the same
+    // select.  An answer costs n - 1 stream waits (enqueued by the ranks' issuers, see spread_waits) + one launch + one record; an RCCL all-gather of the same
     // 960 B costs ncclGroupStart + n ncclAllGather + ncclGroupEnd there.
     int transport = SMT_TRANSPORT_RCCL;
     bool peer_ok = false;               // every local device may read every other local device's memory
     std::vector<hipStream_t> pub_stream;   // [n_local] the stream ev_ready[j] was last recorded on
+    // Who enqueues the n - 1 waits in front of a merge: the issuer of rank j, right behind its own event record (`spread_waits`: the
+    // waits of one answer are spread over the issuing threads instead of queueing on the caller's thread -- ~3-5 us each), or the
+    // caller's thread in peer_merge.  Checked by the self-test at creation: a runtime that refuses a wait enqueued on another
+    // device's stream turns it off.  $SEMTOOLS_GROUP_WAITS=caller turns it off too (A/B).
+    bool spread_waits = true;
     // The pipelined entry point (smt_sharded_search_topk_device: nothing synchronises) writes rank j's list of exchange e into slot
     // e % slots of rank j's RING, so that no rank ever waits for a reader on the device: a slot is reused `slots` exchanges later,
     // and the caller's thread first makes sure -- hipEventSynchronize on an event that has long completed, or real back-pressure
