@@ -948,6 +948,10 @@ def compact_line(d):
     put("ivf100m_queries_per_s", "ivfpq_full", "nprobe_8", "queries_per_s")
     put("ivf100m_np1_recall_at_k", "ivfpq_full", "nprobe_1", "recall_at_k_vs_exact")
     put("ivf100m_np1_queries_per_s", "ivfpq_full", "nprobe_1", "queries_per_s")
+    put("ivf100m_np32_recall_at_k", "ivfpq_full", "nprobe_32", "recall_at_k_vs_exact")
+    put("ivf100m_np32_queries_per_s", "ivfpq_full", "nprobe_32", "queries_per_s")
+    put("ivf100m_np128_recall_at_k", "ivfpq_full", "nprobe_128", "recall_at_k_vs_exact")
+    put("ivf100m_np128_queries_per_s", "ivfpq_full", "nprobe_128", "queries_per_s")
     put("ivf_pq_recall_at_k", "ivfpq", "global_pq_m32", "recall_at_k_vs_exact")
     put("ivf_pq_queries_per_s", "ivfpq", "global_pq_m32", "queries_per_s")
     put("ivf_pq_build_s", "ivfpq", "global_pq_m32", "build_s")
@@ -1960,7 +1964,7 @@ def bench_c5_full(smt, ctx, device, rows, k, nq=1000, nlist=4096, rerank=128):
     out = {"config": {"workload": f"c5 at its named size on one GPU: IVF index nlist={nlist}, 32 B codes per row, over {rows} chunks in 20000 topics, "
                                   f"{nq} independent queries, {rerank} ADC candidates per list segment re-scored, top-{k}"},
            "rows": rows, "build_s": build_s, "build_ms": info["build_ms"], "index_bytes": info["index_bytes"], "exact_batch_search_s": exact_s}
-    for nprobe in (8, 1):
+    for nprobe in (8, 1, 32, 128):     # (SURVEY 8(d) c5 names nprobe 8 / 32 / 128)
         got = ix.search(q, top_k=k, nprobe=nprobe, rerank=rerank)
         hit = sum(len(set(r.tolist()) & set(e.tolist())) for (r, _), (e, _) in zip(got, exact))
         ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
@@ -1975,6 +1979,9 @@ def bench_c5_full(smt, ctx, device, rows, k, nq=1000, nlist=4096, rerank=128):
         same = all(dev_rows[i, :len(got[i][0])].tolist() == got[i][0].tolist() for i in range(nq))
         out[f"nprobe_{nprobe}"] = {"recall_at_k_vs_exact": hit / (nq * k), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
                                    "checks": {"device_and_host_forms_agree": bool(same)}}
+    # more probes must never cost recall (the segments of a probed list share out its codes evenly whatever nprobe: ivfpq_search.hip)
+    rc = [out[f"nprobe_{p}"]["recall_at_k_vs_exact"] for p in (8, 32, 128)]
+    out["checks"] = {"recall_does_not_fall_with_nprobe": bool(rc[1] >= rc[0] - 0.002 and rc[2] >= rc[1] - 0.002)}
     ix.close()
     corpus.close()
     del x

@@ -403,11 +403,6 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     SMT_REQUIRE(top_k <= 56, "top_k must be <= 56 for the IVF-PQ path");
     if (rerank == 0) rerank = 512;
     SMT_REQUIRE(rerank >= 4 && rerank <= 512, "rerank (full-precision re-scored ADC candidates per probed list) must be in [4, 512]");
-    // waves per (query, list segment) block.  (PQ, kind 0, with 8-wave blocks -- two blocks' worth of waves sharing one 32 KiB LUT --
-    // measured +4 % queries/s for -0.5 point of recall@10 at rerank 128: sixteen candidates per wave are too few.  Not taken.)
-    const int adc_waves = rerank > 256 ? 8 : 4;
-    const uint32_t shortlist = (rerank + adc_waves - 1) / adc_waves;  // per wave
-    const uint32_t kp = top_k + 8;                // re-scored candidates handed to the exact select stage
     // A list longer than ADC_SEGMENT codes is scanned by several blocks, each with its own shortlist of `rerank`
     // candidates (config 5's 100 M rows over 4096 lists: 24 k codes per list -- one shortlist of 512 would re-score
     // 2 % of them and recall@10 drops to 0.75); the select stage takes at most 512 lists per query.
@@ -417,9 +412,20 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     // segment of an unusually long list simply takes the rest
     const uint64_t typical = (ix->n_rows / std::max<uint32_t>(ix->nlist, 1u)) * 3 / 2;
     uint32_t n_seg = (uint32_t)std::max<uint64_t>(1, (typical + ADC_SEGMENT - 1) / ADC_SEGMENT);
+    // ... and when that limit takes segments away (nprobe 128 over 100 M rows: 4 instead of 5), the typical list is cut into EQUAL
+    // longer segments -- with ADC_SEGMENT kept, the last one took a double share behind one shortlist and recall@10 FELL with
+    // nprobe (0.9795 at 32, 0.9708 at 128)
+    const uint32_t want_seg = n_seg;
     n_seg = std::min<uint32_t>(n_seg, std::max<uint32_t>(1u, 512u / nprobe));
-    const uint32_t seg_len = (uint32_t)ADC_SEGMENT;
+    const uint32_t seg_len = n_seg < want_seg ? (uint32_t)(((typical + n_seg - 1) / n_seg + 255) & ~(uint64_t)255) : (uint32_t)ADC_SEGMENT;
+    // (... each with a shortlist longer by the same factor: the re-scored fraction of a list does not depend on nprobe)
+    if (n_seg < want_seg) rerank = std::min<uint32_t>(512u, (rerank * want_seg + n_seg - 1) / n_seg);
 
+    // waves per (query, list segment) block.  (PQ, kind 0, with 8-wave blocks -- two blocks' worth of waves sharing one 32 KiB LUT --
+    // measured +4 % queries/s for -0.5 point of recall@10 at rerank 128: sixteen candidates per wave are too few.  Not taken.)
+    const int adc_waves = rerank > 256 ? 8 : 4;
+    const uint32_t shortlist = (rerank + adc_waves - 1) / adc_waves;  // per wave
+    const uint32_t kp = top_k + 8;                // re-scored candidates handed to the exact select stage
     // every temporary lives in the context's scratch (no hipMalloc/hipFree per call), results come back through
     // the pinned staging buffer
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
