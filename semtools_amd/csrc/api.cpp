@@ -345,6 +345,7 @@ void smt_ctx_destroy(smt_ctx *ctx)
     for (auto &kv : ctx->prof)
         for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_embed_runs) (void)hipFree(ctx->d_embed_runs);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_pinned_in) (void)hipHostFree(ctx->h_pinned_in);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -455,7 +456,7 @@ try {
         SMT_REQUIRE(value >= 0 && value <= 2, "gemm_split_last: 0 no level in two parts, 1 a ratio-16 last level, 2 (default) also the first level after the bootstrap");
         ctx->tune.gemm_split_last = (int)value;
     } else if (k == "embed_batched") {
-        SMT_REQUIRE(value >= 0 && value <= 7, "embed_batched is a bit mask: 1 batched id loads, 2 id prefetch kernel, 4 (tests) 64-token spans");
+        SMT_REQUIRE(value >= 0 && value <= 15, "embed_batched is a bit mask: 1 batched id loads, 2 id prefetch kernel, 4 (tests) 64-token spans, 8 runs of equal line counts (A/B)");
         ctx->tune.embed_batched = (int)value;
     } else if (k == "gemm_resident") { /* the kernel it selected left in round 2: accepted and ignored, as before round 4 */ }
     else if (k == "gemm_image") ctx->tune.gemm_image = (int)value;

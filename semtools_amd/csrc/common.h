@@ -93,6 +93,8 @@ struct smt_ctx {
     // scratch (grown on demand, reused across calls)
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    uint64_t *d_embed_runs = nullptr;   // K1: first line of every group's run (token-balanced runs, embed_kernels.hip), made on first use
+    size_t embed_runs_cap = 0;          // entries
     void *h_pinned = nullptr;
     size_t pinned_bytes = 0;
     void *h_pinned_in = nullptr;   // smt_search's inputs (queries, ranges, prefixes) assembled for ONE upload

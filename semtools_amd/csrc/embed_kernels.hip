@@ -47,7 +47,9 @@ struct EmbedParams {
     int normalize;
     int batched;                // 1: parked lines wait for a wave-wide epilogue (0: each line is finished when it completes; A/B)
     float *out;
-    uint64_t lines_per_group;   // a group of 16 lanes walks lines [g * lines_per_group, ...)
+    uint64_t lines_per_group;   // a group of 16 lanes walks lines [g * lines_per_group, ...) -- unless:
+    const uint64_t *run_start;  // [n_groups + 1] or nullptr: group g walks lines [run_start[g], run_start[g + 1]) (embed_runs_kernel)
+    uint64_t n_groups;
     uint64_t span_limit;        // PF kernel: runs spanning this many tokens or more are left to the generic kernel (2^32; tests: small)
     int only_large;             // generic kernel: 1 = walk only the runs the PF kernel left
 };
@@ -57,6 +59,30 @@ struct EmbedParams {
 // The PF kernel keeps token positions as 32-bit counts from the first token of its run (six position registers instead of twelve:
 // that is what takes it under the 128-VGPR line of four waves per SIMD without spilling); a run spanning 2^32 tokens or more --
 // 16 GiB of ids under one group -- is skipped here and walked by the generic kernel, launched behind it with only_large = 1.
+// Runs of equal WORK instead of equal line counts.  A group's time is its tokens plus ~4 token-steps per line (the epilogue), and
+// line lengths of real text have a heavy tail: with equal line counts a run that holds one 2048-token line among four-token ones
+// takes three times as long as its neighbours and the launch waits for it (8 M lines of 4 tokens with 0.2 % of 2048: 6.6 ms against
+// 4.7 for the same tokens spread evenly).  key(i) = offsets[i] - offsets[0] + 4 i is strictly increasing; run_start[g] = the first
+// line whose key reaches g / n_groups of key(n_lines) -- a binary search per group, one thread each.  (The truncation to
+// max_tokens is not in the key: a line far beyond it spreads its share over groups that then find nothing to do.)
+constexpr uint64_t EMBED_LINE_WEIGHT = 4;
+__global__ void __launch_bounds__(256) embed_runs_kernel(const uint64_t *__restrict__ offsets, uint64_t n_lines, uint64_t n_groups,
+                                                         uint64_t *__restrict__ run_start)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g > n_groups) return;
+    const uint64_t o0 = offsets[0];
+    const uint64_t total = offsets[n_lines] - o0 + EMBED_LINE_WEIGHT * n_lines;
+    // target = total * g / n_groups without overflow: total < 2^52 in practice, g <= 2^20 -- 128-bit to be safe
+    const uint64_t target = (uint64_t)(((unsigned __int128)total * g) / n_groups);
+    uint64_t lo = 0, hi = n_lines;   // first i in [0, n_lines] with key(i) >= target (key(n_lines) = total >= target)
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] - o0 + EMBED_LINE_WEIGHT * mid >= target) hi = mid; else lo = mid + 1;
+    }
+    run_start[g] = g == n_groups ? n_lines : lo;
+}
+
 template <bool PF>
 __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
 {
@@ -66,8 +92,16 @@ __global__ void __launch_bounds__(256, 4) embed_kernel(EmbedParams p)
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     // (register diet: the kernel sits at the 128-VGPR edge of four waves per SIMD -- the position inside the run is a 32-bit count,
     // the parked line is always the one before the current, its token count is kept as the float the mean divides by)
-    const uint64_t line0 = group * p.lines_per_group;
-    uint32_t n_run = line0 < p.n_lines ? (uint32_t)min(p.n_lines - line0, p.lines_per_group) : 0u;
+    uint64_t line0;
+    uint32_t n_run;
+    if (p.run_start) {   // (kernel-uniform)
+        const bool mine = group < p.n_groups;
+        line0 = mine ? p.run_start[group] : 0;
+        n_run = mine ? (uint32_t)(p.run_start[group + 1] - line0) : 0u;
+    } else {
+        line0 = group * p.lines_per_group;
+        n_run = line0 < p.n_lines ? (uint32_t)min(p.n_lines - line0, p.lines_per_group) : 0u;
+    }
     // positions are counted from `tb`: the run's first token in the PF kernel, 0 in the generic one
     using pos_t = typename std::conditional<PF, uint32_t, uint64_t>::type;
     uint64_t tb = 0;
@@ -248,10 +282,31 @@ int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, co
     // lines average out inside a run (a group with 100 lines of 0..32 tokens ends within ~5 % of its neighbours)
     const uint64_t want_groups = (uint64_t)std::max(ctx->num_cus, 1) * 64;
     p.lines_per_group = std::max<uint64_t>(1, (n_lines + want_groups - 1) / want_groups);
-    const uint64_t groups = (n_lines + p.lines_per_group - 1) / p.lines_per_group;
+    uint64_t groups = (n_lines + p.lines_per_group - 1) / p.lines_per_group;
+    p.run_start = nullptr;
+    p.n_groups = 0;
+    // more than one line per group: the runs are cut by work, not by line count (embed_runs_kernel; tuning key embed_batched bit 3
+    // turns it off for A/B)
+    const bool balanced = p.lines_per_group > 1 && !(ctx->tune.embed_batched & 8);
+    if (balanced) {
+        groups = want_groups;
+        if (ctx->embed_runs_cap < groups + 1) {
+            SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_embed_runs) SMT_HIP_CHECK(hipFree(ctx->d_embed_runs));
+            ctx->d_embed_runs = nullptr;
+            ctx->embed_runs_cap = 0;
+            SMT_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_embed_runs), (groups + 1) * sizeof(uint64_t)));
+            ctx->embed_runs_cap = groups + 1;
+        }
+        p.run_start = ctx->d_embed_runs;
+        p.n_groups = groups;
+    }
     const uint64_t blocks = (groups + 15) / 16;    // 256 threads = 16 groups
     SMT_REQUIRE(blocks < (1ull << 24), "too many lines for one embed launch");
     prof_begin(ctx, "embed");
+    if (balanced)
+        hipLaunchKernelGGL(embed_runs_kernel, dim3((unsigned)((groups + 1 + 255) / 256)), dim3(256), 0, ctx->stream, offsets, n_lines, groups,
+                           ctx->d_embed_runs);
     // (A/B: embed_batched bit 1 = ids prefetched one step ahead.  Probed in round 4 and removed: the same kernel at three waves per
     // SIMD without spills -- Zipf 3.11 -> 3.32 ms -- and nontemporal row loads -- 4.68 / 6.77 ms; profiles/r04_k1/)
     // embed_batched bit 2 (tests): the PF kernel leaves every run of 64 tokens or more to the generic kernel

@@ -40,6 +40,40 @@ def test_embed_runs_of_lines_per_group_bit_exact(model):
         assert not got[lens == 0].any()
 
 
+@pytest.mark.parametrize("shape", ["giants_among_short", "all_empty", "one_line_holds_everything", "empty_then_full"])
+def test_embed_runs_of_equal_work(model, gpu_ctx, shape):
+    """Runs are cut by work (tokens + 4 per line; embed_runs_kernel), not by line count: shapes whose cut points are extreme --
+    2048-token lines among four-token ones (groups that own a single line beside groups that own hundreds), nothing but empty
+    lines, one line holding every token (most groups find nothing to do), 30 k empty lines in front of the tokens.  Bit-exact
+    against the oracle, identical to the cut by line count (tuning bit 3), with and without truncation."""
+    table, m = model
+    rng = np.random.default_rng(23)
+    n = 40_000                                             # > 256 CUs x 64 groups: more than one line per group
+    if shape == "giants_among_short":
+        lens = np.full(n, 4)
+        lens[rng.choice(n, size=60, replace=False)] = 2048
+    elif shape == "all_empty":
+        lens = np.zeros(n, dtype=np.int64)
+    elif shape == "one_line_holds_everything":
+        lens = np.zeros(n, dtype=np.int64)
+        lens[n // 3] = 300_000
+    else:
+        lens = np.concatenate([np.zeros(30_000, dtype=np.int64), rng.integers(1, 40, size=n - 30_000)])
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    ids = rng.integers(0, 5000, size=int(offsets[-1])).astype(np.uint32)
+    for cap in (2048, 7):
+        ref = orc.embed_lines(table, ids, offsets, normalize=True, max_tokens=cap)
+        got, _ = m.embed(ids, offsets, max_tokens=cap)
+        assert np.array_equal(got, ref), (shape, cap)
+        gpu_ctx.set_tuning("embed_batched", 3 | 8)
+        try:
+            by_lines, _ = m.embed(ids, offsets, max_tokens=cap)
+        finally:
+            gpu_ctx.set_tuning("embed_batched", 3)
+        assert np.array_equal(by_lines, ref), (shape, cap)
+
+
 def test_embed_runs_too_long_for_32_bit_positions_take_the_generic_kernel(model, gpu_ctx):
     """The default kernel counts token positions in 32 bits from the first token of a group's run and leaves runs that do not fit
     (2^32 tokens) to the generic kernel launched behind it.  Tuning bit 2 of embed_batched lowers that limit to 64 tokens so the
