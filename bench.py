@@ -237,6 +237,8 @@ class ClockSampler:
                     samples.append(self._sample())
                     stop.wait(0.02)
 
+            import gc
+            gc.collect()          # (the collector is disabled while the legs run: run())
             th = None
             if self.dev:
                 th = threading.Thread(target=loop, daemon=True)
@@ -273,6 +275,13 @@ class ClockSampler:
 
 
 def run(args, under_launcher):
+    # Python's cyclic collector stays out of the timed regions: with torch imported a full collection takes 30-45 ms and is triggered
+    # by allocation COUNTS -- tools/sweep_routes.py caught one inside a 20-call loop of 60 us calls (the ~39th search of a process,
+    # every time).  Everything timed here is reference-counted; a collection runs at the start of every leg instead.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -465,8 +465,10 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *                        operand image: f16 x 1 from 128 queries, f16 x 2 below, shards up to 2^28 rows
  *   corpus_image (1/0)   corpora the library owns build and keep their fp16 operand image (smt_corpus_prepack)
  *   gemm_image (1/0)     batched searches read the image when the corpus has one
- *   image_scan_min_rows  shards of at least this many rows (1 500 000; 0 = never) that HAVE their image answer ONE query
- *                        from it as well (2..7 queries from a third of that), and build it at their fourth small search
+ *   image_scan_min_rows  shards of at least this many rows (1 500 000; 0 = never) answer ONE query from their image as well
+ *                        (3..7 queries from two thirds of that), and build it at their fourth small search if they have none
+ *   image_use_min_rows   a shard that already HAS its image answers one query from it from this many rows (600 000), two from
+ *                        5/12 of it, three and more from 1/60 (unfiltered calls; 0 = only the rule above)
  *   gemm_buffered (1/0)  A/B switch of the LDS nomination buffer
  *   gemm_split_last (0/1/2)  levels run in two parts with a select pass in between: 0 none, 1 a ratio-16 last level, 2 (default)
  *                        also the first level after the bootstrap

@@ -63,6 +63,7 @@ struct Tuning {
     int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
     int gemm_image = 1;         // 1: batched searches read the corpus' fp16 operand image when it has one (0: A/B only)
     int64_t image_scan_min_rows = 1500000;   // shards this large answer ONE query from the operand image too, when they have one; 2..7 queries from a third of this (0: never)
+    int64_t image_use_min_rows = 600000;     // a corpus that already HAS its image answers one query from it from this many rows (unfiltered calls), two from 5/12 of it, three and more from 1/60 (0: only the image_scan_min_rows rule)
     int corpus_image = 1;       // 1: a corpus this library owns builds its operand image at the first batch of >= 8 queries (>= 64 Ki rows)
     int embed_batched = 3;      // bit 0: K1 finishes parked lines wave-wide; bit 1: token ids prefetched one step ahead (A/B only)
     int gemm_split_last = 2;    // a streamed K3 sweep runs a thin-threshold level in two parts with a select pass in between: 1 = its last level (ratio >= 16), 2 = also the quarter-corpus level of a bootstrap plan (0: none; A/B)
@@ -72,7 +73,7 @@ struct Tuning {
     int gemm_dma_nt = 1;        // 1: the LDS-row kernel's row DMA carries the nt cache policy (streamed once: 1.99 -> 1.84 ms at 32 x 10 M)
     int64_t fallback_batch_min_rows = 100000;   // >= 2 uncertain queries of a call on a shard this large are re-answered by ONE batched threshold pass
     int guard_band = 8;         // K2 / K3 nominate min(64, top_k + guard_band) rows per list (8..56)
-    int gemm_min_nq = 5;        // batches of this many queries (up to 7) take K3 when the shard has gemm_min_rows_small rows; 8+ always do
+    int gemm_min_nq = 5;        // batches of this many queries (up to 7) take K3 (document subsets: when rows x queries >= 1.2 x gemm_min_rows_small); 8+ always do; up to two queries fewer take it between 1/50 and 4/5 of gemm_min_rows_small rows
     int64_t gemm_min_rows_small = 1000000;   // K3 from gemm_min_nq queries when rows x queries >= 1.2 x this (search.cpp topk_dispatch)
     int gemm_nominate = 0;      // gemm_rowreg_kernel: 0 auto (shards <= 32 M rows: f16 x 2 from 128 queries, f16 x 1 from 256), 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1
     int gemm_rowreg = 1;        // 1: with gemm_bf16x3, unfiltered batches use gemm_rowreg_kernel (coalesced row loads + LDS transpose)

@@ -332,6 +332,15 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     const uint64_t image_min = (uint64_t)ctx->tune.image_scan_min_rows * (a.nq >= 3 ? 2 : 3) / 3;
     const bool scan_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && whole &&
                             ctx->tune.image_scan_min_rows > 0 && scanned >= image_min;
+    // Round 5, late: every route timed alone across sizes (profiles/r05_sweep_crossover.json, tools/sweep_crossover.py; us per host
+    // call, scan kernel | batched kernel over the image): ONE query 500 k rows 110 | 114, 700 k 139 | 132, 1 M 181 | 155, 1.5 M 254 | 193;
+    // TWO 200 k 91 | 92, 300 k 103 | 95, 500 k 130 | 111, 1 M 200 | 156; THREE 50 k 88 | 66, 100 k 104 | 88, 1 M 259 | 161; four and more:
+    // the image at every size (1000 rows: 80 | 70).  The batched call lost its host read-back in this round and with it ~25 us: an
+    // image that EXISTS is used from image_use_min_rows (600 k) rows by one query, 5/12 of that by two, 1/60 by three and more
+    // (unfiltered calls; building one for a corpus that has none keeps the thresholds above).
+    const uint64_t use_min = (uint64_t)ctx->tune.image_use_min_rows * (a.nq >= 3 ? 1 : a.nq == 2 ? 25 : 60) / 60;
+    const bool use_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && whole && a.n_ranges == 0 && ctx->tune.image_scan_min_rows > 0 &&
+                           ctx->tune.image_use_min_rows > 0 && scanned >= use_min;
     if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&
         ++corpus->small_searches >= 4) {
         const void *img;
@@ -340,7 +349,7 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
         if (int rc_img = corpus_image_sync(corpus, a.nq, &img, &zero)) return rc_img;
         if (corpus->image_mode == 1) corpus->image_mode = 0;   // (-1 when there was no room)
     }
-    const bool image_scan = scan_sized && corpus->image && corpus->image_mode >= 0;
+    const bool image_scan = (scan_sized || use_sized) && corpus->image && corpus->image_mode >= 0;
     // Round 4 (bootstrap level: three launches and three select passes fewer per batch) moved the crossover down; measured again
     // (profiles/r04_k2_k3_small.json, us per device-resident call, K2 | K3, no image): 400 k rows 3 queries 175 | 172, 4: 182 | 170,
     // 5: 244 | 171; 200 k rows 4: 115 | 134, 5: 152 | 133, 7: 210 | 138; 100 k rows 5: 104 | 120, 7: 141 | 129; 1 M rows 2: 236 | 275,
@@ -348,8 +357,16 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     // With the chunk-wise reduction (us per call, K2 | K3, profiles/r04_k2_k3_small.json refreshed): 1 M rows 2 queries 172 | 264, 4: 230 |
     // 270, 5: 379 | 280; 400 k rows 4: 134 | 161, 5: 196 | 162; 100 k rows 5: 98 | 111, 7: 133 | 117; 2 M rows 4: 381 | 455, 5: 672 | 475 --
     // up to four queries stay on the scan kernel (gemm_min_nq = 5), five to seven move as before.
+    // Same sweep, scan kernel | batched kernel over f32 rows: FIVE queries 1000 rows 89 | 76, 100 k 131 | 99, 2 M 709 | 472 -- the batched
+    // kernel at every size (unfiltered; the rows x queries bound above stays for document subsets, whose tile table is one more
+    // launch); THREE 50 k 88 | 79, 300 k 146 | 129, 700 k 213 | 208, 1 M 259 | 266; FOUR 50 k 95 | 80, 300 k 152 | 129, 1 M 266 | 261, 1.5 M
+    // 340 | 360; TWO: the scan kernel everywhere (2 M: 345 | 443).  So up to two queries below gemm_min_nq (three, four) take the
+    // batched kernel in the band [small / 50, 0.8 small] = 20 k .. 800 k rows.
+    const bool mid_band = a.n_ranges == 0 && a.nq >= 3 && a.nq + 2 >= (uint32_t)ctx->tune.gemm_min_nq && small > 0 &&
+                          scanned >= small / 50 && scanned <= small / 5 * 4;
     const bool batched = a.nq >= 8 ||
-                         (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && scanned * a.nq >= small + small / 5) || image_scan;
+                         (fast_k3 && a.nq >= (uint32_t)ctx->tune.gemm_min_nq && (a.n_ranges == 0 || scanned * a.nq >= small + small / 5)) ||
+                         (fast_k3 && mid_band) || image_scan;
     if (batched && fast_k3 && whole) {
         if (int rc_img = corpus_image_sync(corpus, a.nq, &a.image, &a.image_zero)) return rc_img;
     }
