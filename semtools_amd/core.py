@@ -561,6 +561,8 @@ class ShardedCorpus:
         nq = q.shape[0]
         if out_cap is None:
             out_cap = max(int(top_k), 1)
+            if max_distance is not None and mode == L.MODE_DOCUMENTS:
+                out_cap = max(min(self.rows, 1 << 16), 1)     # (every row under the threshold: a first guess, grown on SMT_E_TRUNCATED)
         rng, n_rng = _ranges_arg(ranges)
         while True:
             out_rows = np.empty((nq, out_cap), dtype=np.uint64)
