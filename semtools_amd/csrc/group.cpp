@@ -690,7 +690,10 @@ static int exchange_host_lists(smt_group *g, const std::vector<std::vector<Local
     int rc;
     std::vector<HitSpan> src;
     // every rank lives in this process (one-process and logical groups): the lists are all here already -- nothing travels
-    if (g->n_local == g->n_ranks) {
+    // ($SEMTOOLS_GROUP_HOST_LISTS=exchange sends them through the devices anyway: the tests' way to run the multi-process path below
+    // on the logical ranks of one GPU)
+    const char *force = getenv("SEMTOOLS_GROUP_HOST_LISTS");
+    if (g->n_local == g->n_ranks && !(force && std::string(force) == "exchange")) {
         for (uint32_t q = 0; q < nq; ++q) {
             src.clear();
             for (int i = 0; i < g->n_local; ++i) src.push_back({local[i][q].rows.data(), local[i][q].dist.data(), local[i][q].rows.size()});

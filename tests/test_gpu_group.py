@@ -136,6 +136,32 @@ def test_logical_shards_equal_the_unsharded_search(plain, n_shards, transport):
     g.close()
 
 
+@pytest.mark.parametrize("n_shards", [2, 5])
+def test_variable_length_lists_through_the_exchange_of_a_multi_process_group(plain, n_shards, monkeypatch):
+    """Threshold mode and k > 56 produce per-rank host lists.  A one-process group merges them where they are; ranks in different
+    processes send them through a count all-gather and one padded all-gather.  $SEMTOOLS_GROUP_HOST_LISTS=exchange runs THAT path
+    on logical ranks (the only way to run it on one GPU): same answers as the unsharded search, with and without it."""
+    import semtools_amd as smt
+
+    emb, c = plain
+    qs = synth.unit_query(8, nq=5)
+    cases = [dict(top_k=3, max_distance=0.9), dict(top_k=3, max_distance=0.2), dict(top_k=100), dict(top_k=64), dict(top_k=2000),
+             dict(top_k=5, max_distance=0.93, ranges=[(10, 900), (2000, 2600)])]
+    for how in ("exchange", "direct"):
+        if how == "exchange":
+            monkeypatch.setenv("SEMTOOLS_GROUP_HOST_LISTS", "exchange")
+        else:
+            monkeypatch.delenv("SEMTOOLS_GROUP_HOST_LISTS", raising=False)
+        g = smt.Group.logical(0, n_shards)
+        sc = smt.ShardedCorpus(g, rows=emb)
+        try:
+            for kw in cases:
+                _same(sc.search(qs, **kw), c.search(qs, **kw))
+        finally:
+            sc.close()
+            g.close()
+
+
 @pytest.mark.parametrize("transport", ["peer", "copy"])
 def test_sharded_device_form_and_file_round_trip(plain, tmp_path, transport):
     """smt_sharded_search_topk_device (what bench.py --gpus N times) + save/load through the corpus file."""
