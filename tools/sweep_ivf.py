@@ -1,76 +1,51 @@
-"""IVF index quality sweep on a corpus whose structure does NOT match the index: n_centers topics (default 20 000)
-against nlist = 4096 lists, queries drawn independently from the generative model (not perturbed corpus rows).
-For both index kinds (0 = global residual PQ, 1 = per-list PCA codes): build time, then recall@k vs the exact batched
-search and device-resident queries/s over nprobe x re-score depth."""
-import argparse
-import json
-import os
-import sys
-import time
+"""The IVF index across its query parameters on a 10 M-row clustered corpus (per-list PCA codes): recall@k against the exact batched
+search and ms per device-form call over nprobe x rerank, top_k, and query counts 1 .. 10 000.  Recall must not fall when nprobe or
+rerank grow; time must not fall when they grow.  python tools/sweep_ivf.py > gpurun_out/sweep_ivf.json"""
+import gc, json, os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import semtools_amd as smt
+from tests import synth
 
-import numpy as np
-import torch
+gc.disable()
+dev = torch.device("cuda", 0)
+ctx = smt.Context(0)
+rows = 10_000_000
+gen = synth.clustered_model_torch(20000, 8, 11, dev)
+x = synth.clustered_sample_torch(gen, rows, 12)
+q_all = synth.clustered_sample_torch(gen, 10000, 13)
+del gen
+torch.cuda.synchronize()   # (the library works on its own stream: the rows must exist before the index is built from them)
+corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
+ix = smt.IvfPq(corpus, nlist=4096, train_iters=10, local_pca=True)
+out = {}
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import semtools_amd as smt  # noqa: E402
-from tests import synth  # noqa: E402
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--topics", type=int, default=20000)
-    ap.add_argument("--nlist", type=int, default=4096)
-    ap.add_argument("--nq", type=int, default=1000)
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--kinds", type=int, nargs="+", default=[1, 0])
-    ap.add_argument("--nprobe", type=int, nargs="+", default=[1, 2, 4, 8, 16, 32, 64])
-    ap.add_argument("--rerank", type=int, nargs="+", default=[32, 64, 128, 512])
-    ap.add_argument("--out", default=None)
-    args = ap.parse_args()
-    dev = torch.device("cuda:0")
-    model = synth.clustered_model_torch(args.topics, 8, 11, dev)
-    x = synth.clustered_sample_torch(model, args.rows, 12)
-    q = synth.clustered_sample_torch(model, args.nq, 13)
-    torch.cuda.synchronize()
-    ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=args.rows)
-    qh = q.cpu().numpy()
+def run(nq, k, nprobe, rerank, exact=None):
+    qd = q_all[:nq].contiguous()
+    o_rows = torch.empty((nq, k), dtype=torch.int64, device=dev); o_dist = torch.empty((nq, k), dtype=torch.float64, device=dev)
+    ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr()); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    exact = corpus.search(qh, top_k=args.k)
-    exact_s = time.perf_counter() - t0
-    out = dict(rows=args.rows, topics=args.topics, nlist=args.nlist, nq=args.nq, k=args.k, exact_batch_s=round(exact_s, 4),
-               queries="independent draws from the generative model", kinds={})
-    o_rows = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
-    o_dist = torch.empty((args.nq, args.k), dtype=torch.float64, device=dev)
-    for kind in args.kinds:
-        t0 = time.perf_counter()
-        ix = smt.IvfPq(corpus, nlist=args.nlist, train_iters=10, local_pca=bool(kind))
-        build_s = time.perf_counter() - t0
-        info = ix.info()
-        rec = dict(kind="per-list PCA codes" if kind else "global residual PQ", build_s=round(build_s, 3), build_ms=info["build_ms"],
-                   index_MB=round(info["index_bytes"] / 1e6, 1), sweep=[])
-        print(json.dumps({k: v for k, v in rec.items() if k != "sweep"}), flush=True)
-        for nprobe in args.nprobe:
-            for rerank in args.rerank:
-                ix.search_device(q.data_ptr(), args.nq, args.k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
-                ctx.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    ix.search_device(q.data_ptr(), args.nq, args.k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
-                ctx.synchronize()
-                dt = (time.perf_counter() - t0) / 3
-                got = o_rows.cpu().numpy().view(np.uint64)
-                hit = sum(len(set(got[i].tolist()) & set(exact[i][0].tolist())) for i in range(args.nq))
-                row = dict(nprobe=nprobe, rerank=rerank, recall=round(hit / (args.nq * args.k), 4), ms_per_batch=round(dt * 1e3, 3),
-                           qps=round(args.nq / dt))
-                rec["sweep"].append(row)
-                print(json.dumps(row), flush=True)
-        out["kinds"][str(kind)] = rec
-        ix.close()
-    if args.out:
-        json.dump(out, open(args.out, "w"), indent=1)
+    for _ in range(3): ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    rec = None
+    if exact is not None:
+        got = o_rows.cpu().numpy().view(np.uint64)
+        rec = sum(len(set(got[i].tolist()) & set(exact[i][0].tolist())) for i in range(nq)) / (nq * k)
+    return round(ms, 3), (round(rec, 4) if rec is not None else None)
 
-
-if __name__ == "__main__":
-    main()
+qh = q_all[:1000].cpu().numpy()
+exact10 = corpus.search(qh, top_k=10)
+for nprobe in (1, 4, 8, 32, 128, 512):
+    for rerank in (16, 64, 128, 512):
+        out[f"nq=1000 k=10 nprobe={nprobe} rerank={rerank}"] = dict(zip(("ms", "recall"), run(1000, 10, nprobe, rerank, exact10)))
+        print(f"nprobe={nprobe} rerank={rerank}", out[f"nq=1000 k=10 nprobe={nprobe} rerank={rerank}"], file=sys.stderr)
+for k in (1, 3, 10, 30, 56):
+    ex = corpus.search(qh[:200], top_k=k)
+    out[f"nq=200 k={k} nprobe=8 rerank=128"] = dict(zip(("ms", "recall"), run(200, k, 8, 128, ex)))
+    print(f"k={k}", out[f"nq=200 k={k} nprobe=8 rerank=128"], file=sys.stderr)
+for nq in (1, 8, 64, 512, 4096, 10000):
+    ms, _ = run(nq, 10, 8, 128)
+    out[f"nq={nq} k=10 nprobe=8 rerank=128"] = {"ms": ms, "us_per_query": round(ms / nq * 1e3, 2)}
+    print(f"nq={nq}", out[f"nq={nq} k=10 nprobe=8 rerank=128"], file=sys.stderr)
+print(json.dumps(out, indent=1))
