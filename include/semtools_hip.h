@@ -65,7 +65,9 @@ typedef struct smt_range {
 
 /* ------------------------------------------------------------------ context */
 
-/* Bind to GPU `device` and create a private (non-blocking) HIP stream. */
+/* Bind to GPU `device` and create a private (non-blocking) HIP stream.  Everything the library enqueues is ordered on THAT stream
+ * only: device memory handed in (smt_corpus_from_device, the *_device entry points) must be complete before the call -- synchronise
+ * the stream that produced it, or create the context on that stream (below). */
 int smt_ctx_create(int device, smt_ctx **out);
 /* Same, but enqueue on an existing hipStream_t owned by the caller (e.g. the
  * host framework's current stream).  NULL here means THE NULL STREAM. */
