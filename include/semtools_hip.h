@@ -463,7 +463,7 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *   gemm_rowreg (1/0)    unfiltered batches run gemm_rowreg_kernel (coalesced row loads + LDS transpose)
  *   gemm_nominate (0/1/2/3) how the row-register kernel nominates: 1 bf16 x 3 (band 7e-5), 2 f16 x 2 (a third fewer MFMAs,
  *                        band 5.2e-4, guard band >= 16), 3 f16 x 1 (a third of the MFMAs, band 1.0e-3, guard band >= 24);
- *                        0 = on shards <= 32 M rows f16 x 1 from 256 queries, f16 x 2 from 128, bf16 x 3 below; with the corpus'
+ *                        0 = on shards <= 32 M rows f16 x 1 from 129 queries, f16 x 2 at 128, bf16 x 3 below; with the corpus'
  *                        operand image: f16 x 1 from 128 queries, f16 x 2 below, shards up to 2^28 rows
  *   corpus_image (1/0)   corpora the library owns build and keep their fp16 operand image (smt_corpus_prepack)
  *   gemm_image (1/0)     batched searches read the image when the corpus has one

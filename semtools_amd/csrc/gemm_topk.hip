@@ -379,7 +379,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
                         (!filtered || (a.range_tile_prefix != nullptr && tiles_dense(a.n_virtual, a.n_vtiles)));
     // How gemm_rowreg_kernel nominates (tuning key gemm_nominate: 0 auto, 1 bf16 x 3, 2 f16 x 2, 3 f16 x 1).  The fp16 modes
     // issue 2/3 resp. 1/3 of the MFMAs of bf16 x 3 -- what large batches are bound by -- for a wider certificate band
-    // (5.2e-4 / 1.0e-3 against 7e-5): auto takes f16 x 2 from 128 queries and f16 x 1 from 256 queries on shards of at most
+    // (5.2e-4 / 1.0e-3 against 7e-5): auto takes f16 x 2 from 128 queries and f16 x 1 from 129 (until round 5: 256) queries on shards of at most
     // 32 M rows (the rank spacing of the distances shrinks with the shard; at 10 M random rows the k-th and k+8-th distances
     // are ~8e-3 apart), provided the lists have room for the wider guard band.  Small batches are HBM-bound: bf16 x 3.
     // ... and on larger shards when the operand image is there: at 100 M rows one query takes 7.6 ms from the image against
@@ -394,8 +394,11 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // fit the four slots of the 1 KiB query image; <= 96: equal)
     // (every automatic fp16 choice needs room for its guard band in the 64-entry lists -- k + 24 resp. k + 16 -- or most queries
     // would fail their certificate and be re-answered exhaustively: bf16 x 3 then)
+    // (round 5, late, tools/probe_mid.py -> profiles/r05_nominate_modes.json, f32 rows, ms per call, f16 x 2 | f16 x 1: 10 M rows 160
+    // queries 2.73 | 2.14, 200: 3.28 | 1.95, 224: 3.22 | 1.98; 2 M rows 200: 0.78 | 0.59; 128 queries: equal; no query re-answered --
+    // five to seven query tiles are no longer HBM-bound with two MFMA passes: f16 x 1 from 129 queries, not 256)
     const bool f16x1 = rowreg && (ctx->tune.gemm_nominate == 3 ||
-                                  (auto_fp16 && (nqt >= 8 || (have_image && nqt >= 4)) && a.k_out + 24 <= 64));
+                                  (auto_fp16 && (nqt >= 5 || (have_image && nqt >= 4)) && a.k_out + 24 <= 64));
     const bool f16x2 = rowreg && !f16x1 && (ctx->tune.gemm_nominate == 2 || (auto_fp16 && (nqt >= 4 || have_image) && a.k_out + 16 <= 64));
     const bool use_image = have_image && (f16x1 || f16x2);
     // (Round 5 built the obvious alternative for ONE to FOUR queries over the image -- a single pass with per-wave candidate lists,
