@@ -469,8 +469,9 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *   gemm_image (1/0)     batched searches read the image when the corpus has one
  *   image_scan_min_rows  shards of at least this many rows (1 500 000; 0 = never) answer ONE query from their image as well
  *                        (3..7 queries from two thirds of that), and build it at their fourth small search if they have none
- *   image_use_min_rows   a shard that already HAS its image answers one query from it from this many rows (600 000), two from
- *                        5/12 of it, three and more from 1/60 (unfiltered calls; 0 = only the rule above)
+ *   image_use_min_rows   a shard that already HAS its image answers one query from it from this many rows (400 000), two from
+ *                        1/5 of it, three and more from 1/60 (unfiltered calls; 0 = only the rule above)
+ *   gemm_boot_fine (1/0) corpora of 2 Ki .. 32 Ki tiles take their first thresholds from every 2nd / 4th / 8th tile (0: every 16th)
  *   gemm_buffered (1/0)  A/B switch of the LDS nomination buffer
  *   gemm_split_last (0/1/2)  levels run in two parts with a select pass in between: 0 none, 1 a ratio-16 last level, 2 (default)
  *                        also the first level after the bootstrap

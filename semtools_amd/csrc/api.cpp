@@ -462,6 +462,7 @@ try {
     else if (k == "gemm_image") ctx->tune.gemm_image = (int)value;
     else if (k == "corpus_image") ctx->tune.corpus_image = (int)value;
     else if (k == "image_scan_min_rows") ctx->tune.image_scan_min_rows = value < 0 ? 0 : value;
+    else if (k == "gemm_boot_fine") ctx->tune.gemm_boot_fine = (int)value;
     else if (k == "image_use_min_rows") ctx->tune.image_use_min_rows = value < 0 ? 0 : value;
     else if (k == "prof_every") ctx->tune.prof_every = (int)value;
     else if (k == "merge_on_aux") {

@@ -63,10 +63,11 @@ struct Tuning {
     int async_select = 0;       // 1: single-query top-k searches overlap their select stage with the next scan
     int gemm_image = 1;         // 1: batched searches read the corpus' fp16 operand image when it has one (0: A/B only)
     int64_t image_scan_min_rows = 1500000;   // shards this large answer ONE query from the operand image too, when they have one; 2..7 queries from a third of this (0: never)
-    int64_t image_use_min_rows = 600000;     // a corpus that already HAS its image answers one query from it from this many rows (unfiltered calls), two from 5/12 of it, three and more from 1/60 (0: only the image_scan_min_rows rule)
+    int64_t image_use_min_rows = 400000;     // a corpus that already HAS its image answers one query from it from this many rows (unfiltered calls), two from 1/5 of it, three and more from 1/60 (0: only the image_scan_min_rows rule)
     int corpus_image = 1;       // 1: a corpus this library owns builds its operand image at the first batch of >= 8 queries (>= 64 Ki rows)
     int embed_batched = 3;      // bit 0: K1 finishes parked lines wave-wide; bit 1: token ids prefetched one step ahead (A/B only)
     int gemm_split_last = 2;    // a streamed K3 sweep runs a thin-threshold level in two parts with a select pass in between: 1 = its last level (ratio >= 16), 2 = also the quarter-corpus level of a bootstrap plan (0: none; A/B)
+    int gemm_boot_fine = 1;     // 1: corpora of 2 Ki .. 32 Ki tiles bootstrap over every 2nd / 4th / 8th tile (0: every 16th, as up to 128 Ki tiles; A/B)
     int gemm_bootstrap = 1;     // 1: gemm_rowreg_kernel batches start from a bootstrap level of tile minima (0: the round-1..3 plan of appended levels; A/B only)
     int gemm_buffered = 1;      // 1: gemm_rowreg_kernel nominations go through the wave's LDS buffer (0: straight to the lists; A/B only)
     int gemm_qsplit = 1;        // 1: K3 levels with fewer row-tile groups than CUs split the query tiles over blocks

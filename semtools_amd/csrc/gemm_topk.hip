@@ -449,7 +449,13 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     // appended level over all tiles follows; beyond that every 64th (x 16 until <= BOOTSTRAP_MAX_TILES tiles are left).
     uint64_t boot_stride = 1;
     if (bootstrap && plan_tiles > 2048) {
-        boot_stride = plan_tiles <= (uint64_t)131072 ? 16 : 64;
+        // Graded since the end of round 5 (tools/ab_boot_stride.py, profiles/r05_boot_stride.txt; ms per call, 1000 queries, every 16th
+        // tile | the stride below): 66 k rows 0.67 | 0.44, 131 k 0.53 | 0.41, 262 k 0.59 | 0.51, 524 k 0.75 | 0.69, 1 M 1.01 | 1.02; 256
+        // queries 66 k 0.27 | 0.19, 262 k 0.30 | 0.21, 524 k 0.34 | 0.26 -- a 1/16 sample of a SMALL corpus leaves thresholds that admit
+        // 16 k' rows per query into few tiles (4 nominations per product at 2050 tiles), and the bootstrap's own pass is cheap there.
+        // (tuning key gemm_boot_fine = 0: every 16th tile up to 131 072 tiles, as in round 4)
+        boot_stride = !ctx->tune.gemm_boot_fine ? (plan_tiles <= (uint64_t)131072 ? 16 : 64)
+                      : plan_tiles <= 4096 ? 2 : plan_tiles <= 8192 ? 4 : plan_tiles <= 32768 ? 8 : plan_tiles <= (uint64_t)131072 ? 16 : 64;
         while ((plan_tiles + boot_stride - 1) / boot_stride > (uint64_t)BOOTSTRAP_MAX_TILES) boot_stride *= 16;
     }
     const uint64_t boot_tiles = bootstrap ? (plan_tiles + boot_stride - 1) / boot_stride : 0;
@@ -501,7 +507,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     //    <= LEVEL0_MAX_TILES tiles appended without a threshold.
     //  * bootstrap plan (gemm_rowreg_kernel, round 4): a bootstrap level of tile minima gives the first thresholds; then
     //      <= 2048 tiles: bootstrap over ALL tiles, one appended level over all of them (twice the work of a corpus of <= 64 k rows);
-    //      <= 128 Ki tiles: bootstrap over every 16th, one appended level over ALL tiles (1/16 multiplied twice; admits ~16 k');
+    //      <= 128 Ki tiles: bootstrap over every 2nd / 4th / 8th / 16th (4 Ki / 8 Ki / 32 Ki / 128 Ki tiles), one appended level over ALL tiles;
     //      larger: bootstrap over every 64th (x 16 while more than BOOTSTRAP_MAX_TILES are left), appended levels at strides
     //      ... 64, 4 -- the first visits every multiple of its stride, the bootstrap's tiles included -- and a LAST level of
     //      ratio 4: the 3/4 of the corpus it holds are appended under thresholds a quarter of the corpus produced (~4 k' rows per

@@ -336,9 +336,11 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     // call, scan kernel | batched kernel over the image): ONE query 500 k rows 110 | 114, 700 k 139 | 132, 1 M 181 | 155, 1.5 M 254 | 193;
     // TWO 200 k 91 | 92, 300 k 103 | 95, 500 k 130 | 111, 1 M 200 | 156; THREE 50 k 88 | 66, 100 k 104 | 88, 1 M 259 | 161; four and more:
     // the image at every size (1000 rows: 80 | 70).  The batched call lost its host read-back in this round and with it ~25 us: an
-    // image that EXISTS is used from image_use_min_rows (600 k) rows by one query, 5/12 of that by two, 1/60 by three and more
-    // (unfiltered calls; building one for a corpus that has none keeps the thresholds above).
-    const uint64_t use_min = (uint64_t)ctx->tune.image_use_min_rows * (a.nq >= 3 ? 1 : a.nq == 2 ? 25 : 60) / 60;
+    // image that EXISTS is used from image_use_min_rows rows by one query, 1/5 of that by two, 1/60 by three and more (unfiltered
+    // calls; building one for a corpus that has none keeps the thresholds above).  Measured once more after the bootstrap stride of
+    // mid-sized corpora was graded (gemm_topk.hip; same table): ONE query 300 k rows 83 | 86, 500 k 111 | 105; TWO 50 k 68 | 68, 100 k
+    // 77 | 71, 300 k 104 | 86 -- image_use_min_rows = 400 k.
+    const uint64_t use_min = (uint64_t)ctx->tune.image_use_min_rows * (a.nq >= 3 ? 1 : a.nq == 2 ? 12 : 60) / 60;
     const bool use_sized = fast_k3 && ctx->tune.gemm_image && !a.allow_async && whole && a.n_ranges == 0 && ctx->tune.image_scan_min_rows > 0 &&
                            ctx->tune.image_use_min_rows > 0 && scanned >= use_min;
     if (scan_sized && a.nq < 8 && !corpus->image && corpus->owned && corpus->image_mode == 0 && ctx->tune.corpus_image != 0 &&

@@ -107,12 +107,10 @@ def test_batched_sorted_corpus_is_still_exact(gpu_ctx):
     c.close()
 
 
-def test_candidate_buffer_overflow_falls_back_to_exact_scan(gpu_ctx):
-    """Adversarial order for the level thresholds: every tile the early levels sample (tile index = 0 mod 16)
-    holds far rows, everything else is near the queries, so the main level floods the 2048-slot candidate buffers.
-    The overflow flag must route those queries through the exact K2 scan: results stay exact."""
-    import semtools_amd as smt
-
+def _flooding_corpus(gpu_ctx, stride):
+    """Adversarial order for the level thresholds: every tile the bootstrap level samples (tile index = 0 mod its stride: 2 for a
+    corpus of 2188 tiles since round 5, 16 with tuning key gemm_boot_fine = 0) holds far rows, everything else is near the queries."""
+    gpu_ctx.set_tuning("gemm_boot_fine", 1 if stride == 2 else 0)
     n = 70_000
     rng = np.random.default_rng(3)
     qs = synth.unit_query(8, nq=9)
@@ -120,15 +118,29 @@ def test_candidate_buffer_overflow_falls_back_to_exact_scan(gpu_ctx):
     near = qs[rng.integers(0, 9, n)] + 0.05 * rng.standard_normal((n, 256)).astype(np.float32)
     near /= np.linalg.norm(near, axis=1, keepdims=True)
     tile = np.arange(n) // 32
-    emb = np.where((tile % 16 == 0)[:, None], far, near).astype(np.float32)
-    c = smt.Corpus(gpu_ctx)
-    c.append(emb)
-    got = c.search(qs, top_k=10)
-    for i in range(9):
-        res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
-        assert got[i][0].tolist() == [r["match_line"] for r in res], i
-        assert np.array_equal(got[i][1], np.array([r["distance"] for r in res]))
-    c.close()
+    return n, qs, np.where((tile % stride == 0)[:, None], far, near).astype(np.float32)
+
+
+@pytest.mark.parametrize("stride", [2, 16])
+def test_candidate_buffer_overflow_falls_back_to_exact_scan(gpu_ctx, stride):
+    """The main level floods the 2048-slot candidate buffers (_flooding_corpus).
+    The overflow flag must route those queries through the exact K2 scan: results stay exact."""
+    import semtools_amd as smt
+
+    try:
+        n, qs, emb = _flooding_corpus(gpu_ctx, stride)
+        c = smt.Corpus(gpu_ctx)
+        c.append(emb)
+        gpu_ctx.uncertain_count()
+        got = c.search(qs, top_k=10)
+        assert gpu_ctx.uncertain_count() >= 1          # (the corpus does flood: somebody was re-answered)
+        for i in range(9):
+            res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
+            assert got[i][0].tolist() == [r["match_line"] for r in res], i
+            assert np.array_equal(got[i][1], np.array([r["distance"] for r in res]))
+        c.close()
+    finally:
+        gpu_ctx.set_tuning("gemm_boot_fine", 1)
 
 
 @pytest.mark.parametrize("nq", [8, 33, 70])
@@ -412,7 +424,8 @@ def test_random_shapes_against_the_oracle(gpu_ctx, nominate_with):
         gpu_ctx.set_tuning("gemm_min_nq", 5)
 
 
-def test_device_form_counts_an_overflowed_query_instead_of_synchronising(gpu_ctx):
+@pytest.mark.parametrize("stride", [2, 16])
+def test_device_form_counts_an_overflowed_query_instead_of_synchronising(gpu_ctx, stride):
     """The batched device form (smt_search_topk_device: nothing synchronises) on the corpus that floods the candidate buffers: until
     round 5 launch_gemm_topk read an overflow flag back after every batch (one host synchronisation per call) and re-answered such
     queries with the scan kernel; now the final select flags them like a failed certificate -- counted by the context for the device
@@ -420,28 +433,24 @@ def test_device_form_counts_an_overflowed_query_instead_of_synchronising(gpu_ctx
     import torch
     import semtools_amd as smt
 
-    n = 70_000
-    rng = np.random.default_rng(3)
-    qs = synth.unit_query(8, nq=9)
-    far = synth.unit_rows(n, seed=4, dup_frac=0, zero_frac=0)
-    near = qs[rng.integers(0, 9, n)] + 0.05 * rng.standard_normal((n, 256)).astype(np.float32)
-    near /= np.linalg.norm(near, axis=1, keepdims=True)
-    tile = np.arange(n) // 32
-    emb = np.where((tile % 16 == 0)[:, None], far, near).astype(np.float32)
-    c = smt.Corpus(gpu_ctx)
-    c.append(emb)
-    qd = torch.from_numpy(qs).cuda()
-    o_r = torch.zeros((9, 10), dtype=torch.int64, device="cuda")
-    o_d = torch.zeros((9, 10), dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    gpu_ctx.uncertain_count()
-    c.search_topk_device(qd.data_ptr(), 9, 10, 0, o_r.data_ptr(), o_d.data_ptr())
-    gpu_ctx.synchronize()
-    flagged = gpu_ctx.uncertain_count()
-    inexact = 0
-    rows = o_r.cpu().numpy()
-    for i in range(9):
-        res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
-        inexact += rows[i].tolist() != [r["match_line"] for r in res]
-    assert flagged >= max(inexact, 1), (flagged, inexact)      # this corpus does overflow: at least one query is counted
-    c.close()
+    try:
+        n, qs, emb = _flooding_corpus(gpu_ctx, stride)
+        c = smt.Corpus(gpu_ctx)
+        c.append(emb)
+        qd = torch.from_numpy(qs).cuda()
+        o_r = torch.zeros((9, 10), dtype=torch.int64, device="cuda")
+        o_d = torch.zeros((9, 10), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.uncertain_count()
+        c.search_topk_device(qd.data_ptr(), 9, 10, 0, o_r.data_ptr(), o_d.data_ptr())
+        gpu_ctx.synchronize()
+        flagged = gpu_ctx.uncertain_count()
+        inexact = 0
+        rows = o_r.cpu().numpy()
+        for i in range(9):
+            res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
+            inexact += rows[i].tolist() != [r["match_line"] for r in res]
+        assert flagged >= max(inexact, 1), (flagged, inexact)      # this corpus does overflow: at least one query is counted
+        c.close()
+    finally:
+        gpu_ctx.set_tuning("gemm_boot_fine", 1)
