@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -486,6 +487,20 @@ static bool run_on_threads(int n, const std::function<void(int)> &fn)
     return ok;
 }
 
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+static inline long long mono_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // issuing thread t of T: it issues the shares of local ranks t, t + T, ... (T = one per device for a group of real GPUs)
 static void worker_main(smt_group *g, int t)
 {
@@ -494,27 +509,37 @@ static void worker_main(smt_group *g, int t)
     (void)hipSetDevice(g->ctx[t]->device);   // the thread's current device (every entry point binds again: cheap when unchanged)
     uint64_t seen = 0;
     for (;;) {
-        const std::function<int(int)> *work;
-        {
-            std::unique_lock<std::mutex> lk(w->mu);
-            w->cv_go.wait(lk, [&] { return w->stop || w->epoch != seen; });
-            if (w->stop) return;
-            seen = w->epoch;
-            work = w->work;
+        // the next call: spin for a while (GroupWorkers), then block
+        bool got = false;
+        if (w->spin_ns > 0) {
+            const long long t0 = mono_ns();
+            for (unsigned spins = 1;; ++spins) {
+                if (w->epoch.load(std::memory_order_acquire) != seen || w->stop.load(std::memory_order_acquire)) { got = true; break; }
+                cpu_relax();
+                if ((spins & 127) == 0 && mono_ns() - t0 > w->spin_ns) break;
+            }
         }
+        if (!got) {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->sleepers.fetch_add(1, std::memory_order_seq_cst);
+            w->cv_go.wait(lk, [&] { return w->stop.load(std::memory_order_seq_cst) || w->epoch.load(std::memory_order_seq_cst) != seen; });
+            w->sleepers.fetch_sub(1, std::memory_order_seq_cst);
+        }
+        if (w->stop.load(std::memory_order_acquire)) return;
+        seen = w->epoch.load(std::memory_order_acquire);
+        const std::function<int(int)> *work = w->work;   // (written before the epoch moved)
         for (int i = t; i < g->n_local; i += T) {
             int rc;
             try { rc = (*work)(i); }   // (an exception must reach the caller as a status, not std::terminate the process from this thread)
             catch (const std::bad_alloc &) { set_error("out of host memory"); rc = SMT_E_NOMEM; }
             catch (const std::exception &e) { set_error("%s", e.what()); rc = SMT_E_INVALID; }
-            std::string err = rc ? smt_last_error() : "";   // (thread-local: carried back to the caller's thread)
-            std::lock_guard<std::mutex> lk(w->mu);
-            w->rcs[i] = rc;
-            w->errs[i].swap(err);
+            w->rcs[i] = rc;                                  // (slot i is this thread's until `pending` reaches 0)
+            if (rc) w->errs[i] = smt_last_error();           // (thread-local: carried back to the caller's thread)
+            else w->errs[i].clear();
         }
-        {
+        if (w->pending.fetch_sub(1, std::memory_order_seq_cst) == 1 && w->caller_blocked.load(std::memory_order_seq_cst)) {
             std::lock_guard<std::mutex> lk(w->mu);
-            if (--w->pending == 0) w->cv_done.notify_one();
+            w->cv_done.notify_one();
         }
     }
 }
@@ -538,6 +563,7 @@ static int group_start_workers(smt_group *g)
     g->workers = new (std::nothrow) GroupWorkers();
     if (!g->workers) { set_error("out of host memory"); return SMT_E_NOMEM; }
     g->workers->n_threads = n_threads;
+    if (const char *sp = getenv("SEMTOOLS_GROUP_SPIN_US")) g->workers->spin_ns = std::max(0LL, atoll(sp)) * 1000;
     g->workers->rcs.assign(g->n_local, SMT_OK);
     g->workers->errs.assign(g->n_local, std::string());
     try {
@@ -555,7 +581,7 @@ static void group_stop_workers(smt_group *g)
     if (!w) return;
     {
         std::lock_guard<std::mutex> lk(w->mu);
-        w->stop = true;
+        w->stop.store(true, std::memory_order_seq_cst);
     }
     w->cv_go.notify_all();
     for (auto &t : w->threads) t.join();
@@ -578,15 +604,33 @@ int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool
     if (g->n_local == 1 || !threads) {
         for (int i = 0; i < g->n_local; ++i) run(i);
     } else if (GroupWorkers *w = g->workers) {
-        std::unique_lock<std::mutex> lk(w->mu);
+        // (one caller at a time per group, as for every entry point that takes it)
         w->work = &work;
-        w->pending = w->n_threads;
-        ++w->epoch;
-        w->cv_go.notify_all();
-        w->cv_done.wait(lk, [&] { return w->pending == 0; });
+        w->pending.store(w->n_threads, std::memory_order_relaxed);
+        w->epoch.fetch_add(1, std::memory_order_seq_cst);
+        if (w->sleepers.load(std::memory_order_seq_cst) > 0) {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->cv_go.notify_all();
+        }
+        bool done = false;
+        if (w->spin_ns > 0) {   // the shares of a search are issued in tens of microseconds: wait for them here
+            const long long t0 = mono_ns();
+            for (unsigned spins = 1;; ++spins) {
+                if (w->pending.load(std::memory_order_acquire) == 0) { done = true; break; }
+                cpu_relax();
+                if ((spins & 127) == 0 && mono_ns() - t0 > 20 * w->spin_ns) break;
+            }
+        }
+        if (!done) {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->caller_blocked.store(1, std::memory_order_seq_cst);
+            w->cv_done.wait(lk, [&] { return w->pending.load(std::memory_order_seq_cst) == 0; });
+            w->caller_blocked.store(0, std::memory_order_seq_cst);
+        }
         w->work = nullptr;
-        rcs = w->rcs;
-        errs = w->errs;
+        bool any = false;
+        for (int i = 0; i < g->n_local; ++i) any = any || w->rcs[i] != SMT_OK;
+        if (any) { rcs = w->rcs; errs = w->errs; }
     } else if (!run_on_threads(g->n_local, run)) return SMT_E_NOMEM;
     for (int i = 0; i < g->n_local; ++i)
         if (rcs[i]) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -30,9 +31,17 @@ struct GroupWorkers {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     const std::function<int(int)> *work = nullptr;
-    uint64_t epoch = 0;
-    int pending = 0;
-    bool stop = false;
+    // A search arrives every ~100 us in a pipelined caller: a thread that blocks in the kernel between two of them pays a futex wake
+    // each way, and what that costs is the HOST's business (idle states): the same binary issued an 8-shard search in 56-67 us on
+    // some leases and 85-95 on others.  So both sides SPIN first -- a worker for `spin_ns` after its last share, the caller while the
+    // shares are being issued -- and only then block on the condition variables (the usual two-flag hand-over: whoever is about to
+    // block says so, seq_cst, before its last look at the other side's counter).
+    std::atomic<uint64_t> epoch{0};
+    std::atomic<int> pending{0};
+    std::atomic<int> sleepers{0};        // workers blocked (or about to block) on cv_go
+    std::atomic<int> caller_blocked{0};  // the caller is blocked (or about to block) on cv_done
+    std::atomic<bool> stop{false};
+    long long spin_ns = 100000;          // $SEMTOOLS_GROUP_SPIN_US (0: block at once)
     std::vector<int> rcs;
     std::vector<std::string> errs;
 };
