@@ -630,8 +630,17 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     }
     SEL_STAMP(0);
 
-    // ---- ONE global-latency phase: every key of the L lists goes to registers (<= 36 per thread)
     static_assert(KREG == 8 || KREG == (SEL_MAX_LISTS * 72 + SEL_THREADS - 1) / SEL_THREADS, "8 or 36");
+    if (L == 1) {
+        // ONE list per query (the batched kernel's level select left the k' best of every query sorted at the head of its buffer;
+        // an index search with one probed segment): it IS the answer's candidate set -- no column bounds, no compaction, no ranks.
+        // (Round 5: those three phases were ~7 us of dependent latencies in front of every batched call's rescoring, 10 % of a
+        // small batch over a small corpus.)
+        if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; }
+        for (int t = threadIdx.x; t < kp; t += blockDim.x) { s_best[t] = lists[t]; s_rank[t] = 0; }
+        __syncthreads();
+    } else {
+    // ---- ONE global-latency phase: every key of the L lists goes to registers (<= 36 per thread)
     const int M = L * kp;
     const int n_round = (M + SEL_THREADS - 1) / SEL_THREADS;  // block-uniform
     key_t64 kreg[KREG];
@@ -738,8 +747,9 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         }
     }
     __syncthreads();
-    SEL_STAMP(4);
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[8] = (unsigned long long)S;
+    }   // (L > 1)
+    SEL_STAMP(4);
 
     // ---- exact rescoring (bit-identical to the oracle's index-order f64 sums, see exact_sums()).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
