@@ -12,6 +12,9 @@ from tests.compare import assert_topk_tie_aware, reference_distances
 
 pytestmark = pytest.mark.gpu
 SCALE = int(os.environ.get("SMT_FUZZ_SCALE", "1"))  # SMT_FUZZ_SCALE=10: ten times the examples (soak run)
+# The default run draws the SAME examples every time (a suite that stops at its first failure must not depend on the day's dice);
+# soak runs (SMT_FUZZ_SCALE > 1) draw fresh ones -- thousands per test passed on the last day of round 5.
+DERANDOMIZE = SCALE == 1
 
 
 def _oracle(emb, q, k, thr=None):
@@ -19,7 +22,7 @@ def _oracle(emb, q, k, thr=None):
     return [r["match_line"] for r in res], [r["distance"] for r in res]
 
 
-@settings(max_examples=40 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=40 * SCALE, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(1, 3000), k=st.integers(1, 80), nq=st.sampled_from([1, 1, 2, 3, 5, 8, 9, 33]),
        seed=st.integers(0, 10_000), dup=st.sampled_from([0.0, 0.05, 0.5]), use_ranges=st.booleans())
 def test_topk_random_shapes(gpu_ctx, n, k, nq, seed, dup, use_ranges):
@@ -48,7 +51,7 @@ def test_topk_random_shapes(gpu_ctx, n, k, nq, seed, dup, use_ranges):
     c.close()
 
 
-@settings(max_examples=15 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=15 * SCALE, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(1, 5000), seed=st.integers(0, 10_000), thr=st.floats(0.5, 1.2))
 def test_threshold_random(gpu_ctx, n, seed, thr):
     import semtools_amd as smt
@@ -63,7 +66,7 @@ def test_threshold_random(gpu_ctx, n, seed, thr):
     c.close()
 
 
-@settings(max_examples=30 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=30 * SCALE, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(1, 5000), k=st.integers(1, 40), nq=st.sampled_from([1, 2, 8, 9, 33, 70, 130]),
        seed=st.integers(0, 10_000), dup=st.sampled_from([0.0, 0.05, 0.5]))
 def test_topk_random_shapes_over_the_operand_image(gpu_ctx, n, k, nq, seed, dup):
@@ -88,7 +91,7 @@ def test_topk_random_shapes_over_the_operand_image(gpu_ctx, n, k, nq, seed, dup)
     c.close()
 
 
-@settings(max_examples=30 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=30 * SCALE, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(40, 9000), k=st.integers(1, 40), nq=st.sampled_from([1, 2, 8, 9, 40, 130]), seed=st.integers(0, 10_000),
        max_doc=st.sampled_from([1, 4, 70, 700]), p_want=st.sampled_from([0.1, 0.5, 0.9]), image=st.booleans())
 def test_document_subsets_random_shapes(gpu_ctx, n, k, nq, seed, max_doc, p_want, image):
@@ -125,7 +128,7 @@ def test_document_subsets_random_shapes(gpu_ctx, n, k, nq, seed, max_doc, p_want
     c.close()
 
 
-@settings(max_examples=25 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=25 * SCALE, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n_shards=st.sampled_from([2, 3, 4, 7]), transport=st.sampled_from(["peer", "copy"]), seed=st.integers(0, 10_000),
        pieces=st.lists(st.integers(1, 1500), min_size=1, max_size=6), k=st.integers(1, 70), nq=st.sampled_from([1, 1, 2, 4, 9, 40]),
        what=st.sampled_from(["topk", "topk", "subset", "threshold", "workspace"]))
