@@ -437,6 +437,18 @@ int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset);
  * searching the same file set again uploads only its queries.  kept: sets alive; hits: searches answered from one; builds: sets made. */
 int smt_debug_range_sets(const smt_corpus *corpus, uint64_t *kept, uint64_t *hits, uint64_t *builds);
 
+/* Test hook for the SPMD error paths of multi-process groups: arms ONE injected failure with status `code` (an SMT_E_* value) on
+ * THIS process's ranks; it fires at the next step of kind `where` and disarms.  The tests arm it on one rank of an n-rank group and
+ * check that every rank returns `code` from the same call and that none is left waiting inside a collective.
+ *   SMT_DEBUG_FAIL_STAGE  the local scan + select stage of the next smt_sharded_search that exchanges packed k-lists
+ *   SMT_DEBUG_FAIL_AGREE  the next status agreement (threshold / large-k searches, sharded save / append / embed / index life cycle)
+ *   SMT_DEBUG_FAIL_BUILD  the set-up of the next shared-centroid smt_sharded_ivfpq_build (before its first all-reduce)
+ * where == 0 disarms. */
+#define SMT_DEBUG_FAIL_STAGE 1
+#define SMT_DEBUG_FAIL_AGREE 2
+#define SMT_DEBUG_FAIL_BUILD 3
+int smt_debug_group_fail_next(smt_group *group, int where, int code);
+
 /* Test hook for the certificate's error bound: the f32 distances the batched kernels NOMINATE candidates with
  * (f32 MFMA, or bf16 x 3 split products when tuning key gemm_bf16x3 is set -- the default), for nq <= 32 host
  * queries against rows [first_row, first_row + n_rows) of the corpus; out is a host buffer [n_rows][32].

@@ -46,6 +46,9 @@ pub const SMT_TRANSPORT_COPY: c_int = 1;
 pub const SMT_TRANSPORT_PEER: c_int = 2;
 pub const SMT_APPEND_WRITE_AHEAD: c_int = 1;
 pub const SMT_APPEND_CREATE: c_int = 2;
+pub const SMT_DEBUG_FAIL_STAGE: c_int = 1;
+pub const SMT_DEBUG_FAIL_AGREE: c_int = 2;
+pub const SMT_DEBUG_FAIL_BUILD: c_int = 3;
 
 extern "C" {
     pub fn smt_ctx_create(device: c_int, out: *mut *mut SmtCtx) -> c_int;
@@ -406,6 +409,7 @@ extern "C" {
     ) -> c_int;
     pub fn smt_ctx_uncertain_count(ctx: *mut SmtCtx, count: *mut u64, reset: c_int) -> c_int;
     pub fn smt_debug_range_sets(corpus: *const SmtCorpus, kept: *mut u64, hits: *mut u64, builds: *mut u64) -> c_int;
+    pub fn smt_debug_group_fail_next(group: *mut SmtGroup, where_: c_int, code: c_int) -> c_int;
     pub fn smt_debug_batched_scores(
         corpus: *mut SmtCorpus,
         queries: *const f32,

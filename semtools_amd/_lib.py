@@ -39,6 +39,7 @@ EXPORTS = [
     "smt_sharded_model_create", "smt_sharded_model_create_from_file", "smt_sharded_model_destroy", "smt_sharded_embed",
     "smt_sharded_ivfpq_save", "smt_sharded_ivfpq_load", "smt_sharded_ivfpq_append", "smt_sharded_ivfpq_info",
     "smt_group_set_transport", "smt_group_transport", "smt_debug_range_sets", "smt_sharded_corpus_append_to_file_ex",
+    "smt_debug_group_fail_next",
 ]
 TRANSPORT_RCCL, TRANSPORT_COPY, TRANSPORT_PEER = 0, 1, 2
 TRANSPORT_NAMES = {TRANSPORT_RCCL: "rccl", TRANSPORT_COPY: "copy", TRANSPORT_PEER: "peer"}
@@ -184,6 +185,7 @@ def lib():
     L.smt_group_barrier.argtypes = [vp]
     try:   # (a test hook: an older build of the library under tools/ab_* A/B runs does not have it)
         L.smt_debug_range_sets.argtypes = [vp, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+        L.smt_debug_group_fail_next.argtypes = [vp, i32, i32]
     except AttributeError:
         pass
     L.smt_sharded_corpus_append_to_file_ex.argtypes = [vp, C.c_char_p, u64, u64, i32]

@@ -425,6 +425,10 @@ class Group:
     def barrier(self):
         L.check(L.lib().smt_group_barrier(self._h))
 
+    def debug_fail_next(self, where, code):
+        """Test hook (smt_debug_group_fail_next): the next local step of kind `where` on this process's ranks fails with `code`."""
+        L.check(L.lib().smt_debug_group_fail_next(self._h, int(where), int(code)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             L.lib().smt_group_destroy(self._h)

@@ -431,8 +431,17 @@ int group_barrier(smt_group *g)
     return SMT_OK;
 }
 
+int group_debug_fail(smt_group *g, int where)
+{
+    int armed = where;
+    if (!g->debug_fail_where.compare_exchange_strong(armed, 0)) return SMT_OK;
+    set_error("injected failure (smt_debug_group_fail_next, kind %d) on rank %d", where, g->first_rank);
+    return g->debug_fail_code;
+}
+
 int group_agree(smt_group *g, int rc)
 {
+    if (!rc) rc = group_debug_fail(g, SMT_DEBUG_FAIL_AGREE);
     if (g->n_local == g->n_ranks) return rc;   // every rank is in this process: nothing to agree on
     const std::string mine = rc ? smt_last_error() : "";
     for (int i = 0; i < g->n_local; ++i) {
@@ -929,6 +938,7 @@ static int group_share_agree(void *user, int rc)
 {
     ShareCtx *sc = static_cast<ShareCtx *>(user);
     smt_group *g = sc->g;
+    if (!rc && sc->local == 0) rc = group_debug_fail(g, SMT_DEBUG_FAIL_BUILD);
     if (g->n_local == 1) return group_agree(g, rc);
     const std::string mine = rc ? smt_last_error() : "";
     {
@@ -1126,6 +1136,16 @@ try {
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }
 
+int smt_debug_group_fail_next(smt_group *group, int where, int code)
+try {
+    SMT_REQUIRE(group != nullptr, "group");
+    SMT_REQUIRE(where == 0 || where == SMT_DEBUG_FAIL_STAGE || where == SMT_DEBUG_FAIL_AGREE || where == SMT_DEBUG_FAIL_BUILD, "where");
+    SMT_REQUIRE(where == 0 || code < 0, "code must be an SMT_E_* status");
+    group->debug_fail_code = code;
+    group->debug_fail_where.store(where);
+    return SMT_OK;
+} catch (...) { return smt::api_catch(); }
+
 int smt_group_transport(const smt_group *group)
 try {
     SMT_REQUIRE(group != nullptr, "group");
@@ -1241,6 +1261,7 @@ try {
                                                    (uint32_t)lr.size(), n_ranges != 0, sc->contiguous ? sc->rank_base[r] : 0, loc,
                                                    loc + list_words, false);
                 if (!rc2 && !sc->contiguous) rc2 = layout_translate_packed(sc, i, g->ctx[i]->stream, loc, nq, K);
+                if (!rc2 && i == 0) rc2 = group_debug_fail(g, SMT_DEBUG_FAIL_STAGE);
                 return rc2;
             }();
             if (stage_rc) { stage_rcs[i] = stage_rc; stage_errs[i] = smt_last_error(); }

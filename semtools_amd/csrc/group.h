@@ -96,6 +96,10 @@ struct smt_group {
     int ar_failed = 0;               // first failure reported to group_share_agree by a rank's thread
     std::vector<const long long *> ar_sums;
     std::vector<const unsigned int *> ar_counts;
+    // smt_debug_group_fail_next (test hook): the next local step of kind `debug_fail_where` on THIS process's ranks fails with
+    // `debug_fail_code` -- how the tests make ONE rank of a multi-process group fail and check that all of them return together
+    std::atomic<int> debug_fail_where{0};
+    int debug_fail_code = 0;
 };
 
 struct smt_sharded_ivfpq {
@@ -151,6 +155,8 @@ int group_barrier(smt_group *g);
 // Barrier that carries a status: every rank contributes `rc` and all of them return the first non-zero one (0 if none).
 // Error paths of collective operations go through this so that no rank leaves while the others wait.
 int group_agree(smt_group *g, int rc);
+// the test hook's trigger: non-zero (an error status, message set) once if a failure of kind `where` is armed on the group
+int group_debug_fail(smt_group *g, int where);
 // run work(i) for every local device, on one host thread per device when there are several; first error wins
 int group_for_each_local(smt_group *g, const std::function<int(int)> &work, bool threads = true);
 

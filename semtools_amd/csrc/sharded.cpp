@@ -478,10 +478,13 @@ try {
         const int r = g->first_rank + i;
         if (add[r]) rc = smt_corpus_append_host(sc->shard[i], rows + (size_t)begin[r] * sc->dim, add[r], nullptr);
     }
-    if (rc) {  // leave the shards as they were
+    // a rank failed -- this one, or (multi-process groups) one the agreement tells us about: every shard stays as it was
+    if ((rc = group_agree(g, rc))) {
+        const std::string why = smt_last_error();
         for (int i = 0; i < g->n_local; ++i) (void)smt_corpus_truncate(sc->shard[i], sc->rank_rows[g->first_rank + i]);
+        set_error("%s", why.c_str());
+        return rc;
     }
-    if ((rc = group_agree(g, rc))) return rc;
     layout_append(sc, add);
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }
@@ -589,9 +592,14 @@ try {
         return smt_embed(model->model[i], ids, offsets + begin[r], add[r], max_tokens,
                          out_host ? out_host + (size_t)begin[r] * SMT_DIM : nullptr, append_to ? append_to->shard[i] : nullptr, nullptr);
     }, n_lines >= 4096);
-    if (rc && append_to)   // a rank failed: leave every shard as it was
-        for (int i = 0; i < g->n_local; ++i) (void)smt_corpus_truncate(append_to->shard[i], append_to->rank_rows[g->first_rank + i]);
-    if ((rc = group_agree(g, rc))) return rc;
+    // a rank failed -- this one, or (multi-process groups) one the agreement tells us about: every shard stays as it was
+    if ((rc = group_agree(g, rc))) {
+        const std::string why = smt_last_error();
+        if (append_to)
+            for (int i = 0; i < g->n_local; ++i) (void)smt_corpus_truncate(append_to->shard[i], append_to->rank_rows[g->first_rank + i]);
+        set_error("%s", why.c_str());
+        return rc;
+    }
     if (append_to) layout_append(append_to, add);
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }

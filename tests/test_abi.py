@@ -155,3 +155,27 @@ def test_every_int_entry_point_is_a_function_try_block():
             if not rest.startswith("try"):
                 missing.append(f"{os.path.basename(path)}: {m.group(1)}")
     assert seen > 60 and not missing, (seen, missing)
+
+
+def test_the_rccl_double_exports_what_the_library_binds():
+    """tests/fake_rccl stands in for librccl.so.1 in the multi-process GPU tests (tests/test_gpu_spmd.py): it must carry RCCL's
+    SONAME -- load_rccl's dlopen(RTLD_NOLOAD) finds it by that -- and every nccl* symbol csrc/group.cpp resolves."""
+    import re
+    import subprocess
+
+    from tests import fake_rccl
+
+    lib = fake_rccl.build()
+    src = open(os.path.join(ROOT, "semtools_amd", "csrc", "group.cpp")).read()
+    bound = {"nccl" + m for m in re.findall(r"^\s*SMT_RCCL_SYM\((\w+)\)", src, flags=re.M)}
+    assert len(bound) >= 12
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True)
+    have = {line.split()[-1] for line in syms.splitlines() if line.strip()}
+    assert bound <= have, sorted(bound - have)
+    dyn = subprocess.check_output(["readelf", "-d", lib], text=True)
+    assert "librccl.so.1" in dyn
+    # ... and the product neither links nor names it
+    for root, _, files in os.walk(os.path.join(ROOT, "semtools_amd")):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".py", ".sh")):
+                assert "fake_rccl" not in open(os.path.join(root, f), errors="replace").read(), f
