@@ -193,6 +193,23 @@ int smt_search(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t t
 int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq,
                            uint32_t top_k, uint64_t row_base, uint64_t *out_rows_dev,
                            double *out_dist_dev);
+/* The same with a verdict PER QUERY: search_documents returns a definite list (src/search/mod.rs:107-119), so a caller that
+ * pipelines device calls must be able to tell which answer of which call is the proved exact top-k and which is not.
+ * out_status_dev [nq] (device-addressable: HBM or pinned host; NULL = smt_search_topk_device) receives, in stream order with
+ * the lists:
+ *   SMT_STATUS_PROVED     the list IS the exact top-k (the select's exactness certificate held: "Exactness bookkeeping" below)
+ *   SMT_STATUS_UNCERTAIN  more near-ties around the k-th place than the guard band holds: every returned (row, distance) pair is
+ *                         exact, but a row outside the list may belong to it -- re-ask this query through smt_search
+ *   SMT_STATUS_OVERFLOW   batched path only: a candidate buffer overflowed (adversarial row order) and rows were dropped on the
+ *                         way; same remedy
+ * Queries with a non-zero status are also counted by smt_ctx_uncertain_count.  smt_search / smt_sharded_search never return such
+ * a list: they re-answer the query exhaustively themselves. */
+#define SMT_STATUS_PROVED 0
+#define SMT_STATUS_UNCERTAIN 1
+#define SMT_STATUS_OVERFLOW 2
+int smt_search_topk_device_ex(smt_corpus *corpus, const float *queries_dev, uint32_t nq,
+                              uint32_t top_k, uint64_t row_base, uint64_t *out_rows_dev,
+                              double *out_dist_dev, uint32_t *out_status_dev);
 
 /* Merge `n_lists` sorted (dist asc, row asc) lists of length k_in each (padded
  * with UINT64_MAX/+inf) per query into the best k_out.  Inputs are laid out
@@ -401,6 +418,12 @@ int smt_sharded_search(smt_sharded_corpus *corpus, const float *queries, uint32_
  * contexts' aux streams while the scan of call i+1 streams. */
 int smt_sharded_search_topk_device(smt_sharded_corpus *corpus, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
                                    uint64_t *const *out_packed);
+/* ... with the per-query verdict of smt_search_topk_device_ex: out_status (NULL = none) holds one pointer per LOCAL device,
+ * out_status[i] (NULL = not wanted there; needs out_packed[i]) receiving [nq] SMT_STATUS_* codes -- the WORST status any shard
+ * of the group reported for that query (every rank's status words travel with its k-lists: same all-gather, or read in place by
+ * the peer transport). */
+int smt_sharded_search_topk_device_ex(smt_sharded_corpus *corpus, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
+                                      uint64_t *const *out_packed, uint32_t *const *out_status);
 
 /* IVF index over a sharded corpus: every rank indexes ITS rows.  shared_centroids != 0 makes the build data-parallel
  * (SURVEY.md 8(e)): the coarse k-means runs on every rank's sample of its own rows and the fixed-point centroid
@@ -429,7 +452,11 @@ int smt_sharded_ivfpq_info(const smt_sharded_ivfpq *index, uint64_t *rows_covere
  * that no other row can belong to the exact answer (the k-th exact distance lies more than the f32 error bound
  * below the worst nominated f32 distance).  When the proof fails -- more than 8 near-ties around the k-th place --
  * smt_search / smt_sharded_search re-answer that query exhaustively; the *_device entry points cannot (nothing
- * synchronises), they count such queries here.  reset != 0 clears the counter. */
+ * synchronises): they count such queries here and, in their _ex form, say WHICH query of the call it was
+ * (SMT_STATUS_*).  A batched query whose candidate buffer overflowed is reported the same way (the device entry points
+ * deliver its list as it is; the host entry points re-answer it).  reset != 0 clears the counter.
+ * (smt_ivfpq_search_device has no _ex form: an IVF answer carries no certificate -- exact distances, approximate
+ * membership by contract -- so there is no per-query verdict to report.) */
 int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset);
 
 /* Test hook for the kept range sets: a range list (the path subset of a workspace search) that a corpus sees for the second time

@@ -40,6 +40,9 @@ pub const SMT_E_UNSUPPORTED: c_int = -6;
 pub const SMT_DIM: u32 = 256;
 pub const SMT_MODE_DOCUMENTS: c_int = 0;
 pub const SMT_MODE_WORKSPACE: c_int = 1;
+pub const SMT_STATUS_PROVED: c_int = 0;
+pub const SMT_STATUS_UNCERTAIN: c_int = 1;
+pub const SMT_STATUS_OVERFLOW: c_int = 2;
 pub const SMT_UNIQUE_ID_BYTES: usize = 128;
 pub const SMT_TRANSPORT_RCCL: c_int = 0;
 pub const SMT_TRANSPORT_COPY: c_int = 1;
@@ -153,6 +156,16 @@ extern "C" {
         row_base: u64,
         out_rows_dev: *mut u64,
         out_dist_dev: *mut f64,
+    ) -> c_int;
+    pub fn smt_search_topk_device_ex(
+        corpus: *mut SmtCorpus,
+        queries_dev: *const f32,
+        nq: u32,
+        top_k: u32,
+        row_base: u64,
+        out_rows_dev: *mut u64,
+        out_dist_dev: *mut f64,
+        out_status_dev: *mut u32,
     ) -> c_int;
     pub fn smt_merge_topk(
         rows: *const u64,
@@ -373,6 +386,14 @@ extern "C" {
         nq: u32,
         top_k: u32,
         out_packed: *const *mut u64,
+    ) -> c_int;
+    pub fn smt_sharded_search_topk_device_ex(
+        corpus: *mut SmtShardedCorpus,
+        queries_dev: *const *const f32,
+        nq: u32,
+        top_k: u32,
+        out_packed: *const *mut u64,
+        out_status: *const *mut u32,
     ) -> c_int;
     pub fn smt_sharded_ivfpq_build(
         corpus: *mut SmtShardedCorpus,

@@ -39,8 +39,9 @@ EXPORTS = [
     "smt_sharded_model_create", "smt_sharded_model_create_from_file", "smt_sharded_model_destroy", "smt_sharded_embed",
     "smt_sharded_ivfpq_save", "smt_sharded_ivfpq_load", "smt_sharded_ivfpq_append", "smt_sharded_ivfpq_info",
     "smt_group_set_transport", "smt_group_transport", "smt_debug_range_sets", "smt_sharded_corpus_append_to_file_ex",
-    "smt_debug_group_fail_next",
+    "smt_debug_group_fail_next", "smt_search_topk_device_ex", "smt_sharded_search_topk_device_ex",
 ]
+STATUS_PROVED, STATUS_UNCERTAIN, STATUS_OVERFLOW = 0, 1, 2
 TRANSPORT_RCCL, TRANSPORT_COPY, TRANSPORT_PEER = 0, 1, 2
 TRANSPORT_NAMES = {TRANSPORT_RCCL: "rccl", TRANSPORT_COPY: "copy", TRANSPORT_PEER: "peer"}
 UNIQUE_ID_BYTES = 128
@@ -145,6 +146,7 @@ def lib():
     L.smt_corpus_append_to_file.argtypes = [vp, C.c_char_p, u64]
     L.smt_search.argtypes = [vp, vp, u32, u32, f64, i32, vp, u32, u64, vp, vp, vp, u64]
     L.smt_search_topk_device.argtypes = [vp, vp, u32, u32, u64, vp, vp]
+    L.smt_search_topk_device_ex.argtypes = [vp, vp, u32, u32, u64, vp, vp, vp]
     L.smt_merge_topk.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
     L.smt_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp]
     L.smt_merge_topk_packed_device.argtypes = [vp, vp, u32, u32, u32, u32, vp]
@@ -204,6 +206,7 @@ def lib():
     L.smt_sharded_corpus_append_host.argtypes = [vp, vp, u64, P(u64)]
     L.smt_sharded_search.argtypes = [vp, vp, u32, u32, f64, i32, vp, u32, vp, vp, vp, u64]
     L.smt_sharded_search_topk_device.argtypes = [vp, P(vp), u32, u32, P(vp)]
+    L.smt_sharded_search_topk_device_ex.argtypes = [vp, P(vp), u32, u32, P(vp), P(vp)]
     L.smt_sharded_ivfpq_build.argtypes = [vp, P(SmtIvfPqParams), i32, P(vp)]
     L.smt_sharded_ivfpq_destroy.argtypes = [vp]
     L.smt_sharded_ivfpq_destroy.restype = None

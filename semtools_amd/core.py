@@ -244,7 +244,13 @@ class Corpus:
         L.check(L.lib().smt_debug_range_sets(self._h, *[C.byref(x) for x in v]))
         return tuple(int(x.value) for x in v)
 
-    def search_topk_device(self, queries_ptr, nq, top_k, row_base, out_rows_ptr, out_dist_ptr):
+    def search_topk_device(self, queries_ptr, nq, top_k, row_base, out_rows_ptr, out_dist_ptr, out_status_ptr=None):
+        """out_status_ptr: device-addressable uint32[nq] receiving the per-query verdict (smt_search_topk_device_ex: 0 proved exact,
+        1 certificate failed, 2 candidate buffer overflowed), or None."""
+        if out_status_ptr:
+            L.check(L.lib().smt_search_topk_device_ex(self._h, C.c_void_p(queries_ptr), int(nq), int(top_k), int(row_base),
+                                                      C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr), C.c_void_p(int(out_status_ptr))))
+            return
         L.check(L.lib().smt_search_topk_device(self._h, C.c_void_p(queries_ptr), int(nq), int(top_k), int(row_base),
                                                C.c_void_p(out_rows_ptr), C.c_void_p(out_dist_ptr)))
 
@@ -583,11 +589,16 @@ class ShardedCorpus:
             break
         return [(out_rows[i, :int(counts[i])].copy(), out_dist[i, :int(counts[i])].copy()) for i in range(nq)]
 
-    def search_topk_device(self, query_ptrs, nq, top_k, out_packed_ptrs):
-        """Device-resident form: one queries pointer and one output pointer (or 0/None) per LOCAL device."""
+    def search_topk_device(self, query_ptrs, nq, top_k, out_packed_ptrs, out_status_ptrs=None):
+        """Device-resident form: one queries pointer and one output pointer (or 0/None) per LOCAL device.  out_status_ptrs: per local
+        device a uint32[nq] buffer (or 0/None) for the per-query verdicts -- the worst status over the shards (_ex entry point)."""
         n = len(query_ptrs)
         qp = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in query_ptrs])
         op = (C.c_void_p * n)(*[C.c_void_p(int(p)) if p else C.c_void_p(None) for p in out_packed_ptrs])
+        if out_status_ptrs is not None:
+            sp = (C.c_void_p * n)(*[C.c_void_p(int(p)) if p else C.c_void_p(None) for p in out_status_ptrs])
+            L.check(L.lib().smt_sharded_search_topk_device_ex(self._h, qp, int(nq), int(top_k), op, sp))
+            return
         L.check(L.lib().smt_sharded_search_topk_device(self._h, qp, int(nq), int(top_k), op))
 
 

@@ -226,9 +226,11 @@ struct ScanArgs {
     uint64_t *out_rows;
     double *out_dist;
     uint64_t *out_counts;     // may be nullptr
-    uint64_t *out_uncertain = nullptr;  // device [nq] or nullptr: 1 where the f32 nomination could not be PROVEN to
-                                        // contain the exact top-k (see SelectArgs::f32_err); the host API then
-                                        // re-answers that query exhaustively
+    uint64_t *out_uncertain = nullptr;  // device [nq] or nullptr: non-zero where the f32 nomination could not be PROVEN to
+                                        // contain the exact top-k (see SelectArgs::f32_err; SMT_STATUS_* code); the host API
+                                        // then re-answers that query exhaustively
+    uint32_t *out_status = nullptr;     // device [nq] or nullptr: the same verdict as a SMT_STATUS_* code per query -- what the
+                                        // *_device_ex entry points hand their caller (include/semtools_hip.h)
     bool allow_async = false; // the caller does not read the outputs on the main stream before smt_ctx_synchronize
     const void *image = nullptr;          // the corpus' fp16 operand image covering all `rows` (smt_corpus::image), or nullptr
     const uint32_t *image_zero = nullptr;
@@ -300,6 +302,7 @@ struct SelectArgs {
     // sticky counter is bumped) and the host entry points re-answer it exhaustively.  0 = no certificate (IVF-PQ).
     double f32_err = 0.0;
     uint64_t *out_uncertain = nullptr;
+    uint32_t *out_status = nullptr;   // [nq] or nullptr: 0 proved exact, 1 certificate failed, 2 a candidate buffer overflowed
     // batched path: != 0 where a query's candidate buffer overflowed between two level selects (rows were dropped: the lists may
     // miss an answer row).  Such a query is flagged like a failed certificate -- the host entry points re-answer it exhaustively,
     // the device entry points count it -- so that no batched call needs a host synchronisation of its own (until round 5
@@ -363,6 +366,10 @@ int launch_merge_topk_packed_on(smt_ctx *ctx, hipStream_t st, const uint64_t *pa
 struct MergeSources { const uint64_t *list[SMT_MAX_MERGE_SOURCES]; };
 int launch_merge_topk_sources_on(hipStream_t st, const MergeSources &src, uint32_t n_lists, uint32_t nq, uint32_t k_in, uint32_t k_out,
                                  uint64_t *out_packed);
+// out[q] = max over the n sources of their q-th status word (u64 words, SMT_STATUS_* codes): the per-query verdict of a sharded
+// search is the worst of its shards'.  Sources by pointer (peer transport), or `stride_words` apart behind `base` (gathered buffer).
+int launch_combine_status_on(hipStream_t st, const MergeSources *src, const uint64_t *base, uint64_t stride_words, uint32_t n, uint32_t nq,
+                             uint32_t *out);
 
 int launch_merge_topk(smt_ctx *ctx, const uint64_t *rows, const double *dist, uint32_t n_lists,
                       uint32_t nq, uint32_t k_in, uint32_t k_out, uint64_t *out_rows,

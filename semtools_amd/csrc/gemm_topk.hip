@@ -424,6 +424,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
             c.out_dist = a.out_dist + (size_t)q0 * ostride;
             c.out_counts = a.out_counts ? a.out_counts + q0 : nullptr;
             c.out_uncertain = a.out_uncertain ? a.out_uncertain + q0 : nullptr;
+            c.out_status = a.out_status ? a.out_status + q0 : nullptr;
             const int rc_chunk = launch_gemm_topk(ctx, c);
             if (rc_chunk) return rc_chunk;
         }
@@ -702,6 +703,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     sel.out_stride = a.out_stride;
     sel.f32_err = f16x1 ? F32_ERR_F16X1 : f16x2 ? F32_ERR_F16X2 : bf16 ? F32_ERR_BF16X3 : F32_ERR_MFMA;
     sel.out_uncertain = a.out_uncertain;
+    sel.out_status = a.out_status;
     sel.overflow = overflow;
     rc = launch_select(ctx, sel);
     if (rc) return rc;

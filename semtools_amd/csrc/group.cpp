@@ -1342,14 +1342,23 @@ try {
 int smt_sharded_search_topk_device(smt_sharded_corpus *sc, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
                                    uint64_t *const *out_packed)
 try {
+    return smt_sharded_search_topk_device_ex(sc, queries_dev, nq, top_k, out_packed, nullptr);
+} catch (...) { return smt::api_catch(); }
+
+int smt_sharded_search_topk_device_ex(smt_sharded_corpus *sc, const float *const *queries_dev, uint32_t nq, uint32_t top_k,
+                                      uint64_t *const *out_packed, uint32_t *const *out_status)
+try {
     SMT_REQUIRE(sc && queries_dev && out_packed, "null argument");
     SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
     smt_group *g = sc->group;
     SMT_REQUIRE((uint64_t)g->n_ranks * top_k <= 8192, "device merge handles up to 8192 candidates per query");
     if (nq == 0) return SMT_OK;
-    const size_t list_words = (size_t)nq * 2 * top_k;
-    const size_t gath_off = (list_words * 8 + 255) & ~(size_t)255;
-    const size_t dev_bytes = gath_off + (size_t)g->n_ranks * list_words * 8 + 64;
+    // with per-query verdicts wanted, every rank's nq status words (SMT_STATUS_* codes written by its select) travel behind its lists
+    bool want_status = false;
+    for (int i = 0; out_status && i < g->n_local; ++i) want_status = want_status || out_status[i] != nullptr;
+    const size_t list_words = (size_t)nq * 2 * top_k, rank_words = list_words + (want_status ? nq : 0);
+    const size_t gath_off = (rank_words * 8 + 255) & ~(size_t)255;
+    const size_t dev_bytes = gath_off + (size_t)g->n_ranks * rank_words * 8 + 64;
     std::vector<char> on_aux(g->n_local, 0);
     const bool peer = g->transport == SMT_TRANSPORT_PEER;
     int rc;
@@ -1360,7 +1369,7 @@ try {
     const bool spread = peer && g->spread_waits && g->workers != nullptr;
     int slot = 0;
     if (peer) {   // rank j writes its list into slot `slot` of its ring; whoever needs the answer reads the slots in place
-        if ((rc = ring_ensure(g, list_words * 8))) return rc;
+        if ((rc = ring_ensure(g, rank_words * 8))) return rc;
         if ((rc = ring_next_slot(g, &slot))) return rc;
     }
     // every device's scan + select is issued by its own thread (group_for_each_local); the collective follows on this one
@@ -1374,7 +1383,7 @@ try {
         uint64_t *list = peer ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->ring.dev[i]) + (size_t)slot * g->ring.slot_bytes)
                               : reinterpret_cast<uint64_t *>(g->buf[i].dev);
         rc_i = search_topk_packed_local(sc->shard[i], queries_dev[i], nq, top_k, 0, 0.f, nullptr, 0, false,
-                                        sc->contiguous ? sc->rank_base[r] : 0, list, nullptr, async);
+                                        sc->contiguous ? sc->rank_base[r] : 0, list, want_status ? list + list_words : nullptr, async);
         if (rc_i) return rc_i;
         if (!sc->contiguous && (rc_i = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream, list, nq, top_k)))
             return rc_i;
@@ -1386,8 +1395,10 @@ try {
         return SMT_OK;
     }, g->workers != nullptr);
     if (rc) return rc;
-    if (!peer && (rc = allgather_words(g, 0, gath_off, list_words, &on_aux))) return rc;
+    if (!peer && (rc = allgather_words(g, 0, gath_off, rank_words, &on_aux))) return rc;
     for (int i = 0; i < g->n_local; ++i) {
+        uint32_t *status_i = out_status ? out_status[i] : nullptr;
+        SMT_REQUIRE(!status_i || out_packed[i], "a device that wants the verdicts takes the answer too");
         if (!out_packed[i]) continue;
         smt_ctx *c = g->ctx[i];
         hipStream_t st = on_aux[i] ? c->aux_stream : c->stream;
@@ -1395,14 +1406,24 @@ try {
             // (an answer wanted on ONE device -- the one-thread caller of SURVEY 8(b) -- costs n - 1 waits + a launch + a record here)
             hipEvent_t done = nullptr;
             if ((rc = ring_done_event(g, slot, i, &done))) return rc;
-            if ((rc = peer_merge(g, i, st, g->ring.dev.data(), (size_t)slot * g->ring.slot_bytes, nq, top_k, top_k, out_packed[i], done, spread))) return rc;
+            const size_t off = (size_t)slot * g->ring.slot_bytes;
+            // (the verdicts are read in place like the lists, by a second small kernel between the merge and the slot's `done` record)
+            if ((rc = peer_merge(g, i, st, g->ring.dev.data(), off, nq, top_k, top_k, out_packed[i], status_i ? nullptr : done, spread))) return rc;
+            if (status_i) {
+                MergeSources src;
+                for (int j = 0; j < g->n_local; ++j)
+                    src.list[j] = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(g->ring.dev[j]) + off) + list_words;
+                if ((rc = launch_combine_status_on(st, &src, nullptr, 0, (uint32_t)g->n_local, nq, status_i))) return rc;
+                SMT_HIP_CHECK(hipEventRecord(done, st));
+            }
             if (on_aux[i]) c->async_pending = true;
             continue;
         }
         if ((rc = group_bind(g, i))) return rc;
         const uint64_t *gath = reinterpret_cast<const uint64_t *>(reinterpret_cast<char *>(g->buf[i].dev) + gath_off);
-        rc = launch_merge_topk_packed_on(c, st, gath, (uint32_t)g->n_ranks, nq, top_k, top_k, out_packed[i], 0);
+        rc = launch_merge_topk_packed_on(c, st, gath, (uint32_t)g->n_ranks, nq, top_k, top_k, out_packed[i], want_status ? rank_words : 0);
         if (rc) return rc;
+        if (status_i && (rc = launch_combine_status_on(st, nullptr, gath + list_words, rank_words, (uint32_t)g->n_ranks, nq, status_i))) return rc;
     }
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }

@@ -571,6 +571,7 @@ struct FinalParams {
     uint64_t out_stride;  // words between consecutive queries' output lists (>= k_out)
     double f32_err;       // > 0: exactness certificate (SelectArgs::f32_err)
     uint64_t *out_uncertain;       // [nq] or nullptr
+    unsigned int *out_status;      // [nq] or nullptr (SelectArgs::out_status)
     unsigned long long *status;    // the context's sticky "uncertain selects" counter
     unsigned long long *dbg;  // optional: s_memtime stamps of query 0's phases (tuning key select_debug_ptr)
     unsigned long long *flags;  // async select (or nullptr), see ScanParams
@@ -860,6 +861,7 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     double *odist = p.out_dist + (size_t)qi * p.out_stride;
     if (threadIdx.x < p.k_out) { orow[threadIdx.x] = 0xFFFFFFFFFFFFFFFFull; odist[threadIdx.x] = __builtin_inf(); }
     if (threadIdx.x == 0 && p.out_uncertain) p.out_uncertain[qi] = 0;
+    if (threadIdx.x == 0 && p.out_status) p.out_status[qi] = 0;
     __syncthreads();
     SEL_STAMP(6);
     for (int pr = threadIdx.x; pr < kp * kp; pr += blockDim.x) {
@@ -889,16 +891,19 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
             decide = true;
             uncertain = p.ws_threshold ? ((1.0 - floor_out) > (double)p.ws_thr_score) : true;
         }
+        unsigned int code = uncertain ? 1u : 0u;   // SMT_STATUS_UNCERTAIN
         if constexpr (OVF) {
-            if (decide && !uncertain && p.overflow[qi]) uncertain = true;   // rows were dropped on the way (SelectArgs::overflow)
+            if (decide && p.overflow[qi]) { uncertain = true; code = 2u; }   // rows were dropped on the way (SelectArgs::overflow): SMT_STATUS_OVERFLOW
         }
         if (decide && uncertain) {
-            if (p.out_uncertain) p.out_uncertain[qi] = 1;
+            if (p.out_uncertain) p.out_uncertain[qi] = code;
+            if (p.out_status) p.out_status[qi] = code;
             if (p.status) atomicAdd(p.status, 1ull);
         }
     } else if constexpr (OVF) {
         if (threadIdx.x == 0 && p.overflow[qi]) {
-            if (p.out_uncertain) p.out_uncertain[qi] = 1;
+            if (p.out_uncertain) p.out_uncertain[qi] = 2;
+            if (p.out_status) p.out_status[qi] = 2u;
             if (p.status) atomicAdd(p.status, 1ull);
         }
     }
@@ -1064,6 +1069,7 @@ int launch_select(smt_ctx *ctx, const SelectArgs &a)
     f.out_stride = a.out_stride ? a.out_stride : a.k_out;
     f.f32_err = a.f32_err;
     f.out_uncertain = a.out_uncertain;
+    f.out_status = a.out_status;
     f.status = ctx->d_status;
     f.dbg = reinterpret_cast<unsigned long long *>(ctx->tune.select_debug_ptr);
     f.flags = a.async_step ? ctx->d_flags : nullptr;
@@ -1180,6 +1186,7 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
     s.out_stride = a.out_stride;
     s.f32_err = F32_ERR_SCAN;
     s.out_uncertain = a.out_uncertain;
+    s.out_status = a.out_status;
     return launch_select(ctx, s);
 }
 
@@ -1252,6 +1259,30 @@ int launch_merge_topk_sources_on(hipStream_t st, const MergeSources &src, uint32
     const size_t smem = (size_t)n_lists * k_in * 16;
     hipLaunchKernelGGL(merge_topk_sources_kernel, dim3(nq), dim3(256), smem, st, src, n_lists, (uint64_t)2 * k_in, k_in, k_out, out_packed,
                        reinterpret_cast<double *>(out_packed + k_out), (uint64_t)2 * k_out);
+    SMT_HIP_CHECK(hipGetLastError());
+    return SMT_OK;
+}
+
+__global__ void combine_status_kernel(MergeSources src, const uint64_t *base, uint64_t stride_words, uint32_t n, uint32_t nq, uint32_t *out)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint64_t worst = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint64_t v = base ? base[(size_t)j * stride_words + q] : src.list[j][q];
+        worst = v > worst ? v : worst;
+    }
+    out[q] = (uint32_t)worst;
+}
+
+int launch_combine_status_on(hipStream_t st, const MergeSources *src, const uint64_t *base, uint64_t stride_words, uint32_t n, uint32_t nq,
+                             uint32_t *out)
+{
+    SMT_REQUIRE((src != nullptr) != (base != nullptr), "status sources: pointers or a strided buffer");
+    SMT_REQUIRE(src == nullptr || n <= SMT_MAX_MERGE_SOURCES, "1..64 status sources are read in place");
+    if (nq == 0) return SMT_OK;
+    MergeSources none{};
+    hipLaunchKernelGGL(combine_status_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, src ? *src : none, base, stride_words, n, nq, out);
     SMT_HIP_CHECK(hipGetLastError());
     return SMT_OK;
 }

@@ -735,6 +735,12 @@ try {
 int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,
                            uint64_t *out_rows_dev, double *out_dist_dev)
 try {
+    return smt_search_topk_device_ex(corpus, queries_dev, nq, top_k, row_base, out_rows_dev, out_dist_dev, nullptr);
+} catch (...) { return smt::api_catch(); }
+
+int smt_search_topk_device_ex(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t top_k, uint64_t row_base,
+                              uint64_t *out_rows_dev, double *out_dist_dev, uint32_t *out_status_dev)
+try {
     SMT_REQUIRE(corpus != nullptr, "corpus");
     SMT_REQUIRE(nq == 0 || (queries_dev && out_rows_dev && out_dist_dev), "null argument");
     SMT_REQUIRE(top_k >= 1 && top_k <= SCAN_MAX_K, "top_k must be in [1, 56]");
@@ -761,9 +767,11 @@ try {
     a.out_rows = out_rows_dev;
     a.out_dist = out_dist_dev;
     a.out_counts = nullptr;
+    a.out_status = out_status_dev;
     a.allow_async = async;
     if (corpus->rows == 0) {
-        // nothing to scan: fill with padding through the merge kernel on zero lists
+        // nothing to scan: fill with padding through the merge kernel on zero lists (an empty answer is a proved one)
+        if (out_status_dev) SMT_HIP_CHECK(hipMemsetAsync(out_status_dev, 0, (size_t)nq * sizeof(uint32_t), ctx->stream));
         return launch_merge_topk(ctx, out_rows_dev, out_dist_dev, 0, nq, 1, top_k, out_rows_dev, out_dist_dev);
     }
     rc = topk_dispatch(ctx, corpus, a);

@@ -169,6 +169,27 @@ def main():
         g.ctx(0).set_tuning("async_select", 0)
         res["uncertain"] = g.ctx(0).uncertain_count()
         hip.free(qd)
+        # per-query verdicts (_ex): the ranks' status words ride in the same all-gather as their k-lists; worst status wins
+        from tests.test_gpu_nearties import adversarial_corpus
+
+        qa, emb_a, _ = adversarial_corpus(n=6000, n_cluster=50 * world, seed=57)
+        q5 = synth.unit_query(95, nq=5)
+        q5[3] = qa
+        sca = smt.ShardedCorpus(g, rows=emb_a)
+        qd5 = hip.upload(q5)
+        o5 = hip.malloc(5 * 2 * K_DEV * 8)
+        st5 = hip.upload(np.full(5, 7, dtype=np.uint32))
+        hip.sync()
+        sca.search_topk_device([qd5], 5, K_DEV, [o5], [st5])
+        g.synchronize()
+        res["verdicts"] = hip.download(st5, (5,), np.uint32).tolist()
+        m5 = hip.download(o5, (5, 2, K_DEV), np.uint64)
+        res["verdict_rows"] = m5[:, 0, :].copy()
+        res["verdict_dist"] = m5[:, 1, :].copy().view(np.float64)
+        res["verdict_uncertain_local"] = g.ctx(0).uncertain_count()
+        for p in (qd5, o5, st5):
+            hip.free(p)
+        sca.close()
         out["pipelined"] = res
 
     # ---------------------------------------------------------------- the store's side: dealt appends, file round trip, sharded embed

@@ -442,15 +442,20 @@ def test_device_form_counts_an_overflowed_query_instead_of_synchronising(gpu_ctx
         o_d = torch.zeros((9, 10), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
         gpu_ctx.uncertain_count()
-        c.search_topk_device(qd.data_ptr(), 9, 10, 0, o_r.data_ptr(), o_d.data_ptr())
+        st = torch.full((9,), 7, dtype=torch.int32, device="cuda")
+        c.search_topk_device(qd.data_ptr(), 9, 10, 0, o_r.data_ptr(), o_d.data_ptr(), out_status_ptr=st.data_ptr())
         gpu_ctx.synchronize()
         flagged = gpu_ctx.uncertain_count()
         inexact = 0
         rows = o_r.cpu().numpy()
+        status = st.cpu().tolist()
         for i in range(9):
             res = orc.search_documents(emb, [n], qs[i], 0, 10, accurate=True)
-            inexact += rows[i].tolist() != [r["match_line"] for r in res]
+            wrong = rows[i].tolist() != [r["match_line"] for r in res]
+            inexact += wrong
+            assert not (wrong and status[i] == 0), i               # per query (_ex): an answer that says "proved" IS exact
         assert flagged >= max(inexact, 1), (flagged, inexact)      # this corpus does overflow: at least one query is counted
+        assert set(status) <= {0, 1, 2} and 2 in status and sum(x != 0 for x in status) == flagged, status   # ... as SMT_STATUS_OVERFLOW
         c.close()
     finally:
         gpu_ctx.set_tuning("gemm_boot_fine", 1)

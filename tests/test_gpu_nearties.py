@@ -152,6 +152,87 @@ def test_device_entry_point_counts_what_it_cannot_prove(gpu_ctx):
     c.close()
 
 
+@pytest.mark.parametrize("nq,at", [(1, 0), (3, 1), (12, 7), (140, 77)])
+def test_device_entry_point_says_which_query_it_could_not_prove(gpu_ctx, nq, at):
+    """smt_search_topk_device_ex: a verdict PER QUERY (0 proved / 1 certificate failed / 2 overflow) next to the lists, in stream
+    order -- search_documents returns a definite list (src/search/mod.rs:107-119), so a pipelined caller must be able to tell WHICH
+    answer of WHICH call is not the proved exact top-k.  One adversarial query at index `at` of an otherwise easy batch, through the
+    scan kernel (1, 3 queries) and the batched kernel (12: f32-grade nomination, 140: f16 x 2)."""
+    import torch
+    import semtools_amd as smt
+
+    q, emb, _ = adversarial_corpus(seed=55)
+    qs = synth.unit_query(90 + nq, nq=nq)
+    qs[at] = q
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    gpu_ctx.uncertain_count()
+    qd = torch.from_numpy(qs).cuda()
+    o_rows = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
+    o_dist = torch.empty((nq, 10), dtype=torch.float64, device="cuda")
+    for pinned in (False, True):                               # the verdicts may land in HBM or straight in pinned host memory
+        st = torch.full((nq,), 7, dtype=torch.int32)
+        st = st.pin_memory() if pinned else st.cuda()
+        torch.cuda.synchronize()
+        c.search_topk_device(qd.data_ptr(), nq, 10, 0, o_rows.data_ptr(), o_dist.data_ptr(), out_status_ptr=st.data_ptr())
+        gpu_ctx.synchronize()
+        want = [0] * nq
+        want[at] = 1                                           # 40 near-ties around the 10th place: no certificate for THAT query
+        assert st.cpu().tolist() == want, (nq, at, pinned)
+        assert gpu_ctx.uncertain_count() == 1                  # (the context-wide counter still counts it)
+        rows, dist = o_rows.cpu().numpy(), o_dist.cpu().numpy()
+        for i in range(nq):
+            if i != at:                                        # every answer that says "proved" IS the oracle's
+                exp_rows, exp_dist = _oracle_topk(emb, qs[i], 10)
+                assert rows[i].tolist() == exp_rows and np.array_equal(dist[i], exp_dist), i
+    # the plain entry point is the _ex one without a status buffer
+    c.search_topk_device(qd.data_ptr(), nq, 10, 0, o_rows.data_ptr(), o_dist.data_ptr())
+    gpu_ctx.synchronize()
+    assert gpu_ctx.uncertain_count() == 1
+    c.close()
+
+
+@pytest.mark.parametrize("transport", ["peer", "copy"])
+def test_sharded_device_entry_point_reports_the_worst_verdict_of_its_shards(gpu_ctx, transport):
+    """smt_sharded_search_topk_device_ex: every rank's status words travel with its k-lists (read in place by the peer transport, in
+    the same all-gather otherwise); the device that takes the answer gets, per query, the worst status any shard reported."""
+    import torch
+    import semtools_amd as smt
+
+    q, emb, cluster = adversarial_corpus(n=6000, n_cluster=150, seed=57)      # ~50 near-ties per shard: no shard can prove its list
+    emb[:2000][np.isin(np.arange(2000), cluster)] = synth.unit_rows(2000, seed=5, dup_frac=0, zero_frac=0)[np.isin(np.arange(2000), cluster)]
+    # (... except shard 0, whose cluster rows were just replaced: the verdict must come from shards 1 and 2)
+    qs = synth.unit_query(95, nq=5)
+    qs[3] = q
+    n = 3
+    g = smt.Group.logical(0, n)
+    g.set_transport(transport)
+    sc = smt.ShardedCorpus(g, rows=emb)
+    qd = torch.from_numpy(qs).cuda()
+    outs = [torch.zeros((5, 2, 10), dtype=torch.int64, device="cuda") for _ in range(n)]
+    sts = [torch.full((5,), 7, dtype=torch.int32, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    for i in range(n):
+        g.ctx(i).uncertain_count()
+    # device 0 and device 2 want the answer and the verdicts, device 1 only the answer
+    sc.search_topk_device([qd.data_ptr()] * n, 5, 10, [o.data_ptr() for o in outs], [sts[0].data_ptr(), 0, sts[2].data_ptr()])
+    # ... and pipelined: the next call (one query, no verdicts wanted) must not disturb the first one's
+    sc.search_topk_device([qd.data_ptr()] * n, 1, 10, [0, outs[1].data_ptr(), 0])
+    g.synchronize()
+    assert sts[0].cpu().tolist() == [0, 0, 0, 1, 0] and sts[2].cpu().tolist() == [0, 0, 0, 1, 0]
+    assert sts[1].cpu().tolist() == [7] * 5
+    assert g.ctx(0).uncertain_count() == 0 and g.ctx(1).uncertain_count() == 1 and g.ctx(2).uncertain_count() == 1
+    m = outs[0].cpu().numpy()
+    for i in (0, 1, 2, 4):
+        exp_rows, exp_dist = _oracle_topk(emb, qs[i], 10)
+        assert np.ascontiguousarray(m[i, 0]).view(np.uint64).tolist() == exp_rows
+        assert np.array_equal(np.ascontiguousarray(m[i, 1]).view(np.float64), exp_dist)
+    with pytest.raises(RuntimeError):                          # verdicts without the answer: refused
+        sc.search_topk_device([qd.data_ptr()] * n, 5, 10, [outs[0].data_ptr(), 0, 0], [0, sts[1].data_ptr(), 0])
+    g.synchronize()
+    sc.close(); g.close()
+
+
 def test_many_uncertain_queries_are_reanswered_by_one_batched_pass(gpu_ctx):
     """A batch whose queries ALL sit on near-tie clusters: instead of one exhaustive K4 scan per query the host entry
     point runs ONE batched threshold pass (api.cpp batched_fallback) -- same answers as the oracle, and the pass is

@@ -109,7 +109,17 @@ def test_every_search_mode_with_one_rank_per_process(plain, tmp_path, world):
     want12, want140, want_thr5 = _lists(c.search(q12, top_k=10)), _lists(c.search(q140, top_k=7)), _lists(c.search(q140[:5], max_distance=0.88))
     q16 = synth.unit_query(21, nq=16)
     want16 = c.search(q16, top_k=W.K_DEV)
+    from tests.test_gpu_nearties import adversarial_corpus, _oracle_topk
+
+    qa, emb_a, _ = adversarial_corpus(n=6000, n_cluster=50 * world, seed=57)
+    q5 = synth.unit_query(95, nq=5)
+    q5[3] = qa
     for o in outs:                                            # EVERY rank holds the whole answer
+        p = o["pipelined"]
+        assert p["verdicts"] == [0, 0, 0, 1, 0], (o["rank"], p["verdicts"])      # smt_sharded_search_topk_device_ex: worst status of the shards
+        for i in (0, 1, 2, 4):
+            exp_rows, exp_dist = _oracle_topk(emb_a, q5[i], W.K_DEV)
+            assert p["verdict_rows"][i].tolist() == exp_rows and np.array_equal(p["verdict_dist"][i], exp_dist), (o["rank"], i)
         for kw, got, w in zip(W.CASES, o["modes"], want):
             assert got == w, (o["rank"], kw)
         assert o["batch12"] == want12 and o["batch140"] == want140 and o["thr5"] == want_thr5, o["rank"]
