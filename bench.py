@@ -373,6 +373,12 @@ def run(args, under_launcher):
     host_rows = host[:, 0]
     host_dist = host[:, 1].view(torch.float64)
     async_select = os.environ.get("SEMTOOLS_BENCH_ASYNC_SELECT", "1") != "0"
+    # the verdict of EVERY timed answer (smt_search_topk_device_ex: 0 = proved the exact top-k), one pinned word per step, written
+    # by the select (or, sharded: the worst over the shards, by the merging device) in stream order with the answer
+    n_status = max(ring, args.steps)
+    status_host = torch.full((n_status,), 7, dtype=torch.int32).pin_memory()
+    status_ptr0 = status_host.data_ptr()
+    want_verdicts = os.environ.get("SEMTOOLS_BENCH_NO_VERDICTS") != "1"     # (A/B hook: the plain entry points, no status words)
     if sp:
         # one process, n_dev devices: the raw C call with its pointer arrays made once (the ctypes marshalling of the Python wrapper
         # would be ~10 us of the caller's thread per step).  ONE answer per search, delivered by local device 0 into pinned memory.
@@ -381,22 +387,24 @@ def run(args, under_launcher):
         from semtools_amd import _lib as L
         q_arrays = [(C.c_void_p * n_dev)(*[C.c_void_p(queries_on[i][j].data_ptr()) for i in range(n_dev)]) for j in range(n_queries)]
         o_arrays = [(C.c_void_p * n_dev)(*([C.c_void_p(host[r].data_ptr())] + [C.c_void_p(None)] * (n_dev - 1))) for r in range(ring)]
-        sharded_fn = L.lib().smt_sharded_search_topk_device
+        s_arrays = [(C.c_void_p * n_dev)(*([C.c_void_p(status_ptr0 + 4 * j)] + [C.c_void_p(None)] * (n_dev - 1))) for j in range(n_status)]
+        sharded_fn = L.lib().smt_sharded_search_topk_device_ex
 
     def step(i, corpora=None, slot_of=None):
         cs = corpora if corpora is not None else CORPORA
         if sp:
-            rc = sharded_fn(cs[i % len(cs)]._h, q_arrays[i % n_queries], 1, k, o_arrays[i % ring])
+            rc = sharded_fn(cs[i % len(cs)]._h, q_arrays[i % n_queries], 1, k, o_arrays[i % ring], s_arrays[i % n_status] if want_verdicts else None)
             if rc:
                 L.check(rc)
             return
         q = queries[i % n_queries]
         slot = host[i % ring]      # pinned host memory is device-addressable: zero-copy result delivery
         if not exchange:
-            cs[i % len(cs)].search_topk_device(q.data_ptr(), 1, k, row_base, slot[0].data_ptr(), slot[1].data_ptr())
+            cs[i % len(cs)].search_topk_device(q.data_ptr(), 1, k, row_base, slot[0].data_ptr(), slot[1].data_ptr(),
+                                               out_status_ptr=(status_ptr0 + 4 * (i % n_status)) if want_verdicts else None)
         else:
             # one call = scan (main stream) -> select -> all-gather -> merge (aux stream, overlapping the next scan)
-            cs[i % len(cs)].search_topk_device([q.data_ptr()], 1, k, [slot.data_ptr()])
+            cs[i % len(cs)].search_topk_device([q.data_ptr()], 1, k, [slot.data_ptr()], [status_ptr0 + 4 * (i % n_status)] if want_verdicts else None)
 
     def sync():
         if exchange:
@@ -438,12 +446,15 @@ def run(args, under_launcher):
     sync()
     # HIP events bracket every launch of the dominant kernel (K2 scan) inside the timed region; the select
     # stage is timed in a short extra loop afterwards (each event pair costs ~5 us of stream time)
-    ctx.set_tuning("prof_select", 0)
-    ctx.set_tuning("prof_every", args.event_every)   # an event pair costs ~6 us of stream time: sample the launches
-    ctx.prof_enable(True)
-    ctx.prof_reset()
+    # (every local context: at N > 1 the line carries each rank's scan / select time and the merging device's wait for the others)
+    for c in local_ctxs:
+        c.set_tuning("prof_select", 0)
+        c.set_tuning("prof_every", args.event_every)   # an event pair costs ~6 us of stream time: sample the launches
+        c.prof_enable(True)
+        c.prof_reset()
     sync()
     uncertain_all()                               # reset the "exactness certificate failed" counters
+    status_host.fill_(7)
     clocks = ClockSampler(local_rank)
     with clocks.leg("c2"):
         t0 = time.perf_counter()
@@ -453,6 +464,8 @@ def run(args, under_launcher):
         sync()
         elapsed = time.perf_counter() - t0
     n_scan, scan_ms = ctx.prof_read("scan")
+    verdicts = status_host[:min(args.steps, n_status)].numpy().copy()   # one per timed step
+    rank_elapsed = elapsed                                          # this rank's own clock (the MAX over ranks is taken below)
     got_rows = host_rows[(args.steps - 1) % ring].numpy().copy()   # the last timed step's answer (checked below)
     got_dist = host_dist[(args.steps - 1) % ring].numpy().copy()
     # the roofline figure must not rest on a handful of samples when the caller passes a small --steps: top the
@@ -466,15 +479,35 @@ def run(args, under_launcher):
         sync()
         n_scan, scan_ms = ctx.prof_read("scan")
     uncertain = uncertain_all()
-    ctx.set_tuning("prof_every", 1)
+
+    def avg_us(c, name):
+        n, ms = c.prof_read(name)
+        return (ms / n * 1e3) if n else None
+
+    # per LOCAL rank: its scan launches, and (the devices that take the answer) how long the merge waited for the other ranks'
+    # lists once its own was ready + the merge kernel itself
+    per_rank = [{"scan_avg_us": avg_us(c, "scan"), "exchange_wait_us": avg_us(c, "exchange") if exchange else None,
+                 "merge_us": avg_us(c, "merge") if exchange else None} for c in local_ctxs]
     tune_all("async_select", 0)                   # the select stage is timed on its own, back to back with the scan
-    ctx.set_tuning("prof_select", 1)
-    ctx.prof_reset()
+    for c in local_ctxs:
+        c.set_tuning("prof_every", 1)
+        c.set_tuning("prof_select", 1)
+        c.prof_reset()
     for i in range(20):
         step(i)
     sync()
     n_sel, sel_ms = ctx.prof_read("select")
-    ctx.prof_enable(False)
+    for c, pr in zip(local_ctxs, per_rank):
+        pr["select_avg_us"] = avg_us(c, "select")
+        c.prof_enable(False)
+        c.set_tuning("prof_select", 0)
+    for pr in per_rank:
+        pr["elapsed_ms"] = rank_elapsed * 1e3
+        pr["rows_per_s"] = rows * args.steps / rank_elapsed
+    if use_dist and world > 1:                    # one rank per process: every rank's figures travel to rank 0
+        box = [None] * world
+        dist.all_gather_object(box, per_rank[0])
+        per_rank = box
 
     if use_dist:                                  # MAX over the ranks (one process: there is one clock)
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -545,6 +578,9 @@ def run(args, under_launcher):
         result["config"]["logical_shards_on_one_gpu"] = n_dev   # test hook: n_gpus is 1, the N shards' GPU work serialises
     if rank == 0:
         scan_us = scan_ms / max(n_scan, 1) * 1e3
+        rank_scan = [pr["scan_avg_us"] for pr in per_rank if pr.get("scan_avg_us")]
+        if len(per_rank) > 1 and len(rank_scan) == len(per_rank):
+            scan_us = max(rank_scan)              # the roofline figure of a sharded job is its SLOWEST rank's (min frac over ranks)
         achieved = rows * ROW_BYTES / (scan_us * 1e-6) / 1e9 if n_scan else None
         traffic, traffic_source = measured_traffic("c2", rows)
         result["roofline"] = {
@@ -556,8 +592,28 @@ def run(args, under_launcher):
                              + (f" + {extra_steps} more steps of the same pipeline (--min-bracketed)" if extra_steps else ""),
             "select_avg_us": sel_ms / max(n_sel, 1) * 1e3,
         }
+        if len(per_rank) > 1:
+            result["roofline"]["frac_is"] = "the minimum over the ranks (slowest rank's average scan launch)"
+            result["roofline"]["frac_per_rank"] = [rows * ROW_BYTES / (u * 1e-6) / 1e9 / HBM_PEAK_GBPS if u else None
+                                                   for u in (pr.get("scan_avg_us") for pr in per_rank)]
+        if exchange:
+            # what a SCALE record needs to be explained: who was slow (scan / select per rank), what the exchange cost the merging
+            # device (wait for the slowest list + merge), which transport really ran, every rank's own clock
+            merging = per_rank[0]
+            result["ranks"] = {
+                "process_model": "one process, logical ranks" if args.logical_shards else "one process" if sp else "one rank per process",
+                "transport": ginfo["transport"], "rccl_ranks": ginfo["rccl_ranks"], "n_ranks": n_shards,
+                "scan_avg_us": [pr.get("scan_avg_us") for pr in per_rank], "select_avg_us": [pr.get("select_avg_us") for pr in per_rank],
+                "exchange_wait_us": merging.get("exchange_wait_us"), "merge_us": merging.get("merge_us"),
+                "exchange_wait_us_per_rank": [pr.get("exchange_wait_us") for pr in per_rank],
+                "rank_rows_per_s": [pr.get("rows_per_s") for pr in per_rank], "rank_elapsed_ms": [pr.get("elapsed_ms") for pr in per_rank],
+                "note": "scan / select: HIP events around each rank's own launches; exchange_wait: from the merging device's own k-list being "
+                        "ready to every rank's list being there (rank skew + transport); merge: the merge kernel.  One-process groups: rank 0 "
+                        "takes the answer, so only it has exchange / merge figures; rank_elapsed is the one caller's clock for all of them",
+            }
         result["checks"] = {"torch_fp64_topk_distances_match": torch_ok,
-                            "selects_without_exactness_certificate": uncertain}
+                            "selects_without_exactness_certificate": uncertain,
+                            "every_timed_answer_proved_exact": f"{int((verdicts == 0).sum())}/{len(verdicts)}" if want_verdicts else "not asked/asked"}
         if rows_ok is not None:
             result["checks"]["rows_match_fp64_topk_over_all_shards"] = rows_ok
         if exchange:
@@ -872,6 +928,16 @@ def compact_line(d):
                             "launches": rf.get("launches"), "select_avg_us": _r(rf.get("select_avg_us")),
                             "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate run)"}
     line["host_issue_ms_per_step"] = _r(d.get("host_issue_ms_per_step"))
+    rk = d.get("ranks")
+    if rk:     # N > 1 (or a forced / logical exchange): per-rank figures, 3 significant digits
+        def arr(key):
+            return [_r(v, 3) for v in rk.get(key) or []]
+        line["ranks"] = {"process_model": rk.get("process_model"), "transport": rk.get("transport"), "rccl_ranks": rk.get("rccl_ranks"),
+                         "scan_avg_us": arr("scan_avg_us"), "select_avg_us": arr("select_avg_us"),
+                         "exchange_wait_us": _r(rk.get("exchange_wait_us"), 3), "merge_us": _r(rk.get("merge_us"), 3),
+                         "rank_rows_per_s": arr("rank_rows_per_s")}
+        if rf and rf.get("frac_per_rank"):
+            line["roofline"]["frac_is"] = "min over ranks"
     cb = d.get("cpu_baseline")
     if cb and "error" not in cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),

@@ -106,7 +106,7 @@ int ensure_pinned_in(smt_ctx *ctx, size_t bytes)
     return SMT_OK;
 }
 
-void prof_begin(smt_ctx *ctx, const char *name)
+void prof_begin_on(smt_ctx *ctx, const char *name, hipStream_t st)
 {
     if (!ctx->prof_on) return;
     ProfEntry &e = ctx->prof[name];
@@ -118,18 +118,21 @@ void prof_begin(smt_ctx *ctx, const char *name)
         e.ev.resize(old + 256);
         for (size_t i = old; i < e.ev.size(); ++i) (void)hipEventCreate(&e.ev[i]);
     }
-    (void)hipEventRecord(e.ev[e.used], ctx->stream);
+    (void)hipEventRecord(e.ev[e.used], st);
 }
 
-void prof_end(smt_ctx *ctx, const char *name)
+void prof_end_on(smt_ctx *ctx, const char *name, hipStream_t st)
 {
     if (!ctx->prof_on) return;
     ProfEntry &e = ctx->prof[name];
     if (!e.armed) return;
     e.armed = false;
-    (void)hipEventRecord(e.ev[e.used + 1], ctx->stream);
+    (void)hipEventRecord(e.ev[e.used + 1], st);
     e.used += 2;
 }
+
+void prof_begin(smt_ctx *ctx, const char *name) { prof_begin_on(ctx, name, ctx->stream); }
+void prof_end(smt_ctx *ctx, const char *name) { prof_end_on(ctx, name, ctx->stream); }
 
 int check_ctx(const smt_ctx *ctx)
 {
@@ -410,6 +413,7 @@ try {
     if (rc) return rc;
     SMT_REQUIRE(kernel && launches && total_ms, "null argument");
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) SMT_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));   // ("exchange" / "merge" pairs may lie on it)
     *launches = 0;
     *total_ms = 0.0;
     auto it = ctx->prof.find(kernel);

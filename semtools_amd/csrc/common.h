@@ -201,6 +201,10 @@ int ensure_async(smt_ctx *ctx);  // aux stream + flags
 // RAII-less helpers for event timing around a kernel family.
 void prof_begin(smt_ctx *ctx, const char *name);
 void prof_end(smt_ctx *ctx, const char *name);
+// ... on a given stream of the context's device (the pair may straddle two streams: "exchange" begins behind a rank's own select and
+// ends in front of the merge that waited for every other rank's list)
+void prof_begin_on(smt_ctx *ctx, const char *name, hipStream_t st);
+void prof_end_on(smt_ctx *ctx, const char *name, hipStream_t st);
 
 // ---- kernel launchers (defined in the .hip files) -------------------------
 // K2: single/few-query f32 scan with per-wave top-k' lists, then merge +

@@ -221,7 +221,12 @@ static int peer_merge(smt_group *g, int i, hipStream_t st, void *const *bases, s
         if (waits_enqueued || (j == i && g->pub_stream[j] == st)) continue;   // (the ranks' issuers did it: peer_await / stream order)
         SMT_HIP_CHECK(hipStreamWaitEvent(st, g->ev_ready[j], 0));
     }
+    // profiling (smt_prof_enable on device i's context): "exchange" = from this rank's own list being ready to every list being there
+    // (the skew between the ranks + what the transport costs), "merge" = the merge kernel
+    prof_end_on(g->ctx[i], "exchange", st);
+    prof_begin_on(g->ctx[i], "merge", st);
     if ((rc = launch_merge_topk_sources_on(st, src, (uint32_t)g->n_local, nq, k_in, k_out, out_packed))) return rc;
+    prof_end_on(g->ctx[i], "merge", st);
     if (done) SMT_HIP_CHECK(hipEventRecord(done, st));
     return SMT_OK;
 }
@@ -1388,6 +1393,7 @@ try {
         if (!sc->contiguous && (rc_i = layout_translate_packed(sc, i, async ? c->aux_stream : c->stream, list, nq, top_k)))
             return rc_i;
         if (async) c->async_pending = true;
+        if (out_packed[i]) prof_begin_on(c, "exchange", async ? c->aux_stream : c->stream);   // this rank's list is ready: the wait for the others starts
         if (peer && (rc_i = peer_publish(g, i, async ? c->aux_stream : c->stream))) return rc_i;
         if (spread)   // every merge that will want this rank's list waits for it: enqueued here, off the caller's thread
             for (int m = 0; m < g->n_local; ++m)
@@ -1421,8 +1427,11 @@ try {
         }
         if ((rc = group_bind(g, i))) return rc;
         const uint64_t *gath = reinterpret_cast<const uint64_t *>(reinterpret_cast<char *>(g->buf[i].dev) + gath_off);
+        prof_end_on(c, "exchange", st);
+        prof_begin_on(c, "merge", st);
         rc = launch_merge_topk_packed_on(c, st, gath, (uint32_t)g->n_ranks, nq, top_k, top_k, out_packed[i], want_status ? rank_words : 0);
         if (rc) return rc;
+        prof_end_on(c, "merge", st);
         if (status_i && (rc = launch_combine_status_on(st, nullptr, gath + list_words, rank_words, (uint32_t)g->n_ranks, nq, status_i))) return rc;
     }
     return SMT_OK;

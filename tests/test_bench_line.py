@@ -35,6 +35,30 @@ def test_compact_line_fits_the_drivers_tail_and_carries_every_leg():
     assert line["checks_ok"] is True and line["checks_failed"] == []
 
 
+def test_per_rank_figures_of_a_sharded_run_reach_the_line():
+    """N > 1: the line must explain its own number -- every rank's scan / select microseconds, the merging device's wait for the other
+    ranks' lists and its merge, the transport that ran, every rank's own rate -- and still fit the tail at 8 ranks."""
+    import bench
+
+    d = _canned()
+    n = 8
+    d["config"]["group"] = {"n_ranks": n, "n_local": 1, "first_rank": 0, "rccl_ranks": n, "rccl_version": 22606, "transport": "rccl",
+                            "mode": "one rank per process (smt_group_create_rank: ncclCommInitRank)"}
+    d["n_gpus"] = n
+    d["ranks"] = {"process_model": "one rank per process", "transport": "rccl", "rccl_ranks": n, "n_ranks": n,
+                  "scan_avg_us": [150.123456 + i for i in range(n)], "select_avg_us": [14.87654 + 0.1 * i for i in range(n)],
+                  "exchange_wait_us": 31.4159, "merge_us": 4.2424, "exchange_wait_us_per_rank": [30.0 + i for i in range(n)],
+                  "rank_rows_per_s": [6.2e9 - 1e7 * i for i in range(n)], "rank_elapsed_ms": [3.2 + 0.01 * i for i in range(n)], "note": "x" * 400}
+    d["roofline"]["frac_per_rank"] = [0.84 - 0.005 * i for i in range(n)]
+    line = bench.compact_line(d)
+    rk = line["ranks"]
+    assert rk["transport"] == "rccl" and rk["rccl_ranks"] == n and rk["process_model"] == "one rank per process"
+    assert len(rk["scan_avg_us"]) == n and len(rk["select_avg_us"]) == n and len(rk["rank_rows_per_s"]) == n
+    assert rk["scan_avg_us"][0] == 150.1 and rk["exchange_wait_us"] == 31.42 and rk["merge_us"] == 4.242   # 4 significant digits
+    assert line["roofline"]["frac_is"] == "min over ranks"
+    assert "note" not in rk and len(json.dumps(line)) < 6000, len(json.dumps(line))
+
+
 def test_failed_checks_and_leg_errors_surface_in_the_line():
     import bench
 

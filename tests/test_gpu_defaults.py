@@ -184,6 +184,10 @@ def test_bench_exchange_path_under_torchrun_on_one_rank():
     assert detail["checks"]["torch_fp64_topk_distances_match"] is True
     assert detail["c4"]["checks"]["torch_fp64_topk_distances_match"] is True and detail["c4"]["checks"]["rows_match_fp64_topk"] is True
     assert "rccl_ranks=1" in r.stderr                      # the pre-run diagnostics of a multi-rank launch
+    rk = res["ranks"]                                      # (the per-rank figures travel through dist.all_gather_object in this process model)
+    assert rk["process_model"] == "one rank per process" and rk["transport"] == "rccl" and rk["rccl_ranks"] == 1
+    assert len(rk["scan_avg_us"]) == 1 and rk["scan_avg_us"][0] > 0 and rk["select_avg_us"][0] > 0 and rk["exchange_wait_us"] > 0 and rk["merge_us"] > 0
+    assert detail["checks"]["every_timed_answer_proved_exact"] == "5/5"
 
 
 SMALL = ["--steps", "5", "--warmup", "2", "--settle-steps", "8", "--no-secondary", "--no-ivfpq", "--no-embed", "--no-cpu-baseline",
@@ -228,6 +232,17 @@ def test_bench_one_process_over_logical_shards():
     assert detail["checks"]["rows_match_fp64_topk_over_all_shards"] is True
     assert detail["c4"]["checks"]["rows_match_fp64_topk"] is True and detail["c4"]["config"]["rows_per_gpu"] == 1333334
     assert abs(res["value"] - 3 * 1_000_000 * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3   # rows of ALL shards / time
+    # what makes a SCALE record diagnosable: every rank's scan / select time, the merging device's wait for the others + its merge, the
+    # transport that really ran, every rank's own rate -- in the compact line; roofline.frac is the SLOWEST rank's
+    rk = res["ranks"]
+    assert rk["process_model"] == "one process, logical ranks" and rk["transport"] == "peer" and rk["rccl_ranks"] == 0
+    for key in ("scan_avg_us", "select_avg_us", "rank_rows_per_s"):
+        assert len(rk[key]) == 3 and all(v and v > 0 for v in rk[key]), (key, rk)
+    assert rk["exchange_wait_us"] > 0 and 0 < rk["merge_us"] < 100
+    assert res["roofline"]["frac_is"] == "min over ranks"
+    assert abs(res["roofline"]["avg_kernel_us"] - max(rk["scan_avg_us"])) / res["roofline"]["avg_kernel_us"] < 0.02
+    assert len(detail["roofline"]["frac_per_rank"]) == 3 and abs(min(detail["roofline"]["frac_per_rank"]) - detail["roofline"]["frac"]) < 1e-9
+    assert detail["checks"]["every_timed_answer_proved_exact"] == "5/5"
 
 
 def test_bench_more_gpus_than_the_box_has_is_a_line_not_a_traceback():
