@@ -141,7 +141,8 @@ struct FileWriter {
     bool stop = false, busy = false;
     int device = 0;
     uint32_t dim = 0;
-    std::string error;   // first failure (reported by the drain; the commit then writes everything itself)
+    std::string error;   // first failure since the last commit (consumed by the commit's drain; the commit then writes everything itself)
+    uint64_t jobs_seen = 0;
 
     void run()
     {
@@ -164,6 +165,11 @@ struct FileWriter {
             }
             std::string err;
             if (!ready) err = "write-ahead: no stream / pinned buffers";
+            // test hook: $SEMTOOLS_DEBUG_FAIL_WRITE_AHEAD=n makes this writer's n-th job fail before it writes anything (what ENOSPC or
+            // EIO does to a real one) -- tests/test_gpu_host.py checks that the commit still knows after the corpus has grown
+            ++jobs_seen;
+            if (const char *inj = getenv("SEMTOOLS_DEBUG_FAIL_WRITE_AHEAD"))
+                if (err.empty() && atoll(inj) == (long long)jobs_seen) err = "write-ahead: injected failure (SEMTOOLS_DEBUG_FAIL_WRITE_AHEAD)";
             const int fd = err.empty() ? open(job.path.c_str(), O_WRONLY) : -1;
             if (err.empty() && fd < 0) err = std::string("write-ahead: cannot open '") + job.path + "': " + strerror(errno);
             if (err.empty() && hipStreamWaitEvent(st, job.ready, 0) != hipSuccess) err = "write-ahead: hipStreamWaitEvent failed";
@@ -197,7 +203,11 @@ struct FileWriter {
     }
 };
 
-// Wait until the writer has nothing queued or in hand.  *failed (may be null) receives its first error since the last drain.
+// Wait until the writer has nothing queued or in hand.  *failed (may be null) receives its first error since the last COMMIT: only
+// the caller that passes `failed` -- the commit, which then writes everything itself -- consumes it.  The other drains (the rows are
+// about to move, change or go: corpus_reserve, write_rows, truncate, a save) leave it standing: a corpus doubles its capacity several
+// times during an ingest, and a write-ahead job that failed before one of those growths (ENOSPC, EIO, a copy error) must still be
+// known to the commit -- forgetting it would commit a header over a hole the failed job left in the file.
 int corpus_writer_drain(smt_corpus *c, std::string *failed)
 {
     if (failed) failed->clear();
@@ -206,7 +216,6 @@ int corpus_writer_drain(smt_corpus *c, std::string *failed)
     std::unique_lock<std::mutex> lk(w->mu);
     w->cv_idle.wait(lk, [&] { return w->q.empty() && !w->busy; });
     if (failed) failed->swap(w->error);
-    else w->error.clear();
     return SMT_OK;
 }
 
@@ -334,6 +343,7 @@ int corpus_save_runs(smt_corpus *c, const char *path, const FileRun *runs, size_
     smt_ctx *ctx = c->ctx;
     int rc = bind_device(ctx);
     if (rc) return rc;
+    corpus_writer_drain(c);   // (a queued write-ahead job must not write into a file that is being rewritten; its error, if any, stays for the commit)
     uint64_t total = 0, longest = 0;
     for (size_t j = 0; j < n_runs; ++j) {
         SMT_REQUIRE(runs[j].local_first + runs[j].n_rows <= c->rows, "run extends past the shard");

@@ -787,6 +787,49 @@ def test_rows_written_ahead_are_not_durable_until_the_commit(gpu_ctx, tmp_path):
     sc3.close(); g3.close(); plain.close(); sc.close(); g.close()
 
 
+def test_a_failed_write_ahead_job_is_still_known_to_the_commit_after_the_corpus_grew(gpu_ctx, tmp_path, monkeypatch):
+    """a write-ahead job that fails (ENOSPC, EIO, a copy error -- injected here) leaves a zero-filled hole in the
+    file.  Growing the corpus drains the writer (its rows are about to move); that drain used to CLEAR the writer's error, and the
+    commit then trusted rows_written and put a header over the hole: embeddings persisted corrupt, no error reported.  Only the
+    commit may consume the error; it then writes everything itself.  The file must end byte-identical to a plain save."""
+    import semtools_amd as smt
+    from semtools_amd import _lib as L
+
+    emb = synth.unit_rows(9000, seed=62)
+    g = smt.Group.from_ctx(gpu_ctx)
+    sc = smt.ShardedCorpus(g, empty=True)
+    path = tmp_path / "rows.f32"
+    fn = L.lib().smt_sharded_corpus_append_to_file_ex
+    AHEAD, CREATE = 1, 2
+    monkeypatch.setenv("SEMTOOLS_DEBUG_FAIL_WRITE_AHEAD", "2")              # the writer's second job fails before it writes a byte
+    sc.append(emb[:1200])
+    L.check(fn(sc._h, str(path).encode(), 0, 0, AHEAD | CREATE))            # job 1: rows 0..1200, fine
+    sc.append(emb[1200:3000])
+    L.check(fn(sc._h, str(path).encode(), 0, 1200, AHEAD))                  # job 2: rows 1200..3000 -- fails in the background
+    sc.append(emb[3000:9000])                                               # the corpus outgrows its capacity: corpus_reserve drains the writer
+    L.check(fn(sc._h, str(path).encode(), 0, 3000, AHEAD))                  # job 3: rows 3000..9000, fine
+    L.check(fn(sc._h, str(path).encode(), 0, 9000, 0))                      # the commit: told that everything was written ahead
+    c = smt.Corpus.load(gpu_ctx, path)
+    got = c.read_rows(0, 9000)
+    c.close()
+    assert c is not None and got.shape == (9000, 256)
+    assert np.array_equal(got[1200:3000], emb[1200:3000]), "the failed job's rows are a hole in the committed file"
+    assert np.array_equal(got, emb)
+    plain = smt.Corpus(gpu_ctx)
+    plain.append(emb)
+    plain.save(tmp_path / "plain.f32")
+    assert path.read_bytes() == (tmp_path / "plain.f32").read_bytes()
+    # the commit consumed the error: the next cycle starts clean (job 4 writes, the commit trusts it)
+    monkeypatch.delenv("SEMTOOLS_DEBUG_FAIL_WRITE_AHEAD")
+    more = synth.unit_rows(500, seed=63)
+    sc.append(more)
+    L.check(fn(sc._h, str(path).encode(), 9000, 9000, AHEAD))
+    L.check(fn(sc._h, str(path).encode(), 9000, 9500, 0))
+    c = smt.Corpus.load(gpu_ctx, path)
+    assert c.rows == 9500 and np.array_equal(c.read_rows(9000, 500), more)
+    c.close(); plain.close(); sc.close(); g.close()
+
+
 def test_workspace_written_ahead_equals_the_workspace_written_at_the_end(gpu_ctx, model_dir, prose_files, tmp_path, monkeypatch, capfd):
     """The cold path of a workspace search embeds in batches and writes each batch's rows to line_embeddings.f32 while the next one
     is tokenised (Store::write_rows_ahead; src/workspace/store.rs:402-434 flushes as it goes).  With small batches -- many
