@@ -98,6 +98,7 @@ def parse_args(argv):
     ap.add_argument("--c4-steps", type=int, default=40)
     ap.add_argument("--c4-timeout", type=float, default=300.0, help="several ranks: seconds after which a c4 leg that hangs is abandoned")
     ap.add_argument("--no-group-issue", action="store_true", help="skip the host-issue cost of an 8-shard logical group")
+    ap.add_argument("--no-small-calls", action="store_true", help="skip the small-call latency leg (c1-sized host-form searches)")
     ap.add_argument("--no-workspace", action="store_true", help="skip the workspace-mode leg (range-filtered searches, A10)")
     ap.add_argument("--ws-rows", type=int, default=10_000_000)
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest leg (tokenise || H2D || K1 through the host layer)")
@@ -720,6 +721,12 @@ def run(args, under_launcher):
         except Exception as exc:
             result["group_issue"] = {"error": repr(exc)}
 
+    if rank == 0 and solo and not args.no_small_calls:
+        try:
+            result["small_calls"] = bench_small_calls(smt, ctx, device, shard, k)
+        except Exception as exc:
+            result["small_calls"] = {"error": repr(exc)}
+
     if rank == 0 and solo and not args.no_workspace:
         try:
             with clocks.leg("workspace"):
@@ -961,6 +968,16 @@ def compact_line(d):
     put("c3_image_queries_per_s", "secondary", "operand_image", "queries_per_s")
     put("c3_image_ms_per_batch", "secondary", "operand_image", "ms_per_batch")
     put("c3_image_frac_of_2p5PF", "secondary", "operand_image", "roofline", "frac")
+    # MFMA-busy fraction of the main level of that batch, from counters: a SEPARATE rocprofv3 --pmc run of the same binary
+    # (tools/gpu_r06_pmc.sh -> profiles/r06_k3/r06_k3_summary.json); counters cannot be collected inside a timed run
+    if "c3_queries_per_s" in line:
+        try:
+            k3 = json.load(open(os.path.join(ROOT, "profiles", "r06_k3", "r06_k3_summary.json")))
+            line["c3_mfma_busy_frac"] = k3["1000q_f32rows"]["mfma_busy_frac_main_level"]
+            line["c3_image_mfma_busy_frac"] = k3["1000q_image"]["mfma_busy_frac_main_level"]
+            line["c3_mfma_busy_source"] = "profiles/r06_k3/r06_k3_summary.json (rocprofv3 --pmc, separate run)"
+        except Exception:
+            pass
     put("c3_f32mfma_queries_per_s", "secondary", "roofline_f32_mfma", "queries_per_s")
     put("c3_f32mfma_frac_of_157TF", "secondary", "roofline_f32_mfma", "frac")
     put("c3_1q_10M_f32_scan_ms", "secondary", "single_query_same_corpus", "f32_scan_ms")
@@ -987,6 +1004,14 @@ def compact_line(d):
     put("ws_batch_image_queries_per_s", "workspace", "batch_image", "queries_per_s")
     put("ws_batch_image_ms", "workspace", "batch_image", "ms_per_call")
     put("ws_batch_image_cost_per_scanned_row_vs_unfiltered", "workspace", "batch_image", "cost_per_scanned_row_vs_unfiltered")
+    # host-form calls where the reference lives (c1: one query over 1000 lines): us per synchronous call
+    put("c1_call_us", "small_calls", "delivered", "c1_1000_rows_1q_top3_us", digits=3)
+    put("c1_3q_call_us", "small_calls", "delivered", "c1_1000_rows_3q_top3_us", digits=3)
+    put("one_row_call_us", "small_calls", "delivered", "one_row_1q_us", digits=3)
+    put("rows_64k_call_us", "small_calls", "delivered", "rows_65536_1q_top10_us", digits=3)
+    put("c2_host_call_us", "small_calls", "delivered", "c2_1M_rows_1q_us", digits=4)
+    put("c1_call_us_copy_sync", "small_calls", "copy_and_synchronize", "c1_1000_rows_1q_top3_us", digits=3)
+    put("c2_host_call_us_copy_sync", "small_calls", "copy_and_synchronize", "c2_1M_rows_1q_us", digits=4)
     # several shards driven by one host thread (logical group on one GPU: the issue cost, not the collective)
     put("group_issue_us_8_logical_shards", "group_issue", "host_issue_us_per_search")
     put("group_launches_only_us_8_shards", "group_issue", "one_thread_issues_every_shard_us")
@@ -1027,6 +1052,14 @@ def compact_line(d):
     put("ivf100m_np32_queries_per_s", "ivfpq_full", "nprobe_32", "queries_per_s")
     put("ivf100m_np128_recall_at_k", "ivfpq_full", "nprobe_128", "recall_at_k_vs_exact")
     put("ivf100m_np128_queries_per_s", "ivfpq_full", "nprobe_128", "queries_per_s")
+    put("ivf100m_pq_build_s", "ivfpq_full", "global_pq_m32", "build_s")
+    for np_ in (8, 32):
+        put(f"ivf100m_pq_np{np_}_recall_at_k", "ivfpq_full", "global_pq_m32", f"nprobe_{np_}", "recall_at_k_vs_exact")
+        put(f"ivf100m_pq_np{np_}_queries_per_s", "ivfpq_full", "global_pq_m32", f"nprobe_{np_}", "queries_per_s")
+    for coding, tag in (("per_list_pca", "ivf_hard"), ("global_pq_m32", "ivf_hard_pq")):
+        for np_ in (8, 32, 128):
+            put(f"{tag}_np{np_}_recall_at_k", "ivfpq", "hard_corpus", coding, f"nprobe_{np_}", "recall_at_k_vs_exact")
+            put(f"{tag}_np{np_}_queries_per_s", "ivfpq", "hard_corpus", coding, f"nprobe_{np_}", "queries_per_s")
     put("ivf_pq_recall_at_k", "ivfpq", "global_pq_m32", "recall_at_k_vs_exact")
     put("ivf_pq_queries_per_s", "ivfpq", "global_pq_m32", "queries_per_s")
     put("ivf_pq_build_s", "ivfpq", "global_pq_m32", "build_s")
@@ -1445,6 +1478,85 @@ def bench_group_issue(smt, device, n_shards=8, rows=1_000_000, k=10, n=40):
             "copy_transport_us": copy_us, "copy_transport_every_rank_us": copy_all_us,
             "one_thread_issues_every_shard_us": serial * 1e6, "one_shard_scan_us": 150.0,
             "checks": {"last_answer_matches_fp64_topk": ok_peer and ok_peer_all, "copy_transport_answer_matches": ok_copy and ok_copy_all}}
+
+
+def bench_small_calls(smt, ctx, device, shard, k):
+    """Latency of the HOST-form call (smt_search: host query in, host answer out, synchronous) where the reference lives: c1 -- one
+    query over 1000 lines, top-3 (src/cmds/search.rs:245-257; the agent tool repeats it, src/ask/tools.rs:229-258) -- beside the
+    call's fixed cost (one query over ONE row) and the 1 M-row call of c2.  Small answers are DELIVERED by the select kernel into
+    pinned host memory (tuning key direct_delivery); the same calls with the key off show what the D2H copy + hipStreamSynchronize
+    cost.  Median of 7 rounds of 200 calls, microseconds per call; every answer checked against the fp64 reference of torch."""
+    import ctypes as C
+
+    from semtools_amd import _lib as L
+
+    g = torch.Generator(device=device)
+    g.manual_seed(77)
+    small = torch.randn(65536, 256, device=device, generator=g)
+    small /= small.norm(dim=1, keepdim=True)
+    q = torch.randn(4, 256, device=device, generator=g)
+    q /= q.norm(dim=1, keepdim=True)
+    qh = np.ascontiguousarray(q.cpu().numpy())
+    torch.cuda.synchronize(device)
+    o_rows = np.empty((4, 16), dtype=np.uint64)
+    o_dist = np.empty((4, 16), dtype=np.float64)
+    o_cnt = np.zeros(4, dtype=np.uint64)
+
+    def call(corpus, nq, kk):
+        L.check(L.lib().smt_search(corpus._h, L.np_ptr(qh), nq, kk, float("nan"), L.MODE_DOCUMENTS, None, 0, 0,
+                                   L.np_ptr(o_rows), L.np_ptr(o_dist), L.np_ptr(o_cnt), 16))
+
+    def timed(corpus, nq, kk, reps=200, rounds=7):
+        for _ in range(20):
+            call(corpus, nq, kk)
+        v = []
+        for _ in range(rounds):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call(corpus, nq, kk)
+            v.append((time.perf_counter() - t0) / reps * 1e6)
+        return float(np.median(v))
+
+    def check(corpus_rows, n_rows, nq, kk):
+        sim = (q[:nq].double() @ corpus_rows[:n_rows].double().T)
+        nrm = corpus_rows[:n_rows].double().norm(dim=1)
+        d = (1.0 - sim / (q[:nq].double().norm(dim=1)[:, None] * nrm[None, :])).clamp_min(0)
+        want = torch.topk(d, min(kk, n_rows), dim=1, largest=False, sorted=True)
+        ok = True
+        for i in range(nq):
+            n = int(o_cnt[i])
+            ok = ok and n == min(kk, n_rows) and o_rows[i, :n].astype(np.int64).tolist() == want.indices[i].cpu().tolist()
+            ok = ok and bool(np.abs(o_dist[i, :n] - want.values[i].cpu().numpy()).max() < 1e-9)
+        return ok
+
+    one = smt.Corpus(ctx, device_ptr=small.data_ptr(), rows=1)
+    c1 = smt.Corpus(ctx, device_ptr=small.data_ptr(), rows=1000)
+    c64k = smt.Corpus(ctx, device_ptr=small.data_ptr(), rows=65536)
+    c2 = smt.Corpus(ctx, device_ptr=shard.data_ptr(), rows=shard.shape[0])
+    out = {"config": {"workload": "smt_search, host buffers in and out, one synchronous call at a time: us per call (median of 7 x 200 calls)"}}
+    checks = {}
+    for fused in (1, 0):
+        ctx.set_tuning("direct_delivery", fused)
+        tag = "delivered" if fused else "copy_and_synchronize"
+        leg = {}
+        leg["one_row_1q_us"] = timed(one, 1, 3)
+        leg["c1_1000_rows_1q_top3_us"] = timed(c1, 1, 3)
+        call(c1, 1, 3)
+        checks[f"c1_answer_{tag}"] = check(small, 1000, 1, 3)
+        leg["c1_1000_rows_3q_top3_us"] = timed(c1, 3, 3)
+        call(c1, 3, 3)
+        checks[f"c1_3q_answer_{tag}"] = check(small, 1000, 3, 3)
+        leg["rows_65536_1q_top10_us"] = timed(c64k, 1, 10)
+        call(c64k, 1, 10)
+        checks[f"64k_answer_{tag}"] = check(small, 65536, 1, 10)
+        out[tag] = leg
+        leg["c2_1M_rows_1q_us"] = timed(c2, 1, k, reps=100)
+    ctx.set_tuning("direct_delivery", 1)
+    out["deliveries"] = ctx.deliveries()
+    out["checks"] = checks
+    for c in (one, c1, c64k, c2):
+        c.close()
+    return out
 
 
 def bench_workspace(smt, ctx, device, rows, k, nq_batch=256, n_docs=10_000, max_d=0.9):
@@ -2007,7 +2119,58 @@ def bench_c5(smt, ctx, device, rows, k, nq=1000, nlist=4096, nprobe=8, rerank=12
                                   f"top-{k}; two codings: per-list PCA (shipped) and global PQ m=32 (as BASELINE c5 names it)"}}
     out.update(shipped)                       # the shipped coding's figures at the top level (as in rounds 1-2)
     out["global_pq_m32"] = pq
+    # The 20 000-topic corpus above is EASY for probing (a topic sits inside one list: recall is the same at nprobe 1 and 128), so it
+    # says nothing about the nprobe trade-off SURVEY 8(d) asks for.  The same generative model with 64 broad topics of 32 latent
+    # dimensions (spread 0.8) puts ~64 lists on every topic and a query's true neighbours into many of them: recall RISES with nprobe
+    # (tools/probe_ivf_corpus.py, profiles/r06_probe_ivf_corpus.jsonl: 0.23 / 0.73 / 0.98 / 0.997 at nprobe 1 / 8 / 32 / 128; the 500-topic
+    # corpus of the round-2 sweeps is flat from nprobe 8 on).  Both codings, nprobe 8 / 32 / 128.
+    try:
+        gen = synth.clustered_model_torch(64, 32, 21, device)
+        x = synth.clustered_sample_torch(gen, rows, 22, spread=0.8)
+        qh = synth.clustered_sample_torch(gen, nq, 23, spread=0.8).cpu().numpy()
+        del gen
+        torch.cuda.synchronize(device)
+        hard = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
+        hard_exact = hard.search(qh, top_k=k)
+        out["hard_corpus"] = {"config": {"workload": f"the same index over {rows} chunks in 64 broad topics (32 latent dimensions, spread 0.8: ~{nlist // 64} "
+                                                     f"lists per topic): recall@{k} and queries/s by nprobe, both codings, {rerank} ADC candidates per list re-scored"}}
+        for name, lp in (("per_list_pca", True), ("global_pq_m32", False)):
+            out["hard_corpus"][name] = _c5_probe_sweep(smt, ctx, device, hard, qh, hard_exact, k, lp, nlist, rerank, (8, 32, 128))
+        hard.close()
+        del x
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out["hard_corpus"] = {"error": repr(exc)}
     return out
+
+
+def _c5_probe_sweep(smt, ctx, device, corpus, q, exact, k, local_pca, nlist, rerank, nprobes):
+    """One index over `corpus` (coding by local_pca), searched with every nprobe: recall@k against `exact`, queries/s of the
+    device-resident form (5 batches back to back), agreement of the host and device forms."""
+    nq = len(q)
+    qd = torch.from_numpy(q).to(device)
+    o_rows = torch.empty((nq, k), dtype=torch.int64, device=device)
+    o_dist = torch.empty((nq, k), dtype=torch.float64, device=device)
+    t0 = time.perf_counter()
+    ix = smt.IvfPq(corpus, nlist=nlist, train_iters=10, local_pca=local_pca)
+    res = {"build_s": time.perf_counter() - t0, "index_bytes": ix.info()["index_bytes"]}
+    for nprobe in nprobes:
+        got = ix.search(q, top_k=k, nprobe=nprobe, rerank=rerank)
+        hit = sum(len(set(r.tolist()) & set(e.tolist())) for (r, _), (e, _) in zip(got, exact))
+        ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
+        torch.cuda.synchronize(device)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ix.search_device(qd.data_ptr(), nq, k, nprobe, rerank, 0, o_rows.data_ptr(), o_dist.data_ptr())
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / reps
+        dev_rows = o_rows.cpu().numpy().view(np.uint64)
+        same = all(dev_rows[i, :len(got[i][0])].tolist() == got[i][0].tolist() for i in range(nq))
+        res[f"nprobe_{nprobe}"] = {"recall_at_k_vs_exact": hit / (nq * k), "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
+                                   "checks": {"device_and_host_forms_agree": bool(same)}}
+    ix.close()
+    return res
 
 
 def bench_c5_full(smt, ctx, device, rows, k, nq=1000, nlist=4096, rerank=128):
@@ -2058,6 +2221,11 @@ def bench_c5_full(smt, ctx, device, rows, k, nq=1000, nlist=4096, rerank=128):
     rc = [out[f"nprobe_{p}"]["recall_at_k_vs_exact"] for p in (8, 32, 128)]
     out["checks"] = {"recall_does_not_fall_with_nprobe": bool(rc[1] >= rc[0] - 0.002 and rc[2] >= rc[1] - 0.002)}
     ix.close()
+    # ... and the coding BASELINE config 5 NAMES -- "PQ m=32" -- at the same size: global product quantisation, m = 32 x 256 codes
+    try:
+        out["global_pq_m32"] = _c5_probe_sweep(smt, ctx, device, corpus, q, exact, k, False, nlist, rerank, (8, 32))
+    except Exception as exc:
+        out["global_pq_m32"] = {"error": repr(exc)}
     corpus.close()
     del x
     torch.cuda.empty_cache()

@@ -29,6 +29,23 @@
  *     context's stream without synchronising (bench / multi-GPU pipelines).
  *   - There is no CPU fallback: every compute entry point fails with
  *     SMT_E_HIP when no gfx950 device is usable.
+ *
+ * Domain (semtools_amd/csrc/domain.hip)
+ *   A row or query vector is IN DOMAIN iff every component is finite and its largest magnitude is 0 or lies in
+ *   [2^-40, 2^40].  Inside it the returned distance is simsimd's cosine in its f64 "accurate" form, bit for bit, and
+ *   scaling a vector by a power of two changes no answer.  Outside it the reference itself has no single answer --
+ *   cos_finish turns a NaN into distance 0.0 (the BEST score: src/search/mod.rs:86-89 pushes it, :107-111 sorts it
+ *   first) and the f32 accumulators of simsimd's serial / SIMD backends overflow beyond |x| ~ 1.8e19 and underflow
+ *   below ~1e-19 in an order-dependent way -- and the f32 / fp16 nominating kernels and their error bounds do not
+ *   cover it.  Such vectors are REFUSED at the boundary instead of being answered for:
+ *     - rows, where they enter a corpus (smt_corpus_append_host, smt_corpus_write_rows, smt_corpus_from_device,
+ *       smt_embed with append_to, the sharded forms of these): SMT_E_INVALID, the corpus unchanged, the message
+ *       names the first offending row; the file loaders return SMT_E_IO (a damaged file);
+ *     - queries of the host-form searches: SMT_E_INVALID before anything is launched;
+ *     - queries of the *_device entry points: SMT_STATUS_INVALID_QUERY in the _ex form's status word (and the
+ *       context's uncertain counter); that query's list means nothing.
+ *   model2vec's pool step with `normalize` emits unit or zero rows: nothing the reference's own path produces is
+ *   ever refused.  A corpus adopted with smt_corpus_from_device is checked once, as it is at that call.
  */
 #ifndef SEMTOOLS_HIP_H
 #define SEMTOOLS_HIP_H
@@ -202,11 +219,14 @@ int smt_search_topk_device(smt_corpus *corpus, const float *queries_dev, uint32_
  *                         exact, but a row outside the list may belong to it -- re-ask this query through smt_search
  *   SMT_STATUS_OVERFLOW   batched path only: a candidate buffer overflowed (adversarial row order) and rows were dropped on the
  *                         way; same remedy
+ *   SMT_STATUS_INVALID_QUERY  the query is outside the library's domain ("Domain" at the top of this file: a non-finite
+ *                         component or an absurd magnitude); the list means nothing.  smt_search refuses such a query instead
  * Queries with a non-zero status are also counted by smt_ctx_uncertain_count.  smt_search / smt_sharded_search never return such
  * a list: they re-answer the query exhaustively themselves. */
 #define SMT_STATUS_PROVED 0
 #define SMT_STATUS_UNCERTAIN 1
 #define SMT_STATUS_OVERFLOW 2
+#define SMT_STATUS_INVALID_QUERY 3
 int smt_search_topk_device_ex(smt_corpus *corpus, const float *queries_dev, uint32_t nq,
                               uint32_t top_k, uint64_t row_base, uint64_t *out_rows_dev,
                               double *out_dist_dev, uint32_t *out_status_dev);
@@ -235,7 +255,10 @@ int smt_merge_topk_packed_device(smt_ctx *ctx, const uint64_t *packed_dev, uint3
  * label); the contract is recall against smt_search on the same corpus.  Every returned
  * (row, distance) is exact -- candidates from the ADC scan are re-ranked with the exact f64
  * distance -- only top-k membership is approximate.  The index keeps a pointer to `corpus`,
- * which must stay alive and unchanged. */
+ * which must stay alive and unchanged.  It is built for what model2vec emits -- UNIT rows (zero
+ * rows are fine): its quantisers work on the rows as they are, not on their directions, so
+ * smt_ivfpq_build / smt_ivfpq_append refuse a corpus holding rows of other lengths
+ * (| |x|^2 - 1 | > 1e-3) with SMT_E_UNSUPPORTED; the exact searches have no such condition. */
 typedef struct smt_ivfpq smt_ivfpq;
 typedef struct smt_ivfpq_params {
     uint32_t nlist;        /* coarse lists: multiple of 32 in [32, 4096]                  */
@@ -464,6 +487,10 @@ int smt_ctx_uncertain_count(smt_ctx *ctx, uint64_t *count, int reset);
  * searching the same file set again uploads only its queries.  kept: sets alive; hits: searches answered from one; builds: sets made. */
 int smt_debug_range_sets(const smt_corpus *corpus, uint64_t *kept, uint64_t *hits, uint64_t *builds);
 
+/* Test hook for delivered answers (tuning key direct_delivery): how many host-form searches on this context got their answer written
+ * into pinned host memory by the select kernel and waited on its completion word, instead of a D2H copy + hipStreamSynchronize. */
+int smt_debug_deliveries(smt_ctx *ctx, uint64_t *count);
+
 /* Test hook for the SPMD error paths of multi-process groups: arms ONE injected failure with status `code` (an SMT_E_* value) on
  * THIS process's ranks; it fires at the next step of kind `where` and disarms.  The tests arm it on one rank of an n-rank group and
  * check that every rank returns `code` from the same call and that none is left waiting inside a collective.
@@ -520,6 +547,9 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
  *   gemm_resident        accepted and ignored (its kernel left in round 2)
  *   gemm_bf16x3 (1/0)    K3 nominates with bf16 x 3 split products on the bf16 MFMA pipe (default) or with f32 MFMAs;
  *                        answers are identical either way (exact re-scoring + the exactness certificate)
+ *   direct_delivery (1/0)  smt_search top-k calls with a small answer (<= 32 queries, <= 8 KiB of rows and distances) get it DELIVERED
+ *                        by the select kernel: its last block writes the answer into pinned host memory and a completion word behind
+ *                        it, which the host waits on -- no D2H copy command, no hipStreamSynchronize (~10 us of a small call); 0: A/B
  *   prof_select (0/1), prof_every (N: HIP events on one launch in N)       profiling cost control
  *   scan_debug_ptr, select_debug_ptr                                       device pointers for phase stamps
  *   async_select (0/1)   smt_search_topk_device with ONE query: the select stage of call i runs on an

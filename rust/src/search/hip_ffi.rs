@@ -43,6 +43,7 @@ pub const SMT_MODE_WORKSPACE: c_int = 1;
 pub const SMT_STATUS_PROVED: c_int = 0;
 pub const SMT_STATUS_UNCERTAIN: c_int = 1;
 pub const SMT_STATUS_OVERFLOW: c_int = 2;
+pub const SMT_STATUS_INVALID_QUERY: c_int = 3;
 pub const SMT_UNIQUE_ID_BYTES: usize = 128;
 pub const SMT_TRANSPORT_RCCL: c_int = 0;
 pub const SMT_TRANSPORT_COPY: c_int = 1;
@@ -430,6 +431,7 @@ extern "C" {
     ) -> c_int;
     pub fn smt_ctx_uncertain_count(ctx: *mut SmtCtx, count: *mut u64, reset: c_int) -> c_int;
     pub fn smt_debug_range_sets(corpus: *const SmtCorpus, kept: *mut u64, hits: *mut u64, builds: *mut u64) -> c_int;
+    pub fn smt_debug_deliveries(ctx: *mut SmtCtx, count: *mut u64) -> c_int;
     pub fn smt_debug_group_fail_next(group: *mut SmtGroup, where_: c_int, code: c_int) -> c_int;
     pub fn smt_debug_batched_scores(
         corpus: *mut SmtCorpus,

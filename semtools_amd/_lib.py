@@ -39,9 +39,9 @@ EXPORTS = [
     "smt_sharded_model_create", "smt_sharded_model_create_from_file", "smt_sharded_model_destroy", "smt_sharded_embed",
     "smt_sharded_ivfpq_save", "smt_sharded_ivfpq_load", "smt_sharded_ivfpq_append", "smt_sharded_ivfpq_info",
     "smt_group_set_transport", "smt_group_transport", "smt_debug_range_sets", "smt_sharded_corpus_append_to_file_ex",
-    "smt_debug_group_fail_next", "smt_search_topk_device_ex", "smt_sharded_search_topk_device_ex",
+    "smt_debug_group_fail_next", "smt_search_topk_device_ex", "smt_sharded_search_topk_device_ex", "smt_debug_deliveries",
 ]
-STATUS_PROVED, STATUS_UNCERTAIN, STATUS_OVERFLOW = 0, 1, 2
+STATUS_PROVED, STATUS_UNCERTAIN, STATUS_OVERFLOW, STATUS_INVALID_QUERY = 0, 1, 2, 3
 TRANSPORT_RCCL, TRANSPORT_COPY, TRANSPORT_PEER = 0, 1, 2
 TRANSPORT_NAMES = {TRANSPORT_RCCL: "rccl", TRANSPORT_COPY: "copy", TRANSPORT_PEER: "peer"}
 UNIQUE_ID_BYTES = 128
@@ -188,6 +188,7 @@ def lib():
     try:   # (a test hook: an older build of the library under tools/ab_* A/B runs does not have it)
         L.smt_debug_range_sets.argtypes = [vp, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         L.smt_debug_group_fail_next.argtypes = [vp, i32, i32]
+        L.smt_debug_deliveries.argtypes = [vp, P(C.c_uint64)]
     except AttributeError:
         pass
     L.smt_sharded_corpus_append_to_file_ex.argtypes = [vp, C.c_char_p, u64, u64, i32]

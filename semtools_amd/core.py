@@ -50,6 +50,12 @@ class Context:
         L.check(L.lib().smt_ctx_uncertain_count(self._h, C.byref(n), int(bool(reset))))
         return int(n.value)
 
+    def deliveries(self):
+        """Host-form searches whose answer the select kernel delivered into pinned host memory (smt_debug_deliveries)."""
+        n = C.c_uint64(0)
+        L.check(L.lib().smt_debug_deliveries(self._h, C.byref(n)))
+        return int(n.value)
+
     def aux_stream(self):
         """Raw hipStream_t of the context's second stream (async selects run there); wrap it with
         torch.cuda.ExternalStream to chain torch / RCCL work behind an async select."""
@@ -572,7 +578,9 @@ class ShardedCorpus:
         if out_cap is None:
             out_cap = max(int(top_k), 1)
             if max_distance is not None and mode == L.MODE_DOCUMENTS:
-                out_cap = max(min(self.rows, 1 << 16), 1)     # (every row under the threshold: a first guess, grown on SMT_E_TRUNCATED)
+                # every row under the threshold: a first guess bounded by a TOTAL budget of 64 MB of result buffers (1000 queries x
+                # 65 536 slots x 16 B was 1 GB of numpy arrays up front), grown on SMT_E_TRUNCATED to the true counts
+                out_cap = max(int(top_k), min(self.rows, 1 << 16, (64 << 20) // (16 * max(nq, 1))), 1)
         rng, n_rng = _ranges_arg(ranges)
         while True:
             out_rows = np.empty((nq, out_cap), dtype=np.uint64)

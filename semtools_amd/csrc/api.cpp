@@ -482,6 +482,7 @@ try {
     else if (k == "scan_debug_ptr") ctx->tune.scan_debug_ptr = value;
     else if (k == "select_debug_ptr") ctx->tune.select_debug_ptr = value;
     else if (k == "prof_select") ctx->tune.prof_select = (int)value;
+    else if (k == "direct_delivery") ctx->tune.direct_delivery = (int)value;
     else { set_error("unknown tuning key '%s'", key); return SMT_E_INVALID; }
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }
@@ -570,6 +571,12 @@ try {
     c->ctx = ctx; c->dim = D; c->owned = false;
     c->d_rows = const_cast<float *>(rows_dev);
     c->rows = n_rows; c->capacity = n_rows;
+    // the rows as they are NOW must be in the library's domain (domain.hip); the caller answers for what it writes there later
+    if (n_rows) {
+        int rc2 = bind_device(ctx);
+        if (!rc2) rc2 = require_rows_domain(ctx, rows_dev, n_rows, "smt_corpus_from_device");
+        if (rc2) { delete c; return rc2; }
+    }
     *out = c;
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }
@@ -601,7 +608,8 @@ try {
     if ((rc = corpus_reserve(c, c->rows + n_rows))) return rc;
     SMT_HIP_CHECK(hipMemcpyAsync(c->d_rows + (size_t)c->rows * c->dim, rows, (size_t)n_rows * c->dim * sizeof(float),
                                  hipMemcpyHostToDevice, c->ctx->stream));
-    SMT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    // (checked where they landed, behind the last counted row: a refused batch leaves the corpus as it was)
+    if ((rc = require_rows_domain(c->ctx, c->d_rows + (size_t)c->rows * c->dim, n_rows, "smt_corpus_append_host", 0))) return rc;
     c->rows += n_rows;
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }
@@ -613,6 +621,14 @@ try {
     int rc = bind_device(c->ctx);
     if (rc) return rc;
     if (n_rows == 0) return SMT_OK;
+    {
+        const int64_t bad = first_outside_domain_host(rows, n_rows, c->dim);   // (before anything is overwritten)
+        if (bad >= 0) {
+            set_error("smt_corpus_write_rows: row %lld of the %llu given is outside the library's domain (finite, largest magnitude 0 "
+                      "or within [2^-40, 2^40])", (long long)bad, (unsigned long long)n_rows);
+            return SMT_E_INVALID;
+        }
+    }
     corpus_writer_drain(c);   // (a write-ahead job may be reading these rows)
     SMT_HIP_CHECK(hipMemcpyAsync(c->d_rows + (size_t)first_row * c->dim, rows, (size_t)n_rows * c->dim * sizeof(float),
                                  hipMemcpyHostToDevice, c->ctx->stream));
@@ -727,7 +743,11 @@ try {
     if (out_host)
         SMT_HIP_CHECK(hipMemcpyAsync(out_host, d_out, (size_t)n_lines * model->D * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (append_to) append_to->rows += n_lines;
+    if (append_to) {
+        // a table with non-finite or absurd entries pools rows no search kernel answers for: they do not enter the corpus
+        if ((rc = require_rows_domain(ctx, d_out, n_lines, "smt_embed (rows pooled from the table)", 0))) return rc;
+        append_to->rows += n_lines;
+    }
     return SMT_OK;
 } catch (...) { return smt::api_catch(); }
 

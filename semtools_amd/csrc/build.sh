@@ -10,7 +10,7 @@ objs=()
 pids=()
 jobs_max="${BUILD_JOBS:-$(nproc)}"
 newest_hdr="$(ls -t "$here"/*.h "$here"/host/*.h "$here"/../../include/*.h | head -1)"
-for src in api.cpp search.cpp corpus_io.cpp group.cpp sharded.cpp scan_kernels.hip embed_kernels.hip gemm_topk.hip gemm_rowreg.hip gemm_ldsrow.hip gemm_level.hip largek.hip threshold.hip ivfpq_build.hip ivfpq_search.hip ivfpq_io.hip host/host.cpp host/store.cpp host/output.cpp host/hf_tokenizer.cpp host/host_capi.cpp; do
+for src in api.cpp search.cpp corpus_io.cpp group.cpp sharded.cpp scan_kernels.hip embed_kernels.hip gemm_topk.hip gemm_rowreg.hip gemm_ldsrow.hip gemm_level.hip largek.hip threshold.hip domain.hip ivfpq_build.hip ivfpq_search.hip ivfpq_io.hip host/host.cpp host/store.cpp host/output.cpp host/hf_tokenizer.cpp host/host_capi.cpp; do
   base="$(basename "${src%.*}")"
   obj="$out/$base.o"
   if [[ ! -f "$obj" || "$here/$src" -nt "$obj" || "$newest_hdr" -nt "$obj" ]]; then

@@ -81,6 +81,7 @@ struct Tuning {
     int gemm_bf16x3 = 1;        // 1: K3 nominates candidates with bf16 x 3 split products on the bf16 MFMA pipe (mfma_tile.h); 0: f32 MFMA
     int gemm_ldsrow = 1;        // 1: batches <= 128 queries and range-filtered batches use the LDS-row kernel (64 queries per pass)
     int prof_select = 1;        // 0: do not bracket the select stage with events (2 fewer event records per query)
+    int direct_delivery = 1;    // 1: host-form top-k searches with small answers (<= 8 KiB) get them DELIVERED by the select kernel into pinned host memory, completion word last; the host waits on that word (search.cpp; 0: D2H copy + hipStreamSynchronize, A/B)
     int64_t scan_debug_ptr = 0;    // device pointer to (2*waves + blocks) u64 wall_clock64 stamps (profiling only)
     int64_t select_debug_ptr = 0;  // device pointer to 16 u64 for phase stamps (profiling only)
 };
@@ -106,10 +107,12 @@ struct smt_ctx {
     // async select (tuning key async_select): the select of query i runs on aux_stream WHILE query i+1 scans;
     // the two kernels meet through device-scope flags, not stream events
     hipStream_t aux_stream = nullptr;
-    unsigned long long *d_status = nullptr; // [0] selects whose exactness certificate failed since the last read (sticky)
+    unsigned long long *d_status = nullptr; // [0] selects whose exactness certificate failed since the last read (sticky); [2], [3] the row domain check's (count, first row) (domain.hip); [4] the select blocks of a delivering launch that have finished (scan_kernels.hip)
     unsigned long long *d_flags = nullptr;  // [0] scan_done step, [1] select_done step, [2] blocks finished, [3] timeout flag
     uint64_t async_step = 0;
     bool async_pending = false;
+    unsigned long long deliver_seq = 0;      // sequence number of the last delivered answer (its completion word in pinned memory)
+    uint64_t deliveries = 0;                 // host-form searches answered that way (smt_debug_deliveries)
     bool prof_on = false;
     // kernels whose >64 KiB dynamic-LDS attribute has been set ON THIS DEVICE (bit per kernel family, smt::ATTR_*).
     // Per context, not per process: hipFuncSetAttribute applies to the current device's copy of the function, and a
@@ -124,7 +127,7 @@ namespace smt {
 // a `serve -w` session, an `ask` agent or a shell loop search the same file set again and again, and validating + prefixing +
 // uploading 5000 ranges and rebuilding their tile table was 0.17 ms of a 0.59 ms one-query call.  Identified by two independent
 // 64-bit hashes of the list; built the SECOND time a list is seen (one-shot subsets never allocate); at most RANGE_SETS_MAX per
-// corpus, least recently used goes first.  The tables depend on the ranges only, never on the rows: appends do not invalidate them.
+// corpus, least recently used goes first.  The hashes only FIND a candidate: the kept host copy of the list decides (memcmp).  The tables depend on the ranges only, never on the rows: appends do not invalidate them.
 struct RangeSet {
     uint64_t h1 = 0, h2 = 0;
     uint32_t n_in = 0;                 // ranges as passed (empty ones included: part of the identity)
@@ -136,6 +139,7 @@ struct RangeSet {
     uint64_t *d_tile_table = nullptr, *d_chunk_table = nullptr;   // nullptr: too large to keep (rebuilt per call in scratch)
     bool have_tile_table = false, have_chunk_table = false;
     uint64_t last_use = 0;
+    std::vector<smt_range> host_ranges;   // the list as passed (n_in entries): a hash hit is confirmed by comparing it
 };
 struct FileWriter;
 constexpr int RANGE_SETS_MAX = 4;
@@ -241,6 +245,7 @@ struct ScanArgs {
     uint64_t out_stride = 0;  // words between the output lists of consecutive queries (0 = k_out); the packed
                               // [nq][2][k] exchange layout of group.cpp uses 2*k with out_dist = out_rows + k
     struct RangeSet *range_set = nullptr;   // the ranges come from a kept set: its tile / chunk tables are built once and reused
+    const struct Delivery *deliver = nullptr;   // the select stage delivers the answers to pinned host memory (below)
 };
 int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a);
 void corpus_range_sets_drop(smt_corpus *c);   // search.cpp (smt_corpus_destroy)
@@ -281,6 +286,20 @@ int launch_gather_rows256(smt_ctx *ctx, const float *src, const uint32_t *idx_de
 int launch_rescore_rows_multi(smt_ctx *ctx, const float *corpus, const float *queries, const uint32_t *rows, const uint32_t *qidx,
                               uint64_t n, double *out_dist);
 
+// DELIVERY of a small answer by the select kernel itself (host-form searches, search.cpp): the outputs of a launch lie in ONE device
+// block (dev_out, n_words 8-byte words); the LAST select block to finish copies it to pinned host memory (host_out) and then stores
+// `seq` into the pinned word host_flag with a system-scope release.  The host waits on that word instead of enqueueing a D2H copy
+// and calling hipStreamSynchronize: measured on an MI355X (tools/micro/call_floor.hip, profiles/r06_call_floor.json) a kernel that
+// announces its result in pinned memory is back in 6.5 us, kernel + hipStreamSynchronize in 12.5, with the download 15+.
+struct Delivery {
+    const unsigned long long *dev_out = nullptr;
+    unsigned long long *host_out = nullptr;
+    uint32_t n_words = 0;
+    unsigned long long *host_flag = nullptr;
+    unsigned long long seq = 0;
+    unsigned long long *done = nullptr;   // device counter of finished select blocks (0 between launches)
+};
+
 // Select stage: block lists -> best k_out per query with exact f64 distances (scan_kernels.hip).
 struct SelectArgs {
     const float *corpus = nullptr;
@@ -312,8 +331,10 @@ struct SelectArgs {
     // the device entry points count it -- so that no batched call needs a host synchronisation of its own (until round 5
     // launch_gemm_topk read this flag back after every batch).
     const unsigned int *overflow = nullptr;
+    const Delivery *deliver = nullptr;   // the last block carries the answers home (not with async_step)
 };
 int launch_select(smt_ctx *ctx, const SelectArgs &s);
+
 
 // |f32 scan distance - exact distance| bounds used for the certificate.  What an MFMA does to its accumulator was MEASURED
 // on gfx950 (tools/micro/mfma_rounding.hip, profiles/r03_mfma_rounding.json): v_mfma_f32_32x32x2_f32 is a chain of fused
@@ -345,6 +366,10 @@ struct LocalHits {
 };
 int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
                       const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out);
+// a zero query in workspace mode has a constant answer (search.cpp: qdrant scores it 0 against every point)
+bool query_is_zero(const float *q);
+void workspace_zero_query_hits(const smt_range *ranges, uint32_t n_ranges, uint64_t n_rows, uint32_t top_k, bool has_thr, double max_distance,
+                               uint64_t row_base, LocalHits &out);
 int deliver_hits(const std::vector<LocalHits> &hits, uint64_t *out_rows, double *out_dist, uint64_t *out_counts, uint64_t out_cap);
 int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint32_t nq, uint32_t k_pad, int ws_threshold,
                              float ws_thr_score, const smt_range *ranges_local, uint32_t n_ranges, bool filtered,
@@ -406,6 +431,19 @@ namespace smt {
 int ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, const IvfBuildShare *share, smt_ivfpq **out);
 int ivfpq_search_packed(smt_ivfpq *ix, const float *queries_dev, uint32_t nq, uint32_t top_k, uint32_t nprobe, uint32_t rerank,
                         uint64_t row_base, uint64_t *packed_dev);
+
+// domain.hip: the numeric domain of rows and queries (finite, largest magnitude 0 or within [2^-40, 2^40]) and its checks
+constexpr uint32_t DOMAIN_MIN_BITS = 0x2B800000u;   // 2^-40f
+constexpr uint32_t DOMAIN_MAX_BITS = 0x53800000u;   // 2^40f
+__host__ __device__ inline bool magnitude_in_domain(uint32_t max_abs_bits)
+{
+    return max_abs_bits == 0 || (max_abs_bits >= DOMAIN_MIN_BITS && max_abs_bits <= DOMAIN_MAX_BITS);
+}
+int check_rows_domain(smt_ctx *ctx, const float *d_rows, uint64_t n_rows, uint64_t *n_bad, uint64_t *first_bad);
+int require_rows_domain(smt_ctx *ctx, const float *d_rows, uint64_t n_rows, const char *what, uint64_t base = 0);
+int require_unit_rows(smt_ctx *ctx, const float *d_rows, uint64_t n_rows, const char *what, uint64_t base = 0);   // (the IVF index)
+int64_t first_outside_domain_host(const float *v, uint64_t n, uint32_t dim);
+int require_queries_domain_host(const float *queries, uint32_t nq, const char *what);
 
 // K1
 int launch_embed(smt_ctx *ctx, const float *table, uint64_t V, int normalize, const uint32_t *ids,

@@ -315,6 +315,17 @@ int corpus_load_slice(smt_corpus *c, const char *path, uint64_t first_row, uint6
     fclose(f);
     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     pp.busy[0] = pp.busy[1] = false;
+    // a foreign or damaged file may hold anything: its rows enter the corpus only if they are in the library's domain (domain.hip)
+    {
+        uint64_t n_bad = 0, first = 0;
+        if ((rc = check_rows_domain(ctx, c->d_rows + (size_t)c->rows * c->dim, n_rows, &n_bad, &first))) return rc;
+        if (n_bad) {
+            set_error("'%s': %llu rows are outside the library's domain (first: row %llu of the file) -- non-finite or absurd "
+                      "magnitudes: a damaged or foreign file (include/semtools_hip.h, \"Domain\")", path, (unsigned long long)n_bad,
+                      (unsigned long long)(first_row + first));
+            return SMT_E_IO;   // (what a truncated file returns too: the workspace store then starts empty and re-embeds)
+        }
+    }
     c->rows += n_rows;
     return SMT_OK;
 }

@@ -416,6 +416,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     if (a.nq > pass_nq) {
         // (GEMM_MAX_NQ: the per-query thresholds of one gemm_level_kernel launch live in LDS beside the four
         // query-tile slots: larger batches are answered in chunks, each its own sweep over the corpus)
+        SMT_REQUIRE(a.deliver == nullptr, "an answer delivered by the select kernel comes from ONE select launch (search.cpp keeps such calls below one pass)");
         for (uint32_t q0 = 0; q0 < a.nq; q0 += pass_nq) {
             ScanArgs c = a;
             c.nq = std::min<uint32_t>(pass_nq, a.nq - q0);
@@ -705,6 +706,7 @@ int launch_gemm_topk(smt_ctx *ctx, const ScanArgs &a)
     sel.out_uncertain = a.out_uncertain;
     sel.out_status = a.out_status;
     sel.overflow = overflow;
+    sel.deliver = a.deliver;
     rc = launch_select(ctx, sel);
     if (rc) return rc;
 

@@ -1200,6 +1200,8 @@ try {
     SMT_REQUIRE(n_ranges == 0 || ranges != nullptr, "ranges");
     smt_group *g = sc->group;
     if (nq == 0) return SMT_OK;
+    // (domain.hip; SPMD callers pass the same host arguments, so every rank refuses together, before any collective)
+    if (int rcq = require_queries_domain_host(queries, nq, "smt_sharded_search")) return rcq;
     if (g->n_ranks == 1)   // one shard: the single-GPU call, nothing to exchange
         return smt_search(sc->shard[0], queries, nq, top_k, max_distance, mode, ranges, n_ranges, 0, out_rows, out_dist, out_counts, out_cap);
     for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
@@ -1341,6 +1343,10 @@ try {
             return rc;
         for (size_t j = 0; j < redo.size(); ++j) hits[redo[j]] = std::move(merged[j]);
     }
+    if (mode == SMT_MODE_WORKSPACE)   // (a zero query's answer is a constant: search.cpp workspace_zero_query_hits -- the same on every rank)
+        for (uint32_t q = 0; q < nq; ++q)
+            if (query_is_zero(queries + (size_t)q * SMT_DIM))
+                workspace_zero_query_hits(ranges, n_ranges, total, top_k, has_thr, max_distance, 0, hits[q]);
     return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
 } catch (...) { return smt::api_catch(); }
 
@@ -1371,7 +1377,10 @@ try {
     // the select of a single query may run on the aux stream while the NEXT call's scan streams (async select); the exchange and
     // the merge then follow it there, and the main stream carries nothing but scans
     for (int i = 0; i < g->n_local; ++i) on_aux[i] = g->ctx[i]->tune.async_select && nq == 1 && sc->shard[i]->rows >= top_k ? 1 : 0;
-    const bool spread = peer && g->spread_waits && g->workers != nullptr;
+    const bool spread = peer && g->spread_waits && g->workers != nullptr && g->n_local <= 64;
+    std::vector<std::atomic<uint64_t>> awaiting(g->n_local);   // [m]: ranks whose list is published and whose wait on m's stream nobody has enqueued yet
+    std::vector<std::atomic<int>> issued(g->n_local);          // [m]: m's own scan + select + publish are on its stream
+    for (int i = 0; i < g->n_local; ++i) { awaiting[i].store(0, std::memory_order_relaxed); issued[i].store(0, std::memory_order_relaxed); }
     int slot = 0;
     if (peer) {   // rank j writes its list into slot `slot` of its ring; whoever needs the answer reads the slots in place
         if ((rc = ring_ensure(g, rank_words * 8))) return rc;
@@ -1395,11 +1404,36 @@ try {
         if (async) c->async_pending = true;
         if (out_packed[i]) prof_begin_on(c, "exchange", async ? c->aux_stream : c->stream);   // this rank's list is ready: the wait for the others starts
         if (peer && (rc_i = peer_publish(g, i, async ? c->aux_stream : c->stream))) return rc_i;
-        if (spread)   // every merge that will want this rank's list waits for it: enqueued here, off the caller's thread
-            for (int m = 0; m < g->n_local; ++m)
-                if (out_packed[m] && (rc_i = peer_await(g, i, m, on_aux[m] ? g->ctx[m]->aux_stream : g->ctx[m]->stream))) return rc_i;
+        if (spread) {
+            // Every merge that will want this rank's list waits for it, enqueued off the caller's thread -- but never AHEAD of the
+            // merging device's own scan: a wait for rank i's event that lands on device m's stream before m's issuer has put its scan
+            // and select there makes shard m's whole share queue up behind shard i's (twice the latency, by timing).  So a
+            // wait is enqueued by whoever comes SECOND: rank i posts its bit in awaiting[m] and then looks at issued[m]; if m's own
+            // work is on its stream already, i takes the bit back and, if it still had it, enqueues the wait itself; m, once its own
+            // work is issued, raises issued[m] and enqueues the waits of every bit it finds.  Each bit is claimed exactly once.
+            const uint64_t mine = 1ull << i;
+            auto stream_of = [&](int m) { return on_aux[m] ? g->ctx[m]->aux_stream : g->ctx[m]->stream; };
+            if (out_packed[i]) {
+                if ((rc_i = peer_await(g, i, i, stream_of(i)))) return rc_i;   // (its own list: stream order, or the hop from its aux stream)
+                issued[i].store(1, std::memory_order_seq_cst);
+                uint64_t got = awaiting[i].exchange(0, std::memory_order_seq_cst);
+                for (int j = 0; got; ++j, got >>= 1)
+                    if ((got & 1) && (rc_i = peer_await(g, j, i, stream_of(i)))) return rc_i;
+            }
+            for (int m = 0; m < g->n_local; ++m) {
+                if (!out_packed[m] || m == i) continue;
+                awaiting[m].fetch_or(mine, std::memory_order_seq_cst);
+                if (issued[m].load(std::memory_order_seq_cst) && (awaiting[m].fetch_and(~mine, std::memory_order_seq_cst) & mine))
+                    if ((rc_i = peer_await(g, i, m, stream_of(m)))) return rc_i;
+            }
+        }
         return SMT_OK;
     }, g->workers != nullptr);
+    if (spread && !rc)   // (a merging device whose issuer failed before raising its flag leaves bits behind: the call fails anyway)
+        for (int m = 0; m < g->n_local; ++m)
+            if (uint64_t left = awaiting[m].exchange(0, std::memory_order_seq_cst))
+                for (int j = 0; left; ++j, left >>= 1)
+                    if ((left & 1) && (rc = peer_await(g, j, m, on_aux[m] ? g->ctx[m]->aux_stream : g->ctx[m]->stream))) return rc;
     if (rc) return rc;
     if (!peer && (rc = allgather_words(g, 0, gath_off, rank_words, &on_aux))) return rc;
     for (int i = 0; i < g->n_local; ++i) {
@@ -1502,6 +1536,7 @@ try {
     smt_group *g = sc->group;
     SMT_REQUIRE((uint64_t)g->n_ranks * top_k <= 8192, "device merge handles up to 8192 candidates per query");
     if (nq == 0) return SMT_OK;
+    if (int rcq = require_queries_domain_host(queries, nq, "smt_sharded_ivfpq_search")) return rcq;   // (domain.hip; SPMD: all ranks alike)
     if (g->n_ranks == 1) return smt_ivfpq_search(six->shard[0], queries, nq, top_k, nprobe, rerank, 0, out_rows, out_dist, out_counts, out_cap);
     const size_t list_words = (size_t)nq * 2 * top_k;
     const size_t q_bytes = ((size_t)nq * SMT_DIM * 4 + 255) & ~(size_t)255;

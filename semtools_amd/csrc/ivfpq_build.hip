@@ -578,6 +578,9 @@ int smt::ivfpq_build_shared(smt_corpus *corpus, const smt_ivfpq_params *prm, con
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf b_assign, b_sums, b_counts;
     int rc = [&]() -> int {
+        // the index ranks rows as they are, not their directions: unit (or zero) rows only (domain.hip); part of the set-up so
+        // that, in a shared build, a rank holding other rows takes the others with it
+        if (int rcu = smt::require_unit_rows(ctx, corpus->d_rows, N, "smt_ivfpq_build")) return rcu;
         if (lpca) {
             IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_basis), (size_t)nlist * LP_DIMS * 256 * 4));
             IVF_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_lscale), (size_t)nlist * LP_DIMS * 4));
@@ -752,6 +755,7 @@ try {
     const uint32_t nlist = ix->nlist;
     DevBuf b_assign, b_sorted, b_iota, b_ids, b_temp, b_codes, b_noff;
     int rc;
+    if ((rc = smt::require_unit_rows(ctx, corpus->d_rows + (size_t)n_old * 256, n_new, "smt_ivfpq_append", n_old))) return rc;
     if ((rc = dev_alloc(b_assign, n_new * 4)) || (rc = dev_alloc(b_sorted, n_new * 4)) || (rc = dev_alloc(b_iota, n_new * 4)) ||
         (rc = dev_alloc(b_ids, n_new * 4)) || (rc = dev_alloc(b_codes, n_new * PQ_M)) || (rc = dev_alloc(b_noff, (size_t)(nlist + 1) * 8)))
         return rc;

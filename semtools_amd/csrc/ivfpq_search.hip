@@ -108,16 +108,20 @@ __global__ void __launch_bounds__(256) ivf_probe_select_kernel(ProbeParams p, co
     }
 }
 
-// LUT[q][s][code] = <q_s, codebook[s][code]>; grid (nq, 32), 256 threads
+// LUT[q][code][s] = <q_s, codebook[s][code]>; grid (nq, 32), 256 threads.  CODE-major: sub-quantiser s owns LDS bank s of the scan
+// kernel's copy (ivf_adc_kernel, KIND 0), whatever the codes are.
 __global__ void ivf_lut_kernel(const float *queries, const float *codebooks, float *lut)
 {
-    const uint32_t qi = blockIdx.x, s = blockIdx.y, code = threadIdx.x;
+    // 8 codes x 32 sub-quantisers per block, s fastest: the stores are coalesced (with one sub-quantiser per block and code = thread
+    // they lay 128 B apart and this kernel doubled the probe stage, 0.11 -> 0.21 ms per 1000 queries); the 32 B codebook reads scatter
+    // over the 256 KiB of codebooks, which every query re-reads from L2
+    const uint32_t qi = blockIdx.x, s = threadIdx.x & 31u, code = blockIdx.y * 8u + (threadIdx.x >> 5);
     const float *q = queries + (size_t)qi * 256 + s * PQ_DSUB;
     const float *cb = codebooks + ((size_t)s * PQ_K + code) * PQ_DSUB;
     float acc = 0.f;
 #pragma unroll
     for (int d = 0; d < PQ_DSUB; ++d) acc += q[d] * cb[d];
-    lut[((size_t)qi * PQ_M + s) * PQ_K + code] = acc;
+    lut[((size_t)qi * PQ_K + code) * PQ_M + s] = acc;
 }
 
 
@@ -141,14 +145,29 @@ __global__ void __launch_bounds__(256) lpca_project_kernel(const float *queries,
     if (lane < LP_DIMS) w[pair * LP_DIMS + lane] = mine;
 }
 
+// The index ranks by inner products with UNIT rows: the probe score 0.5|c|^2 - q.c and the ADC sums mean "cosine" only for a unit
+// query.  Queries of any in-domain length are therefore brought to unit length first (one wave per query; a zero query stays zero);
+// the exact select stage at the end re-scores against the query AS GIVEN, like every other path.
+__global__ void __launch_bounds__(256) ivf_unit_queries_kernel(const float *queries, uint32_t nq, float *out)
+{
+    const uint32_t qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4 v = reinterpret_cast<const f32x4 *>(queries + (size_t)qi * 256)[lane];
+    const float a2 = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    const float r = a2 > 0.0f ? __frsqrt_rn(a2) : 0.0f;
+    reinterpret_cast<f32x4 *>(out + (size_t)qi * 256)[lane] = f32x4{v.x * r, v.y * r, v.z * r, v.w * r};
+}
+
 // ------------------------------------------------------------------ query: ADC scan
 struct AdcParams {
     const float *queries;
-    const float *lut;          // [nq][32][256]  (kind 0)
+    const float *lut;          // [nq][256][32]  (kind 0: code-major, see ivf_lut_kernel)
     const float *lw;           // [nq][nprobe][32] per-pair weights of the per-list PCA codes (kind 1), or nullptr
     const uint32_t *probe_list;
     const float *probe_dot;
     uint32_t nprobe;
+    uint32_t nq;
     const uint64_t *list_offsets;
     const uint8_t *codes;      // [N][32] in list order
     const uint32_t *ids;       // [N] corpus row of each code
@@ -160,21 +179,37 @@ struct AdcParams {
     key_t64 *lists;            // [nq][nprobe][kp]
 };
 
-// KIND 0: product quantisation, the query's 32 x 256 LUT staged in LDS (32 KiB: 4 blocks per CU); KIND 1: per-list PCA codes scored
+// KIND 0: product quantisation, the query's 256 x 32 LUT staged in LDS (32 KiB: 4 blocks per CU); KIND 1: per-list PCA codes scored
 // with 32 block-uniform weights -- no LUT, 2-4 KiB of LDS per block, so the register budget (50 VGPRs) decides the occupancy:
-// 8 waves per SIMD instead of 4.  (Until round 5 both kinds were one kernel and the unused LUT array halved the resident waves of
+// 8 waves per SIMD instead of 4.
+// KIND 0's gathers are CONFLICT-FREE (round 6).  A lane scores its own row: 32 lookups LUT[s][code_s].  With the table laid out
+// [s][code] and every lane on the same s at the same time, 32 random codes fell on the 32 banks of ds_read_b32 like balls into bins
+// -- 3.5 LDS cycles per lane group instead of 1, 55 % of the kernel's LDS cycles were conflicts and the LDS, not HBM, bounded it
+// (0.57 of HBM; profiles/r05_ivf/r05_ivf_pmc_lds.json).  Now the table is [code][s] -- sub-quantiser s lives in bank s -- and lane l
+// walks the sub-quantisers in ITS OWN order, s = (t + l) mod 32 at step t: the 32 lanes of a group are on 32 different sub-quantisers,
+// hence 32 different banks, at every step, whatever the codes are.  The code bytes stay as the build wrote them (no layout change in
+// the index, its files or its append path): each lane rotates its 32-byte record by l mod 32 bytes in registers -- three conditional
+// dword stages and one v_alignbyte per dword, 32 VALU instructions per row beside the 96 of the lookups.  (Until round 5 both kinds were one kernel and the unused LUT array halved the resident waves of
 // the shipped coding: the re-score stage is random 1 KiB row reads, i.e. latency hidden by waves in flight.)
 template <int ADC_THREADS, int KIND>
 __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
 {
     __shared__ __attribute__((aligned(16))) float s_lut[KIND == 0 ? PQ_M * PQ_K : 4];
     __shared__ key_t64 s_keys[(ADC_THREADS / 64) * 64];
-    const uint32_t pi = blockIdx.x / p.n_seg, seg = blockIdx.x % p.n_seg, qi = blockIdx.y;
+    // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: with one grid
+    // row per query the P = nprobe x n_seg blocks of a query landed on P different XCDs and every one of them fetched the query's
+    // 32 KiB LUT (kind 0) from HBM again -- 262 MB of a 2.4 GB launch (profiles/r05_ivf/, r06_ivf/).  The grid is one line of
+    // ceil(nq / 8) x 8 x P blocks: XCD x takes the queries q = 8 j + x, and the P blocks of a query follow each other ON that XCD.
+    const uint32_t P = p.nprobe * p.n_seg;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t qi = (slot / P) * 8u + xcd, pblk = slot % P;
+    if (qi >= p.nq) return;   // (the last group of eight queries may be short)
+    const uint32_t pi = pblk / p.n_seg, seg = pblk % p.n_seg;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kp = (int)p.kp;
     const int ks = (int)p.shortlist;
-    key_t64 *out = p.lists + ((size_t)qi * p.nprobe * p.n_seg + blockIdx.x) * kp;
+    key_t64 *out = p.lists + ((size_t)qi * p.nprobe * p.n_seg + pblk) * kp;
     {
         // this block's segment of the probed list; most lists are shorter than n_seg segments: leave an empty list
         const uint32_t l0 = p.probe_list[(size_t)qi * p.nprobe + pi];
@@ -205,6 +240,13 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
         for (int k = 0; k < PQ_M; ++k) lw_bias += lw[k];
         lw_bias *= 128.0f;
     }
+    const uint32_t rot = (uint32_t)lane & 31u;   // KIND 0: this lane's walk through the sub-quantisers starts at rot
+    const uint32_t m16 = (rot & 16u) ? 0xFFFFFFFFu : 0u, m8 = (rot & 8u) ? 0xFFFFFFFFu : 0u, m4 = (rot & 4u) ? 0xFFFFFFFFu : 0u;
+    auto bfi = [](uint32_t m, uint32_t a, uint32_t b) -> uint32_t {   // (a & m) | (b & ~m) in ONE instruction, and opaque to the optimiser
+        uint32_t d;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+        return d;
+    };
     const f32x4 qv = reinterpret_cast<const f32x4 *>(p.queries + (size_t)qi * 256)[lane];
     const float a2 = wave_sum(qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w);
     const bool qz = a2 == 0.0f;
@@ -268,12 +310,24 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
                         acc += lw[4 * u + 3] * (float)(x >> 24);
                     }
                 } else {
+                    // the record rotated left by rot = lane % 32 bytes: byte t of x[] is the code of sub-quantiser (t + rot) % 32
+                    // (bit selects through lane masks, one v_bfi_b32 each, as inline asm: written as `rot & 16 ? a : b` clang folds the three stages into ONE
+                    // dynamically indexed pick per dword -- seven compare + select pairs each, 1400 of them per pass, 0.36 of HBM)
+                    uint32_t x[8], y[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = bfi(m16, w[(u + 4) & 7], w[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = bfi(m8, y[(u + 2) & 7], y[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = bfi(m4, x[(u + 1) & 7], x[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = __builtin_amdgcn_alignbyte(y[(u + 1) & 7], y[u], rot & 3);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        acc += s_lut[(4 * u + 0) * PQ_K + (w[u] & 0xFF)];
-                        acc += s_lut[(4 * u + 1) * PQ_K + ((w[u] >> 8) & 0xFF)];
-                        acc += s_lut[(4 * u + 2) * PQ_K + ((w[u] >> 16) & 0xFF)];
-                        acc += s_lut[(4 * u + 3) * PQ_K + (w[u] >> 24)];
+                        acc += s_lut[((x[u] & 0xFF) << 5) | ((4 * u + 0 + rot) & 31)];
+                        acc += s_lut[(((x[u] >> 8) & 0xFF) << 5) | ((4 * u + 1 + rot) & 31)];
+                        acc += s_lut[(((x[u] >> 16) & 0xFF) << 5) | ((4 * u + 2 + rot) & 31)];
+                        acc += s_lut[((x[u] >> 24) << 5) | ((4 * u + 3 + rot) & 31)];
                     }
                 }
                 const float d = fmaxf(1.0f - acc * rq, 0.0f);  // rows are unit-norm (model2vec output), zero rows score ~0
@@ -345,31 +399,40 @@ __global__ void __launch_bounds__(ADC_THREADS) ivf_adc_kernel(AdcParams p)
     uint32_t lr2 = 0xFFFFFFFFu;
     float thr2_d = __builtin_inff();
     uint32_t thr2_r = 0xFFFFFFFFu;
+    // Rows in flight per wave: the reads are random 1 KiB rows, i.e. latency, and what hides it is rows in flight per CU.  The PQ
+    // kind's 32 KiB LUT keeps it at 4 waves per SIMD where the per-list PCA kind runs 7, so its waves keep EIGHT rows in flight
+    // instead of four (round 6: the re-scored rows are 60 % of this kernel's bytes -- 128 KiB per block against 88 KiB of codes --
+    // and their latency, not the LUT gathers, was what held the PQ kind at 0.57 of HBM).
+    constexpr int RS = KIND == 0 ? 8 : 4;
     while (go) {
-        f32x4 c[4];
-        uint32_t rr[4];
-        bool ok[4];
+        f32x4 c[RS];
+        uint32_t rr[RS];
+        bool ok[RS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RS; ++u) {
             ok[u] = go != 0ull;
             const int src = ok[u] ? __ffsll((long long)go) - 1 : 0;
             if (ok[u]) go &= go - 1;
             rr[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_row, src);
             c[u] = reinterpret_cast<const f32x4 *>(p.corpus + (uint64_t)(ok[u] ? rr[u] : 0u) * 256)[lane];
         }
-        // the four rows' norms and dot products reduced together (device_utils.h wave_sum4: lane l ends with the sum of row l % 4)
-        float pb[4], pa[4];
+        // four rows' norms and dot products reduced together (device_utils.h wave_sum4: lane l ends with the sum of row l % 4)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pb[u] = c[u].x * c[u].x + c[u].y * c[u].y + c[u].z * c[u].z + c[u].w * c[u].w;
-            pa[u] = c[u].x * qv.x + c[u].y * qv.y + c[u].z * qv.z + c[u].w * qv.w;
-        }
-        const float b2s = wave_sum4(pb[0], pb[1], pb[2], pb[3], lane);
-        const float abs4 = wave_sum4(pa[0], pa[1], pa[2], pa[3], lane);
+        for (int g4 = 0; g4 < RS; g4 += 4) {
+            float pb[4], pa[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float b2 = readlane_f(b2s, u), ab = readlane_f(abs4, u);
-            if (ok[u]) insert(dist_f32(ab, b2, rq, qz), rr[u], ld2, lr2, thr2_d, thr2_r, kp);
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 cu = c[g4 + u];
+                pb[u] = cu.x * cu.x + cu.y * cu.y + cu.z * cu.z + cu.w * cu.w;
+                pa[u] = cu.x * qv.x + cu.y * qv.y + cu.z * qv.z + cu.w * qv.w;
+            }
+            const float b2s = wave_sum4(pb[0], pb[1], pb[2], pb[3], lane);
+            const float abs4 = wave_sum4(pa[0], pa[1], pa[2], pa[3], lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float b2 = readlane_f(b2s, u), ab = readlane_f(abs4, u);
+                if (ok[g4 + u]) insert(dist_f32(ab, b2, rq, qz), rr[g4 + u], ld2, lr2, thr2_d, thr2_r, kp);
+            }
         }
     }
 
@@ -429,7 +492,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     // every temporary lives in the context's scratch (no hipMalloc/hipFree per call), results come back through
     // the pinned staging buffer
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_q = 0, b_q = al((size_t)nq * 256 * 4);
+    const size_t o_q = 0, b_q = 2 * al((size_t)nq * 256 * 4);   // [the queries as given (host form) | their unit-length copies]
     const size_t o_pl = o_q + b_q, b_pl = al((size_t)nq * nprobe * 4);
     const size_t o_pd = o_pl + b_pl, b_pd = b_pl;
     const size_t o_lut = o_pd + b_pd, b_lut = al((size_t)nq * PQ_M * PQ_K * 4);
@@ -446,6 +509,12 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     if (!queries_on_device) {
         IVF_HIP(hipMemcpyAsync(base + o_q, queries, (size_t)nq * 256 * 4, hipMemcpyHostToDevice, ctx->stream));
         d_q = reinterpret_cast<const float *>(base + o_q);
+    }
+    const float *d_q_given = d_q;   // (the exact select re-scores against these)
+    {
+        float *d_unit = reinterpret_cast<float *>(base + o_q + b_q / 2);
+        hipLaunchKernelGGL(ivf_unit_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_q, nq, d_unit);
+        d_q = d_unit;
     }
 
     if (!(ctx->attr_done & ATTR_IVF_SCORE)) {
@@ -470,7 +539,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
         hipLaunchKernelGGL(lpca_project_kernel, dim3((unsigned)((n_pairs * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_q, pp.probe_list,
                            n_pairs, nprobe, ix->d_basis, ix->d_lscale, reinterpret_cast<float *>(base + o_lw));
     } else {
-        hipLaunchKernelGGL(ivf_lut_kernel, dim3(nq, PQ_M), dim3(PQ_K), 0, ctx->stream, d_q, ix->d_codebooks, reinterpret_cast<float *>(base + o_lut));
+        hipLaunchKernelGGL(ivf_lut_kernel, dim3(nq, PQ_K / 8), dim3(256), 0, ctx->stream, d_q, ix->d_codebooks, reinterpret_cast<float *>(base + o_lut));
     }
     prof_end(ctx, "ivf_probe");
     AdcParams ap;
@@ -480,6 +549,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     ap.probe_list = pp.probe_list;
     ap.probe_dot = pp.probe_dot;
     ap.nprobe = nprobe;
+    ap.nq = nq;
     ap.list_offsets = ix->d_offsets;
     ap.codes = ix->d_codes;
     ap.ids = ix->d_ids;
@@ -490,7 +560,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     ap.kp = kp;
     ap.lists = reinterpret_cast<key_t64 *>(base + o_lists);
     prof_begin(ctx, "ivf_adc");
-    const dim3 adc_grid(nprobe * n_seg, nq);
+    const dim3 adc_grid(((nq + 7) / 8) * 8 * nprobe * n_seg);   // (one line: see the XCD-aware order in the kernel)
     if (ix->kind == 1) {
         if (adc_waves == 8) hipLaunchKernelGGL((ivf_adc_kernel<512, 1>), adc_grid, dim3(512), 0, ctx->stream, ap);
         else hipLaunchKernelGGL((ivf_adc_kernel<256, 1>), adc_grid, dim3(256), 0, ctx->stream, ap);
@@ -505,7 +575,7 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     uint64_t *d_oc = d_or_user ? d_oc_user : reinterpret_cast<uint64_t *>(base + o_oc);
     SelectArgs sel;  // no exactness certificate: the index is approximate by contract (f32_err = 0)
     sel.corpus = ix->corpus->d_rows;
-    sel.queries = d_q;
+    sel.queries = d_q_given;
     sel.nq = nq;
     sel.lists = ap.lists;
     sel.n_lists = nprobe * n_seg;
@@ -534,6 +604,7 @@ try {
     { int rc_drain = smt::drain_async(ctx); if (rc_drain) return rc_drain; }
     if (nq == 0) return SMT_OK;
     for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    if (int rcq = smt::require_queries_domain_host(queries, nq, "smt_ivfpq_search")) return rcq;   // (domain.hip)
     if (top_k == 0) return SMT_OK;
     uint64_t *d_or = nullptr;
     size_t out_bytes = 0;

@@ -504,6 +504,7 @@ constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAX_LISTS = 512;
 constexpr int SEL_MAX_COLS = 8;
 constexpr int SEL_SURV_CAP = 1024;
+constexpr int SEL_FEW_KEYS = 512;    // up to this many keys over all lists the select ranks them all (no column bounds)
 constexpr int ROW_STRIDE_F4 = 65;  // LDS row stride in float4 (1040 B): conflict-free b128 reads
 constexpr int PROD_STRIDE = 258;   // LDS row stride of the f64 product tables (2064 B)
 constexpr int SEL_FAST_KP = 34;    // product tables fit the 160 KiB LDS up to this k' (k <= 26)
@@ -577,6 +578,13 @@ struct FinalParams {
     unsigned long long *flags;  // async select (or nullptr), see ScanParams
     unsigned long long step;
     const unsigned int *overflow;  // SelectArgs::overflow
+    // delivery by the last block to finish (common.h Delivery; host_flag == nullptr: none)
+    const unsigned long long *dev_out;
+    unsigned long long *host_out;
+    unsigned long long *host_flag;
+    unsigned long long *done;
+    unsigned long long seq;
+    uint32_t out_words;
 };
 
 #define SEL_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
@@ -589,10 +597,9 @@ struct FinalParams {
 // parameter and not a null test: with the flag code in it final_select_kernel<8> allocated 106 VGPRs instead of 90 and no longer
 // fitted on a CU NEXT TO a scan block (4 waves/SIMD x 96 + the scan's 2 x 56 <= 512) -- the async select of the one-query pipeline
 // then waited for scan blocks to leave and a 1 M-row step went from 153 to 204 us (found by the round-5 closing bench run).
-template <int KREG, bool OVF = false>
-__global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p)
+template <int KREG, bool OVF>
+__device__ __forceinline__ void final_select_body(const FinalParams &p, const uint32_t qi, unsigned char *smem_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int kp = (int)p.kp;
     const int L = (int)p.n_lists;
     // LDS carve (all offsets multiples of 16; no static LDS in this kernel): small arrays first, then one big
@@ -607,7 +614,7 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     uint32_t *s_r = reinterpret_cast<uint32_t *>(s_b2 + ((kp + 1) & ~1));      // [kp]
     key_t64 *s_tau = reinterpret_cast<key_t64 *>(s_r + ((kp + 3) & ~3));       // [1]
     double *s_a2 = reinterpret_cast<double *>(s_tau + 1);                       // [1] query norm^2
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_a2 + 1);          // [0]=survivors [1]=valid (+2 pad)
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_a2 + 1);          // [0]=survivors [1]=valid [2]=max |q_i| bits [3]=this block delivers
     unsigned char *s_big = reinterpret_cast<unsigned char *>(s_cnt + 4);
     f32x4 *s_rows = reinterpret_cast<f32x4 *>(s_big);                           // [kp+1][65] float4
     key_t64 *s_surv = reinterpret_cast<key_t64 *>(s_rows + (size_t)(kp + 1) * ROW_STRIDE_F4);  // [SEL_SURV_CAP]
@@ -617,7 +624,6 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     double *s_Q = s_B + (size_t)kp * PROD_STRIDE;                               // [256]            q_i * q_i
     const bool fast_rescore = kp <= SEL_FAST_KP;
 
-    const uint32_t qi = blockIdx.x;
     const key_t64 *lists = p.lists + (size_t)qi * p.list_stride;
     if (p.flags) {
         // launched on the aux stream while the scan of this step may still be running on the main stream
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         // an index search with one probed segment): it IS the answer's candidate set -- no column bounds, no compaction, no ranks.
         // (Round 5: those three phases were ~7 us of dependent latencies in front of every batched call's rescoring, 10 % of a
         // small batch over a small corpus.)
-        if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; }
+        if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
         for (int t = threadIdx.x; t < kp; t += blockDim.x) { s_best[t] = lists[t]; s_rank[t] = 0; }
         __syncthreads();
     } else {
@@ -668,23 +674,31 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     for (int j = 1; j < kp && ncols < SEL_MAX_COLS; j <<= 1) ++ncols;
     auto col_of = [&](int jj) { return jj < ncols - 1 ? (1 << jj) : kp; };
     // the column entries are fetched in the same latency window as the keys (<= 4 per thread)
+    // FEW keys in all (a small corpus: 16 blocks x 11 keys for 1000 rows): no pruning bound -- every key is a survivor and the ranks
+    // below order them directly.  (The column bounds are ~3 us of dependent bisection steps, a quarter of this stage, to prune a set
+    // that is already small.)
+    const bool few = M <= SEL_FEW_KEYS;   // block-uniform
     key_t64 cval[(SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS];
-    const int n_col_entries = ncols * L;
+    const int n_col_entries = few ? 0 : ncols * L;
+    if (!few) {
 #pragma unroll
-    for (int u = 0; u < (SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS; ++u) {
-        int t = (int)threadIdx.x + u * SEL_THREADS;
-        const bool ok = t < n_col_entries;
-        t = ok ? t : 0;
-        const int jj = t / L, bb = t - jj * L;
-        const key_t64 x = lists[(size_t)bb * kp + (col_of(jj) - 1)];
-        cval[u] = ok ? x : KEY_PAD;
+        for (int u = 0; u < (SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS; ++u) {
+            int t = (int)threadIdx.x + u * SEL_THREADS;
+            const bool ok = t < n_col_entries;
+            t = ok ? t : 0;
+            const int jj = t / L, bb = t - jj * L;
+            const key_t64 x = lists[(size_t)bb * kp + (col_of(jj) - 1)];
+            cval[u] = ok ? x : KEY_PAD;
+        }
     }
-    if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; }
+    if (threadIdx.x == 0) { *s_tau = KEY_PAD; s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
     for (int t = threadIdx.x; t < kp; t += blockDim.x) { s_best[t] = KEY_PAD; s_rank[t] = 0; }
+    if (!few) {
 #pragma unroll
-    for (int u = 0; u < (SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS; ++u) {
-        const int t = (int)threadIdx.x + u * SEL_THREADS;
-        if (t < n_col_entries) s_col[t] = cval[u];
+        for (int u = 0; u < (SEL_MAX_COLS * SEL_MAX_LISTS) / SEL_THREADS; ++u) {
+            const int t = (int)threadIdx.x + u * SEL_THREADS;
+            if (t < n_col_entries) s_col[t] = cval[u];
+        }
     }
     __syncthreads();
     SEL_STAMP(1);
@@ -692,7 +706,7 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
     // tau_j = c_j-th smallest key of column j.  One wave per column: the column sits in registers
     // (4 or 8 keys per lane); bisection on the 32 distance bits with ballot counts, then -- only if
     // several entries share that distance -- on the row bits.  No sort, no O(L^2) ranks.
-    {
+    if (!few) {
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (wave < ncols) {
             const int colv = col_of(wave);
@@ -700,10 +714,10 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
             if (L <= 256) column_tau<4>(s_col + (size_t)wave * L, L, c, s_tau);
             else column_tau<8>(s_col + (size_t)wave * L, L, c, s_tau);
         }
+        __syncthreads();
     }
-    __syncthreads();
     SEL_STAMP(2);
-    const key_t64 tau = *s_tau;
+    const key_t64 tau = *s_tau;   // (few: still KEY_PAD -- every real key passes)
 
     // compact the survivors (keys <= tau) straight from the registers
 #pragma unroll
@@ -731,21 +745,36 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         for (int t = threadIdx.x; t < S; t += blockDim.x)
             if ((int)s_srank[t] < kp) s_best[s_srank[t]] = s_surv[t];
     } else {
-        for (int e = threadIdx.x; e < S; e += blockDim.x) {
+        // T = 1024 / S' threads share a survivor (S' = the power of two >= S): each ranks it against a T-th of the set and adds its
+        // share to the survivor's counter.  (One thread per survivor walked all S keys alone while the other 1024 - S threads
+        // idled: 176 survivors -- 16 lists x 11 keys, no column bounds -- took 2.9 us, 349 took 6.3.)  The counters reuse the column
+        // entries' space, which nobody reads any more.
+        unsigned int *s_rk = reinterpret_cast<unsigned int *>(s_col);
+        for (int t = threadIdx.x; t < S; t += blockDim.x) s_rk[t] = 0;
+        __syncthreads();
+        int Sp = 128;
+        while (Sp < S) Sp <<= 1;                      // <= SEL_SURV_CAP = SEL_THREADS
+        const int T = SEL_THREADS / Sp;               // 8, 4, 2 or 1 threads per survivor
+        const int e = (int)threadIdx.x / T, part = (int)threadIdx.x - e * T;
+        if (e < S) {
             const key_t64 key = s_surv[e];
-            int rank = 0;
-            int i = 0;
+            const int per = (S + T - 1) / T, lo = part * per, hi = min(S, lo + per);
+            unsigned int rank = 0;
+            int i = lo;
 #pragma unroll 1
-            for (; i + 8 <= S; i += 8) {
-                key_t64 x[8];
+            for (; i + 4 <= hi; i += 4) {
+                key_t64 x[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = s_surv[i + u];
+                for (int u = 0; u < 4; ++u) x[u] = s_surv[i + u];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) rank += (x[u] < key) ? 1 : 0;
+                for (int u = 0; u < 4; ++u) rank += (x[u] < key) ? 1u : 0u;
             }
-            for (; i < S; ++i) rank += (s_surv[i] < key) ? 1 : 0;
-            if (rank < kp) s_best[rank] = key;
+            for (; i < hi; ++i) rank += (s_surv[i] < key) ? 1u : 0u;
+            if (rank) atomicAdd(&s_rk[e], rank);
         }
+        __syncthreads();
+        for (int t = threadIdx.x; t < S; t += blockDim.x)
+            if ((int)s_rk[t] < kp) s_best[s_rk[t]] = s_surv[t];
     }
     __syncthreads();
     if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[8] = (unsigned long long)S;
@@ -779,6 +808,9 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         if (wave == n_waves - 1) {
             double *dst = s_Q + 4 * lane;
             dst[0] = q0 * q0; dst[1] = q1 * q1; dst[2] = q2 * q2; dst[3] = q3 * q3;
+            // the query's largest magnitude, for the domain verdict below (domain.hip)
+            atomicMax(&s_cnt[2], max(max(__float_as_uint(qv.x) & 0x7fffffffu, __float_as_uint(qv.y) & 0x7fffffffu),
+                                     max(__float_as_uint(qv.z) & 0x7fffffffu, __float_as_uint(qv.w) & 0x7fffffffu)));
         }
 #pragma unroll
         for (int u = 0; u < ROWS_PER_WAVE; ++u) {
@@ -811,7 +843,11 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         if ((int)threadIdx.x < kp) my_b2 = s_b2[threadIdx.x];
     } else {
         // large k': stage the candidate rows (one wave per row, 16 B per lane) and the query converted to f64
-        if (threadIdx.x < 256) s_qd[threadIdx.x] = (double)p.queries[(size_t)qi * 256 + threadIdx.x];
+        if (threadIdx.x < 256) {
+            const float qf = p.queries[(size_t)qi * 256 + threadIdx.x];
+            s_qd[threadIdx.x] = (double)qf;
+            atomicMax(&s_cnt[2], __float_as_uint(qf) & 0x7fffffffu);
+        }
         for (int c = wave; c < kp; c += n_waves) {
             if (s_best[c] != KEY_PAD) {
                 const float *g = p.corpus + (uint64_t)(uint32_t)(s_best[c] & 0xFFFFFFFFull) * 256;
@@ -877,7 +913,16 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         const unsigned rank = s_rank[threadIdx.x];
         if (rank < p.k_out) { orow[rank] = p.row_base + s_r[threadIdx.x]; odist[rank] = s_d[threadIdx.x]; }
     }
-    if (p.f32_err > 0.0 && s_best[kp - 1] != KEY_PAD) {
+    if (!magnitude_in_domain(s_cnt[2])) {
+        // The query is outside the library's domain (a non-finite component, or a magnitude the f32 nominating kernels do not answer
+        // for: domain.hip).  The host entry points refuse such queries before anything is launched; a device entry point says so
+        // here -- SMT_STATUS_INVALID_QUERY: the list means nothing.
+        if (threadIdx.x == 0) {
+            if (p.out_uncertain) p.out_uncertain[qi] = 3;
+            if (p.out_status) p.out_status[qi] = 3u;
+            if (p.status) atomicAdd(p.status, 1ull);
+        }
+    } else if (p.f32_err > 0.0 && s_best[kp - 1] != KEY_PAD) {
         // Exactness certificate (SelectArgs::f32_err).  kp rows were nominated, so rows outside the lists may
         // exist; each of them has f32 distance >= tau32, hence exact distance >= tau32 - f32_err.  Exactly one
         // thread decides: the owner of the k_out-th result, or thread 0 when fewer than k_out rows qualified
@@ -914,7 +959,33 @@ __global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p
         if (threadIdx.x == 0 && blockIdx.x == 0)  // async mode: one query per launch
             __hip_atomic_store(p.flags + 1, p.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (p.host_flag) {
+        // Delivery (common.h): count this block as finished -- thread 0's agent-scope release covers the block's output stores, ordered
+        // before it by the barrier, the same hand-over the scan kernel uses for its lists -- and let the LAST block carry every query's
+        // answer home: ONE wave copies the device block to pinned host memory and raises the completion word behind it (its own
+        // stores, one system-scope release; a fence in each of the 16 waves would be 16 write-backs of the L2).
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long prev = __hip_atomic_fetch_add(p.done, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_cnt[3] = prev == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_cnt[3] && threadIdx.x < 64) {
+            for (uint32_t i = threadIdx.x; i < p.out_words; i += 64)
+                p.host_out[i] = __hip_atomic_load(p.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the copy is out before the flag
+            if (threadIdx.x == 0) __hip_atomic_store(p.host_flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     SEL_STAMP(7);
+}
+
+template <int KREG, bool OVF = false>
+__global__ void __launch_bounds__(SEL_THREADS) final_select_kernel(FinalParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    final_select_body<KREG, OVF>(p, blockIdx.x, smem_raw);
 }
 
 static size_t final_smem_bytes(uint32_t n_lists, uint32_t kp)
@@ -1075,6 +1146,13 @@ int launch_select(smt_ctx *ctx, const SelectArgs &a)
     f.flags = a.async_step ? ctx->d_flags : nullptr;
     f.step = a.async_step;
     f.overflow = a.overflow;
+    const Delivery *dl = a.async_step ? nullptr : a.deliver;
+    f.dev_out = dl ? dl->dev_out : nullptr;
+    f.host_out = dl ? dl->host_out : nullptr;
+    f.host_flag = dl ? dl->host_flag : nullptr;
+    f.done = dl ? dl->done : nullptr;
+    f.seq = dl ? dl->seq : 0;
+    f.out_words = dl ? dl->n_words : 0;
     const bool small = (uint64_t)a.n_lists * a.kp <= (uint64_t)8 * SEL_THREADS;
     const size_t smem = final_smem_bytes(a.n_lists, a.kp);
     if (a.async_step) {
@@ -1187,6 +1265,7 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
     s.f32_err = F32_ERR_SCAN;
     s.out_uncertain = a.out_uncertain;
     s.out_status = a.out_status;
+    s.deliver = a.deliver;
     return launch_select(ctx, s);
 }
 

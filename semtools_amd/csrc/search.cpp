@@ -8,6 +8,9 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+
 #include "common.h"
 
 using namespace smt;
@@ -75,7 +78,8 @@ static int range_set_find(smt_corpus *corpus, const smt_range *ranges, uint32_t 
     *found = nullptr;
     *build = false;
     for (RangeSet *rs : corpus->range_sets)
-        if (rs->h1 == h1 && rs->h2 == h2 && rs->n_in == n && rs->n_virtual == t) {
+        if (rs->h1 == h1 && rs->h2 == h2 && rs->n_in == n && rs->n_virtual == t && rs->host_ranges.size() == n &&
+            (n == 0 || memcmp(rs->host_ranges.data(), ranges, (size_t)n * sizeof(smt_range)) == 0)) {   // (a collision must not answer for another subset)
             rs->last_use = ++corpus->range_clock;
             ++corpus->range_set_hits;
             *found = rs;
@@ -90,8 +94,8 @@ static int range_set_find(smt_corpus *corpus, const smt_range *ranges, uint32_t 
 }
 
 // A new kept set for (rr, prefixes): one device block, uploaded on the context's stream from pinned memory.
-static int range_set_build(smt_corpus *corpus, uint32_t n_in, uint64_t h1, uint64_t h2, const std::vector<smt_range> &rr,
-                           const std::vector<uint64_t> &prefixes, uint64_t n_virtual, RangeSet **out)
+static int range_set_build(smt_corpus *corpus, const smt_range *ranges_in, uint32_t n_in, uint64_t h1, uint64_t h2,
+                           const std::vector<smt_range> &rr, const std::vector<uint64_t> &prefixes, uint64_t n_virtual, RangeSet **out)
 {
     smt_ctx *ctx = corpus->ctx;
     *out = nullptr;
@@ -119,6 +123,7 @@ static int range_set_build(smt_corpus *corpus, uint32_t n_in, uint64_t h1, uint6
         return SMT_OK;
     }
     rs->h1 = h1; rs->h2 = h2; rs->n_in = n_in; rs->nr = nr;
+    rs->host_ranges.assign(ranges_in, ranges_in + n_in);
     rs->n_virtual = n_virtual; rs->n_chunks = n_chunks; rs->n_vtiles = n_vtiles;
     rs->d_r = reinterpret_cast<smt_range *>(rs->dev);
     rs->d_p = reinterpret_cast<uint64_t *>(rs->dev + r_bytes);
@@ -377,8 +382,48 @@ static int topk_dispatch(smt_ctx *ctx, smt_corpus *corpus, ScanArgs &a)
     return rc;
 }
 
+// Store::search_line_embeddings with a ZERO query vector (an empty query, or one made of unknown tokens only: model2vec pools it to
+// zeros).  qdrant's cosine_preprocess leaves a vector with |x|^2 < f32::EPSILON as it is, so the query scores 0 against EVERY point --
+// distance 1.0 for all of them, zero rows included -- where simsimd's rule for search_documents says (zero, zero) -> distance 0
+// (oracle: orc_search_line_embeddings against orc_cosine_*; src/workspace/store.rs:500-531).  The answer is a constant, so it is
+// written here instead of being computed: with a threshold nothing unless 0 > 1 - max_distance (f32), else the first top_k rows of
+// the subset in storage order (equal scores: earlier row first, as in the oracle), each at distance 1.0.
+bool query_is_zero(const float *q)
+{
+    for (uint32_t d = 0; d < SMT_DIM; ++d)
+        if (q[d] != 0.0f) return false;
+    return true;
+}
+
+void workspace_zero_query_hits(const smt_range *ranges, uint32_t n_ranges, uint64_t n_rows, uint32_t top_k, bool has_thr, double max_distance,
+                               uint64_t row_base, LocalHits &out)
+{
+    out.rows.clear();
+    out.dist.clear();
+    if (has_thr && !(0.0f > 1.0f - (float)max_distance)) return;
+    auto take = [&](uint64_t b, uint64_t e) {
+        for (uint64_t r = b; r < e && out.rows.size() < top_k; ++r) { out.rows.push_back(row_base + r); out.dist.push_back(1.0); }
+    };
+    if (n_ranges == 0) take(0, n_rows);
+    for (uint32_t i = 0; i < n_ranges && out.rows.size() < top_k; ++i) take(ranges[i].begin, ranges[i].end);
+}
+
+static int search_local_host_impl(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+                                  const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out);
+
 int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
                       const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out)
+{
+    int rc = search_local_host_impl(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, out);
+    if (rc || mode != SMT_MODE_WORKSPACE) return rc;
+    for (uint32_t q = 0; q < nq && q < out.size(); ++q)
+        if (query_is_zero(queries + (size_t)q * SMT_DIM))
+            workspace_zero_query_hits(ranges, n_ranges, corpus->rows, top_k, !std::isnan(max_distance), max_distance, row_base, out[q]);
+    return SMT_OK;
+}
+
+static int search_local_host_impl(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
+                                  const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out)
 {
     SMT_REQUIRE(corpus != nullptr, "corpus");
     SMT_REQUIRE(mode == SMT_MODE_DOCUMENTS || mode == SMT_MODE_WORKSPACE, "mode");
@@ -389,6 +434,7 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     if (rc) return rc;
     out.assign(nq, LocalHits());
     if (nq == 0) return SMT_OK;
+    if ((rc = require_queries_domain_host(queries, nq, "search"))) return rc;   // (domain.hip: finite, ordinary magnitudes)
 
     const bool has_thr = !std::isnan(max_distance);
     const bool all_under_threshold = (mode == SMT_MODE_DOCUMENTS) && has_thr;
@@ -411,7 +457,7 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
     std::vector<uint64_t> prefixes;
     if (!rset && !rr.empty()) {
         range_prefixes(rr, prefixes);
-        if (rset_build && (rc = range_set_build(corpus, n_ranges, rh1, rh2, rr, prefixes, n_virtual, &rset))) return rc;
+        if (rset_build && (rc = range_set_build(corpus, ranges, n_ranges, rh1, rh2, rr, prefixes, n_virtual, &rset))) return rc;
     }
 
     // ---- device staging: queries, ranges(+prefix)
@@ -523,16 +569,56 @@ int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uin
         a.out_counts = d_ocnt;
         a.out_uncertain = d_ocnt + nq;
         a.range_set = rset;
+        if ((rc = ensure_pinned(ctx, 64 + o_rows + o_dist + o_cnt))) return rc;
+        // the answers' place in the pinned buffer: behind a 64-byte line whose first word is the completion word of a delivered answer
+        char *h_ans = reinterpret_cast<char *>(ctx->h_pinned) + 64;
+        // A SMALL answer is delivered by the select kernel itself (common.h Delivery): its last block copies the device block
+        // [rows | distances | counts | flags] into the pinned buffer and stores this call's sequence number behind it; the host waits
+        // for that word -- no D2H copy command, no hipStreamSynchronize: ~10 us of every small call (profiles/r06_call_floor.json,
+        // profiles/r06_small_calls.json).  One select launch answers the whole call (<= 32 queries: below the batched kernel's pass size).
+        const bool direct = ctx->tune.direct_delivery != 0 && nq <= 32 && o_rows + o_dist + o_cnt <= 8192;
+        Delivery dl;
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(ctx->h_pinned);
+        if (direct) {
+            dl.dev_out = reinterpret_cast<const unsigned long long *>(outs);
+            dl.host_out = reinterpret_cast<unsigned long long *>(h_ans);
+            dl.n_words = (uint32_t)((o_rows + o_dist + o_cnt) / 8);
+            dl.host_flag = const_cast<unsigned long long *>(flag);
+            dl.seq = ++ctx->deliver_seq;
+            dl.done = ctx->d_status + 4;
+            *flag = 0;
+            a.deliver = &dl;
+        }
         // K2 or K3: topk_dispatch above
         rc = topk_dispatch(ctx, corpus, a);
         if (rc) return rc;
-
-        if ((rc = ensure_pinned(ctx, o_rows + o_dist + o_cnt))) return rc;
-        SMT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, outs, o_rows + o_dist + o_cnt, hipMemcpyDeviceToHost, ctx->stream));
-        SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
-        const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows);
-        const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(ctx->h_pinned) + o_rows + o_dist);
+        if (direct) {
+            // spin on the completion word (a small search is over in tens of microseconds); past 200 us ask the runtime, which also
+            // reports a launch that failed
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned long long got = 0;
+            for (unsigned spins = 1; (got = *flag) == 0; ++spins) {
+                if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                    SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    got = *flag;
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (got != dl.seq) {
+                (void)hipStreamSynchronize(ctx->stream);   // (whatever is left of the launch) -- and the block counter starts from zero again
+                (void)hipMemsetAsync(ctx->d_status + 4, 0, sizeof(unsigned long long), ctx->stream);
+                set_error("the select kernel did not deliver its answer (completion word %llu, expected %llu)", got, dl.seq);
+                return SMT_E_HIP;
+            }
+            ++ctx->deliveries;
+        } else {
+            SMT_HIP_CHECK(hipMemcpyAsync(h_ans, outs, o_rows + o_dist + o_cnt, hipMemcpyDeviceToHost, ctx->stream));
+            SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(h_ans);
+        const double *h_dist = reinterpret_cast<const double *>(h_ans + o_rows);
+        const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(h_ans + o_rows + o_dist);
         std::vector<uint32_t> redo;
         for (uint32_t q = 0; q < nq; ++q) {
             const uint64_t n = h_cnt[q];
@@ -657,7 +743,7 @@ int search_topk_packed_local(smt_corpus *corpus, const float *queries_dev, uint3
     std::vector<uint64_t> prefixes;
     if (!rset && !rr.empty()) {
         range_prefixes(rr, prefixes);
-        if (rset_build && (rc = range_set_build(corpus, n_ranges, rh1, rh2, rr, prefixes, n_virtual, &rset))) return rc;
+        if (rset_build && (rc = range_set_build(corpus, ranges_local, n_ranges, rh1, rh2, rr, prefixes, n_virtual, &rset))) return rc;
     }
     const uint32_t nr = rset ? rset->nr : (uint32_t)rr.size();
     smt_range *d_r = nullptr;
@@ -721,6 +807,13 @@ try {
     int rc = search_local_host(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, hits);
     if (rc) return rc;
     return deliver_hits(hits, out_rows, out_dist, out_counts, out_cap);
+} catch (...) { return smt::api_catch(); }
+
+int smt_debug_deliveries(smt_ctx *ctx, uint64_t *count)
+try {
+    SMT_REQUIRE(ctx != nullptr && count != nullptr, "null argument");
+    *count = ctx->deliveries;
+    return SMT_OK;
 } catch (...) { return smt::api_catch(); }
 
 int smt_debug_range_sets(const smt_corpus *corpus, uint64_t *kept, uint64_t *hits, uint64_t *builds)

@@ -350,3 +350,46 @@ def test_cosine_and_pool_against_scipy_and_sklearn():
         want = normalize(table[ids].astype(np.float64).mean(axis=0, keepdims=True))[0]
         got = orc.pool_ids(table, ids, True)
         assert np.abs(got.astype(np.float64) - want).max() <= 2e-6, n
+
+
+# ------------------------------------------------------------------ outside the library's domain (semtools_amd/csrc/domain.hip)
+def test_non_finite_rows_score_zero_in_every_form():
+    """cos_finish's `unclipped > 0 ? unclipped : 0` (simsimd SIMSIMD_MAKE_COS, every backend's normalise step) turns a NaN into
+    distance 0.0: a row with a NaN or Inf component is the reference's BEST match (src/search/mod.rs:86-89 pushes it, 0.0 < 100.0;
+    :107-111 sorts it first).  Both restatements agree on that -- it is what the library REFUSES to reproduce
+    (SMT_E_INVALID where such a row would enter a corpus; tests/test_gpu_domain.py)."""
+    rng = np.random.default_rng(3)
+    q = synth.unit_query(1)[0]
+    for bad in (np.nan, np.inf, -np.inf):
+        row = synth.unit_rows(1, seed=4)[0].copy()
+        row[int(rng.integers(0, 256))] = bad
+        for accurate in (False, True):
+            assert orc.cosine(q, row, accurate=accurate) == 0.0
+            assert orc.cosine(row, q, accurate=accurate) == 0.0
+    emb = synth.unit_rows(50, seed=5, dup_frac=0, zero_frac=0)
+    emb[37, 100] = np.nan
+    res = orc.search_documents(emb, [50], q, n_lines=0, top_k=3, accurate=True)
+    assert res[0]["match_line"] == 37 and res[0]["distance"] == 0.0
+
+
+def test_serial_and_accurate_forms_part_company_outside_the_domain():
+    """Where f32 accumulators overflow or underflow the two forms -- and simsimd's backends among themselves -- stop agreeing, so the
+    1e-5 contract has nothing to hold on to: the serial-f32 form answers 1.0 (b2 = +Inf, rsqrt 0) or 0.0 (b2 underflows to 0, rsqrt +Inf, the
+    clip), the f64 form the true cosine.  Inside [2^-40, 2^40] (largest magnitude of a vector) they agree to 1e-5 and a power-of-two scale
+    changes neither by a bit."""
+    base = synth.unit_rows(1, seed=9, dup_frac=0, zero_frac=0)[0]
+    q = (base + 0.05 * synth.unit_query(2)[0]).astype(np.float32)
+    true = orc.cosine(q, base, accurate=True)
+    assert 0.0 < true < 0.01
+    huge = (base * np.float32(1e20)).astype(np.float32)          # squares overflow f32
+    assert orc.cosine(q, huge, accurate=True) == pytest.approx(true, abs=1e-7)     # (the f32 product by 1e20 rounds each component)
+    assert orc.cosine(q, huge, accurate=False) == 1.0             # b2 = +Inf -> rsqrt 0 -> 1 - 0
+    tiny = (base * np.float32(1e-25)).astype(np.float32)          # squares underflow to 0
+    assert orc.cosine(q, tiny, accurate=True) == pytest.approx(true, abs=1e-7)
+    assert orc.cosine(q, tiny, accurate=False) == 0.0             # b2 underflows to 0 -> rsqrt +Inf -> 1 - Inf -> clipped to 0: the BEST score
+    for e in (-38, -20, 0, 20, 38):                               # rows whose largest magnitude stays within [2^-40, 2^40]
+        s = np.float32(2.0 ** e)
+        scaled = (base * s).astype(np.float32)
+        assert orc.cosine(q, scaled, accurate=True) == true       # bit for bit
+        assert abs(orc.cosine(q, scaled, accurate=False) - true) < 1e-5
+        assert orc.cosine((q * s).astype(np.float32), scaled, accurate=True) == true
