@@ -2102,9 +2102,9 @@ def bench_c5(smt, ctx, device, rows, k, nq=1000, nlist=4096, nprobe=8, rerank=12
                              "algorithmic_bytes_per_launch": code_bytes + rescore_bytes, "code_bytes": code_bytes, "rescored_row_bytes": rescore_bytes,
                              "adc_ms_per_batch": adc_s * 1e3, "probe_ms_per_batch": ms_pr / max(n_pr, 1), "launches": n_adc,
                              "valu_busy_frac": (_traffic_entry("ivf_adc_lpca" if local_pca else "ivf_adc_pq") or {}).get("valu_busy_frac"),
-                             "note": "counters (profiles/r05_ivf/, round 5): per-list PCA codes: measured HBM traffic 2.12 GB per launch = 1.13 x these "
-                                     "algorithmic bytes, 6.7 TB/s under the profiler (0.84 of peak: the part's read ceiling), VALUs 0.67 busy, no LDS "
-                                     "conflicts; global PQ: 2.41 GB at 6.0 TB/s, 55 % of its LDS cycles are bank conflicts of the LUT gathers"}}
+                             "note": "counters (profiles/r06_ivf/, round 6 binary): per-list PCA codes: measured HBM traffic 2.19 GB per launch at 6.8 TB/s under "
+                                     "the profiler (0.85 of peak: the part's read ceiling), VALUs 0.65 busy, no LDS conflicts; global PQ: 2.23 GB at 5.5 TB/s "
+                                     "(2.41 GB before the XCD-aware block order), LDS bank conflicts 55 % of its LDS cycles in round 5 -> 0 (conflict-free LUT walk)"}}
 
     shipped = one_coding(True)
     try:
