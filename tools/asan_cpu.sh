@@ -9,7 +9,7 @@ here="$root/semtools_amd/csrc"; out=/tmp/asan; mkdir -p "$out"
 HIPCC=/opt/rocm/bin/hipcc
 FLAGS=(--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fno-gpu-rdc -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer)
 objs=()
-for src in api.cpp search.cpp corpus_io.cpp group.cpp sharded.cpp scan_kernels.hip embed_kernels.hip gemm_topk.hip gemm_rowreg.hip gemm_ldsrow.hip gemm_level.hip largek.hip threshold.hip ivfpq_build.hip ivfpq_search.hip ivfpq_io.hip host/host.cpp host/store.cpp host/output.cpp host/hf_tokenizer.cpp host/host_capi.cpp; do
+for src in api.cpp search.cpp corpus_io.cpp group.cpp sharded.cpp scan_kernels.hip embed_kernels.hip gemm_topk.hip gemm_rowreg.hip gemm_ldsrow.hip gemm_level.hip largek.hip threshold.hip domain.hip ivfpq_build.hip ivfpq_search.hip ivfpq_io.hip host/host.cpp host/store.cpp host/output.cpp host/hf_tokenizer.cpp host/host_capi.cpp; do
   obj="$out/$(basename "${src%.*}").o"
   "$HIPCC" "${FLAGS[@]}" -x hip -c "$here/$src" -o "$obj" &
   objs+=("$obj")
