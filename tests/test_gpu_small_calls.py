@@ -107,6 +107,22 @@ def test_workspace_threshold_and_zero_query_with_delivery(counting):
     for i in range(3):
         rows, dist = _oracle_topk(emb, qs[i], 5)
         assert got[i][0].tolist() == rows and np.array_equal(got[i][1], dist)
+    # workspace mode without a threshold and over a path subset; the ZERO query's answer is qdrant's (every point scores 0: the first
+    # rows of the subset at distance 1.0), not search_documents' (zero rows first at distance 0) -- on one GPU and on three shards
+    ranges = [(10, 60), (2000, 2004), (4000, 5000)]
+    row_path[:] = 0
+    for a, b in ranges:
+        row_path[a:b] = 1
+    g = smt.Group.logical(0, 3)
+    sc = smt.ShardedCorpus(g, rows=emb)
+    for searcher in (c, sc):
+        got = searcher.search(qs, top_k=6, mode=L.MODE_WORKSPACE, ranges=ranges)
+        for i in range(3):
+            ref = orc.search_line_embeddings(emb, row_path, row_line, qs[i], [1], 6, None)
+            assert got[i][0].tolist() == [r["row"] for r in ref], i
+            assert np.allclose(got[i][1].astype(np.float32), [r["distance"] for r in ref], rtol=0, atol=1e-5)
+        assert got[1][0].tolist() == [10, 11, 12, 13, 14, 15] and got[1][1].tolist() == [1.0] * 6
+    sc.close(); g.close()
     c.close()
 
 

@@ -393,3 +393,21 @@ def test_serial_and_accurate_forms_part_company_outside_the_domain():
         assert orc.cosine(q, scaled, accurate=True) == true       # bit for bit
         assert abs(orc.cosine(q, scaled, accurate=False) - true) < 1e-5
         assert orc.cosine((q * s).astype(np.float32), scaled, accurate=True) == true
+
+
+def test_a_zero_query_scores_every_point_zero_in_the_store():
+    """Store::search_line_embeddings with an all-zero query (an empty query, or unknown tokens only: model2vec pools zeros): qdrant's
+    cosine_preprocess leaves it as it is, every dot product is 0 -> distance 1.0 for EVERY point, zero rows included (search_documents'
+    simsimd rule says (zero, zero) -> 0 instead).  With a threshold nothing passes unless 0 > 1 - max_distance; without one the first
+    top_k rows of the subset come back in storage order.  The library answers such a query with this constant
+    (semtools_amd/csrc/search.cpp workspace_zero_query_hits; tests/test_gpu_small_calls.py)."""
+    emb = synth.unit_rows(200, seed=3, dup_frac=0, zero_frac=0.05)
+    row_path = (np.arange(200) >= 50).astype(np.uint32)
+    row_line = np.arange(200, dtype=np.int32)
+    q = np.zeros(256, dtype=np.float32)
+    assert orc.search_line_embeddings(emb, row_path, row_line, q, [1], 4, 0.5) == []
+    res = orc.search_line_embeddings(emb, row_path, row_line, q, [1], 4, None)
+    assert [r["row"] for r in res] == [50, 51, 52, 53] and all(r["distance"] == 1.0 for r in res)
+    res = orc.search_line_embeddings(emb, row_path, row_line, q, [1], 4, 1.5)
+    assert [r["row"] for r in res] == [50, 51, 52, 53]
+    assert orc.cosine(q, np.zeros(256, dtype=np.float32), accurate=True) == 0.0       # (search_documents' rule, for contrast)
