@@ -517,6 +517,9 @@ int smt_ctx_aux_stream(smt_ctx *ctx, void **stream_out);
 
 /* Tuning knobs; for benchmarking sweeps and throughput pipelines.  Keys:
  *   scan_blocks, scan_threads, scan_unroll (2/4/8), scan_nontemporal   K2 launch shape
+ *   scan_steal (0/1/2/4/8/16), scan_steal_pct (1..50)   K2, unfiltered: the last scan_steal_pct per cent of the rows are dealt to the
+ *                        blocks WHILE the kernel runs, in groups of scan_steal rounds (0, the default: the static deal).  Evens the
+ *                        blocks' finish times out and gains nothing: the launch is bound by the aggregate read rate (A/B only)
  *   gemm_blocks, gemm_qsplit, gemm_ldsrow, gemm_dma_nt                     K3 (f32 kernels / range-filtered batches)
  *   gemm_bootstrap (1)                                                     K3 row-register kernel: first thresholds from a bootstrap level of
  *                                                                          tile minima (0: the appended-levels plan of rounds 1-3; A/B only)

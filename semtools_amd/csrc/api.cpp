@@ -345,6 +345,7 @@ void smt_ctx_destroy(smt_ctx *ctx)
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_steal) (void)hipFree(ctx->d_steal);
     for (auto &kv : ctx->prof)
         for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -443,6 +444,13 @@ try {
         ctx->tune.scan_unroll = (int)value;
     } else if (k == "scan_nontemporal") ctx->tune.scan_nontemporal = (int)value;
     else if (k == "scan_prefetch") ctx->tune.scan_prefetch = (int)value;
+    else if (k == "scan_steal") {
+        SMT_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, "scan_steal: rounds per dynamically dealt group, a power of two up to 16 (0 = the static deal)");
+        ctx->tune.scan_steal = (int)value;
+    } else if (k == "scan_steal_pct") {
+        SMT_REQUIRE(value >= 1 && value <= 50, "scan_steal_pct: 1..50 per cent of the corpus dealt dynamically");
+        ctx->tune.scan_steal_pct = (int)value;
+    }
     else if (k == "gemm_blocks") ctx->tune.gemm_blocks = (int)value;
     else if (k == "gemm_ldsrow") ctx->tune.gemm_ldsrow = (int)value;
     else if (k == "gemm_bootstrap") ctx->tune.gemm_bootstrap = (int)value;

@@ -57,6 +57,8 @@ struct Tuning {
     int scan_unroll = 4;
     int scan_nontemporal = 1;
     int scan_prefetch = 1;      // software-pipelined row loads (single-query kernel)
+    int scan_steal = 0;         // K2, unfiltered: rounds per dynamically dealt group (power of two; 0 = the static deal, the default: the dynamic deal evens the blocks out and gains nothing -- the launch is bound by the part's aggregate read rate): scan_kernels.hip STEAL
+    int scan_steal_pct = 6;     // ... and the share of the corpus dealt that way, at the end of the launch (1..50 per cent)
     int gemm_blocks = 0;        // 0 = CU count
     int prof_every = 1;         // HIP events bracket one launch in N (an event pair costs ~6 us of stream time)
     int merge_on_aux = 0;       // 1: smt_merge_topk_packed_device runs on the aux stream (behind the async select it consumes)
@@ -111,6 +113,8 @@ struct smt_ctx {
     unsigned long long *d_flags = nullptr;  // [0] scan_done step, [1] select_done step, [2] blocks finished, [3] timeout flag
     uint64_t async_step = 0;
     bool async_pending = false;
+    unsigned int *d_steal = nullptr;         // K2 STEAL: 64 group counters, one per launch in rotation (scan_kernels.hip)
+    uint64_t steal_seq = 0;
     unsigned long long deliver_seq = 0;      // sequence number of the last delivered answer (its completion word in pinned memory)
     uint64_t deliveries = 0;                 // host-form searches answered that way (smt_debug_deliveries)
     bool prof_on = false;

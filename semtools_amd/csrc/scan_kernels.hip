@@ -34,6 +34,9 @@ struct ScanParams {
     unsigned long long *stamps;  // optional (tuning key scan_debug_ptr): wall_clock64 per wave [start, loop end], per block [end]
     unsigned long long *flags;   // async select (or nullptr): [0] scan_done step, [1] select_done step, [2] blocks done, [3] timeout
     unsigned long long step;     // this launch's step number (>= 1)
+    unsigned int *steal_ctr;     // STEAL: this launch's group counter (zero at launch), see scan_topk_kernel
+    uint32_t steal_lr;           // STEAL: log2 of the rounds per group
+    uint32_t steal_static;       // STEAL: a block's first steal_static groups are dealt statically (group g of block b = g * blocks + b)
 };
 
 // ---- async select: device-scope flags between the scan of step i (main stream) and its select (aux stream) ----
@@ -129,10 +132,32 @@ int launch_build_tile_table(smt_ctx *ctx, const smt_range *ranges, const uint64_
 }
 
 // ------------------------------------------------------------------------- K2
-template <int NQ, int U, bool NT, bool FILTERED>
+// STEAL (round 6; unfiltered, 8-wave blocks): WHICH rows a block scans is decided while the kernel runs.  With the static deal every
+// block owns the same number of rows, and the launch ends when the slowest block does: wall_clock64 stamps of 1 M-row launches
+// (tools/scan_balance_async.py) show the blocks of one or two XCDs -- different ones from run to run -- finishing 10-14 us behind
+// the median block (block ends 128 / 134 / 148 us: min / median / max), i.e. the kernel waits ~7 % of its time for a quarter of its
+// blocks.  So the rounds (8 chunks = 32 rows, one per wave) are dealt in GROUPS of 2^steal_lr rounds, and only MOST of them up
+// front: a block's first steal_static groups are static (group g of block b = g * gridDim.x + b, as before: nothing new in the
+// loop but a compare), the last few per cent of the corpus are claimed group by group from a device counter -- STEAL_DEPTH groups
+// ahead, by the wave that takes the first chunk of a group, the atomic's latency hidden behind that wave's row loads -- and
+// published in an 8-entry LDS ring (group | base slot) that the waves' chunk claims look their rows up in.  Fast blocks simply
+// come back for more.  (Everything dynamic was tried first: device-scope atomics on one address are served at ~65 per us on this
+// part -- memory-side -- and 15 000 of them made the kernel 230 us instead of 151; a few hundred at the end are free.)
+// RESULT, and why this is OFF by default (tuning key scan_steal = 0): the deal does what it should -- last block minus median
+// block 2.7 us instead of 5-14 (profiles/r06_scan_balance.txt) -- and the launch is not a microsecond shorter (151.5 -> 152.5 us,
+// profiles/r06_ab_steal.json): the median block moves UP to the last one, the last one does not come down.  The launch is bound by
+// the part's AGGREGATE read rate (1.024 GB in 146-148 us of block time = 7.0 TB/s, the 0.88-0.90 of peak a 100 M-row launch shows
+// too); blocks that finish early under the static deal are the ones that got a larger share of it, and their rows cost the same
+// time whoever reads them.  Kept as an A/B switch with its parity test: it is the measurement that says the 1 M-row kernel has
+// no imbalance left to recover, only its ramp.  Which block reduces a row cannot change
+// the answer: the union of the blocks' k' best contains the k' best rows whatever the deal, and the select's threshold (the k'-th
+// key of the union) is the k'-th smallest key of all rows either way.
+constexpr int STEAL_DEPTH = 2;
+template <int NQ, int U, bool NT, bool FILTERED, bool STEAL = false>
 __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
 {
     static_assert(!FILTERED || U == FILTER_CHUNK, "filtered scans use the chunk table's chunk size");
+    static_assert(!STEAL || !FILTERED, "dynamic groups are for the unfiltered scan");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     key_t64 *s_keys = reinterpret_cast<key_t64 *>(smem_raw);  // [waves][64]
 
@@ -199,7 +224,12 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             c[j] = NT ? __builtin_nontemporal_load(src) : *src;
         }
     };
+    // STEAL: ring[g & 7] = (group g of this block | its base slot / 2^steal_lr); the first STEAL_DEPTH groups are static
+    uint2 *s_ring = reinterpret_cast<uint2 *>(s_next + 2);
     if (threadIdx.x == 0) *s_next = (uint32_t)waves_per_block;  // chunks 0..waves-1 are dealt: wave w starts on chunk w
+    if constexpr (STEAL) {
+        if (threadIdx.x < 8) s_ring[threadIdx.x] = make_uint2(0xFFFFFFFFu, 0u);
+    }
     __syncthreads();
 
     // One row against the NQ queries.  `valid` is wave-uniform and gates only the (rare) insert, never the
@@ -290,8 +320,60 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
                 c[j] = NT ? __builtin_nontemporal_load(src) : *src;
             }
         };
+        // STEAL: a group this wave has asked the device counter for (lane 0 holds the answer once the atomic has returned)
+        uint32_t pend_group = 0xFFFFFFFFu, pend_val = 0;
         auto chunk_v0 = [&](uint32_t t) -> uint64_t {
-            return (((uint64_t)(t / waves_per_block) * gridDim.x + blockIdx.x) * waves_per_block + t % waves_per_block) * U;
+            if constexpr (STEAL) {
+                // (8-wave blocks) round r = t / 8 of this block lies in its group g = r >> lr; the group's base comes from the ring
+                const uint32_t r = t >> 3, g = r >> p.steal_lr, rho = r & ((1u << p.steal_lr) - 1u);
+                uint32_t base;
+                if (g < p.steal_static) {
+                    base = g * gridDim.x + blockIdx.x;   // the static part of the deal: no look-up, no atomic
+                } else {
+                    // (a wave never waits while it holds an answer others may be waiting for: twice in a row only in the prologue)
+                    if (pend_group != 0xFFFFFFFFu) {
+                        if (lane == 0) s_ring[pend_group & 7u] = make_uint2(pend_group, p.steal_static * gridDim.x + pend_val);
+                        pend_group = 0xFFFFFFFFu;
+                    }
+                    uint32_t tag, spins = 0;
+                    do {
+                        // (one address for the wave: a broadcast 8-byte read, so that tag and base come from ONE publish)
+                        const unsigned long long e = *reinterpret_cast<volatile unsigned long long *>(s_ring + (g & 7u));
+                        tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)e);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(e >> 32));
+                        if (++spins == (1u << 26)) __builtin_trap();   // (seconds: a publish that never comes must end in an error, not in a hung GPU)
+                    } while (tag != g);   // (published STEAL_DEPTH groups ahead: the wait is for a wave that is late with its publish)
+                }
+                const uint64_t slot = ((uint64_t)base << p.steal_lr) + rho;
+                const uint64_t v = (slot * 8u + (t & 7u)) * U;
+                // the wave that takes the FIRST chunk of group g fetches group g + STEAL_DEPTH if that one is dynamic (unless its own
+                // group lies past the end: then so do all later ones, and the ring gets a base that says so without asking the counter)
+                if ((t & ((8u << p.steal_lr) - 1u)) == 0u && g + STEAL_DEPTH >= p.steal_static) {
+                    if (pend_group != 0xFFFFFFFFu) {
+                        if (lane == 0) s_ring[pend_group & 7u] = make_uint2(pend_group, p.steal_static * gridDim.x + pend_val);
+                        pend_group = 0xFFFFFFFFu;
+                    }
+                    if (v < p.n_virtual) {
+                        if (lane == 0) pend_val = atomicAdd(p.steal_ctr, 1u);
+                        pend_group = g + STEAL_DEPTH;
+                    } else if (lane == 0) {
+                        s_ring[(g + STEAL_DEPTH) & 7u] = make_uint2(g + STEAL_DEPTH, 0x0FFFFFFFu);
+                    }
+                }
+                return uniform_u64(v);
+            } else {
+                return (((uint64_t)(t / waves_per_block) * gridDim.x + blockIdx.x) * waves_per_block + t % waves_per_block) * U;
+            }
+        };
+        // ... and publishes it once the answer is there: called where the wave has just waited for its row loads, which the atomic
+        // was issued in front of
+        auto publish = [&]() {
+            if constexpr (STEAL) {
+                if (pend_group != 0xFFFFFFFFu) {
+                    if (lane == 0) s_ring[pend_group & 7u] = make_uint2(pend_group, p.steal_static * gridDim.x + pend_val);
+                    pend_group = 0xFFFFFFFFu;
+                }
+            }
         };
         f32x4 cn[U];
         uint32_t rown[U];
@@ -306,6 +388,7 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
             uint32_t row[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) { c[j] = cn[j]; row[j] = rown[j]; }
+            publish();
             if (v0n < p.n_virtual) issue_rows(v0n, cn, rown);
             const uint64_t v0nn = chunk_v0(claim());
             if constexpr (CHUNK4) {
@@ -1088,8 +1171,16 @@ static inline uint32_t candidates_per_list(const smt_ctx *ctx, uint32_t k_out)
 template <int NQ, int U>
 static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt)
 {
-    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16;  // per-wave key slots + chunk counter
+    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16 + 64;  // per-wave key slots + chunk counter + the STEAL ring
     dim3 g(blocks), b(threads);
+    if constexpr (U == 4) {
+        if (p.steal_ctr) {   // groups of rounds dealt while the kernel runs (512-thread blocks, checked by the caller)
+            if (nt) hipLaunchKernelGGL((scan_topk_kernel<NQ, U, true, false, true>), g, b, smem, ctx->stream, p);
+            else hipLaunchKernelGGL((scan_topk_kernel<NQ, U, false, false, true>), g, b, smem, ctx->stream, p);
+            SMT_HIP_CHECK(hipGetLastError());
+            return SMT_OK;
+        }
+    }
     if (nt) hipLaunchKernelGGL((scan_topk_kernel<NQ, U, true, false>), g, b, smem, ctx->stream, p);
     else hipLaunchKernelGGL((scan_topk_kernel<NQ, U, false, false>), g, b, smem, ctx->stream, p);
     SMT_HIP_CHECK(hipGetLastError());
@@ -1099,7 +1190,7 @@ static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, in
 template <int NQ>
 static int launch_scan_filtered(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt)
 {
-    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16;
+    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16 + 64;
     dim3 g(blocks), b(threads);
     if (nt) hipLaunchKernelGGL((scan_topk_kernel<NQ, FILTER_CHUNK, true, true>), g, b, smem, ctx->stream, p);
     else hipLaunchKernelGGL((scan_topk_kernel<NQ, FILTER_CHUNK, false, true>), g, b, smem, ctx->stream, p);
@@ -1221,6 +1312,26 @@ int launch_scan_topk(smt_ctx *ctx, const ScanArgs &a)
         p.stamps = reinterpret_cast<unsigned long long *>(ctx->tune.scan_debug_ptr);
         p.flags = async ? ctx->d_flags : nullptr;
         p.step = step;
+        p.steal_ctr = nullptr;
+        p.steal_lr = 0;
+        // Dynamic groups (scan_topk_kernel STEAL; tuning key scan_steal = rounds per group, 0 = the static deal): unfiltered scans of
+        // 8-wave blocks over enough rows that every block gets well past its static groups.  Each launch has its own counter: a ring
+        // of 64, zeroed together every 64th launch (one 256-byte memset in stream order).
+        if (!filtered && U == 4 && threads == 512 && ctx->tune.scan_steal > 0 &&
+            n_chunks >= (uint64_t)blocks * 8u * (uint64_t)ctx->tune.scan_steal * 8u) {
+            if (!ctx->d_steal) SMT_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_steal), 64 * sizeof(unsigned int)));
+            if (ctx->steal_seq % 64 == 0) SMT_HIP_CHECK(hipMemsetAsync(ctx->d_steal, 0, 64 * sizeof(unsigned int), ctx->stream));
+            p.steal_ctr = ctx->d_steal + (ctx->steal_seq % 64);
+            ++ctx->steal_seq;
+            uint32_t lr = 0;
+            while ((2 << lr) <= ctx->tune.scan_steal) ++lr;
+            p.steal_lr = lr;
+            // the dynamic share: scan_steal_pct per cent of the groups (at least STEAL_DEPTH + 1 per block stay static)
+            const uint64_t n_groups = (n_chunks + (8ull << lr) - 1) / (8ull << lr);
+            const uint64_t per_block = n_groups / (uint64_t)blocks;
+            const uint64_t n_static = per_block * (uint64_t)(100 - ctx->tune.scan_steal_pct) / 100;
+            p.steal_static = (uint32_t)std::max<uint64_t>(n_static, 3);
+        }
         const uint32_t left = a.nq - q0;
         p.nq_active = left >= 4 ? 4u : left;
         // (three queries ride in the four-query kernel: with the four rows of a chunk reduced together a pass costs 1.06 x / 1.4 x one

@@ -463,3 +463,35 @@ def test_async_select_pipeline_equals_stream_order(gpu_ctx):
     gr, gd = series(big, 10, 50)
     assert np.array_equal(gr, want[("big", 10)][0][:50])
     big.close(); small.close(); ctx.close()
+
+
+@pytest.mark.parametrize("steal,pct", [(1, 3), (2, 6), (4, 6), (4, 50), (8, 10), (16, 25)])
+def test_rows_dealt_while_the_kernel_runs_change_no_answer(gpu_ctx, steal, pct):
+    """K2's dynamic deal (tuning keys scan_steal / scan_steal_pct; off by default): which block reduces a row cannot change the answer
+    -- the union of the blocks' k' best holds the k' best rows whatever the deal.  1, 2, 3 and 4 queries over enough rows that the
+    dynamic groups are in play, against the static deal (bytes) and the oracle."""
+    import semtools_amd as smt
+
+    n = 600_000
+    emb = synth.unit_rows(n, seed=17, dup_frac=0.001, zero_frac=0.0005)
+    qs = synth.unit_query(23, nq=4)
+    qs[2] = emb[n - 7]                                            # an exact hit in the very last (dynamic) group
+    c = smt.Corpus(gpu_ctx)
+    c.append(emb)
+    gpu_ctx.set_tuning("gemm_min_nq", 8)                         # (keep 3 and 4 queries on the scan kernel)
+    try:
+        want = {nq: c.search(qs[:nq], top_k=10) for nq in (1, 2, 3, 4)}
+        gpu_ctx.set_tuning("scan_steal", steal)
+        gpu_ctx.set_tuning("scan_steal_pct", pct)
+        for rep in range(3):
+            for nq in (1, 2, 3, 4):
+                got = c.search(qs[:nq], top_k=10)
+                for i in range(nq):
+                    assert got[i][0].tolist() == want[nq][i][0].tolist() and np.array_equal(got[i][1], want[nq][i][1]), (rep, nq, i)
+    finally:
+        gpu_ctx.set_tuning("scan_steal", 0)
+        gpu_ctx.set_tuning("scan_steal_pct", 6)
+        gpu_ctx.set_tuning("gemm_min_nq", 5)
+    res = orc.search_documents(emb, [n], qs[2], n_lines=0, top_k=10, accurate=True)
+    assert want[3][2][0].tolist() == [r["match_line"] for r in res]
+    c.close()

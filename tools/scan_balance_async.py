@@ -20,6 +20,8 @@ q = torch.randn(16, 256, device=dev, generator=g)
 torch.cuda.set_stream(torch.cuda.Stream(dev))
 ctx = smt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 corpus = smt.Corpus(ctx, device_ptr=x.data_ptr(), rows=rows)
+for kv in sys.argv[1:]:   # tuning keys to set first, e.g. scan_steal=0
+    ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 blocks, waves = 256, 8
 stamps = torch.zeros(2 * blocks * waves + blocks, dtype=torch.int64, device=dev)
 out = torch.empty((64, 2, 10), dtype=torch.int64).pin_memory()
