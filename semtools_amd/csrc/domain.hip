@@ -96,7 +96,7 @@ int require_rows_domain(smt_ctx *ctx, const float *d_rows, uint64_t n_rows, cons
 // The approximate index (ivfpq_*.hip) is built for what model2vec emits: UNIT rows (and zero rows, which every list scores alike).
 // Its coarse quantiser, its residual codes and the ADC score q.c + sum LUT all work on the rows as they are, not on their
 // directions, so rows of other lengths would be ranked by length as much as by angle (tests/test_gpu_domain.py: a power-of-two
-// scaled corpus finds 23 of 200 true neighbours).  smt_ivfpq_build / _append / _load therefore check | |x|^2 - 1 | <= 1e-3 (or
+// scaled corpus finds 23 of 200 true neighbours).  smt_ivfpq_build / _append therefore check | |x|^2 - 1 | <= 1e-3 (or
 // x = 0) for every row the index is to cover and refuse the rest with SMT_E_UNSUPPORTED; the exact searches have no such condition.
 __global__ void __launch_bounds__(256) rows_unit_kernel(const float *rows, uint64_t n_rows, unsigned long long *out /* [count, first] */)
 {
