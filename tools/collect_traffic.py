@@ -12,8 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEGS = {
     # leg: (kernel fragment, statistic, rows key)
-    "c2": ("scan_topk_kernel<1, 4, true, false>", "min"),   # (the same kernel also runs c4's 100 M-row launches: min = the 1 M-row shard)
-    "c4": ("scan_topk_kernel<1, 4, true, false>", "max"),
+    "c2": ("scan_topk_kernel<1, 4, true, false,", "min"),   # (the same kernel also runs c4's 100 M-row launches: min = the 1 M-row shard)
+    "c4": ("scan_topk_kernel<1, 4, true, false,", "max"),
     "c3": ("gemm_rowreg_kernel<", "max"),   # main level of the batch (15/16 of the corpus)
     "embed_zipf_ids_500k_table": ("embed_kernel", "min"),
     "embed_uniform_ids_4M_table": ("embed_kernel", "max"),
