@@ -598,6 +598,9 @@ static int search_local_host_impl(smt_corpus *corpus, const float *queries, uint
             const auto t0 = std::chrono::steady_clock::now();
             unsigned long long got = 0;
             for (unsigned spins = 1; (got = *flag) == 0; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();   // (a polite spin: the sibling hyperthread keeps its issue slots)
+#endif
                 if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
                     SMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     got = *flag;
