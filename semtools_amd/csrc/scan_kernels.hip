@@ -447,20 +447,38 @@ __global__ void __launch_bounds__(1024) scan_topk_kernel(ScanParams p)
     // time a block gets here the flag is long up, the wait normally reads it once)
     if (p.flags && threadIdx.x == 0 && p.step >= 2) flag_wait(p.flags, 1, p.step - 1);
 
-    // block merge: rank every wave's candidates among all of the block's.
+    // block merge: rank every wave's candidates among all of the block's.  ONE barrier for all the queries of the pass, and no global
+    // store in front of it: every query has its own LDS region (the loop's chunk counter and ring are dead by now), and every slot of
+    // a block list is written exactly once -- its key, or the padding from the first slot no key ranks into.  (Until round 6 each
+    // query took two barriers with the padding stored between them; a __syncthreads() waits for the wave's outstanding global
+    // stores, so every query -- the one-query headline launch included -- paid a store round trip or two in its tail: a one-row
+    // search cost 4.4 / 9.4 / 15 / 18.5 us of scan kernel with 1 / 2 / 3 / 4 queries.)
+    __syncthreads();
+    unsigned int *s_valid = reinterpret_cast<unsigned int *>(s_keys + (size_t)NQ * waves_per_block * 64);   // [NQ][waves] valid keys per wave list
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const bool have = lane < kp && lr[n] != 0xFFFFFFFFu;
+        s_keys[((size_t)n * waves_per_block + wave) * 64 + lane] = have ? make_key(ld[n], lr[n]) : KEY_PAD;
+        const unsigned int cnt = (unsigned int)__popcll(__ballot(have));
+        if (lane == 0) s_valid[n * waves_per_block + wave] = cnt;
+    }
+    __syncthreads();
+#pragma unroll
     for (int n = 0; n < NQ; ++n) {
         if ((uint32_t)n >= p.nq_active) break;   // (uniform over the block)
-        __syncthreads();
-        s_keys[wave * 64 + lane] = (lane < kp && lr[n] != 0xFFFFFFFFu) ? make_key(ld[n], lr[n]) : KEY_PAD;
+        const key_t64 *keys_n = s_keys + (size_t)n * waves_per_block * 64;
         key_t64 *out = p.block_lists + ((size_t)n * gridDim.x + blockIdx.x) * kp;
-        if ((int)threadIdx.x < kp) out[threadIdx.x] = KEY_PAD;
-        __syncthreads();
-        const key_t64 mine = s_keys[wave * 64 + lane];
+        const key_t64 mine = keys_n[wave * 64 + lane];
         if (mine != KEY_PAD) {
             int rank = 0;
             for (int w = 0; w < waves_per_block; ++w)
-                for (int i = 0; i < kp; ++i) rank += (s_keys[w * 64 + i] < mine) ? 1 : 0;
+                for (int i = 0; i < kp; ++i) rank += (keys_n[w * 64 + i] < mine) ? 1 : 0;
             if (rank < kp) out[rank] = mine;
+        }
+        if (wave == 0 && lane < kp) {   // the padding: slots [valid keys of the block, kp)
+            unsigned int total = 0;
+            for (int w = 0; w < waves_per_block; ++w) total += s_valid[n * waves_per_block + w];
+            if ((unsigned int)lane >= total) out[lane] = KEY_PAD;
         }
     }
     if (p.flags) {
@@ -1171,7 +1189,7 @@ static inline uint32_t candidates_per_list(const smt_ctx *ctx, uint32_t k_out)
 template <int NQ, int U>
 static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt)
 {
-    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16 + 64;  // per-wave key slots + chunk counter + the STEAL ring
+    const size_t smem = (size_t)NQ * (threads / 64) * 64 * sizeof(key_t64) + 16 + 64 + 256;  // per-query, per-wave key slots (the chunk counter and the STEAL ring live in the second query's until the merge) + the waves' key counts
     dim3 g(blocks), b(threads);
     if constexpr (U == 4) {
         if (p.steal_ctr) {   // groups of rounds dealt while the kernel runs (512-thread blocks, checked by the caller)
@@ -1190,7 +1208,7 @@ static int launch_scan_variant(smt_ctx *ctx, const ScanParams &p, int blocks, in
 template <int NQ>
 static int launch_scan_filtered(smt_ctx *ctx, const ScanParams &p, int blocks, int threads, bool nt)
 {
-    const size_t smem = (size_t)(threads / 64) * 64 * sizeof(key_t64) + 16 + 64;
+    const size_t smem = (size_t)NQ * (threads / 64) * 64 * sizeof(key_t64) + 16 + 64 + 256;
     dim3 g(blocks), b(threads);
     if (nt) hipLaunchKernelGGL((scan_topk_kernel<NQ, FILTER_CHUNK, true, true>), g, b, smem, ctx->stream, p);
     else hipLaunchKernelGGL((scan_topk_kernel<NQ, FILTER_CHUNK, false, true>), g, b, smem, ctx->stream, p);

@@ -8,7 +8,7 @@ cp $LIB /tmp/lib_orig.so
 for round in 1 2 3; do
   for v in A B; do
     cp semtools_amd/lib/ab/lib$v.so $LIB
-    timeout 300 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary --no-embed --no-ivfpq --no-c4 --no-group-issue --no-workspace --no-ingest \
+    timeout 300 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary --no-embed --no-ivfpq --no-c4 --no-group-issue --no-workspace --no-ingest --no-small-calls \
         --detail-out gpurun_out/ab_$v$round.json 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

@@ -24,7 +24,7 @@ def timed(c, nq, k, reps=300):
 out = []
 for n in (1, 1000, 65536):
     c = smt.Corpus(ctx); c.append(emb[:n])
-    for nq in (1, 3):
+    for nq in (1, 2, 3, 4):
         row = {"rows": n, "nq": nq}
         for direct in (1, 0):
             ctx.set_tuning("direct_delivery", direct)
