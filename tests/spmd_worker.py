@@ -274,6 +274,20 @@ def main():
         rows_before = scx.rank_rows().tolist()
         attempt("append", 2, L.SMT_E_INVALID, lambda: scx.append(synth.unit_rows(300, seed=5)))
         res["append_rolled_back"] = scx.rank_rows().tolist() == rows_before and scx.rows == 4000
+        # ... and a failure nobody injected: ONE row of a dealt append is outside the library's domain (a NaN component): it lands in
+        # one rank's share, that rank refuses it (domain.hip), and the append must fail on EVERY rank and roll back everywhere
+        bad = synth.unit_rows(400, seed=6)
+        bad[399, 17] = np.nan                                   # the last row: the last rank's share
+        t0 = time.time()
+        try:
+            scx.append(bad)
+            res[("domain", "code")] = 0
+        except smt.SmtError as e:
+            res[("domain", "code")] = e.code
+            res[("domain", "msg")] = str(e)
+        res[("domain", "seconds")] = time.time() - t0
+        res["domain_rolled_back"] = scx.rank_rows().tolist() == rows_before and scx.rows == 4000
+        res[("domain", "after")] = _lists(sc.search(qs, top_k=5))
         scx.close()
         out["failures"] = res
 

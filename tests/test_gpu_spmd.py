@@ -224,6 +224,11 @@ def test_a_rank_that_fails_locally_takes_every_rank_with_it(plain, tmp_path, wor
         assert f[("stage", "code")] == L.SMT_E_NOMEM and f[("threshold", "code")] == L.SMT_E_IO, f
         assert f[("build", "code")] == L.SMT_E_NOMEM and f[("append", "code")] == L.SMT_E_INVALID, f
         assert f["append_rolled_back"], "a failed dealt append must leave every shard as it was"
+        # a row outside the library's domain in ONE rank's share of a dealt append: refused there, failed and rolled back everywhere
+        assert f[("domain", "code")] == L.SMT_E_INVALID and f["domain_rolled_back"], f
+        assert f[("domain", "seconds")] < 20 and f[("domain", "after")] == want
+        if o["rank"] == world - 1:
+            assert "outside the library's domain" in f[("domain", "msg")], f[("domain", "msg")]
         for label in ("stage", "threshold", "build", "append"):
             assert f[(label, "seconds")] < 20, "a rank waited for the double's timeout: it was left inside a collective"
             assert f[(label, "after")] == want, (o["rank"], label)
