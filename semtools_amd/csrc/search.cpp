@@ -414,9 +414,33 @@ static int search_local_host_impl(smt_corpus *corpus, const float *queries, uint
 int search_local_host(smt_corpus *corpus, const float *queries, uint32_t nq, uint32_t top_k, double max_distance, int mode,
                       const smt_range *ranges, uint32_t n_ranges, uint64_t row_base, std::vector<LocalHits> &out)
 {
-    int rc = search_local_host_impl(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, out);
-    if (rc || mode != SMT_MODE_WORKSPACE) return rc;
-    for (uint32_t q = 0; q < nq && q < out.size(); ++q)
+    if (mode != SMT_MODE_WORKSPACE || !queries || nq == 0)
+        return search_local_host_impl(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, out);
+    // workspace mode: zero queries never reach the GPU (every row ties at distance 1.0: the kernels would flag the answer uncertain
+    // and the exhaustive re-answer would collect the whole subset to order a constant)
+    std::vector<uint32_t> live;
+    for (uint32_t q = 0; q < nq; ++q)
+        if (!query_is_zero(queries + (size_t)q * SMT_DIM)) live.push_back(q);
+    if (live.size() == nq) return search_local_host_impl(corpus, queries, nq, top_k, max_distance, mode, ranges, n_ranges, row_base, out);
+    SMT_REQUIRE(corpus != nullptr, "corpus");
+    std::vector<float> packed(live.size() * (size_t)SMT_DIM);
+    for (size_t j = 0; j < live.size(); ++j) memcpy(&packed[j * SMT_DIM], queries + (size_t)live[j] * SMT_DIM, SMT_DIM * sizeof(float));
+    std::vector<LocalHits> part;
+    // (an all-zero batch still goes through the argument checks of the search proper: ranges, mode, the corpus' device)
+    int rc = search_local_host_impl(corpus, packed.empty() ? queries : packed.data(), packed.empty() ? 0u : (uint32_t)live.size(), top_k,
+                                    max_distance, mode, ranges, n_ranges, row_base, part);
+    if (rc) return rc;
+    if (n_ranges) {   // (validated by the search proper only when it had a query to answer)
+        uint64_t prev_end = 0;
+        for (uint32_t i = 0; i < n_ranges; ++i) {
+            SMT_REQUIRE(ranges[i].begin <= ranges[i].end && ranges[i].end <= corpus->rows && (i == 0 || ranges[i].begin >= prev_end),
+                        "ranges must be sorted, disjoint and inside the corpus");
+            prev_end = ranges[i].end;
+        }
+    }
+    out.assign(nq, LocalHits());
+    for (size_t j = 0; j < live.size(); ++j) out[live[j]] = std::move(part[j]);
+    for (uint32_t q = 0; q < nq; ++q)
         if (query_is_zero(queries + (size_t)q * SMT_DIM))
             workspace_zero_query_hits(ranges, n_ranges, corpus->rows, top_k, !std::isnan(max_distance), max_distance, row_base, out[q]);
     return SMT_OK;
