@@ -41,4 +41,5 @@ def test_select_kernel_fits_beside_a_scan_block_and_nothing_spills():
     for k, v in scans.items():
         assert v["VGPRs Spill"] == 0 and v["VGPRs"] <= 128, (k, v)      # 8 waves per CU: two per SIMD with room for the select
     one_query = [v for k, v in scans.items() if "ILi1ELi4ELb1ELb0" in k]
-    assert one_query and one_query[0]["VGPRs"] <= 64, one_query         # the headline instantiation: beside 4 x 96 of the select
+    assert len(one_query) == 2 and all(v["VGPRs"] <= 64 for v in one_query), one_query   # the headline instantiation (static deal and the
+                                                                                          # scan_steal A/B form): beside 4 x 96 of the select
