@@ -1,5 +1,8 @@
 // ivfpq_search.hip -- querying the IVF index: probe (query x centroid scores on the MFMA pipe, nprobe smallest per query), LUT or
 // per-list projection, the ADC scan with its in-kernel re-score of the shortlist, and the search entry points.  ivfpq.h, DESIGN.md 4.6.
+#include <atomic>
+#include <chrono>
+
 #include "ivfpq.h"
 
 namespace smt {
@@ -458,7 +461,7 @@ extern "C" {
 
 static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_on_device, uint32_t nq, uint32_t top_k, uint32_t nprobe,
                              uint32_t rerank, uint64_t row_base, uint64_t *d_or_user, double *d_od_user, uint64_t *d_oc_user,
-                             uint64_t **d_or_out, size_t *out_bytes_contig, uint64_t out_stride = 0)
+                             uint64_t **d_or_out, size_t *out_bytes_contig, uint64_t out_stride = 0, smt::Delivery *deliver = nullptr)
 {
     smt_ctx *ctx = ix->corpus->ctx;
     SMT_REQUIRE(ix->corpus->rows >= ix->n_rows, "the corpus shrank after the index was built: rebuild");
@@ -587,6 +590,11 @@ static int ivfpq_search_core(smt_ivfpq *ix, const float *queries, bool queries_o
     sel.out_dist = d_od;
     sel.out_counts = d_oc;
     sel.out_stride = out_stride;
+    if (deliver) {   // (host form, small answer: the select kernel carries [rows | distances | counts] home -- common.h Delivery)
+        deliver->dev_out = reinterpret_cast<const unsigned long long *>(d_or);
+        deliver->n_words = (uint32_t)((b_or + b_od + (size_t)nq * 8) / 8);
+        sel.deliver = deliver;
+    }
     rc = launch_select(ctx, sel);
     if (rc) return rc;
     if (d_or_out) *d_or_out = d_or;
@@ -608,15 +616,49 @@ try {
     if (top_k == 0) return SMT_OK;
     uint64_t *d_or = nullptr;
     size_t out_bytes = 0;
-    int rc = ivfpq_search_core(ix, queries, false, nq, top_k, nprobe, rerank, row_base, nullptr, nullptr, nullptr, &d_or, &out_bytes);
-    if (rc) return rc;
     const size_t b_or = (size_t)nq * top_k * 8, b_od = b_or;
-    if ((rc = smt::ensure_pinned(ctx, out_bytes))) return rc;
-    IVF_HIP(hipMemcpyAsync(ctx->h_pinned, d_or, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    IVF_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(ctx->h_pinned);
-    const double *h_dist = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ctx->h_pinned) + b_or);
-    const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(ctx->h_pinned) + b_or + b_od);
+    // a small answer is delivered by the select kernel (as in smt_search: search.cpp), a large one copied and waited for
+    const bool direct = ctx->tune.direct_delivery != 0 && nq <= 32 && b_or + b_od + (size_t)nq * 8 <= 8192;
+    int rc = smt::ensure_pinned(ctx, 64 + b_or + b_od + (size_t)nq * 8);
+    if (rc) return rc;
+    char *h_ans = reinterpret_cast<char *>(ctx->h_pinned) + 64;
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(ctx->h_pinned);
+    smt::Delivery dl;
+    if (direct) {
+        dl.host_out = reinterpret_cast<unsigned long long *>(h_ans);
+        dl.host_flag = const_cast<unsigned long long *>(flag);
+        dl.seq = ++ctx->deliver_seq;
+        dl.done = ctx->d_status + 4;
+        *flag = 0;
+    }
+    rc = ivfpq_search_core(ix, queries, false, nq, top_k, nprobe, rerank, row_base, nullptr, nullptr, nullptr, &d_or, &out_bytes, 0,
+                           direct ? &dl : nullptr);
+    if (rc) return rc;
+    if (direct) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned long long got = 0;
+        for (unsigned spins = 1; (got = *flag) == 0; ++spins) {
+            if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                IVF_HIP(hipStreamSynchronize(ctx->stream));
+                got = *flag;
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (got != dl.seq) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemsetAsync(ctx->d_status + 4, 0, sizeof(unsigned long long), ctx->stream);
+            smt::set_error("the select kernel did not deliver its answer (completion word %llu, expected %llu)", got, dl.seq);
+            return SMT_E_HIP;
+        }
+        ++ctx->deliveries;
+    } else {
+        IVF_HIP(hipMemcpyAsync(h_ans, d_or, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        IVF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const uint64_t *h_rows = reinterpret_cast<const uint64_t *>(h_ans);
+    const double *h_dist = reinterpret_cast<const double *>(h_ans + b_or);
+    const uint64_t *h_cnt = reinterpret_cast<const uint64_t *>(h_ans + b_or + b_od);
     bool truncated = false;
     for (uint32_t q = 0; q < nq; ++q) {
         out_counts[q] = h_cnt[q];

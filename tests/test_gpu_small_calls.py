@@ -195,3 +195,30 @@ def test_a_thousand_small_calls_in_a_row_with_other_calls_in_between(counting):
             orows, odist = _oracle_topk(b_rows, qs[(i + 1) % 40], 2)
             assert rows.tolist() == orows and np.array_equal(dist, odist)
     a.close(); b.close()
+
+
+def test_the_index_search_delivers_small_answers_too(counting):
+    """smt_ivfpq_search (host form) takes the same way home: the select stage of the index search writes a small answer into pinned
+    memory and the host waits on its completion word; same bytes as the copy + synchronise path, large answers keep the copy."""
+    import semtools_amd as smt
+    from tests.test_gpu_ivfpq import clustered
+
+    ctx = counting
+    x, _ = clustered(30000, 128, seed=4)
+    q, _ = clustered(64, 128, seed=5)
+    c = smt.Corpus(ctx)
+    c.append(x)
+    ix = smt.IvfPq(c, nlist=64, train_iters=5, local_pca=True)
+    for nq, k in ((1, 10), (4, 3), (32, 10), (64, 10), (20, 56)):
+        before = _fused_launches(ctx)
+        got = ix.search(q[:nq], top_k=k, nprobe=8, rerank=128)
+        delivered = _fused_launches(ctx) - before
+        assert delivered == (1 if nq <= 32 and nq * k * 16 + nq * 8 <= 8192 else 0), (nq, k, delivered)
+        ctx.set_tuning("direct_delivery", 0)
+        ref = ix.search(q[:nq], top_k=k, nprobe=8, rerank=128)
+        ctx.set_tuning("direct_delivery", 1)
+        for (r1, d1), (r2, d2) in zip(got, ref):
+            assert r1.tolist() == r2.tolist() and np.array_equal(d1, d2)
+        for i in range(min(nq, 4)):   # every returned pair is exact
+            assert np.array_equal(got[i][1], np.array([orc.cosine(q[i], x[int(r)], accurate=True) for r in got[i][0]]))
+    ix.close(); c.close()
